@@ -1,0 +1,257 @@
+#!/usr/bin/env python3
+"""Generate the committed golden vectors by running the UNMODIFIED reference modules on CPU.
+
+Run in the build container only (needs /root/reference; the GPU box never sees it):
+
+    python tests/golden/make_golden.py            # writes tests/golden/*.npz
+
+What is imported from the reference: `vit_model`, `Losses`, `nets.ShfitScaleFormer`
+(nets/ShfitScaleFormer.py:9 imports two symbols from `timm`, which is not installed; as
+SURVEY.md section 8c records, an in-process module object provides
+`trunc_normal_ = torch.nn.init.trunc_normal_` and `DropPath = vit_model.DropPath` -- both only
+touch initialisation / a never-instantiated identity, and every weight used in a fixture is
+overwritten by tests/golden/recipe.py anyway).
+
+Fixtures hold data only: seeds/recipes for inputs and weights, and the reference's outputs,
+losses, gradients and post-Adam weights (as compact summaries, see recipe.summarize).
+No reference source text is stored.
+"""
+import os
+import sys
+import types
+import warnings
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import recipe  # noqa: E402
+
+REF = os.environ.get("DEEPMERGE_REFERENCE", "/root/reference")
+
+
+def import_reference():
+    sys.path.insert(0, REF)
+    import vit_model  # noqa
+    layers = types.ModuleType("timm.models.layers")
+    layers.trunc_normal_ = torch.nn.init.trunc_normal_
+    layers.DropPath = vit_model.DropPath
+    for name, mod in (("timm", types.ModuleType("timm")), ("timm.models", types.ModuleType("timm.models")),
+                      ("timm.models.layers", layers)):
+        sys.modules[name] = mod
+    from nets import ShfitScaleFormer as S2F  # noqa
+    import Losses  # noqa
+    return S2F, vit_model, Losses
+
+
+def load_det_weights(module: torch.nn.Module, prefix: str = ""):
+    """Overwrite every float tensor of module.state_dict() with the name-keyed recipe."""
+    sd = module.state_dict()
+    new = {}
+    for k, v in sd.items():
+        if v.dtype.is_floating_point:
+            new[k] = torch.from_numpy(recipe.det_weight(prefix + k, v.shape))
+        else:
+            new[k] = v
+    module.load_state_dict(new, strict=True)
+
+
+def t(name, shape, kind="normal"):
+    return torch.from_numpy(recipe.det_input(name, shape, kind))
+
+
+def add(fx, name, tensor, k=2048):
+    fx.update(recipe.summarize(name, tensor.detach().cpu().numpy(), k))
+
+
+# ------------------------------------------------------------------------------------------
+def gen_relpos(S2F):
+    fx = {}
+    for cube in ([2, 2, 2], [3, 8, 8], [3, 4, 4], [3, 2, 2], [4, 8, 8], [4, 4, 4], [4, 2, 2], [1, 3, 5]):
+        attn = S2F.CrossScaleAttention(dim=768, num_heads=12, cube_size=list(cube), qkv_bias=True)
+        idx = attn.relative_position_index.numpy()
+        assert idx.dtype == np.int64
+        key = "x".join(map(str, cube))
+        fx["index/" + key] = idx.astype(np.int32)
+        fx["table_rows/" + key] = np.int64(attn.relative_position_bias_table.shape[0])
+    np.savez_compressed(os.path.join(HERE, "relpos_index.npz"), **fx)
+    print("relpos_index.npz", len(fx))
+
+
+def gen_ops(S2F, Losses):
+    fx = {}
+    # ---- PatchEmbed -----------------------------------------------------------------
+    for tag, img, patch, in_c in (("pe32", 32, 4, 3), ("pe64", 64, 8, 3), ("pe128", 128, 16, 3), ("pe256c4", 256, 32, 4)):
+        m = S2F.PatchEmbed(img_size=img, patch_size=patch, in_c=in_c, out_c=768)
+        load_det_weights(m, tag + ".")
+        x = t(tag + ".x", (2, in_c, img, img), "unit").requires_grad_(True)
+        y = m(x)
+        go = t(tag + ".go", y.shape)
+        (y * go).sum().backward()
+        add(fx, tag + "/y", y)
+        add(fx, tag + "/dx", x.grad)
+        add(fx, tag + "/dw", m.proj.weight.grad)
+        add(fx, tag + "/db", m.proj.bias.grad)
+    # ---- Mlp ------------------------------------------------------------------------
+    m = S2F.Mlp(in_features=768, hidden_features=3072)
+    load_det_weights(m, "mlp.")
+    x = t("mlp.x", (2, 12, 768)).requires_grad_(True)
+    y = m(x)
+    (y * t("mlp.go", y.shape)).sum().backward()
+    add(fx, "mlp/y", y); add(fx, "mlp/dx", x.grad)
+    for n, p in m.named_parameters():
+        add(fx, "mlp/d_" + n, p.grad)
+    # config-1 style 2-linear block on 128-d pair features
+    m = S2F.Mlp(in_features=128, hidden_features=128, out_features=128)
+    load_det_weights(m, "mlp128.")
+    x = t("mlp128.x", (64, 128)).requires_grad_(True)
+    y = m(x)
+    (y * t("mlp128.go", y.shape)).sum().backward()
+    add(fx, "mlp128/y", y); add(fx, "mlp128/dx", x.grad)
+    for n, p in m.named_parameters():
+        add(fx, "mlp128/d_" + n, p.grad)
+    # ---- FeatureEmbed ---------------------------------------------------------------
+    m = S2F.FeatureEmbed(feature_size=19, embed_dim=768)
+    load_det_weights(m, "fe.")
+    x = t("fe.x", (3, 1, 19), "designed").requires_grad_(True)
+    y = m(x)
+    (y * t("fe.go", y.shape)).sum().backward()
+    add(fx, "fe/y", y); add(fx, "fe/dx", x.grad)
+    for n, p in m.named_parameters():
+        add(fx, "fe/d_" + n, p.grad)
+    # ---- CrossScaleAttention / CrossScaleBlock ----------------------------------------
+    for cube in ([3, 2, 2], [3, 4, 4], [3, 8, 8], [4, 8, 8], [4, 4, 4], [4, 2, 2]):
+        tag = "attn" + "x".join(map(str, cube))
+        n = cube[0] * cube[1] * cube[2]
+        m = S2F.CrossScaleAttention(dim=768, num_heads=12, cube_size=list(cube), qkv_bias=True)
+        load_det_weights(m, tag + ".")
+        x = t(tag + ".x", (2, n, 768)).requires_grad_(True)
+        y = m(x)
+        (y * t(tag + ".go", y.shape)).sum().backward()
+        add(fx, tag + "/y", y); add(fx, tag + "/dx", x.grad)
+        for pn, p in m.named_parameters():
+            add(fx, tag + "/d_" + pn, p.grad)
+    for cube in ([3, 4, 4], [4, 8, 8]):
+        tag = "block" + "x".join(map(str, cube))
+        n = cube[0] * cube[1] * cube[2]
+        m = S2F.CrossScaleBlock(dim=768, num_heads=12, cube_size=list(cube))
+        load_det_weights(m, tag + ".")
+        x = t(tag + ".x", (2, n, 768)).requires_grad_(True)
+        y = m(x)
+        (y * t(tag + ".go", y.shape)).sum().backward()
+        add(fx, tag + "/y", y); add(fx, tag + "/dx", x.grad)
+        for pn, p in m.named_parameters():
+            add(fx, tag + "/d_" + pn, p.grad)
+    # ---- Loss -----------------------------------------------------------------------
+    crit = Losses.Loss(margin=1.0, lamda=0.1, belta=0)
+    a = t("loss.a", (16, 100)) * 0.2
+    b = a + t("loss.b", (16, 100)) * np.linspace(0.01, 0.25, 16, dtype=np.float32)[:, None]  # d from << 1 to >> 1
+    flag_i = torch.tensor([1, 0] * 8, dtype=torch.int64)
+    for tag, flag in (("loss_i64", flag_i), ("loss_f32", flag_i.to(torch.float32))):
+        aa = a.clone().requires_grad_(True); bb = b.clone().requires_grad_(True)
+        val = crit(aa, bb, flag)
+        val.backward()
+        fx[tag + "/value"] = np.float64(val.item())
+        add(fx, tag + "/da", aa.grad); add(fx, tag + "/db", bb.grad)
+    d = (a - b).pow(2).sum(1)
+    fx["loss/n_below_margin"] = np.int64((d < 1.0).sum().item())
+    fx["loss/n_above_margin"] = np.int64((d > 1.0).sum().item())
+    fx["loss/a"] = a.numpy(); fx["loss/b"] = b.numpy(); fx["loss/flag"] = flag_i.numpy()
+    # MultiLoss / ClassLoss
+    ll = t("loss.ll", (16, 11)); rl = t("loss.rl", (16, 11))
+    lt = torch.arange(16) % 11; rt = (torch.arange(16) * 3) % 11
+    fx["multiloss/value"] = np.float64(Losses.MultiLoss(1.0, 0.1, 0)(a, b, flag_i, ll, lt, rl, rt).item())
+    fx["classloss/value"] = np.float64(Losses.ClassLoss(1.0, 0.1, 0)(ll, lt, rl, rt).item())
+    np.savez_compressed(os.path.join(HERE, "ops_s2former.npz"), **fx)
+    print("ops_s2former.npz", len(fx))
+
+
+def model_inputs(tag, scales, in_c, B=4):
+    """Pair batch of 4: (unrelated, flag 1), (near-identical, flag 0: hinge branch d < margin
+    live, SURVEY 8a L1 note), (near-identical, flag 1), (unrelated, flag 0: hinge dead)."""
+    assert B == 4
+    left = [t(f"{tag}.left{i}", (B, in_c, s, s), "unit") for i, s in enumerate(scales)]
+    right = [t(f"{tag}.right{i}", (B, in_c, s, s), "unit") for i, s in enumerate(scales)]
+    ld = t(tag + ".ld", (B, 1, 19), "designed")
+    rd = t(tag + ".rd", (B, 1, 19), "designed")
+    eps = 0.2
+    for i in range(len(scales)):
+        for b in (1, 2):
+            right[i][b] = left[i][b] * (1 - eps) + eps * right[i][b]
+    for b in (1, 2):
+        rd[b] = ld[b] * (1 + eps)
+    flag = torch.tensor([1, 0, 1, 0], dtype=torch.int64)
+    return left, ld, right, rd, flag
+
+
+def gen_model(S2F, Losses):
+    fx = {}
+    for tag, scales, in_c, depth in (("v3_3s3c_642", [32, 64, 128], 3, [6, 4, 2]),
+                                     ("v3_4s4c_321", [32, 64, 128, 256], 4, [3, 2, 1]),
+                                     ("v3_3s3c_111", [32, 64, 128], 3, [1, 1, 1])):
+        PE = S2F.PatchEmbed if in_c == 3 else (
+            lambda img_size, patch_size, in_c, out_c, _c=in_c: S2F.PatchEmbed(img_size=img_size, patch_size=patch_size, in_c=_c, out_c=out_c))
+        net = S2F.ShfitScaleFormer_v3(is_designed_feature_embedding=True, PatchEmbed=PE, cube_size=[8, 8],
+                                      input_image_scales=list(scales), embed_dim=768, depth=list(depth))
+        load_det_weights(net, "")
+        sd = net.state_dict()
+        fx[tag + "/manifest_keys"] = np.array(list(sd.keys()))
+        fx[tag + "/manifest_shapes"] = np.array([",".join(map(str, v.shape)) for v in sd.values()])
+        fx[tag + "/manifest_dtypes"] = np.array([str(v.dtype).replace("torch.", "") for v in sd.values()])
+        fx[tag + "/name"] = np.array(net.name)
+        fx[tag + "/n_params"] = np.int64(sum(p.numel() for p in net.parameters()))
+        left, ld, right, rd, flag = model_inputs(tag, scales, in_c, 4)
+        crit = Losses.Loss(margin=1.0, lamda=0.1, belta=0)
+        net.train()
+        opt = torch.optim.Adam(filter(lambda p: p.requires_grad, net.parameters()), lr=1e-4)
+        watch = ["blocks0.0.attn.qkv.weight", "blocks2.0.mlp.fc2.bias", "norm.weight",
+                 "blocks1.0.attn.relative_position_bias_table", "patch_embed_blocks.0.proj.weight",
+                 "final_features_with_design.weight", "feature_embed.proj0.weight"]
+        named = dict(net.named_parameters())
+        for step in range(1, 4):
+            out_a, out_b = net(left, ld, right, rd)
+            loss = crit(out_a, out_b, flag)
+            opt.zero_grad()
+            loss.backward()
+            if step == 1:
+                add(fx, tag + "/out_a", out_a); add(fx, tag + "/out_b", out_b)
+                fx[tag + "/loss"] = np.float64(loss.item())
+                fx[tag + "/dist"] = (out_a - out_b).pow(2).sum(1).detach().numpy().astype(np.float64)
+                none = []
+                for n, p in named.items():
+                    if p.grad is None:
+                        none.append(n)
+                    else:
+                        add(fx, tag + "/grad/" + n, p.grad, k=1024)
+                fx[tag + "/grad_none"] = np.array(none)
+                net.eval()
+                ev = net(left, ld)
+                net.train()
+                fx[tag + "/eval_equals_train"] = np.bool_(torch.equal(ev, out_a))
+            opt.step()
+            fx[tag + f"/loss_step{step}"] = np.float64(loss.item())
+            if step in (1, 3):
+                for n in watch:
+                    add(fx, tag + f"/adam{step}/" + n, named[n], k=1024)
+        print(tag, "loss", fx[tag + "/loss"], "dist", fx[tag + "/dist"], "none", list(fx[tag + "/grad_none"]))
+    np.savez_compressed(os.path.join(HERE, "model_v3.npz"), **fx)
+    print("model_v3.npz", len(fx))
+
+
+def main():
+    warnings.filterwarnings("ignore")
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    S2F, vit_model, Losses = import_reference()
+    which = sys.argv[1:] or ["relpos", "ops", "model"]
+    if "relpos" in which:
+        gen_relpos(S2F)
+    if "ops" in which:
+        gen_ops(S2F, Losses)
+    if "model" in which:
+        gen_model(S2F, Losses)
+
+
+if __name__ == "__main__":
+    main()
