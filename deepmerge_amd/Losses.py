@@ -1,0 +1,45 @@
+"""MI355X-native drop-in for the reference module `Losses.py`.
+
+`Loss` (the one Train_SMT.py uses, Losses.py:12-38) runs forward and gradient in one HIP kernel
+(dm_contrastive_loss).  `MultiLoss` / `ClassLoss` (Losses.py:41-95; unused by the shipped trainer)
+combine it with cross-entropy terms, for which torch's own CE is used (not yet on
+the accelerated path).
+"""
+import torch.nn.functional as F
+from torch import nn
+
+from . import ops
+
+
+class Loss(nn.Module):
+    def __init__(self, margin, lamda, belta):
+        super().__init__()
+        self.margin, self.lamda, self.belta = margin, lamda, belta   # lamda / belta unused upstream too
+
+    def forward(self, positive, negative, flag, size_average=True):
+        return ops.ContrastiveLossFn.apply(positive, negative, flag, float(self.margin))
+
+
+class MultiLoss(nn.Module):
+    def __init__(self, margin, lamda, belta):
+        super().__init__()
+        self.margin, self.lamda, self.belta = margin, lamda, belta
+
+    def Loss_Class(self, inputs, targets):
+        return F.cross_entropy(inputs, targets)
+
+    def forward(self, positive, negative, flag, left_logits, left_one_hot, right_logits, right_one_hot, size_average=True):
+        c = ops.ContrastiveLossFn.apply(positive, negative, flag, float(self.margin))
+        return 0.7 * c + 0.15 * self.Loss_Class(left_logits, left_one_hot) + 0.15 * self.Loss_Class(right_logits, right_one_hot)
+
+
+class ClassLoss(nn.Module):
+    def __init__(self, margin, lamda, belta):
+        super().__init__()
+        self.margin, self.lamda, self.belta = margin, lamda, belta
+
+    def Loss_Class(self, inputs, targets):
+        return F.cross_entropy(inputs, targets)
+
+    def forward(self, left_logits, left_one_hot, right_logits, right_one_hot, size_average=True):
+        return 0.5 * self.Loss_Class(left_logits, left_one_hot) + 0.5 * self.Loss_Class(right_logits, right_one_hot)

@@ -1,0 +1,438 @@
+// MFMA GEMM family for the DeepMerge pair encoder (gfx950 / CDNA4).
+//
+// One kernel template covers the three products a Linear layer needs
+//   NT  y  = x  W^T   (forward)      A [M,K] k-contiguous,  B [N,K] k-contiguous
+//   NN  dx = dy W     (dgrad)        A [M,K] k-contiguous,  B [K,N] n-contiguous
+//   TN  dW = dy^T x   (wgrad)        A [K,M] m-contiguous,  B [K,N] n-contiguous
+// in two numerics modes: bf16 operands on v_mfma_f32_16x16x32_bf16 (throughput mode) and fp32
+// operands on v_mfma_f32_16x16x4_f32 (parity mode; exact fp32 fmaf chains).  Accumulation is
+// fp32 in both.
+//
+// Geometry: 128x128 output tile per 256-thread workgroup (4 waves as 2x2, 64x64 per wave =
+// 4x4 MFMA tiles of 16x16), K staged through LDS in stages of 128 bytes per row (64 bf16 / 32
+// fp32), double-buffered; global->register loads of stage t+1 are issued before the MFMAs of
+// stage t and written to LDS after them, one barrier per stage.
+//
+// LDS images (per operand per stage, 16 KiB + pad):
+//   k-contiguous operand  : [128 rows][8 chunks of 16 B], chunk index XOR (row & 7)
+//                           -> every ds_read_b128 fragment read is bank-conflict free;
+//   m-contiguous operand  : bf16  [64 k-rows][8 slots of 32 B], slot XOR f(k),
+//                                 f(k) = (k&3) | ((k>>3)&1)<<2, read with ds_read_b64_tr_b16
+//                                 (hardware transpose: 4 k-rows x 16 columns per 16 lanes);
+//                           fp32  [32 k-rows][128+4 floats], read with ds_read_b32.
+// Fragment convention (both dtypes): a "fragment" is 16 bytes per lane; lane group g = lane>>4
+// owns the g-th 16-byte chunk of a 64-byte k-block, i.e. k = 8g..8g+7 (bf16) or 4g..4g+3 (fp32).
+// For fp32 the four MFMA k-steps of a block take element j of every lane's chunk, which is a
+// permutation of k applied identically to A and B.
+//
+// The MFMA is issued with the operands swapped (B fragment in the A slot), so a lane ends up
+// with 4 CONSECUTIVE columns n of one row m: epilogue loads/stores are 16-byte (fp32) or 8-byte
+// (bf16) vectors.
+#include "dm_common.h"
+#include "dm_mfma.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128;
+constexpr int STAGE_BYTES = 16896;  // 16 KiB, or 32 rows x 528 B for the padded fp32 m-contiguous image
+constexpr int NTHREADS = 256;
+
+struct GemmParams {
+  const void *A, *B;
+  void *C;
+  const float *bias;
+  const float *residual;
+  void *aux;
+  long long lda, ldb, ldc, ldr, ldaux, group_stride;
+  int M, N, K;
+  int epilogue, accumulate, c_dtype, aux_dtype, rows_per_group;
+  int tiles_m, tiles_n, split_k, k_per_split;
+  float *workspace;
+};
+
+__device__ __forceinline__ int tr_swz(int k) { return (k & 3) | (((k >> 3) & 1) << 2); }
+
+// ---- global -> register staging -------------------------------------------------------------
+// K-contiguous tile: 128 rows x 8 chunks; thread t: chunk t&7, rows (t>>3)+32i.
+template <typename T>
+__device__ __forceinline__ void load_kmajor(u32x4 (&r)[4], const T *base, long long ld, int row0, int rows,
+                                            int k0, int kend, int t) {
+  constexpr int EPC = DmTypeInfo<T>::kPerChunk;
+  const int c = t & 7;
+  const int k = k0 + c * EPC;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = row0 + (t >> 3) + 32 * i;
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (row < rows && k < kend) v = *reinterpret_cast<const u32x4 *>(base + (long long)row * ld + k);
+    r[i] = v;
+  }
+}
+__device__ __forceinline__ void store_kmajor(char *lds, const u32x4 (&r)[4], int t) {
+  const int c = t & 7;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = (t >> 3) + 32 * i;
+    *reinterpret_cast<u32x4 *>(lds + row * 128 + ((c ^ (row & 7)) << 4)) = r[i];
+  }
+}
+// M-contiguous tile: rows are k. bf16: 64 rows x 16 chunks; fp32: 32 rows x 32 chunks.
+template <typename T>
+__device__ __forceinline__ void load_mmajor(u32x4 (&r)[4], const T *base, long long ld, int col0, int cols,
+                                            int k0, int kend, int t) {
+  constexpr int EPC = DmTypeInfo<T>::kPerChunk;
+  constexpr int CPR = 128 / EPC;         // chunks per row: 16 (bf16) / 32 (fp32)
+  constexpr int RPI = NTHREADS / CPR;    // rows per iteration: 16 / 8
+  const int c = t % CPR;
+  const int col = col0 + c * EPC;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int k = k0 + t / CPR + RPI * i;
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (k < kend && col < cols) v = *reinterpret_cast<const u32x4 *>(base + (long long)k * ld + col);
+    r[i] = v;
+  }
+}
+template <typename T> __device__ __forceinline__ void store_mmajor(char *lds, const u32x4 (&r)[4], int t);
+template <> __device__ __forceinline__ void store_mmajor<bf16_t>(char *lds, const u32x4 (&r)[4], int t) {
+  const int c = t & 15;  // 16-byte chunk = 8 columns; two chunks per 32-byte slot
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int k = (t >> 4) + 16 * i;
+    *reinterpret_cast<u32x4 *>(lds + k * 256 + ((((c >> 1) ^ tr_swz(k))) << 5) + ((c & 1) << 4)) = r[i];
+  }
+}
+template <> __device__ __forceinline__ void store_mmajor<float>(char *lds, const u32x4 (&r)[4], int t) {
+  const int c = t & 31;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int k = (t >> 5) + 8 * i;
+    *reinterpret_cast<u32x4 *>(lds + k * 528 + (c << 4)) = r[i];
+  }
+}
+
+// ---- LDS -> fragment reads -------------------------------------------------------------------
+// K-contiguous: tile row = wave-local row; same code for both dtypes.
+__device__ __forceinline__ u32x4 frag_kmajor(const char *lds, int row, int kb, int lane) {
+  const int chunk = kb * 4 + (lane >> 4);
+  return *reinterpret_cast<const u32x4 *>(lds + row * 128 + ((chunk ^ (row & 7)) << 4));
+}
+template <typename T> __device__ __forceinline__ u32x4 frag_mmajor(const char *lds, int col0, int kb, int lane);
+template <> __device__ __forceinline__ u32x4 frag_mmajor<bf16_t>(const char *lds, int col0, int kb, int lane) {
+  // ds_read_b64_tr_b16: within a 16-lane group, lane 4q+p supplies the address of row q,
+  // columns 4p..4p+3; lane i receives column i of the 4 rows.
+  const int g = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
+  const int col = col0 + 4 * p;
+  u32x4 out;
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    const int k = kb * 32 + 8 * g + 4 * half + q;
+    const char *addr = lds + k * 256 + ((((col >> 4) ^ tr_swz(k))) << 5) + ((col & 15) << 1);
+    const u32x2 w = dm_ds_read_tr16(addr);
+    out[2 * half] = w[0];
+    out[2 * half + 1] = w[1];
+  }
+  return out;
+}
+template <> __device__ __forceinline__ u32x4 frag_mmajor<float>(const char *lds, int col0, int kb, int lane) {
+  const int g = lane >> 4, i = lane & 15;
+  u32x4 out;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int k = kb * 16 + 4 * g + j;
+    out[j] = *reinterpret_cast<const unsigned int *>(lds + k * 528 + ((col0 + i) << 2));
+  }
+  return out;
+}
+
+template <typename T, int LAYOUT>
+__global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(const GemmParams p) {
+  constexpr bool A_MMAJOR = (LAYOUT == DM_TN);
+  constexpr bool B_MMAJOR = (LAYOUT != DM_NT);
+  constexpr int BK = 128 / (int)sizeof(T);
+  __shared__ __attribute__((aligned(16))) char smem[4 * STAGE_BYTES];
+  auto ldsA = [&](int buf) -> char * { return smem + (2 * buf) * STAGE_BYTES; };
+  auto ldsB = [&](int buf) -> char * { return smem + (2 * buf + 1) * STAGE_BYTES; };
+
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+
+  const int nwg = gridDim.x;
+  int id = dm_xcd_remap(blockIdx.x, nwg);
+  const int tn = id % p.tiles_n;
+  id /= p.tiles_n;
+  const int tm = id % p.tiles_m;
+  const int z = id / p.tiles_m;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int kbeg = z * p.k_per_split;
+  const int kend = min(p.K, kbeg + p.k_per_split);
+
+  const T *A = reinterpret_cast<const T *>(p.A);
+  const T *B = reinterpret_cast<const T *>(p.B);
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  u32x4 ra[4], rb[4];
+  auto gload = [&](int k0) {
+    if constexpr (A_MMAJOR) load_mmajor<T>(ra, A, p.lda, m0, p.M, k0, kend, t);
+    else load_kmajor<T>(ra, A, p.lda, m0, p.M, k0, kend, t);
+    if constexpr (B_MMAJOR) load_mmajor<T>(rb, B, p.ldb, n0, p.N, k0, kend, t);
+    else load_kmajor<T>(rb, B, p.ldb, n0, p.N, k0, kend, t);
+  };
+  auto lstore = [&](int buf) {
+    if constexpr (A_MMAJOR) store_mmajor<T>(ldsA(buf), ra, t);
+    else store_kmajor(ldsA(buf), ra, t);
+    if constexpr (B_MMAJOR) store_mmajor<T>(ldsB(buf), rb, t);
+    else store_kmajor(ldsB(buf), rb, t);
+  };
+
+  const int nk = (kend - kbeg + BK - 1) / BK;
+  if (nk > 0) {
+    gload(kbeg);
+    lstore(0);
+  }
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    const bool more = (kt + 1 < nk);
+    if (more) gload(kbeg + (kt + 1) * BK);
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      u32x4 fa[4], fb[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if constexpr (A_MMAJOR) fa[i] = frag_mmajor<T>(ldsA(cur), wm * 64 + i * 16, kb, lane);
+        else fa[i] = frag_kmajor(ldsA(cur), wm * 64 + i * 16 + (lane & 15), kb, lane);
+        if constexpr (B_MMAJOR) fb[i] = frag_mmajor<T>(ldsB(cur), wn * 64 + i * 16, kb, lane);
+        else fb[i] = frag_kmajor(ldsB(cur), wn * 64 + i * 16 + (lane & 15), kb, lane);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) mma<T>(acc[i][j], fa[i], fb[j]);
+    }
+    if (more) lstore(cur ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue ----------------------------------------------------------------------------
+  const int g = lane >> 4, li = lane & 15;
+  if (p.split_k > 1) {
+    float *W = p.workspace + (long long)z * p.M * p.N;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = m0 + wm * 64 + i * 16 + li;
+      if (m >= p.M) continue;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int n = n0 + wn * 64 + j * 16 + 4 * g;
+        if (n < p.N) dm_store4(W + (long long)m * p.N + n, acc[i][j]);
+      }
+    }
+    return;
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = m0 + wm * 64 + i * 16 + li;
+    if (m >= p.M) continue;
+    long long rbase_c, rbase_r, rbase_x;
+    if (p.rows_per_group > 0) {
+      const long long grp = m / p.rows_per_group, rr = m % p.rows_per_group;
+      rbase_c = grp * p.group_stride + rr * p.ldc;
+      rbase_r = grp * p.group_stride + rr * p.ldr;
+      rbase_x = grp * p.group_stride + rr * p.ldaux;
+    } else {
+      rbase_c = (long long)m * p.ldc;
+      rbase_r = (long long)m * p.ldr;
+      rbase_x = (long long)m * p.ldaux;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = n0 + wn * 64 + j * 16 + 4 * g;
+      if (n >= p.N) continue;   // N % 4 == 0 is enforced by the launcher
+      f32x4 v = acc[i][j];
+      if (p.bias) v += dm_load4(p.bias + n);
+      if (p.epilogue == DM_EPI_GELU) {
+        if (p.aux_dtype == DM_F32) dm_store4(reinterpret_cast<float *>(p.aux) + rbase_x + n, v);
+        else dm_store4(reinterpret_cast<bf16_t *>(p.aux) + rbase_x + n, v);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = dm_gelu(v[e]);
+      } else if (p.epilogue == DM_EPI_DGELU) {
+        f32x4 u = (p.aux_dtype == DM_F32) ? dm_load4(reinterpret_cast<const float *>(p.aux) + rbase_x + n)
+                                          : dm_load4(reinterpret_cast<const bf16_t *>(p.aux) + rbase_x + n);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] *= dm_dgelu(u[e]);
+      }
+      if (p.residual) v += dm_load4(p.residual + rbase_r + n);
+      if (p.c_dtype == DM_F32) {
+        float *c = reinterpret_cast<float *>(p.C) + rbase_c + n;
+        if (p.accumulate) v += dm_load4(c);
+        dm_store4(c, v);
+      } else {
+        dm_store4(reinterpret_cast<bf16_t *>(p.C) + rbase_c + n, v);
+      }
+    }
+  }
+}
+
+// out[i] = (accumulate ? out[i] : 0) + sum_s slab[s][i], slices summed in index order.
+__global__ void splitk_reduce_kernel(const float *__restrict__ slab, float *__restrict__ out, long long ldc,
+                                     int M, int N, int S, int accumulate) {
+  const long long n4 = (long long)M * N / 4;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+    const long long e = i * 4;
+    const int m = (int)(e / N), n = (int)(e % N);
+    float *o = out + (long long)m * ldc + n;
+    f32x4 v = accumulate ? dm_load4(o) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < S; ++s) v += dm_load4(slab + (long long)s * M * N + e);
+    dm_store4(o, v);
+  }
+}
+
+// Generic fp32 kernel for the small/odd-shaped products of the tail (K = 19, N = 100, M = batch):
+// plain FMA chains in k order, one output element per thread, LDS-tiled 16x16.
+template <int LAYOUT>
+__global__ void sgemm_small_kernel(const GemmParams p) {
+  __shared__ float sa[16][17], sb[16][17];
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const int m = blockIdx.y * 16 + ty, n = blockIdx.x * 16 + tx;
+  const float *A = reinterpret_cast<const float *>(p.A);
+  const float *B = reinterpret_cast<const float *>(p.B);
+  float acc = 0.f;
+  for (int k0 = 0; k0 < p.K; k0 += 16) {
+    // sa[i][kk] = A(op)[m0+i][k0+kk], sb[kk][j] = B(op)[k0+kk][n0+j]
+    {
+      const int mi = blockIdx.y * 16 + ty, kk = k0 + tx;
+      float v = 0.f;
+      if (mi < p.M && kk < p.K) v = (LAYOUT == DM_TN) ? A[(long long)kk * p.lda + mi] : A[(long long)mi * p.lda + kk];
+      sa[ty][tx] = v;
+    }
+    {
+      const int kk = k0 + ty, nj = blockIdx.x * 16 + tx;
+      float v = 0.f;
+      if (kk < p.K && nj < p.N) v = (LAYOUT == DM_NT) ? B[(long long)nj * p.ldb + kk] : B[(long long)kk * p.ldb + nj];
+      sb[ty][tx] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) acc = fmaf(sa[ty][kk], sb[kk][tx], acc);
+    __syncthreads();
+  }
+  if (m >= p.M || n >= p.N) return;
+  float v = acc;
+  if (p.bias) v += p.bias[n];
+  const long long ro = (long long)m;
+  if (p.epilogue == DM_EPI_GELU) {
+    reinterpret_cast<float *>(p.aux)[ro * p.ldaux + n] = v;
+    v = dm_gelu(v);
+  } else if (p.epilogue == DM_EPI_DGELU) {
+    v *= dm_dgelu(reinterpret_cast<const float *>(p.aux)[ro * p.ldaux + n]);
+  }
+  if (p.residual) v += p.residual[ro * p.ldr + n];
+  float *c = reinterpret_cast<float *>(p.C) + ro * p.ldc + n;
+  if (p.accumulate) v += *c;
+  *c = v;
+}
+
+template <typename T>
+void launch_mfma(const GemmParams &p, int layout, int grid, hipStream_t s) {
+  switch (layout) {
+    case DM_NT: hipLaunchKernelGGL((gemm_kernel<T, DM_NT>), dim3(grid), dim3(NTHREADS), 0, s, p); break;
+    case DM_NN: hipLaunchKernelGGL((gemm_kernel<T, DM_NN>), dim3(grid), dim3(NTHREADS), 0, s, p); break;
+    default: hipLaunchKernelGGL((gemm_kernel<T, DM_TN>), dim3(grid), dim3(NTHREADS), 0, s, p); break;
+  }
+}
+
+int choose_split(int tiles, int K, int bk) {
+  // Fill ~2 workgroups per CU on 256 CUs, keep >= 8 stages per slice.
+  int s = 1;
+  while (tiles * s < 512 && s < 32 && K / (s * 2) >= 8 * bk) s *= 2;
+  return s;
+}
+
+}  // namespace
+
+extern "C" int64_t dm_gemm_workspace_bytes(int32_t layout, int32_t M, int32_t N, int32_t K) {
+  if (layout != DM_TN) return 0;
+  const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+  const int s = choose_split(tiles, K, 32);
+  return s > 1 ? (int64_t)s * M * N * 4 : 0;
+}
+
+extern "C" int dm_gemm(const DmGemmArgs *a, void *stream) {
+  DM_REQUIRE(a != nullptr, DM_ERR_BAD_SHAPE, "dm_gemm: null args");
+  DM_REQUIRE(a->M > 0 && a->N > 0 && a->K > 0, DM_ERR_BAD_SHAPE, "dm_gemm: M,N,K must be positive (got %d,%d,%d)", a->M, a->N, a->K);
+  DM_REQUIRE(a->layout >= DM_NT && a->layout <= DM_TN, DM_ERR_BAD_SHAPE, "dm_gemm: bad layout %d", a->layout);
+  DM_REQUIRE(a->ab_dtype == DM_F32 || a->ab_dtype == DM_BF16, DM_ERR_BAD_DTYPE, "dm_gemm: bad ab_dtype %d", a->ab_dtype);
+  DM_REQUIRE(a->c_dtype == DM_F32 || a->c_dtype == DM_BF16, DM_ERR_BAD_DTYPE, "dm_gemm: bad c_dtype %d", a->c_dtype);
+  DM_REQUIRE(a->A && a->B && a->C, DM_ERR_BAD_SHAPE, "dm_gemm: null operand");
+  DM_REQUIRE(!(a->accumulate && a->c_dtype != DM_F32), DM_ERR_BAD_DTYPE, "dm_gemm: accumulate needs an fp32 C");
+  DM_REQUIRE(a->epilogue == DM_EPI_NONE || a->aux != nullptr, DM_ERR_BAD_SHAPE, "dm_gemm: GELU epilogues need aux");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+
+  GemmParams p{};
+  p.A = a->A; p.B = a->B; p.C = a->C; p.bias = a->bias; p.residual = a->residual; p.aux = a->aux;
+  p.lda = a->lda; p.ldb = a->ldb; p.ldc = a->ldc; p.ldr = a->ldr; p.ldaux = a->ldaux;
+  p.group_stride = a->group_stride; p.rows_per_group = a->rows_per_group;
+  p.M = a->M; p.N = a->N; p.K = a->K;
+  p.epilogue = a->epilogue; p.accumulate = a->accumulate; p.c_dtype = a->c_dtype; p.aux_dtype = a->aux_dtype;
+
+  // Which extents must be chunk (16-byte) multiples for the MFMA path.
+  const int epc = (a->ab_dtype == DM_BF16) ? 8 : 4;
+  const int a_inner = (a->layout == DM_TN) ? a->M : a->K;   // contiguous extent of A rows
+  const int b_inner = (a->layout == DM_NT) ? a->K : a->N;
+  const bool mfma_ok = (a_inner % epc == 0) && (b_inner % epc == 0) && (a->lda % epc == 0) && (a->ldb % epc == 0) &&
+                       dm_aligned16(a->A) && dm_aligned16(a->B) && (a->N % 4 == 0) && (a->ldc % 4 == 0) &&
+                       (a->residual == nullptr || (a->ldr % 4 == 0 && dm_aligned16(a->residual))) &&
+                       (a->aux == nullptr || a->ldaux % 4 == 0) && (a->bias == nullptr || dm_aligned16(a->bias)) &&
+                       dm_aligned16(a->C) && (a->rows_per_group == 0 || a->group_stride % 4 == 0) &&
+                       (a->M >= 32 || a->ab_dtype == DM_BF16);
+  if (!mfma_ok) {
+    DM_REQUIRE(a->ab_dtype == DM_F32 && a->c_dtype == DM_F32 && (a->aux == nullptr || a->aux_dtype == DM_F32),
+               DM_ERR_BAD_ALIGN, "dm_gemm: shape/alignment needs the generic path, which is fp32-only "
+               "(M=%d N=%d K=%d lda=%lld ldb=%lld)", a->M, a->N, a->K, (long long)a->lda, (long long)a->ldb);
+    DM_REQUIRE(a->rows_per_group == 0, DM_ERR_UNSUPPORTED, "dm_gemm: grouped rows need the MFMA path");
+    dim3 grid((a->N + 15) / 16, (a->M + 15) / 16);
+    switch (a->layout) {
+      case DM_NT: hipLaunchKernelGGL((sgemm_small_kernel<DM_NT>), grid, dim3(256), 0, s, p); break;
+      case DM_NN: hipLaunchKernelGGL((sgemm_small_kernel<DM_NN>), grid, dim3(256), 0, s, p); break;
+      default: hipLaunchKernelGGL((sgemm_small_kernel<DM_TN>), grid, dim3(256), 0, s, p); break;
+    }
+    DM_LAUNCH_CHECK("dm_gemm(generic)");
+    return DM_OK;
+  }
+
+  p.tiles_m = (a->M + BM - 1) / BM;
+  p.tiles_n = (a->N + BN - 1) / BN;
+  const int bk = (a->ab_dtype == DM_BF16) ? 64 : 32;
+  int split = a->split_k;
+  const bool can_split = (a->layout == DM_TN) && a->epilogue == DM_EPI_NONE && !a->bias && !a->residual &&
+                         a->c_dtype == DM_F32 && a->rows_per_group == 0 && a->workspace != nullptr;
+  if (split == 0) split = can_split ? choose_split(p.tiles_m * p.tiles_n, a->K, bk) : 1;
+  if (split > 1) {
+    DM_REQUIRE(can_split, DM_ERR_UNSUPPORTED, "dm_gemm: split_k needs DM_TN, no epilogue, fp32 C and a workspace");
+    while (split > 1 && (int64_t)split * a->M * a->N * 4 > a->workspace_bytes) split >>= 1;
+  }
+  int kps = ((a->K + split - 1) / split + bk - 1) / bk * bk;
+  split = (a->K + kps - 1) / kps;
+  p.split_k = split;
+  p.k_per_split = kps;
+  p.workspace = reinterpret_cast<float *>(a->workspace);
+  const int grid = p.tiles_m * p.tiles_n * split;
+  if (a->ab_dtype == DM_BF16) launch_mfma<bf16_t>(p, a->layout, grid, s);
+  else launch_mfma<float>(p, a->layout, grid, s);
+  DM_LAUNCH_CHECK("dm_gemm");
+  if (split > 1) {
+    const long long n4 = (long long)a->M * a->N / 4;
+    const long long want = (n4 + 255) / 256;
+    const int rgrid = (int)(want < 2048 ? want : 2048);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(rgrid), dim3(256), 0, s, p.workspace,
+                       reinterpret_cast<float *>(a->C), (long long)a->ldc, a->M, a->N, split, a->accumulate);
+    DM_LAUNCH_CHECK("dm_gemm(split-k reduce)");
+  }
+  return DM_OK;
+}

@@ -1,0 +1,503 @@
+// HBM-bound row / element kernels of the DeepMerge hot path (gfx950): LayerNorm fwd/bwd,
+// token pooling, column sums, casts, patch extraction, contrastive loss, Adam, and the
+// relative-position-bias gather / gradient reduction.  All loads/stores are 16-byte vectors
+// along the contiguous (channel) axis; reductions are wave64 butterflies.
+#include "dm_common.h"
+
+namespace {
+
+constexpr int MAXCH = 4;          // float4 chunks per lane per row -> cols <= 1024
+constexpr int LN_MAX_WG = 512;
+constexpr int CS_MAX_SLICES = 64;
+
+// ---------------------------------------------------------------------------------------------
+// LayerNorm forward: one wave per row.
+// ---------------------------------------------------------------------------------------------
+template <typename TY>
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float *__restrict__ x, const float *__restrict__ gamma,
+                                                            const float *__restrict__ beta, TY *__restrict__ y,
+                                                            float *__restrict__ mean_out, float *__restrict__ rstd_out,
+                                                            int rows, int cols, float eps) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nch = cols >> 2;
+  for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
+    const float *xr = x + (long long)row * cols;
+    f32x4 v[MAXCH];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXCH; ++i) {
+      const int c = lane + 64 * i;
+      v[i] = (c < nch) ? dm_load4(xr + 4 * c) : (f32x4){0.f, 0.f, 0.f, 0.f};
+      s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+    }
+    const float mean = dm_wave_sum(s) / (float)cols;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXCH; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nch) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float d = v[i][e] - mean;
+          q += d * d;
+        }
+      }
+    }
+    const float rstd = rsqrtf(dm_wave_sum(q) / (float)cols + eps);
+    if (lane == 0) {
+      mean_out[row] = mean;
+      rstd_out[row] = rstd;
+    }
+    TY *yr = y + (long long)row * cols;
+#pragma unroll
+    for (int i = 0; i < MAXCH; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nch) {
+        const f32x4 g = dm_load4(gamma + 4 * c), b = dm_load4(beta + 4 * c);
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mean) * rstd * g[e] + b[e];
+        dm_store4(yr + 4 * c, o);
+      }
+    }
+  }
+}
+
+// LayerNorm backward: dx = dres + rstd*(g - mean(g) - xhat*mean(g*xhat)), g = dy*gamma.
+// Each workgroup keeps per-column partial sums of dy*xhat (dgamma) and dy (dbeta) in registers
+// over its grid-stride rows, combines its 4 waves through LDS and writes one partial row.
+template <typename TDY>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const TDY *__restrict__ dy, const float *__restrict__ x,
+                                                            const float *__restrict__ gamma, const float *__restrict__ mean,
+                                                            const float *__restrict__ rstd, const float *__restrict__ dres,
+                                                            float *__restrict__ dx, float *__restrict__ partial,
+                                                            int rows, int cols) {
+  __shared__ float red[4][2][MAXCH * 256];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nch = cols >> 2;
+  f32x4 dg[MAXCH], db[MAXCH], gam[MAXCH];
+#pragma unroll
+  for (int i = 0; i < MAXCH; ++i) {
+    dg[i] = db[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int c = lane + 64 * i;
+    gam[i] = (c < nch) ? dm_load4(gamma + 4 * c) : (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+  for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
+    const long long off = (long long)row * cols;
+    const float mu = mean[row], rs = rstd[row];
+    f32x4 xh[MAXCH], g[MAXCH];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXCH; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nch) {
+        const f32x4 xv = dm_load4(x + off + 4 * c);
+        const f32x4 d = dm_load4(dy + off + 4 * c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          xh[i][e] = (xv[e] - mu) * rs;
+          g[i][e] = d[e] * gam[i][e];
+          s1 += g[i][e];
+          s2 += g[i][e] * xh[i][e];
+          dg[i][e] += d[e] * xh[i][e];
+          db[i][e] += d[e];
+        }
+      } else {
+        xh[i] = g[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
+    }
+    const float c1 = dm_wave_sum(s1) / (float)cols, c2 = dm_wave_sum(s2) / (float)cols;
+#pragma unroll
+    for (int i = 0; i < MAXCH; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nch) {
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = rs * (g[i][e] - c1 - xh[i][e] * c2);
+        if (dres) o += dm_load4(dres + off + 4 * c);
+        dm_store4(dx + off + 4 * c, o);
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < MAXCH; ++i) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      red[wave][0][(lane + 64 * i) * 4 + e] = dg[i][e];
+      red[wave][1][(lane + 64 * i) * 4 + e] = db[i][e];
+    }
+  }
+  __syncthreads();
+  float *prow = partial + (long long)blockIdx.x * 2 * cols;
+  for (int c = threadIdx.x; c < 2 * cols; c += 256) {
+    const int which = c / cols, col = c % cols;
+    prow[c] = (red[0][which][col] + red[1][which][col]) + (red[2][which][col] + red[3][which][col]);
+  }
+}
+
+// out[j] (+)= sum_r partial[r][j], r in order (deterministic).
+__global__ void partial_reduce_kernel(const float *__restrict__ partial, float *__restrict__ out0, float *__restrict__ out1,
+                                      int nrows, int width, int split, int accumulate) {
+  // `partial` rows are `width` wide; columns [0,split) go to out0, [split,width) to out1.
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= width) return;
+  float s = 0.f;
+  for (int r = 0; r < nrows; ++r) s += partial[(long long)r * width + j];
+  float *o = (j < split) ? out0 + j : out1 + (j - split);
+  *o = accumulate ? *o + s : s;
+}
+
+// ---------------------------------------------------------------------------------------------
+// token pooling
+// ---------------------------------------------------------------------------------------------
+__global__ void token_pool_fwd_kernel(const float *__restrict__ x, float *__restrict__ y, int B, int S, int side, int C) {
+  const int half = side >> 1, c4 = C >> 2;
+  const long long total = (long long)B * S * half * half * c4;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % c4);
+    long long r = i / c4;
+    const int px = (int)(r % half); r /= half;
+    const int py = (int)(r % half); r /= half;   // r = b*S + s
+    const float *src = x + ((r * side + 2 * py) * side + 2 * px) * (long long)C + 4 * c;
+    const f32x4 a = dm_load4(src), b = dm_load4(src + C), d = dm_load4(src + (long long)side * C), e = dm_load4(src + (long long)side * C + C);
+    dm_store4(y + ((r * half + py) * half + px) * (long long)C + 4 * c, ((a + b) + (d + e)) * 0.25f);
+  }
+}
+__global__ void token_pool_bwd_kernel(const float *__restrict__ dy, float *__restrict__ dx, int B, int S, int side, int C) {
+  const int half = side >> 1, c4 = C >> 2;
+  const long long total = (long long)B * S * side * side * c4;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % c4);
+    long long r = i / c4;
+    const int xx = (int)(r % side); r /= side;
+    const int yy = (int)(r % side); r /= side;
+    const f32x4 g = dm_load4(dy + ((r * half + (yy >> 1)) * half + (xx >> 1)) * (long long)C + 4 * c);
+    dm_store4(dx + ((r * side + yy) * side + xx) * (long long)C + 4 * c, g * 0.25f);
+  }
+}
+__global__ void group_mean_fwd_kernel(const float *__restrict__ x, float *__restrict__ y, int rows, int g, int C) {
+  const int c4 = C >> 2;
+  const long long total = (long long)rows * c4;
+  const float inv = 1.0f / (float)g;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % c4);
+    const long long r = i / c4;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < g; ++k) s += dm_load4(x + (r * g + k) * C + 4 * c);
+    dm_store4(y + r * C + 4 * c, s * inv);
+  }
+}
+__global__ void group_mean_bwd_kernel(const float *__restrict__ dy, float *__restrict__ dx, int rows, int g, int C) {
+  const int c4 = C >> 2;
+  const long long total = (long long)rows * g * c4;
+  const float inv = 1.0f / (float)g;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % c4);
+    const long long r = i / c4;
+    dm_store4(dx + r * C + 4 * c, dm_load4(dy + (r / g) * C + 4 * c) * inv);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// column sums (bias gradients): slices of rows -> partial[slice][N]
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T *__restrict__ X, long long ldx, float *__restrict__ partial,
+                                                     int M, int N, int rows_per_slice) {
+  __shared__ f32x4 red[16][16];
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const int n = blockIdx.x * 64 + tx * 4;
+  const int r0 = blockIdx.y * rows_per_slice, r1 = min(M, r0 + rows_per_slice);
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  if (n < N)
+    for (int r = r0 + ty; r < r1; r += 16) s += dm_load4(X + (long long)r * ldx + n);
+  red[ty][tx] = s;
+  __syncthreads();
+  if (ty == 0 && n < N) {
+    f32x4 a = red[0][tx];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) a += red[k][tx];
+    dm_store4(partial + (long long)blockIdx.y * N + n, a);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// cast / patchify
+// ---------------------------------------------------------------------------------------------
+__global__ void cast_bf16_kernel(const float *__restrict__ src, bf16_t *__restrict__ dst, long long n) {
+  const long long n8 = n >> 3;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long long)gridDim.x * blockDim.x) {
+    const f32x4 a = dm_load4(src + 8 * i), b = dm_load4(src + 8 * i + 4);
+    bf16x8 o = {(bf16_t)a[0], (bf16_t)a[1], (bf16_t)a[2], (bf16_t)a[3], (bf16_t)b[0], (bf16_t)b[1], (bf16_t)b[2], (bf16_t)b[3]};
+    *reinterpret_cast<bf16x8 *>(dst + 8 * i) = o;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 7)) dst[(n8 << 3) + threadIdx.x] = (bf16_t)src[(n8 << 3) + threadIdx.x];
+}
+__global__ void copy_f32_kernel(const float *__restrict__ src, float *__restrict__ dst, long long n) {
+  const long long n4 = n >> 2;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x)
+    dm_store4(dst + 4 * i, dm_load4(src + 4 * i));
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) dst[(n4 << 2) + threadIdx.x] = src[(n4 << 2) + threadIdx.x];
+}
+
+template <typename T>
+__global__ void patchify_kernel(const float *__restrict__ x, T *__restrict__ cols, int B, int C, int side, int p) {
+  const int grid = side / p, p4 = p >> 2;
+  const long long K = (long long)C * p * p;
+  const long long total = (long long)B * grid * grid * (K >> 2);
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    long long r = i;
+    const int dx4 = (int)(r % p4); r /= p4;
+    const int dy = (int)(r % p); r /= p;
+    const int c = (int)(r % C); r /= C;     // r = row = (b*grid + py)*grid + px
+    const int px = (int)(r % grid);
+    const long long bp = r / grid;
+    const int py = (int)(bp % grid);
+    const long long b = bp / grid;
+    const f32x4 v = dm_load4(x + ((b * C + c) * side + (py * p + dy)) * (long long)side + px * p + 4 * dx4);
+    dm_store4(cols + r * K + ((long long)c * p + dy) * p + 4 * dx4, v);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// contrastive loss (single workgroup; B is a few hundred pairs at most)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void contrastive_loss_kernel(const float *__restrict__ a, const float *__restrict__ b,
+                                                               const float *__restrict__ flag, float margin, float upstream,
+                                                               float *__restrict__ loss, float *__restrict__ da,
+                                                               float *__restrict__ db, int B, int D) {
+  __shared__ float wsum[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float acc = 0.f;
+  const float gscale = upstream / (float)B;
+  for (int r = wave; r < B; r += 4) {
+    float d = 0.f;
+    for (int c = lane; c < D; c += 64) {
+      const float t = a[(long long)r * D + c] - b[(long long)r * D + c];
+      d += t * t;
+    }
+    d = dm_wave_sum(d);
+    const float f = flag[r];
+    const float hinge = margin - d;
+    acc += f * d + (1.f - f) * fmaxf(hinge, 0.f);
+    if (da) {
+      // d(l)/d(d) = flag - (1-flag)*[margin - d > 0]   (relu'(0) = 0 as in torch)
+      const float coef = (f - (1.f - f) * (hinge > 0.f ? 1.f : 0.f)) * 2.f * gscale;
+      for (int c = lane; c < D; c += 64) {
+        const float t = a[(long long)r * D + c] - b[(long long)r * D + c];
+        da[(long long)r * D + c] = coef * t;
+        db[(long long)r * D + c] = -coef * t;
+      }
+    }
+  }
+  if (lane == 0) wsum[wave] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) loss[0] = ((wsum[0] + wsum[1]) + (wsum[2] + wsum[3])) / (float)B;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Adam (flat buffers).  Operation order follows torch.optim.Adam's single-tensor path.
+// ---------------------------------------------------------------------------------------------
+__global__ void adam_kernel(float *__restrict__ param, const float *__restrict__ grad, float *__restrict__ m,
+                            float *__restrict__ v, bf16_t *__restrict__ lp, long long n, float beta1, float beta2,
+                            float eps, float step_size, float bc2_sqrt, float grad_scale) {
+  const long long n4 = n >> 2;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+    f32x4 p = dm_load4(param + 4 * i), g = dm_load4(grad + 4 * i) * grad_scale, mm = dm_load4(m + 4 * i), vv = dm_load4(v + 4 * i);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      mm[e] = mm[e] * beta1 + g[e] * (1.f - beta1);
+      vv[e] = vv[e] * beta2 + (g[e] * g[e]) * (1.f - beta2);
+      const float denom = sqrtf(vv[e]) / bc2_sqrt + eps;
+      p[e] = p[e] - step_size * (mm[e] / denom);
+    }
+    dm_store4(param + 4 * i, p); dm_store4(m + 4 * i, mm); dm_store4(v + 4 * i, vv);
+    if (lp) dm_store4(lp + 4 * i, p);
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    const long long i = (n4 << 2) + threadIdx.x;
+    const float g = grad[i] * grad_scale;
+    const float mm = m[i] * beta1 + g * (1.f - beta1);
+    const float vv = v[i] * beta2 + (g * g) * (1.f - beta2);
+    const float p = param[i] - step_size * (mm / (sqrtf(vv) / bc2_sqrt + eps));
+    param[i] = p; m[i] = mm; v[i] = vv;
+    if (lp) lp[i] = (bf16_t)p;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// relative-position bias: gather and gradient reduction
+// ---------------------------------------------------------------------------------------------
+__global__ void relpos_gather_kernel(const float *__restrict__ table, const int *__restrict__ index,
+                                     float *__restrict__ bias, int NN, int H, int n_bins) {
+  for (int ij = blockIdx.x * blockDim.x + threadIdx.x; ij < NN; ij += gridDim.x * blockDim.x) {
+    int bin = index[ij];
+    bin = min(max(bin, 0), n_bins - 1);
+    for (int h = 0; h < H; ++h) bias[(long long)h * NN + ij] = table[bin * H + h];
+  }
+}
+__global__ void relpos_scatter_kernel(const float *__restrict__ slab, float *__restrict__ dtable, int B, int H, int R,
+                                      int n_bins, int accumulate) {
+  const int bin = blockIdx.x * blockDim.x + threadIdx.x;
+  const int h = blockIdx.y;
+  if (bin >= n_bins) return;
+  float s = 0.f;
+  for (int b = 0; b < B; ++b)
+    for (int q = 0; q < R; ++q) s += slab[(((long long)b * H + h) * R + q) * n_bins + bin];
+  float *o = dtable + (long long)bin * H + h;
+  *o = accumulate ? *o + s : s;
+}
+
+inline int grid_for(long long work_items, int block = 256, int cap = 4096) {
+  long long g = (work_items + block - 1) / block;
+  if (g < 1) g = 1;
+  if (g > cap) g = cap;
+  return (int)g;
+}
+
+}  // namespace
+
+// =============================================================================================
+extern "C" int dm_layernorm_fwd(const float *x, const float *gamma, const float *beta, void *y, int32_t y_dtype,
+                                float *mean, float *rstd, int32_t rows, int32_t cols, float eps, void *stream) {
+  DM_REQUIRE(rows > 0 && cols > 0 && cols % 4 == 0 && cols <= MAXCH * 256, DM_ERR_BAD_SHAPE,
+             "dm_layernorm_fwd: rows=%d cols=%d (cols must be a multiple of 4, <= %d)", rows, cols, MAXCH * 256);
+  DM_REQUIRE(x && gamma && beta && y && mean && rstd, DM_ERR_BAD_SHAPE, "dm_layernorm_fwd: null pointer");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const int grid = grid_for((long long)rows, 4, 2048);
+  if (y_dtype == DM_F32)
+    hipLaunchKernelGGL(layernorm_fwd_kernel<float>, dim3(grid), dim3(256), 0, s, x, gamma, beta, (float *)y, mean, rstd, rows, cols, eps);
+  else if (y_dtype == DM_BF16)
+    hipLaunchKernelGGL(layernorm_fwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, x, gamma, beta, (bf16_t *)y, mean, rstd, rows, cols, eps);
+  else DM_REQUIRE(false, DM_ERR_BAD_DTYPE, "dm_layernorm_fwd: bad y_dtype %d", y_dtype);
+  DM_LAUNCH_CHECK("dm_layernorm_fwd");
+  return DM_OK;
+}
+
+extern "C" int64_t dm_layernorm_bwd_partial_floats(int32_t cols) { return (int64_t)LN_MAX_WG * 2 * cols; }
+
+extern "C" int dm_layernorm_bwd(const void *dy, int32_t dy_dtype, const float *x, const float *gamma, const float *mean,
+                                const float *rstd, const float *dres, float *dx, float *dgamma, float *dbeta,
+                                int32_t accumulate_params, float *partial, int32_t rows, int32_t cols, void *stream) {
+  DM_REQUIRE(rows > 0 && cols > 0 && cols % 4 == 0 && cols <= MAXCH * 256, DM_ERR_BAD_SHAPE,
+             "dm_layernorm_bwd: rows=%d cols=%d", rows, cols);
+  DM_REQUIRE(dy && x && gamma && mean && rstd && dx && dgamma && dbeta && partial, DM_ERR_BAD_SHAPE, "dm_layernorm_bwd: null pointer");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const int grid = grid_for((long long)rows, 4, LN_MAX_WG);
+  if (dy_dtype == DM_F32)
+    hipLaunchKernelGGL(layernorm_bwd_kernel<float>, dim3(grid), dim3(256), 0, s, (const float *)dy, x, gamma, mean, rstd, dres, dx, partial, rows, cols);
+  else if (dy_dtype == DM_BF16)
+    hipLaunchKernelGGL(layernorm_bwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t *)dy, x, gamma, mean, rstd, dres, dx, partial, rows, cols);
+  else DM_REQUIRE(false, DM_ERR_BAD_DTYPE, "dm_layernorm_bwd: bad dy_dtype %d", dy_dtype);
+  DM_LAUNCH_CHECK("dm_layernorm_bwd");
+  hipLaunchKernelGGL(partial_reduce_kernel, dim3((2 * cols + 255) / 256), dim3(256), 0, s, partial, dgamma, dbeta, grid, 2 * cols, cols, accumulate_params);
+  DM_LAUNCH_CHECK("dm_layernorm_bwd(reduce)");
+  return DM_OK;
+}
+
+extern "C" int dm_token_pool_fwd(const float *x, float *y, int32_t B, int32_t S, int32_t side, int32_t C, void *stream) {
+  DM_REQUIRE(B > 0 && S > 0 && side >= 2 && side % 2 == 0 && C % 4 == 0, DM_ERR_BAD_SHAPE, "dm_token_pool_fwd: B=%d S=%d side=%d C=%d", B, S, side, C);
+  const long long total = (long long)B * S * (side / 2) * (side / 2) * (C / 4);
+  hipLaunchKernelGGL(token_pool_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, y, B, S, side, C);
+  DM_LAUNCH_CHECK("dm_token_pool_fwd");
+  return DM_OK;
+}
+extern "C" int dm_token_pool_bwd(const float *dy, float *dx, int32_t B, int32_t S, int32_t side, int32_t C, void *stream) {
+  DM_REQUIRE(B > 0 && S > 0 && side >= 2 && side % 2 == 0 && C % 4 == 0, DM_ERR_BAD_SHAPE, "dm_token_pool_bwd: B=%d S=%d side=%d C=%d", B, S, side, C);
+  const long long total = (long long)B * S * side * side * (C / 4);
+  hipLaunchKernelGGL(token_pool_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), dy, dx, B, S, side, C);
+  DM_LAUNCH_CHECK("dm_token_pool_bwd");
+  return DM_OK;
+}
+extern "C" int dm_group_mean_fwd(const float *x, float *y, int32_t rows, int32_t g, int32_t C, void *stream) {
+  DM_REQUIRE(rows > 0 && g > 0 && C % 4 == 0, DM_ERR_BAD_SHAPE, "dm_group_mean_fwd: rows=%d g=%d C=%d", rows, g, C);
+  hipLaunchKernelGGL(group_mean_fwd_kernel, dim3(grid_for((long long)rows * (C / 4))), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, y, rows, g, C);
+  DM_LAUNCH_CHECK("dm_group_mean_fwd");
+  return DM_OK;
+}
+extern "C" int dm_group_mean_bwd(const float *dy, float *dx, int32_t rows, int32_t g, int32_t C, void *stream) {
+  DM_REQUIRE(rows > 0 && g > 0 && C % 4 == 0, DM_ERR_BAD_SHAPE, "dm_group_mean_bwd: rows=%d g=%d C=%d", rows, g, C);
+  hipLaunchKernelGGL(group_mean_bwd_kernel, dim3(grid_for((long long)rows * g * (C / 4))), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), dy, dx, rows, g, C);
+  DM_LAUNCH_CHECK("dm_group_mean_bwd");
+  return DM_OK;
+}
+
+extern "C" int64_t dm_colsum_partial_floats(int32_t N) { return (int64_t)CS_MAX_SLICES * N; }
+
+extern "C" int dm_colsum(const void *X, int32_t dtype, int64_t ldx, float *out, int32_t M, int32_t N, int32_t accumulate,
+                         float *partial, void *stream) {
+  DM_REQUIRE(M > 0 && N > 0 && N % 4 == 0 && ldx % 4 == 0, DM_ERR_BAD_SHAPE, "dm_colsum: M=%d N=%d ldx=%lld", M, N, (long long)ldx);
+  DM_REQUIRE(X && out && partial, DM_ERR_BAD_SHAPE, "dm_colsum: null pointer");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  int slices = (M + 255) / 256;
+  if (slices > CS_MAX_SLICES) slices = CS_MAX_SLICES;
+  const int rps = (M + slices - 1) / slices;
+  slices = (M + rps - 1) / rps;
+  dim3 grid((N + 63) / 64, slices);
+  if (dtype == DM_F32) hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, s, (const float *)X, (long long)ldx, partial, M, N, rps);
+  else if (dtype == DM_BF16) hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t *)X, (long long)ldx, partial, M, N, rps);
+  else DM_REQUIRE(false, DM_ERR_BAD_DTYPE, "dm_colsum: bad dtype %d", dtype);
+  DM_LAUNCH_CHECK("dm_colsum");
+  hipLaunchKernelGGL(partial_reduce_kernel, dim3((N + 255) / 256), dim3(256), 0, s, partial, out, out, slices, N, N, accumulate);
+  DM_LAUNCH_CHECK("dm_colsum(reduce)");
+  return DM_OK;
+}
+
+extern "C" int dm_cast(const float *src, void *dst, int32_t dst_dtype, int64_t n, void *stream) {
+  DM_REQUIRE(src && dst && n > 0, DM_ERR_BAD_SHAPE, "dm_cast: bad arguments");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (dst_dtype == DM_BF16) hipLaunchKernelGGL(cast_bf16_kernel, dim3(grid_for(n / 8 + 1)), dim3(256), 0, s, src, (bf16_t *)dst, (long long)n);
+  else if (dst_dtype == DM_F32) hipLaunchKernelGGL(copy_f32_kernel, dim3(grid_for(n / 4 + 1)), dim3(256), 0, s, src, (float *)dst, (long long)n);
+  else DM_REQUIRE(false, DM_ERR_BAD_DTYPE, "dm_cast: bad dtype %d", dst_dtype);
+  DM_LAUNCH_CHECK("dm_cast");
+  return DM_OK;
+}
+
+extern "C" int dm_patchify(const float *x, void *cols, int32_t dtype, int32_t B, int32_t C, int32_t side, int32_t p, void *stream) {
+  DM_REQUIRE(B > 0 && C > 0 && p > 0 && p % 4 == 0 && side % p == 0, DM_ERR_BAD_SHAPE,
+             "dm_patchify: B=%d C=%d side=%d patch=%d (patch must be a multiple of 4 dividing side)", B, C, side, p);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const long long total = (long long)B * (side / p) * (side / p) * ((long long)C * p * p / 4);
+  if (dtype == DM_F32) hipLaunchKernelGGL(patchify_kernel<float>, dim3(grid_for(total)), dim3(256), 0, s, x, (float *)cols, B, C, side, p);
+  else if (dtype == DM_BF16) hipLaunchKernelGGL(patchify_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, s, x, (bf16_t *)cols, B, C, side, p);
+  else DM_REQUIRE(false, DM_ERR_BAD_DTYPE, "dm_patchify: bad dtype %d", dtype);
+  DM_LAUNCH_CHECK("dm_patchify");
+  return DM_OK;
+}
+
+extern "C" int dm_contrastive_loss(const float *a, const float *b, const float *flag, float margin, float upstream,
+                                   float *loss, float *da, float *db, int32_t B, int32_t D, void *stream) {
+  DM_REQUIRE(a && b && flag && loss && B > 0 && D > 0, DM_ERR_BAD_SHAPE, "dm_contrastive_loss: bad arguments");
+  DM_REQUIRE((da == nullptr) == (db == nullptr), DM_ERR_BAD_SHAPE, "dm_contrastive_loss: da and db must both be set or both NULL");
+  hipLaunchKernelGGL(contrastive_loss_kernel, dim3(1), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a, b, flag, margin, upstream, loss, da, db, B, D);
+  DM_LAUNCH_CHECK("dm_contrastive_loss");
+  return DM_OK;
+}
+
+extern "C" int dm_adam_step(float *param, const float *grad, float *m, float *v, void *param_lp, int64_t n, int32_t step,
+                            float lr, float beta1, float beta2, float eps, float grad_scale, void *stream) {
+  DM_REQUIRE(param && grad && m && v && n > 0 && step >= 1, DM_ERR_BAD_SHAPE, "dm_adam_step: bad arguments");
+  const double bc1 = 1.0 - pow((double)beta1, (double)step);
+  const double bc2 = 1.0 - pow((double)beta2, (double)step);
+  const float step_size = (float)((double)lr / bc1);
+  const float bc2_sqrt = (float)sqrt(bc2);
+  hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n / 4 + 1)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), param, grad, m, v,
+                     (bf16_t *)param_lp, (long long)n, beta1, beta2, eps, step_size, bc2_sqrt, grad_scale);
+  DM_LAUNCH_CHECK("dm_adam_step");
+  return DM_OK;
+}
+
+extern "C" int dm_relpos_bias_gather(const float *table, const int32_t *index, float *bias, int32_t N, int32_t H,
+                                     int32_t n_bins, void *stream) {
+  DM_REQUIRE(table && index && bias && N > 0 && H > 0 && n_bins > 0, DM_ERR_BAD_SHAPE, "dm_relpos_bias_gather: bad arguments");
+  hipLaunchKernelGGL(relpos_gather_kernel, dim3(grid_for((long long)N * N)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), table, index, bias, N * N, H, n_bins);
+  DM_LAUNCH_CHECK("dm_relpos_bias_gather");
+  return DM_OK;
+}
+extern "C" int dm_relpos_bias_scatter(const float *slab, float *dtable, int32_t B, int32_t H, int32_t rows_per_bh,
+                                      int32_t n_bins, int32_t accumulate, void *stream) {
+  DM_REQUIRE(slab && dtable && B > 0 && H > 0 && rows_per_bh > 0 && n_bins > 0, DM_ERR_BAD_SHAPE, "dm_relpos_bias_scatter: bad arguments");
+  hipLaunchKernelGGL(relpos_scatter_kernel, dim3((n_bins + 255) / 256, H), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), slab, dtable, B, H, rows_per_bh, n_bins, accumulate);
+  DM_LAUNCH_CHECK("dm_relpos_bias_scatter");
+  return DM_OK;
+}

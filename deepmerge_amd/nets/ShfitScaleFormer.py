@@ -1,0 +1,310 @@
+"""MI355X-native drop-in for the reference module `nets/ShfitScaleFormer.py` (spelling is API).
+
+Same class names, constructor keywords, forward signatures, attributes (`name`, `depth`,
+`input_image_scales`, `cube_size`) and state_dict keys/shapes/dtypes as the reference, so reference
+checkpoints load strictly and `Train_SMT.py` / `ExtractFeatures.py` style callers work unchanged.
+All arithmetic runs in libdeepmerge_hip (hand-written gfx950 kernels) through `deepmerge_amd.ops`;
+the torch.nn.Linear / Conv / LayerNorm objects below are parameter containers only (they give the
+reference's key names and default initialisation) and their own forward() is never called.
+
+Additive keyword arguments (defaults keep reference behaviour): `in_c` (the reference hard-codes 3,
+nets/ShfitScaleFormer.py:809) and `numerics` ("bf16" throughput mode / "fp32" parity mode; default
+`deepmerge_amd.get_numerics()`).
+"""
+from __future__ import annotations
+
+import math
+from typing import List, Optional, Sequence
+
+import torch
+import torch.nn as nn
+
+from .. import ops
+
+__all__ = ["PatchEmbed", "Mlp", "FeatureEmbed", "CrossScaleAttention", "CrossScaleBlock", "ShfitScaleFormer_v3"]
+
+
+def _mode(numerics: Optional[str]) -> str:
+    m = numerics or ops.get_numerics()
+    if m not in ("bf16", "fp32"):
+        raise ValueError(f"numerics must be 'bf16' or 'fp32', got {m!r}")
+    return m
+
+
+def relative_position_index(cube: Sequence[int]) -> torch.Tensor:
+    """int64 [N,N] bias-table index of a (scales, rows, cols) token cube, tokens scale-major then
+    row-major: idx[i,j] = (zi-zj+S-1)(2H-1)(2W-1) + (yi-yj+H-1)(2W-1) + (xi-xj+W-1).
+    Same values as the buffer built at nets/ShfitScaleFormer.py:139-156 (pinned by tests/golden)."""
+    S, H, W = (int(c) for c in cube)
+    t = torch.arange(S * H * W)
+    z, y, x = t // (H * W), (t // W) % H, t % W
+    d = lambda a, n: a[:, None] - a[None, :] + (n - 1)
+    return (d(z, S) * ((2 * H - 1) * (2 * W - 1)) + d(y, H) * (2 * W - 1) + d(x, W)).to(torch.int64)
+
+
+class PatchEmbed(nn.Module):
+    """2-D image to patch tokens: Conv2d(k = stride = patch) -> [B, HW/p^2, out_c]
+    (reference :12-37).  Runs as patch extraction (dm_patchify) + one MFMA GEMM."""
+
+    def __init__(self, img_size=224, patch_size=16, in_c=3, out_c=768, norm_layer=None, numerics=None):
+        super().__init__()
+        self.img_size = (img_size, img_size)
+        self.patch_size = (patch_size, patch_size)
+        self.grid_size = (img_size // patch_size, img_size // patch_size)
+        self.num_patches = self.grid_size[0] * self.grid_size[1]
+        self.proj = nn.Conv2d(in_c, out_c, kernel_size=patch_size, stride=patch_size)
+        self.norm = norm_layer(out_c) if norm_layer else nn.Identity()
+        self.numerics = _mode(numerics)
+
+    def forward(self, x):
+        B, C, H, W = x.shape
+        assert H == self.img_size[0] and W == self.img_size[1], \
+            f"Input image size ({H}*{W}) doesn't match model ({self.img_size[0]}*{self.img_size[1]})."
+        cols = ops.patchify(x.float(), self.patch_size[0], ops.act_dtype(self.numerics))
+        y = ops.LinearFn.apply(cols, self.proj.weight, self.proj.bias, None, torch.float32)
+        return self.norm(y.view(B, self.num_patches, -1))
+
+
+class Mlp(nn.Module):
+    """fc2(GELU(fc1(x))) (reference :39-58); dropout is identity at the reference's drop=0."""
+
+    def __init__(self, in_features, hidden_features=None, out_features=None, act_layer=nn.GELU, drop=0., numerics=None):
+        super().__init__()
+        out_features = out_features or in_features
+        hidden_features = hidden_features or in_features
+        if act_layer is not nn.GELU:
+            raise ValueError("the fused MLP kernel implements nn.GELU (erf) only")
+        if drop != 0.:
+            raise ValueError("dropout > 0 is not part of the accelerated path (reference uses drop=0)")
+        self.fc1 = nn.Linear(in_features, hidden_features)
+        self.act = act_layer()
+        self.fc2 = nn.Linear(hidden_features, out_features)
+        self.drop = nn.Dropout(drop)
+        self.numerics = _mode(numerics)
+
+    def _run(self, x2d, residual2d, out_dtype):
+        return ops.MlpFn.apply(x2d, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias, residual2d, out_dtype)
+
+    def forward(self, x):
+        shp = x.shape
+        xin = _CastFn.apply(x.reshape(-1, shp[-1]), ops.act_dtype(self.numerics))
+        y = self._run(xin, None, torch.float32)
+        return y.view(*shp[:-1], y.shape[-1])
+
+
+class _CastFn(torch.autograd.Function):
+    """fp32 -> operand dtype with a pass-through gradient (module boundaries of standalone blocks)."""
+
+    @staticmethod
+    def forward(ctx, x, dtype):
+        return ops._as_operand(x, dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.float(), None
+
+
+class FeatureEmbed(nn.Module):
+    """Designed-feature embedding: three k=1 Conv1d with GELU after the first only (reference :60-82).
+    Always fp32: the 19 inputs are un-normalised physical quantities."""
+
+    def __init__(self, feature_size=19, embed_dim=768, act_layer=nn.GELU, norm_layer=None, numerics=None):
+        super().__init__()
+        self.proj0 = nn.Conv1d(feature_size, embed_dim, kernel_size=1, stride=1)
+        self.proj1 = nn.Conv1d(embed_dim, embed_dim, kernel_size=1, stride=1)
+        self.proj2 = nn.Conv1d(embed_dim, embed_dim, kernel_size=1, stride=1)
+        self.norm = norm_layer(embed_dim) if norm_layer else nn.Identity()
+        self.act = act_layer()
+        self.numerics = _mode(numerics)
+
+    def forward(self, x):
+        B, T, F = x.shape                                    # [B, 1, 19]
+        h = ops.MlpFn.apply(x.reshape(B * T, F).float(), self.proj0.weight, self.proj0.bias,
+                            self.proj1.weight, self.proj1.bias, None, torch.float32)
+        y = ops.LinearFn.apply(h, self.proj2.weight, self.proj2.bias, None, torch.float32)
+        return self.norm(y.view(B, T, -1))
+
+
+class CrossScaleAttention(nn.Module):
+    """Global attention over the 3-D token cube with a relative-position bias table (reference :84-156).
+    qkv and proj are MFMA GEMMs; the core (scale, QK^T, bias gather, softmax, PV) is one fused kernel."""
+
+    def __init__(self, dim, num_heads, cube_size, qkv_bias=False, qk_scale=None, attn_drop_ratio=0., proj_drop_ratio=0,
+                 numerics=None):
+        super().__init__()
+        if attn_drop_ratio != 0. or proj_drop_ratio != 0:
+            raise ValueError("dropout > 0 is not part of the accelerated path (reference uses 0)")
+        self.num_heads = num_heads
+        head_dim = dim // num_heads
+        self.scale = qk_scale or head_dim ** -0.5
+        self.qkv = nn.Linear(dim, dim * 3, bias=qkv_bias)
+        self.attn_drop = nn.Dropout(attn_drop_ratio)
+        self.proj = nn.Linear(dim, dim)
+        self.proj_drop = nn.Dropout(proj_drop_ratio)
+        self.cube_size = cube_size
+        rows = (2 * cube_size[0] - 1) * (2 * cube_size[1] - 1) * (2 * cube_size[2] - 1)
+        self.relative_position_bias_table = nn.Parameter(torch.zeros(rows, num_heads))
+        self.register_buffer("relative_position_index", relative_position_index(cube_size))
+        nn.init.trunc_normal_(self.relative_position_bias_table, std=.02)
+        self.numerics = _mode(numerics)
+        self._idx32 = None
+
+    def _index32(self) -> torch.Tensor:
+        src = self.relative_position_index
+        tag = (src.data_ptr(), src._version, src.device)
+        if self._idx32 is None or self._idx32[0] != tag:
+            self._idx32 = (tag, src.to(torch.int32).contiguous())
+        return self._idx32[1]
+
+    def _run(self, y, residual2d, out_dtype):
+        """y: [B, N, C] in the operand dtype.  Returns [B*N, C] = proj(attn(y)) (+ residual)."""
+        B, N, Cc = y.shape
+        H = self.num_heads
+        qkv = ops.LinearFn.apply(y.reshape(B * N, Cc), self.qkv.weight, self.qkv.bias, None, y.dtype)
+        o = ops.AttentionFn.apply(qkv, self.relative_position_bias_table, self._index32(), B, N, H, Cc // H, float(self.scale))
+        return ops.LinearFn.apply(o.reshape(B * N, Cc), self.proj.weight, self.proj.bias, residual2d, out_dtype)
+
+    def forward(self, x):
+        B_, N, Cc = x.shape
+        y = _CastFn.apply(x, ops.act_dtype(self.numerics))
+        return self._run(y, None, torch.float32).view(B_, N, Cc)
+
+
+class CrossScaleBlock(nn.Module):
+    """Pre-norm block x += attn(LN(x)); x += mlp(LN(x)) (reference :158-184).  The residual stream stays
+    fp32; both residual additions are fused into the proj / fc2 GEMM epilogues."""
+
+    def __init__(self, dim, num_heads, cube_size, mlp_ratio=4., qkv_bias=True, qk_scale=None, drop_ratio=0.,
+                 attn_drop_ratio=0., drop_path_ratio=0., act_layer=nn.GELU, norm_layer=nn.LayerNorm, numerics=None):
+        super().__init__()
+        if drop_path_ratio > 0.:
+            raise ValueError("stochastic depth is not part of the accelerated path (reference passes 0)")
+        self.numerics = _mode(numerics)
+        self.norm1 = norm_layer(dim)
+        self.attn = CrossScaleAttention(dim=dim, num_heads=num_heads, cube_size=cube_size, qkv_bias=qkv_bias,
+                                        qk_scale=qk_scale, attn_drop_ratio=attn_drop_ratio, proj_drop_ratio=drop_ratio,
+                                        numerics=self.numerics)
+        self.drop_path = nn.Identity()
+        self.norm2 = norm_layer(dim)
+        self.mlp = Mlp(in_features=dim, hidden_features=int(dim * mlp_ratio), act_layer=act_layer, drop=drop_ratio,
+                       numerics=self.numerics)
+
+    def forward(self, x):
+        B, N, Cc = x.shape
+        T = ops.act_dtype(self.numerics)
+        x = x.float()
+        y = ops.LayerNormFn.apply(x, self.norm1.weight, self.norm1.bias, self.norm1.eps, T)
+        x = self.attn._run(y, x.reshape(B * N, Cc), torch.float32).view(B, N, Cc)
+        y = ops.LayerNormFn.apply(x, self.norm2.weight, self.norm2.bias, self.norm2.eps, T)
+        x = self.mlp._run(y.reshape(B * N, Cc), x.reshape(B * N, Cc), torch.float32).view(B, N, Cc)
+        return x
+
+
+class ShfitScaleFormer_v3(nn.Module):
+    """Multi-scale Siamese encoder, the variant the reference trains and serves (reference :772-1010)."""
+
+    def __init__(self, num_classes=11, is_designed_feature_embedding=True, FeatureEmbed=FeatureEmbed, PatchEmbed=PatchEmbed,
+                 cube_size=[8, 8], input_image_scales=[32, 64, 128], embed_dim=768, depth=[6, 4, 2], num_heads=12,
+                 mlp_ratio=4.0, drop_path_ratio=0., drop_ratio=0., attn_drop_ratio=0., norm_layer=nn.LayerNorm,
+                 act_layer=nn.GELU, cuda=True, in_c=3, numerics=None):
+        super().__init__()
+        self.numerics = _mode(numerics)
+        self.name = "S2Former_v3-3CH" + ("-3DP-SEF" if is_designed_feature_embedding else "")
+        self.name = "{0}-{1}{2}{3}".format(self.name, depth[0], depth[1], depth[2])
+        self.num_classes = num_classes
+        self.is_designed_feature_embedding = is_designed_feature_embedding
+        self.patch_embed_layer, self.feature_embed_layer = PatchEmbed, FeatureEmbed
+        self.input_image_scales = input_image_scales
+        self.input_scales_num = S = len(input_image_scales)
+        self.cube_size = cube_size
+        self.cube_size.insert(0, S)          # the reference mutates the caller's list the same way (:804)
+        grid = self.cube_size[1]
+        self.num_features = int(S * embed_dim)
+        self.depth = depth
+        self.in_c = in_c
+        kw = {"numerics": self.numerics} if PatchEmbed is globals()["PatchEmbed"] else {}
+        self.patch_embed_blocks = nn.ModuleList(
+            [PatchEmbed(img_size=s, patch_size=int(s / grid), in_c=in_c, out_c=embed_dim, **kw) for s in input_image_scales])
+        self.feature_embed = FeatureEmbed(feature_size=19, embed_dim=embed_dim) if is_designed_feature_embedding else None
+
+        def stage(cube, n):
+            return nn.Sequential(*[CrossScaleBlock(dim=embed_dim, num_heads=num_heads, cube_size=cube, mlp_ratio=mlp_ratio,
+                                                   drop_ratio=drop_ratio, attn_drop_ratio=attn_drop_ratio, drop_path_ratio=0,
+                                                   norm_layer=norm_layer, act_layer=act_layer, numerics=self.numerics)
+                                   for _ in range(n)])
+        self.blocks0 = stage(self.cube_size, depth[0])
+        self.blocks1 = stage([S, grid // 2, grid // 2], depth[1])
+        self.blocks2 = stage([S, grid // 4, grid // 4], depth[2])
+        self.norm = norm_layer(embed_dim)
+        self.pos_drop = nn.Dropout(p=drop_ratio)
+        self.avgpool = nn.AdaptiveAvgPool1d(1)
+        self.final_features = nn.Linear(int(S * embed_dim), 100)
+        self.final_features_with_design = nn.Linear(int((S + 1) * embed_dim), 100)
+        self.head = nn.Linear(100, num_classes) if num_classes > 0 else nn.Identity()
+        self.avgpool2D = nn.AvgPool2d(kernel_size=2, stride=2)
+        self.apply(self._init_weights)
+
+    # -- pieces (public names as in the reference) ------------------------------------------------
+    def patch_embed(self, x: List[torch.Tensor]):
+        return torch.cat([layer(x[i]) for i, layer in enumerate(self.patch_embed_blocks)], 1)
+
+    def designed_feature_embed(self, x):
+        return self.feature_embed(x)
+
+    def _ln(self, x, out_dtype=torch.float32):
+        return ops.LayerNormFn.apply(x, self.norm.weight, self.norm.bias, self.norm.eps, out_dtype)
+
+    def backbone(self, x):
+        S, side = self.input_scales_num, self.cube_size[1]
+        x = self.blocks0(x)
+        x = self._ln(ops.TokenPoolFn.apply(x, S, side))
+        x = self.blocks1(x)
+        x = self._ln(ops.TokenPoolFn.apply(x, S, side // 2))
+        return self.blocks2(x)
+
+    def _pooled_tokens(self, x):
+        B = x.shape[0]
+        x = self._ln(self.backbone(self.pos_drop(self.patch_embed(x))))
+        g = x.shape[1] // self.input_scales_num
+        return ops.GroupMeanFn.apply(x, g).view(B, -1)
+
+    def forward_once_design_feature(self, x, designed_features):
+        x = self._pooled_tokens(x)
+        d = torch.squeeze(self.designed_feature_embed(designed_features), dim=1)
+        x = torch.cat((x, self._ln(d)), 1)
+        return ops.LinearFn.apply(x, self.final_features_with_design.weight, self.final_features_with_design.bias, None, torch.float32)
+
+    def forward_once(self, x):
+        x = self._pooled_tokens(x)
+        return ops.LinearFn.apply(x, self.final_features.weight, self.final_features.bias, None, torch.float32)
+
+    def extract_features_with_design_features(self, x_path, x_designed_features):
+        return self.forward_once_design_feature(x_path, x_designed_features)
+
+    def extract_features(self, x_path):
+        return self.forward_once(x_path)
+
+    def forward(self, x1_patches, x1_designed_features, x2_patches=None, x2_designed_features=None):
+        """Training mode returns (feature1, feature2); eval mode returns feature1 (reference :977-999).
+        Both sides share every weight and no op mixes samples, so they run as ONE batch of 2B."""
+        S = self.input_scales_num
+        if self.training:
+            B = x1_patches[0].shape[0]
+            both = [torch.cat((x1_patches[i], x2_patches[i]), 0) for i in range(S)]
+            if self.is_designed_feature_embedding:
+                f = self.forward_once_design_feature(both, torch.cat((x1_designed_features, x2_designed_features), 0))
+            else:
+                f = self.forward_once(both)
+            return f[:B], f[B:]
+        if self.is_designed_feature_embedding:
+            return self.forward_once_design_feature(x1_patches, x1_designed_features)
+        return self.forward_once(x1_patches)
+
+    def _init_weights(self, m):
+        if isinstance(m, nn.Linear):
+            nn.init.trunc_normal_(m.weight, std=.02)
+            if m.bias is not None:
+                nn.init.constant_(m.bias, 0)
+        elif isinstance(m, nn.LayerNorm):
+            nn.init.constant_(m.bias, 0)
+            nn.init.constant_(m.weight, 1.0)

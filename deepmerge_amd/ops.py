@@ -1,0 +1,440 @@
+"""Torch-facing wrappers over the C-ABI (include/deepmerge_hip.h).
+
+Two layers:
+  * `raw_*` / plain functions: validate tensors, pass device pointers + the current HIP stream to the
+    library.  PyTorch is only the allocator / stream provider here.
+  * `*Fn` autograd Functions: the forward/backward pairs the reference gets from torch autograd for
+    nn.Linear, nn.LayerNorm, the attention core, pooling and the loss (reference lines cited per
+    class), built from the raw calls.
+
+Numerics mode: "bf16" (throughput: bf16 operands/activations, fp32 accumulate, fp32 residual stream,
+LayerNorm statistics, softmax, loss and master weights) or "fp32" (parity: fp32 everywhere on the
+f32-input MFMA).  There is no CPU path: every function needs CUDA(HIP) tensors and the built library.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._lib import DM_BF16, DM_EPI_DGELU, DM_EPI_GELU, DM_EPI_NONE, DM_F32, DM_NN, DM_NT, DM_TN, DmGemmArgs, check
+
+_NUMERICS = "bf16"
+
+
+def set_numerics(mode: str) -> None:
+    """Default numerics mode for modules constructed afterwards ("bf16" or "fp32")."""
+    global _NUMERICS
+    if mode not in ("bf16", "fp32"):
+        raise ValueError(f"numerics must be 'bf16' or 'fp32', got {mode!r}")
+    _NUMERICS = mode
+
+
+def get_numerics() -> str:
+    return _NUMERICS
+
+
+def act_dtype(mode: str) -> torch.dtype:
+    return torch.bfloat16 if mode == "bf16" else torch.float32
+
+
+def _dt(t: torch.Tensor) -> int:
+    if t.dtype == torch.float32:
+        return DM_F32
+    if t.dtype == torch.bfloat16:
+        return DM_BF16
+    raise ValueError(f"unsupported dtype {t.dtype}")
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _need_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("deepmerge_amd ops need tensors on the GPU (there is no CPU fallback)")
+
+
+# ------------------------------------------------------------------------------------------------
+# workspace (grow-only scratch per device; stream-ordered reuse on the current stream)
+# ------------------------------------------------------------------------------------------------
+_ws = {}
+
+
+def workspace(nbytes: int, device, slot: str = "main") -> torch.Tensor:
+    key = (torch.device(device).index, slot)
+    buf = _ws.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        _ws[key] = buf
+    return buf
+
+
+# ------------------------------------------------------------------------------------------------
+# raw calls
+# ------------------------------------------------------------------------------------------------
+def gemm(layout: int, A: torch.Tensor, B: torch.Tensor, C_out: torch.Tensor, M: int, N: int, K: int, *,
+         lda: Optional[int] = None, ldb: Optional[int] = None, ldc: Optional[int] = None,
+         bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None, ldr: Optional[int] = None,
+         epilogue: int = DM_EPI_NONE, aux: Optional[torch.Tensor] = None, ldaux: Optional[int] = None,
+         accumulate: bool = False, split_k: int = 0, rows_per_group: int = 0, group_stride: int = 0) -> torch.Tensor:
+    """dm_gemm.  A/B/C are 2-D (or flat) row-major tensors; leading dims default to their last-dim size."""
+    _need_cuda(A, B, C_out, bias, residual, aux)
+    if A.dtype != B.dtype:
+        raise ValueError(f"A/B dtype mismatch: {A.dtype} vs {B.dtype}")
+    a = DmGemmArgs()
+    a.layout, a.ab_dtype, a.c_dtype = layout, _dt(A), _dt(C_out)
+    a.aux_dtype = _dt(aux) if aux is not None else DM_F32
+    a.M, a.N, a.K = M, N, K
+    a.epilogue, a.accumulate, a.split_k = epilogue, int(accumulate), split_k
+    a.A, a.lda = A.data_ptr(), (lda if lda is not None else A.stride(-2) if A.dim() >= 2 else K)
+    a.B, a.ldb = B.data_ptr(), (ldb if ldb is not None else B.stride(-2) if B.dim() >= 2 else K)
+    a.C, a.ldc = C_out.data_ptr(), (ldc if ldc is not None else N)
+    a.bias = _ptr(bias)
+    if bias is not None and (bias.dtype != torch.float32 or bias.numel() < N):
+        raise ValueError("bias must be fp32 with >= N elements")
+    a.residual, a.ldr = _ptr(residual), (ldr if ldr is not None else N)
+    if residual is not None and residual.dtype != torch.float32:
+        raise ValueError("residual must be fp32")
+    a.aux, a.ldaux = _ptr(aux), (ldaux if ldaux is not None else N)
+    a.rows_per_group, a.group_stride = rows_per_group, group_stride
+    ws_bytes = _lib.lib().dm_gemm_workspace_bytes(layout, M, N, K) if split_k != 1 else 0
+    if ws_bytes > 0:
+        ws = workspace(ws_bytes, A.device, "gemm")
+        a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
+    check(_lib.lib().dm_gemm(C.byref(a), _stream()), "dm_gemm")
+    return C_out
+
+
+def cast(src: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+    """fp32 -> activation dtype copy through dm_cast (identity object if already that dtype)."""
+    if src.dtype == dtype:
+        return src
+    _need_cuda(src)
+    if src.dtype != torch.float32:
+        raise ValueError("dm_cast source must be fp32")
+    src = src.contiguous()
+    dst = torch.empty(src.shape, dtype=dtype, device=src.device)
+    check(_lib.lib().dm_cast(src.data_ptr(), dst.data_ptr(), _dt(dst), src.numel(), _stream()), "dm_cast")
+    return dst
+
+
+def colsum(X: torch.Tensor, out: torch.Tensor, accumulate: bool = False) -> torch.Tensor:
+    _need_cuda(X, out)
+    M, N = X.shape
+    part = workspace(_lib.lib().dm_colsum_partial_floats(N) * 4, X.device, "partial")
+    check(_lib.lib().dm_colsum(X.data_ptr(), _dt(X), X.stride(0), out.data_ptr(), M, N, int(accumulate), part.data_ptr(), _stream()), "dm_colsum")
+    return out
+
+
+def layernorm_fwd(x: torch.Tensor, gamma, beta, eps: float, out_dtype: torch.dtype):
+    _need_cuda(x, gamma, beta)
+    rows, cols = x.numel() // x.shape[-1], x.shape[-1]
+    y = torch.empty(x.shape, dtype=out_dtype, device=x.device)
+    mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+    check(_lib.lib().dm_layernorm_fwd(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), _dt(y), mean.data_ptr(),
+                                      rstd.data_ptr(), rows, cols, eps, _stream()), "dm_layernorm_fwd")
+    return y, mean, rstd
+
+
+def layernorm_bwd(dy, x, gamma, mean, rstd, dres=None, dgamma=None, dbeta=None, accumulate=False):
+    _need_cuda(dy, x)
+    rows, cols = x.numel() // x.shape[-1], x.shape[-1]
+    dx = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    if dgamma is None:
+        dgamma = torch.empty(cols, dtype=torch.float32, device=x.device)
+        dbeta = torch.empty(cols, dtype=torch.float32, device=x.device)
+        accumulate = False
+    part = workspace(_lib.lib().dm_layernorm_bwd_partial_floats(cols) * 4, x.device, "partial")
+    check(_lib.lib().dm_layernorm_bwd(dy.data_ptr(), _dt(dy), x.data_ptr(), gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                      _ptr(dres), dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), int(accumulate),
+                                      part.data_ptr(), rows, cols, _stream()), "dm_layernorm_bwd")
+    return dx, dgamma, dbeta
+
+
+def relpos_bias_gather(table: torch.Tensor, index32: torch.Tensor, N: int) -> torch.Tensor:
+    _need_cuda(table, index32)
+    n_bins, H = table.shape
+    bias = torch.empty((H, N, N), dtype=torch.float32, device=table.device)
+    check(_lib.lib().dm_relpos_bias_gather(table.data_ptr(), index32.data_ptr(), bias.data_ptr(), N, H, n_bins, _stream()),
+          "dm_relpos_bias_gather")
+    return bias
+
+
+def attention_fwd(qkv: torch.Tensor, bias: Optional[torch.Tensor], B: int, N: int, H: int, D: int, scale: float):
+    _need_cuda(qkv, bias)
+    out = torch.empty((B, N, H * D), dtype=qkv.dtype, device=qkv.device)
+    lse = torch.empty((B, H, N), dtype=torch.float32, device=qkv.device)
+    check(_lib.lib().dm_attention_fwd(qkv.data_ptr(), _ptr(bias), out.data_ptr(), lse.data_ptr(), B, N, H, D, scale, _dt(qkv), _stream()),
+          "dm_attention_fwd")
+    return out, lse
+
+
+def attention_bwd(qkv, bias, out, dout, lse, B, N, H, D, scale, index32=None, n_bins=0):
+    _need_cuda(qkv, out, dout, lse)
+    dqkv = torch.empty_like(qkv)
+    delta = torch.empty((B, H, N), dtype=torch.float32, device=qkv.device)
+    slab = None
+    rows = _lib.lib().dm_attention_bwd_slab_rows(N)
+    if index32 is not None:
+        slab = torch.empty((B * H * rows, n_bins), dtype=torch.float32, device=qkv.device)
+    check(_lib.lib().dm_attention_bwd(qkv.data_ptr(), _ptr(bias), out.data_ptr(), dout.data_ptr(), lse.data_ptr(), dqkv.data_ptr(),
+                                      delta.data_ptr(), _ptr(index32), n_bins, _ptr(slab), B, N, H, D, scale, _dt(qkv), _stream()),
+          "dm_attention_bwd")
+    return dqkv, slab, rows
+
+
+def relpos_bias_scatter(slab, dtable, B, H, rows, n_bins, accumulate=False):
+    check(_lib.lib().dm_relpos_bias_scatter(slab.data_ptr(), dtable.data_ptr(), B, H, rows, n_bins, int(accumulate), _stream()),
+          "dm_relpos_bias_scatter")
+    return dtable
+
+
+def patchify(x: torch.Tensor, patch: int, dtype: torch.dtype) -> torch.Tensor:
+    _need_cuda(x)
+    B, Cc, H, W = x.shape
+    if H != W:
+        raise ValueError("square images only")
+    x = x.contiguous()
+    g = H // patch
+    cols = torch.empty((B * g * g, Cc * patch * patch), dtype=dtype, device=x.device)
+    check(_lib.lib().dm_patchify(x.data_ptr(), cols.data_ptr(), _dt(cols), B, Cc, H, patch, _stream()), "dm_patchify")
+    return cols
+
+
+def adam_step(param, grad, m, v, step, lr=1e-4, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0, param_lp=None):
+    _need_cuda(param, grad, m, v)
+    check(_lib.lib().dm_adam_step(param.data_ptr(), grad.data_ptr(), m.data_ptr(), v.data_ptr(), _ptr(param_lp), param.numel(), step,
+                                  lr, beta1, beta2, eps, grad_scale, _stream()), "dm_adam_step")
+
+
+def segment_mean(F: torch.Tensor, ptr: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
+    _need_cuda(F, ptr, idx)
+    S, D = ptr.numel() - 1, F.shape[1]
+    pooled = torch.empty((S, D), dtype=torch.float32, device=F.device)
+    check(_lib.lib().dm_segment_mean(F.data_ptr(), ptr.data_ptr(), idx.data_ptr(), pooled.data_ptr(), S, D, _stream()), "dm_segment_mean")
+    return pooled
+
+
+def edge_similarity(pooled: torch.Tensor, edges: torch.Tensor, margin: float = 1.0):
+    _need_cuda(pooled, edges)
+    E, D = edges.shape[0], pooled.shape[1]
+    simi = torch.empty(E, dtype=torch.float32, device=pooled.device)
+    merge = torch.empty(E, dtype=torch.uint8, device=pooled.device)
+    check(_lib.lib().dm_edge_similarity(pooled.data_ptr(), edges.data_ptr(), simi.data_ptr(), merge.data_ptr(), E, D, margin, _stream()),
+          "dm_edge_similarity")
+    return simi, merge
+
+
+# ------------------------------------------------------------------------------------------------
+# autograd Functions
+# ------------------------------------------------------------------------------------------------
+def _as_operand(t: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+    """Contiguous tensor in the MFMA operand dtype (fp32 -> bf16 goes through dm_cast)."""
+    t = t.contiguous()
+    if t.dtype == dtype:
+        return t
+    if t.dtype == torch.float32:
+        return cast(t, dtype)
+    raise ValueError(f"cannot use a {t.dtype} gradient with {dtype} operands")
+
+
+def _linear_backward(x, w, dy, need_dx, need_dw, need_db, wshape):
+    """dx = dy W (NN), dW = dy^T x (TN, split-K), db = column sums -- autograd of y = x W^T + b."""
+    M, K = x.shape
+    N = w.shape[0]
+    dx = dw = db = None
+    if need_dx:
+        dx = torch.empty((M, K), dtype=x.dtype, device=x.device)
+        gemm(DM_NN, dy, w, dx, M, K, N, lda=N, ldb=K, ldc=K)
+    if need_dw:
+        dw = torch.empty((N, K), dtype=torch.float32, device=x.device)
+        gemm(DM_TN, dy, x, dw, N, K, M, lda=N, ldb=K, ldc=K)
+        dw = dw.reshape(wshape)
+    if need_db:
+        db = torch.empty(N, dtype=torch.float32, device=x.device)
+        colsum(dy, db)
+    return dx, dw, db
+
+
+class LinearFn(torch.autograd.Function):
+    """y = x W^T + b [+ residual]  (nn.Linear / k=1 Conv1d / patch Conv2d after patchify;
+    nets/ShfitScaleFormer.py:35, :76-79, :119, :134, :948).
+
+    x [M,K] in the operand dtype; weight is the fp32 master [N,K,...]; residual fp32 [M,N] or None.
+    """
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, residual, out_dtype):
+        x = x.contiguous()
+        M, K = x.shape
+        N = weight.shape[0]
+        w = cast(weight.reshape(N, K), x.dtype)
+        y = torch.empty((M, N), dtype=out_dtype, device=x.device)
+        gemm(DM_NT, x, w, y, M, N, K, lda=K, ldb=K, ldc=N, bias=bias,
+             residual=None if residual is None else residual.contiguous())
+        ctx.save_for_backward(x, w)
+        ctx.has_bias, ctx.wshape = bias is not None, weight.shape
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dres = dy if ctx.needs_input_grad[3] else None
+        dyo = _as_operand(dy, x.dtype)
+        dx, dw, db = _linear_backward(x, w, dyo, ctx.needs_input_grad[0], ctx.needs_input_grad[1],
+                                      ctx.has_bias and ctx.needs_input_grad[2], ctx.wshape)
+        return dx, dw, db, dres, None
+
+
+class MlpFn(torch.autograd.Function):
+    """y = fc2(GELU_erf(fc1(x))) [+ residual]  (Mlp, nets/ShfitScaleFormer.py:52-58; also the
+    proj0 -> GELU -> proj1 head of FeatureEmbed, :76-78).  GELU is fused into fc1's epilogue and its
+    derivative into the epilogue of fc2's dgrad."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, residual, out_dtype):
+        x = x.contiguous()
+        M, K = x.shape
+        Hd, N = w1.shape[0], w2.shape[0]
+        w1c = cast(w1.reshape(Hd, K), x.dtype)
+        w2c = cast(w2.reshape(N, Hd), x.dtype)
+        pre = torch.empty((M, Hd), dtype=x.dtype, device=x.device)
+        h = torch.empty((M, Hd), dtype=x.dtype, device=x.device)
+        gemm(DM_NT, x, w1c, h, M, Hd, K, lda=K, ldb=K, ldc=Hd, bias=b1, epilogue=DM_EPI_GELU, aux=pre, ldaux=Hd)
+        y = torch.empty((M, N), dtype=out_dtype, device=x.device)
+        gemm(DM_NT, h, w2c, y, M, N, Hd, lda=Hd, ldb=Hd, ldc=N, bias=b2,
+             residual=None if residual is None else residual.contiguous())
+        ctx.save_for_backward(x, w1c, w2c, pre, h)
+        ctx.shapes = (w1.shape, w2.shape)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w1c, w2c, pre, h = ctx.saved_tensors
+        M, K = x.shape
+        Hd, N = w1c.shape[0], w2c.shape[0]
+        need = ctx.needs_input_grad
+        dres = dy if need[5] else None
+        dyo = _as_operand(dy, x.dtype)
+        # fc2: dW2 = dy^T h, db2 = colsum(dy); dpre = (dy W2) * gelu'(pre)  (DGELU epilogue)
+        _, dw2, db2 = _linear_backward(h, w2c, dyo, False, need[3], need[4], ctx.shapes[1])
+        dpre = torch.empty((M, Hd), dtype=x.dtype, device=x.device)
+        gemm(DM_NN, dyo, w2c, dpre, M, Hd, N, lda=N, ldb=Hd, ldc=Hd, epilogue=DM_EPI_DGELU, aux=pre, ldaux=Hd)
+        dx, dw1, db1 = _linear_backward(x, w1c, dpre, need[0], need[1], need[2], ctx.shapes[0])
+        return dx, dw1, db1, dw2, db2, dres, None
+
+
+class LayerNormFn(torch.autograd.Function):
+    """nn.LayerNorm over the last dim, fp32 in, `out_dtype` out (nets/ShfitScaleFormer.py:173, :177, :856)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps, out_dtype):
+        x = x.contiguous()
+        y, mean, rstd = layernorm_fwd(x, gamma, beta, eps, out_dtype)
+        ctx.save_for_backward(x, gamma, mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, mean, rstd = ctx.saved_tensors
+        dx, dg, db = layernorm_bwd(dy.contiguous(), x, gamma, mean, rstd)
+        return dx, dg, db, None, None
+
+
+class AttentionFn(torch.autograd.Function):
+    """softmax(scale * q k^T + table[index]) v over [B, N, 3, H, D] packed qkv
+    (nets/ShfitScaleFormer.py:119-133; table/index None -> vit_model.py:119-133)."""
+
+    @staticmethod
+    def forward(ctx, qkv, table, index32, B, N, H, D, scale):
+        qkv = qkv.contiguous()
+        bias = relpos_bias_gather(table.contiguous(), index32, N) if table is not None else None
+        out, lse = attention_fwd(qkv, bias, B, N, H, D, scale)
+        ctx.save_for_backward(qkv, out, lse, bias, index32)
+        ctx.dims = (B, N, H, D, scale, None if table is None else table.shape[0])
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        qkv, out, lse, bias, index32 = ctx.saved_tensors
+        B, N, H, D, scale, n_bins = ctx.dims
+        want_table = bias is not None and ctx.needs_input_grad[1]
+        dqkv, slab, rows = attention_bwd(qkv, bias, out, _as_operand(dout, qkv.dtype), lse, B, N, H, D, scale,
+                                         index32 if want_table else None, n_bins or 0)
+        dtable = None
+        if want_table:
+            dtable = torch.empty((n_bins, H), dtype=torch.float32, device=qkv.device)
+            relpos_bias_scatter(slab, dtable, B, H, rows, n_bins)
+        return dqkv, dtable, None, None, None, None, None, None
+
+
+class TokenPoolFn(torch.autograd.Function):
+    """Per-scale AvgPool2d(2,2) over the token grid (nets/ShfitScaleFormer.py:892-901, :905-914)."""
+
+    @staticmethod
+    def forward(ctx, x, S, side):
+        x = x.contiguous()
+        B, N, Cc = x.shape
+        y = torch.empty((B, S * (side // 2) ** 2, Cc), dtype=torch.float32, device=x.device)
+        check(_lib.lib().dm_token_pool_fwd(x.data_ptr(), y.data_ptr(), B, S, side, Cc, _stream()), "dm_token_pool_fwd")
+        ctx.dims = (B, S, side, Cc)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, S, side, Cc = ctx.dims
+        dy = dy.contiguous()
+        dx = torch.empty((B, S * side * side, Cc), dtype=torch.float32, device=dy.device)
+        check(_lib.lib().dm_token_pool_bwd(dy.data_ptr(), dx.data_ptr(), B, S, side, Cc, _stream()), "dm_token_pool_bwd")
+        return dx, None, None
+
+
+class GroupMeanFn(torch.autograd.Function):
+    """Mean over groups of g consecutive tokens (AdaptiveAvgPool1d(1) per scale, :930-938)."""
+
+    @staticmethod
+    def forward(ctx, x, g):
+        x = x.contiguous()
+        rows, Cc = x.numel() // (x.shape[-1] * g), x.shape[-1]
+        y = torch.empty((rows, Cc), dtype=torch.float32, device=x.device)
+        check(_lib.lib().dm_group_mean_fwd(x.data_ptr(), y.data_ptr(), rows, g, Cc, _stream()), "dm_group_mean_fwd")
+        ctx.dims = (rows, g, Cc, x.shape)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        rows, g, Cc, xshape = ctx.dims
+        dy = dy.contiguous()
+        dx = torch.empty(xshape, dtype=torch.float32, device=dy.device)
+        check(_lib.lib().dm_group_mean_bwd(dy.data_ptr(), dx.data_ptr(), rows, g, Cc, _stream()), "dm_group_mean_bwd")
+        return dx, None
+
+
+class ContrastiveLossFn(torch.autograd.Function):
+    """Losses.py:34-38 forward and its gradient in one kernel."""
+
+    @staticmethod
+    def forward(ctx, a, b, flag, margin):
+        a, b = a.contiguous(), b.contiguous()
+        B, D = a.shape
+        flag = flag.to(torch.float32).contiguous()
+        loss = torch.empty(1, dtype=torch.float32, device=a.device)
+        da, db = torch.empty_like(a), torch.empty_like(b)
+        check(_lib.lib().dm_contrastive_loss(a.data_ptr(), b.data_ptr(), flag.data_ptr(), margin, 1.0, loss.data_ptr(),
+                                             da.data_ptr(), db.data_ptr(), B, D, _stream()), "dm_contrastive_loss")
+        ctx.save_for_backward(da, db)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        da, db = ctx.saved_tensors
+        return da * g, db * g, None, None

@@ -1,0 +1,191 @@
+/*
+ * deepmerge_hip.h -- C-ABI of libdeepmerge_hip.so, the MI355X (gfx950) kernels behind the
+ * DeepMerge pair-encoder hot path.
+ *
+ * The reference (lvxianwei/DeepMerge) has NO native/FFI boundary: the path sits behind plain
+ * Python torch.nn.Module classes that call stock torch ops.  Each entry point below therefore
+ * cites the reference *Python* statement(s) whose arithmetic it replaces (file:line relative to
+ * the reference tree); INTEGRATION.md shows the ctypes binding and the module-level drop-in.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer into caller-owned memory (torch storage); the library
+ *     never allocates, frees or retains memory and never synchronises the device;
+ *   - every call enqueues on the caller's `stream` (hipStream_t passed as void*; NULL = default);
+ *   - return value: 0 on success, negative DmStatus otherwise; dm_last_error() gives a
+ *     thread-local message; no C++ exception crosses the boundary;
+ *   - `dtype` arguments take DmDtype; "T" below means the activation type of the numerics mode:
+ *     DM_BF16 (throughput mode: bf16 operands, fp32 accumulate) or DM_F32 (parity mode: fp32
+ *     operands on the f32-input MFMA, bit-equivalent to an fmaf chain);
+ *   - all matrices are row-major with an explicit leading dimension in ELEMENTS.
+ */
+#ifndef DEEPMERGE_HIP_H
+#define DEEPMERGE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum { DM_F32 = 0, DM_BF16 = 1 } DmDtype;
+
+typedef enum {
+  DM_OK = 0,
+  DM_ERR_BAD_SHAPE = -1,
+  DM_ERR_BAD_DTYPE = -2,
+  DM_ERR_BAD_ALIGN = -3,
+  DM_ERR_WORKSPACE = -4,
+  DM_ERR_HIP = -5,
+  DM_ERR_UNSUPPORTED = -6
+} DmStatus;
+
+/* ---- library ------------------------------------------------------------------------- */
+int dm_abi_version(void);
+const char *dm_last_error(void);
+/* Name of the code object architecture the library was built for ("gfx950"). */
+const char *dm_arch(void);
+
+/* ---- GEMM family (MFMA, LDS-staged 128x128 tiles) ---------------------------------------
+ * Replaces every nn.Linear / k=stride Conv2d / k=1 Conv1d on the path and their autograd:
+ *   qkv, proj        nets/ShfitScaleFormer.py:119, :134        (vit_model.py:119, :133)
+ *   fc1, fc2         nets/ShfitScaleFormer.py:53, :56          (vit_model.py:152-156)
+ *   PatchEmbed.proj  nets/ShfitScaleFormer.py:35               (after dm_patchify)
+ *   FeatureEmbed     nets/ShfitScaleFormer.py:76-79, final Linear :948 / :967
+ * layout: DM_NT  C[m,n] = sum_k A[m,k] * B[n,k]   (forward  y = x W^T,  W = [out,in])
+ *         DM_NN  C[m,n] = sum_k A[m,k] * B[k,n]   (dgrad    dx = dy W)
+ *         DM_TN  C[m,n] = sum_k A[k,m] * B[k,n]   (wgrad    dW = dy^T x)
+ * epilogue, applied in this order on the fp32 accumulator v of element (m,n):
+ *   v += bias[n]                     if bias != NULL
+ *   aux[m,n] = v (as aux_dtype)      if epilogue == DM_EPI_GELU     (pre-activation saved for backward)
+ *   v  = gelu_erf(v)                 if epilogue == DM_EPI_GELU     (nn.GELU, erf form)
+ *   v *= gelu_erf'(aux[m,n])         if epilogue == DM_EPI_DGELU    (backward through GELU)
+ *   v += residual[m,n]               if residual != NULL (fp32)
+ *   v += C_old[m,n]                  if accumulate (C must be fp32)
+ *   C[m,n] = v (as c_dtype)
+ * split_k > 1 (DM_TN only): the contraction is cut into split_k slices whose fp32 partial tiles
+ * go to `workspace` ([split_k, M, N] floats) and are summed deterministically by a second
+ * kernel that applies the epilogue.  split_k == 0 lets the library choose.
+ */
+typedef enum { DM_NT = 0, DM_NN = 1, DM_TN = 2 } DmGemmLayout;
+typedef enum { DM_EPI_NONE = 0, DM_EPI_GELU = 1, DM_EPI_DGELU = 2 } DmEpilogue;
+
+typedef struct {
+  int32_t layout;        /* DmGemmLayout */
+  int32_t ab_dtype;      /* DmDtype of A and B */
+  int32_t c_dtype;       /* DmDtype of C */
+  int32_t aux_dtype;     /* DmDtype of aux */
+  int32_t M, N, K;
+  int32_t epilogue;      /* DmEpilogue */
+  int32_t accumulate;    /* 0/1 */
+  int32_t split_k;       /* 0 = auto, 1 = none */
+  const void *A; int64_t lda;
+  const void *B; int64_t ldb;
+  void *C; int64_t ldc;
+  const float *bias;                     /* [N] or NULL */
+  const float *residual; int64_t ldr;    /* [M,N] fp32 or NULL */
+  void *aux; int64_t ldaux;              /* see epilogue */
+  /* Optional two-level row addressing of C / residual / aux: row m lives at
+   * (m / rows_per_group) * group_stride + (m % rows_per_group) * ld.  rows_per_group == 0: plain.
+   * Used to write each scale's 64 patch tokens into its slice of the token cube (torch.cat at
+   * nets/ShfitScaleFormer.py:877). */
+  int32_t rows_per_group; int64_t group_stride;
+  void *workspace; int64_t workspace_bytes;
+} DmGemmArgs;
+
+int dm_gemm(const DmGemmArgs *args, void *stream);
+/* Bytes of workspace dm_gemm may use for these dimensions (upper bound over split_k choices). */
+int64_t dm_gemm_workspace_bytes(int32_t layout, int32_t M, int32_t N, int32_t K);
+
+/* ---- fused attention with 3-D relative-position bias -------------------------------------
+ * Replaces nets/ShfitScaleFormer.py:119-133 (reshape/permute, q*scale, q@k^T, bias add, softmax,
+ * attn@v, transpose/reshape) and vit_model.py:119-133 (bias == NULL; the scale 64^-0.5 = 2^-3 is
+ * exact, so applying it before or after q@k^T is bit-identical).
+ *   qkv   [B, N, 3, H, D]  T   (output of the qkv Linear; D = 64)
+ *   bias  [H, N, N] fp32 or NULL  (dense, from dm_relpos_bias_gather)
+ *   out   [B, N, H*D]      T
+ *   lse   [B, H, N] fp32   row log-sum-exp of the biased scores (saved for backward)
+ */
+int dm_attention_fwd(const void *qkv, const float *bias, void *out, float *lse,
+                     int32_t B, int32_t N, int32_t H, int32_t D, float scale, int32_t dtype, void *stream);
+/* Backward: dqkv [B,N,3,H,D] T (fully written).  If index != NULL, the gradient of the bias is
+ * binned on the fly: dtable_slab[(b*H+h)*n_qblk + qblk][bin] = sum of dS over (i,j) with
+ * index[i,j] == bin (int32 [N,N], values < n_bins), fp32, fully written; reduce it with
+ * dm_relpos_bias_scatter.  delta is a [B,H,N] fp32 scratch. */
+int dm_attention_bwd(const void *qkv, const float *bias, const void *out, const void *dout, const float *lse,
+                     void *dqkv, float *delta, const int32_t *index, int32_t n_bins, float *dtable_slab,
+                     int32_t B, int32_t N, int32_t H, int32_t D, float scale, int32_t dtype, void *stream);
+/* Number of slab rows per (b,h) that dm_attention_bwd writes (query blocks of 64 rows). */
+int32_t dm_attention_bwd_slab_rows(int32_t N);
+
+/* relative_position_bias_table[index.view(-1)].view(N,N,H).permute(2,0,1)
+ * (nets/ShfitScaleFormer.py:123-128): table [n_bins,H] fp32, index int32 [N,N] -> bias [H,N,N]. */
+int dm_relpos_bias_gather(const float *table, const int32_t *index, float *bias,
+                          int32_t N, int32_t H, int32_t n_bins, void *stream);
+/* Autograd of that gather: dtable[bin,h] (+)= sum over slab rows r (r = (b*H+h)*rows_per_bh + q)
+ * of slab[r][bin]. */
+int dm_relpos_bias_scatter(const float *slab, float *dtable, int32_t B, int32_t H, int32_t rows_per_bh,
+                           int32_t n_bins, int32_t accumulate, void *stream);
+
+/* ---- row kernels (HBM-bound) ------------------------------------------------------------ */
+/* nn.LayerNorm over the last dim (nets/ShfitScaleFormer.py:182-183, :902, :915, :926, :941;
+ * vit_model.py:183-184, :498): x [rows, cols] fp32 -> y (y_dtype), saving mean / rstd [rows]. */
+int dm_layernorm_fwd(const float *x, const float *gamma, const float *beta, void *y, int32_t y_dtype,
+                     float *mean, float *rstd, int32_t rows, int32_t cols, float eps, void *stream);
+/* dx = (dres ? dres : 0) + LN'(dy); dgamma/dbeta (+)= column sums.  partial: fp32 scratch of
+ * dm_layernorm_bwd_partial_floats(cols) floats. */
+int dm_layernorm_bwd(const void *dy, int32_t dy_dtype, const float *x, const float *gamma,
+                     const float *mean, const float *rstd, const float *dres, float *dx,
+                     float *dgamma, float *dbeta, int32_t accumulate_params, float *partial,
+                     int32_t rows, int32_t cols, void *stream);
+int64_t dm_layernorm_bwd_partial_floats(int32_t cols);
+
+/* Per-scale 2x2 average pooling of the token grid (AvgPool2d(2,2) on [B,C,side,side] views,
+ * nets/ShfitScaleFormer.py:892-901, :905-914): x [B, S*side*side, C] -> y [B, S*(side/2)^2, C], fp32. */
+int dm_token_pool_fwd(const float *x, float *y, int32_t B, int32_t S, int32_t side, int32_t C, void *stream);
+int dm_token_pool_bwd(const float *dy, float *dx, int32_t B, int32_t S, int32_t side, int32_t C, void *stream);
+/* Mean over groups of `g` consecutive rows (AdaptiveAvgPool1d(1) per scale, :930-938):
+ * x [rows*g, C] -> y [rows, C]; backward broadcasts dy/g. */
+int dm_group_mean_fwd(const float *x, float *y, int32_t rows, int32_t g, int32_t C, void *stream);
+int dm_group_mean_bwd(const float *dy, float *dx, int32_t rows, int32_t g, int32_t C, void *stream);
+
+/* out[n] (+)= sum_m X[m,n]  (bias gradients).  partial: dm_colsum_partial_floats(N) floats. */
+int dm_colsum(const void *X, int32_t dtype, int64_t ldx, float *out, int32_t M, int32_t N,
+              int32_t accumulate, float *partial, void *stream);
+int64_t dm_colsum_partial_floats(int32_t N);
+
+/* fp32 -> T element-wise copy (weights / activations), n elements. */
+int dm_cast(const float *src, void *dst, int32_t dst_dtype, int64_t n, void *stream);
+
+/* Patch extraction for the k=stride Conv2d of PatchEmbed (nets/ShfitScaleFormer.py:25, :35):
+ * x [B, C, side, side] fp32 -> cols [B*(side/p)^2, C*p*p] T, column order (c, dy, dx) = the
+ * conv weight's [out, C, p, p] flattening, row order (b, py, px) = flatten(2).transpose(1,2). */
+int dm_patchify(const float *x, void *cols, int32_t dtype, int32_t B, int32_t C, int32_t side, int32_t p, void *stream);
+
+/* ---- loss / optimiser -------------------------------------------------------------------- */
+/* Losses.py:34-38: d = sum((a-b)^2, 1); l = flag*d + (1-flag)*relu(margin-d); loss = mean(l).
+ * Writes loss[0], and (if da/db != NULL) da = upstream*dloss/da, db likewise.  flag: fp32 [B]. */
+int dm_contrastive_loss(const float *a, const float *b, const float *flag, float margin, float upstream,
+                        float *loss, float *da, float *db, int32_t B, int32_t D, void *stream);
+
+/* torch.optim.Adam single step over a flat fp32 buffer (Train_SMT.py:192-193, :300): in-place on
+ * param/m/v; `step` is 1-based; if param_lp != NULL also writes the bf16 copy of the new weights.
+ * grad_scale multiplies the gradient first (1/world_size after an RCCL sum all-reduce). */
+int dm_adam_step(float *param, const float *grad, float *m, float *v, void *param_lp, int64_t n,
+                 int32_t step, float lr, float beta1, float beta2, float eps, float grad_scale, void *stream);
+
+/* ---- ExtractFeatures sweep ---------------------------------------------------------------- */
+/* Per-superpixel mean pooling (ExtractFeatures.py:190-212): F [P,D] fp32, CSR ptr[S+1] / idx[*]
+ * (int32) -> pooled [S,D]; rows are added in idx order then divided by the count (np.mean axis 0). */
+int dm_segment_mean(const float *F, const int32_t *ptr, const int32_t *idx, float *pooled,
+                    int32_t S, int32_t D, void *stream);
+/* Per-edge distance (ExtractFeatures.py:139-147, :215-216): simi[e] = sqrt(max(0, |a|^2+|b|^2-2a.b))
+ * for a = pooled[L], b = pooled[R]; edges int32 [E,2]; an edge with L == -1 or R == -1 yields NaN and
+ * merge 0 (MyUtils2.py:184-186 skips them).  merge[e] = simi[e] < margin (uint8), may be NULL.
+ * Summation order is fixed and documented in oracle/sweep_strict.c (bit-exact contract). */
+int dm_edge_similarity(const float *pooled, const int32_t *edges, float *simi, uint8_t *merge,
+                       int32_t E, int32_t D, float margin, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DEEPMERGE_HIP_H */

@@ -1,0 +1,307 @@
+"""GPU: kernel-level parity through the C-ABI (deepmerge_amd.ops -> libdeepmerge_hip.so).
+
+GEMM / attention layouts are first checked with small-integer data, for which bf16 and fp32 MFMA
+results are EXACT, so any lane/fragment/swizzle mistake shows up as a bit mismatch; then with random
+data against the CPU oracle (numpy / torch fp32) at the tolerances of SURVEY 8d.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+def _ops():
+    from deepmerge_amd import ops
+    return ops
+
+
+def _ints(rng, shape, lo=-3, hi=4):
+    return torch.from_numpy(rng.integers(lo, hi, size=shape).astype(np.float32))
+
+
+DT = {"fp32": torch.float32, "bf16": torch.bfloat16}
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+@pytest.mark.parametrize("layout", ["NT", "NN", "TN"])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 192), (200, 136, 72), (16, 768, 768), (1000, 100, 3840), (64, 2304, 768)])
+def test_gemm_exact_integers(mode, layout, M, N, K):
+    ops = _ops()
+    from deepmerge_amd._lib import DM_NN, DM_NT, DM_TN
+    rng = np.random.default_rng(M * 7 + N * 3 + K)
+    a = _ints(rng, (M, K))
+    b = _ints(rng, (N, K))
+    want = a.double() @ b.double().T
+    dt = DT[mode]
+    if mode == "bf16" and layout != "NT" and N % 8 != 0:
+        pytest.skip("bf16 n-contiguous operands need N % 8 == 0 (the model's N = 100 head runs in fp32)")
+    if layout == "NT":
+        A, B_, lay = a, b, DM_NT
+    elif layout == "NN":
+        A, B_, lay = a, b.T.contiguous(), DM_NN
+    else:
+        A, B_, lay = a.T.contiguous(), b.T.contiguous(), DM_TN
+    A, B_ = A.to(DEV).to(dt), B_.to(DEV).to(dt)
+    Cc = torch.full((M, N), float("nan"), device=DEV)
+    ops.gemm(lay, A, B_, Cc, M, N, K, lda=A.shape[1], ldb=B_.shape[1], ldc=N)
+    got = Cc.cpu().double()
+    assert torch.equal(got, want), f"max diff {(got - want).abs().max()}"
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+def test_gemm_epilogues(mode):
+    """bias, GELU (+saved pre-activation), DGELU, residual, accumulate, bf16 output, grouped rows."""
+    ops = _ops()
+    from deepmerge_amd._lib import DM_EPI_DGELU, DM_EPI_GELU, DM_NN, DM_NT
+    rng = np.random.default_rng(5)
+    M, N, K = 192, 256, 128
+    dt = DT[mode]
+    a, b = _ints(rng, (M, K), -2, 3), _ints(rng, (N, K), -2, 3)
+    bias = torch.from_numpy(rng.normal(size=N).astype(np.float32))
+    res = torch.from_numpy(rng.normal(size=(M, N)).astype(np.float32))
+    base = (a.double() @ b.double().T) * 0.03125
+    a = a * 0.03125   # exact in bf16
+    A, B_ = a.to(DEV).to(dt), b.to(DEV).to(dt)
+    # bias + residual, fp32 out
+    out = torch.empty((M, N), device=DEV)
+    ops.gemm(DM_NT, A, B_, out, M, N, K, lda=K, ldb=K, ldc=N, bias=bias.to(DEV), residual=res.to(DEV))
+    np.testing.assert_allclose(out.cpu().double().numpy(), (base + bias.double() + res.double()).numpy(), rtol=0, atol=2e-6)
+    # GELU with saved pre-activation
+    pre = torch.empty((M, N), device=DEV, dtype=dt)
+    h = torch.empty((M, N), device=DEV, dtype=dt)
+    ops.gemm(DM_NT, A, B_, h, M, N, K, lda=K, ldb=K, ldc=N, bias=bias.to(DEV), epilogue=DM_EPI_GELU, aux=pre, ldaux=N)
+    u = (base + bias.double())
+    tol = 1e-5 if mode == "fp32" else 1.6e-2
+    np.testing.assert_allclose(pre.float().cpu().double().numpy(), u.numpy(), rtol=tol, atol=tol)
+    np.testing.assert_allclose(h.float().cpu().double().numpy(), torch.nn.functional.gelu(u).numpy(), rtol=tol, atol=tol)
+    # DGELU epilogue: out = (A B^T) * gelu'(aux)
+    aux = torch.from_numpy(rng.normal(size=(M, N)).astype(np.float32))
+    out2 = torch.empty((M, N), device=DEV)
+    ops.gemm(DM_NT, A, B_, out2, M, N, K, lda=K, ldb=K, ldc=N, epilogue=DM_EPI_DGELU, aux=aux.to(DEV), ldaux=N)
+    x = aux.double().requires_grad_(True)
+    torch.nn.functional.gelu(x).sum().backward()
+    np.testing.assert_allclose(out2.cpu().double().numpy(), (base * x.grad).numpy(), rtol=1e-5, atol=1e-5)
+    # accumulate
+    out3 = res.clone().to(DEV)
+    ops.gemm(DM_NT, A, B_, out3, M, N, K, lda=K, ldb=K, ldc=N, accumulate=True)
+    np.testing.assert_allclose(out3.cpu().double().numpy(), (base + res.double()).numpy(), rtol=0, atol=2e-6)
+    # grouped rows: groups of 64 rows land in slices of a [3, 100, N] cube at token offset 36
+    cube = torch.zeros((3, 100, N), device=DEV)
+    ops.gemm(DM_NT, A, B_, cube[:, 36:], M, N, K, lda=K, ldb=K, ldc=N, rows_per_group=64, group_stride=100 * N)
+    np.testing.assert_allclose(cube[:, 36:].cpu().double().numpy().reshape(M, N), base.numpy(), rtol=0, atol=2e-6)
+    assert float(cube[:, :36].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+@pytest.mark.parametrize("Mrows,N,K", [(16384, 768, 768), (4096, 2304, 768), (777 * 8, 768, 3072)])
+def test_gemm_wgrad_split_k(mode, Mrows, N, K):
+    """TN with automatic split-K + deterministic slab reduction, accumulate into an existing gradient."""
+    ops = _ops()
+    from deepmerge_amd._lib import DM_TN
+    rng = np.random.default_rng(11)
+    dt = DT[mode]
+    dy = _ints(rng, (Mrows, N), -1, 2)
+    x = _ints(rng, (Mrows, K), -1, 2)
+    g0 = torch.from_numpy(rng.integers(-5, 6, size=(N, K)).astype(np.float32))
+    want = g0.double() + dy.double().T @ x.double()
+    G = g0.clone().to(DEV)
+    ops.gemm(DM_TN, dy.to(DEV).to(dt), x.to(DEV).to(dt), G, N, K, Mrows, lda=N, ldb=K, ldc=K, accumulate=True)
+    assert torch.equal(G.cpu().double(), want)
+    G2 = g0.clone().to(DEV)
+    ops.gemm(DM_TN, dy.to(DEV).to(dt), x.to(DEV).to(dt), G2, N, K, Mrows, lda=N, ldb=K, ldc=K, accumulate=True)
+    assert torch.equal(G, G2), "split-K reduction must be run-to-run deterministic"
+
+
+def test_gemm_generic_fp32_odd_shapes():
+    ops = _ops()
+    from deepmerge_amd._lib import DM_NN, DM_NT, DM_TN
+    rng = np.random.default_rng(3)
+    M, N, K = 37, 768, 19
+    a = torch.from_numpy(rng.normal(size=(M, K)).astype(np.float32))
+    b = torch.from_numpy(rng.normal(size=(N, K)).astype(np.float32))
+    bias = torch.from_numpy(rng.normal(size=N).astype(np.float32))
+    out = torch.empty((M, N), device=DEV)
+    ops.gemm(DM_NT, a.to(DEV), b.to(DEV), out, M, N, K, lda=K, ldb=K, ldc=N, bias=bias.to(DEV))
+    np.testing.assert_allclose(out.cpu().numpy(), (a.double() @ b.double().T + bias.double()).numpy(), rtol=1e-5, atol=1e-5)
+    dy = torch.from_numpy(rng.normal(size=(M, N)).astype(np.float32))
+    dx = torch.empty((M, K), device=DEV)
+    ops.gemm(DM_NN, dy.to(DEV), b.to(DEV), dx, M, K, N, lda=N, ldb=K, ldc=K)
+    np.testing.assert_allclose(dx.cpu().numpy(), (dy.double() @ b.double()).numpy(), rtol=1e-4, atol=1e-4)
+    dw = torch.empty((N, K), device=DEV)
+    ops.gemm(DM_TN, dy.to(DEV), a.to(DEV), dw, N, K, M, lda=N, ldb=K, ldc=K)
+    np.testing.assert_allclose(dw.cpu().numpy(), (dy.double().T @ a.double()).numpy(), rtol=1e-4, atol=1e-4)
+
+
+def test_gemm_rejects_bad_arguments():
+    ops = _ops()
+    from deepmerge_amd._lib import DM_NT
+    a = torch.zeros((8, 19), device=DEV, dtype=torch.bfloat16)
+    b = torch.zeros((16, 19), device=DEV, dtype=torch.bfloat16)
+    with pytest.raises(ValueError):
+        ops.gemm(DM_NT, a, b, torch.empty((8, 16), device=DEV), 8, 16, 19, lda=19, ldb=19, ldc=16)   # K % 8 != 0 in bf16
+    with pytest.raises(ValueError):
+        ops.gemm(DM_NT, a, b, torch.empty((8, 16), device=DEV), 0, 16, 16)
+    with pytest.raises(RuntimeError):
+        ops.gemm(DM_NT, a.cpu(), b.cpu(), torch.empty((8, 16)), 8, 16, 16)
+
+
+# ---------------------------------------------------------------------------------------------
+def _attn_ref(qkv, bias, scale):
+    """fp64 reference of the fused core on CPU.  qkv [B,N,3,H,D] double; bias [H,N,N] or None."""
+    q, k, v = qkv[:, :, 0].permute(0, 2, 1, 3), qkv[:, :, 1].permute(0, 2, 1, 3), qkv[:, :, 2].permute(0, 2, 1, 3)
+    s = (q * scale) @ k.transpose(-1, -2)
+    if bias is not None:
+        s = s + bias[None]
+    p = torch.softmax(s, -1)
+    o = (p @ v).permute(0, 2, 1, 3).reshape(qkv.shape[0], qkv.shape[1], -1)
+    return o, torch.logsumexp(s, -1)
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+@pytest.mark.parametrize("N,with_bias", [(12, True), (16, True), (48, True), (64, True), (192, True), (256, True), (197, False), (198, False), (100, True)])
+def test_attention_forward_backward(mode, N, with_bias):
+    ops = _ops()
+    rng = np.random.default_rng(N)
+    B, H, D = 3, 4, 64
+    dt = DT[mode]
+    qkv = torch.from_numpy(rng.normal(size=(B, N, 3, H, D)).astype(np.float32))
+    qkv = qkv.to(dt).float()                     # operands exactly representable in the mode's dtype
+    n_bins = 157
+    table = torch.from_numpy(rng.normal(size=(n_bins, H)).astype(np.float32))
+    index = torch.from_numpy(rng.integers(0, n_bins, size=(N, N)).astype(np.int32))
+    dout = torch.from_numpy(rng.normal(size=(B, N, H * D)).astype(np.float32)).to(dt).float()
+    scale = 0.125
+
+    q64 = qkv.double().requires_grad_(True)
+    t64 = table.double().requires_grad_(True)
+    bias64 = t64[index.long().reshape(-1)].reshape(N, N, H).permute(2, 0, 1) if with_bias else None
+    o_ref, lse_ref = _attn_ref(q64, bias64, scale)
+    (o_ref * dout.double()).sum().backward()
+
+    qd = qkv.to(DEV).to(dt)
+    bias = None
+    if with_bias:
+        bias = ops.relpos_bias_gather(table.to(DEV), index.to(DEV), N)
+        np.testing.assert_array_equal(bias.cpu().numpy(), bias64.detach().float().numpy())
+    out, lse = ops.attention_fwd(qd, bias, B, N, H, D, scale)
+    tol = 2e-5 if mode == "fp32" else 2e-2
+    np.testing.assert_allclose(lse.cpu().numpy(), lse_ref.detach().numpy(), rtol=1e-4 if mode == "fp32" else 2e-2, atol=1e-4 if mode == "fp32" else 2e-2)
+    err = (out.float().cpu().double() - o_ref.detach()).abs().max().item()
+    assert err < tol, f"forward max err {err}"
+
+    dqkv, slab, rows = ops.attention_bwd(qd, bias, out, dout.to(DEV).to(dt), lse, B, N, H, D, scale,
+                                         index.to(DEV) if with_bias else None, n_bins if with_bias else 0)
+    gq = q64.grad
+    scale_ref = gq.abs().max().item()
+    err = (dqkv.float().cpu().double() - gq).abs().max().item()
+    assert err < (5e-5 if mode == "fp32" else 4e-2) * max(1.0, scale_ref), f"dqkv max err {err} (scale {scale_ref})"
+    if with_bias:
+        dtable = torch.empty((n_bins, H), device=DEV)
+        ops.relpos_bias_scatter(slab, dtable, B, H, rows, n_bins)
+        gt = t64.grad
+        err = (dtable.cpu().double() - gt).abs().max().item()
+        assert err < (1e-4 if mode == "fp32" else 6e-2) * max(1.0, gt.abs().max().item()), f"dtable max err {err}"
+
+
+@pytest.mark.parametrize("out_dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("rows,cols", [(1, 768), (37, 768), (4096, 768), (50, 128), (9, 1024)])
+def test_layernorm(rows, cols, out_dtype):
+    ops = _ops()
+    rng = np.random.default_rng(rows + cols)
+    x = torch.from_numpy(rng.normal(2.0, 3.0, size=(rows, cols)).astype(np.float32))
+    g = torch.from_numpy(rng.normal(1.0, 0.2, size=cols).astype(np.float32))
+    b = torch.from_numpy(rng.normal(size=cols).astype(np.float32))
+    dy = torch.from_numpy(rng.normal(size=(rows, cols)).astype(np.float32)).to(out_dtype).float()
+    dres = torch.from_numpy(rng.normal(size=(rows, cols)).astype(np.float32))
+    xr, gr, br = x.double().requires_grad_(True), g.double().requires_grad_(True), b.double().requires_grad_(True)
+    yr = torch.nn.functional.layer_norm(xr, (cols,), gr, br, 1e-5)
+    (yr * dy.double()).sum().backward()
+    y, mean, rstd = ops.layernorm_fwd(x.to(DEV), g.to(DEV), b.to(DEV), 1e-5, out_dtype)
+    tol = 2e-5 if out_dtype == torch.float32 else 2e-2
+    np.testing.assert_allclose(y.float().cpu().numpy(), yr.detach().numpy(), rtol=tol, atol=tol)
+    g0 = torch.from_numpy(rng.normal(size=cols).astype(np.float32))
+    dgam, dbet = g0.clone().to(DEV), g0.clone().to(DEV)
+    dx, _, _ = ops.layernorm_bwd(dy.to(DEV).to(out_dtype), x.to(DEV), g.to(DEV), mean, rstd, dres=dres.to(DEV),
+                                 dgamma=dgam, dbeta=dbet, accumulate=True)
+    np.testing.assert_allclose(dx.cpu().numpy(), (xr.grad + dres.double()).numpy(), rtol=2e-4, atol=2e-4)
+    np.testing.assert_allclose(dgam.cpu().numpy(), (gr.grad + g0.double()).numpy(), rtol=2e-4, atol=2e-4 * max(1, rows) ** 0.5)
+    np.testing.assert_allclose(dbet.cpu().numpy(), (br.grad + g0.double()).numpy(), rtol=2e-4, atol=2e-4 * max(1, rows) ** 0.5)
+
+
+def test_pooling_patchify_colsum_cast():
+    ops = _ops()
+    from oracle import s2former as O
+    rng = np.random.default_rng(9)
+    B, S, side, Cc = 3, 4, 8, 768
+    x = torch.from_numpy(rng.normal(size=(B, S * side * side, Cc)).astype(np.float32))
+    xd = x.to(DEV).requires_grad_(True)
+    y = ops.TokenPoolFn.apply(xd, S, side)
+    want = O.token_pool2x2(x.double(), S, side)
+    np.testing.assert_allclose(y.detach().cpu().numpy(), want.numpy(), rtol=1e-6, atol=1e-6)
+    go = torch.from_numpy(rng.normal(size=tuple(y.shape)).astype(np.float32))
+    y.backward(go.to(DEV))
+    xr = x.double().requires_grad_(True)
+    (O.token_pool2x2(xr, S, side) * go.double()).sum().backward()
+    np.testing.assert_allclose(xd.grad.cpu().numpy(), xr.grad.numpy(), rtol=1e-6, atol=1e-6)
+    # group mean
+    z = torch.from_numpy(rng.normal(size=(B, S * 4, Cc)).astype(np.float32))
+    zd = z.to(DEV).requires_grad_(True)
+    gm = ops.GroupMeanFn.apply(zd, 4)
+    np.testing.assert_allclose(gm.detach().cpu().numpy(), z.reshape(B * S, 4, Cc).mean(1).numpy(), rtol=1e-6, atol=1e-6)
+    gm.sum().backward()
+    np.testing.assert_allclose(zd.grad.cpu().numpy(), np.full(z.shape, 0.25, np.float32))
+    # patchify == unfold with (c, dy, dx) column order
+    img = torch.from_numpy(rng.normal(size=(2, 4, 64, 64)).astype(np.float32))
+    for p in (4, 8, 16, 32):
+        cols = ops.patchify(img.to(DEV), p, torch.float32).cpu()
+        want = torch.nn.functional.unfold(img, kernel_size=p, stride=p).transpose(1, 2).reshape(-1, 4 * p * p)
+        assert torch.equal(cols, want), p
+    colsb = ops.patchify(img.to(DEV), 8, torch.bfloat16).cpu()
+    assert torch.equal(colsb, torch.nn.functional.unfold(img, kernel_size=8, stride=8).transpose(1, 2).reshape(-1, 256).bfloat16())
+    # colsum
+    X = torch.from_numpy(rng.normal(size=(1234, 768)).astype(np.float32))
+    out = torch.ones(768, device=DEV)
+    ops.colsum(X.to(DEV), out, accumulate=True)
+    np.testing.assert_allclose(out.cpu().numpy(), 1.0 + X.double().sum(0).numpy(), rtol=1e-4, atol=1e-4)
+    outb = torch.empty(768, device=DEV)
+    ops.colsum(X.to(DEV).bfloat16(), outb)
+    np.testing.assert_allclose(outb.cpu().numpy(), X.bfloat16().double().sum(0).numpy(), rtol=1e-4, atol=1e-3)
+    # cast
+    w = torch.from_numpy(rng.normal(size=(1001,)).astype(np.float32))
+    assert torch.equal(ops.cast(w.to(DEV), torch.bfloat16).cpu(), w.bfloat16())
+
+
+def test_contrastive_loss_and_adam():
+    ops = _ops()
+    from oracle import adam as OA
+    from oracle import losses as OL
+    from util import load_fx
+    fx = load_fx("ops_s2former.npz")
+    a = torch.from_numpy(fx["loss/a"]); b = torch.from_numpy(fx["loss/b"]); flag = torch.from_numpy(fx["loss/flag"])
+    ad, bd = a.to(DEV).requires_grad_(True), b.to(DEV).requires_grad_(True)
+    loss = ops.ContrastiveLossFn.apply(ad, bd, flag.to(DEV), 1.0)
+    (loss * 3.0).backward()
+    ar, br = a.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    lr_ = OL.contrastive_loss(ar, br, flag, 1.0)
+    (lr_ * 3.0).backward()
+    assert abs(loss.item() - float(fx["loss_i64/value"])) < 1e-6 * abs(float(fx["loss_i64/value"])) + 1e-7
+    np.testing.assert_allclose(ad.grad.cpu().numpy(), ar.grad.numpy(), rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(bd.grad.cpu().numpy(), br.grad.numpy(), rtol=1e-5, atol=1e-7)
+    # Adam: 3 steps against the oracle (itself pinned to torch.optim.Adam by the golden fixtures)
+    rng = np.random.default_rng(2)
+    n = 100003
+    p0 = torch.from_numpy(rng.normal(size=n).astype(np.float32))
+    pr, mr, vr = p0.clone(), torch.zeros(n), torch.zeros(n)
+    pd, md, vd = p0.clone().to(DEV), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    lp = torch.empty(n, device=DEV, dtype=torch.bfloat16)
+    for step in range(1, 4):
+        g = torch.from_numpy((rng.normal(size=n) * 10.0 ** rng.uniform(-6, 0, size=n)).astype(np.float32))
+        OA.adam_step(pr, g * 0.5, mr, vr, step, lr=1e-3)
+        ops.adam_step(pd, g.to(DEV), md, vd, step, lr=1e-3, grad_scale=0.5, param_lp=lp)
+    np.testing.assert_allclose(pd.cpu().numpy(), pr.numpy(), rtol=2e-6, atol=2e-7)
+    np.testing.assert_allclose(md.cpu().numpy(), mr.numpy(), rtol=2e-6, atol=1e-12)
+    np.testing.assert_allclose(vd.cpu().numpy(), vr.numpy(), rtol=2e-6, atol=1e-20)
+    assert torch.equal(lp.cpu(), pd.cpu().bfloat16())

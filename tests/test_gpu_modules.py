@@ -1,0 +1,188 @@
+"""GPU: the drop-in modules (deepmerge_amd.nets.ShfitScaleFormer, deepmerge_amd.Losses) against the
+golden vectors captured from the reference (tests/golden/*.npz) -- the same fixtures and recipe the
+oracle is pinned with, so these read like the reference's own per-module tests would.
+
+Parity (fp32) mode gate: 1e-3 relative; typical observed error ~1e-5.
+Throughput (bf16) mode: drift is measured and bounded loosely (the reference itself under bf16
+autocast drifts 6.6e-3 on embeddings / 2.6e-2 on gradients).
+"""
+import numpy as np
+import pytest
+import torch
+
+import recipe
+from oracle import s2former as O
+from util import MODEL_CASES, load_fx, model_inputs, tin
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+GATE = 1e-3
+
+
+def load_recipe_weights(module, prefix=""):
+    sd = module.state_dict()
+    new = {k: (torch.from_numpy(recipe.det_weight(prefix + k, v.shape)) if v.dtype.is_floating_point else v) for k, v in sd.items()}
+    module.load_state_dict(new, strict=True)
+    return module
+
+
+def S2F():
+    from deepmerge_amd.nets import ShfitScaleFormer as m
+    return m
+
+
+@pytest.mark.parametrize("tag,img,patch,in_c", [("pe32", 32, 4, 3), ("pe64", 64, 8, 3), ("pe128", 128, 16, 3), ("pe256c4", 256, 32, 4)])
+def test_patch_embed(tag, img, patch, in_c):
+    fx = load_fx("ops_s2former.npz")
+    m = load_recipe_weights(S2F().PatchEmbed(img_size=img, patch_size=patch, in_c=in_c, out_c=768, numerics="fp32"), tag + ".").to(DEV)
+    x = tin(tag + ".x", (2, in_c, img, img), "unit").to(DEV)
+    y = m(x)
+    (y * tin(tag + ".go", y.shape).to(DEV)).sum().backward()
+    recipe.check_summary(tag + "/y", y.detach().cpu().numpy(), fx, GATE)
+    recipe.check_summary(tag + "/dw", m.proj.weight.grad.cpu().numpy(), fx, GATE)
+    recipe.check_summary(tag + "/db", m.proj.bias.grad.cpu().numpy(), fx, GATE)
+    with pytest.raises(AssertionError):
+        m(torch.zeros(1, in_c, img + patch, img + patch, device=DEV))
+
+
+@pytest.mark.parametrize("tag,cin,hid,xs", [("mlp", 768, 3072, (2, 12, 768)), ("mlp128", 128, 128, (64, 128))])
+def test_mlp(tag, cin, hid, xs):
+    fx = load_fx("ops_s2former.npz")
+    m = load_recipe_weights(S2F().Mlp(in_features=cin, hidden_features=hid, numerics="fp32"), tag + ".").to(DEV)
+    x = tin(tag + ".x", xs).to(DEV).requires_grad_(True)
+    y = m(x)
+    (y * tin(tag + ".go", y.shape).to(DEV)).sum().backward()
+    recipe.check_summary(tag + "/y", y.detach().cpu().numpy(), fx, GATE)
+    recipe.check_summary(tag + "/dx", x.grad.cpu().numpy(), fx, GATE)
+    for n, p in m.named_parameters():
+        recipe.check_summary(tag + "/d_" + n, p.grad.cpu().numpy(), fx, GATE)
+
+
+def test_feature_embed():
+    fx = load_fx("ops_s2former.npz")
+    m = load_recipe_weights(S2F().FeatureEmbed(feature_size=19, embed_dim=768), "fe.").to(DEV)
+    x = tin("fe.x", (3, 1, 19), "designed").to(DEV).requires_grad_(True)
+    y = m(x)
+    (y * tin("fe.go", y.shape).to(DEV)).sum().backward()
+    recipe.check_summary("fe/y", y.detach().cpu().numpy(), fx, GATE)
+    recipe.check_summary("fe/dx", x.grad.cpu().numpy(), fx, GATE)
+    for n, p in m.named_parameters():
+        recipe.check_summary("fe/d_" + n, p.grad.cpu().numpy(), fx, GATE)
+
+
+@pytest.mark.parametrize("cube", [[3, 2, 2], [3, 4, 4], [3, 8, 8], [4, 8, 8], [4, 4, 4], [4, 2, 2]])
+def test_cross_scale_attention(cube):
+    fx = load_fx("ops_s2former.npz")
+    tag = "attn" + "x".join(map(str, cube))
+    n = cube[0] * cube[1] * cube[2]
+    m = S2F().CrossScaleAttention(dim=768, num_heads=12, cube_size=list(cube), qkv_bias=True, numerics="fp32")
+    assert torch.equal(m.relative_position_index, torch.from_numpy(O.relpos_index(cube)))
+    m = load_recipe_weights(m, tag + ".").to(DEV)
+    x = tin(tag + ".x", (2, n, 768)).to(DEV).requires_grad_(True)
+    y = m(x)
+    (y * tin(tag + ".go", y.shape).to(DEV)).sum().backward()
+    recipe.check_summary(tag + "/y", y.detach().cpu().numpy(), fx, GATE)
+    recipe.check_summary(tag + "/dx", x.grad.cpu().numpy(), fx, GATE)
+    for pn, p in m.named_parameters():
+        recipe.check_summary(tag + "/d_" + pn, p.grad.cpu().numpy(), fx, GATE)
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+@pytest.mark.parametrize("cube", [[3, 4, 4], [4, 8, 8]])
+def test_cross_scale_block(cube, mode):
+    fx = load_fx("ops_s2former.npz")
+    tag = "block" + "x".join(map(str, cube))
+    n = cube[0] * cube[1] * cube[2]
+    m = load_recipe_weights(S2F().CrossScaleBlock(dim=768, num_heads=12, cube_size=list(cube), numerics=mode), tag + ".").to(DEV)
+    x = tin(tag + ".x", (2, n, 768)).to(DEV).requires_grad_(True)
+    y = m(x)
+    (y * tin(tag + ".go", y.shape).to(DEV)).sum().backward()
+    if mode == "fp32":
+        recipe.check_summary(tag + "/y", y.detach().cpu().numpy(), fx, GATE)
+        recipe.check_summary(tag + "/dx", x.grad.cpu().numpy(), fx, GATE)
+        for pn, p in m.named_parameters():
+            recipe.check_summary(tag + "/d_" + pn, p.grad.cpu().numpy(), fx, GATE)
+    else:
+        e_y = recipe.summary_error(tag + "/y", y.detach().cpu().numpy(), fx)
+        e_dx = recipe.summary_error(tag + "/dx", x.grad.cpu().numpy(), fx)
+        print(f"bf16 drift {tag}: y rel-L2 {e_y[0]:.2e}, dx rel-L2 {e_dx[0]:.2e}")
+        assert e_y[0] < 2e-2 and e_dx[0] < 5e-2
+
+
+def test_loss_module_matches_reference_values():
+    from deepmerge_amd.Losses import ClassLoss, Loss, MultiLoss
+    fx = load_fx("ops_s2former.npz")
+    a = torch.from_numpy(fx["loss/a"]).to(DEV); b = torch.from_numpy(fx["loss/b"]).to(DEV)
+    flag = torch.from_numpy(fx["loss/flag"]).to(DEV)
+    crit = Loss(margin=1.0, lamda=0.1, belta=0)
+    for tag, fl in (("loss_i64", flag), ("loss_f32", flag.float())):
+        aa, bb = a.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        val = crit(aa, bb, fl)
+        val.backward()
+        assert abs(val.item() - float(fx[tag + "/value"])) <= 1e-6 * abs(float(fx[tag + "/value"]))
+        recipe.check_summary(tag + "/da", aa.grad.cpu().numpy(), fx, 1e-5)
+        recipe.check_summary(tag + "/db", bb.grad.cpu().numpy(), fx, 1e-5)
+    ll = tin("loss.ll", (16, 11)).to(DEV); rl = tin("loss.rl", (16, 11)).to(DEV)
+    lt = (torch.arange(16) % 11).to(DEV); rt = ((torch.arange(16) * 3) % 11).to(DEV)
+    assert abs(MultiLoss(1.0, 0.1, 0)(a, b, flag, ll, lt, rl, rt).item() - float(fx["multiloss/value"])) < 1e-5
+    assert abs(ClassLoss(1.0, 0.1, 0)(ll, lt, rl, rt).item() - float(fx["classloss/value"])) < 1e-5
+
+
+def build_model(tag, mode):
+    cfg = MODEL_CASES[tag]
+    net = S2F().ShfitScaleFormer_v3(is_designed_feature_embedding=True, cube_size=[8, 8], input_image_scales=list(cfg.scales),
+                                    embed_dim=768, depth=list(cfg.depth), in_c=cfg.in_c, numerics=mode)
+    return cfg, load_recipe_weights(net).to(DEV)
+
+
+@pytest.mark.parametrize("tag", ["v3_3s3c_111", "v3_4s4c_321", "v3_3s3c_642"])
+def test_whole_model_parity_fp32(tag):
+    from deepmerge_amd.Losses import Loss
+    fx = load_fx("model_v3.npz")
+    cfg, net = build_model(tag, "fp32")
+    sd = net.state_dict()
+    assert list(sd.keys()) == [str(k) for k in fx[tag + "/manifest_keys"]]
+    assert [",".join(map(str, v.shape)) for v in sd.values()] == [str(s) for s in fx[tag + "/manifest_shapes"]]
+    assert [str(v.dtype).replace("torch.", "") for v in sd.values()] == [str(s) for s in fx[tag + "/manifest_dtypes"]]
+    assert net.name == str(fx[tag + "/name"])
+    left, ld, right, rd, flag = model_inputs(tag, cfg.scales, cfg.in_c, 4)
+    left = [t.to(DEV) for t in left]; right = [t.to(DEV) for t in right]
+    net.train()
+    fa, fb = net(left, ld.to(DEV), right, rd.to(DEV))
+    loss = Loss(1.0, 0.1, 0)(fa, fb, flag.to(DEV))
+    loss.backward()
+    recipe.check_summary(tag + "/out_a", fa.detach().cpu().numpy(), fx, GATE)
+    recipe.check_summary(tag + "/out_b", fb.detach().cpu().numpy(), fx, GATE)
+    assert abs(loss.item() - float(fx[tag + "/loss"])) <= GATE * abs(float(fx[tag + "/loss"]))
+    none = sorted(n for n, p in net.named_parameters() if p.grad is None)
+    assert none == sorted(str(s) for s in fx[tag + "/grad_none"])
+    worst = 0.0
+    for n, p in net.named_parameters():
+        if p.grad is not None:
+            recipe.check_summary(tag + "/grad/" + n, p.grad.cpu().numpy(), fx, GATE, k=1024)
+            worst = max(worst, recipe.summary_error(tag + "/grad/" + n, p.grad.cpu().numpy(), fx, k=1024)[0])
+    print(f"{tag}: worst gradient rel-L2 error {worst:.2e}")
+    net.eval()
+    with torch.no_grad():
+        ev = net(left, ld.to(DEV))
+    recipe.check_summary(tag + "/out_a", ev.cpu().numpy(), fx, GATE)
+
+
+def test_whole_model_bf16_drift_is_bounded():
+    from deepmerge_amd.Losses import Loss
+    tag = "v3_4s4c_321"
+    fx = load_fx("model_v3.npz")
+    cfg, net = build_model(tag, "bf16")
+    left, ld, right, rd, flag = model_inputs(tag, cfg.scales, cfg.in_c, 4)
+    net.train()
+    fa, fb = net([t.to(DEV) for t in left], ld.to(DEV), [t.to(DEV) for t in right], rd.to(DEV))
+    loss = Loss(1.0, 0.1, 0)(fa, fb, flag.to(DEV))
+    loss.backward()
+    e_out = recipe.summary_error(tag + "/out_a", fa.detach().cpu().numpy(), fx)
+    errs = {n: recipe.summary_error(tag + "/grad/" + n, p.grad.cpu().numpy(), fx, k=1024)[0]
+            for n, p in net.named_parameters() if p.grad is not None}
+    worst = max(errs, key=errs.get)
+    print(f"bf16 drift: embeddings rel-L2 {e_out[0]:.2e}; median grad rel-L2 {np.median(list(errs.values())):.2e}; "
+          f"worst {worst} {errs[worst]:.2e}; loss {loss.item():.4f} vs {float(fx[tag + '/loss']):.4f}")
+    assert e_out[0] < 3e-2
+    assert np.median(list(errs.values())) < 8e-2
