@@ -43,7 +43,12 @@ class DmGemmArgs(C.Structure):
     ]
 
 
-_P, _I, _L, _F = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+class DmProfRow(C.Structure):
+    _fields_ = [("name", C.c_char * 64), ("launches", C.c_int64), ("total_ms", C.c_double),
+                ("total_flops", C.c_double), ("total_bytes", C.c_double)]
+
+
+_P, _I, _L, _F, _D = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_double
 
 # name -> (restype, argtypes); must list every function include/deepmerge_hip.h declares.
 SIGNATURES = {
@@ -69,9 +74,11 @@ SIGNATURES = {
     "dm_cast": (_I, [_P, _P, _I, _L, _P]),
     "dm_patchify": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "dm_contrastive_loss": (_I, [_P, _P, _P, _F, _F, _P, _P, _P, _I, _I, _P]),
-    "dm_adam_step": (_I, [_P, _P, _P, _P, _P, _L, _I, _F, _F, _F, _F, _F, _P]),
+    "dm_adam_step": (_I, [_P, _P, _P, _P, _P, _L, _I, _D, _D, _D, _D, _D, _P]),
     "dm_segment_mean": (_I, [_P, _P, _P, _P, _I, _I, _P]),
     "dm_edge_similarity": (_I, [_P, _P, _P, _P, _I, _I, _F, _P]),
+    "dm_prof_enable": (_I, [_I]),
+    "dm_prof_collect": (_I, [C.POINTER(DmProfRow), _I]),
 }
 
 _lock = threading.Lock()

@@ -19,6 +19,7 @@
 // lane owns 4 consecutive columns of one row).
 #include "dm_common.h"
 #include "dm_mfma.h"
+#include "dm_prof.h"
 
 namespace {
 
@@ -488,7 +489,12 @@ extern "C" int dm_attention_fwd(const void *qkv, const float *bias, void *out, f
   AttnParams p{};
   p.qkv = qkv; p.bias = bias; p.out = out; p.lse = lse; p.B = B; p.N = N; p.H = H; p.scale = scale;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  if (dtype == DM_BF16) dispatch<bf16_t>(0, p, s); else dispatch<float>(0, p, s);
+  {
+    const double esz = (dtype == DM_BF16) ? 2.0 : 4.0;
+    DmProfScope prof(dtype == DM_BF16 ? "attn_fwd_bf16" : "attn_fwd_f32", s, 4.0 * B * H * (double)N * N * HD,
+                     esz * 4.0 * B * H * (double)N * HD);
+    if (dtype == DM_BF16) dispatch<bf16_t>(0, p, s); else dispatch<float>(0, p, s);
+  }
   DM_LAUNCH_CHECK("dm_attention_fwd");
   return DM_OK;
 }
@@ -507,8 +513,13 @@ extern "C" int dm_attention_bwd(const void *qkv, const float *bias, const void *
   p.index = index; p.slab = dtable_slab; p.n_bins = n_bins; p.nblk = (N + QB - 1) / QB;
   p.B = B; p.N = N; p.H = H; p.scale = scale;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  if (dtype == DM_BF16) { dispatch<bf16_t>(1, p, s); dispatch<bf16_t>(2, p, s); }
-  else { dispatch<float>(1, p, s); dispatch<float>(2, p, s); }
+  {
+    const double esz = (dtype == DM_BF16) ? 2.0 : 4.0;
+    DmProfScope prof(dtype == DM_BF16 ? "attn_bwd_bf16" : "attn_bwd_f32", s, 10.0 * B * H * (double)N * N * HD,
+                     esz * 8.0 * B * H * (double)N * HD);
+    if (dtype == DM_BF16) { dispatch<bf16_t>(1, p, s); dispatch<bf16_t>(2, p, s); }
+    else { dispatch<float>(1, p, s); dispatch<float>(2, p, s); }
+  }
   DM_LAUNCH_CHECK("dm_attention_bwd");
   return DM_OK;
 }

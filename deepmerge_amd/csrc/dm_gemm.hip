@@ -30,6 +30,7 @@
 // (bf16) vectors.
 #include "dm_common.h"
 #include "dm_mfma.h"
+#include "dm_prof.h"
 
 namespace {
 
@@ -423,8 +424,15 @@ extern "C" int dm_gemm(const DmGemmArgs *a, void *stream) {
   p.k_per_split = kps;
   p.workspace = reinterpret_cast<float *>(a->workspace);
   const int grid = p.tiles_m * p.tiles_n * split;
-  if (a->ab_dtype == DM_BF16) launch_mfma<bf16_t>(p, a->layout, grid, s);
-  else launch_mfma<float>(p, a->layout, grid, s);
+  {
+    static const char *kNames[2][3] = {{"gemm_f32_NT", "gemm_f32_NN", "gemm_f32_TN"}, {"gemm_bf16_NT", "gemm_bf16_NN", "gemm_bf16_TN"}};
+    const double esz = (a->ab_dtype == DM_BF16) ? 2.0 : 4.0;
+    const double csz = (a->c_dtype == DM_BF16) ? 2.0 : 4.0;
+    DmProfScope prof(kNames[a->ab_dtype == DM_BF16][a->layout], s, 2.0 * a->M * a->N * a->K,
+                     esz * ((double)a->M * a->K + (double)a->N * a->K) + csz * (double)a->M * a->N);
+    if (a->ab_dtype == DM_BF16) launch_mfma<bf16_t>(p, a->layout, grid, s);
+    else launch_mfma<float>(p, a->layout, grid, s);
+  }
   DM_LAUNCH_CHECK("dm_gemm");
   if (split > 1) {
     const long long n4 = (long long)a->M * a->N / 4;

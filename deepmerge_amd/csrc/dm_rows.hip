@@ -300,14 +300,14 @@ __global__ __launch_bounds__(256) void contrastive_loss_kernel(const float *__re
 // ---------------------------------------------------------------------------------------------
 __global__ void adam_kernel(float *__restrict__ param, const float *__restrict__ grad, float *__restrict__ m,
                             float *__restrict__ v, bf16_t *__restrict__ lp, long long n, float beta1, float beta2,
-                            float eps, float step_size, float bc2_sqrt, float grad_scale) {
+                            float omb1, float omb2, float eps, float step_size, float bc2_sqrt, float grad_scale) {
   const long long n4 = n >> 2;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
     f32x4 p = dm_load4(param + 4 * i), g = dm_load4(grad + 4 * i) * grad_scale, mm = dm_load4(m + 4 * i), vv = dm_load4(v + 4 * i);
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      mm[e] = mm[e] * beta1 + g[e] * (1.f - beta1);
-      vv[e] = vv[e] * beta2 + (g[e] * g[e]) * (1.f - beta2);
+      mm[e] = mm[e] * beta1 + g[e] * omb1;
+      vv[e] = vv[e] * beta2 + (g[e] * g[e]) * omb2;
       const float denom = sqrtf(vv[e]) / bc2_sqrt + eps;
       p[e] = p[e] - step_size * (mm[e] / denom);
     }
@@ -317,8 +317,8 @@ __global__ void adam_kernel(float *__restrict__ param, const float *__restrict__
   if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
     const long long i = (n4 << 2) + threadIdx.x;
     const float g = grad[i] * grad_scale;
-    const float mm = m[i] * beta1 + g * (1.f - beta1);
-    const float vv = v[i] * beta2 + (g * g) * (1.f - beta2);
+    const float mm = m[i] * beta1 + g * omb1;
+    const float vv = v[i] * beta2 + (g * g) * omb2;
     const float p = param[i] - step_size * (mm / (sqrtf(vv) / bc2_sqrt + eps));
     param[i] = p; m[i] = mm; v[i] = vv;
     if (lp) lp[i] = (bf16_t)p;
@@ -475,14 +475,15 @@ extern "C" int dm_contrastive_loss(const float *a, const float *b, const float *
 }
 
 extern "C" int dm_adam_step(float *param, const float *grad, float *m, float *v, void *param_lp, int64_t n, int32_t step,
-                            float lr, float beta1, float beta2, float eps, float grad_scale, void *stream) {
+                            double lr, double beta1, double beta2, double eps, double grad_scale, void *stream) {
   DM_REQUIRE(param && grad && m && v && n > 0 && step >= 1, DM_ERR_BAD_SHAPE, "dm_adam_step: bad arguments");
-  const double bc1 = 1.0 - pow((double)beta1, (double)step);
-  const double bc2 = 1.0 - pow((double)beta2, (double)step);
-  const float step_size = (float)((double)lr / bc1);
+  const double bc1 = 1.0 - pow(beta1, (double)step);
+  const double bc2 = 1.0 - pow(beta2, (double)step);
+  const float step_size = (float)(lr / bc1);
   const float bc2_sqrt = (float)sqrt(bc2);
   hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n / 4 + 1)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), param, grad, m, v,
-                     (bf16_t *)param_lp, (long long)n, beta1, beta2, eps, step_size, bc2_sqrt, grad_scale);
+                     (bf16_t *)param_lp, (long long)n, (float)beta1, (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2),
+                     (float)eps, step_size, bc2_sqrt, (float)grad_scale);
   DM_LAUNCH_CHECK("dm_adam_step");
   return DM_OK;
 }

@@ -263,7 +263,7 @@ class ShfitScaleFormer_v3(nn.Module):
         return self.blocks2(x)
 
     def _pooled_tokens(self, x):
-        B = x.shape[0]
+        B = x[0].shape[0]
         x = self._ln(self.backbone(self.pos_drop(self.patch_embed(x))))
         g = x.shape[1] // self.input_scales_num
         return ops.GroupMeanFn.apply(x, g).view(B, -1)

@@ -1,0 +1,153 @@
+"""Data-parallel pair trainer: the MI355X counterpart of the loop body of the reference's
+`train()` (Train_SMT.py:226-307: forward both sides -> Loss -> zero_grad -> backward -> Adam.step),
+one process per GPU, gradients averaged with RCCL (`torch.distributed`, backend "nccl") over xGMI.
+
+Memory layout (288 GB HBM3E per GPU makes replication free: 88 M params = 0.35 GB fp32):
+  * ONE flat fp32 buffer holds every parameter, one holds every gradient, two hold Adam's m / v;
+    each nn.Parameter (and its .grad) is a view into them.  Parameters are laid out in REVERSE
+    forward order, so the gradients that backward produces first sit at the front of the buffer.
+  * the gradient all-reduce runs on a few large contiguous buckets of that buffer (xGMI rings are
+    per-link bound: few large transfers, not many small ones), each launched as soon as backward has
+    written every gradient in it, overlapping the rest of backward;
+  * Adam is a single fused launch over the flat buffers (dm_adam_step), which also applies the
+    1/world_size averaging.
+Pairs shard by contiguous equal slices of the global batch; the loss is a mean over pairs, so the
+average of per-rank gradients equals the single-GPU gradient of the global batch.
+Parameters that never receive a gradient (final_features.*, head.* on the designed-feature path,
+SURVEY 8a M11) keep a zero gradient; with m = v = 0 Adam leaves them untouched, which matches
+torch.optim.Adam skipping `grad is None` parameters.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence
+
+import torch
+import torch.distributed as dist
+
+from . import ops
+from .Losses import Loss
+
+
+def multistep_lr(base_lr: float, epoch: int, milestones=(40, 80), gamma: float = 0.2) -> float:
+    """MultiStepLR([40, 80], 0.2) stepped per epoch (Train_SMT.py:194, :351)."""
+    return base_lr * gamma ** sum(1 for m in milestones if epoch >= m)
+
+
+def shard_slice(global_batch: int, rank: int, world: int) -> slice:
+    """Contiguous equal shard of the pair batch owned by `rank` (both sides of a pair stay together)."""
+    if global_batch % world:
+        raise ValueError(f"global batch {global_batch} must divide evenly over {world} ranks "
+                         f"(equal shards make mean-of-means equal the global mean)")
+    per = global_batch // world
+    return slice(rank * per, (rank + 1) * per)
+
+
+class FlatParams:
+    """Re-homes a module's parameters and gradients into flat fp32 buffers (views keep autograd working)."""
+
+    def __init__(self, module: torch.nn.Module, align: int = 64):
+        params = [p for p in module.parameters() if p.requires_grad]
+        params.reverse()                      # backward order: last-used parameters first
+        self.params = params
+        offs, total = [], 0
+        for p in params:
+            offs.append(total)
+            total += (p.numel() + align - 1) // align * align
+        dev = params[0].device
+        self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.grad = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.offsets, self.total = offs, total
+        for p, o in zip(params, offs):
+            n = p.numel()
+            self.flat[o:o + n].copy_(p.data.reshape(-1))
+            p.data = self.flat[o:o + n].view_as(p)
+            p.grad = self.grad[o:o + n].view_as(p)
+
+    def zero_grad(self):
+        self.grad.zero_()
+        for p, o in zip(self.params, self.offsets):      # re-attach views if something replaced them
+            if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + 4 * o:
+                p.grad = self.grad[o:o + p.numel()].view_as(p)
+
+    def buckets(self, n_buckets: int) -> List[slice]:
+        """Contiguous ranges of the flat buffer with roughly equal sizes, cut at parameter boundaries."""
+        target = self.total / max(1, n_buckets)
+        cuts, acc = [0], 0
+        for p, o in zip(self.params, self.offsets):
+            if o - cuts[-1] >= target and len(cuts) < n_buckets:
+                cuts.append(o)
+        cuts.append(self.total)
+        return [slice(a, b) for a, b in zip(cuts[:-1], cuts[1:]) if b > a]
+
+
+class PairTrainer:
+    """One training step of the Siamese encoder on this rank's shard of the pair batch."""
+
+    def __init__(self, net: torch.nn.Module, margin: float = 1.0, lr: float = 1e-4, lamda: float = 0.1, belta: float = 0,
+                 betas=(0.9, 0.999), eps: float = 1e-8, n_buckets: int = 4, process_group=None):
+        self.net = net
+        self.criterion = Loss(margin, lamda, belta)
+        self.lr, self.betas, self.eps = lr, betas, eps
+        self.pg = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
+        self.fp = FlatParams(net)
+        self.m = torch.zeros_like(self.fp.flat)
+        self.v = torch.zeros_like(self.fp.flat)
+        self.step_count = 0
+        self.bucket_slices = self.fp.buckets(n_buckets if self.world > 1 else 1)
+        self._pending = []
+        self._hooks_installed = False
+        if self.world > 1:
+            self._install_bucket_hooks()
+
+    # -- gradient exchange -----------------------------------------------------------------------
+    def _install_bucket_hooks(self):
+        """Launch a bucket's all-reduce from autograd as soon as its last gradient has been accumulated."""
+        fp = self.fp
+        self._bucket_of, self._remaining0 = {}, []
+        for bi, sl in enumerate(self.bucket_slices):
+            members = [p for p, o in zip(fp.params, fp.offsets) if sl.start <= o < sl.stop]
+            self._remaining0.append(len(members))
+            for p in members:
+                self._bucket_of[p] = bi
+        self._remaining = list(self._remaining0)
+
+        def hook(p):
+            bi = self._bucket_of[p]
+            self._remaining[bi] -= 1
+            if self._remaining[bi] == 0:
+                self._launch_bucket(bi)
+        for p in fp.params:
+            p.register_post_accumulate_grad_hook(hook)
+        self._hooks_installed = True
+
+    def _launch_bucket(self, bi: int):
+        sl = self.bucket_slices[bi]
+        self._pending.append((bi, dist.all_reduce(self.fp.grad[sl], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)))
+
+    def _finish_exchange(self):
+        launched = {bi for bi, _ in self._pending}
+        for bi in range(len(self.bucket_slices)):        # buckets whose params got no gradient this step
+            if bi not in launched:
+                self._launch_bucket(bi)
+        for _, work in self._pending:
+            work.wait()
+        self._pending.clear()
+        self._remaining = list(self._remaining0)
+
+    # -- the step ----------------------------------------------------------------------------------
+    def step(self, left: Sequence[torch.Tensor], left_designed, right: Sequence[torch.Tensor], right_designed, flag,
+             lr: Optional[float] = None) -> torch.Tensor:
+        """forward -> Loss -> zero_grad -> backward -> (all-reduce) -> Adam.  Returns the local loss tensor
+        (no host sync; the reference's per-step `.item()` at Train_SMT.py:301 is left to the caller)."""
+        self.net.train()
+        self.fp.zero_grad()
+        fa, fb = self.net(left, left_designed, right, right_designed)
+        loss = self.criterion(fa, fb, flag)
+        loss.backward()
+        if self.world > 1:
+            self._finish_exchange()
+        self.step_count += 1
+        ops.adam_step(self.fp.flat, self.fp.grad, self.m, self.v, self.step_count, lr=self.lr if lr is None else lr,
+                      beta1=self.betas[0], beta2=self.betas[1], eps=self.eps, grad_scale=1.0 / self.world)
+        return loss.detach()

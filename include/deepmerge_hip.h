@@ -169,9 +169,11 @@ int dm_contrastive_loss(const float *a, const float *b, const float *flag, float
 
 /* torch.optim.Adam single step over a flat fp32 buffer (Train_SMT.py:192-193, :300): in-place on
  * param/m/v; `step` is 1-based; if param_lp != NULL also writes the bf16 copy of the new weights.
- * grad_scale multiplies the gradient first (1/world_size after an RCCL sum all-reduce). */
+ * grad_scale multiplies the gradient first (1/world_size after an RCCL sum all-reduce).
+ * Hyper-parameters are doubles: torch derives 1-beta and the bias corrections in double precision
+ * before rounding to fp32, and 1-0.999f differs from (float)(1-0.999) by 1.3e-5 relative. */
 int dm_adam_step(float *param, const float *grad, float *m, float *v, void *param_lp, int64_t n,
-                 int32_t step, float lr, float beta1, float beta2, float eps, float grad_scale, void *stream);
+                 int32_t step, double lr, double beta1, double beta2, double eps, double grad_scale, void *stream);
 
 /* ---- ExtractFeatures sweep ---------------------------------------------------------------- */
 /* Per-superpixel mean pooling (ExtractFeatures.py:190-212): F [P,D] fp32, CSR ptr[S+1] / idx[*]
@@ -184,6 +186,21 @@ int dm_segment_mean(const float *F, const int32_t *ptr, const int32_t *idx, floa
  * Summation order is fixed and documented in oracle/sweep_strict.c (bit-exact contract). */
 int dm_edge_similarity(const float *pooled, const int32_t *edges, float *simi, uint8_t *merge,
                        int32_t E, int32_t D, float margin, void *stream);
+
+/* ---- optional in-library kernel timing ------------------------------------------------------
+ * While enabled, the GEMM and attention entry points bracket their main kernel with hipEvents on
+ * the caller's stream.  dm_prof_collect waits for the recorded events, aggregates them per kernel
+ * name (launch count, total milliseconds, total algorithmic FLOPs and bytes as computed from the
+ * call's dimensions) and clears the log.  Used by bench.py for the roofline figure. */
+typedef struct {
+  char name[64];
+  int64_t launches;
+  double total_ms;
+  double total_flops;
+  double total_bytes;
+} DmProfRow;
+int dm_prof_enable(int32_t on);
+int32_t dm_prof_collect(DmProfRow *rows, int32_t max_rows);
 
 #ifdef __cplusplus
 }
