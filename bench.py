@@ -41,6 +41,26 @@ def synth_batch(B, scales, in_c, device, seed):
     return [mv(t) for t in left], mv(ld), [mv(t) for t in right], mv(rd), mv(flag)
 
 
+def log(msg):
+    print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
+def usable_cores():
+    """Host cores this process may really use: affinity mask capped by the cgroup CPU quota."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, min(n, 64))
+
+
 def cpu_baseline(cfg_scales, in_c, depth, pairs, steps):
     """The oracle (CPU restatement, plain PyTorch fp32) timed on this box's host cores: forward both
     sides + loss + backward + Adam on a bounded sample of the same workload.  Reported, not a target."""
@@ -51,12 +71,9 @@ def cpu_baseline(cfg_scales, in_c, depth, pairs, steps):
     from oracle import losses as OL
     from oracle import s2former as O
     from util import model_params
-    cores = os.cpu_count() or 1
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except Exception:
-        pass
+    cores = usable_cores()
     torch.set_num_threads(cores)
+    log(f"cpu_baseline: {cores} threads, {pairs} pairs x {steps + 1} steps")
     cfg = O.S2Config(scales=tuple(cfg_scales), in_c=in_c, depth=tuple(depth))
     p = model_params(cfg)
     fparams = {k: v for k, v in p.items() if v.dtype.is_floating_point}
@@ -76,6 +93,7 @@ def cpu_baseline(cfg_scales, in_c, depth, pairs, steps):
                 if t.grad is not None:
                     OA.adam_step(t, t.grad, m[k], v2[k], step)
         times.append(time.perf_counter() - t0)
+        log(f"cpu_baseline: step {step} took {times[-1]:.2f} s")
     dt = sum(times[1:]) / max(1, len(times) - 1)      # first step is warm-up
     return {"value": pairs / dt, "unit": "pairs/s", "cores": cores, "kind": "port",
             "sample": f"{steps} timed steps (+1 warm-up) of {pairs} pairs, same model/inputs shape, torch CPU fp32 oracle"}
@@ -129,8 +147,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    log(f"model built on {dev}; {args.warmup} warm-up steps")
+    for i in range(args.warmup):
         trainer.step(*batch)
+        torch.cuda.synchronize()
+        log(f"warm-up step {i} done")
     lib = _lib.lib()
     sync()
     lib.dm_prof_enable(1)
@@ -140,6 +161,7 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     lib.dm_prof_enable(0)
+    log(f"timed region: {args.steps} steps in {dt:.3f} s")
     if world > 1:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)

@@ -391,7 +391,10 @@ extern "C" int dm_gemm(const DmGemmArgs *a, void *stream) {
                        (a->residual == nullptr || (a->ldr % 4 == 0 && dm_aligned16(a->residual))) &&
                        (a->aux == nullptr || a->ldaux % 4 == 0) && (a->bias == nullptr || dm_aligned16(a->bias)) &&
                        dm_aligned16(a->C) && (a->rows_per_group == 0 || a->group_stride % 4 == 0) &&
-                       (a->M >= 32 || a->ab_dtype == DM_BF16);
+                       // skinny fp32 products of the tail (M = batch) have too few 128x128 tiles to fill the chip
+                       !(a->ab_dtype == DM_F32 && a->layout != DM_TN && a->rows_per_group == 0 && a->c_dtype == DM_F32 &&
+                         (a->aux == nullptr || a->aux_dtype == DM_F32) &&
+                         ((a->M + BM - 1) / BM) * ((a->N + BN - 1) / BN) < 16);
   if (!mfma_ok) {
     DM_REQUIRE(a->ab_dtype == DM_F32 && a->c_dtype == DM_F32 && (a->aux == nullptr || a->aux_dtype == DM_F32),
                DM_ERR_BAD_ALIGN, "dm_gemm: shape/alignment needs the generic path, which is fp32-only "

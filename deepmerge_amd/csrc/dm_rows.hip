@@ -7,7 +7,7 @@
 namespace {
 
 constexpr int MAXCH = 4;          // float4 chunks per lane per row -> cols <= 1024
-constexpr int LN_MAX_WG = 512;
+constexpr int LN_MAX_WG = 256;
 constexpr int CS_MAX_SLICES = 64;
 
 // ---------------------------------------------------------------------------------------------
@@ -135,16 +135,25 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const TDY *__restric
   }
 }
 
-// out[j] (+)= sum_r partial[r][j], r in order (deterministic).
-__global__ void partial_reduce_kernel(const float *__restrict__ partial, float *__restrict__ out0, float *__restrict__ out1,
-                                      int nrows, int width, int split, int accumulate) {
+// out[j] (+)= sum_r partial[r][j].  Block = 32 columns x 8 row-slices; each slice sums its rows in
+// order, slices are combined in a fixed tree -> deterministic.
+__global__ __launch_bounds__(256) void partial_reduce_kernel(const float *__restrict__ partial, float *__restrict__ out0,
+                                                             float *__restrict__ out1, int nrows, int width, int split,
+                                                             int accumulate) {
   // `partial` rows are `width` wide; columns [0,split) go to out0, [split,width) to out1.
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= width) return;
+  __shared__ float red[8][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int j = blockIdx.x * 32 + tx;
   float s = 0.f;
-  for (int r = 0; r < nrows; ++r) s += partial[(long long)r * width + j];
-  float *o = (j < split) ? out0 + j : out1 + (j - split);
-  *o = accumulate ? *o + s : s;
+  if (j < width)
+    for (int r = ty; r < nrows; r += 8) s += partial[(long long)r * width + j];
+  red[ty][tx] = s;
+  __syncthreads();
+  if (ty == 0 && j < width) {
+    s = ((red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx])) + ((red[4][tx] + red[5][tx]) + (red[6][tx] + red[7][tx]));
+    float *o = (j < split) ? out0 + j : out1 + (j - split);
+    *o = accumulate ? *o + s : s;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -336,16 +345,25 @@ __global__ void relpos_gather_kernel(const float *__restrict__ table, const int 
     for (int h = 0; h < H; ++h) bias[(long long)h * NN + ij] = table[bin * H + h];
   }
 }
-__global__ void relpos_scatter_kernel(const float *__restrict__ slab, float *__restrict__ dtable, int B, int H, int R,
-                                      int n_bins, int accumulate) {
-  const int bin = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(256) void relpos_scatter_kernel(const float *__restrict__ slab, float *__restrict__ dtable, int B, int H,
+                                                             int R, int n_bins, int accumulate) {
+  __shared__ float red[4][65];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int bin = blockIdx.x * 64 + tx;
   const int h = blockIdx.y;
-  if (bin >= n_bins) return;
   float s = 0.f;
-  for (int b = 0; b < B; ++b)
-    for (int q = 0; q < R; ++q) s += slab[(((long long)b * H + h) * R + q) * n_bins + bin];
-  float *o = dtable + (long long)bin * H + h;
-  *o = accumulate ? *o + s : s;
+  if (bin < n_bins)
+    for (int i = ty; i < B * R; i += 4) {
+      const int b = i / R, q = i % R;
+      s += slab[(((long long)b * H + h) * R + q) * n_bins + bin];
+    }
+  red[ty][tx] = s;
+  __syncthreads();
+  if (ty == 0 && bin < n_bins) {
+    s = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
+    float *o = dtable + (long long)bin * H + h;
+    *o = accumulate ? *o + s : s;
+  }
 }
 
 inline int grid_for(long long work_items, int block = 256, int cap = 4096) {
@@ -390,7 +408,7 @@ extern "C" int dm_layernorm_bwd(const void *dy, int32_t dy_dtype, const float *x
     hipLaunchKernelGGL(layernorm_bwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t *)dy, x, gamma, mean, rstd, dres, dx, partial, rows, cols);
   else DM_REQUIRE(false, DM_ERR_BAD_DTYPE, "dm_layernorm_bwd: bad dy_dtype %d", dy_dtype);
   DM_LAUNCH_CHECK("dm_layernorm_bwd");
-  hipLaunchKernelGGL(partial_reduce_kernel, dim3((2 * cols + 255) / 256), dim3(256), 0, s, partial, dgamma, dbeta, grid, 2 * cols, cols, accumulate_params);
+  hipLaunchKernelGGL(partial_reduce_kernel, dim3((2 * cols + 31) / 32), dim3(256), 0, s, partial, dgamma, dbeta, grid, 2 * cols, cols, accumulate_params);
   DM_LAUNCH_CHECK("dm_layernorm_bwd(reduce)");
   return DM_OK;
 }
@@ -438,7 +456,7 @@ extern "C" int dm_colsum(const void *X, int32_t dtype, int64_t ldx, float *out, 
   else if (dtype == DM_BF16) hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t *)X, (long long)ldx, partial, M, N, rps);
   else DM_REQUIRE(false, DM_ERR_BAD_DTYPE, "dm_colsum: bad dtype %d", dtype);
   DM_LAUNCH_CHECK("dm_colsum");
-  hipLaunchKernelGGL(partial_reduce_kernel, dim3((N + 255) / 256), dim3(256), 0, s, partial, out, out, slices, N, N, accumulate);
+  hipLaunchKernelGGL(partial_reduce_kernel, dim3((N + 31) / 32), dim3(256), 0, s, partial, out, out, slices, N, N, accumulate);
   DM_LAUNCH_CHECK("dm_colsum(reduce)");
   return DM_OK;
 }
@@ -498,7 +516,7 @@ extern "C" int dm_relpos_bias_gather(const float *table, const int32_t *index, f
 extern "C" int dm_relpos_bias_scatter(const float *slab, float *dtable, int32_t B, int32_t H, int32_t rows_per_bh,
                                       int32_t n_bins, int32_t accumulate, void *stream) {
   DM_REQUIRE(slab && dtable && B > 0 && H > 0 && rows_per_bh > 0 && n_bins > 0, DM_ERR_BAD_SHAPE, "dm_relpos_bias_scatter: bad arguments");
-  hipLaunchKernelGGL(relpos_scatter_kernel, dim3((n_bins + 255) / 256, H), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), slab, dtable, B, H, rows_per_bh, n_bins, accumulate);
+  hipLaunchKernelGGL(relpos_scatter_kernel, dim3((n_bins + 63) / 64, H), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), slab, dtable, B, H, rows_per_bh, n_bins, accumulate);
   DM_LAUNCH_CHECK("dm_relpos_bias_scatter");
   return DM_OK;
 }

@@ -84,9 +84,12 @@ class PairTrainer:
     """One training step of the Siamese encoder on this rank's shard of the pair batch."""
 
     def __init__(self, net: torch.nn.Module, margin: float = 1.0, lr: float = 1e-4, lamda: float = 0.1, belta: float = 0,
-                 betas=(0.9, 0.999), eps: float = 1e-8, n_buckets: int = 4, process_group=None):
+                 betas=(0.9, 0.999), eps: float = 1e-8, n_buckets: int = 4, process_group=None, criterion=None, adam_fn=None):
+        """`criterion` / `adam_fn` default to the HIP loss and fused Adam; tests of the exchange logic may
+        inject stand-ins with the same signatures."""
         self.net = net
-        self.criterion = Loss(margin, lamda, belta)
+        self.criterion = criterion if criterion is not None else Loss(margin, lamda, belta)
+        self.adam_fn = adam_fn if adam_fn is not None else ops.adam_step
         self.lr, self.betas, self.eps = lr, betas, eps
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
@@ -148,6 +151,6 @@ class PairTrainer:
         if self.world > 1:
             self._finish_exchange()
         self.step_count += 1
-        ops.adam_step(self.fp.flat, self.fp.grad, self.m, self.v, self.step_count, lr=self.lr if lr is None else lr,
-                      beta1=self.betas[0], beta2=self.betas[1], eps=self.eps, grad_scale=1.0 / self.world)
+        self.adam_fn(self.fp.flat, self.fp.grad, self.m, self.v, self.step_count, lr=self.lr if lr is None else lr,
+                     beta1=self.betas[0], beta2=self.betas[1], eps=self.eps, grad_scale=1.0 / self.world)
         return loss.detach()

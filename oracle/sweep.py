@@ -72,3 +72,35 @@ def merge_decisions(simi: np.ndarray, margin: float = 1.0) -> np.ndarray:
     """merge[e] = simi[e] < margin (NaN -> False); margin from Train_SMT.py:380."""
     with np.errstate(invalid="ignore"):
         return np.less(simi, np.float32(margin))
+
+
+# ---- pinned-order variant (oracle/sweep_strict.c) ----------------------------------------------
+def _strict_lib():
+    import ctypes
+    import os
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_ref", "liboracle_sweep.so")
+    if not os.path.exists(path):
+        raise FileNotFoundError(f"{path} missing: run `make -C oracle` (or __graft_entry__.build())")
+    lib = ctypes.CDLL(path)
+    return lib, ctypes
+
+
+def strict_segment_mean(F: np.ndarray, ptr: np.ndarray, idx: np.ndarray) -> np.ndarray:
+    lib, C = _strict_lib()
+    F = np.ascontiguousarray(F, np.float32); ptr = np.ascontiguousarray(ptr, np.int32); idx = np.ascontiguousarray(idx, np.int32)
+    S, D = len(ptr) - 1, F.shape[1]
+    out = np.zeros((S, D), np.float32)
+    lib.dm_oracle_segment_mean(F.ctypes.data_as(C.c_void_p), ptr.ctypes.data_as(C.c_void_p), idx.ctypes.data_as(C.c_void_p),
+                               out.ctypes.data_as(C.c_void_p), C.c_int32(S), C.c_int32(D))
+    return out
+
+
+def strict_edge_similarity(pooled: np.ndarray, edges: np.ndarray, margin: float = 1.0):
+    lib, C = _strict_lib()
+    pooled = np.ascontiguousarray(pooled, np.float32); edges = np.ascontiguousarray(edges, np.int32)
+    E, D = edges.shape[0], pooled.shape[1]
+    simi = np.zeros(E, np.float32); merge = np.zeros(E, np.uint8)
+    lib.dm_oracle_edge_similarity(pooled.ctypes.data_as(C.c_void_p), edges.ctypes.data_as(C.c_void_p),
+                                  simi.ctypes.data_as(C.c_void_p), merge.ctypes.data_as(C.c_void_p),
+                                  C.c_int32(E), C.c_int32(D), C.c_float(margin))
+    return simi, merge.astype(bool)

@@ -1,0 +1,108 @@
+"""CPU: the C-ABI library loads and exports every symbol include/deepmerge_hip.h declares; the ctypes
+binding mirrors the header; the product never imports the oracle or falls back to CPU."""
+import ctypes
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def built_lib():
+    import __graft_entry__ as g
+    from deepmerge_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        g.build()
+    return _lib
+
+
+def test_library_exports_every_declared_symbol(built_lib):
+    declared = built_lib.declared_symbols()
+    assert len(declared) >= 25
+    handle = ctypes.CDLL(built_lib.LIB_PATH)
+    missing = [s for s in declared if not hasattr(handle, s)]
+    assert not missing, missing
+    assert sorted(built_lib.SIGNATURES) == declared, "deepmerge_amd/_lib.py SIGNATURES out of sync with the header"
+    nm = subprocess.run(["nm", "-D", "--defined-only", built_lib.LIB_PATH], capture_output=True, text=True).stdout
+    exported = set(re.findall(r" T (dm_[a-z0-9_]+)", nm))
+    assert set(declared) <= exported
+
+
+def test_library_identity_calls(built_lib):
+    lib = built_lib.lib()
+    assert lib.dm_abi_version() == 1
+    assert lib.dm_arch() == b"gfx950"
+    assert lib.dm_gemm_workspace_bytes(built_lib.DM_NT, 1024, 768, 768) == 0
+    assert lib.dm_gemm_workspace_bytes(built_lib.DM_TN, 768, 768, 16384) > 0
+    assert lib.dm_attention_bwd_slab_rows(256) == 4 and lib.dm_attention_bwd_slab_rows(12) == 1
+    assert lib.dm_layernorm_bwd_partial_floats(768) >= 2 * 768
+    assert ctypes.sizeof(built_lib.DmGemmArgs) == 160   # == sizeof(DmGemmArgs) in C (gcc, LP64)
+    assert ctypes.sizeof(built_lib.DmProfRow) == 96
+
+
+def test_argument_validation_needs_no_gpu(built_lib):
+    """Shape/dtype errors are reported through the status code + dm_last_error before any launch."""
+    lib = built_lib.lib()
+    a = built_lib.DmGemmArgs()
+    a.M, a.N, a.K = 0, 8, 8
+    assert lib.dm_gemm(ctypes.byref(a), None) == -1
+    assert b"M,N,K" in lib.dm_last_error()
+    assert lib.dm_attention_fwd(None, None, None, None, 1, 300, 12, 64, 0.125, 0, None) == -1
+    assert b"N <= 256" in lib.dm_last_error()
+    assert lib.dm_edge_similarity(1, 1, 1, None, 4, 1000, 1.0, None) == -6
+
+
+def test_ops_fail_loudly_without_gpu_tensors(built_lib):
+    import torch
+    from deepmerge_amd import ops
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.layernorm_fwd(torch.zeros(2, 8), torch.ones(8), torch.zeros(8), 1e-5, torch.float32)
+    from deepmerge_amd.nets.ShfitScaleFormer import Mlp
+    with pytest.raises(RuntimeError):
+        Mlp(8, 16)(torch.zeros(2, 8))
+
+
+def test_missing_library_raises(monkeypatch, built_lib):
+    monkeypatch.setattr(built_lib, "_lib", None)
+    monkeypatch.setattr(built_lib, "LIB_PATH", "/nonexistent/libdeepmerge_hip.so")
+    with pytest.raises(built_lib.DeepMergeLibraryError, match="no CPU fallback"):
+        built_lib.lib()
+
+
+def test_product_never_imports_the_oracle_or_reference():
+    bad = []
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "deepmerge_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cpp", ".h")):
+                text = open(os.path.join(dirpath, f)).read()
+                if re.search(r"^\s*(from|import)\s+oracle\b", text, re.M) or "/root/reference" in text:
+                    bad.append(os.path.join(dirpath, f))
+    assert not bad, bad
+
+
+def test_drop_in_surface_names():
+    """Class / kwarg surface of the mirrored modules."""
+    import inspect
+    from deepmerge_amd import Losses
+    from deepmerge_amd.nets import ShfitScaleFormer as S
+    for name in ("PatchEmbed", "Mlp", "FeatureEmbed", "CrossScaleAttention", "CrossScaleBlock", "ShfitScaleFormer_v3"):
+        assert hasattr(S, name)
+    sig = inspect.signature(S.ShfitScaleFormer_v3.__init__).parameters
+    for kw in ("num_classes", "is_designed_feature_embedding", "FeatureEmbed", "PatchEmbed", "cube_size", "input_image_scales",
+               "embed_dim", "depth", "num_heads", "mlp_ratio", "drop_path_ratio", "drop_ratio", "attn_drop_ratio", "norm_layer",
+               "act_layer", "cuda"):
+        assert kw in sig, kw
+    fsig = list(inspect.signature(S.ShfitScaleFormer_v3.forward).parameters)
+    assert fsig == ["self", "x1_patches", "x1_designed_features", "x2_patches", "x2_designed_features"]
+    for m in ("extract_features_with_design_features", "extract_features", "forward_once", "forward_once_design_feature",
+              "patch_embed", "backbone", "designed_feature_embed"):
+        assert callable(getattr(S.ShfitScaleFormer_v3, m))
+    assert list(inspect.signature(Losses.Loss.__init__).parameters) == ["self", "margin", "lamda", "belta"]
+    assert list(inspect.signature(Losses.Loss.forward).parameters) == ["self", "positive", "negative", "flag", "size_average"]
+    cube = [8, 8]
+    net = S.ShfitScaleFormer_v3(depth=[1, 1, 1], cube_size=cube, input_image_scales=[32, 64, 128])
+    assert cube == [3, 8, 8] and net.name == "S2Former_v3-3CH-3DP-SEF-111" and net.depth == [1, 1, 1]
+    assert net.input_image_scales == [32, 64, 128]

@@ -27,7 +27,7 @@ DT = {"fp32": torch.float32, "bf16": torch.bfloat16}
 
 @pytest.mark.parametrize("mode", ["fp32", "bf16"])
 @pytest.mark.parametrize("layout", ["NT", "NN", "TN"])
-@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 192), (200, 136, 72), (16, 768, 768), (1000, 100, 3840), (64, 2304, 768)])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (512, 512, 256), (256, 384, 192), (200, 136, 72), (16, 768, 768), (1000, 100, 3840), (64, 2304, 768)])
 def test_gemm_exact_integers(mode, layout, M, N, K):
     ops = _ops()
     from deepmerge_amd._lib import DM_NN, DM_NT, DM_TN

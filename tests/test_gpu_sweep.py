@@ -1,0 +1,99 @@
+"""GPU: ExtractFeatures sweep kernels against the pinned-order oracle (bit-exact) and the numpy
+restatement of the reference (merge decisions), from tiny ragged cases to BASELINE config 4 size."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import sweep as OS
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def run_gpu(F, ptr, idx, edges, margin=1.0):
+    from deepmerge_amd.ExtractFeatures import rag_similarity_sweep
+    pooled, simi, merge = rag_similarity_sweep(torch.from_numpy(F).to(DEV), torch.from_numpy(ptr).to(DEV),
+                                               torch.from_numpy(idx).to(DEV), torch.from_numpy(edges).to(DEV), margin)
+    return pooled.cpu().numpy(), simi.cpu().numpy(), merge.cpu().numpy()
+
+
+def make_case(rng, S, D, kmax, E, dead=True):
+    counts = rng.integers(0, kmax + 1, size=S)
+    counts[rng.integers(0, S, size=max(1, S // 10))] = 0      # some polygons without sample points
+    ptr = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
+    P = max(1, int(ptr[-1]))
+    idx = rng.integers(0, P, size=int(ptr[-1])).astype(np.int32)
+    F = (rng.normal(size=(P, D)) * 0.08).astype(np.float32)
+    edges = rng.integers(0, S, size=(E, 2)).astype(np.int32)
+    same = edges[:, 0] == edges[:, 1]
+    edges[same, 1] = (edges[same, 0] + 1) % S
+    if dead:
+        edges[::17, 0] = -1
+        edges[5::23, 1] = -1
+    return F, ptr, idx, edges
+
+
+@pytest.mark.parametrize("S,D,kmax,E", [(5, 100, 3, 7), (64, 100, 9, 300), (300, 8, 4, 1000), (200, 37, 5, 999), (100, 128, 6, 512), (50, 5, 3, 64)])
+def test_sweep_bit_exact_vs_pinned_oracle(S, D, kmax, E):
+    rng = np.random.default_rng(S * 1000 + D)
+    F, ptr, idx, edges = make_case(rng, S, D, kmax, E)
+    pooled, simi, merge = run_gpu(F, ptr, idx, edges)
+    want_pooled = OS.strict_segment_mean(F, ptr, idx)
+    assert np.array_equal(pooled, want_pooled)
+    want_simi, want_merge = OS.strict_edge_similarity(want_pooled, edges, 1.0)
+    assert np.array_equal(np.isnan(simi), np.isnan(want_simi))
+    live = ~np.isnan(want_simi)
+    assert np.array_equal(simi[live].view(np.uint32), want_simi[live].view(np.uint32)), "simi must match bit for bit"
+    assert np.array_equal(merge, want_merge)
+
+
+def test_sweep_matches_reference_formula_on_merge_decisions():
+    """Against the numpy restatement of the reference (BLAS dot): identical merge decisions except for edges
+    within float32 noise of the margin (counted and required to be rare)."""
+    rng = np.random.default_rng(77)
+    F, ptr, idx, edges = make_case(rng, 400, 100, 5, 3000)
+    counts = np.diff(ptr)
+    edges = edges[(edges < 0).any(1) | ((counts[np.maximum(edges[:, 0], 0)] > 0) & (counts[np.maximum(edges[:, 1], 0)] > 0))]
+    _, simi, merge = run_gpu(F, ptr, idx, edges)
+    ref = OS.edge_similarity(F, ptr, idx, edges)
+    live = ~np.isnan(ref)
+    np.testing.assert_allclose(simi[live], ref[live], rtol=3e-6, atol=1e-6)
+    ref_merge = OS.merge_decisions(ref, 1.0)
+    near = np.abs(ref - 1.0) < 1e-5
+    print(f"edges within 1e-5 of the margin: {int(near.sum())} of {len(ref)}")
+    assert near.sum() <= 3
+    assert np.array_equal(merge[~near], ref_merge[~near])
+    assert 0.05 < merge[live].mean() < 0.95
+
+
+def test_sweep_full_config4_size_properties():
+    """BASELINE configs[3] size: ~19.9k superpixels x 3 points, ~58k edges, D = 100.  Checked by
+    size-independent properties + the pinned oracle (C, a few ms)."""
+    rng = np.random.default_rng(4)
+    S, k, D = 19881, 3, 100
+    ptr = (np.arange(S + 1) * k).astype(np.int32)
+    idx = rng.permutation(S * k).astype(np.int32)
+    F = (rng.normal(size=(S * k, D)) * 0.07).astype(np.float32)
+    side = 141
+    sp = np.arange(S).reshape(side, side)
+    edges = np.concatenate([np.stack([sp[:, :-1].ravel(), sp[:, 1:].ravel()], 1), np.stack([sp[:-1].ravel(), sp[1:].ravel()], 1)]).astype(np.int32)
+    pooled, simi, merge = run_gpu(F, ptr, idx, edges)
+    # symmetry: swapping LEFT/RIGHT changes nothing (bitwise: all sums are commutative per element)
+    _, simi_sw, merge_sw = run_gpu(F, ptr, idx, edges[:, ::-1].copy())
+    assert np.array_equal(simi.view(np.uint32), simi_sw.view(np.uint32)) and np.array_equal(merge, merge_sw)
+    # permutation of the edge list permutes the result
+    perm = rng.permutation(len(edges))
+    _, simi_p, _ = run_gpu(F, ptr, idx, edges[perm])
+    assert np.array_equal(simi_p.view(np.uint32), simi[perm].view(np.uint32))
+    # pooling is a mean: scaling F by 2 scales pooled and simi by exactly 2
+    pooled2, simi2, _ = run_gpu(F * 2, ptr, idx, edges)
+    assert np.array_equal(pooled2, pooled * 2) and np.array_equal(simi2, simi * 2)
+    want_simi, want_merge = OS.strict_edge_similarity(OS.strict_segment_mean(F, ptr, idx), edges, 1.0)
+    assert np.array_equal(simi.view(np.uint32), want_simi.view(np.uint32)) and np.array_equal(merge, want_merge)
+    assert len(edges) == 2 * side * (side - 1)
+
+
+def test_sweep_rejects_unpinned_dims():
+    from deepmerge_amd import ops
+    with pytest.raises(ValueError):
+        ops.edge_similarity(torch.zeros(4, 200, device=DEV), torch.zeros(2, 2, dtype=torch.int32, device=DEV))
