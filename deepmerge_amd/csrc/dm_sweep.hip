@@ -5,6 +5,10 @@
 // intrinsics and can never be contracted into FMAs.
 #include "dm_common.h"
 
+// The summation order is a bit-exact contract: forbid FMA contraction of the a*b + c chains below
+// (hipcc defaults to -ffp-contract=fast, and __fmul_rn/__fadd_rn are plain * and + in the HIP headers).
+#pragma clang fp contract(off)
+
 namespace {
 
 // One wave per superpixel; lane owns columns lane, lane+64, ...  Rows are added in idx order and the
@@ -78,7 +82,9 @@ __global__ __launch_bounds__(256) void edge_similarity_kernel(const float *__res
   if (live && j == 0) {
     float d = __fsub_rn(__fadd_rn(xx, yy), __fmul_rn(2.0f, xy));
     if (d < 0.f) d = 0.f;                 // D[D < 0] = 0 (NaN stays NaN)
-    float sm = __fsqrt_rn(d);
+    // correctly rounded float sqrt: a double sqrt rounded once more to float is exact-rounded because
+    // 53 >= 2*24 + 2 (the single-precision intrinsic forms are not guaranteed IEEE on this target)
+    float sm = (float)sqrt((double)d);
     if (!ok) sm = __builtin_nanf("");
     simi[e] = sm;
     if (merge) merge[e] = (sm < margin) ? 1 : 0;
