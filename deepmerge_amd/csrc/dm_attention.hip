@@ -3,20 +3,28 @@
 // Problem shape: per (sample b, head h) one N x N attention with N <= 256 tokens and head dim
 // D = 64 (N = 12..256 for ShfitScaleFormer stages, 197/198 for the ViT variants).  The whole
 // score row fits in registers, so softmax is exact (no online rescaling) and nothing of size
-// N x N ever goes to HBM.
+// N x N ever goes to HBM or LDS.
 //
-// Forward  : workgroup = (64-query block, h, b), 4 waves x 16 query rows.
-//            K tile -> LDS (k-contiguous image) -> S = scale*Q K^T + bias -> softmax in registers
-//            (lane holds 4 consecutive keys of one query row; row reductions are 2 butterflies) ->
-//            P -> LDS (wave-private, operand dtype) ; V tile -> LDS (transposed-read image) ->
-//            O = P V.  K and V time-share one LDS buffer.
-// Backward : two kernels so that no gradient is accumulated across workgroups:
-//            dq kernel  (64-query block): recompute P, dP = dO V^T, dS = P*(dP - delta),
-//                        dQ = scale * dS K; also delta = rowsum(dO*O) and the relative-position
-//                        bias gradient binned into an LDS histogram (table bins) -> slab row.
-//            dkv kernel (64-key block):   recompute P^T, dV = P^T dO, dK = scale * dS^T Q.
-// MFMA operand conventions are those of dm_gemm.hip (16-byte fragments, swapped operands so a
-// lane owns 4 consecutive columns of one row).
+// Workgroup = (64-row block, head, sample), 4 waves x 16 rows; one barrier per kernel.
+//   forward : K and V tiles -> LDS; S = scale*Q K^T + bias (MFMA, K read by rows) -> softmax in
+//             registers -> O = P V (MFMA, V read through the hardware transpose).
+//   backward: two kernels so that no gradient is summed across workgroups:
+//             dq  (rows = queries): P = exp(S - lse), dP = dO V^T, dS = P*(dP - delta),
+//                  dQ = scale * dS K; also delta = rowsum(dO*O) and the bias-table gradient
+//                  binned into an LDS histogram -> one slab row per workgroup;
+//             dkv (rows = keys):    P^T, dP^T, dS^T likewise, dV = P^T dO, dK = scale * dS^T Q.
+//
+// Two ideas carry the kernel:
+//  (1) ONE LDS image per tile serves both the row reads (contraction over d: QK^T, dO V^T) and the
+//      transposed reads (contraction over tokens: P V, dS K, P^T dO, dS^T Q).  Image: [token][64 d],
+//      16-byte chunk index XOR s(token); bf16: s = ((t1^t2)<<2 | t0<<1 | t1), t = token>>1, which is
+//      bank-conflict free for ds_read_b128 row fragments AND for ds_read_b64_tr_b16 in both row
+//      patterns used here (checked by brute force against the gfx950 bank model); fp32: s = token&15
+//      (conflict free for ds_read_b128 and the ds_read_b32 column reads).
+//  (2) P / dS never leave registers: with the MFMA operands swapped a lane owns 4 consecutive
+//      tokens of one row per 16x16 tile, and two adjacent tiles (bf16) or one tile (fp32) ARE a valid
+//      operand fragment of the next MFMA for a permuted contraction order; the other operand is
+//      fetched in the same permuted order (rows 4g+16*half+q of the transposed read).
 #include "dm_common.h"
 #include "dm_mfma.h"
 #include "dm_prof.h"
@@ -25,83 +33,99 @@ namespace {
 
 constexpr int HD = 64;         // head dim
 constexpr int QB = 64;         // rows (queries or keys) per workgroup
-constexpr int MAX_BINS = 4096; // LDS histogram capacity (3-D table for a 4x8x8 cube has 1575 bins)
+constexpr int MAX_BINS = 4096; // LDS histogram capacity (a 4x8x8 cube's table has 1575 rows)
 
-template <typename T> struct AttnLayout {
+template <typename T> struct AL {
   static constexpr int RB = HD * (int)sizeof(T);       // bytes per 64-d row: 128 / 256
   static constexpr int CPRW = RB / 16;                 // 16-byte chunks per row: 8 / 16
-  static constexpr int KBD = RB / 64;                  // 64-byte k-blocks across d: 2 / 4
-  static constexpr int MROW = (sizeof(T) == 2) ? 128 : 272;   // row stride of the transposed-read image
-  static constexpr int EPC = 16 / (int)sizeof(T);      // elements per chunk
+  static constexpr int KBD = RB / 64;                  // 64-byte contraction blocks across d: 2 / 4
+  static constexpr int EPC = 16 / (int)sizeof(T);      // elements per chunk: 8 / 4
+  static constexpr int TPB = (sizeof(T) == 2) ? 2 : 1; // 16-token tiles per contraction block over tokens
 };
 
-__device__ __forceinline__ int fv_swz(int k) { return ((k >> 1) & 1) | (((k >> 3) & 1) << 1); }
+template <typename T> __device__ __forceinline__ int swz(int row);
+template <> __device__ __forceinline__ int swz<bf16_t>(int row) {
+  const int t0 = (row >> 1) & 1, t1 = (row >> 2) & 1, t2 = (row >> 3) & 1;
+  return ((t1 ^ t2) << 2) | (t0 << 1) | t1;
+}
+template <> __device__ __forceinline__ int swz<float>(int row) { return row & 15; }
 
-// ---- global [rows][64] (row stride `ld` elements) -> LDS images ------------------------------
-// k-contiguous image: addr(row, chunk) = row*RB + ((chunk ^ (row & (CPRW-1))) << 4)
+template <typename T> __device__ __forceinline__ int img_off(int row, int chunk) {
+  return row * AL<T>::RB + ((chunk ^ swz<T>(row)) << 4);
+}
+
+// global [rows][64] (row stride `ld` elements) -> LDS image; rows >= nvalid are zero-filled.
 template <typename T>
-__device__ __forceinline__ void tile_to_lds_k(char *lds, const T *g, long long ld, int nvalid, int nrows, int t) {
-  using L = AttnLayout<T>;
+__device__ __forceinline__ void tile_to_lds(char *lds, const T *g, long long ld, int nvalid, int nrows, int t) {
+  using L = AL<T>;
   const int c = t % L::CPRW;
   constexpr int RPI = 256 / L::CPRW;
   for (int row = t / L::CPRW; row < nrows; row += RPI) {
     u32x4 v = {0u, 0u, 0u, 0u};
     if (row < nvalid) v = *reinterpret_cast<const u32x4 *>(g + (long long)row * ld + c * L::EPC);
-    *reinterpret_cast<u32x4 *>(lds + row * L::RB + ((c ^ (row & (L::CPRW - 1))) << 4)) = v;
+    *reinterpret_cast<u32x4 *>(lds + img_off<T>(row, c)) = v;
   }
 }
-// transposed-read image (rows are the contraction index):
-//   bf16: addr(k, d) = k*128 + (((d>>4) ^ fv(k)) << 5) + (d&15)*2     fp32: addr(k, d) = k*272 + d*4
-template <typename T>
-__device__ __forceinline__ void tile_to_lds_m(char *lds, const T *g, long long ld, int nvalid, int nrows, int t) {
-  using L = AttnLayout<T>;
-  const int c = t % L::CPRW;
-  constexpr int RPI = 256 / L::CPRW;
-  for (int row = t / L::CPRW; row < nrows; row += RPI) {
-    u32x4 v = {0u, 0u, 0u, 0u};
-    if (row < nvalid) v = *reinterpret_cast<const u32x4 *>(g + (long long)row * ld + c * L::EPC);
-    if constexpr (sizeof(T) == 2)
-      *reinterpret_cast<u32x4 *>(lds + row * 128 + ((((c >> 1) ^ fv_swz(row))) << 5) + ((c & 1) << 4)) = v;
-    else
-      *reinterpret_cast<u32x4 *>(lds + row * 272 + (c << 4)) = v;
-  }
+
+// row fragment: token `row`, 64-byte block kb across d.
+template <typename T> __device__ __forceinline__ u32x4 frag_row(const char *lds, int row, int kb, int lane) {
+  return *reinterpret_cast<const u32x4 *>(lds + img_off<T>(row, kb * 4 + (lane >> 4)));
 }
-// fragment of a k-contiguous image: tile row `row`, 64-byte block kb
-template <typename T> __device__ __forceinline__ u32x4 lds_frag_k(const char *lds, int row, int kb, int lane) {
-  using L = AttnLayout<T>;
-  const int chunk = kb * 4 + (lane >> 4);
-  return *reinterpret_cast<const u32x4 *>(lds + row * L::RB + ((chunk ^ (row & (L::CPRW - 1))) << 4));
-}
-// fragment of a transposed-read image: columns d0..d0+15, contraction block kb
-template <typename T> __device__ __forceinline__ u32x4 lds_frag_m(const char *lds, int d0, int kb, int lane);
-template <> __device__ __forceinline__ u32x4 lds_frag_m<bf16_t>(const char *lds, int d0, int kb, int lane) {
+// transposed fragment: columns d0..d0+15, contraction block m over tokens, in the order the
+// register-resident P/dS fragments use: bf16 slot j of lane group g = token 32m + 4g + 16(j>>2) + (j&3);
+// fp32 slot j = token 16m + 4g + j.
+template <typename T> __device__ __forceinline__ u32x4 frag_tr(const char *lds, int d0, int m, int lane);
+template <> __device__ __forceinline__ u32x4 frag_tr<bf16_t>(const char *lds, int d0, int m, int lane) {
   const int g = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
   const int d = d0 + 4 * p;
   u32x4 out;
 #pragma unroll
   for (int half = 0; half < 2; ++half) {
-    const int k = kb * 32 + 8 * g + 4 * half + q;
-    const u32x2 w = dm_ds_read_tr16(lds + k * 128 + ((((d >> 4) ^ fv_swz(k))) << 5) + ((d & 15) << 1));
+    const int k = 32 * m + 4 * g + 16 * half + q;
+    const u32x2 w = dm_ds_read_tr16(lds + img_off<bf16_t>(k, d >> 3) + ((d & 7) << 1));
     out[2 * half] = w[0];
     out[2 * half + 1] = w[1];
   }
   return out;
 }
-template <> __device__ __forceinline__ u32x4 lds_frag_m<float>(const char *lds, int d0, int kb, int lane) {
-  const int g = lane >> 4, i = lane & 15;
+template <> __device__ __forceinline__ u32x4 frag_tr<float>(const char *lds, int d0, int m, int lane) {
+  const int g = lane >> 4, d = d0 + (lane & 15);
   u32x4 out;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    const int k = kb * 16 + 4 * g + j;
-    out[j] = *reinterpret_cast<const unsigned int *>(lds + k * 272 + ((d0 + i) << 2));
+    const int k = 16 * m + 4 * g + j;
+    out[j] = *reinterpret_cast<const unsigned int *>(lds + img_off<float>(k, d >> 2) + ((d & 3) << 2));
   }
   return out;
 }
 // fragment straight from global: row pointer `rowp` (64 contiguous d), block kb; zero if !valid
 template <typename T> __device__ __forceinline__ u32x4 gl_frag(const T *rowp, bool valid, int kb, int lane) {
   u32x4 v = {0u, 0u, 0u, 0u};
-  if (valid) v = *reinterpret_cast<const u32x4 *>(rowp + (kb * 4 + (lane >> 4)) * AttnLayout<T>::EPC);
+  if (valid) v = *reinterpret_cast<const u32x4 *>(rowp + (kb * 4 + (lane >> 4)) * AL<T>::EPC);
   return v;
+}
+
+// accumulator tiles -> operand fragment of contraction block m
+template <typename T, int NKT> __device__ __forceinline__ u32x4 acc_frag(const f32x4 (&s)[NKT], int m) {
+  if constexpr (sizeof(T) == 2) {
+    const f32x4 lo = s[2 * m], hi = s[2 * m + 1];
+    bf16x8 r = {(bf16_t)lo[0], (bf16_t)lo[1], (bf16_t)lo[2], (bf16_t)lo[3], (bf16_t)hi[0], (bf16_t)hi[1], (bf16_t)hi[2], (bf16_t)hi[3]};
+    return __builtin_bit_cast(u32x4, r);
+  } else {
+    return __builtin_bit_cast(u32x4, s[m]);
+  }
+}
+
+// out[dt] += sum over tokens of s[row][token] * img[token][d]   (P V, dS K, P^T dO, dS^T Q)
+template <typename T, int NKT>
+__device__ __forceinline__ void contract_tokens(f32x4 (&o)[4], const f32x4 (&s)[NKT], const char *img, int lane) {
+#pragma unroll
+  for (int m = 0; m < NKT / AL<T>::TPB; ++m) {
+    const u32x4 fp = acc_frag<T, NKT>(s, m);
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) mma<T>(o[dt], fp, frag_tr<T>(img, dt * 16, m, lane));
+    if ((m & 1) == 1) __builtin_amdgcn_sched_barrier(0);
+  }
 }
 
 // reductions over the 4 lane groups that share a row (lanes i, i+16, i+32, i+48)
@@ -114,17 +138,24 @@ __device__ __forceinline__ float row_sum(float v) {
   return v + __shfl_xor(v, 32, 64);
 }
 
-template <typename T> __device__ __forceinline__ void store_row4(char *p, f32x4 v);
-template <> __device__ __forceinline__ void store_row4<float>(char *p, f32x4 v) { *reinterpret_cast<f32x4 *>(p) = v; }
-template <> __device__ __forceinline__ void store_row4<bf16_t>(char *p, f32x4 v) {
-  bf16x4 r = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
-  *reinterpret_cast<bf16x4 *>(p) = r;
+template <typename T> __device__ __forceinline__ float fast_exp(float x);
+template <> __device__ __forceinline__ float fast_exp<float>(float x) { return expf(x); }
+template <> __device__ __forceinline__ float fast_exp<bf16_t>(float x) { return __expf(x); }
+
+// 4 consecutive floats p[i..i+3] with i % 4 == 0; vector load when the row length allows it.
+__device__ __forceinline__ f32x4 load4_guard(const float *p, int i, int n, bool vec) {
+  if (vec) return (i < n) ? dm_load4(p + i) : (f32x4){0.f, 0.f, 0.f, 0.f};  // `vec` is a compile-time constant at every call site
+  f32x4 r;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) r[e] = (i + e < n) ? p[i + e] : 0.f;
+  return r;
 }
 
 struct AttnParams {
   const void *qkv;
-  const float *bias;
-  const void *out;     // forward: written; backward: read
+  const float *bias;    // [H,N,N]  bias[h][q][key]
+  const float *bias_t;  // [H,N,N]  bias_t[h][key][q] or NULL
+  const void *out;      // forward: written; backward: read
   const void *dout;
   float *lse;
   float *delta;
@@ -135,62 +166,84 @@ struct AttnParams {
   float scale;
 };
 
-// Shared score computation: acc[kt] <- scale * (rows x tile^T) + bias, masked; `rows` fragments in
-// `fa` (this wave's 16 rows, KBD blocks), tile in the k-contiguous LDS image.
-// TRANSPOSED = false: rows are queries, columns keys  -> bias[h][row][col]
-// TRANSPOSED = true : rows are keys, columns queries  -> bias[h][col][row]
-template <typename T, int NKT, bool TRANSPOSED>
-__device__ __forceinline__ void scores(f32x4 (&acc)[NKT], const u32x4 (&fa)[AttnLayout<T>::KBD], const char *lds,
-                                       const float *bias_h, int N, int row, float scale, int lane) {
-  using L = AttnLayout<T>;
+// One 16x16 score tile: a[r] = scale * (this wave's row) . (tile row 16kt+4g+r) + bias_rows[row][col];
+// entries with row >= N or col >= N become -inf.  bias_rows is indexed [row*N + col]; when `strided`
+// it is indexed [col*N + row] instead (transposed use without a transposed copy).
+template <typename T, bool FAST, bool STRIDED>
+__device__ __forceinline__ f32x4 score_tile(const u32x4 (&fa)[AL<T>::KBD], const char *img, const float *bias_rows,
+                                            int N, int row, float scale, int lane, int kt) {
+  using L = AL<T>;
   const int g = lane >> 4, li = lane & 15;
+  constexpr bool vec = FAST;
+  f32x4 a = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int kt = 0; kt < NKT; ++kt) {
-    f32x4 a = {0.f, 0.f, 0.f, 0.f};
+  for (int kb = 0; kb < L::KBD; ++kb) mma<T>(a, fa[kb], frag_row<T>(img, kt * 16 + li, kb, lane));
+  const int col = kt * 16 + 4 * g;
+  f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+  if (bias_rows && row < N) {
+    if constexpr (!STRIDED) {
+      bv = load4_guard(bias_rows + (long long)row * N, col, N, vec);
+    } else {
 #pragma unroll
-    for (int kb = 0; kb < L::KBD; ++kb) mma<T>(a, fa[kb], lds_frag_k<T>(lds, kt * 16 + li, kb, lane));
-    const int col = kt * 16 + 4 * g;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      float s = a[r] * scale;
-      const bool ok = (row < N) && (col + r < N);
-      if (bias_h && ok) s += TRANSPOSED ? bias_h[(long long)(col + r) * N + row] : bias_h[(long long)row * N + col + r];
-      a[r] = ok ? s : -INFINITY;
+      for (int r = 0; r < 4; ++r) bv[r] = (col + r < N) ? bias_rows[(long long)(col + r) * N + row] : 0.f;
     }
-    acc[kt] = a;
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) a[r] = (row < N && col + r < N) ? a[r] * scale + bv[r] : -INFINITY;
+  return a;
+}
+
+// pack TPB accumulator tiles (tokens 16*TPB*m ...) into the operand fragment of contraction block m
+template <typename T> __device__ __forceinline__ u32x4 pack_tiles(const f32x4 (&tl)[AL<T>::TPB]) {
+  if constexpr (sizeof(T) == 2) {
+    bf16x8 r = {(bf16_t)tl[0][0], (bf16_t)tl[0][1], (bf16_t)tl[0][2], (bf16_t)tl[0][3],
+                (bf16_t)tl[1][0], (bf16_t)tl[1][1], (bf16_t)tl[1][2], (bf16_t)tl[1][3]};
+    return __builtin_bit_cast(u32x4, r);
+  } else {
+    return __builtin_bit_cast(u32x4, tl[0]);
+  }
+}
+
+// out[dt] += sum over tokens of frag[row][token] * img[token][d], fragments already packed
+template <typename T, int NB>
+__device__ __forceinline__ void contract_frags(f32x4 (&o)[4], const u32x4 (&f)[NB], const char *img, int lane) {
+#pragma unroll
+  for (int m = 0; m < NB; ++m) {
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) mma<T>(o[dt], f[m], frag_tr<T>(img, dt * 16, m, lane));
+    if ((m & 1) == 1) __builtin_amdgcn_sched_barrier(0);   // bound how many transposed reads are in flight (VGPRs)
   }
 }
 
 // =============================================================================================
 // forward
 // =============================================================================================
-template <typename T, int NKT>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
-  using L = AttnLayout<T>;
+template <typename T, int NKT, bool FAST>
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
+  using L = AL<T>;
   constexpr int NK = NKT * 16;
-  constexpr int KV_BYTES = NK * (L::RB > L::MROW ? L::RB : L::MROW);
-  constexpr int PS = NK * (int)sizeof(T) + 16;     // P row stride (bytes)
-  constexpr int NKBP = NK * (int)sizeof(T) / 64;   // 64-byte blocks along keys
-  __shared__ __attribute__((aligned(16))) char smem[KV_BYTES + 4 * 16 * PS];
-  char *kv = smem;
+  constexpr int IMG = NK * L::RB;
+  __shared__ __attribute__((aligned(16))) char smem[2 * IMG];
+  char *kimg = smem, *vimg = smem + IMG;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, g = lane >> 4, li = lane & 15;
   const int qblk = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
   const int N = p.N, H = p.H;
-  char *pw = smem + KV_BYTES + wave * 16 * PS;
 
   const long long tok_stride = 3LL * H * HD;
   const T *base = reinterpret_cast<const T *>(p.qkv) + (long long)b * N * tok_stride + (long long)h * HD;
-  const T *Kg = base + (long long)H * HD, *Vg = base + 2LL * H * HD;
   const int q = qblk * QB + wave * 16 + li;
 
-  tile_to_lds_k<T>(kv, Kg, tok_stride, N, NK, t);
+  tile_to_lds<T>(kimg, base + (long long)H * HD, tok_stride, N, NK, t);
+  tile_to_lds<T>(vimg, base + 2LL * H * HD, tok_stride, N, NK, t);
   u32x4 fq[L::KBD];
 #pragma unroll
   for (int kb = 0; kb < L::KBD; ++kb) fq[kb] = gl_frag<T>(base + (long long)q * tok_stride, q < N, kb, lane);
   __syncthreads();
 
   f32x4 s[NKT];
-  scores<T, NKT, false>(s, fq, kv, p.bias ? p.bias + (long long)h * N * N : nullptr, N, q, p.scale, lane);
+  const float *brows = p.bias ? p.bias + (long long)h * N * N : nullptr;
+#pragma unroll
+  for (int kt = 0; kt < NKT; ++kt) s[kt] = score_tile<T, FAST, false>(fq, kimg, brows, N, q, p.scale, lane, kt);
 
   float m = -INFINITY;
 #pragma unroll
@@ -204,7 +257,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
   for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const float e = expf(s[kt][r] - msafe);
+      const float e = fast_exp<T>(s[kt][r] - msafe);
       s[kt][r] = e;
       l += e;
     }
@@ -212,21 +265,12 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
   const float inv = (l > 0.f) ? 1.f / l : 0.f;
   if (g == 0 && q < N) p.lse[((long long)b * H + h) * N + q] = msafe + logf(l);
 #pragma unroll
-  for (int kt = 0; kt < NKT; ++kt) store_row4<T>(pw + li * PS + (kt * 16 + 4 * g) * (int)sizeof(T), s[kt] * inv);
-
-  __syncthreads();   // every wave is done reading the K image
-  tile_to_lds_m<T>(kv, Vg, tok_stride, N, NK, t);
-  __syncthreads();
+  for (int kt = 0; kt < NKT; ++kt) s[kt] *= inv;
 
   f32x4 o[4];
 #pragma unroll
   for (int dt = 0; dt < 4; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int kb = 0; kb < NKBP; ++kb) {
-    const u32x4 fp = *reinterpret_cast<const u32x4 *>(pw + li * PS + (kb * 4 + g) * 16);
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt) mma<T>(o[dt], fp, lds_frag_m<T>(kv, dt * 16, kb, lane));
-  }
+  contract_tokens<T, NKT>(o, s, vimg, lane);
   if (q < N) {
     T *orow = reinterpret_cast<T *>(const_cast<void *>(p.out)) + ((long long)b * N + q) * H * HD + (long long)h * HD;
 #pragma unroll
@@ -237,24 +281,20 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
 // =============================================================================================
 // backward, dQ + delta + bias-gradient histogram
 // =============================================================================================
-template <typename T, int NKT>
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnParams p) {
-  using L = AttnLayout<T>;
+template <typename T, int NKT, bool FAST>
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnParams p) {
+  using L = AL<T>;
   constexpr int NK = NKT * 16;
-  constexpr int KV_BYTES = NK * (L::RB > L::MROW ? L::RB : L::MROW);
-  constexpr int PS = NK * (int)sizeof(T) + 16;
-  constexpr int NKBP = NK * (int)sizeof(T) / 64;
-  __shared__ __attribute__((aligned(16))) char smem[KV_BYTES + 4 * 16 * PS];
-  __shared__ float bins[MAX_BINS];
-  char *kv = smem;
+  constexpr int IMG = NK * L::RB;
+  __shared__ __attribute__((aligned(16))) char smem[2 * IMG];
+  extern __shared__ float bins[];     // n_bins floats (dynamic), only when the bias gradient is wanted
+  char *kimg = smem, *vimg = smem + IMG;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, g = lane >> 4, li = lane & 15;
   const int qblk = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
   const int N = p.N, H = p.H;
-  char *pw = smem + KV_BYTES + wave * 16 * PS;
 
   const long long tok_stride = 3LL * H * HD;
   const T *base = reinterpret_cast<const T *>(p.qkv) + (long long)b * N * tok_stride + (long long)h * HD;
-  const T *Kg = base + (long long)H * HD, *Vg = base + 2LL * H * HD;
   const int q = qblk * QB + wave * 16 + li;
   const bool qok = q < N;
   const long long orow = ((long long)b * N + q) * H * HD + (long long)h * HD;
@@ -263,7 +303,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnParams p) {
 
   if (p.index)
     for (int i = t; i < p.n_bins; i += 256) bins[i] = 0.f;
-  tile_to_lds_k<T>(kv, Kg, tok_stride, N, NK, t);
+  tile_to_lds<T>(kimg, base + (long long)H * HD, tok_stride, N, NK, t);
+  tile_to_lds<T>(vimg, base + 2LL * H * HD, tok_stride, N, NK, t);
   u32x4 fq[L::KBD], fdo[L::KBD];
 #pragma unroll
   for (int kb = 0; kb < L::KBD; ++kb) {
@@ -285,86 +326,83 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnParams p) {
   const float lse = qok ? p.lse[rowid] : 0.f;
   __syncthreads();
 
-  f32x4 s[NKT];
-  scores<T, NKT, false>(s, fq, kv, p.bias ? p.bias + (long long)h * N * N : nullptr, N, q, p.scale, lane);
+  constexpr int NB = NKT / L::TPB;
+  u32x4 fds[NB];
+  const float *brows = p.bias ? p.bias + (long long)h * N * N : nullptr;
+  constexpr bool vec = FAST;
 #pragma unroll
-  for (int kt = 0; kt < NKT; ++kt)
+  for (int m = 0; m < NB; ++m) {
+    f32x4 tl[L::TPB];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) s[kt][r] = expf(s[kt][r] - lse);   // masked entries: exp(-inf) = 0
-
-  __syncthreads();
-  tile_to_lds_k<T>(kv, Vg, tok_stride, N, NK, t);
-  __syncthreads();
-
-  // dS = P * (dP - delta), dP = dO V^T
+    for (int u = 0; u < L::TPB; ++u) {
+      const int kt = m * L::TPB + u;
+      const f32x4 sc = score_tile<T, FAST, false>(fq, kimg, brows, N, q, p.scale, lane, kt);
+      // dP = dO V^T for this tile, then dS = P * (dP - delta)
+      f32x4 a = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int kt = 0; kt < NKT; ++kt) {
-    f32x4 a = {0.f, 0.f, 0.f, 0.f};
+      for (int kb = 0; kb < L::KBD; ++kb) mma<T>(a, fdo[kb], frag_row<T>(vimg, kt * 16 + li, kb, lane));
+      f32x4 dsv;
 #pragma unroll
-    for (int kb = 0; kb < L::KBD; ++kb) mma<T>(a, fdo[kb], lds_frag_k<T>(kv, kt * 16 + li, kb, lane));
+      for (int r = 0; r < 4; ++r) dsv[r] = fast_exp<T>(sc[r] - lse) * (a[r] - dl);   // masked: exp(-inf) = 0
+      if (p.index && qok) {
+        const int key = kt * 16 + 4 * g;
+        if (vec) {
+          if (key < N) {
+            const int *ip = p.index + (long long)q * N + key;
+            const int b0 = ip[0], b1 = ip[1], b2 = ip[2], b3 = ip[3];
+            if ((unsigned)b0 < (unsigned)p.n_bins) atomicAdd(&bins[b0], dsv[0]);
+            if ((unsigned)b1 < (unsigned)p.n_bins) atomicAdd(&bins[b1], dsv[1]);
+            if ((unsigned)b2 < (unsigned)p.n_bins) atomicAdd(&bins[b2], dsv[2]);
+            if ((unsigned)b3 < (unsigned)p.n_bins) atomicAdd(&bins[b3], dsv[3]);
+          }
+        } else {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) s[kt][r] = s[kt][r] * (a[r] - dl);
-  }
-  if (p.index && qok) {
-#pragma unroll
-    for (int kt = 0; kt < NKT; ++kt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int key = kt * 16 + 4 * g + r;
-        if (key < N) {
-          const int bin = p.index[(long long)q * N + key];
-          if (bin >= 0 && bin < p.n_bins) atomicAdd(&bins[bin], s[kt][r]);
+          for (int r = 0; r < 4; ++r)
+            if (key + r < N) {
+              const int bin = p.index[(long long)q * N + key + r];
+              if ((unsigned)bin < (unsigned)p.n_bins) atomicAdd(&bins[bin], dsv[r]);
+            }
         }
       }
+      tl[u] = dsv;
+    }
+    fds[m] = pack_tiles<T>(tl);
+    asm volatile("" : "+v"(fds[m]));
+    __builtin_amdgcn_sched_barrier(0);
   }
-#pragma unroll
-  for (int kt = 0; kt < NKT; ++kt) store_row4<T>(pw + li * PS + (kt * 16 + 4 * g) * (int)sizeof(T), s[kt]);
-
-  __syncthreads();
-  tile_to_lds_m<T>(kv, Kg, tok_stride, N, NK, t);
-  __syncthreads();
 
   f32x4 o[4];
 #pragma unroll
   for (int dt = 0; dt < 4; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int kb = 0; kb < NKBP; ++kb) {
-    const u32x4 fp = *reinterpret_cast<const u32x4 *>(pw + li * PS + (kb * 4 + g) * 16);
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt) mma<T>(o[dt], fp, lds_frag_m<T>(kv, dt * 16, kb, lane));
-  }
+  contract_frags<T, NB>(o, fds, kimg, lane);
   if (qok) {
     T *dq = reinterpret_cast<T *>(p.dqkv) + ((long long)b * N + q) * tok_stride + (long long)h * HD;
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) dm_store4(dq + dt * 16 + 4 * g, o[dt] * p.scale);
   }
   if (p.index) {
-    // bins are complete once every wave passed the barrier above (all atomics precede it)
+    __syncthreads();   // all histogram atomics of the workgroup are done
     float *srow = p.slab + (((long long)b * H + h) * p.nblk + qblk) * p.n_bins;
     for (int i = t; i < p.n_bins; i += 256) srow[i] = bins[i];
   }
 }
 
 // =============================================================================================
-// backward, dK + dV
+// backward, dK + dV  (rows of the workgroup are KEYS; columns are queries)
 // =============================================================================================
-template <typename T, int NKT>
-__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnParams p) {
-  using L = AttnLayout<T>;
-  constexpr int NK = NKT * 16;   // padded number of QUERIES here (columns)
-  constexpr int KV_BYTES = NK * (L::RB > L::MROW ? L::RB : L::MROW);
-  constexpr int PS = NK * (int)sizeof(T) + 16;
-  constexpr int NKBP = NK * (int)sizeof(T) / 64;
-  __shared__ __attribute__((aligned(16))) char smem[KV_BYTES + 4 * 16 * PS];
-  char *qd = smem;
+template <typename T, int NKT, bool FAST>
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnParams p) {
+  using L = AL<T>;
+  constexpr int NK = NKT * 16;
+  constexpr int IMG = NK * L::RB;
+  __shared__ __attribute__((aligned(16))) char smem[2 * IMG];
+  char *qimg = smem, *doimg = smem + IMG;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, g = lane >> 4, li = lane & 15;
   const int kblk = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
   const int N = p.N, H = p.H;
-  char *pw = smem + KV_BYTES + wave * 16 * PS;
 
   const long long tok_stride = 3LL * H * HD;
   const T *base = reinterpret_cast<const T *>(p.qkv) + (long long)b * N * tok_stride + (long long)h * HD;
-  const T *Qg = base;
   const long long o_stride = (long long)H * HD;
   const T *dOg = reinterpret_cast<const T *>(p.dout) + (long long)b * N * o_stride + (long long)h * HD;
   const int key = kblk * QB + wave * 16 + li;
@@ -374,7 +412,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnParams p) {
   const float *lse = p.lse + ((long long)b * H + h) * N;
   const float *delta = p.delta + ((long long)b * H + h) * N;
 
-  tile_to_lds_k<T>(qd, Qg, tok_stride, N, NK, t);
+  tile_to_lds<T>(qimg, base, tok_stride, N, NK, t);
+  tile_to_lds<T>(doimg, dOg, o_stride, N, NK, t);
   u32x4 fk[L::KBD], fvv[L::KBD];
 #pragma unroll
   for (int kb = 0; kb < L::KBD; ++kb) {
@@ -383,68 +422,53 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnParams p) {
   }
   __syncthreads();
 
-  // P^T[key][q] = exp(scale * K Q^T + bias[q][key] - lse[q])
-  f32x4 s[NKT];
-  scores<T, NKT, true>(s, fk, qd, p.bias ? p.bias + (long long)h * N * N : nullptr, N, key, p.scale, lane);
+  // P^T[key][q] = exp(scale * K Q^T + bias[q][key] - lse[q]);   dS^T = P^T * (V dO^T - delta[q])
+  constexpr int NB = NKT / L::TPB;
+  u32x4 fpt[NB], fds[NB];
+  // FAST: N % 4 == 0 and a transposed bias copy is available -> vector loads everywhere;
+  // otherwise the generic form reads `bias` with a stride and lse/delta element-wise.
+  const float *bsrc = FAST ? p.bias_t : p.bias;
+  const float *brows = bsrc ? bsrc + (long long)h * N * N : nullptr;
+  constexpr bool vec = FAST;
 #pragma unroll
-  for (int qt = 0; qt < NKT; ++qt)
+  for (int m = 0; m < NB; ++m) {
+    f32x4 tp[L::TPB], td[L::TPB];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int qq = qt * 16 + 4 * g + r;
-      s[qt][r] = (qq < N) ? expf(s[qt][r] - lse[qq]) : 0.f;
+    for (int u = 0; u < L::TPB; ++u) {
+      const int qt = m * L::TPB + u;
+      const int q0 = qt * 16 + 4 * g;
+      const f32x4 sc = score_tile<T, FAST, !FAST>(fk, qimg, brows, N, key, p.scale, lane, qt);
+      const f32x4 lv = load4_guard(lse, q0, N, vec), dv = load4_guard(delta, q0, N, vec);
+      f32x4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kb = 0; kb < L::KBD; ++kb) mma<T>(a, fvv[kb], frag_row<T>(doimg, qt * 16 + li, kb, lane));
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float pv = (q0 + r < N) ? fast_exp<T>(sc[r] - lv[r]) : 0.f;
+        tp[u][r] = pv;
+        td[u][r] = pv * (a[r] - dv[r]);
+      }
     }
-  // stash P^T (operand dtype) for dV = P^T dO
-#pragma unroll
-  for (int qt = 0; qt < NKT; ++qt) store_row4<T>(pw + li * PS + (qt * 16 + 4 * g) * (int)sizeof(T), s[qt]);
-
-  __syncthreads();
-  tile_to_lds_k<T>(qd, dOg, o_stride, N, NK, t);
-  __syncthreads();
-  // dS^T = P^T * (dP^T - delta[q]),  dP^T[key][q] = V dO^T
-#pragma unroll
-  for (int qt = 0; qt < NKT; ++qt) {
-    f32x4 a = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int kb = 0; kb < L::KBD; ++kb) mma<T>(a, fvv[kb], lds_frag_k<T>(qd, qt * 16 + li, kb, lane));
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int qq = qt * 16 + 4 * g + r;
-      const float dlt = (qq < N) ? delta[qq] : 0.f;
-      s[qt][r] = s[qt][r] * (a[r] - dlt);
-    }
+    fpt[m] = pack_tiles<T>(tp);
+    fds[m] = pack_tiles<T>(td);
+    // Pin the packed fragments HERE: otherwise the optimiser sinks exp/pack of every block down to the
+    // contractions below and keeps all raw score tiles + loaded bias/lse/delta alive (>256 VGPRs, spills).
+    asm volatile("" : "+v"(fpt[m]), "+v"(fds[m]));
+    __builtin_amdgcn_sched_barrier(0);
   }
-  __syncthreads();
-  tile_to_lds_m<T>(qd, dOg, o_stride, N, NK, t);
-  __syncthreads();
   f32x4 o[4];
+  T *dk = reinterpret_cast<T *>(p.dqkv) + ((long long)b * N + key) * tok_stride + (long long)H * HD + (long long)h * HD;
+  T *dvp = dk + (long long)H * HD;
 #pragma unroll
   for (int dt = 0; dt < 4; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int kb = 0; kb < NKBP; ++kb) {
-    const u32x4 fp = *reinterpret_cast<const u32x4 *>(pw + li * PS + (kb * 4 + g) * 16);
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt) mma<T>(o[dt], fp, lds_frag_m<T>(qd, dt * 16, kb, lane));
-  }
-  T *dk = reinterpret_cast<T *>(p.dqkv) + ((long long)b * N + key) * tok_stride + (long long)H * HD + (long long)h * HD;
-  T *dv = dk + (long long)H * HD;
+  contract_frags<T, NB>(o, fpt, doimg, lane);            // dV = P^T dO
   if (kok) {
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt) dm_store4(dv + dt * 16 + 4 * g, o[dt]);
+    for (int dt = 0; dt < 4; ++dt) dm_store4(dvp + dt * 16 + 4 * g, o[dt]);
   }
-  // dK = scale * dS^T Q  (P region is wave-private: its reads above are complete for this wave)
-#pragma unroll
-  for (int qt = 0; qt < NKT; ++qt) store_row4<T>(pw + li * PS + (qt * 16 + 4 * g) * (int)sizeof(T), s[qt]);
-  __syncthreads();
-  tile_to_lds_m<T>(qd, Qg, tok_stride, N, NK, t);
-  __syncthreads();
 #pragma unroll
   for (int dt = 0; dt < 4; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int kb = 0; kb < NKBP; ++kb) {
-    const u32x4 fp = *reinterpret_cast<const u32x4 *>(pw + li * PS + (kb * 4 + g) * 16);
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt) mma<T>(o[dt], fp, lds_frag_m<T>(qd, dt * 16, kb, lane));
-  }
+  contract_frags<T, NB>(o, fds, qimg, lane);             // dK = scale * dS^T Q
   if (kok) {
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) dm_store4(dk + dt * 16 + 4 * g, o[dt] * p.scale);
@@ -452,20 +476,27 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnParams p) {
 }
 
 // ---- dispatch -----------------------------------------------------------------------------------
-template <typename T, int NKT> void launch3(int which, const AttnParams &p, dim3 grid, hipStream_t s) {
-  if (which == 0) hipLaunchKernelGGL((attn_fwd_kernel<T, NKT>), grid, dim3(256), 0, s, p);
-  else if (which == 1) hipLaunchKernelGGL((attn_bwd_dq_kernel<T, NKT>), grid, dim3(256), 0, s, p);
-  else hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, NKT>), grid, dim3(256), 0, s, p);
+template <typename T, int NKT, bool FAST> void launch3(int which, const AttnParams &p, dim3 grid, hipStream_t s) {
+  if (which == 0) hipLaunchKernelGGL((attn_fwd_kernel<T, NKT, FAST>), grid, dim3(256), 0, s, p);
+  else if (which == 1) hipLaunchKernelGGL((attn_bwd_dq_kernel<T, NKT, FAST>), grid, dim3(256), p.index ? p.n_bins * sizeof(float) : 0, s, p);
+  else hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, NKT, FAST>), grid, dim3(256), 0, s, p);
 }
-template <typename T> int dispatch(int which, const AttnParams &p, hipStream_t s) {
+template <typename T, bool FAST> void dispatch_nkt(int which, const AttnParams &p, hipStream_t s) {
   const dim3 grid((p.N + QB - 1) / QB, p.H, p.B);
   const int nkt = (p.N + 15) / 16;
-  if (nkt <= 2) launch3<T, 2>(which, p, grid, s);
-  else if (nkt <= 4) launch3<T, 4>(which, p, grid, s);
-  else if (nkt <= 8) launch3<T, 8>(which, p, grid, s);
-  else if (nkt <= 12) launch3<T, 12>(which, p, grid, s);
-  else if (nkt <= 14) launch3<T, 14>(which, p, grid, s);
-  else launch3<T, 16>(which, p, grid, s);
+  if (nkt <= 2) launch3<T, 2, FAST>(which, p, grid, s);
+  else if (nkt <= 4) launch3<T, 4, FAST>(which, p, grid, s);
+  else if (nkt <= 8) launch3<T, 8, FAST>(which, p, grid, s);
+  else if (nkt <= 12) launch3<T, 12, FAST>(which, p, grid, s);
+  else if (nkt <= 14) launch3<T, 14, FAST>(which, p, grid, s);
+  else launch3<T, 16, FAST>(which, p, grid, s);
+}
+template <typename T> int dispatch(int which, const AttnParams &p, hipStream_t s) {
+  // fast form: rows are a multiple of 4 tokens (vector loads of bias / lse / delta / index) and, for the
+  // key-major kernel, either no bias or a transposed bias copy.
+  const bool fast = (p.N % 4 == 0) && (which != 2 || p.bias == nullptr || p.bias_t != nullptr);
+  if (fast) dispatch_nkt<T, true>(which, p, s);
+  else dispatch_nkt<T, false>(which, p, s);
   return 0;
 }
 
@@ -485,7 +516,7 @@ extern "C" int dm_attention_fwd(const void *qkv, const float *bias, void *out, f
                                 int32_t D, float scale, int32_t dtype, void *stream) {
   if (int rc = check_common("dm_attention_fwd", B, N, H, D, dtype)) return rc;
   DM_REQUIRE(qkv && out && lse, DM_ERR_BAD_SHAPE, "dm_attention_fwd: null pointer");
-  DM_REQUIRE(dm_aligned16(qkv) && dm_aligned16(out), DM_ERR_BAD_ALIGN, "dm_attention_fwd: qkv/out must be 16-byte aligned");
+  DM_REQUIRE(dm_aligned16(qkv) && dm_aligned16(out) && dm_aligned16(bias), DM_ERR_BAD_ALIGN, "dm_attention_fwd: qkv/out/bias must be 16-byte aligned");
   AttnParams p{};
   p.qkv = qkv; p.bias = bias; p.out = out; p.lse = lse; p.B = B; p.N = N; p.H = H; p.scale = scale;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
@@ -499,18 +530,20 @@ extern "C" int dm_attention_fwd(const void *qkv, const float *bias, void *out, f
   return DM_OK;
 }
 
-extern "C" int dm_attention_bwd(const void *qkv, const float *bias, const void *out, const void *dout, const float *lse,
-                                void *dqkv, float *delta, const int32_t *index, int32_t n_bins, float *dtable_slab,
-                                int32_t B, int32_t N, int32_t H, int32_t D, float scale, int32_t dtype, void *stream) {
+extern "C" int dm_attention_bwd(const void *qkv, const float *bias, const float *bias_t, const void *out, const void *dout,
+                                const float *lse, void *dqkv, float *delta, const int32_t *index, int32_t n_bins,
+                                float *dtable_slab, int32_t B, int32_t N, int32_t H, int32_t D, float scale, int32_t dtype,
+                                void *stream) {
   if (int rc = check_common("dm_attention_bwd", B, N, H, D, dtype)) return rc;
   DM_REQUIRE(qkv && out && dout && lse && dqkv && delta, DM_ERR_BAD_SHAPE, "dm_attention_bwd: null pointer");
-  DM_REQUIRE(dm_aligned16(qkv) && dm_aligned16(out) && dm_aligned16(dout) && dm_aligned16(dqkv), DM_ERR_BAD_ALIGN,
+  DM_REQUIRE(dm_aligned16(qkv) && dm_aligned16(out) && dm_aligned16(dout) && dm_aligned16(dqkv) && dm_aligned16(bias) &&
+             dm_aligned16(bias_t) && dm_aligned16(lse) && dm_aligned16(delta) && dm_aligned16(index), DM_ERR_BAD_ALIGN,
              "dm_attention_bwd: tensors must be 16-byte aligned");
   DM_REQUIRE(index == nullptr || (dtable_slab != nullptr && n_bins > 0 && n_bins <= MAX_BINS), DM_ERR_BAD_SHAPE,
              "dm_attention_bwd: bias gradient needs a slab and 0 < n_bins <= %d (got %d)", MAX_BINS, n_bins);
   AttnParams p{};
-  p.qkv = qkv; p.bias = bias; p.out = out; p.dout = dout; p.lse = const_cast<float *>(lse); p.delta = delta; p.dqkv = dqkv;
-  p.index = index; p.slab = dtable_slab; p.n_bins = n_bins; p.nblk = (N + QB - 1) / QB;
+  p.qkv = qkv; p.bias = bias; p.bias_t = bias ? bias_t : nullptr; p.out = out; p.dout = dout; p.lse = const_cast<float *>(lse);
+  p.delta = delta; p.dqkv = dqkv; p.index = index; p.slab = dtable_slab; p.n_bins = n_bins; p.nblk = (N + QB - 1) / QB;
   p.B = B; p.N = N; p.H = H; p.scale = scale;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   {

@@ -338,11 +338,18 @@ __global__ void adam_kernel(float *__restrict__ param, const float *__restrict__
 // relative-position bias: gather and gradient reduction
 // ---------------------------------------------------------------------------------------------
 __global__ void relpos_gather_kernel(const float *__restrict__ table, const int *__restrict__ index,
-                                     float *__restrict__ bias, int NN, int H, int n_bins) {
+                                     float *__restrict__ bias, float *__restrict__ bias_t, int N, int H, int n_bins) {
+  const int NN = N * N;
   for (int ij = blockIdx.x * blockDim.x + threadIdx.x; ij < NN; ij += gridDim.x * blockDim.x) {
     int bin = index[ij];
     bin = min(max(bin, 0), n_bins - 1);
     for (int h = 0; h < H; ++h) bias[(long long)h * NN + ij] = table[bin * H + h];
+    if (bias_t) {   // second pass with the roles of i and j swapped keeps both stores coalesced
+      const int i = ij / N, j = ij % N;
+      int bt = index[j * N + i];
+      bt = min(max(bt, 0), n_bins - 1);
+      for (int h = 0; h < H; ++h) bias_t[(long long)h * NN + ij] = table[bt * H + h];
+    }
   }
 }
 __global__ __launch_bounds__(256) void relpos_scatter_kernel(const float *__restrict__ slab, float *__restrict__ dtable, int B, int H,
@@ -506,10 +513,10 @@ extern "C" int dm_adam_step(float *param, const float *grad, float *m, float *v,
   return DM_OK;
 }
 
-extern "C" int dm_relpos_bias_gather(const float *table, const int32_t *index, float *bias, int32_t N, int32_t H,
+extern "C" int dm_relpos_bias_gather(const float *table, const int32_t *index, float *bias, float *bias_t, int32_t N, int32_t H,
                                      int32_t n_bins, void *stream) {
   DM_REQUIRE(table && index && bias && N > 0 && H > 0 && n_bins > 0, DM_ERR_BAD_SHAPE, "dm_relpos_bias_gather: bad arguments");
-  hipLaunchKernelGGL(relpos_gather_kernel, dim3(grid_for((long long)N * N)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), table, index, bias, N * N, H, n_bins);
+  hipLaunchKernelGGL(relpos_gather_kernel, dim3(grid_for((long long)N * N)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), table, index, bias, bias_t, N, H, n_bins);
   DM_LAUNCH_CHECK("dm_relpos_bias_gather");
   return DM_OK;
 }

@@ -160,13 +160,15 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dres=None, dgamma=None, dbeta=None, 
     return dx, dgamma, dbeta
 
 
-def relpos_bias_gather(table: torch.Tensor, index32: torch.Tensor, N: int) -> torch.Tensor:
+def relpos_bias_gather(table: torch.Tensor, index32: torch.Tensor, N: int, transposed: bool = False):
+    """Dense bias [H,N,N]; with transposed=True also its per-head transpose -> (bias, bias_t)."""
     _need_cuda(table, index32)
     n_bins, H = table.shape
     bias = torch.empty((H, N, N), dtype=torch.float32, device=table.device)
-    check(_lib.lib().dm_relpos_bias_gather(table.data_ptr(), index32.data_ptr(), bias.data_ptr(), N, H, n_bins, _stream()),
+    bias_t = torch.empty_like(bias) if transposed else None
+    check(_lib.lib().dm_relpos_bias_gather(table.data_ptr(), index32.data_ptr(), bias.data_ptr(), _ptr(bias_t), N, H, n_bins, _stream()),
           "dm_relpos_bias_gather")
-    return bias
+    return (bias, bias_t) if transposed else bias
 
 
 def attention_fwd(qkv: torch.Tensor, bias: Optional[torch.Tensor], B: int, N: int, H: int, D: int, scale: float):
@@ -178,7 +180,7 @@ def attention_fwd(qkv: torch.Tensor, bias: Optional[torch.Tensor], B: int, N: in
     return out, lse
 
 
-def attention_bwd(qkv, bias, out, dout, lse, B, N, H, D, scale, index32=None, n_bins=0):
+def attention_bwd(qkv, bias, out, dout, lse, B, N, H, D, scale, index32=None, n_bins=0, bias_t=None):
     _need_cuda(qkv, out, dout, lse)
     dqkv = torch.empty_like(qkv)
     delta = torch.empty((B, H, N), dtype=torch.float32, device=qkv.device)
@@ -186,7 +188,7 @@ def attention_bwd(qkv, bias, out, dout, lse, B, N, H, D, scale, index32=None, n_
     rows = _lib.lib().dm_attention_bwd_slab_rows(N)
     if index32 is not None:
         slab = torch.empty((B * H * rows, n_bins), dtype=torch.float32, device=qkv.device)
-    check(_lib.lib().dm_attention_bwd(qkv.data_ptr(), _ptr(bias), out.data_ptr(), dout.data_ptr(), lse.data_ptr(), dqkv.data_ptr(),
+    check(_lib.lib().dm_attention_bwd(qkv.data_ptr(), _ptr(bias), _ptr(bias_t), out.data_ptr(), dout.data_ptr(), lse.data_ptr(), dqkv.data_ptr(),
                                       delta.data_ptr(), _ptr(index32), n_bins, _ptr(slab), B, N, H, D, scale, _dt(qkv), _stream()),
           "dm_attention_bwd")
     return dqkv, slab, rows
@@ -357,19 +359,21 @@ class AttentionFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, qkv, table, index32, B, N, H, D, scale):
         qkv = qkv.contiguous()
-        bias = relpos_bias_gather(table.contiguous(), index32, N) if table is not None else None
+        bias = bias_t = None
+        if table is not None:
+            bias, bias_t = relpos_bias_gather(table.contiguous(), index32, N, transposed=True)
         out, lse = attention_fwd(qkv, bias, B, N, H, D, scale)
-        ctx.save_for_backward(qkv, out, lse, bias, index32)
+        ctx.save_for_backward(qkv, out, lse, bias, bias_t, index32)
         ctx.dims = (B, N, H, D, scale, None if table is None else table.shape[0])
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        qkv, out, lse, bias, index32 = ctx.saved_tensors
+        qkv, out, lse, bias, bias_t, index32 = ctx.saved_tensors
         B, N, H, D, scale, n_bins = ctx.dims
         want_table = bias is not None and ctx.needs_input_grad[1]
         dqkv, slab, rows = attention_bwd(qkv, bias, out, _as_operand(dout, qkv.dtype), lse, B, N, H, D, scale,
-                                         index32 if want_table else None, n_bins or 0)
+                                         index32 if want_table else None, n_bins or 0, bias_t=bias_t)
         dtable = None
         if want_table:
             dtable = torch.empty((n_bins, H), dtype=torch.float32, device=qkv.device)

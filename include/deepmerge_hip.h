@@ -110,16 +110,20 @@ int dm_attention_fwd(const void *qkv, const float *bias, void *out, float *lse,
 /* Backward: dqkv [B,N,3,H,D] T (fully written).  If index != NULL, the gradient of the bias is
  * binned on the fly: dtable_slab[(b*H+h)*n_qblk + qblk][bin] = sum of dS over (i,j) with
  * index[i,j] == bin (int32 [N,N], values < n_bins), fp32, fully written; reduce it with
- * dm_relpos_bias_scatter.  delta is a [B,H,N] fp32 scratch. */
-int dm_attention_bwd(const void *qkv, const float *bias, const void *out, const void *dout, const float *lse,
-                     void *dqkv, float *delta, const int32_t *index, int32_t n_bins, float *dtable_slab,
-                     int32_t B, int32_t N, int32_t H, int32_t D, float scale, int32_t dtype, void *stream);
+ * dm_relpos_bias_scatter.  delta is a [B,H,N] fp32 scratch.  bias_t (optional) is the per-head
+ * transpose of bias, bias_t[h][key][q], which lets the key-major kernel read the bias with coalesced
+ * vector loads; NULL falls back to strided reads of `bias`. */
+int dm_attention_bwd(const void *qkv, const float *bias, const float *bias_t, const void *out, const void *dout,
+                     const float *lse, void *dqkv, float *delta, const int32_t *index, int32_t n_bins,
+                     float *dtable_slab, int32_t B, int32_t N, int32_t H, int32_t D, float scale, int32_t dtype,
+                     void *stream);
 /* Number of slab rows per (b,h) that dm_attention_bwd writes (query blocks of 64 rows). */
 int32_t dm_attention_bwd_slab_rows(int32_t N);
 
 /* relative_position_bias_table[index.view(-1)].view(N,N,H).permute(2,0,1)
- * (nets/ShfitScaleFormer.py:123-128): table [n_bins,H] fp32, index int32 [N,N] -> bias [H,N,N]. */
-int dm_relpos_bias_gather(const float *table, const int32_t *index, float *bias,
+ * (nets/ShfitScaleFormer.py:123-128): table [n_bins,H] fp32, index int32 [N,N] -> bias [H,N,N] and,
+ * if bias_t != NULL, its per-head transpose bias_t[h][j][i] = bias[h][i][j]. */
+int dm_relpos_bias_gather(const float *table, const int32_t *index, float *bias, float *bias_t,
                           int32_t N, int32_t H, int32_t n_bins, void *stream);
 /* Autograd of that gather: dtable[bin,h] (+)= sum over slab rows r (r = (b*H+h)*rows_per_bh + q)
  * of slab[r][bin]. */

@@ -161,7 +161,7 @@ def _attn_ref(qkv, bias, scale):
 
 
 @pytest.mark.parametrize("mode", ["fp32", "bf16"])
-@pytest.mark.parametrize("N,with_bias", [(12, True), (16, True), (48, True), (64, True), (192, True), (256, True), (197, False), (198, False), (100, True)])
+@pytest.mark.parametrize("N,with_bias", [(12, True), (16, True), (48, True), (64, True), (192, True), (256, True), (197, False), (198, False), (100, True), (37, True), (250, True)])
 def test_attention_forward_backward(mode, N, with_bias):
     ops = _ops()
     rng = np.random.default_rng(N)
@@ -182,10 +182,13 @@ def test_attention_forward_backward(mode, N, with_bias):
     (o_ref * dout.double()).sum().backward()
 
     qd = qkv.to(DEV).to(dt)
-    bias = None
+    bias = bias_t = None
     if with_bias:
-        bias = ops.relpos_bias_gather(table.to(DEV), index.to(DEV), N)
+        bias, bias_t = ops.relpos_bias_gather(table.to(DEV), index.to(DEV), N, transposed=True)
         np.testing.assert_array_equal(bias.cpu().numpy(), bias64.detach().float().numpy())
+        np.testing.assert_array_equal(bias_t.cpu().numpy(), bias64.detach().float().transpose(1, 2).numpy())
+        if N in (48, 192):
+            bias_t = None           # exercise the strided fallback of the key-major kernel too
     out, lse = ops.attention_fwd(qd, bias, B, N, H, D, scale)
     tol = 2e-5 if mode == "fp32" else 2e-2
     np.testing.assert_allclose(lse.cpu().numpy(), lse_ref.detach().numpy(), rtol=1e-4 if mode == "fp32" else 2e-2, atol=1e-4 if mode == "fp32" else 2e-2)
@@ -193,7 +196,7 @@ def test_attention_forward_backward(mode, N, with_bias):
     assert err < tol, f"forward max err {err}"
 
     dqkv, slab, rows = ops.attention_bwd(qd, bias, out, dout.to(DEV).to(dt), lse, B, N, H, D, scale,
-                                         index.to(DEV) if with_bias else None, n_bins if with_bias else 0)
+                                         index.to(DEV) if with_bias else None, n_bins if with_bias else 0, bias_t=bias_t)
     gq = q64.grad
     scale_ref = gq.abs().max().item()
     err = (dqkv.float().cpu().double() - gq).abs().max().item()
