@@ -166,28 +166,33 @@ struct AttnParams {
   float scale;
 };
 
-// One 16x16 score tile: a[r] = scale * (this wave's row) . (tile row 16kt+4g+r) + bias_rows[row][col];
-// entries with row >= N or col >= N become -inf.  bias_rows is indexed [row*N + col]; when `strided`
-// it is indexed [col*N + row] instead (transposed use without a transposed copy).
-template <typename T, bool FAST, bool STRIDED>
-__device__ __forceinline__ f32x4 score_tile(const u32x4 (&fa)[AL<T>::KBD], const char *img, const float *bias_rows,
-                                            int N, int row, float scale, int lane, int kt) {
-  using L = AL<T>;
-  const int g = lane >> 4, li = lane & 15;
-  constexpr bool vec = FAST;
-  f32x4 a = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int kb = 0; kb < L::KBD; ++kb) mma<T>(a, fa[kb], frag_row<T>(img, kt * 16 + li, kb, lane));
-  const int col = kt * 16 + 4 * g;
+// Bias values of one 16x16 score tile for this lane: bias_rows[row][16kt + 4g .. +3]; when STRIDED the
+// array is indexed [col*N + row] instead (transposed use without a transposed copy).  Zero when absent.
+template <bool FAST, bool STRIDED>
+__device__ __forceinline__ f32x4 bias_tile(const float *bias_rows, int N, int row, int lane, int kt) {
+  const int col = kt * 16 + 4 * (lane >> 4);
   f32x4 bv = {0.f, 0.f, 0.f, 0.f};
   if (bias_rows && row < N) {
     if constexpr (!STRIDED) {
-      bv = load4_guard(bias_rows + (long long)row * N, col, N, vec);
+      bv = load4_guard(bias_rows + (long long)row * N, col, N, FAST);
     } else {
 #pragma unroll
       for (int r = 0; r < 4; ++r) bv[r] = (col + r < N) ? bias_rows[(long long)(col + r) * N + row] : 0.f;
     }
   }
+  return bv;
+}
+// One 16x16 score tile: a[r] = scale * (this wave's row) . (tile row 16kt+4g+r) + bv[r];
+// entries with row >= N or col >= N become -inf.
+template <typename T>
+__device__ __forceinline__ f32x4 score_tile(const u32x4 (&fa)[AL<T>::KBD], const char *img, const f32x4 bv,
+                                            int N, int row, float scale, int lane, int kt) {
+  using L = AL<T>;
+  const int g = lane >> 4, li = lane & 15;
+  f32x4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int kb = 0; kb < L::KBD; ++kb) mma<T>(a, fa[kb], frag_row<T>(img, kt * 16 + li, kb, lane));
+  const int col = kt * 16 + 4 * g;
 #pragma unroll
   for (int r = 0; r < 4; ++r) a[r] = (row < N && col + r < N) ? a[r] * scale + bv[r] : -INFINITY;
   return a;
@@ -243,7 +248,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
   f32x4 s[NKT];
   const float *brows = p.bias ? p.bias + (long long)h * N * N : nullptr;
 #pragma unroll
-  for (int kt = 0; kt < NKT; ++kt) s[kt] = score_tile<T, FAST, false>(fq, kimg, brows, N, q, p.scale, lane, kt);
+  for (int kt = 0; kt < NKT; ++kt) s[kt] = score_tile<T>(fq, kimg, bias_tile<FAST, false>(brows, N, q, lane, kt), N, q, p.scale, lane, kt);
 
   float m = -INFINITY;
 #pragma unroll
@@ -287,7 +292,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnParams p)
   constexpr int NK = NKT * 16;
   constexpr int IMG = NK * L::RB;
   __shared__ __attribute__((aligned(16))) char smem[2 * IMG];
-  extern __shared__ float bins[];     // n_bins floats (dynamic), only when the bias gradient is wanted
+  extern __shared__ float bins[];     // n_bins + 1 floats (dynamic), only when the bias gradient is wanted
   char *kimg = smem, *vimg = smem + IMG;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, g = lane >> 4, li = lane & 15;
   const int qblk = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
@@ -302,7 +307,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnParams p)
   const T *dOg = reinterpret_cast<const T *>(p.dout) + orow;
 
   if (p.index)
-    for (int i = t; i < p.n_bins; i += 256) bins[i] = 0.f;
+    for (int i = t; i <= p.n_bins; i += 256) bins[i] = 0.f;
   tile_to_lds<T>(kimg, base + (long long)H * HD, tok_stride, N, NK, t);
   tile_to_lds<T>(vimg, base + 2LL * H * HD, tok_stride, N, NK, t);
   u32x4 fq[L::KBD], fdo[L::KBD];
@@ -329,14 +334,44 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnParams p)
   constexpr int NB = NKT / L::TPB;
   u32x4 fds[NB];
   const float *brows = p.bias ? p.bias + (long long)h * N * N : nullptr;
-  constexpr bool vec = FAST;
+  const bool want_bins = p.index != nullptr;
+  const int dummy = p.n_bins;        // out-of-range bins land in one spare LDS slot: no per-element branch
+  // bias / index of block m+1 are fetched while block m computes (the loop is pinned block by block to
+  // bound registers, so the prefetch has to be explicit)
+  f32x4 bnext[L::TPB];
+  i32x4 inext[L::TPB];
+  auto fetch = [&](int m) {
+#pragma unroll
+    for (int u = 0; u < L::TPB; ++u) {
+      const int kt = m * L::TPB + u;
+      bnext[u] = bias_tile<FAST, false>(brows, N, q, lane, kt);
+      const int key = kt * 16 + 4 * g;
+      i32x4 iv = {dummy, dummy, dummy, dummy};
+      if (want_bins && qok) {
+        if constexpr (FAST) {
+          if (key < N) iv = *reinterpret_cast<const i32x4 *>(p.index + (long long)q * N + key);
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (key + r < N) iv[r] = p.index[(long long)q * N + key + r];
+        }
+      }
+      inext[u] = iv;
+    }
+  };
+  fetch(0);
 #pragma unroll
   for (int m = 0; m < NB; ++m) {
+    f32x4 bcur[L::TPB];
+    i32x4 icur[L::TPB];
+#pragma unroll
+    for (int u = 0; u < L::TPB; ++u) { bcur[u] = bnext[u]; icur[u] = inext[u]; }
+    if (m + 1 < NB) fetch(m + 1);
     f32x4 tl[L::TPB];
 #pragma unroll
     for (int u = 0; u < L::TPB; ++u) {
       const int kt = m * L::TPB + u;
-      const f32x4 sc = score_tile<T, FAST, false>(fq, kimg, brows, N, q, p.scale, lane, kt);
+      const f32x4 sc = score_tile<T>(fq, kimg, bcur[u], N, q, p.scale, lane, kt);
       // dP = dO V^T for this tile, then dS = P * (dP - delta)
       f32x4 a = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -344,24 +379,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnParams p)
       f32x4 dsv;
 #pragma unroll
       for (int r = 0; r < 4; ++r) dsv[r] = fast_exp<T>(sc[r] - lse) * (a[r] - dl);   // masked: exp(-inf) = 0
-      if (p.index && qok) {
-        const int key = kt * 16 + 4 * g;
-        if (vec) {
-          if (key < N) {
-            const int *ip = p.index + (long long)q * N + key;
-            const int b0 = ip[0], b1 = ip[1], b2 = ip[2], b3 = ip[3];
-            if ((unsigned)b0 < (unsigned)p.n_bins) atomicAdd(&bins[b0], dsv[0]);
-            if ((unsigned)b1 < (unsigned)p.n_bins) atomicAdd(&bins[b1], dsv[1]);
-            if ((unsigned)b2 < (unsigned)p.n_bins) atomicAdd(&bins[b2], dsv[2]);
-            if ((unsigned)b3 < (unsigned)p.n_bins) atomicAdd(&bins[b3], dsv[3]);
-          }
-        } else {
+      if (want_bins) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r)
-            if (key + r < N) {
-              const int bin = p.index[(long long)q * N + key + r];
-              if ((unsigned)bin < (unsigned)p.n_bins) atomicAdd(&bins[bin], dsv[r]);
-            }
+        for (int r = 0; r < 4; ++r) {
+          const unsigned bin = min((unsigned)icur[u][r], (unsigned)dummy);   // padding / bad indices -> spare slot
+          atomicAdd(&bins[bin], dsv[r]);
         }
       }
       tl[u] = dsv;
@@ -429,24 +451,37 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnParams p
   // otherwise the generic form reads `bias` with a stride and lse/delta element-wise.
   const float *bsrc = FAST ? p.bias_t : p.bias;
   const float *brows = bsrc ? bsrc + (long long)h * N * N : nullptr;
-  constexpr bool vec = FAST;
+  f32x4 bnext[L::TPB], lnext[L::TPB], dnext[L::TPB];
+  auto fetch = [&](int m) {
+#pragma unroll
+    for (int u = 0; u < L::TPB; ++u) {
+      const int qt = m * L::TPB + u;
+      bnext[u] = bias_tile<FAST, !FAST>(brows, N, key, lane, qt);
+      lnext[u] = load4_guard(lse, qt * 16 + 4 * g, N, FAST);
+      dnext[u] = load4_guard(delta, qt * 16 + 4 * g, N, FAST);
+    }
+  };
+  fetch(0);
 #pragma unroll
   for (int m = 0; m < NB; ++m) {
+    f32x4 bcur[L::TPB], lcur[L::TPB], dcur[L::TPB];
+#pragma unroll
+    for (int u = 0; u < L::TPB; ++u) { bcur[u] = bnext[u]; lcur[u] = lnext[u]; dcur[u] = dnext[u]; }
+    if (m + 1 < NB) fetch(m + 1);
     f32x4 tp[L::TPB], td[L::TPB];
 #pragma unroll
     for (int u = 0; u < L::TPB; ++u) {
       const int qt = m * L::TPB + u;
       const int q0 = qt * 16 + 4 * g;
-      const f32x4 sc = score_tile<T, FAST, !FAST>(fk, qimg, brows, N, key, p.scale, lane, qt);
-      const f32x4 lv = load4_guard(lse, q0, N, vec), dv = load4_guard(delta, q0, N, vec);
+      const f32x4 sc = score_tile<T>(fk, qimg, bcur[u], N, key, p.scale, lane, qt);
       f32x4 a = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int kb = 0; kb < L::KBD; ++kb) mma<T>(a, fvv[kb], frag_row<T>(doimg, qt * 16 + li, kb, lane));
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float pv = (q0 + r < N) ? fast_exp<T>(sc[r] - lv[r]) : 0.f;
+        const float pv = (q0 + r < N) ? fast_exp<T>(sc[r] - lcur[u][r]) : 0.f;
         tp[u][r] = pv;
-        td[u][r] = pv * (a[r] - dv[r]);
+        td[u][r] = pv * (a[r] - dcur[u][r]);
       }
     }
     fpt[m] = pack_tiles<T>(tp);
@@ -478,7 +513,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnParams p
 // ---- dispatch -----------------------------------------------------------------------------------
 template <typename T, int NKT, bool FAST> void launch3(int which, const AttnParams &p, dim3 grid, hipStream_t s) {
   if (which == 0) hipLaunchKernelGGL((attn_fwd_kernel<T, NKT, FAST>), grid, dim3(256), 0, s, p);
-  else if (which == 1) hipLaunchKernelGGL((attn_bwd_dq_kernel<T, NKT, FAST>), grid, dim3(256), p.index ? p.n_bins * sizeof(float) : 0, s, p);
+  else if (which == 1) hipLaunchKernelGGL((attn_bwd_dq_kernel<T, NKT, FAST>), grid, dim3(256), p.index ? (p.n_bins + 1) * sizeof(float) : 0, s, p);
   else hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, NKT, FAST>), grid, dim3(256), 0, s, p);
 }
 template <typename T, bool FAST> void dispatch_nkt(int which, const AttnParams &p, hipStream_t s) {

@@ -13,6 +13,7 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(4))) int i32x4;
 typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 
 #define DM_WAVE 64
@@ -69,8 +70,31 @@ __device__ __forceinline__ void dm_store4(bf16_t *p, f32x4 v) {
 __device__ __forceinline__ float dm_gelu(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 __device__ __forceinline__ float dm_dgelu(float x) {
   const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
-  const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
+  const float pdf = 0.39894228040143267794f * expf(-0.5f * x * x);
   return cdf + x * pdf;
+}
+
+// Throughput-mode variants (results are rounded to bf16 afterwards): erf by Abramowitz-Stegun 7.1.26
+// (|error| <= 1.5e-7) on v_rcp_f32 / v_exp_f32 instead of the ~40-instruction erff; GELU and its
+// derivative share the single exp(-x^2/2).
+__device__ __forceinline__ void dm_gelu_parts_fast(float x, float &cdf, float &pdf) {
+  const float z = fabsf(x) * 0.70710678118654752440f;
+  const float e = __expf(-z * z);                                    // exp(-x^2/2)
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+  const float poly = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f), 0.254829592f);
+  const float erf_abs = fmaf(-poly, e, 1.0f);
+  cdf = 0.5f * (1.0f + copysignf(erf_abs, x));
+  pdf = 0.39894228040143267794f * e;
+}
+__device__ __forceinline__ float dm_gelu_fast(float x) {
+  float cdf, pdf;
+  dm_gelu_parts_fast(x, cdf, pdf);
+  return x * cdf;
+}
+__device__ __forceinline__ float dm_dgelu_fast(float x) {
+  float cdf, pdf;
+  dm_gelu_parts_fast(x, cdf, pdf);
+  return fmaf(x, pdf, cdf);
 }
 
 __device__ __forceinline__ float dm_wave_sum(float v) {

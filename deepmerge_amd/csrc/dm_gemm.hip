@@ -37,6 +37,15 @@ namespace {
 constexpr int BM = 128, BN = 128;
 constexpr int STAGE_BYTES = 16896;  // 16 KiB, or 32 rows x 528 B for the padded fp32 m-contiguous image
 constexpr int NTHREADS = 256;
+// LDS stages per operand.  1 = single LDS buffer + the register staging set as the second stage
+// (two barriers per K stage, 33 KiB per workgroup -> 3 workgroups per CU, which makes the tile count of
+// the model's GEMMs (768 / 2304 / 3072 tiles at M = 16384) an exact number of rounds); 2 = classic
+// double-buffered LDS (one barrier per stage, 66 KiB -> 2 workgroups per CU).
+#ifndef DM_GEMM_LDS_STAGES
+#define DM_GEMM_LDS_STAGES 1
+#endif
+constexpr int LDS_STAGES = DM_GEMM_LDS_STAGES;
+constexpr int WG_PER_CU = (LDS_STAGES == 1) ? 3 : 2;
 
 struct GemmParams {
   const void *A, *B;
@@ -54,20 +63,39 @@ struct GemmParams {
 __device__ __forceinline__ int tr_swz(int k) { return (k & 3) | (((k >> 3) & 1) << 2); }
 
 // ---- global -> register staging -------------------------------------------------------------
+// Loads go through a buffer descriptor covering exactly the operand's bytes: an out-of-range row
+// (tile overhang in M / N, or k >= K for row-per-k operands) reads as ZERO in hardware, so the
+// loop carries no branches and no 64-bit address arithmetic -- four per-thread byte offsets are
+// computed once and each K stage only bumps one scalar offset.
+struct OperandView {
+  __amdgpu_buffer_rsrc_t rsrc;
+  unsigned voff[4];     // per-thread byte offsets of its four 16-byte chunks (stage 0, k = 0)
+  unsigned chunk_k;     // k index (elements) of this thread's chunk inside a stage (k-contiguous operands)
+};
+
 // K-contiguous tile: 128 rows x 8 chunks; thread t: chunk t&7, rows (t>>3)+32i.
 template <typename T>
-__device__ __forceinline__ void load_kmajor(u32x4 (&r)[4], const T *base, long long ld, int row0, int rows,
-                                            int k0, int kend, int t) {
+__device__ __forceinline__ OperandView view_kmajor(const T *base, long long ld, int row0, int rows, int K, int t) {
   constexpr int EPC = DmTypeInfo<T>::kPerChunk;
-  const int c = t & 7;
-  const int k = k0 + c * EPC;
+  OperandView v;
+  const long long bytes = ((long long)(rows - 1) * ld + K) * (long long)sizeof(T);
+  v.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(base), 0, (int)bytes, 0x00020000);
+  v.chunk_k = (t & 7) * EPC;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const int row = row0 + (t >> 3) + 32 * i;
-    u32x4 v = {0u, 0u, 0u, 0u};
-    if (row < rows && k < kend) v = *reinterpret_cast<const u32x4 *>(base + (long long)row * ld + k);
-    r[i] = v;
+    const long long row = row0 + (t >> 3) + 32 * i;
+    const long long off = (row * ld + v.chunk_k) * (long long)sizeof(T);
+    v.voff[i] = (row < rows) ? (unsigned)off : 0x80000000u;      // past the last row: force out of range
   }
+  return v;
+}
+template <typename T>
+__device__ __forceinline__ void load_kmajor(u32x4 (&r)[4], const OperandView &v, int k0, int kend) {
+  // chunks at or beyond kend (K tail of the last stage) must read zero, not the next row
+  const unsigned kill = ((int)(k0 + v.chunk_k) < kend) ? 0u : 0x80000000u;
+  const unsigned soff = (unsigned)k0 * (unsigned)sizeof(T);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) r[i] = __builtin_amdgcn_raw_buffer_load_b128(v.rsrc, v.voff[i] | kill, soff, 0);
 }
 __device__ __forceinline__ void store_kmajor(char *lds, const u32x4 (&r)[4], int t) {
   const int c = t & 7;
@@ -78,21 +106,31 @@ __device__ __forceinline__ void store_kmajor(char *lds, const u32x4 (&r)[4], int
   }
 }
 // M-contiguous tile: rows are k. bf16: 64 rows x 16 chunks; fp32: 32 rows x 32 chunks.
+// Rows k >= K fall outside the descriptor (zero); split-K slices end on stage boundaries, so no
+// other k predicate is needed.  Columns past the operand's width only feed outputs that are never
+// stored.
 template <typename T>
-__device__ __forceinline__ void load_mmajor(u32x4 (&r)[4], const T *base, long long ld, int col0, int cols,
-                                            int k0, int kend, int t) {
+__device__ __forceinline__ OperandView view_mmajor(const T *base, long long ld, int col0, int cols, int K, int t) {
   constexpr int EPC = DmTypeInfo<T>::kPerChunk;
   constexpr int CPR = 128 / EPC;         // chunks per row: 16 (bf16) / 32 (fp32)
   constexpr int RPI = NTHREADS / CPR;    // rows per iteration: 16 / 8
-  const int c = t % CPR;
-  const int col = col0 + c * EPC;
+  OperandView v;
+  const long long bytes = ((long long)(K - 1) * ld + cols) * (long long)sizeof(T);
+  v.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(base), 0, (int)bytes, 0x00020000);
+  v.chunk_k = 0;
+  const int col = col0 + (t % CPR) * EPC;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const int k = k0 + t / CPR + RPI * i;
-    u32x4 v = {0u, 0u, 0u, 0u};
-    if (k < kend && col < cols) v = *reinterpret_cast<const u32x4 *>(base + (long long)k * ld + col);
-    r[i] = v;
+    const long long k = t / CPR + RPI * i;
+    v.voff[i] = (col < cols) ? (unsigned)((k * ld + col) * (long long)sizeof(T)) : 0x80000000u;
   }
+  return v;
+}
+template <typename T>
+__device__ __forceinline__ void load_mmajor(u32x4 (&r)[4], const OperandView &v, long long ld, int k0) {
+  const unsigned soff = (unsigned)((long long)k0 * ld * (long long)sizeof(T));
+#pragma unroll
+  for (int i = 0; i < 4; ++i) r[i] = __builtin_amdgcn_raw_buffer_load_b128(v.rsrc, v.voff[i], soff, 0);
 }
 template <typename T> __device__ __forceinline__ void store_mmajor(char *lds, const u32x4 (&r)[4], int t);
 template <> __device__ __forceinline__ void store_mmajor<bf16_t>(char *lds, const u32x4 (&r)[4], int t) {
@@ -147,13 +185,13 @@ template <> __device__ __forceinline__ u32x4 frag_mmajor<float>(const char *lds,
 }
 
 template <typename T, int LAYOUT>
-__global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(const GemmParams p) {
+__global__ __launch_bounds__(NTHREADS, WG_PER_CU) void gemm_kernel(const GemmParams p) {
   constexpr bool A_MMAJOR = (LAYOUT == DM_TN);
   constexpr bool B_MMAJOR = (LAYOUT != DM_NT);
   constexpr int BK = 128 / (int)sizeof(T);
-  __shared__ __attribute__((aligned(16))) char smem[4 * STAGE_BYTES];
-  auto ldsA = [&](int buf) -> char * { return smem + (2 * buf) * STAGE_BYTES; };
-  auto ldsB = [&](int buf) -> char * { return smem + (2 * buf + 1) * STAGE_BYTES; };
+  __shared__ __attribute__((aligned(16))) char smem[2 * LDS_STAGES * STAGE_BYTES];
+  auto ldsA = [&](int buf) -> char * { return smem + (2 * (buf % LDS_STAGES)) * STAGE_BYTES; };
+  auto ldsB = [&](int buf) -> char * { return smem + (2 * (buf % LDS_STAGES) + 1) * STAGE_BYTES; };
 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int wm = wave >> 1, wn = wave & 1;
@@ -178,11 +216,16 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(const GemmParams p) {
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   u32x4 ra[4], rb[4];
+  OperandView va, vb;
+  if constexpr (A_MMAJOR) va = view_mmajor<T>(A, p.lda, m0, p.M, p.K, t);
+  else va = view_kmajor<T>(A, p.lda, m0, p.M, p.K, t);
+  if constexpr (B_MMAJOR) vb = view_mmajor<T>(B, p.ldb, n0, p.N, p.K, t);
+  else vb = view_kmajor<T>(B, p.ldb, n0, p.N, p.K, t);
   auto gload = [&](int k0) {
-    if constexpr (A_MMAJOR) load_mmajor<T>(ra, A, p.lda, m0, p.M, k0, kend, t);
-    else load_kmajor<T>(ra, A, p.lda, m0, p.M, k0, kend, t);
-    if constexpr (B_MMAJOR) load_mmajor<T>(rb, B, p.ldb, n0, p.N, k0, kend, t);
-    else load_kmajor<T>(rb, B, p.ldb, n0, p.N, k0, kend, t);
+    if constexpr (A_MMAJOR) load_mmajor<T>(ra, va, p.lda, k0);
+    else load_kmajor<T>(ra, va, k0, kend);
+    if constexpr (B_MMAJOR) load_mmajor<T>(rb, vb, p.ldb, k0);
+    else load_kmajor<T>(rb, vb, k0, kend);
   };
   auto lstore = [&](int buf) {
     if constexpr (A_MMAJOR) store_mmajor<T>(ldsA(buf), ra, t);
@@ -216,6 +259,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(const GemmParams p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) mma<T>(acc[i][j], fa[i], fb[j]);
     }
+    if constexpr (LDS_STAGES == 1) __syncthreads();   // every wave is done reading the single buffer
     if (more) lstore(cur ^ 1);
     __syncthreads();
   }
@@ -261,12 +305,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(const GemmParams p) {
         if (p.aux_dtype == DM_F32) dm_store4(reinterpret_cast<float *>(p.aux) + rbase_x + n, v);
         else dm_store4(reinterpret_cast<bf16_t *>(p.aux) + rbase_x + n, v);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = dm_gelu(v[e]);
+        for (int e = 0; e < 4; ++e) v[e] = (sizeof(T) == 2) ? dm_gelu_fast(v[e]) : dm_gelu(v[e]);
       } else if (p.epilogue == DM_EPI_DGELU) {
         f32x4 u = (p.aux_dtype == DM_F32) ? dm_load4(reinterpret_cast<const float *>(p.aux) + rbase_x + n)
                                           : dm_load4(reinterpret_cast<const bf16_t *>(p.aux) + rbase_x + n);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] *= dm_dgelu(u[e]);
+        for (int e = 0; e < 4; ++e) v[e] *= (sizeof(T) == 2) ? dm_dgelu_fast(u[e]) : dm_dgelu(u[e]);
       }
       if (p.residual) v += dm_load4(p.residual + rbase_r + n);
       if (p.c_dtype == DM_F32) {
@@ -351,7 +395,7 @@ void launch_mfma(const GemmParams &p, int layout, int grid, hipStream_t s) {
 int choose_split(int tiles, int K, int bk) {
   // Fill ~2 workgroups per CU on 256 CUs, keep >= 8 stages per slice.
   int s = 1;
-  while (tiles * s < 512 && s < 32 && K / (s * 2) >= 8 * bk) s *= 2;
+  while (tiles * s < 256 * WG_PER_CU && s < 32 && K / (s * 2) >= 8 * bk) s *= 2;
   return s;
 }
 
@@ -383,6 +427,12 @@ extern "C" int dm_gemm(const DmGemmArgs *a, void *stream) {
   p.epilogue = a->epilogue; p.accumulate = a->accumulate; p.c_dtype = a->c_dtype; p.aux_dtype = a->aux_dtype;
 
   // Which extents must be chunk (16-byte) multiples for the MFMA path.
+  {
+    const long long esz = (a->ab_dtype == DM_BF16) ? 2 : 4;
+    const long long a_rows = (a->layout == DM_TN) ? a->K : a->M, b_rows = (a->layout == DM_NT) ? a->N : a->K;
+    DM_REQUIRE(a_rows * a->lda * esz < (1LL << 31) && b_rows * a->ldb * esz < (1LL << 31), DM_ERR_BAD_SHAPE,
+               "dm_gemm: operands must be smaller than 2 GiB each (32-bit buffer offsets)");
+  }
   const int epc = (a->ab_dtype == DM_BF16) ? 8 : 4;
   const int a_inner = (a->layout == DM_TN) ? a->M : a->K;   // contiguous extent of A rows
   const int b_inner = (a->layout == DM_NT) ? a->K : a->N;

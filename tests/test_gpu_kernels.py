@@ -83,7 +83,7 @@ def test_gemm_epilogues(mode):
     ops.gemm(DM_NT, A, B_, out2, M, N, K, lda=K, ldb=K, ldc=N, epilogue=DM_EPI_DGELU, aux=aux.to(DEV), ldaux=N)
     x = aux.double().requires_grad_(True)
     torch.nn.functional.gelu(x).sum().backward()
-    np.testing.assert_allclose(out2.cpu().double().numpy(), (base * x.grad).numpy(), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(out2.cpu().double().numpy(), (base * x.grad).numpy(), rtol=1e-5, atol=1e-5 if mode == "fp32" else 1e-4)
     # accumulate
     out3 = res.clone().to(DEV)
     ops.gemm(DM_NT, A, B_, out3, M, N, K, lda=K, ldb=K, ldc=N, accumulate=True)
