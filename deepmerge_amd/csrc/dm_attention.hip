@@ -162,7 +162,7 @@ struct AttnParams {
   void *dqkv;
   const int *index;
   float *slab;
-  int B, N, H, n_bins, nblk;
+  int B, N, H, n_bins, nblk, bchunk;
   float scale;
 };
 
@@ -288,66 +288,117 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
 // =============================================================================================
 template <typename T, int NKT, bool FAST>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnParams p) {
+  // grid = (query block, head, batch chunk).  The workgroup walks the `bchunk` samples of its chunk and
+  // sums dS over them in registers, so the (slow, ~0.4 lanes/clk) LDS float atomics of the bias-table
+  // histogram are paid once per chunk instead of once per sample.
   using L = AL<T>;
   constexpr int NK = NKT * 16;
   constexpr int IMG = NK * L::RB;
+  constexpr int NB = NKT / L::TPB;
   __shared__ __attribute__((aligned(16))) char smem[2 * IMG];
   extern __shared__ float bins[];     // n_bins + 1 floats (dynamic), only when the bias gradient is wanted
   char *kimg = smem, *vimg = smem + IMG;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, g = lane >> 4, li = lane & 15;
-  const int qblk = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  const int qblk = blockIdx.x, h = blockIdx.y, chunk = blockIdx.z;
   const int N = p.N, H = p.H;
-
   const long long tok_stride = 3LL * H * HD;
-  const T *base = reinterpret_cast<const T *>(p.qkv) + (long long)b * N * tok_stride + (long long)h * HD;
   const int q = qblk * QB + wave * 16 + li;
   const bool qok = q < N;
-  const long long orow = ((long long)b * N + q) * H * HD + (long long)h * HD;
-  const T *Og = reinterpret_cast<const T *>(p.out) + orow;
-  const T *dOg = reinterpret_cast<const T *>(p.dout) + orow;
-
-  if (p.index)
-    for (int i = t; i <= p.n_bins; i += 256) bins[i] = 0.f;
-  tile_to_lds<T>(kimg, base + (long long)H * HD, tok_stride, N, NK, t);
-  tile_to_lds<T>(vimg, base + 2LL * H * HD, tok_stride, N, NK, t);
-  u32x4 fq[L::KBD], fdo[L::KBD];
-#pragma unroll
-  for (int kb = 0; kb < L::KBD; ++kb) {
-    fq[kb] = gl_frag<T>(base + (long long)q * tok_stride, qok, kb, lane);
-    fdo[kb] = gl_frag<T>(dOg, qok, kb, lane);
-  }
-  // delta[q] = sum_d dO[q][d] * O[q][d]  (lane group g covers d = 16g..16g+15)
-  float dl = 0.f;
-  if (qok) {
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const f32x4 a = dm_load4(Og + 16 * g + 4 * c), d = dm_load4(dOg + 16 * g + 4 * c);
-      dl += (a[0] * d[0] + a[1] * d[1]) + (a[2] * d[2] + a[3] * d[3]);
-    }
-  }
-  dl = row_sum(dl);
-  const long long rowid = ((long long)b * H + h) * N + q;
-  if (g == 0 && qok) p.delta[rowid] = dl;
-  const float lse = qok ? p.lse[rowid] : 0.f;
-  __syncthreads();
-
-  constexpr int NB = NKT / L::TPB;
-  u32x4 fds[NB];
   const float *brows = p.bias ? p.bias + (long long)h * N * N : nullptr;
   const bool want_bins = p.index != nullptr;
   const int dummy = p.n_bins;        // out-of-range bins land in one spare LDS slot: no per-element branch
-  // bias / index of block m+1 are fetched while block m computes (the loop is pinned block by block to
-  // bound registers, so the prefetch has to be explicit)
-  f32x4 bnext[L::TPB];
-  i32x4 inext[L::TPB];
-  auto fetch = [&](int m) {
+
+  if (want_bins)
+    for (int i = t; i <= p.n_bins; i += 256) bins[i] = 0.f;
+  f32x4 hacc[NKT];
 #pragma unroll
-    for (int u = 0; u < L::TPB; ++u) {
-      const int kt = m * L::TPB + u;
-      bnext[u] = bias_tile<FAST, false>(brows, N, q, lane, kt);
-      const int key = kt * 16 + 4 * g;
-      i32x4 iv = {dummy, dummy, dummy, dummy};
-      if (want_bins && qok) {
+  for (int kt = 0; kt < NKT; ++kt) hacc[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int b_end = min(p.B, (chunk + 1) * p.bchunk);
+  for (int b = chunk * p.bchunk; b < b_end; ++b) {
+    const T *base = reinterpret_cast<const T *>(p.qkv) + (long long)b * N * tok_stride + (long long)h * HD;
+    const long long orow = ((long long)b * N + q) * H * HD + (long long)h * HD;
+    const T *Og = reinterpret_cast<const T *>(p.out) + orow;
+    const T *dOg = reinterpret_cast<const T *>(p.dout) + orow;
+    __syncthreads();                  // previous sample's reads of the images are complete
+    tile_to_lds<T>(kimg, base + (long long)H * HD, tok_stride, N, NK, t);
+    tile_to_lds<T>(vimg, base + 2LL * H * HD, tok_stride, N, NK, t);
+    u32x4 fq[L::KBD], fdo[L::KBD];
+#pragma unroll
+    for (int kb = 0; kb < L::KBD; ++kb) {
+      fq[kb] = gl_frag<T>(base + (long long)q * tok_stride, qok, kb, lane);
+      fdo[kb] = gl_frag<T>(dOg, qok, kb, lane);
+    }
+    // delta[q] = sum_d dO[q][d] * O[q][d]  (lane group g covers d = 16g..16g+15)
+    float dl = 0.f;
+    if (qok) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const f32x4 a = dm_load4(Og + 16 * g + 4 * c), d = dm_load4(dOg + 16 * g + 4 * c);
+        dl += (a[0] * d[0] + a[1] * d[1]) + (a[2] * d[2] + a[3] * d[3]);
+      }
+    }
+    dl = row_sum(dl);
+    const long long rowid = ((long long)b * H + h) * N + q;
+    if (g == 0 && qok) p.delta[rowid] = dl;
+    const float lse = qok ? p.lse[rowid] : 0.f;
+    __syncthreads();
+
+    u32x4 fds[NB];
+    // the bias tile of block m+1 is fetched while block m computes (the loop is pinned block by block to
+    // bound registers, so the prefetch has to be explicit)
+    f32x4 bnext[L::TPB];
+#pragma unroll
+    for (int u = 0; u < L::TPB; ++u) bnext[u] = bias_tile<FAST, false>(brows, N, q, lane, u);
+#pragma unroll
+    for (int m = 0; m < NB; ++m) {
+      f32x4 bcur[L::TPB];
+#pragma unroll
+      for (int u = 0; u < L::TPB; ++u) bcur[u] = bnext[u];
+      if (m + 1 < NB) {
+#pragma unroll
+        for (int u = 0; u < L::TPB; ++u) bnext[u] = bias_tile<FAST, false>(brows, N, q, lane, (m + 1) * L::TPB + u);
+      }
+      f32x4 tl[L::TPB];
+#pragma unroll
+      for (int u = 0; u < L::TPB; ++u) {
+        const int kt = m * L::TPB + u;
+        const f32x4 sc = score_tile<T>(fq, kimg, bcur[u], N, q, p.scale, lane, kt);
+        // dP = dO V^T for this tile, then dS = P * (dP - delta)
+        f32x4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kb = 0; kb < L::KBD; ++kb) mma<T>(a, fdo[kb], frag_row<T>(vimg, kt * 16 + li, kb, lane));
+        f32x4 dsv;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dsv[r] = fast_exp<T>(sc[r] - lse) * (a[r] - dl);   // masked: exp(-inf) = 0
+        if (want_bins) hacc[kt] += dsv;
+        tl[u] = dsv;
+      }
+      fds[m] = pack_tiles<T>(tl);
+      // Pin the packed fragment HERE: otherwise the optimiser sinks exp/pack of every block down to the
+      // contraction below and keeps all raw score tiles + loaded bias alive (>256 VGPRs, spills).
+      asm volatile("" : "+v"(fds[m]));
+      __builtin_amdgcn_sched_barrier(0);
+    }
+
+    f32x4 o[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    contract_frags<T, NB>(o, fds, kimg, lane);
+    if (qok) {
+      T *dq = reinterpret_cast<T *>(p.dqkv) + ((long long)b * N + q) * tok_stride + (long long)h * HD;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) dm_store4(dq + dt * 16 + 4 * g, o[dt] * p.scale);
+    }
+  }
+
+  if (want_bins) {
+    // histogram of the chunk's summed dS: bins[index[q][key]] += hacc
+    if (qok) {
+#pragma unroll
+      for (int kt = 0; kt < NKT; ++kt) {
+        const int key = kt * 16 + 4 * g;
+        i32x4 iv = {dummy, dummy, dummy, dummy};
         if constexpr (FAST) {
           if (key < N) iv = *reinterpret_cast<const i32x4 *>(p.index + (long long)q * N + key);
         } else {
@@ -355,56 +406,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnParams p)
           for (int r = 0; r < 4; ++r)
             if (key + r < N) iv[r] = p.index[(long long)q * N + key + r];
         }
-      }
-      inext[u] = iv;
-    }
-  };
-  fetch(0);
-#pragma unroll
-  for (int m = 0; m < NB; ++m) {
-    f32x4 bcur[L::TPB];
-    i32x4 icur[L::TPB];
-#pragma unroll
-    for (int u = 0; u < L::TPB; ++u) { bcur[u] = bnext[u]; icur[u] = inext[u]; }
-    if (m + 1 < NB) fetch(m + 1);
-    f32x4 tl[L::TPB];
-#pragma unroll
-    for (int u = 0; u < L::TPB; ++u) {
-      const int kt = m * L::TPB + u;
-      const f32x4 sc = score_tile<T>(fq, kimg, bcur[u], N, q, p.scale, lane, kt);
-      // dP = dO V^T for this tile, then dS = P * (dP - delta)
-      f32x4 a = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int kb = 0; kb < L::KBD; ++kb) mma<T>(a, fdo[kb], frag_row<T>(vimg, kt * 16 + li, kb, lane));
-      f32x4 dsv;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) dsv[r] = fast_exp<T>(sc[r] - lse) * (a[r] - dl);   // masked: exp(-inf) = 0
-      if (want_bins) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const unsigned bin = min((unsigned)icur[u][r], (unsigned)dummy);   // padding / bad indices -> spare slot
-          atomicAdd(&bins[bin], dsv[r]);
+          const unsigned bin = min((unsigned)iv[r], (unsigned)dummy);   // padding / bad indices -> spare slot
+          atomicAdd(&bins[bin], hacc[kt][r]);
         }
       }
-      tl[u] = dsv;
     }
-    fds[m] = pack_tiles<T>(tl);
-    asm volatile("" : "+v"(fds[m]));
-    __builtin_amdgcn_sched_barrier(0);
-  }
-
-  f32x4 o[4];
-#pragma unroll
-  for (int dt = 0; dt < 4; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  contract_frags<T, NB>(o, fds, kimg, lane);
-  if (qok) {
-    T *dq = reinterpret_cast<T *>(p.dqkv) + ((long long)b * N + q) * tok_stride + (long long)h * HD;
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt) dm_store4(dq + dt * 16 + 4 * g, o[dt] * p.scale);
-  }
-  if (p.index) {
     __syncthreads();   // all histogram atomics of the workgroup are done
-    float *srow = p.slab + (((long long)b * H + h) * p.nblk + qblk) * p.n_bins;
+    float *srow = p.slab + (((long long)chunk * H + h) * p.nblk + qblk) * p.n_bins;
     for (int i = t; i < p.n_bins; i += 256) srow[i] = bins[i];
   }
 }
@@ -517,7 +527,7 @@ template <typename T, int NKT, bool FAST> void launch3(int which, const AttnPara
   else hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, NKT, FAST>), grid, dim3(256), 0, s, p);
 }
 template <typename T, bool FAST> void dispatch_nkt(int which, const AttnParams &p, hipStream_t s) {
-  const dim3 grid((p.N + QB - 1) / QB, p.H, p.B);
+  const dim3 grid((p.N + QB - 1) / QB, p.H, which == 1 ? (p.B + p.bchunk - 1) / p.bchunk : p.B);
   const int nkt = (p.N + 15) / 16;
   if (nkt <= 2) launch3<T, 2, FAST>(which, p, grid, s);
   else if (nkt <= 4) launch3<T, 4, FAST>(which, p, grid, s);
@@ -545,7 +555,19 @@ int check_common(const char *who, int B, int N, int H, int D, int dtype) {
 
 }  // namespace
 
+// samples one dq workgroup walks: as many as keeps >= ~1.2 workgroups per CU in flight
+static int batch_chunk(int B, int N, int H) {
+  const int per_sample = ((N + QB - 1) / QB) * H;
+  for (int c = 8; c > 1; c >>= 1)
+    if ((long long)per_sample * ((B + c - 1) / c) >= 300) return c;
+  return 1;
+}
+
 extern "C" int32_t dm_attention_bwd_slab_rows(int32_t N) { return (N + QB - 1) / QB; }
+extern "C" int32_t dm_attention_bwd_batch_chunks(int32_t B, int32_t N, int32_t H) {
+  const int c = batch_chunk(B, N, H);
+  return (B + c - 1) / c;
+}
 
 extern "C" int dm_attention_fwd(const void *qkv, const float *bias, void *out, float *lse, int32_t B, int32_t N, int32_t H,
                                 int32_t D, float scale, int32_t dtype, void *stream) {
@@ -553,7 +575,7 @@ extern "C" int dm_attention_fwd(const void *qkv, const float *bias, void *out, f
   DM_REQUIRE(qkv && out && lse, DM_ERR_BAD_SHAPE, "dm_attention_fwd: null pointer");
   DM_REQUIRE(dm_aligned16(qkv) && dm_aligned16(out) && dm_aligned16(bias), DM_ERR_BAD_ALIGN, "dm_attention_fwd: qkv/out/bias must be 16-byte aligned");
   AttnParams p{};
-  p.qkv = qkv; p.bias = bias; p.out = out; p.lse = lse; p.B = B; p.N = N; p.H = H; p.scale = scale;
+  p.qkv = qkv; p.bias = bias; p.out = out; p.lse = lse; p.B = B; p.N = N; p.H = H; p.scale = scale; p.bchunk = 1;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   {
     const double esz = (dtype == DM_BF16) ? 2.0 : 4.0;
@@ -579,7 +601,7 @@ extern "C" int dm_attention_bwd(const void *qkv, const float *bias, const float 
   AttnParams p{};
   p.qkv = qkv; p.bias = bias; p.bias_t = bias ? bias_t : nullptr; p.out = out; p.dout = dout; p.lse = const_cast<float *>(lse);
   p.delta = delta; p.dqkv = dqkv; p.index = index; p.slab = dtable_slab; p.n_bins = n_bins; p.nblk = (N + QB - 1) / QB;
-  p.B = B; p.N = N; p.H = H; p.scale = scale;
+  p.B = B; p.N = N; p.H = H; p.scale = scale; p.bchunk = batch_chunk(B, N, H);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   {
     const double esz = (dtype == DM_BF16) ? 2.0 : 4.0;

@@ -7,7 +7,7 @@
 namespace {
 
 constexpr int MAXCH = 4;          // float4 chunks per lane per row -> cols <= 1024
-constexpr int LN_MAX_WG = 256;
+constexpr int LN_MAX_WG = 1024;   // 4 workgroups (16 waves) per CU keep enough loads in flight
 constexpr int CS_MAX_SLICES = 64;
 
 // ---------------------------------------------------------------------------------------------
@@ -70,8 +70,8 @@ template <typename TDY>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const TDY *__restrict__ dy, const float *__restrict__ x,
                                                             const float *__restrict__ gamma, const float *__restrict__ mean,
                                                             const float *__restrict__ rstd, const float *__restrict__ dres,
-                                                            float *__restrict__ dx, float *__restrict__ partial,
-                                                            int rows, int cols) {
+                                                            float *__restrict__ dx, bf16_t *__restrict__ dx_lp,
+                                                            float *__restrict__ partial, int rows, int cols) {
   __shared__ float red[4][2][MAXCH * 256];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nch = cols >> 2;
@@ -116,6 +116,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const TDY *__restric
         for (int e = 0; e < 4; ++e) o[e] = rs * (g[i][e] - c1 - xh[i][e] * c2);
         if (dres) o += dm_load4(dres + off + 4 * c);
         dm_store4(dx + off + 4 * c, o);
+        if (dx_lp) dm_store4(dx_lp + off + 4 * c, o);
       }
     }
   }
@@ -402,7 +403,7 @@ extern "C" int dm_layernorm_fwd(const float *x, const float *gamma, const float 
 extern "C" int64_t dm_layernorm_bwd_partial_floats(int32_t cols) { return (int64_t)LN_MAX_WG * 2 * cols; }
 
 extern "C" int dm_layernorm_bwd(const void *dy, int32_t dy_dtype, const float *x, const float *gamma, const float *mean,
-                                const float *rstd, const float *dres, float *dx, float *dgamma, float *dbeta,
+                                const float *rstd, const float *dres, float *dx, void *dx_lp, float *dgamma, float *dbeta,
                                 int32_t accumulate_params, float *partial, int32_t rows, int32_t cols, void *stream) {
   DM_REQUIRE(rows > 0 && cols > 0 && cols % 4 == 0 && cols <= MAXCH * 256, DM_ERR_BAD_SHAPE,
              "dm_layernorm_bwd: rows=%d cols=%d", rows, cols);
@@ -410,9 +411,9 @@ extern "C" int dm_layernorm_bwd(const void *dy, int32_t dy_dtype, const float *x
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const int grid = grid_for((long long)rows, 4, LN_MAX_WG);
   if (dy_dtype == DM_F32)
-    hipLaunchKernelGGL(layernorm_bwd_kernel<float>, dim3(grid), dim3(256), 0, s, (const float *)dy, x, gamma, mean, rstd, dres, dx, partial, rows, cols);
+    hipLaunchKernelGGL(layernorm_bwd_kernel<float>, dim3(grid), dim3(256), 0, s, (const float *)dy, x, gamma, mean, rstd, dres, dx, (bf16_t *)dx_lp, partial, rows, cols);
   else if (dy_dtype == DM_BF16)
-    hipLaunchKernelGGL(layernorm_bwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t *)dy, x, gamma, mean, rstd, dres, dx, partial, rows, cols);
+    hipLaunchKernelGGL(layernorm_bwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t *)dy, x, gamma, mean, rstd, dres, dx, (bf16_t *)dx_lp, partial, rows, cols);
   else DM_REQUIRE(false, DM_ERR_BAD_DTYPE, "dm_layernorm_bwd: bad dy_dtype %d", dy_dtype);
   DM_LAUNCH_CHECK("dm_layernorm_bwd");
   hipLaunchKernelGGL(partial_reduce_kernel, dim3((2 * cols + 31) / 32), dim3(256), 0, s, partial, dgamma, dbeta, grid, 2 * cols, cols, accumulate_params);

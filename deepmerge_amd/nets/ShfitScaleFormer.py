@@ -190,14 +190,13 @@ class CrossScaleBlock(nn.Module):
                        numerics=self.numerics)
 
     def forward(self, x):
-        B, N, Cc = x.shape
-        T = ops.act_dtype(self.numerics)
-        x = x.float()
-        y = ops.LayerNormFn.apply(x, self.norm1.weight, self.norm1.bias, self.norm1.eps, T)
-        x = self.attn._run(y, x.reshape(B * N, Cc), torch.float32).view(B, N, Cc)
-        y = ops.LayerNormFn.apply(x, self.norm2.weight, self.norm2.bias, self.norm2.eps, T)
-        x = self.mlp._run(y.reshape(B * N, Cc), x.reshape(B * N, Cc), torch.float32).view(B, N, Cc)
-        return x
+        a, m = self.attn, self.mlp
+        if a.qkv.bias is None:
+            raise ValueError("the fused block kernel path expects qkv_bias=True (the reference default, :165)")
+        return ops.BlockFn.apply(x.float(), self.norm1.weight, self.norm1.bias, a.relative_position_bias_table, a._index32(),
+                                 a.qkv.weight, a.qkv.bias, a.proj.weight, a.proj.bias, self.norm2.weight, self.norm2.bias,
+                                 m.fc1.weight, m.fc1.bias, m.fc2.weight, m.fc2.bias,
+                                 a.num_heads, self.norm1.eps, float(a.scale), ops.act_dtype(self.numerics))
 
 
 class ShfitScaleFormer_v3(nn.Module):

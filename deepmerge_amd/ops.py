@@ -145,19 +145,21 @@ def layernorm_fwd(x: torch.Tensor, gamma, beta, eps: float, out_dtype: torch.dty
     return y, mean, rstd
 
 
-def layernorm_bwd(dy, x, gamma, mean, rstd, dres=None, dgamma=None, dbeta=None, accumulate=False):
+def layernorm_bwd(dy, x, gamma, mean, rstd, dres=None, dgamma=None, dbeta=None, accumulate=False, want_lp=False):
+    """Returns (dx, dgamma, dbeta) or, with want_lp, (dx, dx_bf16, dgamma, dbeta)."""
     _need_cuda(dy, x)
     rows, cols = x.numel() // x.shape[-1], x.shape[-1]
     dx = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    dx_lp = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device) if want_lp else None
     if dgamma is None:
         dgamma = torch.empty(cols, dtype=torch.float32, device=x.device)
         dbeta = torch.empty(cols, dtype=torch.float32, device=x.device)
         accumulate = False
     part = workspace(_lib.lib().dm_layernorm_bwd_partial_floats(cols) * 4, x.device, "partial")
     check(_lib.lib().dm_layernorm_bwd(dy.data_ptr(), _dt(dy), x.data_ptr(), gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
-                                      _ptr(dres), dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), int(accumulate),
+                                      _ptr(dres), dx.data_ptr(), _ptr(dx_lp), dgamma.data_ptr(), dbeta.data_ptr(), int(accumulate),
                                       part.data_ptr(), rows, cols, _stream()), "dm_layernorm_bwd")
-    return dx, dgamma, dbeta
+    return (dx, dx_lp, dgamma, dbeta) if want_lp else (dx, dgamma, dbeta)
 
 
 def relpos_bias_gather(table: torch.Tensor, index32: torch.Tensor, N: int, transposed: bool = False):
@@ -186,15 +188,19 @@ def attention_bwd(qkv, bias, out, dout, lse, B, N, H, D, scale, index32=None, n_
     delta = torch.empty((B, H, N), dtype=torch.float32, device=qkv.device)
     slab = None
     rows = _lib.lib().dm_attention_bwd_slab_rows(N)
+    chunks = _lib.lib().dm_attention_bwd_batch_chunks(B, N, H)
     if index32 is not None:
-        slab = torch.empty((B * H * rows, n_bins), dtype=torch.float32, device=qkv.device)
+        slab = torch.empty((chunks * H * rows, n_bins), dtype=torch.float32, device=qkv.device)
     check(_lib.lib().dm_attention_bwd(qkv.data_ptr(), _ptr(bias), _ptr(bias_t), out.data_ptr(), dout.data_ptr(), lse.data_ptr(), dqkv.data_ptr(),
                                       delta.data_ptr(), _ptr(index32), n_bins, _ptr(slab), B, N, H, D, scale, _dt(qkv), _stream()),
           "dm_attention_bwd")
-    return dqkv, slab, rows
+    return dqkv, slab, (chunks, rows)
 
 
 def relpos_bias_scatter(slab, dtable, B, H, rows, n_bins, accumulate=False):
+    """`rows` is the (chunks, rows_per_chunk) pair returned by attention_bwd (B is then ignored)."""
+    if isinstance(rows, tuple):
+        B, rows = rows
     check(_lib.lib().dm_relpos_bias_scatter(slab.data_ptr(), dtable.data_ptr(), B, H, rows, n_bins, int(accumulate), _stream()),
           "dm_relpos_bias_scatter")
     return dtable
@@ -442,3 +448,159 @@ class ContrastiveLossFn(torch.autograd.Function):
     def backward(ctx, g):
         da, db = ctx.saved_tensors
         return da * g, db * g, None, None
+
+
+# ------------------------------------------------------------------------------------------------
+# fused transformer block
+# ------------------------------------------------------------------------------------------------
+_GRAD_LP = {}     # data_ptr of an fp32 gradient -> its bf16 copy written by the producing LayerNorm backward
+
+
+def lp_weight(weight: torch.Tensor, dtype: torch.dtype, shape2d) -> torch.Tensor:
+    """Operand-dtype copy of a master weight.  The trainer keeps a flat bf16 mirror updated by the fused
+    Adam kernel and attaches views as `weight._dm_lp`; otherwise cast on the fly."""
+    if dtype == torch.float32:
+        return weight.reshape(shape2d)
+    lp = getattr(weight, "_dm_lp", None)
+    if lp is not None and lp.dtype == dtype:
+        return lp.reshape(shape2d)
+    return cast(weight.reshape(shape2d), dtype)
+
+
+def _operand_grad(dy: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+    """The incoming fp32 gradient as an MFMA operand; reuses the bf16 copy the previous LayerNorm
+    backward already wrote, if there is one."""
+    if dy.dtype == dtype and dy.is_contiguous():
+        return dy
+    lp = _GRAD_LP.pop(dy.data_ptr(), None)
+    if lp is not None and lp.dtype == dtype and lp.numel() == dy.numel():
+        return lp.reshape(dy.shape)
+    return _as_operand(dy, dtype)
+
+
+def _grad_out(param: torch.Tensor, shape, device):
+    """Where a parameter gradient should be written: straight into the trainer's flat gradient buffer
+    (`param._dm_grad_sink`, accumulate) when there is one, else a fresh tensor handed back to autograd."""
+    sink = getattr(param, "_dm_grad_sink", None)
+    if sink is not None:
+        return sink.view(shape), True
+    return torch.empty(shape, dtype=torch.float32, device=device), False
+
+
+def _grad_done(param: torch.Tensor, g: torch.Tensor, direct: bool):
+    """Value to return to autograd for this parameter (None when it went to the sink) + trainer notification."""
+    if not direct:
+        return g.view(param.shape) if g.shape != param.shape else g
+    hook = getattr(param, "_dm_grad_ready", None)
+    if hook is not None:
+        hook(param)
+    return None
+
+
+class BlockFn(torch.autograd.Function):
+    """Whole pre-norm block  x += proj(attn(LN1(x)));  x += fc2(GELU(fc1(LN2(x))))
+    (CrossScaleBlock, nets/ShfitScaleFormer.py:181-184; vit_model.Block :182-185 with table=None).
+
+    One autograd node per block: both residual adds live in GEMM epilogues, the residual-gradient adds in
+    the LayerNorm backward kernels, GELU' in the fc2 dgrad epilogue; nothing is left to torch elementwise ops.
+    """
+
+    @staticmethod
+    def forward(ctx, x, n1w, n1b, table, index32, qkv_w, qkv_b, proj_w, proj_b, n2w, n2b, fc1_w, fc1_b, fc2_w, fc2_b,
+                heads, eps, scale, dtype):
+        x = x.contiguous()
+        B, N, Cc = x.shape
+        M, Hd, D = B * N, fc1_w.shape[0], Cc // heads
+        dev = x.device
+        wq, wp = lp_weight(qkv_w, dtype, (3 * Cc, Cc)), lp_weight(proj_w, dtype, (Cc, Cc))
+        w1, w2 = lp_weight(fc1_w, dtype, (Hd, Cc)), lp_weight(fc2_w, dtype, (Cc, Hd))
+        x2d = x.view(M, Cc)
+        y1, mean1, rstd1 = layernorm_fwd(x2d, n1w, n1b, eps, dtype)
+        qkv = torch.empty((M, 3 * Cc), dtype=dtype, device=dev)
+        gemm(DM_NT, y1, wq, qkv, M, 3 * Cc, Cc, lda=Cc, ldb=Cc, ldc=3 * Cc, bias=qkv_b)
+        bias = bias_t = None
+        if table is not None:
+            bias, bias_t = relpos_bias_gather(table.contiguous(), index32, N, transposed=True)
+        o, lse = attention_fwd(qkv, bias, B, N, heads, D, scale)
+        x1 = torch.empty((M, Cc), dtype=torch.float32, device=dev)
+        gemm(DM_NT, o.view(M, Cc), wp, x1, M, Cc, Cc, lda=Cc, ldb=Cc, ldc=Cc, bias=proj_b, residual=x2d)
+        y2, mean2, rstd2 = layernorm_fwd(x1, n2w, n2b, eps, dtype)
+        pre = torch.empty((M, Hd), dtype=dtype, device=dev)
+        h = torch.empty((M, Hd), dtype=dtype, device=dev)
+        gemm(DM_NT, y2, w1, h, M, Hd, Cc, lda=Cc, ldb=Cc, ldc=Hd, bias=fc1_b, epilogue=DM_EPI_GELU, aux=pre, ldaux=Hd)
+        x2 = torch.empty((M, Cc), dtype=torch.float32, device=dev)
+        gemm(DM_NT, h, w2, x2, M, Cc, Hd, lda=Hd, ldb=Hd, ldc=Cc, bias=fc2_b, residual=x1)
+        ctx.save_for_backward(x2d, mean1, rstd1, y1, qkv, o, lse, bias, bias_t, index32, x1, mean2, rstd2, y2, pre, h,
+                              wq, wp, w1, w2, n1w, n2w)
+        ctx.dims = (B, N, Cc, heads, D, Hd, scale, None if table is None else table.shape[0])
+        ctx.params = (n1w, n1b, table, qkv_w, qkv_b, proj_w, proj_b, n2w, n2b, fc1_w, fc1_b, fc2_w, fc2_b)
+        return x2.view(B, N, Cc)
+
+    @staticmethod
+    def backward(ctx, dx2):
+        (x, mean1, rstd1, y1, qkv, o, lse, bias, bias_t, index32, x1, mean2, rstd2, y2, pre, h,
+         wq, wp, w1, w2, n1w, n2w) = ctx.saved_tensors
+        (P_n1w, P_n1b, P_table, P_qkv_w, P_qkv_b, P_proj_w, P_proj_b, P_n2w, P_n2b, P_fc1_w, P_fc1_b, P_fc2_w, P_fc2_b) = ctx.params
+        B, N, Cc, heads, D, Hd, scale, n_bins = ctx.dims
+        M = B * N
+        dtype, dev = y1.dtype, x.device
+        lp = dtype != torch.float32
+        dx2 = dx2.contiguous().view(M, Cc)
+        dy = _operand_grad(dx2, dtype)
+        # ---- MLP ---------------------------------------------------------------------------
+        dw2, k_w2 = _grad_out(P_fc2_w, (Cc, Hd), dev)
+        gemm(DM_TN, dy, h, dw2, Cc, Hd, M, lda=Cc, ldb=Hd, ldc=Hd, accumulate=k_w2)
+        db2, k_b2 = _grad_out(P_fc2_b, (Cc,), dev)
+        colsum(dy, db2, accumulate=k_b2)
+        dpre = torch.empty((M, Hd), dtype=dtype, device=dev)
+        gemm(DM_NN, dy, w2, dpre, M, Hd, Cc, lda=Cc, ldb=Hd, ldc=Hd, epilogue=DM_EPI_DGELU, aux=pre, ldaux=Hd)
+        dw1, k_w1 = _grad_out(P_fc1_w, (Hd, Cc), dev)
+        gemm(DM_TN, dpre, y2, dw1, Hd, Cc, M, lda=Hd, ldb=Cc, ldc=Cc, accumulate=k_w1)
+        db1, k_b1 = _grad_out(P_fc1_b, (Hd,), dev)
+        colsum(dpre, db1, accumulate=k_b1)
+        dy2 = torch.empty((M, Cc), dtype=dtype, device=dev)
+        gemm(DM_NN, dpre, w1, dy2, M, Cc, Hd, lda=Hd, ldb=Cc, ldc=Cc)
+        dg2, k_n2 = _grad_out(P_n2w, (Cc,), dev)
+        dbt2, k_n2b = _grad_out(P_n2b, (Cc,), dev)
+        if k_n2 != k_n2b:      # mixed sinks: fall back to fresh tensors for both
+            dg2, dbt2, k_n2, k_n2b = torch.empty(Cc, device=dev), torch.empty(Cc, device=dev), False, False
+        r = layernorm_bwd(dy2, x1, n2w, mean2, rstd2, dres=dx2, dgamma=dg2, dbeta=dbt2, accumulate=k_n2, want_lp=lp)
+        dx1, dx1_lp = (r[0], r[1]) if lp else (r[0], r[0])
+        # ---- attention -----------------------------------------------------------------------
+        dwp, k_wp = _grad_out(P_proj_w, (Cc, Cc), dev)
+        gemm(DM_TN, dx1_lp, o.view(M, Cc), dwp, Cc, Cc, M, lda=Cc, ldb=Cc, ldc=Cc, accumulate=k_wp)
+        dbp, k_bp = _grad_out(P_proj_b, (Cc,), dev)
+        colsum(dx1_lp, dbp, accumulate=k_bp)
+        do = torch.empty((M, Cc), dtype=dtype, device=dev)
+        gemm(DM_NN, dx1_lp, wp, do, M, Cc, Cc, lda=Cc, ldb=Cc, ldc=Cc)
+        want_table = bias is not None
+        dqkv, slab, rows = attention_bwd(qkv, bias, o, do, lse, B, N, heads, D, scale,
+                                         index32 if want_table else None, n_bins or 0, bias_t=bias_t)
+        dtable, k_t = None, False
+        if want_table:
+            dtable, k_t = _grad_out(P_table, (n_bins, heads), dev)
+            relpos_bias_scatter(slab, dtable, B, heads, rows, n_bins, accumulate=k_t)
+        dqkv2 = dqkv.view(M, 3 * Cc)
+        dwq, k_wq = _grad_out(P_qkv_w, (3 * Cc, Cc), dev)
+        gemm(DM_TN, dqkv2, y1, dwq, 3 * Cc, Cc, M, lda=3 * Cc, ldb=Cc, ldc=Cc, accumulate=k_wq)
+        dbq, k_bq = _grad_out(P_qkv_b, (3 * Cc,), dev)
+        colsum(dqkv2, dbq, accumulate=k_bq)
+        dy1 = torch.empty((M, Cc), dtype=dtype, device=dev)
+        gemm(DM_NN, dqkv2, wq, dy1, M, Cc, 3 * Cc, lda=3 * Cc, ldb=Cc, ldc=Cc)
+        dg1, k_n1 = _grad_out(P_n1w, (Cc,), dev)
+        dbt1, k_n1b = _grad_out(P_n1b, (Cc,), dev)
+        if k_n1 != k_n1b:
+            dg1, dbt1, k_n1, k_n1b = torch.empty(Cc, device=dev), torch.empty(Cc, device=dev), False, False
+        r = layernorm_bwd(dy1, x, n1w, mean1, rstd1, dres=dx1, dgamma=dg1, dbeta=dbt1, accumulate=k_n1, want_lp=lp)
+        dx = r[0]
+        if lp:
+            if len(_GRAD_LP) > 64:
+                _GRAD_LP.clear()
+            _GRAD_LP[dx.data_ptr()] = r[1]
+        return (dx.view(B, N, Cc), _grad_done(P_n1w, dg1, k_n1), _grad_done(P_n1b, dbt1, k_n1b),
+                _grad_done(P_table, dtable, k_t) if want_table else None, None,
+                _grad_done(P_qkv_w, dwq, k_wq), _grad_done(P_qkv_b, dbq, k_bq),
+                _grad_done(P_proj_w, dwp, k_wp), _grad_done(P_proj_b, dbp, k_bp),
+                _grad_done(P_n2w, dg2, k_n2), _grad_done(P_n2b, dbt2, k_n2b),
+                _grad_done(P_fc1_w, dw1, k_w1), _grad_done(P_fc1_b, db1, k_b1),
+                _grad_done(P_fc2_w, dw2, k_w2), _grad_done(P_fc2_b, db2, k_b2), None, None, None, None)

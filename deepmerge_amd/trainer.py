@@ -45,7 +45,7 @@ def shard_slice(global_batch: int, rank: int, world: int) -> slice:
 class FlatParams:
     """Re-homes a module's parameters and gradients into flat fp32 buffers (views keep autograd working)."""
 
-    def __init__(self, module: torch.nn.Module, align: int = 64):
+    def __init__(self, module: torch.nn.Module, align: int = 64, lp_mirror: bool = True):
         params = [p for p in module.parameters() if p.requires_grad]
         params.reverse()                      # backward order: last-used parameters first
         self.params = params
@@ -57,11 +57,24 @@ class FlatParams:
         self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
         self.grad = torch.zeros(total, dtype=torch.float32, device=dev)
         self.offsets, self.total = offs, total
+        # bf16 mirror of the weights (MFMA operands), rewritten by the fused Adam kernel each step
+        self.flat_lp = torch.zeros(total, dtype=torch.bfloat16, device=dev) if lp_mirror and dev.type == "cuda" else None
         for p, o in zip(params, offs):
             n = p.numel()
             self.flat[o:o + n].copy_(p.data.reshape(-1))
             p.data = self.flat[o:o + n].view_as(p)
             p.grad = self.grad[o:o + n].view_as(p)
+            if self.flat_lp is not None:
+                p._dm_lp = self.flat_lp[o:o + n].view_as(p)
+            if dev.type == "cuda":
+                # fused backward kernels accumulate straight into the flat gradient buffer (ops._grad_out)
+                p._dm_grad_sink = self.grad[o:o + n].view_as(p)
+        self.refresh_lp()
+
+    def refresh_lp(self):
+        """Re-derive the bf16 mirror from the fp32 masters (after load_state_dict or any external update)."""
+        if self.flat_lp is not None:
+            self.flat_lp.copy_(ops.cast(self.flat, torch.bfloat16))
 
     def zero_grad(self):
         self.grad.zero_()
@@ -93,7 +106,7 @@ class PairTrainer:
         self.lr, self.betas, self.eps = lr, betas, eps
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
-        self.fp = FlatParams(net)
+        self.fp = FlatParams(net, lp_mirror=(getattr(net, "numerics", "bf16") == "bf16"))
         self.m = torch.zeros_like(self.fp.flat)
         self.v = torch.zeros_like(self.fp.flat)
         self.step_count = 0
@@ -122,6 +135,7 @@ class PairTrainer:
                 self._launch_bucket(bi)
         for p in fp.params:
             p.register_post_accumulate_grad_hook(hook)
+            p._dm_grad_ready = hook          # same notification when a fused backward wrote the sink directly
         self._hooks_installed = True
 
     def _launch_bucket(self, bi: int):
@@ -151,6 +165,7 @@ class PairTrainer:
         if self.world > 1:
             self._finish_exchange()
         self.step_count += 1
+        extra = {"param_lp": self.fp.flat_lp} if self.fp.flat_lp is not None else {}
         self.adam_fn(self.fp.flat, self.fp.grad, self.m, self.v, self.step_count, lr=self.lr if lr is None else lr,
-                     beta1=self.betas[0], beta2=self.betas[1], eps=self.eps, grad_scale=1.0 / self.world)
+                     beta1=self.betas[0], beta2=self.betas[1], eps=self.eps, grad_scale=1.0 / self.world, **extra)
         return loss.detach()

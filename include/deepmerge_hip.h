@@ -108,17 +108,20 @@ int64_t dm_gemm_workspace_bytes(int32_t layout, int32_t M, int32_t N, int32_t K)
 int dm_attention_fwd(const void *qkv, const float *bias, void *out, float *lse,
                      int32_t B, int32_t N, int32_t H, int32_t D, float scale, int32_t dtype, void *stream);
 /* Backward: dqkv [B,N,3,H,D] T (fully written).  If index != NULL, the gradient of the bias is
- * binned on the fly: dtable_slab[(b*H+h)*n_qblk + qblk][bin] = sum of dS over (i,j) with
- * index[i,j] == bin (int32 [N,N], values < n_bins), fp32, fully written; reduce it with
- * dm_relpos_bias_scatter.  delta is a [B,H,N] fp32 scratch.  bias_t (optional) is the per-head
+ * binned on the fly: dtable_slab[(c*H+h)*n_qblk + qblk][bin] = sum over the samples of batch chunk c
+ * of dS over (i,j) with index[i,j] == bin (int32 [N,N], values < n_bins), fp32, fully written:
+ * dm_attention_bwd_batch_chunks(B,N,H) * H * dm_attention_bwd_slab_rows(N) rows of n_bins floats;
+ * reduce it with dm_relpos_bias_scatter(slab, dtable, chunks, H, rows, ...).  delta is a [B,H,N] fp32 scratch.  bias_t (optional) is the per-head
  * transpose of bias, bias_t[h][key][q], which lets the key-major kernel read the bias with coalesced
  * vector loads; NULL falls back to strided reads of `bias`. */
 int dm_attention_bwd(const void *qkv, const float *bias, const float *bias_t, const void *out, const void *dout,
                      const float *lse, void *dqkv, float *delta, const int32_t *index, int32_t n_bins,
                      float *dtable_slab, int32_t B, int32_t N, int32_t H, int32_t D, float scale, int32_t dtype,
                      void *stream);
-/* Number of slab rows per (b,h) that dm_attention_bwd writes (query blocks of 64 rows). */
+/* Number of slab rows per (chunk,h) that dm_attention_bwd writes (query blocks of 64 rows), and the
+ * number of batch chunks it uses for this problem size. */
 int32_t dm_attention_bwd_slab_rows(int32_t N);
+int32_t dm_attention_bwd_batch_chunks(int32_t B, int32_t N, int32_t H);
 
 /* relative_position_bias_table[index.view(-1)].view(N,N,H).permute(2,0,1)
  * (nets/ShfitScaleFormer.py:123-128): table [n_bins,H] fp32, index int32 [N,N] -> bias [H,N,N] and,
@@ -135,10 +138,11 @@ int dm_relpos_bias_scatter(const float *slab, float *dtable, int32_t B, int32_t 
  * vit_model.py:183-184, :498): x [rows, cols] fp32 -> y (y_dtype), saving mean / rstd [rows]. */
 int dm_layernorm_fwd(const float *x, const float *gamma, const float *beta, void *y, int32_t y_dtype,
                      float *mean, float *rstd, int32_t rows, int32_t cols, float eps, void *stream);
-/* dx = (dres ? dres : 0) + LN'(dy); dgamma/dbeta (+)= column sums.  partial: fp32 scratch of
+/* dx = (dres ? dres : 0) + LN'(dy); dx_lp (optional) receives the same values as bf16 (the operand
+ * copy the previous layer's backward GEMMs consume); dgamma/dbeta (+)= column sums.  partial: fp32 scratch of
  * dm_layernorm_bwd_partial_floats(cols) floats. */
 int dm_layernorm_bwd(const void *dy, int32_t dy_dtype, const float *x, const float *gamma,
-                     const float *mean, const float *rstd, const float *dres, float *dx,
+                     const float *mean, const float *rstd, const float *dres, float *dx, void *dx_lp,
                      float *dgamma, float *dbeta, int32_t accumulate_params, float *partial,
                      int32_t rows, int32_t cols, void *stream);
 int64_t dm_layernorm_bwd_partial_floats(int32_t cols);
