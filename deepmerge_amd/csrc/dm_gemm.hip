@@ -338,37 +338,75 @@ __global__ void splitk_reduce_kernel(const float *__restrict__ slab, float *__re
   }
 }
 
-// Generic fp32 kernel for the small/odd-shaped products of the tail (K = 19, N = 100, M = batch):
-// plain FMA chains in k order, one output element per thread, LDS-tiled 16x16.
+// Generic fp32 kernel for the small / odd-shaped products of the tail (K = 19, N = 100, M = batch): any
+// shape, any alignment.  These products have few output tiles and a long K, so they are latency-bound:
+// the four waves of a workgroup split K four ways for one 16x16 output tile (each wave stages its own
+// 16x32 / 32x16 operand slices through a private LDS region), and the partial tiles are summed in a
+// fixed order before the epilogue.  FMA chains in k order within a wave; deterministic.
 template <int LAYOUT>
-__global__ void sgemm_small_kernel(const GemmParams p) {
-  __shared__ float sa[16][17], sb[16][17];
-  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-  const int m = blockIdx.y * 16 + ty, n = blockIdx.x * 16 + tx;
+__global__ __launch_bounds__(256) void sgemm_small_kernel(const GemmParams p) {
+  __shared__ float sa[4][32][17], sb[4][32][17];
+  __shared__ float red[4][16][17];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int m0 = blockIdx.y * 16, n0 = blockIdx.x * 16;
   const float *A = reinterpret_cast<const float *>(p.A);
   const float *B = reinterpret_cast<const float *>(p.B);
-  float acc = 0.f;
-  for (int k0 = 0; k0 < p.K; k0 += 16) {
-    // sa[i][kk] = A(op)[m0+i][k0+kk], sb[kk][j] = B(op)[k0+kk][n0+j]
-    {
-      const int mi = blockIdx.y * 16 + ty, kk = k0 + tx;
-      float v = 0.f;
-      if (mi < p.M && kk < p.K) v = (LAYOUT == DM_TN) ? A[(long long)kk * p.lda + mi] : A[(long long)mi * p.lda + kk];
-      sa[ty][tx] = v;
-    }
-    {
-      const int kk = k0 + ty, nj = blockIdx.x * 16 + tx;
-      float v = 0.f;
-      if (kk < p.K && nj < p.N) v = (LAYOUT == DM_NT) ? B[(long long)nj * p.ldb + kk] : B[(long long)kk * p.ldb + nj];
-      sb[ty][tx] = v;
-    }
-    __syncthreads();
+  const int kq = ((p.K + 3) / 4 + 31) / 32 * 32;          // K slice per wave, multiple of 32
+  const int kbeg = w * kq, kend = min(p.K, kbeg + kq);
+  const int tx = lane & 15, ty = lane >> 4;                // lane computes rows 4ty..4ty+3 of column tx
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  float ra[8], rb[8];
+  auto gload = [&](int k0) {
 #pragma unroll
-    for (int kk = 0; kk < 16; ++kk) acc = fmaf(sa[ty][kk], sb[kk][tx], acc);
+    for (int i = 0; i < 8; ++i) {
+      const int idx = lane + 64 * i;
+      {   // A(op)[m0 + r][k0 + kk]: consecutive lanes walk the contiguous index of the layout
+        const int r = (LAYOUT == DM_TN) ? (idx & 15) : (idx >> 5), kk = (LAYOUT == DM_TN) ? (idx >> 4) : (idx & 31);
+        const int m = m0 + r, k = k0 + kk;
+        float v = 0.f;
+        if (m < p.M && k < kend) v = (LAYOUT == DM_TN) ? A[(long long)k * p.lda + m] : A[(long long)m * p.lda + k];
+        ra[i] = v;
+      }
+      {   // B(op)[k0 + kk][n0 + c]
+        const int c = (LAYOUT == DM_NT) ? (idx >> 5) : (idx & 15), kk = (LAYOUT == DM_NT) ? (idx & 31) : (idx >> 4);
+        const int n = n0 + c, k = k0 + kk;
+        float v = 0.f;
+        if (n < p.N && k < kend) v = (LAYOUT == DM_NT) ? B[(long long)n * p.ldb + k] : B[(long long)k * p.ldb + n];
+        rb[i] = v;
+      }
+    }
+  };
+  auto lstore = [&]() {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int idx = lane + 64 * i;
+      const int ar = (LAYOUT == DM_TN) ? (idx & 15) : (idx >> 5), ak = (LAYOUT == DM_TN) ? (idx >> 4) : (idx & 31);
+      sa[w][ak][ar] = ra[i];
+      const int bc = (LAYOUT == DM_NT) ? (idx >> 5) : (idx & 15), bk = (LAYOUT == DM_NT) ? (idx & 31) : (idx >> 4);
+      sb[w][bk][bc] = rb[i];
+    }
+  };
+  const int nk = (kq + 31) / 32;                             // same trip count for every wave (barriers inside)
+  gload(kbeg);
+  for (int it = 0; it < nk; ++it) {
     __syncthreads();
+    lstore();
+    __syncthreads();
+    if (it + 1 < nk) gload(kbeg + (it + 1) * 32);
+#pragma unroll
+    for (int kk = 0; kk < 32; ++kk) {
+      const float bv = sb[w][kk][tx];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[j] = fmaf(sa[w][kk][4 * ty + j], bv, acc[j]);
+    }
   }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) red[w][4 * ty + j][tx] = acc[j];
+  __syncthreads();
+  const int om = threadIdx.x >> 4, on = threadIdx.x & 15;
+  const int m = m0 + om, n = n0 + on;
   if (m >= p.M || n >= p.N) return;
-  float v = acc;
+  float v = (red[0][om][on] + red[1][om][on]) + (red[2][om][on] + red[3][om][on]);
   if (p.bias) v += p.bias[n];
   const long long ro = (long long)m;
   if (p.epilogue == DM_EPI_GELU) {

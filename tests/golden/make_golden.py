@@ -239,18 +239,97 @@ def gen_model(S2F, Losses):
     print("model_v3.npz", len(fx))
 
 
+def gen_vit(vit_model, Losses):
+    """vit_model.py pair encoders (BASELINE configs[2])."""
+    fx = {}
+    crit = Losses.Loss(margin=1.0, lamda=0.1, belta=0)
+    flag = torch.tensor([1, 0], dtype=torch.int64)
+    # ---- VisionTransformer ViT-B/16 (num_classes=100, has_logits=False), depth 12 and a 2-block cut ----
+    for tag, depth in (("vitb16_d12", 12), ("vitb16_d2", 2)):
+        if depth == 12:
+            net = vit_model.vit_base_patch16_224_in21k(num_classes=100, has_logits=False)
+        else:
+            net = vit_model.VisionTransformer(img_size=224, patch_size=16, embed_dim=768, depth=depth, num_heads=12,
+                                              representation_size=None, num_classes=100)
+        load_det_weights(net, "")
+        sd = net.state_dict()
+        fx[tag + "/manifest_keys"] = np.array(list(sd.keys()))
+        fx[tag + "/manifest_shapes"] = np.array([",".join(map(str, v.shape)) for v in sd.values()])
+        fx[tag + "/n_params"] = np.int64(sum(p.numel() for p in net.parameters()))
+        x1 = t(tag + ".x1", (2, 3, 224, 224), "unit"); x2 = t(tag + ".x2", (2, 3, 224, 224), "unit")
+        x2[1] = x1[1] * 0.8 + 0.2 * x2[1]
+        net.train()
+        ya, yb = net(x1, x2)
+        loss = crit(ya, yb, flag)
+        loss.backward()
+        add(fx, tag + "/out_a", ya); add(fx, tag + "/out_b", yb)
+        fx[tag + "/loss"] = np.float64(loss.item())
+        fx[tag + "/dist"] = (ya - yb).pow(2).sum(1).detach().numpy().astype(np.float64)
+        for n, p in net.named_parameters():
+            assert p.grad is not None, n
+            add(fx, tag + "/grad/" + n, p.grad, k=512)
+        one = net(x1)
+        fx[tag + "/single_equals_pair"] = np.bool_(torch.equal(one, ya))
+        try:
+            net(x1, x1, x1, x1)
+            fx[tag + "/four_args_raise"] = np.bool_(False)
+        except ValueError:
+            fx[tag + "/four_args_raise"] = np.bool_(True)
+        print(tag, "loss", fx[tag + "/loss"], "dist", fx[tag + "/dist"], "params", int(fx[tag + "/n_params"]))
+    # ---- ScaleEmbedTransformer (multi-scale + designed-feature token) --------------------------------
+    for tag, depth in (("vitscale_d12", 12), ("vitscale_d2", 2)):
+        if depth == 12:
+            net = vit_model.vit_base_patch_scales_224_in21k(num_classes=512, has_logits=False)
+        else:
+            net = vit_model.ScaleEmbedTransformer(img_size=224, patch_size=16, embed_dim=768, depth=depth, num_heads=12,
+                                                  representation_size=None, num_classes=512)
+        load_det_weights(net, "")
+        sd = net.state_dict()
+        fx[tag + "/manifest_keys"] = np.array(list(sd.keys()))
+        fx[tag + "/manifest_shapes"] = np.array([",".join(map(str, v.shape)) for v in sd.values()])
+        fx[tag + "/n_params"] = np.int64(sum(p.numel() for p in net.parameters()))
+        sizes = (28, 56, 112, 224)
+        xa = [t(f"{tag}.xa{i}", (2, 3, s, s), "unit") for i, s in enumerate(sizes)]
+        xb = [t(f"{tag}.xb{i}", (2, 3, s, s), "unit") for i, s in enumerate(sizes)]
+        fa = t(tag + ".fa", (2, 1, 19), "designed"); fb = t(tag + ".fb", (2, 1, 19), "designed")
+        for i in range(4):
+            xb[i][1] = xa[i][1] * 0.8 + 0.2 * xb[i][1]
+        fb[1] = fa[1] * 1.2
+        net.train()
+        ya, yb = net(xa, fa, xb, fb)
+        loss = crit(ya, yb, flag)
+        loss.backward()
+        add(fx, tag + "/out_a", ya); add(fx, tag + "/out_b", yb)
+        fx[tag + "/loss"] = np.float64(loss.item())
+        fx[tag + "/dist"] = (ya - yb).pow(2).sum(1).detach().numpy().astype(np.float64)
+        none = []
+        for n, p in net.named_parameters():
+            if p.grad is None:
+                none.append(n)
+            else:
+                add(fx, tag + "/grad/" + n, p.grad, k=512)
+        fx[tag + "/grad_none"] = np.array(none)
+        two = net(xa, fa)                      # 2 args = (patches, designed), NOT a pair (:544-545)
+        fx[tag + "/two_args_equals_left"] = np.bool_(torch.equal(two, ya))
+        print(tag, "loss", fx[tag + "/loss"], "dist", fx[tag + "/dist"], "none", none)
+    np.savez_compressed(os.path.join(HERE, "model_vit.npz"), **fx)
+    print("model_vit.npz", len(fx))
+
+
 def main():
     warnings.filterwarnings("ignore")
     torch.manual_seed(0)
     torch.set_num_threads(8)
     S2F, vit_model, Losses = import_reference()
-    which = sys.argv[1:] or ["relpos", "ops", "model"]
+    which = sys.argv[1:] or ["relpos", "ops", "model", "vit"]
     if "relpos" in which:
         gen_relpos(S2F)
     if "ops" in which:
         gen_ops(S2F, Losses)
     if "model" in which:
         gen_model(S2F, Losses)
+    if "vit" in which:
+        gen_vit(vit_model, Losses)
 
 
 if __name__ == "__main__":

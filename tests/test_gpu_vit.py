@@ -1,0 +1,105 @@
+"""GPU: deepmerge_amd.vit_model (VisionTransformer / ScaleEmbedTransformer drop-ins) against the golden vectors
+captured from the reference's vit_model.py (tests/golden/model_vit.npz)."""
+import numpy as np
+import pytest
+import torch
+
+import recipe
+from test_gpu_modules import load_recipe_weights
+from test_oracle_vit import scale_inputs, vit_inputs
+from util import load_fx
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+GATE = 1e-3
+
+
+def VM():
+    from deepmerge_amd import vit_model
+    return vit_model
+
+
+@pytest.mark.parametrize("tag,depth", [("vitb16_d2", 2), ("vitb16_d12", 12)])
+def test_vision_transformer_parity_fp32(tag, depth):
+    from deepmerge_amd.Losses import Loss
+    fx = load_fx("model_vit.npz")
+    vm = VM()
+    if depth == 12:
+        net = vm.vit_base_patch16_224_in21k(num_classes=100, has_logits=False, numerics="fp32")
+    else:
+        net = vm.VisionTransformer(img_size=224, patch_size=16, embed_dim=768, depth=depth, num_heads=12, representation_size=None,
+                                   num_classes=100, numerics="fp32")
+    sd = net.state_dict()
+    assert list(sd.keys()) == [str(k) for k in fx[tag + "/manifest_keys"]]
+    assert [",".join(map(str, v.shape)) for v in sd.values()] == [str(s) for s in fx[tag + "/manifest_shapes"]]
+    assert net.has_logits is False
+    net = load_recipe_weights(net).to(DEV).train()
+    x1, x2, flag = vit_inputs(tag)
+    ya, yb = net(x1.to(DEV), x2.to(DEV))
+    loss = Loss(1.0, 0.1, 0)(ya, yb, flag.to(DEV))
+    loss.backward()
+    recipe.check_summary(tag + "/out_a", ya.detach().cpu().numpy(), fx, GATE)
+    recipe.check_summary(tag + "/out_b", yb.detach().cpu().numpy(), fx, GATE)
+    assert abs(loss.item() - float(fx[tag + "/loss"])) <= GATE * abs(float(fx[tag + "/loss"]))
+    worst = 0.0
+    for n, p in net.named_parameters():
+        assert p.grad is not None, n
+        recipe.check_summary(tag + "/grad/" + n, p.grad.cpu().numpy(), fx, GATE, k=512, atol=1e-7)
+        worst = max(worst, recipe.summary_error(tag + "/grad/" + n, p.grad.cpu().numpy(), fx, k=512)[0])
+    print(f"{tag}: worst gradient rel-L2 error {worst:.2e}")
+    with torch.no_grad():
+        one = net(x1.to(DEV))
+    recipe.check_summary(tag + "/out_a", one.cpu().numpy(), fx, GATE)
+    with pytest.raises(ValueError):
+        net(x1, x1, x1, x1)
+
+
+@pytest.mark.parametrize("tag,depth", [("vitscale_d2", 2), ("vitscale_d12", 12)])
+def test_scale_embed_transformer_parity_fp32(tag, depth):
+    from deepmerge_amd.Losses import Loss
+    fx = load_fx("model_vit.npz")
+    vm = VM()
+    if depth == 12:
+        net = vm.vit_base_patch_scales_224_in21k(num_classes=512, has_logits=False, numerics="fp32")
+    else:
+        net = vm.ScaleEmbedTransformer(img_size=224, patch_size=16, embed_dim=768, depth=depth, num_heads=12,
+                                       representation_size=None, num_classes=512, numerics="fp32")
+    sd = net.state_dict()
+    assert list(sd.keys()) == [str(k) for k in fx[tag + "/manifest_keys"]]
+    net = load_recipe_weights(net).to(DEV).train()
+    xa, fa, xb, fb, flag = scale_inputs(tag)
+    ya, yb = net([t.to(DEV) for t in xa], fa.to(DEV), [t.to(DEV) for t in xb], fb.to(DEV))
+    loss = Loss(1.0, 0.1, 0)(ya, yb, flag.to(DEV))
+    loss.backward()
+    recipe.check_summary(tag + "/out_a", ya.detach().cpu().numpy(), fx, GATE)
+    recipe.check_summary(tag + "/out_b", yb.detach().cpu().numpy(), fx, GATE)
+    assert abs(loss.item() - float(fx[tag + "/loss"])) <= GATE * abs(float(fx[tag + "/loss"]))
+    none = sorted(n for n, p in net.named_parameters() if p.grad is None)
+    assert none == sorted(str(s) for s in fx[tag + "/grad_none"])
+    for n, p in net.named_parameters():
+        if p.grad is not None:
+            recipe.check_summary(tag + "/grad/" + n, p.grad.cpu().numpy(), fx, GATE, k=512, atol=1e-7)
+    with torch.no_grad():
+        two = net([t.to(DEV) for t in xa], fa.to(DEV))
+    recipe.check_summary(tag + "/out_a", two.cpu().numpy(), fx, GATE)
+    with pytest.raises(ValueError):
+        net(xa, fa, xb)
+
+
+def test_vit_bf16_drift_bounded():
+    from deepmerge_amd.Losses import Loss
+    tag = "vitb16_d12"
+    fx = load_fx("model_vit.npz")
+    net = load_recipe_weights(VM().vit_base_patch16_224_in21k(num_classes=100, has_logits=False, numerics="bf16")).to(DEV).train()
+    x1, x2, flag = vit_inputs(tag)
+    ya, yb = net(x1.to(DEV), x2.to(DEV))
+    Loss(1.0, 0.1, 0)(ya, yb, flag.to(DEV)).backward()
+    e = recipe.summary_error(tag + "/out_a", ya.detach().cpu().numpy(), fx)
+    errs = [recipe.summary_error(tag + "/grad/" + n, p.grad.cpu().numpy(), fx, k=512)[0] for n, p in net.named_parameters()]
+    print(f"ViT-B/16 bf16 drift: embeddings rel-L2 {e[0]:.2e}; median grad rel-L2 {np.median(errs):.2e}")
+    assert e[0] < 3e-2 and np.median(errs) < 1e-1
+
+
+def test_vit_huge_is_declared_unsupported():
+    with pytest.raises(NotImplementedError):
+        VM().vit_huge_patch14_224_in21k()
