@@ -21,7 +21,8 @@ import torch.nn as nn
 
 from .. import ops
 
-__all__ = ["PatchEmbed", "Mlp", "FeatureEmbed", "CrossScaleAttention", "CrossScaleBlock", "ShfitScaleFormer_v3"]
+__all__ = ["PatchEmbed", "Mlp", "FeatureEmbed", "CrossScaleAttention", "CrossScaleBlock", "ShfitScaleFormer",
+           "ShfitScaleFormer_v2", "ShfitScaleFormer_v3", "ShfitScaleFormer_v6"]
 
 
 def _mode(numerics: Optional[str]) -> str:
@@ -307,3 +308,176 @@ class ShfitScaleFormer_v3(nn.Module):
         elif isinstance(m, nn.LayerNorm):
             nn.init.constant_(m.bias, 0)
             nn.init.constant_(m.weight, 1.0)
+
+
+class _SingleStage(nn.Module):
+    """Shared body of the single-stage variants: S patch embeds -> blocks on the [S, side, side] cube -> norm ->
+    per-scale token mean -> (+ normed designed-feature embedding) -> Linear to 100-d."""
+
+    def _init_weights(self, m):
+        if isinstance(m, nn.Linear):
+            nn.init.trunc_normal_(m.weight, std=.02)
+            if m.bias is not None:
+                nn.init.constant_(m.bias, 0)
+        elif isinstance(m, nn.LayerNorm):
+            nn.init.constant_(m.bias, 0)
+            nn.init.constant_(m.weight, 1.0)
+
+    def _build_tail(self, embed_dim, norm_layer, drop_ratio, num_classes):
+        S = self.input_scales_num
+        self.norm = norm_layer(embed_dim)
+        self.pos_drop = nn.Dropout(p=drop_ratio)
+        self.avgpool = nn.AdaptiveAvgPool1d(1)
+        self.final_features = nn.Linear(int(S * embed_dim), 100)
+        self.final_features_with_design = nn.Linear(int((S + 1) * embed_dim), 100)
+        self.head = nn.Linear(100, num_classes) if num_classes > 0 else nn.Identity()
+
+    def _ln(self, x):
+        return ops.LayerNormFn.apply(x, self.norm.weight, self.norm.bias, self.norm.eps, torch.float32)
+
+    def designed_feature_embed(self, x):
+        return self.feature_embed(x)
+
+    def _scale_means(self, x):
+        B = x[0].shape[0]
+        t = self._ln(self.blocks(self.pos_drop(self.patch_embed(x))))
+        return ops.GroupMeanFn.apply(t, t.shape[1] // self.input_scales_num).view(B, -1)
+
+    def forward_once_design_feature(self, x, designed_features):
+        x = self._scale_means(x)
+        d = self._ln(torch.squeeze(self.designed_feature_embed(designed_features), dim=1))
+        return ops.LinearFn.apply(torch.cat((x, d), 1), self.final_features_with_design.weight,
+                                  self.final_features_with_design.bias, None, torch.float32)
+
+    def forward_once(self, x):
+        return ops.LinearFn.apply(self._scale_means(x), self.final_features.weight, self.final_features.bias, None, torch.float32)
+
+    def extract_features_with_design_features(self, x_path, x_designed_features):
+        return self.forward_once_design_feature(x_path, x_designed_features)
+
+    def extract_features(self, x_path):
+        return self.forward_once(x_path)
+
+    def _pair(self, x1, d1, x2, d2):
+        """Both sides as one batch of 2B (shared weights, per-sample ops only)."""
+        B = x1[0].shape[0]
+        both = [torch.cat((x1[i], x2[i]), 0) for i in range(self.input_scales_num)]
+        if self.is_designed_feature_embedding:
+            f = self.forward_once_design_feature(both, torch.cat((d1, d2), 0))
+        else:
+            f = self.forward_once(both)
+        return f[:B], f[B:]
+
+
+class ShfitScaleFormer(_SingleStage):
+    """First generation (reference :417-607): four fixed scales [28,56,112,224] -> 4 x 49 tokens, `depth` blocks on
+    the [4,7,7] cube.  forward dispatches on which arguments are None, not on train/eval (:571-590)."""
+
+    def __init__(self, num_classes=11, is_designed_feature_embedding=True, FeatureEmbed=FeatureEmbed, PatchEmbed=PatchEmbed,
+                 cube_size=[7, 7], input_image_scales=[28, 56, 112, 224], embed_dim=768, depth=12, num_heads=12, mlp_ratio=4.0,
+                 drop_path_ratio=0., drop_ratio=0., attn_drop_ratio=0., norm_layer=nn.LayerNorm, act_layer=nn.GELU, cuda=True,
+                 numerics=None):
+        super().__init__()
+        self.numerics = _mode(numerics)
+        self.num_classes = num_classes
+        self.is_designed_feature_embedding = is_designed_feature_embedding
+        self.patch_embed_layer, self.feature_embed_layer = PatchEmbed, FeatureEmbed
+        self.input_image_scales = input_image_scales
+        self.input_scales_num = len(input_image_scales)
+        self.cube_size = cube_size
+        self.cube_size.insert(0, self.input_scales_num)
+        self.num_features = int(self.input_scales_num * embed_dim)
+        kw = {"numerics": self.numerics} if PatchEmbed is globals()["PatchEmbed"] else {}
+        for i, ps in enumerate((4, 8, 16, 32)):           # hard-coded upstream (:454-457)
+            setattr(self, f"patch_embed_scale{i}", PatchEmbed(img_size=input_image_scales[i], patch_size=ps, in_c=3, out_c=768, **kw))
+        self.feature_embed = FeatureEmbed(feature_size=19, embed_dim=768) if is_designed_feature_embedding else None
+        self.blocks = nn.Sequential(*[
+            CrossScaleBlock(dim=embed_dim, num_heads=num_heads, cube_size=self.cube_size, mlp_ratio=mlp_ratio, drop_ratio=drop_ratio,
+                            attn_drop_ratio=attn_drop_ratio, drop_path_ratio=0., norm_layer=norm_layer, act_layer=act_layer,
+                            numerics=self.numerics) for _ in range(depth)])
+        self._build_tail(embed_dim, norm_layer, drop_ratio, num_classes)
+        self.apply(self._init_weights)
+
+    def patch_embed(self, x):
+        return torch.cat([getattr(self, f"patch_embed_scale{i}")(x[i]) for i in range(4)], 1)
+
+    def forward(self, x1_patches, x1_designed_features, x2_patches=None, x2_designed_features=None):
+        if x1_designed_features is not None and x2_patches is None and x2_designed_features is None:
+            return self.extract_features_with_design_features(x1_patches, x1_designed_features)
+        if x1_designed_features is None and x2_patches is None and x2_designed_features is None:
+            # upstream calls extract_features with two arguments here and raises TypeError (:578); the intent is clear
+            return self.extract_features(x1_patches)
+        return self._pair(x1_patches, x1_designed_features, x2_patches, x2_designed_features)
+
+
+class ShfitScaleFormer_v2(_SingleStage):
+    """Second generation (reference :610-769): per-scale embeds in a ModuleList, always 12 blocks (`depth` is ignored
+    upstream, :657), train/eval dispatch like v3."""
+
+    def __init__(self, num_classes=11, is_designed_feature_embedding=True, FeatureEmbed=FeatureEmbed, PatchEmbed=PatchEmbed,
+                 cube_size=[7, 7], input_image_scales=[28, 56, 112, 224], embed_dim=768, depth=12, num_heads=12, mlp_ratio=4.0,
+                 drop_path_ratio=0., drop_ratio=0., attn_drop_ratio=0., norm_layer=nn.LayerNorm, act_layer=nn.GELU, cuda=True,
+                 numerics=None):
+        super().__init__()
+        self.numerics = _mode(numerics)
+        self.num_classes = num_classes
+        self.is_designed_feature_embedding = is_designed_feature_embedding
+        self.patch_embed_layer, self.feature_embed_layer = PatchEmbed, FeatureEmbed
+        self.input_image_scales = input_image_scales
+        self.input_scales_num = len(input_image_scales)
+        self.cube_size = cube_size
+        self.cube_size.insert(0, self.input_scales_num)
+        self.num_features = int(self.input_scales_num * embed_dim)
+        kw = {"numerics": self.numerics} if PatchEmbed is globals()["PatchEmbed"] else {}
+        self.patch_embed_blocks = nn.ModuleList(
+            [PatchEmbed(img_size=s, patch_size=int(s / self.cube_size[1]), in_c=3, out_c=768, **kw) for s in input_image_scales])
+        self.feature_embed = FeatureEmbed(feature_size=19, embed_dim=768) if is_designed_feature_embedding else None
+        self.blocks = nn.Sequential(*[
+            CrossScaleBlock(dim=embed_dim, num_heads=num_heads, cube_size=self.cube_size, mlp_ratio=mlp_ratio, drop_ratio=drop_ratio,
+                            attn_drop_ratio=attn_drop_ratio, drop_path_ratio=0, norm_layer=norm_layer, act_layer=act_layer,
+                            numerics=self.numerics) for _ in range(12)])
+        self._build_tail(embed_dim, norm_layer, drop_ratio, num_classes)
+        self.apply(self._init_weights)
+
+    def patch_embed(self, x):
+        return torch.cat([layer(x[i]) for i, layer in enumerate(self.patch_embed_blocks)], 1)
+
+    def forward(self, x1_patches, x1_designed_features, x2_patches=None, x2_designed_features=None):
+        if self.training:
+            return self._pair(x1_patches, x1_designed_features, x2_patches, x2_designed_features)
+        if self.is_designed_feature_embedding:
+            return self.forward_once_design_feature(x1_patches, x1_designed_features)
+        return self.forward_once(x1_patches)
+
+
+class ShfitScaleFormer_v6(_SingleStage):
+    """Designed-features-only network (reference :1506-1569): FeatureEmbed -> LayerNorm -> Linear(768, 100)."""
+
+    def __init__(self, num_classes=11, FeatureEmbed=FeatureEmbed, embed_dim=768, mlp_ratio=4.0, drop_path_ratio=0., drop_ratio=0.,
+                 norm_layer=nn.LayerNorm, act_layer=nn.GELU, cuda=True, numerics=None):
+        super().__init__()
+        self.numerics = _mode(numerics)
+        self.num_classes = num_classes
+        self.feature_embed_layer = FeatureEmbed
+        self.feature_embed = FeatureEmbed(feature_size=19, embed_dim=768)
+        self.norm = norm_layer(embed_dim)
+        self.pos_drop = nn.Dropout(p=drop_ratio)
+        self.final_features_with_design = nn.Linear(embed_dim, 100)
+        self.head = nn.Linear(100, num_classes) if num_classes > 0 else nn.Identity()
+        self.apply(self._init_weights)
+
+    def designed_feature_embed(self, x):
+        return self._ln(torch.squeeze(self.feature_embed(x), dim=1))
+
+    def forward_once_design_feature(self, x, designed_features):
+        return ops.LinearFn.apply(self.designed_feature_embed(designed_features), self.final_features_with_design.weight,
+                                  self.final_features_with_design.bias, None, torch.float32)
+
+    def forward(self, x1_patches, x1_designed_features, x2_patches=None, x2_designed_features=None):
+        if x1_designed_features is not None and x2_patches is None and x2_designed_features is None:
+            return self.extract_features_with_design_features(x1_patches, x1_designed_features)
+        if x2_designed_features is None:
+            raise TypeError("ShfitScaleFormer_v6 needs designed features (upstream raises here too, :1549)")
+        B = x1_designed_features.shape[0]
+        f = self.forward_once_design_feature(None, torch.cat((x1_designed_features, x2_designed_features), 0))
+        return f[:B], f[B:]

@@ -258,3 +258,84 @@ def flops_forward_per_sample(cfg: S2Config) -> float:
     f += 2.0 * (cfg.n_designed * C + 2 * C * C)
     f += 2.0 * (cfg.n_scales + 1) * C * cfg.out_dim
     return f
+
+
+# ----------------------------------------------------------------------------------------
+# single-stage variants v1 / v2 (nets/ShfitScaleFormer.py:417-607, :610-769) and v6 (:1506-1569)
+# ----------------------------------------------------------------------------------------
+V12_SCALES = (28, 56, 112, 224)      # cube [4,7,7]: 4 scales x 49 tokens = 196, patch sizes 4 / 8 / 16 / 32
+
+
+def v12_param_spec(variant: str, depth: int = 12, num_classes: int = 11) -> "OrderedDict[str, Tuple[Tuple[int, ...], str]]":
+    """state_dict manifest of `ShfitScaleFormer` ("v1") / `ShfitScaleFormer_v2` ("v2") in registration order.
+    v2 ignores its `depth` argument upstream and always builds 12 blocks (:657)."""
+    C, Hd, S = 768, 3072, 4
+    cube = (S, 7, 7)
+    if variant == "v2":
+        depth = 12
+    spec: "OrderedDict[str, Tuple[Tuple[int, ...], str]]" = OrderedDict()
+    for i, s in enumerate(V12_SCALES):
+        p = s // 7
+        pre = f"patch_embed_scale{i}." if variant == "v1" else f"patch_embed_blocks.{i}."
+        spec[pre + "proj.weight"] = ((C, 3, p, p), "float32"); spec[pre + "proj.bias"] = ((C,), "float32")
+    spec["feature_embed.proj0.weight"] = ((C, 19, 1), "float32"); spec["feature_embed.proj0.bias"] = ((C,), "float32")
+    for j in (1, 2):
+        spec[f"feature_embed.proj{j}.weight"] = ((C, C, 1), "float32"); spec[f"feature_embed.proj{j}.bias"] = ((C,), "float32")
+    for j in range(depth):
+        pre = f"blocks.{j}."
+        spec[pre + "norm1.weight"] = ((C,), "float32"); spec[pre + "norm1.bias"] = ((C,), "float32")
+        spec[pre + "attn.relative_position_bias_table"] = ((relpos_table_rows(cube), 12), "float32")
+        spec[pre + "attn.relative_position_index"] = ((196, 196), "int64")
+        spec[pre + "attn.qkv.weight"] = ((3 * C, C), "float32"); spec[pre + "attn.qkv.bias"] = ((3 * C,), "float32")
+        spec[pre + "attn.proj.weight"] = ((C, C), "float32"); spec[pre + "attn.proj.bias"] = ((C,), "float32")
+        spec[pre + "norm2.weight"] = ((C,), "float32"); spec[pre + "norm2.bias"] = ((C,), "float32")
+        spec[pre + "mlp.fc1.weight"] = ((Hd, C), "float32"); spec[pre + "mlp.fc1.bias"] = ((Hd,), "float32")
+        spec[pre + "mlp.fc2.weight"] = ((C, Hd), "float32"); spec[pre + "mlp.fc2.bias"] = ((C,), "float32")
+    spec["norm.weight"] = ((C,), "float32"); spec["norm.bias"] = ((C,), "float32")
+    spec["final_features.weight"] = ((100, S * C), "float32"); spec["final_features.bias"] = ((100,), "float32")
+    spec["final_features_with_design.weight"] = ((100, (S + 1) * C), "float32")
+    spec["final_features_with_design.bias"] = ((100,), "float32")
+    spec["head.weight"] = ((num_classes, 100), "float32"); spec["head.bias"] = ((num_classes,), "float32")
+    return spec
+
+
+def v12_forward_once(p: Params, variant: str, patches: Sequence[torch.Tensor], designed, depth: int = 12) -> torch.Tensor:
+    """forward_once_design_feature / forward_once of v1 (:505-569) and v2 (:689-728): 4 patch embeds -> `depth`
+    blocks on the [4,7,7] cube -> norm -> per-scale mean over 49 tokens -> (+ normed designed embedding) -> Linear."""
+    C, S = 768, 4
+    if variant == "v2":
+        depth = 12
+    toks = []
+    for i, s in enumerate(V12_SCALES):
+        pre = f"patch_embed_scale{i}." if variant == "v1" else f"patch_embed_blocks.{i}."
+        toks.append(patch_embed(p, pre, patches[i], s // 7))
+    x = torch.cat(toks, 1)
+    for j in range(depth):
+        x = cross_scale_block(p, f"blocks.{j}.", x, 12, 1e-5)
+    x = F.layer_norm(x, (C,), p["norm.weight"], p["norm.bias"], 1e-5)
+    B = x.shape[0]
+    x = x.reshape(B, S, 49, C).mean(dim=2).reshape(B, S * C)
+    if designed is None:
+        return F.linear(x, p["final_features.weight"], p["final_features.bias"])
+    f = feature_embed(p, "feature_embed.", designed).squeeze(1)
+    f = F.layer_norm(f, (C,), p["norm.weight"], p["norm.bias"], 1e-5)
+    return F.linear(torch.cat((x, f), 1), p["final_features_with_design.weight"], p["final_features_with_design.bias"])
+
+
+def v6_param_spec(num_classes: int = 11) -> "OrderedDict[str, Tuple[Tuple[int, ...], str]]":
+    C = 768
+    spec: "OrderedDict[str, Tuple[Tuple[int, ...], str]]" = OrderedDict()
+    spec["feature_embed.proj0.weight"] = ((C, 19, 1), "float32"); spec["feature_embed.proj0.bias"] = ((C,), "float32")
+    for j in (1, 2):
+        spec[f"feature_embed.proj{j}.weight"] = ((C, C, 1), "float32"); spec[f"feature_embed.proj{j}.bias"] = ((C,), "float32")
+    spec["norm.weight"] = ((C,), "float32"); spec["norm.bias"] = ((C,), "float32")
+    spec["final_features_with_design.weight"] = ((100, C), "float32"); spec["final_features_with_design.bias"] = ((100,), "float32")
+    spec["head.weight"] = ((num_classes, 100), "float32"); spec["head.bias"] = ((num_classes,), "float32")
+    return spec
+
+
+def v6_forward_once(p: Params, designed: torch.Tensor) -> torch.Tensor:
+    """ShfitScaleFormer_v6 (:1529-1537): FeatureEmbed -> squeeze -> norm -> Linear(768, 100)."""
+    f = feature_embed(p, "feature_embed.", designed).squeeze(1)
+    f = F.layer_norm(f, (768,), p["norm.weight"], p["norm.bias"], 1e-5)
+    return F.linear(f, p["final_features_with_design.weight"], p["final_features_with_design.bias"])

@@ -239,6 +239,55 @@ def gen_model(S2F, Losses):
     print("model_v3.npz", len(fx))
 
 
+def gen_variants(S2F, Losses):
+    """Single-stage variants v1 / v2 (cube [4,7,7], N = 196) and the designed-features-only v6."""
+    fx = {}
+    crit = Losses.Loss(margin=1.0, lamda=0.1, belta=0)
+    scales = [28, 56, 112, 224]
+    for tag, ctor, kw in (("v1_d2", S2F.ShfitScaleFormer, dict(depth=2)), ("v2", S2F.ShfitScaleFormer_v2, {})):
+        net = ctor(is_designed_feature_embedding=True, cube_size=[7, 7], input_image_scales=list(scales), **kw)
+        load_det_weights(net, "")
+        sd = net.state_dict()
+        fx[tag + "/manifest_keys"] = np.array(list(sd.keys()))
+        fx[tag + "/manifest_shapes"] = np.array([",".join(map(str, v.shape)) for v in sd.values()])
+        fx[tag + "/n_params"] = np.int64(sum(p.numel() for p in net.parameters()))
+        left, ld, right, rd, flag = model_inputs(tag, scales, 3, 4)
+        net.train()
+        fa, fb = net(left, ld, right, rd)
+        loss = crit(fa, fb, flag)
+        loss.backward()
+        add(fx, tag + "/out_a", fa); add(fx, tag + "/out_b", fb)
+        fx[tag + "/loss"] = np.float64(loss.item())
+        none = []
+        for n, p in net.named_parameters():
+            if p.grad is None:
+                none.append(n)
+            else:
+                add(fx, tag + "/grad/" + n, p.grad, k=512)
+        fx[tag + "/grad_none"] = np.array(none)
+        net.eval()
+        with torch.no_grad():
+            single = net(left, ld)
+        fx[tag + "/single_equals_left"] = np.bool_(torch.equal(single, fa))
+        print(tag, "loss", fx[tag + "/loss"], "params", int(fx[tag + "/n_params"]), "none", none)
+    net = S2F.ShfitScaleFormer_v6()
+    load_det_weights(net, "")
+    fx["v6/manifest_keys"] = np.array(list(net.state_dict().keys()))
+    da = t("v6.da", (4, 1, 19), "designed"); db = t("v6.db", (4, 1, 19), "designed")
+    db[1] = da[1] * 1.05
+    flag = torch.tensor([1, 0, 1, 0], dtype=torch.int64)
+    fa, fb = net(None, da, None, db)
+    loss = crit(fa, fb, flag)
+    loss.backward()
+    add(fx, "v6/out_a", fa); add(fx, "v6/out_b", fb)
+    fx["v6/loss"] = np.float64(loss.item())
+    for n, p in net.named_parameters():
+        if p.grad is not None:
+            add(fx, "v6/grad/" + n, p.grad, k=512)
+    np.savez_compressed(os.path.join(HERE, "model_variants.npz"), **fx)
+    print("model_variants.npz", len(fx))
+
+
 def gen_vit(vit_model, Losses):
     """vit_model.py pair encoders (BASELINE configs[2])."""
     fx = {}
@@ -321,7 +370,7 @@ def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
     S2F, vit_model, Losses = import_reference()
-    which = sys.argv[1:] or ["relpos", "ops", "model", "vit"]
+    which = sys.argv[1:] or ["relpos", "ops", "model", "vit", "variants"]
     if "relpos" in which:
         gen_relpos(S2F)
     if "ops" in which:
@@ -330,6 +379,8 @@ def main():
         gen_model(S2F, Losses)
     if "vit" in which:
         gen_vit(vit_model, Losses)
+    if "variants" in which:
+        gen_variants(S2F, Losses)
 
 
 if __name__ == "__main__":

@@ -206,3 +206,42 @@ def test_flops_formula_matches_baseline_table():
     assert abs(O.flops_forward_per_sample(MODEL_CASES["v3_4s4c_321"]) / 1e9 - 14.08) < 0.02
     big = O.S2Config(scales=(32, 64, 128, 256), in_c=4, depth=(6, 4, 2))
     assert abs(O.flops_forward_per_sample(big) / 1e9 - 27.62) < 0.02
+
+
+@pytest.mark.parametrize("tag,variant,depth", [("v1_d2", "v1", 2), ("v2", "v2", 12)])
+def test_single_stage_variants(tag, variant, depth):
+    fx = load_fx("model_variants.npz")
+    spec = O.v12_param_spec(variant, depth)
+    assert list(spec.keys()) == [str(k) for k in fx[tag + "/manifest_keys"]]
+    assert [",".join(map(str, s)) for s, _ in spec.values()] == [str(s) for s in fx[tag + "/manifest_shapes"]]
+    p = det_params(spec.items(), index_for=lambda k: O.relpos_index([4, 7, 7]))
+    left, ld, right, rd, flag = model_inputs(tag, O.V12_SCALES, 3, 4)
+    fa, fb = O.v12_forward_once(p, variant, left, ld, depth), O.v12_forward_once(p, variant, right, rd, depth)
+    loss = OL.contrastive_loss(fa, fb, flag, 1.0)
+    loss.backward()
+    recipe.check_summary(tag + "/out_a", fa.detach().numpy(), fx, RTOL)
+    recipe.check_summary(tag + "/out_b", fb.detach().numpy(), fx, RTOL)
+    assert abs(loss.item() - float(fx[tag + "/loss"])) <= 2e-5 * abs(float(fx[tag + "/loss"]))
+    for k, (_, dt) in spec.items():
+        if dt == "float32" and p[k].grad is not None:
+            # norm.bias and the output bias cancel exactly between the two Siamese sides here (their expected
+            # gradient is rounding noise ~1e-7), hence the absolute floor
+            recipe.check_summary(tag + "/grad/" + k, p[k].grad.numpy(), fx, 1e-4, k=512, atol=1e-6)
+    assert sorted(k for k, (_, dt) in spec.items() if dt == "float32" and p[k].grad is None) == sorted(str(s) for s in fx[tag + "/grad_none"])
+
+
+def test_v6_designed_features_only():
+    fx = load_fx("model_variants.npz")
+    spec = O.v6_param_spec()
+    assert list(spec.keys()) == [str(k) for k in fx["v6/manifest_keys"]]
+    p = det_params(spec.items())
+    da, db = tin("v6.da", (4, 1, 19), "designed"), tin("v6.db", (4, 1, 19), "designed")
+    db[1] = da[1] * 1.05
+    fa, fb = O.v6_forward_once(p, da), O.v6_forward_once(p, db)
+    loss = OL.contrastive_loss(fa, fb, torch.tensor([1, 0, 1, 0]), 1.0)
+    loss.backward()
+    recipe.check_summary("v6/out_a", fa.detach().numpy(), fx, RTOL)
+    assert abs(loss.item() - float(fx["v6/loss"])) <= 2e-5 * abs(float(fx["v6/loss"]))
+    for k in spec:
+        if p[k].grad is not None:
+            recipe.check_summary("v6/grad/" + k, p[k].grad.numpy(), fx, 1e-4, k=512, atol=1e-8)
