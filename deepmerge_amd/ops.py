@@ -218,6 +218,22 @@ def patchify(x: torch.Tensor, patch: int, dtype: torch.dtype) -> torch.Tensor:
     return cols
 
 
+def patch_pyramid(tile: torch.Tensor, xy: torch.Tensor, windows: torch.Tensor, target: int, max_window: Optional[int] = None) -> torch.Tensor:
+    """One scale of the patch pyramid: tile uint8 [bands,H,W], xy int32 [P,2], windows int32 [P] -> float32 [P,bands,t,t]."""
+    _need_cuda(tile, xy, windows)
+    if tile.dtype != torch.uint8:
+        raise ValueError("tile must be uint8")
+    bands, H, W = tile.shape
+    P = xy.shape[0]
+    if max_window is None:
+        max_window = int(windows.max().item())
+    out = torch.empty((P, bands, target, target), dtype=torch.float32, device=tile.device)
+    check(_lib.lib().dm_patch_pyramid(tile.contiguous().data_ptr(), bands, H, W, xy.to(torch.int32).contiguous().data_ptr(),
+                                      windows.to(torch.int32).contiguous().data_ptr(), max_window, P, target, out.data_ptr(), _stream()),
+          "dm_patch_pyramid")
+    return out
+
+
 def adam_step(param, grad, m, v, step, lr=1e-4, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0, param_lp=None):
     _need_cuda(param, grad, m, v)
     check(_lib.lib().dm_adam_step(param.data_ptr(), grad.data_ptr(), m.data_ptr(), v.data_ptr(), _ptr(param_lp), param.numel(), step,

@@ -195,6 +195,16 @@ int dm_segment_mean(const float *F, const int32_t *ptr, const int32_t *idx, floa
 int dm_edge_similarity(const float *pooled, const int32_t *edges, float *simi, uint8_t *merge,
                        int32_t E, int32_t D, float margin, void *stream);
 
+/* ---- patch pyramid gather --------------------------------------------------------------------
+ * Replaces, for one scale, the per-point loader work of MyUtils1.py:116-223 / MyUtils2.py:286-437:
+ * calculate_left_top_point_and_size (top-left = int(mid - L/2), truncation toward zero), cut_image (window
+ * clipped to the raster, zero padded) and resize_data (per band resize to target x target on uint8, /255).
+ * The resize is the build's exact integer area average (OpenCV parity unpinned; oracle/patches.py).
+ *   tile [bands,H,W] uint8; xy int32 [P,2] = (XPixel, YLine); windows int32 [P] = window side L for this scale,
+ *   every L <= max_window <= 384; out float32 [P, bands, target, target]. */
+int dm_patch_pyramid(const uint8_t *tile, int32_t bands, int32_t H, int32_t W, const int32_t *xy, const int32_t *windows,
+                     int32_t max_window, int32_t P, int32_t target, float *out, void *stream);
+
 /* ---- optional in-library kernel timing ------------------------------------------------------
  * While enabled, the GEMM and attention entry points bracket their main kernel with hipEvents on
  * the caller's stream.  dm_prof_collect waits for the recorded events, aggregates them per kernel

@@ -1,0 +1,83 @@
+"""GPU: dm_patch_pyramid against the oracle (bit-exact: the spec is integer arithmetic) + host window helpers."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import patches as OP
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def test_patch_pyramid_bit_exact_vs_oracle():
+    from deepmerge_amd import ops
+    rng = np.random.default_rng(1)
+    bands, H, W = 4, 300, 340
+    img = rng.integers(0, 256, size=(bands, H, W), dtype=np.uint8)
+    P = 40
+    xy = np.stack([rng.integers(-5, W + 5, P), rng.integers(-5, H + 5, P)], 1).astype(np.int32)
+    xy[:4] = [[0, 0], [W - 1, H - 1], [1, H - 1], [W // 2, 0]]                       # corners / edges
+    tile = torch.from_numpy(img).to(DEV)
+    for t, lo, hi in ((32, 7, 90), (64, 20, 130), (128, 40, 200), (16, 1, 40)):
+        wins = rng.integers(lo, hi, P).astype(np.int32)
+        wins[0], wins[1] = t, 2 * t                                                   # identity and exact 2x box
+        got = ops.patch_pyramid(tile, torch.from_numpy(xy).to(DEV), torch.from_numpy(wins).to(DEV), t).cpu().numpy()
+        for p in range(P):
+            x0, y0 = OP.top_left(int(xy[p, 0]), int(xy[p, 1]), int(wins[p]))
+            win = OP.cut_image(img, x0, y0, int(wins[p]))
+            want = np.stack([OP.area_resize_u8(win[b], t) for b in range(bands)]).astype(np.float32) / 255.0
+            assert np.array_equal(got[p].view(np.uint32), want.view(np.uint32)), (t, p, wins[p])
+
+
+def test_point_batch_matches_reference_contract():
+    from deepmerge_amd.patches import geo_to_pixel, get_scales, point_batch
+    rng = np.random.default_rng(2)
+    img = rng.integers(0, 256, size=(3, 256, 256), dtype=np.uint8)
+    P = 16
+    xy = rng.integers(0, 256, (P, 2)).astype(np.int32)
+    inner = rng.integers(16, 64, P).astype(np.int32)
+    obj = inner + rng.integers(8, 48, P).astype(np.int32)
+    feats = rng.normal(size=(P, 15)).astype(np.float32)
+    patches, designed = point_batch(torch.from_numpy(img).to(DEV), torch.from_numpy(xy).to(DEV), torch.from_numpy(inner),
+                                    torch.from_numpy(obj), torch.from_numpy(feats).to(DEV))
+    assert [tuple(p.shape) for p in patches] == [(P, 3, 32, 32), (P, 3, 64, 64), (P, 3, 128, 128)]
+    assert designed.shape == (P, 1, 19)
+    for p in range(P):
+        w, f = OP.get_scales(int(inner[p]), int(obj[p]))
+        want = OP.patch_pyramid(img, int(xy[p, 0]), int(xy[p, 1]), w[:3], (32, 64, 128))
+        for i in range(3):
+            assert np.array_equal(patches[i][p].cpu().numpy(), want[i])
+        np.testing.assert_allclose(designed[p, 0, 15:].cpu().numpy(), np.array(f, np.float32), rtol=1e-7)
+        np.testing.assert_array_equal(designed[p, 0, :15].cpu().numpy(), feats[p])
+    gt = (100.0, 0.5, 0, 900.0, 0, -0.5)
+    px = geo_to_pixel(gt, torch.tensor([110.2, 100.0]), torch.tensor([880.3, 900.0]))
+    assert px.tolist() == [list(OP.geo_to_pixel(gt, 110.2, 880.3)), [1, 1]]
+
+
+def test_patch_pyramid_full_tile_properties():
+    """BASELINE configs[3] scale: 4096x4096x4 tile, ~60k points.  Size-independent checks: a constant tile gives constant
+    patches; windows fully outside give zeros; the kernel is deterministic; sampled points match the oracle."""
+    from deepmerge_amd import ops
+    rng = np.random.default_rng(3)
+    bands, H, W = 4, 4096, 4096
+    tile = torch.randint(0, 256, (bands, H, W), dtype=torch.uint8, device=DEV)
+    P = 59643
+    xy = torch.stack([torch.randint(0, W, (P,)), torch.randint(0, H, (P,))], 1).to(torch.int32).to(DEV)
+    wins = torch.randint(24, 97, (P,), dtype=torch.int32, device=DEV)
+    a = ops.patch_pyramid(tile, xy, wins, 64, max_window=96)
+    b = ops.patch_pyramid(tile, xy, wins, 64, max_window=96)
+    assert torch.equal(a, b)
+    img = tile.cpu().numpy()
+    for p in rng.integers(0, P, 12):
+        x0, y0 = OP.top_left(int(xy[p, 0]), int(xy[p, 1]), int(wins[p]))
+        win = OP.cut_image(img, x0, y0, int(wins[p]))
+        want = np.stack([OP.area_resize_u8(win[c], 64) for c in range(bands)]).astype(np.float32) / 255.0
+        assert np.array_equal(a[p].cpu().numpy(), want)
+    const = torch.full((bands, 512, 512), 200, dtype=torch.uint8, device=DEV)
+    inside = torch.tensor([[256, 256]], dtype=torch.int32, device=DEV)
+    out = ops.patch_pyramid(const, inside, torch.tensor([77], dtype=torch.int32, device=DEV), 32)
+    assert torch.equal(out, torch.full_like(out, 200.0 / 255.0))
+    far = torch.tensor([[5000, -4000]], dtype=torch.int32, device=DEV)
+    assert float(ops.patch_pyramid(const, far, torch.tensor([50], dtype=torch.int32, device=DEV), 32).abs().max()) == 0.0
+    with pytest.raises(ValueError):
+        ops.patch_pyramid(const, inside, torch.tensor([500], dtype=torch.int32, device=DEV), 32)
