@@ -110,6 +110,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-pairs", type=int, default=8)
     ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--backend", type=str, default="nccl", choices=["nccl", "gloo"],
+                    help="collective backend for --gpus > 1 (gloo only to rehearse the DP path with several ranks on ONE GPU)")
     args = ap.parse_args()
 
     import torch
@@ -122,11 +124,16 @@ def main():
             raise SystemExit("launch with torch.distributed.run for --gpus > 1")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the measured path)")
+    if args.backend == "gloo":
+        local_rank = local_rank % max(1, torch.cuda.device_count())     # rehearsal: ranks may share a GPU
     torch.cuda.set_device(local_rank)
     dev = f"cuda:{local_rank}"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(dev))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(dev))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     import deepmerge_amd
     from deepmerge_amd import _lib
@@ -195,7 +202,7 @@ def main():
                        "pairs_per_gpu": args.pairs, "global_batch": world * args.pairs, "parallelism": f"dp{world}",
                        "gflop_per_pair_step": round(flop_pair / 1e9, 2)},
             "model_tflops_per_gpu": round(value / world * flop_pair / 1e12, 2),
-            "loss": float(loss.item()),
+            "loss": float(loss.item()), "backend": args.backend if world > 1 else None,
             "roofline": roof,
         }
         if not args.no_cpu_baseline and world == 1:
