@@ -19,6 +19,7 @@ torch.optim.Adam skipping `grad is None` parameters.
 """
 from __future__ import annotations
 
+import os
 from typing import List, Optional, Sequence
 
 import torch
@@ -128,7 +129,14 @@ class PairTrainer:
                 self._bucket_of[p] = bi
         self._remaining = list(self._remaining0)
 
+        self._seen = set()
+
         def hook(p):
+            # idempotent per step: a parameter whose gradient went straight to the sink is reported by the fused
+            # backward AND may be reported again by autograd's own post-accumulate hook
+            if id(p) in self._seen:
+                return
+            self._seen.add(id(p))
             bi = self._bucket_of[p]
             self._remaining[bi] -= 1
             if self._remaining[bi] == 0:
@@ -151,6 +159,7 @@ class PairTrainer:
             work.wait()
         self._pending.clear()
         self._remaining = list(self._remaining0)
+        self._seen.clear()
 
     # -- the step ----------------------------------------------------------------------------------
     def step(self, left: Sequence[torch.Tensor], left_designed, right: Sequence[torch.Tensor], right_designed, flag,

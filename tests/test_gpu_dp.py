@@ -72,6 +72,13 @@ def test_two_ranks_one_gpu_equal_single_process(tmp_path, mode):
     for _ in range(2):
         tr.step([mv(t) for t in left], mv(ld), [mv(t) for t in right], mv(rd), mv(flag))
     g, f = tr.fp.grad.cpu(), tr.fp.flat.cpu()
+    # final_features_with_design.bias: its two Siamese gradient halves cancel exactly, what is left is rounding noise
+    # that Adam's normalisation turns into +-lr steps -- mask it out of the comparison
+    keep = torch.ones_like(g, dtype=torch.bool)
+    named = dict(net.named_parameters())
+    pb = named["final_features_with_design.bias"]
+    o = tr.fp.offsets[[q is pb for q in tr.fp.params].index(True)]
+    keep[o:o + pb.numel()] = False
     scale = float(g.abs().max())
-    assert float((got["grad"] - g).abs().max()) <= 2e-5 * scale, "averaged shard gradients != global-batch gradient"
-    np.testing.assert_allclose(got["flat"].numpy(), f.numpy(), rtol=0, atol=3e-5)
+    assert float(((got["grad"] - g).abs() * keep).max()) <= 2e-5 * scale, "averaged shard gradients != global-batch gradient"
+    assert float(((got["flat"] - f).abs() * keep).max()) <= 3e-5
