@@ -81,4 +81,10 @@ def test_two_ranks_one_gpu_equal_single_process(tmp_path, mode):
     keep[o:o + pb.numel()] = False
     scale = float(g.abs().max())
     assert float(((got["grad"] - g).abs() * keep).max()) <= 2e-5 * scale, "averaged shard gradients != global-batch gradient"
-    assert float(((got["flat"] - f).abs() * keep).max()) <= 3e-5
+    # Adam normalises by sqrt(v): where the gradient is at rounding-noise level the step is +-lr in a noise-determined
+    # direction, so weights are compared tightly only where the gradient is well above noise, and bounded by the
+    # largest possible divergence (2 steps x 2 lr) elsewhere
+    dw = (got["flat"] - f).abs()
+    solid = keep & (g.abs() > 1e-4 * scale)
+    assert float((dw * solid).max()) <= 3e-5
+    assert float(dw.max()) <= 4.1e-4
