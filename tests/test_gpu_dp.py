@@ -50,7 +50,7 @@ def _worker(rank, world, port, out, mode):
     left, ld, right, rd, flag = _batch(8)
     sl = shard_slice(8, rank, world)
     mv = lambda t: t[sl].to("cuda:0")
-    for _ in range(2):
+    for _ in range(1):
         loss = tr.step([mv(t) for t in left], mv(ld), [mv(t) for t in right], mv(rd), mv(flag))
     torch.cuda.synchronize()
     if rank == 0:
@@ -69,7 +69,7 @@ def test_two_ranks_one_gpu_equal_single_process(tmp_path, mode):
     tr = PairTrainer(net, lr=1e-4)
     left, ld, right, rd, flag = _batch(8)
     mv = lambda t: t.to("cuda:0")
-    for _ in range(2):
+    for _ in range(1):
         tr.step([mv(t) for t in left], mv(ld), [mv(t) for t in right], mv(rd), mv(flag))
     g, f = tr.fp.grad.cpu(), tr.fp.flat.cpu()
     # final_features_with_design.bias: its two Siamese gradient halves cancel exactly, what is left is rounding noise
@@ -83,8 +83,8 @@ def test_two_ranks_one_gpu_equal_single_process(tmp_path, mode):
     assert float(((got["grad"] - g).abs() * keep).max()) <= 2e-5 * scale, "averaged shard gradients != global-batch gradient"
     # Adam normalises by sqrt(v): where the gradient is at rounding-noise level the step is +-lr in a noise-determined
     # direction, so weights are compared tightly only where the gradient is well above noise, and bounded by the
-    # largest possible divergence (2 steps x 2 lr) elsewhere
+    # largest possible divergence (one step, 2 lr) elsewhere
     dw = (got["flat"] - f).abs()
     solid = keep & (g.abs() > 1e-4 * scale)
     assert float((dw * solid).max()) <= 3e-5
-    assert float(dw.max()) <= 4.1e-4
+    assert float(dw.max()) <= 2.1e-4
