@@ -130,6 +130,7 @@ class PairTrainer:
         self._remaining = list(self._remaining0)
 
         self._seen = set()
+        self._calibrated = False
 
         def hook(p):
             # idempotent per step: a parameter whose gradient went straight to the sink is reported by the fused
@@ -158,6 +159,15 @@ class PairTrainer:
         for _, work in self._pending:
             work.wait()
         self._pending.clear()
+        if not self._calibrated:
+            # parameters that never receive a gradient (final_features.*, head.* on the designed-feature path) would
+            # hold their bucket back until the end of backward: after the first step, count only the used ones
+            counts = [0] * len(self.bucket_slices)
+            for p in self.fp.params:
+                if id(p) in self._seen:
+                    counts[self._bucket_of[p]] += 1
+            self._remaining0 = counts
+            self._calibrated = True
         self._remaining = list(self._remaining0)
         self._seen.clear()
 
