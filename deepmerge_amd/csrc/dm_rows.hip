@@ -7,7 +7,7 @@
 namespace {
 
 constexpr int MAXCH = 4;          // float4 chunks per lane per row -> cols <= 1024
-constexpr int LN_MAX_WG = 1024;   // 4 workgroups (16 waves) per CU keep enough loads in flight
+constexpr int LN_MAX_WG = 512;    // 2 workgroups (8 waves) per CU keep enough loads in flight
 constexpr int CS_MAX_SLICES = 64;
 
 // ---------------------------------------------------------------------------------------------
@@ -136,22 +136,30 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const TDY *__restric
   }
 }
 
-// out[j] (+)= sum_r partial[r][j].  Block = 32 columns x 8 row-slices; each slice sums its rows in
-// order, slices are combined in a fixed tree -> deterministic.
+// out[j] (+)= sum_r partial[r][j].  Block = 16 columns x 16 row-slices (many small workgroups: the input is a few
+// MB spread over up to 1024 rows); each slice sums its rows in order, slices are combined in a fixed tree ->
+// deterministic.
 __global__ __launch_bounds__(256) void partial_reduce_kernel(const float *__restrict__ partial, float *__restrict__ out0,
                                                              float *__restrict__ out1, int nrows, int width, int split,
                                                              int accumulate) {
   // `partial` rows are `width` wide; columns [0,split) go to out0, [split,width) to out1.
-  __shared__ float red[8][33];
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-  const int j = blockIdx.x * 32 + tx;
+  __shared__ float red[16][17];
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const int j = blockIdx.x * 16 + tx;
   float s = 0.f;
   if (j < width)
-    for (int r = ty; r < nrows; r += 8) s += partial[(long long)r * width + j];
+    for (int r = ty; r < nrows; r += 16) s += partial[(long long)r * width + j];
   red[ty][tx] = s;
   __syncthreads();
   if (ty == 0 && j < width) {
-    s = ((red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx])) + ((red[4][tx] + red[5][tx]) + (red[6][tx] + red[7][tx]));
+    float t[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t[k] = red[k][tx];
+#pragma unroll
+    for (int w = 8; w > 0; w >>= 1)
+#pragma unroll
+      for (int k = 0; k < w; ++k) t[k] = t[2 * k] + t[2 * k + 1];
+    s = t[0];
     float *o = (j < split) ? out0 + j : out1 + (j - split);
     *o = accumulate ? *o + s : s;
   }
@@ -416,7 +424,7 @@ extern "C" int dm_layernorm_bwd(const void *dy, int32_t dy_dtype, const float *x
     hipLaunchKernelGGL(layernorm_bwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t *)dy, x, gamma, mean, rstd, dres, dx, (bf16_t *)dx_lp, partial, rows, cols);
   else DM_REQUIRE(false, DM_ERR_BAD_DTYPE, "dm_layernorm_bwd: bad dy_dtype %d", dy_dtype);
   DM_LAUNCH_CHECK("dm_layernorm_bwd");
-  hipLaunchKernelGGL(partial_reduce_kernel, dim3((2 * cols + 31) / 32), dim3(256), 0, s, partial, dgamma, dbeta, grid, 2 * cols, cols, accumulate_params);
+  hipLaunchKernelGGL(partial_reduce_kernel, dim3((2 * cols + 15) / 16), dim3(256), 0, s, partial, dgamma, dbeta, grid, 2 * cols, cols, accumulate_params);
   DM_LAUNCH_CHECK("dm_layernorm_bwd(reduce)");
   return DM_OK;
 }
@@ -464,7 +472,7 @@ extern "C" int dm_colsum(const void *X, int32_t dtype, int64_t ldx, float *out, 
   else if (dtype == DM_BF16) hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t *)X, (long long)ldx, partial, M, N, rps);
   else DM_REQUIRE(false, DM_ERR_BAD_DTYPE, "dm_colsum: bad dtype %d", dtype);
   DM_LAUNCH_CHECK("dm_colsum");
-  hipLaunchKernelGGL(partial_reduce_kernel, dim3((N + 31) / 32), dim3(256), 0, s, partial, out, out, slices, N, N, accumulate);
+  hipLaunchKernelGGL(partial_reduce_kernel, dim3((N + 15) / 16), dim3(256), 0, s, partial, out, out, slices, N, N, accumulate);
   DM_LAUNCH_CHECK("dm_colsum(reduce)");
   return DM_OK;
 }
