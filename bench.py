@@ -187,8 +187,16 @@ def main():
             launches, ms, flops, _ = prof[dom]
             peak = PEAK_BF16_TFLOPS if "bf16" in dom else PEAK_F32_TFLOPS
             ach = flops / (ms * 1e-3) / 1e12
+            traffic = None      # HBM bytes per launch from the committed PMC passes (profiles/pmc_traffic.json), if any
+            try:
+                pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+                if dom in pmc:
+                    traffic = round(pmc[dom]["fetch_bytes"] + pmc[dom]["write_bytes"])
+            except Exception:
+                pass
             roof = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-                    "frac": round(ach / peak, 4), "traffic": None, "launches": launches,
+                    "frac": round(ach / peak, 4), "traffic": traffic, "algorithmic_bytes_per_launch": round(prof[dom][3] / launches),
+                    "launches": launches,
                     "avg_launch_us": round(1e3 * ms / launches, 2),
                     "all_kernels_TFLOPs": {k: round(v[2] / (v[1] * 1e-3) / 1e12, 1) for k, v in prof.items() if v[1] > 0},
                     "all_kernels_ms_per_step": {k: round(v[1] / args.steps, 3) for k, v in prof.items()}}
