@@ -28,6 +28,8 @@
 // The MFMA is issued with the operands swapped (B fragment in the A slot), so a lane ends up
 // with 4 CONSECUTIVE columns n of one row m: epilogue loads/stores are 16-byte (fp32) or 8-byte
 // (bf16) vectors.
+#include <cstdlib>
+
 #include "dm_common.h"
 #include "dm_mfma.h"
 #include "dm_prof.h"
@@ -60,138 +62,153 @@ struct GemmParams {
   float *workspace;
 };
 
-__device__ __forceinline__ int tr_swz(int k) { return (k & 3) | (((k >> 3) & 1) << 2); }
+// Tile geometry.  TM = 16x16 MFMA tiles per wave per dimension: TM = 4 -> 128x128 workgroup tile, TM = 2 -> 64x64
+// (used when a product has too few 128x128 tiles to fill the chip: the M = 4096 / 1024 stages of the encoder).
+template <typename T, int TM> struct Geo {
+  static constexpr int EPC = DmTypeInfo<T>::kPerChunk;
+  static constexpr int TILE = 32 * TM;                         // rows/cols of the workgroup tile
+  static constexpr int BK = 128 / (int)sizeof(T);              // k per stage: 64 (bf16) / 32 (fp32)
+  // m-contiguous image: one row per k, TILE elements wide
+  static constexpr int M_ROWB = (sizeof(T) == 2) ? TILE * 2 : (TILE + 4) * 4;   // bf16: exact; fp32: +4 floats pad
+  static constexpr int M_CPR = TILE / EPC;                     // 16-byte chunks per k-row
+  static constexpr int M_RPI = NTHREADS / M_CPR;               // k-rows staged per pass
+  static constexpr int K_BYTES = TILE * 128;                   // k-contiguous image
+  static constexpr int STAGE = (K_BYTES > BK * M_ROWB) ? K_BYTES : BK * M_ROWB;
+};
+
+// swizzle of the 32-byte column slots of the bf16 m-contiguous image, chosen so that the 8 rows one half-wave
+// touches in a ds_read_b64_tr_b16 (k = q and 8+q, q = 0..3) land in 8 different 32-byte bank groups:
+//   256-byte rows (TM = 4): 8 slots per row  -> f(k) = (k&3) | ((k>>3)&1)<<2
+//   128-byte rows (TM = 2): 4 slots per row, two rows per 256-byte bank row -> f(k) = ((k>>1)&1) | ((k>>3)&1)<<1
+template <int TM> __device__ __forceinline__ int tr_swz(int k) {
+  if constexpr (TM == 4) return (k & 3) | (((k >> 3) & 1) << 2);
+  else return ((k >> 1) & 1) | (((k >> 3) & 1) << 1);
+}
 
 // ---- global -> register staging -------------------------------------------------------------
 // Loads go through a buffer descriptor covering exactly the operand's bytes: an out-of-range row
 // (tile overhang in M / N, or k >= K for row-per-k operands) reads as ZERO in hardware, so the
-// loop carries no branches and no 64-bit address arithmetic -- four per-thread byte offsets are
+// loop carries no branches and no 64-bit address arithmetic -- TM per-thread byte offsets are
 // computed once and each K stage only bumps one scalar offset.
-struct OperandView {
+template <int TM> struct OperandView {
   __amdgpu_buffer_rsrc_t rsrc;
-  unsigned voff[4];     // per-thread byte offsets of its four 16-byte chunks (stage 0, k = 0)
+  unsigned voff[TM];    // per-thread byte offsets of its 16-byte chunks (stage 0, k = 0)
   unsigned chunk_k;     // k index (elements) of this thread's chunk inside a stage (k-contiguous operands)
 };
 
-// K-contiguous tile: 128 rows x 8 chunks; thread t: chunk t&7, rows (t>>3)+32i.
-template <typename T>
-__device__ __forceinline__ OperandView view_kmajor(const T *base, long long ld, int row0, int rows, int K, int t) {
+// K-contiguous tile: 32*TM rows x 8 chunks; thread t: chunk t&7, rows (t>>3)+32i.
+template <typename T, int TM>
+__device__ __forceinline__ OperandView<TM> view_kmajor(const T *base, long long ld, int row0, int rows, int K, int t) {
   constexpr int EPC = DmTypeInfo<T>::kPerChunk;
-  OperandView v;
+  OperandView<TM> v;
   const long long bytes = ((long long)(rows - 1) * ld + K) * (long long)sizeof(T);
   v.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(base), 0, (int)bytes, 0x00020000);
   v.chunk_k = (t & 7) * EPC;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < TM; ++i) {
     const long long row = row0 + (t >> 3) + 32 * i;
     const long long off = (row * ld + v.chunk_k) * (long long)sizeof(T);
     v.voff[i] = (row < rows) ? (unsigned)off : 0x80000000u;      // past the last row: force out of range
   }
   return v;
 }
-template <typename T>
-__device__ __forceinline__ void load_kmajor(u32x4 (&r)[4], const OperandView &v, int k0, int kend) {
+template <typename T, int TM>
+__device__ __forceinline__ void load_kmajor(u32x4 (&r)[TM], const OperandView<TM> &v, int k0, int kend) {
   // chunks at or beyond kend (K tail of the last stage) must read zero, not the next row
   const unsigned kill = ((int)(k0 + v.chunk_k) < kend) ? 0u : 0x80000000u;
   const unsigned soff = (unsigned)k0 * (unsigned)sizeof(T);
 #pragma unroll
-  for (int i = 0; i < 4; ++i) r[i] = __builtin_amdgcn_raw_buffer_load_b128(v.rsrc, v.voff[i] | kill, soff, 0);
+  for (int i = 0; i < TM; ++i) r[i] = __builtin_amdgcn_raw_buffer_load_b128(v.rsrc, v.voff[i] | kill, soff, 0);
 }
-__device__ __forceinline__ void store_kmajor(char *lds, const u32x4 (&r)[4], int t) {
+template <int TM> __device__ __forceinline__ void store_kmajor(char *lds, const u32x4 (&r)[TM], int t) {
   const int c = t & 7;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < TM; ++i) {
     const int row = (t >> 3) + 32 * i;
     *reinterpret_cast<u32x4 *>(lds + row * 128 + ((c ^ (row & 7)) << 4)) = r[i];
   }
 }
-// M-contiguous tile: rows are k. bf16: 64 rows x 16 chunks; fp32: 32 rows x 32 chunks.
+// M-contiguous tile: rows are k (64 for bf16, 32 for fp32), 32*TM elements wide.
 // Rows k >= K fall outside the descriptor (zero); split-K slices end on stage boundaries, so no
 // other k predicate is needed.  Columns past the operand's width only feed outputs that are never
 // stored.
-template <typename T>
-__device__ __forceinline__ OperandView view_mmajor(const T *base, long long ld, int col0, int cols, int K, int t) {
-  constexpr int EPC = DmTypeInfo<T>::kPerChunk;
-  constexpr int CPR = 128 / EPC;         // chunks per row: 16 (bf16) / 32 (fp32)
-  constexpr int RPI = NTHREADS / CPR;    // rows per iteration: 16 / 8
-  OperandView v;
+template <typename T, int TM>
+__device__ __forceinline__ OperandView<TM> view_mmajor(const T *base, long long ld, int col0, int cols, int K, int t) {
+  using G = Geo<T, TM>;
+  OperandView<TM> v;
   const long long bytes = ((long long)(K - 1) * ld + cols) * (long long)sizeof(T);
   v.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(base), 0, (int)bytes, 0x00020000);
   v.chunk_k = 0;
-  const int col = col0 + (t % CPR) * EPC;
+  const int col = col0 + (t % G::M_CPR) * G::EPC;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const long long k = t / CPR + RPI * i;
+  for (int i = 0; i < TM; ++i) {
+    const long long k = t / G::M_CPR + G::M_RPI * i;
     v.voff[i] = (col < cols) ? (unsigned)((k * ld + col) * (long long)sizeof(T)) : 0x80000000u;
   }
   return v;
 }
-template <typename T>
-__device__ __forceinline__ void load_mmajor(u32x4 (&r)[4], const OperandView &v, long long ld, int k0) {
+template <typename T, int TM>
+__device__ __forceinline__ void load_mmajor(u32x4 (&r)[TM], const OperandView<TM> &v, long long ld, int k0) {
   const unsigned soff = (unsigned)((long long)k0 * ld * (long long)sizeof(T));
 #pragma unroll
-  for (int i = 0; i < 4; ++i) r[i] = __builtin_amdgcn_raw_buffer_load_b128(v.rsrc, v.voff[i], soff, 0);
+  for (int i = 0; i < TM; ++i) r[i] = __builtin_amdgcn_raw_buffer_load_b128(v.rsrc, v.voff[i], soff, 0);
 }
-template <typename T> __device__ __forceinline__ void store_mmajor(char *lds, const u32x4 (&r)[4], int t);
-template <> __device__ __forceinline__ void store_mmajor<bf16_t>(char *lds, const u32x4 (&r)[4], int t) {
-  const int c = t & 15;  // 16-byte chunk = 8 columns; two chunks per 32-byte slot
+template <typename T, int TM> __device__ __forceinline__ void store_mmajor(char *lds, const u32x4 (&r)[TM], int t) {
+  using G = Geo<T, TM>;
+  const int c = t % G::M_CPR;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int k = (t >> 4) + 16 * i;
-    *reinterpret_cast<u32x4 *>(lds + k * 256 + ((((c >> 1) ^ tr_swz(k))) << 5) + ((c & 1) << 4)) = r[i];
-  }
-}
-template <> __device__ __forceinline__ void store_mmajor<float>(char *lds, const u32x4 (&r)[4], int t) {
-  const int c = t & 31;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int k = (t >> 5) + 8 * i;
-    *reinterpret_cast<u32x4 *>(lds + k * 528 + (c << 4)) = r[i];
+  for (int i = 0; i < TM; ++i) {
+    const int k = t / G::M_CPR + G::M_RPI * i;
+    if constexpr (sizeof(T) == 2)   // 16-byte chunk = 8 columns; two chunks per 32-byte slot
+      *reinterpret_cast<u32x4 *>(lds + k * G::M_ROWB + (((c >> 1) ^ tr_swz<TM>(k)) << 5) + ((c & 1) << 4)) = r[i];
+    else
+      *reinterpret_cast<u32x4 *>(lds + k * G::M_ROWB + (c << 4)) = r[i];
   }
 }
 
 // ---- LDS -> fragment reads -------------------------------------------------------------------
-// K-contiguous: tile row = wave-local row; same code for both dtypes.
+// K-contiguous: tile row = wave-local row; same code for both dtypes and tile sizes.
 __device__ __forceinline__ u32x4 frag_kmajor(const char *lds, int row, int kb, int lane) {
   const int chunk = kb * 4 + (lane >> 4);
   return *reinterpret_cast<const u32x4 *>(lds + row * 128 + ((chunk ^ (row & 7)) << 4));
 }
-template <typename T> __device__ __forceinline__ u32x4 frag_mmajor(const char *lds, int col0, int kb, int lane);
-template <> __device__ __forceinline__ u32x4 frag_mmajor<bf16_t>(const char *lds, int col0, int kb, int lane) {
-  // ds_read_b64_tr_b16: within a 16-lane group, lane 4q+p supplies the address of row q,
-  // columns 4p..4p+3; lane i receives column i of the 4 rows.
-  const int g = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
-  const int col = col0 + 4 * p;
+template <typename T, int TM> __device__ __forceinline__ u32x4 frag_mmajor(const char *lds, int col0, int kb, int lane) {
+  using G = Geo<T, TM>;
+  const int g = lane >> 4;
   u32x4 out;
+  if constexpr (sizeof(T) == 2) {
+    // ds_read_b64_tr_b16: within a 16-lane group, lane 4q+p supplies the address of row q,
+    // columns 4p..4p+3; lane i receives column i of the 4 rows.
+    const int q = (lane >> 2) & 3, p = lane & 3;
+    const int col = col0 + 4 * p;
 #pragma unroll
-  for (int half = 0; half < 2; ++half) {
-    const int k = kb * 32 + 8 * g + 4 * half + q;
-    const char *addr = lds + k * 256 + ((((col >> 4) ^ tr_swz(k))) << 5) + ((col & 15) << 1);
-    const u32x2 w = dm_ds_read_tr16(addr);
-    out[2 * half] = w[0];
-    out[2 * half + 1] = w[1];
-  }
-  return out;
-}
-template <> __device__ __forceinline__ u32x4 frag_mmajor<float>(const char *lds, int col0, int kb, int lane) {
-  const int g = lane >> 4, i = lane & 15;
-  u32x4 out;
+    for (int half = 0; half < 2; ++half) {
+      const int k = kb * 32 + 8 * g + 4 * half + q;
+      const u32x2 w = dm_ds_read_tr16(lds + k * G::M_ROWB + (((col >> 4) ^ tr_swz<TM>(k)) << 5) + ((col & 15) << 1));
+      out[2 * half] = w[0];
+      out[2 * half + 1] = w[1];
+    }
+  } else {
+    const int i = lane & 15;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int k = kb * 16 + 4 * g + j;
-    out[j] = *reinterpret_cast<const unsigned int *>(lds + k * 528 + ((col0 + i) << 2));
+    for (int j = 0; j < 4; ++j) {
+      const int k = kb * 16 + 4 * g + j;
+      out[j] = *reinterpret_cast<const unsigned int *>(lds + k * G::M_ROWB + ((col0 + i) << 2));
+    }
   }
   return out;
 }
 
-template <typename T, int LAYOUT>
-__global__ __launch_bounds__(NTHREADS, WG_PER_CU) void gemm_kernel(const GemmParams p) {
+template <typename T, int LAYOUT, int TM>
+__global__ __launch_bounds__(NTHREADS, (TM == 4 ? WG_PER_CU : 4)) void gemm_kernel(const GemmParams p) {
+  using G = Geo<T, TM>;
   constexpr bool A_MMAJOR = (LAYOUT == DM_TN);
   constexpr bool B_MMAJOR = (LAYOUT != DM_NT);
-  constexpr int BK = 128 / (int)sizeof(T);
-  __shared__ __attribute__((aligned(16))) char smem[2 * LDS_STAGES * STAGE_BYTES];
-  auto ldsA = [&](int buf) -> char * { return smem + (2 * (buf % LDS_STAGES)) * STAGE_BYTES; };
-  auto ldsB = [&](int buf) -> char * { return smem + (2 * (buf % LDS_STAGES) + 1) * STAGE_BYTES; };
+  constexpr int BK = G::BK;
+  constexpr int TILE = G::TILE, WT = 16 * TM;     // workgroup tile, wave tile
+  __shared__ __attribute__((aligned(16))) char smem[2 * LDS_STAGES * G::STAGE];
+  auto ldsA = [&](int buf) -> char * { return smem + (2 * (buf % LDS_STAGES)) * G::STAGE; };
+  auto ldsB = [&](int buf) -> char * { return smem + (2 * (buf % LDS_STAGES) + 1) * G::STAGE; };
 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int wm = wave >> 1, wn = wave & 1;
@@ -202,36 +219,36 @@ __global__ __launch_bounds__(NTHREADS, WG_PER_CU) void gemm_kernel(const GemmPar
   id /= p.tiles_n;
   const int tm = id % p.tiles_m;
   const int z = id / p.tiles_m;
-  const int m0 = tm * BM, n0 = tn * BN;
+  const int m0 = tm * TILE, n0 = tn * TILE;
   const int kbeg = z * p.k_per_split;
   const int kend = min(p.K, kbeg + p.k_per_split);
 
   const T *A = reinterpret_cast<const T *>(p.A);
   const T *B = reinterpret_cast<const T *>(p.B);
 
-  f32x4 acc[4][4];
+  f32x4 acc[TM][TM];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < TM; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  u32x4 ra[4], rb[4];
-  OperandView va, vb;
-  if constexpr (A_MMAJOR) va = view_mmajor<T>(A, p.lda, m0, p.M, p.K, t);
-  else va = view_kmajor<T>(A, p.lda, m0, p.M, p.K, t);
-  if constexpr (B_MMAJOR) vb = view_mmajor<T>(B, p.ldb, n0, p.N, p.K, t);
-  else vb = view_kmajor<T>(B, p.ldb, n0, p.N, p.K, t);
+  u32x4 ra[TM], rb[TM];
+  OperandView<TM> va, vb;
+  if constexpr (A_MMAJOR) va = view_mmajor<T, TM>(A, p.lda, m0, p.M, p.K, t);
+  else va = view_kmajor<T, TM>(A, p.lda, m0, p.M, p.K, t);
+  if constexpr (B_MMAJOR) vb = view_mmajor<T, TM>(B, p.ldb, n0, p.N, p.K, t);
+  else vb = view_kmajor<T, TM>(B, p.ldb, n0, p.N, p.K, t);
   auto gload = [&](int k0) {
-    if constexpr (A_MMAJOR) load_mmajor<T>(ra, va, p.lda, k0);
-    else load_kmajor<T>(ra, va, k0, kend);
-    if constexpr (B_MMAJOR) load_mmajor<T>(rb, vb, p.ldb, k0);
-    else load_kmajor<T>(rb, vb, k0, kend);
+    if constexpr (A_MMAJOR) load_mmajor<T, TM>(ra, va, p.lda, k0);
+    else load_kmajor<T, TM>(ra, va, k0, kend);
+    if constexpr (B_MMAJOR) load_mmajor<T, TM>(rb, vb, p.ldb, k0);
+    else load_kmajor<T, TM>(rb, vb, k0, kend);
   };
   auto lstore = [&](int buf) {
-    if constexpr (A_MMAJOR) store_mmajor<T>(ldsA(buf), ra, t);
-    else store_kmajor(ldsA(buf), ra, t);
-    if constexpr (B_MMAJOR) store_mmajor<T>(ldsB(buf), rb, t);
-    else store_kmajor(ldsB(buf), rb, t);
+    if constexpr (A_MMAJOR) store_mmajor<T, TM>(ldsA(buf), ra, t);
+    else store_kmajor<TM>(ldsA(buf), ra, t);
+    if constexpr (B_MMAJOR) store_mmajor<T, TM>(ldsB(buf), rb, t);
+    else store_kmajor<TM>(ldsB(buf), rb, t);
   };
 
   const int nk = (kend - kbeg + BK - 1) / BK;
@@ -246,18 +263,18 @@ __global__ __launch_bounds__(NTHREADS, WG_PER_CU) void gemm_kernel(const GemmPar
     if (more) gload(kbeg + (kt + 1) * BK);
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
-      u32x4 fa[4], fb[4];
+      u32x4 fa[TM], fb[TM];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        if constexpr (A_MMAJOR) fa[i] = frag_mmajor<T>(ldsA(cur), wm * 64 + i * 16, kb, lane);
-        else fa[i] = frag_kmajor(ldsA(cur), wm * 64 + i * 16 + (lane & 15), kb, lane);
-        if constexpr (B_MMAJOR) fb[i] = frag_mmajor<T>(ldsB(cur), wn * 64 + i * 16, kb, lane);
-        else fb[i] = frag_kmajor(ldsB(cur), wn * 64 + i * 16 + (lane & 15), kb, lane);
+      for (int i = 0; i < TM; ++i) {
+        if constexpr (A_MMAJOR) fa[i] = frag_mmajor<T, TM>(ldsA(cur), wm * WT + i * 16, kb, lane);
+        else fa[i] = frag_kmajor(ldsA(cur), wm * WT + i * 16 + (lane & 15), kb, lane);
+        if constexpr (B_MMAJOR) fb[i] = frag_mmajor<T, TM>(ldsB(cur), wn * WT + i * 16, kb, lane);
+        else fb[i] = frag_kmajor(ldsB(cur), wn * WT + i * 16 + (lane & 15), kb, lane);
       }
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) mma<T>(acc[i][j], fa[i], fb[j]);
+        for (int j = 0; j < TM; ++j) mma<T>(acc[i][j], fa[i], fb[j]);
     }
     if constexpr (LDS_STAGES == 1) __syncthreads();   // every wave is done reading the single buffer
     if (more) lstore(cur ^ 1);
@@ -269,20 +286,20 @@ __global__ __launch_bounds__(NTHREADS, WG_PER_CU) void gemm_kernel(const GemmPar
   if (p.split_k > 1) {
     float *W = p.workspace + (long long)z * p.M * p.N;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int m = m0 + wm * 64 + i * 16 + li;
+    for (int i = 0; i < TM; ++i) {
+      const int m = m0 + wm * WT + i * 16 + li;
       if (m >= p.M) continue;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int n = n0 + wn * 64 + j * 16 + 4 * g;
+      for (int j = 0; j < TM; ++j) {
+        const int n = n0 + wn * WT + j * 16 + 4 * g;
         if (n < p.N) dm_store4(W + (long long)m * p.N + n, acc[i][j]);
       }
     }
     return;
   }
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int m = m0 + wm * 64 + i * 16 + li;
+  for (int i = 0; i < TM; ++i) {
+    const int m = m0 + wm * WT + i * 16 + li;
     if (m >= p.M) continue;
     long long rbase_c, rbase_r, rbase_x;
     if (p.rows_per_group > 0) {
@@ -296,8 +313,8 @@ __global__ __launch_bounds__(NTHREADS, WG_PER_CU) void gemm_kernel(const GemmPar
       rbase_x = (long long)m * p.ldaux;
     }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int n = n0 + wn * 64 + j * 16 + 4 * g;
+    for (int j = 0; j < TM; ++j) {
+      const int n = n0 + wn * WT + j * 16 + 4 * g;
       if (n >= p.N) continue;   // N % 4 == 0 is enforced by the launcher
       f32x4 v = acc[i][j];
       if (p.bias) v += dm_load4(p.bias + n);
@@ -421,13 +438,26 @@ __global__ __launch_bounds__(256) void sgemm_small_kernel(const GemmParams p) {
   *c = v;
 }
 
-template <typename T>
+template <typename T, int TM>
 void launch_mfma(const GemmParams &p, int layout, int grid, hipStream_t s) {
   switch (layout) {
-    case DM_NT: hipLaunchKernelGGL((gemm_kernel<T, DM_NT>), dim3(grid), dim3(NTHREADS), 0, s, p); break;
-    case DM_NN: hipLaunchKernelGGL((gemm_kernel<T, DM_NN>), dim3(grid), dim3(NTHREADS), 0, s, p); break;
-    default: hipLaunchKernelGGL((gemm_kernel<T, DM_TN>), dim3(grid), dim3(NTHREADS), 0, s, p); break;
+    case DM_NT: hipLaunchKernelGGL((gemm_kernel<T, DM_NT, TM>), dim3(grid), dim3(NTHREADS), 0, s, p); break;
+    case DM_NN: hipLaunchKernelGGL((gemm_kernel<T, DM_NN, TM>), dim3(grid), dim3(NTHREADS), 0, s, p); break;
+    default: hipLaunchKernelGGL((gemm_kernel<T, DM_TN, TM>), dim3(grid), dim3(NTHREADS), 0, s, p); break;
   }
+}
+
+// 64x64 tiles when the product has too few 128x128 tiles to give every CU its share
+// Measured on MI355X (tools/microbench.py, A/B in one process): 64x64 wins only when there are fewer 128x128 tiles than
+// CUs; for wgrad (long contraction, small output) 128x128 + split-K stays ahead unless the contraction is short.
+inline int pick_tile(int layout, int M, int N, int K) {
+  if (const char *f = getenv("DM_GEMM_FORCE_TILE")) {   // tuning / A-B aid: 64 or 128
+    const int v = atoi(f);
+    if (v == 64 || v == 128) return v;
+  }
+  const long long t128 = (long long)((M + 127) / 128) * ((N + 127) / 128);
+  if (t128 >= 256) return 128;
+  return (layout == DM_TN && K > 4096) ? 128 : 64;
 }
 
 int choose_split(int tiles, int K, int bk) {
@@ -441,7 +471,8 @@ int choose_split(int tiles, int K, int bk) {
 
 extern "C" int64_t dm_gemm_workspace_bytes(int32_t layout, int32_t M, int32_t N, int32_t K) {
   if (layout != DM_TN) return 0;
-  const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+  const int tile = pick_tile(layout, M, N, K);
+  const int tiles = ((M + tile - 1) / tile) * ((N + tile - 1) / tile);
   const int s = choose_split(tiles, K, 32);
   return s > 1 ? (int64_t)s * M * N * 4 : 0;
 }
@@ -498,8 +529,9 @@ extern "C" int dm_gemm(const DmGemmArgs *a, void *stream) {
     return DM_OK;
   }
 
-  p.tiles_m = (a->M + BM - 1) / BM;
-  p.tiles_n = (a->N + BN - 1) / BN;
+  const int tile = pick_tile(a->layout, a->M, a->N, a->K);
+  p.tiles_m = (a->M + tile - 1) / tile;
+  p.tiles_n = (a->N + tile - 1) / tile;
   const int bk = (a->ab_dtype == DM_BF16) ? 64 : 32;
   int split = a->split_k;
   const bool can_split = (a->layout == DM_TN) && a->epilogue == DM_EPI_NONE && !a->bias && !a->residual &&
@@ -521,8 +553,11 @@ extern "C" int dm_gemm(const DmGemmArgs *a, void *stream) {
     const double csz = (a->c_dtype == DM_BF16) ? 2.0 : 4.0;
     DmProfScope prof(kNames[a->ab_dtype == DM_BF16][a->layout], s, 2.0 * a->M * a->N * a->K,
                      esz * ((double)a->M * a->K + (double)a->N * a->K) + csz * (double)a->M * a->N);
-    if (a->ab_dtype == DM_BF16) launch_mfma<bf16_t>(p, a->layout, grid, s);
-    else launch_mfma<float>(p, a->layout, grid, s);
+    if (a->ab_dtype == DM_BF16) {
+      if (tile == 128) launch_mfma<bf16_t, 4>(p, a->layout, grid, s); else launch_mfma<bf16_t, 2>(p, a->layout, grid, s);
+    } else {
+      if (tile == 128) launch_mfma<float, 4>(p, a->layout, grid, s); else launch_mfma<float, 2>(p, a->layout, grid, s);
+    }
   }
   DM_LAUNCH_CHECK("dm_gemm");
   if (split > 1) {
