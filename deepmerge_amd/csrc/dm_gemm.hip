@@ -91,24 +91,34 @@ template <int TM> __device__ __forceinline__ int tr_swz(int k) {
 // loop carries no branches and no 64-bit address arithmetic -- TM per-thread byte offsets are
 // computed once and each K stage only bumps one scalar offset.
 template <int TM> struct OperandView {
-  __amdgpu_buffer_rsrc_t rsrc;
-  unsigned voff[TM];    // per-thread byte offsets of its 16-byte chunks (stage 0, k = 0)
-  unsigned chunk_k;     // k index (elements) of this thread's chunk inside a stage (k-contiguous operands)
+  __amdgpu_buffer_rsrc_t rsrc;   // k-contiguous operands: descriptor of this tile's row panel
+  const void *base;              // m-contiguous operands: tile column origin (row k = 0), re-based every stage
+  long long tail_bytes;          // m-contiguous: bytes from `base` to the end of the operand
+  unsigned voff[TM];             // per-thread byte offsets of its 16-byte chunks inside the panel / stage
+  unsigned chunk_k;              // k index (elements) of this thread's chunk inside a stage (k-contiguous operands)
 };
 
-// K-contiguous tile: 32*TM rows x 8 chunks; thread t: chunk t&7, rows (t>>3)+32i.
+__device__ __forceinline__ int clamp_records(long long bytes) {
+  return (int)(bytes < 0 ? 0 : (bytes > 0x7fffffffLL ? 0x7fffffffLL : bytes));
+}
+
+// K-contiguous tile: 32*TM rows x 8 chunks; thread t: chunk t&7, rows (t>>3)+32i.  The descriptor starts at the
+// tile's first row (64-bit pointer arithmetic once per workgroup), so operands of any size work with 32-bit offsets.
 template <typename T, int TM>
 __device__ __forceinline__ OperandView<TM> view_kmajor(const T *base, long long ld, int row0, int rows, int K, int t) {
   constexpr int EPC = DmTypeInfo<T>::kPerChunk;
   OperandView<TM> v;
-  const long long bytes = ((long long)(rows - 1) * ld + K) * (long long)sizeof(T);
-  v.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(base), 0, (int)bytes, 0x00020000);
+  const int nrows = min(32 * TM, rows - row0);                 // >= 1: the grid never starts a tile past the operand
+  const long long bytes = ((long long)(nrows - 1) * ld + K) * (long long)sizeof(T);
+  v.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(base + (long long)row0 * ld), 0, clamp_records(bytes), 0x00020000);
+  v.base = nullptr;
+  v.tail_bytes = 0;
   v.chunk_k = (t & 7) * EPC;
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
-    const long long row = row0 + (t >> 3) + 32 * i;
-    const long long off = (row * ld + v.chunk_k) * (long long)sizeof(T);
-    v.voff[i] = (row < rows) ? (unsigned)off : 0x80000000u;      // past the last row: force out of range
+    const int row = (t >> 3) + 32 * i;
+    const long long off = ((long long)row * ld + v.chunk_k) * (long long)sizeof(T);
+    v.voff[i] = (row < nrows) ? (unsigned)off : 0x80000000u;      // past the last row: force out of range
   }
   return v;
 }
@@ -128,30 +138,33 @@ template <int TM> __device__ __forceinline__ void store_kmajor(char *lds, const 
     *reinterpret_cast<u32x4 *>(lds + row * 128 + ((c ^ (row & 7)) << 4)) = r[i];
   }
 }
-// M-contiguous tile: rows are k (64 for bf16, 32 for fp32), 32*TM elements wide.
-// Rows k >= K fall outside the descriptor (zero); split-K slices end on stage boundaries, so no
-// other k predicate is needed.  Columns past the operand's width only feed outputs that are never
-// stored.
+// M-contiguous tile: rows are k (64 for bf16, 32 for fp32), 32*TM elements wide.  The descriptor is re-based at
+// every stage (scalar work) so that offsets stay small for operands with millions of rows; rows k >= K fall
+// outside it and read zero.  Split-K slices end on stage boundaries, so no other k predicate is needed.  Columns
+// past the operand's width are killed per thread (they would otherwise alias the next row).
 template <typename T, int TM>
 __device__ __forceinline__ OperandView<TM> view_mmajor(const T *base, long long ld, int col0, int cols, int K, int t) {
   using G = Geo<T, TM>;
   OperandView<TM> v;
-  const long long bytes = ((long long)(K - 1) * ld + cols) * (long long)sizeof(T);
-  v.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(base), 0, (int)bytes, 0x00020000);
+  v.base = base + col0;
+  v.tail_bytes = ((long long)(K - 1) * ld + (cols - col0)) * (long long)sizeof(T);
+  v.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(base), 0, 0, 0x00020000);
   v.chunk_k = 0;
-  const int col = col0 + (t % G::M_CPR) * G::EPC;
+  const int col = (t % G::M_CPR) * G::EPC;
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
     const long long k = t / G::M_CPR + G::M_RPI * i;
-    v.voff[i] = (col < cols) ? (unsigned)((k * ld + col) * (long long)sizeof(T)) : 0x80000000u;
+    v.voff[i] = (col0 + col < cols) ? (unsigned)((k * ld + col) * (long long)sizeof(T)) : 0x80000000u;
   }
   return v;
 }
 template <typename T, int TM>
 __device__ __forceinline__ void load_mmajor(u32x4 (&r)[TM], const OperandView<TM> &v, long long ld, int k0) {
-  const unsigned soff = (unsigned)((long long)k0 * ld * (long long)sizeof(T));
+  const long long skip = (long long)k0 * ld * (long long)sizeof(T);
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<char *>(reinterpret_cast<const char *>(v.base) + skip), 0, clamp_records(v.tail_bytes - skip), 0x00020000);
 #pragma unroll
-  for (int i = 0; i < TM; ++i) r[i] = __builtin_amdgcn_raw_buffer_load_b128(v.rsrc, v.voff[i], soff, 0);
+  for (int i = 0; i < TM; ++i) r[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, v.voff[i], 0, 0);
 }
 template <typename T, int TM> __device__ __forceinline__ void store_mmajor(char *lds, const u32x4 (&r)[TM], int t) {
   using G = Geo<T, TM>;
@@ -498,9 +511,8 @@ extern "C" int dm_gemm(const DmGemmArgs *a, void *stream) {
   // Which extents must be chunk (16-byte) multiples for the MFMA path.
   {
     const long long esz = (a->ab_dtype == DM_BF16) ? 2 : 4;
-    const long long a_rows = (a->layout == DM_TN) ? a->K : a->M, b_rows = (a->layout == DM_NT) ? a->N : a->K;
-    DM_REQUIRE(a_rows * a->lda * esz < (1LL << 31) && b_rows * a->ldb * esz < (1LL << 31), DM_ERR_BAD_SHAPE,
-               "dm_gemm: operands must be smaller than 2 GiB each (32-bit buffer offsets)");
+    DM_REQUIRE(128 * a->lda * esz < (1LL << 31) && 128 * a->ldb * esz < (1LL << 31), DM_ERR_BAD_SHAPE,
+               "dm_gemm: leading dimensions too large for 32-bit panel offsets (lda=%lld ldb=%lld)", (long long)a->lda, (long long)a->ldb);
   }
   const int epc = (a->ab_dtype == DM_BF16) ? 8 : 4;
   const int a_inner = (a->layout == DM_TN) ? a->M : a->K;   // contiguous extent of A rows

@@ -115,6 +115,39 @@ def test_gemm_wgrad_split_k(mode, Mrows, N, K):
     assert torch.equal(G, G2), "split-K reduction must be run-to-run deterministic"
 
 
+def test_gemm_operands_beyond_2gib():
+    """Eval batches (ExtractFeatures.py: 2000 points x 192 tokens x hidden 3072) give operands > 2 GiB; the tile
+    descriptors are re-based per panel / per stage, so every layout must still be exact there."""
+    ops = _ops()
+    from deepmerge_amd._lib import DM_NN, DM_NT, DM_TN
+    g = torch.Generator(device=DEV); g.manual_seed(5)
+    R, W, S = 360000, 3072, 64                                    # R*W*2 B = 2.2 GB
+    big = torch.randint(-1, 2, (R, W), device=DEV, generator=g).to(torch.bfloat16)
+    small_w = torch.randint(-1, 2, (S, W), device=DEV, generator=g).to(torch.bfloat16)
+    small_r = torch.randint(-1, 2, (R, S), device=DEV, generator=g).to(torch.bfloat16)
+    assert big.numel() * 2 > (1 << 31)
+    bigf = big.float()
+    # NT, k-contiguous big A: C[R,S] = big @ small_w^T
+    out = torch.empty((R, S), device=DEV)
+    ops.gemm(DM_NT, big, small_w, out, R, S, W, lda=W, ldb=W, ldc=S)
+    assert torch.equal(out, bigf @ small_w.float().T)
+    # NN, big output (> 2 GiB fp32) : C[R,W] = small_r @ small_w
+    out2 = torch.empty((R, W), device=DEV)
+    ops.gemm(DM_NN, small_r, small_w, out2, R, W, S, lda=S, ldb=W, ldc=W)
+    assert torch.equal(out2, small_r.float() @ small_w.float())
+    del out2
+    # NN, m-contiguous big B with K = R rows: C[S,W] = small_r^T(as [S,R] row-major) @ big
+    a_t = small_r.T.contiguous()
+    out3 = torch.empty((S, W), device=DEV)
+    ops.gemm(DM_NN, a_t, big, out3, S, W, R, lda=R, ldb=W, ldc=W)
+    want3 = a_t.float() @ bigf
+    assert torch.equal(out3, want3)
+    # TN, both operands m-contiguous, K = R: C[W,S] = big^T @ small_r
+    out4 = torch.empty((W, S), device=DEV)
+    ops.gemm(DM_TN, big, small_r, out4, W, S, R, lda=W, ldb=S, ldc=S)
+    assert torch.equal(out4, want3.T.contiguous())
+
+
 def test_gemm_generic_fp32_odd_shapes():
     ops = _ops()
     from deepmerge_amd._lib import DM_NN, DM_NT, DM_TN

@@ -1,0 +1,135 @@
+#!/usr/bin/env python3
+"""Secondary measurements on ONE MI355X for the other BASELINE.json configs (the headline is bench.py):
+  config 3  ViT-B/16 pair encoder, 224x224x3, 128 pairs/step, train step
+  config 4  ExtractFeatures pipeline on a 4096x4096x4 tile: patch pyramid gather -> v3 [6,4,2] eval -> segment mean -> edge simi
+  config 5  (single-GPU part) v3 [6,4,2], 4 scales x 4 ch, 120 pairs/step, train step
+Prints one JSON line per config.   python tools/bench_configs.py [3] [4] [5]
+"""
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from bench import synth_batch  # noqa: E402
+from deepmerge_amd import ops  # noqa: E402
+from deepmerge_amd.trainer import PairTrainer  # noqa: E402
+from deepmerge_amd.workload import pair_step_flops  # noqa: E402
+
+DEV = "cuda:0"
+
+
+def timed(fn, steps, warm=2):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps
+
+
+def ev(fn, iters=10):
+    fn(); torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(iters):
+        fn()
+    b.record(); torch.cuda.synchronize()
+    return a.elapsed_time(b) / iters * 1e-3
+
+
+def config3():
+    from deepmerge_amd.Losses import Loss
+    from deepmerge_amd.vit_model import vit_base_patch16_224_in21k
+    B = 128
+    net = vit_base_patch16_224_in21k(num_classes=100, has_logits=False, numerics="bf16").to(DEV)
+
+    class Pair(torch.nn.Module):      # adapt the 2-tensor pair signature to PairTrainer's 4-argument step
+        def __init__(self, n):
+            super().__init__(); self.n = n; self.numerics = "bf16"
+        def forward(self, a, _1, b, _2):
+            return self.n(a, b)
+    tr = PairTrainer(Pair(net), margin=1.0, lr=1e-4)
+    g = torch.Generator().manual_seed(0)
+    x1 = torch.rand(B, 3, 224, 224, generator=g).to(DEV); x2 = torch.rand(B, 3, 224, 224, generator=g).to(DEV)
+    flag = (torch.arange(B) % 2).to(DEV)
+    dt = timed(lambda: tr.step(x1, None, x2, None, flag), 10)
+    gf = 210.6
+    print(json.dumps({"config": "3: ViT-B/16 pair encoder 224x224x3, 128 pairs/step, bf16, fwd+loss+bwd+Adam", "pairs_per_s": round(B / dt, 1),
+                      "ms_per_step": round(dt * 1e3, 2), "model_TFLOPs": round(B / dt * gf / 1e3, 1)}), flush=True)
+
+
+def config5():
+    from deepmerge_amd.nets.ShfitScaleFormer import ShfitScaleFormer_v3
+    scales, in_c, depth, B = [32, 64, 128, 256], 4, [6, 4, 2], 120
+    net = ShfitScaleFormer_v3(cube_size=[8, 8], input_image_scales=list(scales), depth=list(depth), in_c=in_c, numerics="bf16").to(DEV)
+    tr = PairTrainer(net, margin=1.0, lr=1e-4)
+    batch = synth_batch(B, scales, in_c, DEV, 7)
+    dt = timed(lambda: tr.step(*batch), 8)
+    gf = pair_step_flops(scales, in_c, depth) / 1e9
+    print(json.dumps({"config": "5 (1 GPU): v3 [6,4,2], 4 scales x 4 ch, 120 pairs/step, bf16, fwd+loss+bwd+Adam", "pairs_per_s": round(B / dt, 1),
+                      "ms_per_step": round(dt * 1e3, 2), "gflop_per_pair": round(gf, 1), "model_TFLOPs": round(B / dt * gf / 1e3, 1)}), flush=True)
+
+
+def config4():
+    from deepmerge_amd.ExtractFeatures import FeatureIO, rag_similarity_sweep
+    from deepmerge_amd.nets.ShfitScaleFormer import ShfitScaleFormer_v3
+    from deepmerge_amd.patches import point_batch
+    torch.manual_seed(0)
+    bands, H, W, side, k = 4, 4096, 4096, 141, 3
+    S = side * side
+    tile = torch.randint(0, 256, (bands, H, W), dtype=torch.uint8, device=DEV)
+    P = S * k
+    cell = H / side
+    sp = torch.arange(S)
+    cx = ((sp % side).float() + 0.5) * cell; cy = ((sp // side).float() + 0.5) * cell
+    xy = torch.stack([(cx[:, None] + torch.randint(-8, 9, (S, k))).reshape(-1), (cy[:, None] + torch.randint(-8, 9, (S, k))).reshape(-1)], 1)
+    xy = xy.clamp(0, H - 1).to(torch.int32).to(DEV)
+    inner = torch.randint(20, 29, (P,)); obj = inner + torch.randint(20, 29, (P,))
+    feats = torch.rand(P, 15, device=DEV)
+    ptr = (torch.arange(S + 1) * k).to(torch.int32).to(DEV); idx = torch.arange(P, dtype=torch.int32, device=DEV)
+    grid = torch.arange(S).reshape(side, side)
+    edges = torch.cat([torch.stack([grid[:, :-1].reshape(-1), grid[:, 1:].reshape(-1)], 1),
+                       torch.stack([grid[:-1].reshape(-1), grid[1:].reshape(-1)], 1)]).to(torch.int32).to(DEV)
+    net = ShfitScaleFormer_v3(cube_size=[8, 8], input_image_scales=[32, 64, 128], depth=[6, 4, 2], in_c=bands, numerics="bf16")
+    fio = FeatureIO(net, None, DEV)
+    bs = 2000
+    out = {}
+    t_g = ev(lambda: point_batch(tile, xy[:bs], inner[:bs], obj[:bs], feats[:bs]), 5)
+    win_bytes = float(((inner[:bs] ** 2 + obj[:bs] ** 2 + (2 * obj[:bs] - inner[:bs]) ** 2) * bands).sum())
+    out_bytes = bs * bands * (32 * 32 + 64 * 64 + 128 * 128) * 4
+    out["patch_gather"] = {"points_per_s": round(bs / t_g), "GBps_algorithmic(read window bytes + write fp32 patches)": round((win_bytes + out_bytes) / t_g / 1e9, 1)}
+
+    def encode_all():
+        F = torch.empty((P, 100), device=DEV)
+        with torch.no_grad():
+            for s in range(0, P, bs):
+                e = min(P, s + bs)
+                patches, designed = point_batch(tile, xy[s:e], inner[s:e], obj[s:e], feats[s:e])
+                F[s:e] = net(patches, designed)
+        return F
+    t0 = time.perf_counter(); F = encode_all(); torch.cuda.synchronize(); t_enc = time.perf_counter() - t0
+    t0 = time.perf_counter(); F = encode_all(); torch.cuda.synchronize(); t_enc = time.perf_counter() - t0
+    out["encode(gather + v3[6,4,2] eval, batch 2000)"] = {"points_per_s": round(P / t_enc), "seconds_for_tile": round(t_enc, 2)}
+    t_p = ev(lambda: ops.segment_mean(F, ptr, idx), 20)
+    out["segment_mean"] = {"us": round(t_p * 1e6, 1), "GBps_algorithmic": round((P * 404 + S * 400) / t_p / 1e9, 1)}
+    pooled = ops.segment_mean(F, ptr, idx)
+    t_e = ev(lambda: ops.edge_similarity(pooled, edges, 1.0), 20)
+    E = edges.shape[0]
+    out["edge_similarity"] = {"us": round(t_e * 1e6, 1), "edges_per_s": round(E / t_e), "GBps_algorithmic": round(E * 812 / t_e / 1e9, 1)}
+    _, simi, merge = rag_similarity_sweep(F, ptr, idx, edges, 1.0)
+    out["summary"] = {"points": P, "superpixels": S, "edges": E, "merge_fraction": round(float(merge.float().mean()), 3),
+                      "sweep_total_us(pool+edges)": round((t_p + t_e) * 1e6, 1)}
+    print(json.dumps({"config": "4: ExtractFeatures pipeline, 4096x4096x4 tile", **out}), flush=True)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["3", "4", "5"]
+    if "3" in which: config3()
+    if "5" in which: config5()
+    if "4" in which: config4()
