@@ -22,6 +22,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0    # dense bf16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
+PEAK_HBM_TBPS = 8.0
 PEAK_F32_TFLOPS = 157.3
 
 
@@ -197,6 +198,10 @@ def main():
             roof = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
                     "frac": round(ach / peak, 4), "traffic": traffic, "algorithmic_bytes_per_launch": round(prof[dom][3] / launches),
                     "launches": launches,
+                    # roofline position of this launch mix: FLOP per algorithmic HBM byte against the 312 FLOP/B ridge
+                    # (2.5 PFLOP/s / 8 TB/s); attainable = min(peak, intensity * 8 TB/s)
+                    "intensity_flop_per_byte": round(flops / max(prof[dom][3], 1), 1),
+                    "attainable_TFLOPs": round(min(peak, flops / max(prof[dom][3], 1) * PEAK_HBM_TBPS), 1),
                     "avg_launch_us": round(1e3 * ms / launches, 2),
                     "all_kernels_TFLOPs": {k: round(v[2] / (v[1] * 1e-3) / 1e12, 1) for k, v in prof.items() if v[1] > 0},
                     "all_kernels_ms_per_step": {k: round(v[1] / args.steps, 3) for k, v in prof.items()}}
