@@ -174,8 +174,8 @@ def main():
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-    rows = (_lib.DmProfRow * 64)()
-    n = lib.dm_prof_collect(rows, 64)
+    rows = (_lib.DmProfRow * 256)()
+    n = lib.dm_prof_collect(rows, 256)
     prof = {rows[i].name.decode(): (rows[i].launches, rows[i].total_ms, rows[i].total_flops, rows[i].total_bytes) for i in range(n)}
 
     if rank == 0:

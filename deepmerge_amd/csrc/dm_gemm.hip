@@ -563,8 +563,19 @@ extern "C" int dm_gemm(const DmGemmArgs *a, void *stream) {
     static const char *kNames[2][3] = {{"gemm_f32_NT", "gemm_f32_NN", "gemm_f32_TN"}, {"gemm_bf16_NT", "gemm_bf16_NN", "gemm_bf16_TN"}};
     const double esz = (a->ab_dtype == DM_BF16) ? 2.0 : 4.0;
     const double csz = (a->c_dtype == DM_BF16) ? 2.0 : 4.0;
-    DmProfScope prof(kNames[a->ab_dtype == DM_BF16][a->layout], s, 2.0 * a->M * a->N * a->K,
-                     esz * ((double)a->M * a->K + (double)a->N * a->K) + csz * (double)a->M * a->N);
+    // DM_PROF_SHAPES=1: one profiler row per (layout, shape, epilogue) instead of per layout (tuning aid)
+    static const bool by_shape = [] { const char *e = getenv("DM_PROF_SHAPES"); return e && e[0] == '1'; }();
+    char shaped[64];
+    const char *pname = kNames[a->ab_dtype == DM_BF16][a->layout];
+    if (by_shape) {
+      snprintf(shaped, sizeof(shaped), "%s_%lldx%lldx%lld_e%d%s%s_t%d", pname, (long long)a->M, (long long)a->N, (long long)a->K, a->epilogue,
+               a->residual ? "r" : "", a->c_dtype == DM_BF16 ? "h" : "f", tile);
+      pname = shaped;
+    }
+    const double mn = (double)a->M * a->N;
+    DmProfScope prof(pname, s, 2.0 * a->M * a->N * a->K,
+                     esz * ((double)a->M * a->K + (double)a->N * a->K) + csz * mn * (a->accumulate ? 2.0 : 1.0) +
+                         (a->residual ? 4.0 * mn : 0.0) + (a->aux ? ((a->aux_dtype == DM_BF16) ? 2.0 : 4.0) * mn : 0.0));
     if (a->ab_dtype == DM_BF16) {
       if (tile == 128) launch_mfma<bf16_t, 4>(p, a->layout, grid, s); else launch_mfma<bf16_t, 2>(p, a->layout, grid, s);
     } else {

@@ -143,12 +143,19 @@ class CrossScaleAttention(nn.Module):
         self.proj = nn.Linear(dim, dim)
         self.proj_drop = nn.Dropout(proj_drop_ratio)
         self.cube_size = cube_size
-        rows = (2 * cube_size[0] - 1) * (2 * cube_size[1] - 1) * (2 * cube_size[2] - 1)
-        self.relative_position_bias_table = nn.Parameter(torch.zeros(rows, num_heads))
-        self.register_buffer("relative_position_index", relative_position_index(cube_size))
+        self.relative_position_bias_table = nn.Parameter(torch.zeros(self._table_rows(cube_size), num_heads))
+        self.register_buffer("relative_position_index", self._make_index(cube_size))
         nn.init.trunc_normal_(self.relative_position_bias_table, std=.02)
         self.numerics = _mode(numerics)
         self._idx32 = None
+
+    @staticmethod
+    def _table_rows(cube):
+        return (2 * cube[0] - 1) * (2 * cube[1] - 1) * (2 * cube[2] - 1)
+
+    @staticmethod
+    def _make_index(cube):
+        return relative_position_index(cube)
 
     def _index32(self) -> torch.Tensor:
         src = self.relative_position_index
@@ -175,6 +182,8 @@ class CrossScaleBlock(nn.Module):
     """Pre-norm block x += attn(LN(x)); x += mlp(LN(x)) (reference :158-184).  The residual stream stays
     fp32; both residual additions are fused into the proj / fc2 GEMM epilogues."""
 
+    _attention_cls = CrossScaleAttention
+
     def __init__(self, dim, num_heads, cube_size, mlp_ratio=4., qkv_bias=True, qk_scale=None, drop_ratio=0.,
                  attn_drop_ratio=0., drop_path_ratio=0., act_layer=nn.GELU, norm_layer=nn.LayerNorm, numerics=None):
         super().__init__()
@@ -182,7 +191,7 @@ class CrossScaleBlock(nn.Module):
             raise ValueError("stochastic depth is not part of the accelerated path (reference passes 0)")
         self.numerics = _mode(numerics)
         self.norm1 = norm_layer(dim)
-        self.attn = CrossScaleAttention(dim=dim, num_heads=num_heads, cube_size=cube_size, qkv_bias=qkv_bias,
+        self.attn = self._attention_cls(dim=dim, num_heads=num_heads, cube_size=cube_size, qkv_bias=qkv_bias,
                                         qk_scale=qk_scale, attn_drop_ratio=attn_drop_ratio, proj_drop_ratio=drop_ratio,
                                         numerics=self.numerics)
         self.drop_path = nn.Identity()
@@ -228,7 +237,7 @@ class ShfitScaleFormer_v3(nn.Module):
         self.feature_embed = FeatureEmbed(feature_size=19, embed_dim=embed_dim) if is_designed_feature_embedding else None
 
         def stage(cube, n):
-            return nn.Sequential(*[CrossScaleBlock(dim=embed_dim, num_heads=num_heads, cube_size=cube, mlp_ratio=mlp_ratio,
+            return nn.Sequential(*[getattr(self, "_block_cls", CrossScaleBlock)(dim=embed_dim, num_heads=num_heads, cube_size=cube, mlp_ratio=mlp_ratio,
                                                    drop_ratio=drop_ratio, attn_drop_ratio=attn_drop_ratio, drop_path_ratio=0,
                                                    norm_layer=norm_layer, act_layer=act_layer, numerics=self.numerics)
                                    for _ in range(n)])
@@ -308,6 +317,226 @@ class ShfitScaleFormer_v3(nn.Module):
         elif isinstance(m, nn.LayerNorm):
             nn.init.constant_(m.bias, 0)
             nn.init.constant_(m.weight, 1.0)
+
+
+def relative_position_index_v5(cube: Sequence[int]) -> torch.Tensor:
+    """[N+1, N+1] index of the v5 attention: the cube index plus one column / one row of fresh ids for the
+    designed-feature token, the corner aliased to entry [0,0] (reference :217-263)."""
+    base = relative_position_index(cube)
+    n = base.shape[0]
+    bins = CrossScaleAttention._table_rows(cube)
+    col = bins + torch.arange(n, dtype=torch.int64)[:, None]
+    idx = torch.cat([base, col], 1)
+    row = bins + n + torch.arange(n + 1, dtype=torch.int64)[None, :]
+    idx = torch.cat([idx, row], 0)
+    idx[-1, -1] = idx[0, 0]
+    return idx
+
+
+class CrossScaleAttention_v5(CrossScaleAttention):
+    """Attention over the token cube plus ONE extra token (the embedded designed features); the bias table
+    grows by 2 * S*H*W rows (reference :187-296).  Same fused kernels: only the index / table differ."""
+
+    @staticmethod
+    def _table_rows(cube):
+        return CrossScaleAttention._table_rows(cube) + 2 * cube[0] * cube[1] * cube[2]
+
+    @staticmethod
+    def _make_index(cube):
+        return relative_position_index_v5(cube)
+
+
+class CrossScaleBlock_v5(CrossScaleBlock):
+    """Reference :298-327."""
+    _attention_cls = CrossScaleAttention_v5
+
+
+class AuxBolck(nn.Module):
+    """Auxiliary head on an intermediate stage (reference :329-368): per scale Conv2d(k=2, no bias) ->
+    BatchNorm2d -> ReLU -> Dropout2d(0.3) -> Conv2d(1x1, C/S) -> mean over positions; concatenated ->
+    LayerNorm -> Linear(C, 100).  Both convolutions run as MFMA GEMMs (the 2x2 one over gathered windows);
+    BatchNorm2d / ReLU / Dropout2d are the torch modules themselves on the device (they own the running
+    statistics and the RNG stream the reference uses)."""
+    _v5 = False
+
+    def __init__(self, in_c=768, out_c=100, cube_size=[3, 8, 8], norm_layer=nn.LayerNorm, numerics=None):
+        super().__init__()
+        self.cube_size = cube_size
+        self.aux = nn.Sequential(
+            nn.Conv2d(in_c, in_c, kernel_size=2, padding=0, bias=False),
+            nn.BatchNorm2d(in_c),
+            nn.ReLU(inplace=True),
+            nn.Dropout2d(p=0.3),
+            nn.Conv2d(in_c, int(in_c / cube_size[0]), kernel_size=1))
+        self.avgpool = nn.AdaptiveAvgPool1d(1)
+        width = in_c * 2 if self._v5 else in_c
+        self.norm = norm_layer(width)
+        self.out_features = nn.Linear(width, out_c)
+        self.numerics = _mode(numerics)
+
+    def _scale_head(self, t):
+        """t: [B, side*side, C] fp32 tokens of one scale -> [B, C/S]."""
+        B, n, Cc = t.shape
+        side = int(math.isqrt(n))
+        o = side - 1
+        t4 = t.reshape(B, side, side, Cc)
+        # window gather for the 2x2 / stride-1 convolution; element order (c, ky, kx) = the weight's own layout
+        cols = torch.stack([t4[:, ky:ky + o, kx:kx + o, :] for ky in (0, 1) for kx in (0, 1)], dim=-1).reshape(B * o * o, Cc * 4)
+        dt = ops.act_dtype(self.numerics)
+        y = ops.LinearFn.apply(_CastFn.apply(cols, dt), self.aux[0].weight, None, None, torch.float32)
+        y = self.aux[3](self.aux[2](self.aux[1](y.view(B, o, o, Cc).permute(0, 3, 1, 2))))
+        y = y.permute(0, 2, 3, 1).reshape(B * o * o, Cc)
+        y = ops.LinearFn.apply(_CastFn.apply(y, dt), self.aux[4].weight, self.aux[4].bias, None, torch.float32)
+        return ops.GroupMeanFn.apply(y.view(B, o * o, -1), o * o).view(B, -1)
+
+    def forward(self, x):
+        S, side = self.cube_size[0], self.cube_size[1]
+        n = side * side
+        y = torch.cat([self._scale_head(x[:, n * i:n * (i + 1), :]) for i in range(S)], 1)
+        if self._v5:
+            y = torch.cat([y, x[:, n * S:, :].transpose(1, 2).flatten(1)], 1)      # + the designed-feature token; no norm (:412)
+        else:
+            y = ops.LayerNormFn.apply(y, self.norm.weight, self.norm.bias, self.norm.eps, torch.float32)
+        return ops.LinearFn.apply(y, self.out_features.weight, self.out_features.bias, None, torch.float32)
+
+
+class AuxBolck_v5(AuxBolck):
+    """Reference :370-415 (LayerNorm(2C) is registered but never applied upstream; kept for state_dict parity)."""
+    _v5 = True
+
+
+class ShfitScaleFormer_v4(ShfitScaleFormer_v3):
+    """v3 backbone + two auxiliary heads after blocks0 / blocks1 (reference :1013-1261).  Training returns
+    ((x, aux0, aux1), (x, aux0, aux1)); eval returns x.  Three scales / 3 channels, as upstream.
+
+    The two sides run as one batch of 2B through the backbone, but through the aux heads side by side:
+    BatchNorm2d statistics (and their running updates) are per forward_once call upstream."""
+
+    def __init__(self, num_classes=11, is_designed_feature_embedding=True, FeatureEmbed=FeatureEmbed, PatchEmbed=PatchEmbed,
+                 cube_size=[8, 8], input_image_scales=[32, 64, 128], embed_dim=768, depth=[3, 2, 1], num_heads=12,
+                 mlp_ratio=4.0, drop_path_ratio=0., drop_ratio=0., attn_drop_ratio=0., norm_layer=nn.LayerNorm,
+                 act_layer=nn.GELU, cuda=True, numerics=None):
+        if len(input_image_scales) != 3:
+            raise ValueError("v4's auxiliary heads are built for exactly three input scales (reference :1097-1098, :1152)")
+        super().__init__(num_classes=num_classes, is_designed_feature_embedding=is_designed_feature_embedding,
+                         FeatureEmbed=FeatureEmbed, PatchEmbed=PatchEmbed, cube_size=cube_size,
+                         input_image_scales=input_image_scales, embed_dim=embed_dim, depth=depth, num_heads=num_heads,
+                         mlp_ratio=mlp_ratio, drop_path_ratio=drop_path_ratio, drop_ratio=drop_ratio,
+                         attn_drop_ratio=attn_drop_ratio, norm_layer=norm_layer, act_layer=act_layer, cuda=cuda, in_c=3,
+                         numerics=numerics)
+        self.name = "S2Former_v4-3CH" + ("-SFE" if is_designed_feature_embedding else "")
+        self.name = "{0}-{1}{2}{3}".format(self.name, depth[0], depth[1], depth[2])
+        self._build_aux()
+        self.apply(self._init_weights)
+
+    def _build_aux(self):
+        self.aux0 = AuxBolck(numerics=self.numerics)
+        self.aux1 = AuxBolck(cube_size=[3, 4, 4], numerics=self.numerics)
+
+    def _aux(self, head, x, sides):
+        """Aux head per side (None in eval, where upstream discards it and BatchNorm has no side effect)."""
+        if not self.training:
+            return None
+        B = x.shape[0] // sides
+        return [head(x[i * B:(i + 1) * B]) for i in range(sides)]
+
+    def backbone(self, x, sides=1):
+        S, side = self.input_scales_num, self.cube_size[1]
+        x = self.blocks0(x)
+        aux0 = self._aux(self.aux0, x, sides)
+        x = self._ln(ops.TokenPoolFn.apply(x, S, side))
+        x = self.blocks1(x)
+        aux1 = self._aux(self.aux1, x, sides)
+        x = self._ln(ops.TokenPoolFn.apply(x, S, side // 2))
+        return self.blocks2(x), aux0, aux1
+
+    def _encode(self, patches, designed, sides):
+        B2 = patches[0].shape[0]
+        x, aux0, aux1 = self.backbone(self.pos_drop(self.patch_embed(patches)), sides)
+        x = self._ln(x)
+        x = ops.GroupMeanFn.apply(x, x.shape[1] // self.input_scales_num).view(B2, -1)
+        if self.is_designed_feature_embedding:
+            d = torch.squeeze(self.designed_feature_embed(designed), dim=1)
+            x = torch.cat((x, self._ln(d)), 1)
+            w = self.final_features_with_design
+        else:
+            w = self.final_features
+        return ops.LinearFn.apply(x, w.weight, w.bias, None, torch.float32), aux0, aux1
+
+    def forward_once_design_feature(self, x, designed_features):
+        y, aux0, aux1 = self._encode(x, designed_features, 1)
+        return (y, aux0[0], aux1[0]) if self.training else y
+
+    def forward_once(self, x):
+        return self.forward_once_design_feature(x, None)
+
+    def forward(self, x1_patches, x1_designed_features, x2_patches=None, x2_designed_features=None):
+        if not self.training:
+            return self._encode(x1_patches, x1_designed_features, 1)[0]
+        B = x1_patches[0].shape[0]
+        both = [torch.cat((x1_patches[i], x2_patches[i]), 0) for i in range(self.input_scales_num)]
+        d = torch.cat((x1_designed_features, x2_designed_features), 0) if self.is_designed_feature_embedding else None
+        y, aux0, aux1 = self._encode(both, d, 2)
+        return (y[:B], aux0[0], aux1[0]), (y[B:], aux0[1], aux1[1])
+
+
+class ShfitScaleFormer_v5(ShfitScaleFormer_v4):
+    """v4 with the embedded designed features appended to the token cube as one extra TOKEN (N + 1 = 193 at
+    stage 0), carried through both poolings, then `last_block_features` Linear((S+1)C, C) and the final
+    Linear(2C, 100) (reference :1264-1503)."""
+
+    def __init__(self, num_classes=11, FeatureEmbed=FeatureEmbed, PatchEmbed=PatchEmbed, CrossScaleBlock=CrossScaleBlock_v5,
+                 AuxBolck=AuxBolck_v5, cube_size=[8, 8], input_image_scales=[32, 64, 128], embed_dim=768, depth=[3, 2, 1],
+                 num_heads=12, mlp_ratio=4.0, drop_path_ratio=0., drop_ratio=0., attn_drop_ratio=0., norm_layer=nn.LayerNorm,
+                 act_layer=nn.GELU, cuda=True, numerics=None):
+        self._block_cls, self._aux_cls = CrossScaleBlock, AuxBolck
+        super().__init__(num_classes=num_classes, is_designed_feature_embedding=True, FeatureEmbed=FeatureEmbed,
+                         PatchEmbed=PatchEmbed, cube_size=cube_size, input_image_scales=input_image_scales,
+                         embed_dim=embed_dim, depth=depth, num_heads=num_heads, mlp_ratio=mlp_ratio,
+                         drop_path_ratio=drop_path_ratio, drop_ratio=drop_ratio, attn_drop_ratio=attn_drop_ratio,
+                         norm_layer=norm_layer, act_layer=act_layer, cuda=cuda, numerics=numerics)
+        del self.name                                     # upstream v5 has no name attribute
+
+    def _build_aux(self):
+        S, C = self.input_scales_num, self.norm.normalized_shape[0]
+        self.final_features_with_design = nn.Linear(2 * C, 100)
+        self.last_block_features = nn.Linear(int((S + 1) * C), C)
+        head = self.head                                  # keep upstream registration order: ..., last_block_features, head, aux
+        del self.head
+        self.head = head
+        self.aux0 = self._aux_cls(numerics=self.numerics)
+        self.aux1 = self._aux_cls(cube_size=[3, 4, 4], numerics=self.numerics)
+
+    def _pool_keep_last(self, x, side):
+        S = self.input_scales_num
+        n = S * side * side
+        return torch.cat([ops.TokenPoolFn.apply(x[:, :n].contiguous(), S, side), x[:, n:]], 1)
+
+    def backbone(self, x, sides=1):
+        side = self.cube_size[1]
+        x = self.blocks0(x)
+        aux0 = self._aux(self.aux0, x, sides)
+        x = self._ln(self._pool_keep_last(x, side))
+        x = self.blocks1(x)
+        aux1 = self._aux(self.aux1, x, sides)
+        x = self._ln(self._pool_keep_last(x, side // 2))
+        return self.blocks2(x), aux0, aux1
+
+    def _encode(self, patches, designed, sides):
+        if designed is None:
+            raise ValueError("v5 always consumes designed features (upstream forward_once is not runnable: :1464-1478)")
+        S = self.input_scales_num
+        B2 = patches[0].shape[0]
+        f = self._ln(torch.squeeze(self.designed_feature_embed(designed), dim=1))
+        x = torch.cat((self.pos_drop(self.patch_embed(patches)), f.unsqueeze(1)), 1)
+        x, aux0, aux1 = self.backbone(x, sides)
+        x = self._ln(x)
+        n = S * 4
+        y = torch.cat([ops.GroupMeanFn.apply(x[:, :n].contiguous(), 4).view(B2, -1), x[:, n:].mean(dim=1)], 1)
+        y = ops.LinearFn.apply(y, self.last_block_features.weight, self.last_block_features.bias, None, torch.float32)
+        y = torch.cat((y, f), 1)
+        w = self.final_features_with_design
+        return ops.LinearFn.apply(y, w.weight, w.bias, None, torch.float32), aux0, aux1
 
 
 class _SingleStage(nn.Module):

@@ -288,6 +288,59 @@ def gen_variants(S2F, Losses):
     print("model_variants.npz", len(fx))
 
 
+def gen_aux(S2F, Losses):
+    """v4 (aux heads) and v5 (designed-feature token + extended bias table), SURVEY 8a M14 / M15.  Dropout2d in the aux
+    heads is set to p = 0 on the instance (its RNG stream is not reproducible by an independent implementation); everything
+    else, including BatchNorm2d batch statistics and running-statistic updates, is pinned."""
+    fx = {}
+    crit = Losses.Loss(margin=1.0, lamda=0.1, belta=0)
+    scales = [32, 64, 128]
+    for tag, ctor, kw in (("v4_111", S2F.ShfitScaleFormer_v4, dict(is_designed_feature_embedding=True)),
+                          ("v5_111", S2F.ShfitScaleFormer_v5, {})):
+        net = ctor(cube_size=[8, 8], input_image_scales=list(scales), depth=[1, 1, 1], **kw)
+        load_det_weights(net, "")
+        for m in net.modules():
+            if isinstance(m, torch.nn.Dropout2d):
+                m.p = 0.0
+        sd = net.state_dict()
+        fx[tag + "/manifest_keys"] = np.array(list(sd.keys()))
+        fx[tag + "/manifest_shapes"] = np.array([",".join(map(str, v.shape)) for v in sd.values()])
+        fx[tag + "/manifest_dtypes"] = np.array([str(v.dtype).replace("torch.", "") for v in sd.values()])
+        if hasattr(net, "name"):
+            fx[tag + "/name"] = np.array(net.name)
+        fx[tag + "/n_params"] = np.int64(sum(p.numel() for p in net.parameters()))
+        for k, v in sd.items():
+            if k.endswith("relative_position_index"):
+                fx[tag + "/index/" + k] = v.numpy().astype(np.int64)
+        left, ld, right, rd, flag = model_inputs(tag, scales, 3, 4)
+        net.train()
+        (xa, a0a, a1a), (xb, a0b, a1b) = net(left, ld, right, rd)
+        loss = crit(xa, xb, flag) + 0.1 * crit(a0a, a0b, flag) + 0.2 * crit(a1a, a1b, flag)
+        loss.backward()
+        for n_, v in (("out_a", xa), ("out_b", xb), ("aux0_a", a0a), ("aux0_b", a0b), ("aux1_a", a1a), ("aux1_b", a1b)):
+            add(fx, f"{tag}/{n_}", v)
+        fx[tag + "/loss"] = np.float64(loss.item())
+        none = []
+        for n, p in net.named_parameters():
+            if p.grad is None:
+                none.append(n)
+            else:
+                add(fx, tag + "/grad/" + n, p.grad, k=512)
+        fx[tag + "/grad_none"] = np.array(none)
+        for k, v in net.state_dict().items():
+            if "running_" in k:
+                add(fx, tag + "/after/" + k, v, k=768)
+            if k.endswith("num_batches_tracked"):
+                fx[tag + "/after/" + k] = np.int64(v.item())
+        net.eval()
+        with torch.no_grad():
+            ev = net(left, ld)
+        add(fx, tag + "/eval_out", ev)
+        print(tag, "loss", fx[tag + "/loss"], "params", int(fx[tag + "/n_params"]), "none", none)
+    np.savez_compressed(os.path.join(HERE, "model_aux.npz"), **fx)
+    print("model_aux.npz", len(fx))
+
+
 def gen_vit(vit_model, Losses):
     """vit_model.py pair encoders (BASELINE configs[2])."""
     fx = {}
@@ -370,7 +423,7 @@ def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
     S2F, vit_model, Losses = import_reference()
-    which = sys.argv[1:] or ["relpos", "ops", "model", "vit", "variants"]
+    which = sys.argv[1:] or ["relpos", "ops", "model", "vit", "variants", "aux"]
     if "relpos" in which:
         gen_relpos(S2F)
     if "ops" in which:
@@ -381,6 +434,8 @@ def main():
         gen_vit(vit_model, Losses)
     if "variants" in which:
         gen_variants(S2F, Losses)
+    if "aux" in which:
+        gen_aux(S2F, Losses)
 
 
 if __name__ == "__main__":

@@ -23,7 +23,13 @@ def det_weight(name: str, shape) -> np.ndarray:
     shape = tuple(int(s) for s in shape)
     r = _rng(name)
     leaf = name.rsplit(".", 1)[-1]
-    if "relative_position_bias_table" in name:
+    if leaf == "running_var":                       # BatchNorm2d statistics of the v4 / v5 aux heads
+        w = r.uniform(0.5, 1.5, shape)
+    elif leaf == "running_mean":
+        w = r.normal(0.0, 0.1, shape)
+    elif ".aux.1." in name:                         # BatchNorm2d affine
+        w = (1.0 + 0.1 * r.normal(size=shape)) if leaf == "weight" else 0.05 * r.normal(size=shape)
+    elif "relative_position_bias_table" in name:
         w = r.normal(0.0, 0.3, shape)
     elif leaf in ("cls_token", "dist_token") or "pos_embed" in leaf:
         w = r.normal(0.0, 0.05, shape)
