@@ -2,10 +2,9 @@
 
 `Loss` (the one Train_SMT.py uses, Losses.py:12-38) runs forward and gradient in one HIP kernel
 (dm_contrastive_loss).  `MultiLoss` / `ClassLoss` (Losses.py:41-95; unused by the shipped trainer)
-combine it with cross-entropy terms, for which torch's own CE is used (not yet on
-the accelerated path).
+combine it with cross-entropy terms, which run forward + gradient in one HIP kernel too
+(dm_cross_entropy; class-index or class-probability targets).
 """
-import torch.nn.functional as F
 from torch import nn
 
 from . import ops
@@ -26,7 +25,7 @@ class MultiLoss(nn.Module):
         self.margin, self.lamda, self.belta = margin, lamda, belta
 
     def Loss_Class(self, inputs, targets):
-        return F.cross_entropy(inputs, targets)
+        return ops.CrossEntropyFn.apply(inputs, targets)
 
     def forward(self, positive, negative, flag, left_logits, left_one_hot, right_logits, right_one_hot, size_average=True):
         c = ops.ContrastiveLossFn.apply(positive, negative, flag, float(self.margin))
@@ -39,7 +38,7 @@ class ClassLoss(nn.Module):
         self.margin, self.lamda, self.belta = margin, lamda, belta
 
     def Loss_Class(self, inputs, targets):
-        return F.cross_entropy(inputs, targets)
+        return ops.CrossEntropyFn.apply(inputs, targets)
 
     def forward(self, left_logits, left_one_hot, right_logits, right_one_hot, size_average=True):
         return 0.5 * self.Loss_Class(left_logits, left_one_hot) + 0.5 * self.Loss_Class(right_logits, right_one_hot)

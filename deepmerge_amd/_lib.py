@@ -75,6 +75,7 @@ SIGNATURES = {
     "dm_cast": (_I, [_P, _P, _I, _L, _P]),
     "dm_patchify": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "dm_contrastive_loss": (_I, [_P, _P, _P, _F, _F, _P, _P, _P, _I, _I, _P]),
+    "dm_cross_entropy": (_I, [_P, _P, _P, _F, _P, _P, _I, _I, _P]),
     "dm_adam_step": (_I, [_P, _P, _P, _P, _P, _L, _I, _D, _D, _D, _D, _D, _P]),
     "dm_segment_mean": (_I, [_P, _P, _P, _P, _I, _I, _P]),
     "dm_edge_similarity": (_I, [_P, _P, _P, _P, _I, _I, _F, _P]),

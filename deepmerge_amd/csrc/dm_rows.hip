@@ -314,6 +314,51 @@ __global__ __launch_bounds__(256) void contrastive_loss_kernel(const float *__re
 }
 
 // ---------------------------------------------------------------------------------------------
+// cross entropy (nn.CrossEntropyLoss, mean reduction; Losses.py:52-53, :83-84).  Single workgroup: a wave per
+// row, rows reduced in a fixed order.  Targets are class indices (int64) or class probabilities (fp32 [B,K]).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void cross_entropy_kernel(const float *__restrict__ logits, const long long *__restrict__ tidx,
+                                                            const float *__restrict__ tprob, float upstream,
+                                                            float *__restrict__ loss, float *__restrict__ dlogits, int B, int K) {
+  __shared__ float wsum[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float gscale = upstream / (float)B;
+  float acc = 0.f;
+  for (int r = wave; r < B; r += 4) {
+    const float *x = logits + (long long)r * K;
+    float mx = -INFINITY;
+    for (int c = lane; c < K; c += 64) mx = fmaxf(mx, x[c]);
+    mx = dm_wave_max(mx);
+    float se = 0.f;
+    for (int c = lane; c < K; c += 64) se += expf(x[c] - mx);
+    se = dm_wave_sum(se);
+    const float lse = mx + logf(se);
+    float l = 0.f, psum = 0.f;
+    if (tidx) {
+      const long long t = tidx[r];
+      if (lane == 0) l = lse - x[t];
+      psum = 1.f;
+    } else {
+      const float *q = tprob + (long long)r * K;
+      for (int c = lane; c < K; c += 64) { l += q[c] * (lse - x[c]); psum += q[c]; }
+      psum = dm_wave_sum(psum);
+    }
+    acc += dm_wave_sum(l);
+    if (dlogits) {
+      float *g = dlogits + (long long)r * K;
+      for (int c = lane; c < K; c += 64) {
+        const float sm = expf(x[c] - lse);
+        const float tgt = tidx ? ((long long)c == tidx[r] ? 1.f : 0.f) : tprob[(long long)r * K + c];
+        g[c] = (sm * psum - tgt) * gscale;
+      }
+    }
+  }
+  if (lane == 0) wsum[wave] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) loss[0] = ((wsum[0] + wsum[1]) + (wsum[2] + wsum[3])) / (float)B;
+}
+
+// ---------------------------------------------------------------------------------------------
 // Adam (flat buffers).  Operation order follows torch.optim.Adam's single-tensor path.
 // ---------------------------------------------------------------------------------------------
 __global__ void adam_kernel(float *__restrict__ param, const float *__restrict__ grad, float *__restrict__ m,
@@ -496,6 +541,17 @@ extern "C" int dm_patchify(const float *x, void *cols, int32_t dtype, int32_t B,
   else if (dtype == DM_BF16) hipLaunchKernelGGL(patchify_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, s, x, (bf16_t *)cols, B, C, side, p);
   else DM_REQUIRE(false, DM_ERR_BAD_DTYPE, "dm_patchify: bad dtype %d", dtype);
   DM_LAUNCH_CHECK("dm_patchify");
+  return DM_OK;
+}
+
+extern "C" int dm_cross_entropy(const float *logits, const int64_t *target_index, const float *target_prob, float upstream,
+                                float *loss, float *dlogits, int32_t B, int32_t K, void *stream) {
+  DM_REQUIRE(logits && loss && B > 0 && K > 0, DM_ERR_BAD_SHAPE, "dm_cross_entropy: bad arguments");
+  DM_REQUIRE((target_index != nullptr) != (target_prob != nullptr), DM_ERR_BAD_SHAPE,
+             "dm_cross_entropy: exactly one of target_index / target_prob must be given");
+  hipLaunchKernelGGL(cross_entropy_kernel, dim3(1), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), logits,
+                     reinterpret_cast<const long long *>(target_index), target_prob, upstream, loss, dlogits, B, K);
+  DM_LAUNCH_CHECK("dm_cross_entropy");
   return DM_OK;
 }
 

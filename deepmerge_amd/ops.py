@@ -466,6 +466,39 @@ class ContrastiveLossFn(torch.autograd.Function):
         return da * g, db * g, None, None
 
 
+class CrossEntropyFn(torch.autograd.Function):
+    """nn.CrossEntropyLoss (mean) forward and gradient in one kernel (Losses.py:52-53, :83-84).  `target`: int64 class
+    indices [B] or float class probabilities [B,K] (the reference's argument is named *_one_hot)."""
+
+    @staticmethod
+    def forward(ctx, logits, target):
+        _need_cuda(logits, target)
+        x = logits.float().contiguous()
+        B, K = x.shape
+        loss = torch.empty(1, dtype=torch.float32, device=x.device)
+        dl = torch.empty_like(x)
+        if target.dtype.is_floating_point:
+            if target.shape != x.shape:
+                raise ValueError(f"probability targets must be [B,K] = {tuple(x.shape)}, got {tuple(target.shape)}")
+            t = target.float().contiguous()
+            ti, tp = 0, t.data_ptr()
+        else:
+            if target.shape != (B,):
+                raise ValueError(f"index targets must be [B] = ({B},), got {tuple(target.shape)}")
+            t = target.to(torch.int64).contiguous()
+            if B and (int(t.min()) < 0 or int(t.max()) >= K):
+                raise IndexError(f"Target {int(t.max())} is out of bounds.")
+            ti, tp = t.data_ptr(), 0
+        check(_lib.lib().dm_cross_entropy(x.data_ptr(), ti, tp, 1.0, loss.data_ptr(), dl.data_ptr(), B, K, _stream()), "dm_cross_entropy")
+        ctx.save_for_backward(dl)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        (dl,) = ctx.saved_tensors
+        return dl * g, None
+
+
 # ------------------------------------------------------------------------------------------------
 # fused transformer block
 # ------------------------------------------------------------------------------------------------

@@ -175,6 +175,13 @@ int dm_patchify(const float *x, void *cols, int32_t dtype, int32_t B, int32_t C,
 int dm_contrastive_loss(const float *a, const float *b, const float *flag, float margin, float upstream,
                         float *loss, float *da, float *db, int32_t B, int32_t D, void *stream);
 
+/* nn.CrossEntropyLoss, mean reduction (Losses.py:52-53 `MultiLoss.Loss_Class`, :83-84 `ClassLoss.Loss_Class`):
+ * logits fp32 [B,K]; targets either class indices (int64 [B], target_prob NULL) or class probabilities
+ * (fp32 [B,K], target_index NULL).  Writes loss[0] and, if dlogits != NULL, upstream * dloss/dlogits.
+ * Out-of-range class indices are the caller's responsibility (torch raises; this reads out of bounds). */
+int dm_cross_entropy(const float *logits, const int64_t *target_index, const float *target_prob, float upstream,
+                     float *loss, float *dlogits, int32_t B, int32_t K, void *stream);
+
 /* torch.optim.Adam single step over a flat fp32 buffer (Train_SMT.py:192-193, :300): in-place on
  * param/m/v; `step` is 1-based; if param_lp != NULL also writes the bf16 copy of the new weights.
  * grad_scale multiplies the gradient first (1/world_size after an RCCL sum all-reduce).

@@ -341,3 +341,24 @@ def test_contrastive_loss_and_adam():
     np.testing.assert_allclose(md.cpu().numpy(), mr.numpy(), rtol=2e-6, atol=2e-8)
     np.testing.assert_allclose(vd.cpu().numpy(), vr.numpy(), rtol=4e-6, atol=1e-16)
     assert torch.equal(lp.cpu(), pd.cpu().bfloat16())
+
+
+@pytest.mark.parametrize("B,K", [(4, 11), (37, 100), (256, 1000)])
+def test_cross_entropy_matches_torch(B, K):
+    """dm_cross_entropy (MultiLoss / ClassLoss, Losses.py:52-53, :83-84) against torch's CPU float64 CrossEntropyLoss."""
+    ops = _ops()
+    rng = np.random.default_rng(B * 1000 + K)
+    x = torch.from_numpy(rng.normal(0, 3, size=(B, K)).astype(np.float32))
+    ti = torch.from_numpy(rng.integers(0, K, size=B))
+    tp = torch.softmax(torch.from_numpy(rng.normal(size=(B, K)).astype(np.float32)), 1)
+    for tgt in (ti, tp):
+        xr = x.double().requires_grad_(True)
+        want = torch.nn.functional.cross_entropy(xr, tgt.double() if tgt.dtype.is_floating_point else tgt)
+        want.backward()
+        xg = x.to(DEV).requires_grad_(True)
+        got = ops.CrossEntropyFn.apply(xg, tgt.to(DEV))
+        (got * 1.5).backward()
+        assert abs(got.item() - want.item()) <= 2e-6 * abs(want.item())
+        np.testing.assert_allclose(xg.grad.cpu().numpy(), 1.5 * xr.grad.numpy(), rtol=2e-5, atol=1e-8)
+    with pytest.raises(IndexError):
+        ops.CrossEntropyFn.apply(x.to(DEV), torch.full((B,), K, dtype=torch.int64, device=DEV))
