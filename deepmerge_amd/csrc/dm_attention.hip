@@ -11,7 +11,7 @@
 //   backward: two kernels so that no gradient is summed across workgroups:
 //             dq  (rows = queries): P = exp(S - lse), dP = dO V^T, dS = P*(dP - delta),
 //                  dQ = scale * dS K; also delta = rowsum(dO*O) and the bias-table gradient
-//                  binned into an LDS histogram -> one slab row per workgroup;
+//                  summed over the chunk's samples in registers -> one dense [N,N] slab per (chunk, head);
 //             dkv (rows = keys):    P^T, dP^T, dS^T likewise, dV = P^T dO, dK = scale * dS^T Q.
 //
 // Two ideas carry the kernel:
@@ -33,7 +33,6 @@ namespace {
 
 constexpr int HD = 64;         // head dim
 constexpr int QB = 64;         // rows (queries or keys) per workgroup
-constexpr int MAX_BINS = 4096; // LDS histogram capacity (a 4x8x8 cube's table has 1575 rows)
 
 template <typename T> struct AL {
   static constexpr int RB = HD * (int)sizeof(T);       // bytes per 64-d row: 128 / 256
@@ -160,9 +159,8 @@ struct AttnParams {
   float *lse;
   float *delta;
   void *dqkv;
-  const int *index;
   float *slab;
-  int B, N, H, n_bins, nblk, bchunk;
+  int B, N, H, bchunk;
   float scale;
 };
 
@@ -296,7 +294,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnParams p)
   constexpr int IMG = NK * L::RB;
   constexpr int NB = NKT / L::TPB;
   __shared__ __attribute__((aligned(16))) char smem[2 * IMG];
-  extern __shared__ float bins[];     // n_bins + 1 floats (dynamic), only when the bias gradient is wanted
   char *kimg = smem, *vimg = smem + IMG;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, g = lane >> 4, li = lane & 15;
   const int qblk = blockIdx.x, h = blockIdx.y, chunk = blockIdx.z;
@@ -305,11 +302,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnParams p)
   const int q = qblk * QB + wave * 16 + li;
   const bool qok = q < N;
   const float *brows = p.bias ? p.bias + (long long)h * N * N : nullptr;
-  const bool want_bins = p.index != nullptr;
-  const int dummy = p.n_bins;        // out-of-range bins land in one spare LDS slot: no per-element branch
-
-  if (want_bins)
-    for (int i = t; i <= p.n_bins; i += 256) bins[i] = 0.f;
+  const bool want_bins = p.slab != nullptr;
   f32x4 hacc[NKT];
 #pragma unroll
   for (int kt = 0; kt < NKT; ++kt) hacc[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -392,30 +385,21 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnParams p)
     }
   }
 
-  if (want_bins) {
-    // histogram of the chunk's summed dS: bins[index[q][key]] += hacc
-    if (qok) {
+  if (want_bins && qok) {
+    // dense d(bias)[chunk][h][q][key] = the chunk's summed dS; dm_relpos_bias_reduce folds it into the table's
+    // gradient in a fixed order (no atomics anywhere: the bias-table gradient is run-to-run deterministic)
+    float *srow = p.slab + (((long long)chunk * H + h) * N + q) * N;
 #pragma unroll
-      for (int kt = 0; kt < NKT; ++kt) {
-        const int key = kt * 16 + 4 * g;
-        i32x4 iv = {dummy, dummy, dummy, dummy};
-        if constexpr (FAST) {
-          if (key < N) iv = *reinterpret_cast<const i32x4 *>(p.index + (long long)q * N + key);
-        } else {
+    for (int kt = 0; kt < NKT; ++kt) {
+      const int key = kt * 16 + 4 * g;
+      if constexpr (FAST) {
+        if (key < N) dm_store4(srow + key, hacc[kt]);
+      } else {
 #pragma unroll
-          for (int r = 0; r < 4; ++r)
-            if (key + r < N) iv[r] = p.index[(long long)q * N + key + r];
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const unsigned bin = min((unsigned)iv[r], (unsigned)dummy);   // padding / bad indices -> spare slot
-          atomicAdd(&bins[bin], hacc[kt][r]);
-        }
+        for (int r = 0; r < 4; ++r)
+          if (key + r < N) srow[key + r] = hacc[kt][r];
       }
     }
-    __syncthreads();   // all histogram atomics of the workgroup are done
-    float *srow = p.slab + (((long long)chunk * H + h) * p.nblk + qblk) * p.n_bins;
-    for (int i = t; i < p.n_bins; i += 256) srow[i] = bins[i];
   }
 }
 
@@ -523,7 +507,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnParams p
 // ---- dispatch -----------------------------------------------------------------------------------
 template <typename T, int NKT, bool FAST> void launch3(int which, const AttnParams &p, dim3 grid, hipStream_t s) {
   if (which == 0) hipLaunchKernelGGL((attn_fwd_kernel<T, NKT, FAST>), grid, dim3(256), 0, s, p);
-  else if (which == 1) hipLaunchKernelGGL((attn_bwd_dq_kernel<T, NKT, FAST>), grid, dim3(256), p.index ? (p.n_bins + 1) * sizeof(float) : 0, s, p);
+  else if (which == 1) hipLaunchKernelGGL((attn_bwd_dq_kernel<T, NKT, FAST>), grid, dim3(256), 0, s, p);
   else hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, NKT, FAST>), grid, dim3(256), 0, s, p);
 }
 template <typename T, bool FAST> void dispatch_nkt(int which, const AttnParams &p, hipStream_t s) {
@@ -563,7 +547,6 @@ static int batch_chunk(int B, int N, int H) {
   return 1;
 }
 
-extern "C" int32_t dm_attention_bwd_slab_rows(int32_t N) { return (N + QB - 1) / QB; }
 extern "C" int32_t dm_attention_bwd_batch_chunks(int32_t B, int32_t N, int32_t H) {
   const int c = batch_chunk(B, N, H);
   return (B + c - 1) / c;
@@ -588,19 +571,16 @@ extern "C" int dm_attention_fwd(const void *qkv, const float *bias, void *out, f
 }
 
 extern "C" int dm_attention_bwd(const void *qkv, const float *bias, const float *bias_t, const void *out, const void *dout,
-                                const float *lse, void *dqkv, float *delta, const int32_t *index, int32_t n_bins,
-                                float *dtable_slab, int32_t B, int32_t N, int32_t H, int32_t D, float scale, int32_t dtype,
+                                const float *lse, void *dqkv, float *delta, float *dbias_slab, int32_t B, int32_t N, int32_t H, int32_t D, float scale, int32_t dtype,
                                 void *stream) {
   if (int rc = check_common("dm_attention_bwd", B, N, H, D, dtype)) return rc;
   DM_REQUIRE(qkv && out && dout && lse && dqkv && delta, DM_ERR_BAD_SHAPE, "dm_attention_bwd: null pointer");
   DM_REQUIRE(dm_aligned16(qkv) && dm_aligned16(out) && dm_aligned16(dout) && dm_aligned16(dqkv) && dm_aligned16(bias) &&
-             dm_aligned16(bias_t) && dm_aligned16(lse) && dm_aligned16(delta) && dm_aligned16(index), DM_ERR_BAD_ALIGN,
+             dm_aligned16(bias_t) && dm_aligned16(lse) && dm_aligned16(delta) && dm_aligned16(dbias_slab), DM_ERR_BAD_ALIGN,
              "dm_attention_bwd: tensors must be 16-byte aligned");
-  DM_REQUIRE(index == nullptr || (dtable_slab != nullptr && n_bins > 0 && n_bins <= MAX_BINS), DM_ERR_BAD_SHAPE,
-             "dm_attention_bwd: bias gradient needs a slab and 0 < n_bins <= %d (got %d)", MAX_BINS, n_bins);
   AttnParams p{};
   p.qkv = qkv; p.bias = bias; p.bias_t = bias ? bias_t : nullptr; p.out = out; p.dout = dout; p.lse = const_cast<float *>(lse);
-  p.delta = delta; p.dqkv = dqkv; p.index = index; p.slab = dtable_slab; p.n_bins = n_bins; p.nblk = (N + QB - 1) / QB;
+  p.delta = delta; p.dqkv = dqkv; p.slab = dbias_slab;
   p.B = B; p.N = N; p.H = H; p.scale = scale; p.bchunk = batch_chunk(B, N, H);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   {

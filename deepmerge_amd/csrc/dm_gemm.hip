@@ -31,8 +31,11 @@
 #include <cstdlib>
 
 #include "dm_common.h"
+#include "dm_gemm_common.h"
 #include "dm_mfma.h"
 #include "dm_prof.h"
+
+bool dm_gemm256_try(GemmParams &p, int layout, int ab_dtype, hipStream_t s, bool dry_run);   // dm_gemm256.hip
 
 namespace {
 
@@ -49,18 +52,6 @@ constexpr int NTHREADS = 256;
 constexpr int LDS_STAGES = DM_GEMM_LDS_STAGES;
 constexpr int WG_PER_CU = (LDS_STAGES == 1) ? 3 : 2;
 
-struct GemmParams {
-  const void *A, *B;
-  void *C;
-  const float *bias;
-  const float *residual;
-  void *aux;
-  long long lda, ldb, ldc, ldr, ldaux, group_stride;
-  int M, N, K;
-  int epilogue, accumulate, c_dtype, aux_dtype, rows_per_group;
-  int tiles_m, tiles_n, split_k, k_per_split;
-  float *workspace;
-};
 
 // Tile geometry.  TM = 16x16 MFMA tiles per wave per dimension: TM = 4 -> 128x128 workgroup tile, TM = 2 -> 64x64
 // (used when a product has too few 128x128 tiles to fill the chip: the M = 4096 / 1024 stages of the encoder).
@@ -228,10 +219,20 @@ __global__ __launch_bounds__(NTHREADS, (TM == 4 ? WG_PER_CU : 4)) void gemm_kern
 
   const int nwg = gridDim.x;
   int id = dm_xcd_remap(blockIdx.x, nwg);
-  const int tn = id % p.tiles_n;
-  id /= p.tiles_n;
-  const int tm = id % p.tiles_m;
-  const int z = id / p.tiles_m;
+  const int per_z = p.tiles_m * p.tiles_n;
+  const int z = id / per_z;
+  id -= z * per_z;
+  int tm, tn;
+  if (p.group_m > 0) {
+    const int band = id / (p.group_m * p.tiles_n);
+    const int within = id - band * (p.group_m * p.tiles_n);
+    const int gsz = min(p.group_m, p.tiles_m - band * p.group_m);
+    tn = within / gsz;
+    tm = band * p.group_m + (within - tn * gsz);
+  } else {
+    tn = id % p.tiles_n;
+    tm = id / p.tiles_n;
+  }
   const int m0 = tm * TILE, n0 = tn * TILE;
   const int kbeg = z * p.k_per_split;
   const int kend = min(p.K, kbeg + p.k_per_split);
@@ -314,42 +315,12 @@ __global__ __launch_bounds__(NTHREADS, (TM == 4 ? WG_PER_CU : 4)) void gemm_kern
   for (int i = 0; i < TM; ++i) {
     const int m = m0 + wm * WT + i * 16 + li;
     if (m >= p.M) continue;
-    long long rbase_c, rbase_r, rbase_x;
-    if (p.rows_per_group > 0) {
-      const long long grp = m / p.rows_per_group, rr = m % p.rows_per_group;
-      rbase_c = grp * p.group_stride + rr * p.ldc;
-      rbase_r = grp * p.group_stride + rr * p.ldr;
-      rbase_x = grp * p.group_stride + rr * p.ldaux;
-    } else {
-      rbase_c = (long long)m * p.ldc;
-      rbase_r = (long long)m * p.ldr;
-      rbase_x = (long long)m * p.ldaux;
-    }
+    const DmGemmRow rb = dm_gemm_row(p, m);
 #pragma unroll
     for (int j = 0; j < TM; ++j) {
       const int n = n0 + wn * WT + j * 16 + 4 * g;
       if (n >= p.N) continue;   // N % 4 == 0 is enforced by the launcher
-      f32x4 v = acc[i][j];
-      if (p.bias) v += dm_load4(p.bias + n);
-      if (p.epilogue == DM_EPI_GELU) {
-        if (p.aux_dtype == DM_F32) dm_store4(reinterpret_cast<float *>(p.aux) + rbase_x + n, v);
-        else dm_store4(reinterpret_cast<bf16_t *>(p.aux) + rbase_x + n, v);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = (sizeof(T) == 2) ? dm_gelu_fast(v[e]) : dm_gelu(v[e]);
-      } else if (p.epilogue == DM_EPI_DGELU) {
-        f32x4 u = (p.aux_dtype == DM_F32) ? dm_load4(reinterpret_cast<const float *>(p.aux) + rbase_x + n)
-                                          : dm_load4(reinterpret_cast<const bf16_t *>(p.aux) + rbase_x + n);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] *= (sizeof(T) == 2) ? dm_dgelu_fast(u[e]) : dm_dgelu(u[e]);
-      }
-      if (p.residual) v += dm_load4(p.residual + rbase_r + n);
-      if (p.c_dtype == DM_F32) {
-        float *c = reinterpret_cast<float *>(p.C) + rbase_c + n;
-        if (p.accumulate) v += dm_load4(c);
-        dm_store4(c, v);
-      } else {
-        dm_store4(reinterpret_cast<bf16_t *>(p.C) + rbase_c + n, v);
-      }
+      dm_gemm_emit<sizeof(T) == 2>(p, acc[i][j], rb, n);
     }
   }
 }
@@ -541,7 +512,8 @@ extern "C" int dm_gemm(const DmGemmArgs *a, void *stream) {
     return DM_OK;
   }
 
-  const int tile = pick_tile(a->layout, a->M, a->N, a->K);
+  const bool big = dm_gemm256_try(p, a->layout, a->ab_dtype, s, true);   // large forward products: 256x256 LDS-DMA pipeline
+  const int tile = big ? 256 : pick_tile(a->layout, a->M, a->N, a->K);
   p.tiles_m = (a->M + tile - 1) / tile;
   p.tiles_n = (a->N + tile - 1) / tile;
   const int bk = (a->ab_dtype == DM_BF16) ? 64 : 32;
@@ -558,6 +530,10 @@ extern "C" int dm_gemm(const DmGemmArgs *a, void *stream) {
   p.split_k = split;
   p.k_per_split = kps;
   p.workspace = reinterpret_cast<float *>(a->workspace);
+  {
+    static const int forced = [] { const char *e = getenv("DM_GEMM_GROUP_M"); return e ? atoi(e) : -1; }();
+    p.group_m = forced >= 0 ? forced : 8;   // measured over the encoder's step: 8 > 4 > 0 (column-fastest) > 16 > 32, within 2 %
+  }
   const int grid = p.tiles_m * p.tiles_n * split;
   {
     static const char *kNames[2][3] = {{"gemm_f32_NT", "gemm_f32_NN", "gemm_f32_TN"}, {"gemm_bf16_NT", "gemm_bf16_NN", "gemm_bf16_TN"}};
@@ -576,7 +552,9 @@ extern "C" int dm_gemm(const DmGemmArgs *a, void *stream) {
     DmProfScope prof(pname, s, 2.0 * a->M * a->N * a->K,
                      esz * ((double)a->M * a->K + (double)a->N * a->K) + csz * mn * (a->accumulate ? 2.0 : 1.0) +
                          (a->residual ? 4.0 * mn : 0.0) + (a->aux ? ((a->aux_dtype == DM_BF16) ? 2.0 : 4.0) * mn : 0.0));
-    if (a->ab_dtype == DM_BF16) {
+    if (big) {
+      dm_gemm256_try(p, a->layout, a->ab_dtype, s, false);
+    } else if (a->ab_dtype == DM_BF16) {
       if (tile == 128) launch_mfma<bf16_t, 4>(p, a->layout, grid, s); else launch_mfma<bf16_t, 2>(p, a->layout, grid, s);
     } else {
       if (tile == 128) launch_mfma<float, 4>(p, a->layout, grid, s); else launch_mfma<float, 2>(p, a->layout, grid, s);

@@ -406,24 +406,27 @@ __global__ void relpos_gather_kernel(const float *__restrict__ table, const int 
     }
   }
 }
-__global__ __launch_bounds__(256) void relpos_scatter_kernel(const float *__restrict__ slab, float *__restrict__ dtable, int B, int H,
-                                                             int R, int n_bins, int accumulate) {
-  __shared__ float red[4][65];
-  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-  const int bin = blockIdx.x * 64 + tx;
-  const int h = blockIdx.y;
-  float s = 0.f;
-  if (bin < n_bins)
-    for (int i = ty; i < B * R; i += 4) {
-      const int b = i / R, q = i % R;
-      s += slab[(((long long)b * H + h) * R + q) * n_bins + bin];
-    }
-  red[ty][tx] = s;
-  __syncthreads();
-  if (ty == 0 && bin < n_bins) {
-    s = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
+// d(table)[bin][h] = sum over chunks and over the positions (q,key) whose relative_position_index is `bin` of the
+// dense d(bias) slab [chunks][H][N][N].  One wave per (bin, head); `pos` lists the flat positions q*N+key grouped by
+// bin (CSR: off[bin]..off[bin+1]); lanes take items in a fixed interleave and the wave sum is a fixed butterfly.
+__global__ __launch_bounds__(256) void relpos_reduce_kernel(const float *__restrict__ slab, const int *__restrict__ pos,
+                                                            const int *__restrict__ off, float *__restrict__ dtable, int chunks,
+                                                            int H, int N, int n_bins, int accumulate) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int bin = blockIdx.x, h = blockIdx.y * 4 + wave;
+  if (h >= H) return;
+  const int beg = off[bin], cnt = off[bin + 1] - beg;
+  const long long plane = (long long)N * N;
+  float acc = 0.f;
+  for (int c = 0; c < chunks; ++c) {
+    const float *pl = slab + ((long long)c * H + h) * plane;
+#pragma unroll 4
+    for (int j = lane; j < cnt; j += 64) acc += pl[pos[beg + j]];
+  }
+  acc = dm_wave_sum(acc);
+  if (lane == 0) {
     float *o = dtable + (long long)bin * H + h;
-    *o = accumulate ? *o + s : s;
+    *o = accumulate ? *o + acc : acc;
   }
 }
 
@@ -585,10 +588,13 @@ extern "C" int dm_relpos_bias_gather(const float *table, const int32_t *index, f
   DM_LAUNCH_CHECK("dm_relpos_bias_gather");
   return DM_OK;
 }
-extern "C" int dm_relpos_bias_scatter(const float *slab, float *dtable, int32_t B, int32_t H, int32_t rows_per_bh,
-                                      int32_t n_bins, int32_t accumulate, void *stream) {
-  DM_REQUIRE(slab && dtable && B > 0 && H > 0 && rows_per_bh > 0 && n_bins > 0, DM_ERR_BAD_SHAPE, "dm_relpos_bias_scatter: bad arguments");
-  hipLaunchKernelGGL(relpos_scatter_kernel, dim3((n_bins + 63) / 64, H), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), slab, dtable, B, H, rows_per_bh, n_bins, accumulate);
-  DM_LAUNCH_CHECK("dm_relpos_bias_scatter");
+extern "C" int dm_relpos_bias_reduce(const float *dbias_slab, const int32_t *positions, const int32_t *offsets, float *dtable,
+                                     int32_t chunks, int32_t H, int32_t N, int32_t n_bins, int32_t accumulate, void *stream) {
+  DM_REQUIRE(dbias_slab && positions && offsets && dtable && chunks > 0 && H > 0 && N > 0 && n_bins > 0, DM_ERR_BAD_SHAPE,
+             "dm_relpos_bias_reduce: bad arguments");
+  DM_REQUIRE(n_bins <= 65535 * 32, DM_ERR_BAD_SHAPE, "dm_relpos_bias_reduce: too many bins (%d)", n_bins);
+  hipLaunchKernelGGL(relpos_reduce_kernel, dim3(n_bins, (H + 3) / 4), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), dbias_slab,
+                     positions, offsets, dtable, chunks, H, N, n_bins, accumulate);
+  DM_LAUNCH_CHECK("dm_relpos_bias_reduce");
   return DM_OK;
 }

@@ -182,27 +182,52 @@ def attention_fwd(qkv: torch.Tensor, bias: Optional[torch.Tensor], B: int, N: in
     return out, lse
 
 
+_CSR_CACHE = {}
+
+
+def relpos_index_csr(index32: torch.Tensor, n_bins: int):
+    """CSR inverse of a relative_position_index: (positions int32 [<= N*N], offsets int32 [n_bins+1]) with
+    positions[offsets[b]:offsets[b+1]] = the flat entries i*N+j whose index is b, ascending.  Entries outside
+    [0, n_bins) are dropped.  Cached per index tensor (the index is a fixed buffer of the module)."""
+    key = (index32.data_ptr(), index32._version, n_bins, index32.device)
+    hit = _CSR_CACHE.get(key)
+    if hit is None:
+        flat = index32.reshape(-1).to(torch.int64)
+        ok = (flat >= 0) & (flat < n_bins)
+        where = torch.nonzero(ok).reshape(-1)
+        order = torch.argsort(flat[where], stable=True)
+        positions = where[order].to(torch.int32).contiguous()
+        counts = torch.bincount(flat[where], minlength=n_bins)
+        offsets = torch.zeros(n_bins + 1, dtype=torch.int64, device=index32.device)
+        offsets[1:] = torch.cumsum(counts, 0)
+        if len(_CSR_CACHE) > 256:
+            _CSR_CACHE.clear()
+        hit = _CSR_CACHE[key] = (positions, offsets.to(torch.int32).contiguous(), index32)   # keep the index alive: its address is the key
+    return hit[0], hit[1]
+
+
 def attention_bwd(qkv, bias, out, dout, lse, B, N, H, D, scale, index32=None, n_bins=0, bias_t=None):
-    _need_cuda(qkv, out, dout, lse)
+    """Returns (dqkv, dbias_slab or None, info); `info` goes to relpos_bias_scatter with the slab."""
+    _need_cuda(qkv, bias, out, dout, lse, index32, bias_t)
     dqkv = torch.empty_like(qkv)
     delta = torch.empty((B, H, N), dtype=torch.float32, device=qkv.device)
-    slab = None
-    rows = _lib.lib().dm_attention_bwd_slab_rows(N)
-    chunks = _lib.lib().dm_attention_bwd_batch_chunks(B, N, H)
+    slab, info = None, None
     if index32 is not None:
-        slab = torch.empty((chunks * H * rows, n_bins), dtype=torch.float32, device=qkv.device)
+        chunks = _lib.lib().dm_attention_bwd_batch_chunks(B, N, H)
+        slab = torch.empty((chunks, H, N, N), dtype=torch.float32, device=qkv.device)
+        info = (chunks, N, relpos_index_csr(index32, n_bins))
     check(_lib.lib().dm_attention_bwd(qkv.data_ptr(), _ptr(bias), _ptr(bias_t), out.data_ptr(), dout.data_ptr(), lse.data_ptr(), dqkv.data_ptr(),
-                                      delta.data_ptr(), _ptr(index32), n_bins, _ptr(slab), B, N, H, D, scale, _dt(qkv), _stream()),
+                                      delta.data_ptr(), _ptr(slab), B, N, H, D, scale, _dt(qkv), _stream()),
           "dm_attention_bwd")
-    return dqkv, slab, (chunks, rows)
+    return dqkv, slab, info
 
 
-def relpos_bias_scatter(slab, dtable, B, H, rows, n_bins, accumulate=False):
-    """`rows` is the (chunks, rows_per_chunk) pair returned by attention_bwd (B is then ignored)."""
-    if isinstance(rows, tuple):
-        B, rows = rows
-    check(_lib.lib().dm_relpos_bias_scatter(slab.data_ptr(), dtable.data_ptr(), B, H, rows, n_bins, int(accumulate), _stream()),
-          "dm_relpos_bias_scatter")
+def relpos_bias_scatter(slab, dtable, B, H, info, n_bins, accumulate=False):
+    """Fold the dense bias-gradient slab of attention_bwd into d(relative_position_bias_table) [n_bins, H]."""
+    _need_cuda(slab, dtable)
+    chunks, N, (positions, offsets) = info
+    check(_lib.lib().dm_relpos_bias_reduce(slab.data_ptr(), positions.data_ptr(), offsets.data_ptr(), dtable.data_ptr(), chunks, H, N,
+                                           n_bins, int(accumulate), _stream()), "dm_relpos_bias_reduce")
     return dtable
 
 

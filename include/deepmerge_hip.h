@@ -107,20 +107,16 @@ int64_t dm_gemm_workspace_bytes(int32_t layout, int32_t M, int32_t N, int32_t K)
  */
 int dm_attention_fwd(const void *qkv, const float *bias, void *out, float *lse,
                      int32_t B, int32_t N, int32_t H, int32_t D, float scale, int32_t dtype, void *stream);
-/* Backward: dqkv [B,N,3,H,D] T (fully written).  If index != NULL, the gradient of the bias is
- * binned on the fly: dtable_slab[(c*H+h)*n_qblk + qblk][bin] = sum over the samples of batch chunk c
- * of dS over (i,j) with index[i,j] == bin (int32 [N,N], values < n_bins), fp32, fully written:
- * dm_attention_bwd_batch_chunks(B,N,H) * H * dm_attention_bwd_slab_rows(N) rows of n_bins floats;
- * reduce it with dm_relpos_bias_scatter(slab, dtable, chunks, H, rows, ...).  delta is a [B,H,N] fp32 scratch.  bias_t (optional) is the per-head
- * transpose of bias, bias_t[h][key][q], which lets the key-major kernel read the bias with coalesced
- * vector loads; NULL falls back to strided reads of `bias`. */
+/* Backward: dqkv [B,N,3,H,D] T (fully written).  If dbias_slab != NULL the gradient of the dense bias is written
+ * too: dbias_slab[c][h][i][j] = sum over the samples of batch chunk c of dS[b,h,i,j], fp32, fully written,
+ * dm_attention_bwd_batch_chunks(B,N,H) * H * N * N floats; fold it into the table's gradient with
+ * dm_relpos_bias_reduce.  No atomics are used anywhere, so every output is run-to-run deterministic.
+ * delta is a [B,H,N] fp32 scratch.  bias_t (optional) is the per-head transpose of bias, bias_t[h][key][q], which
+ * lets the key-major kernel read the bias with coalesced vector loads; NULL falls back to strided reads of `bias`. */
 int dm_attention_bwd(const void *qkv, const float *bias, const float *bias_t, const void *out, const void *dout,
-                     const float *lse, void *dqkv, float *delta, const int32_t *index, int32_t n_bins,
-                     float *dtable_slab, int32_t B, int32_t N, int32_t H, int32_t D, float scale, int32_t dtype,
-                     void *stream);
-/* Number of slab rows per (chunk,h) that dm_attention_bwd writes (query blocks of 64 rows), and the
- * number of batch chunks it uses for this problem size. */
-int32_t dm_attention_bwd_slab_rows(int32_t N);
+                     const float *lse, void *dqkv, float *delta, float *dbias_slab, int32_t B, int32_t N, int32_t H,
+                     int32_t D, float scale, int32_t dtype, void *stream);
+/* Number of batch chunks dm_attention_bwd uses for this problem size (first dimension of dbias_slab). */
 int32_t dm_attention_bwd_batch_chunks(int32_t B, int32_t N, int32_t H);
 
 /* relative_position_bias_table[index.view(-1)].view(N,N,H).permute(2,0,1)
@@ -128,10 +124,13 @@ int32_t dm_attention_bwd_batch_chunks(int32_t B, int32_t N, int32_t H);
  * if bias_t != NULL, its per-head transpose bias_t[h][j][i] = bias[h][i][j]. */
 int dm_relpos_bias_gather(const float *table, const int32_t *index, float *bias, float *bias_t,
                           int32_t N, int32_t H, int32_t n_bins, void *stream);
-/* Autograd of that gather: dtable[bin,h] (+)= sum over slab rows r (r = (b*H+h)*rows_per_bh + q)
- * of slab[r][bin]. */
-int dm_relpos_bias_scatter(const float *slab, float *dtable, int32_t B, int32_t H, int32_t rows_per_bh,
-                           int32_t n_bins, int32_t accumulate, void *stream);
+/* Autograd of that gather (the index_put the reference's autograd performs for table[index], :123-128):
+ *   dtable[bin,h] (+)= sum_c sum_{(i,j): index[i,j] == bin} dbias_slab[c][h][i][j]
+ * `positions` (int32, flat i*N+j, ascending within a bin) and `offsets` (int32 [n_bins+1]) are the CSR inverse of the
+ * index: positions[offsets[bin] .. offsets[bin+1]) are the entries that read table row `bin`.  Fixed summation
+ * order: deterministic. */
+int dm_relpos_bias_reduce(const float *dbias_slab, const int32_t *positions, const int32_t *offsets, float *dtable,
+                          int32_t chunks, int32_t H, int32_t N, int32_t n_bins, int32_t accumulate, void *stream);
 
 /* ---- row kernels (HBM-bound) ------------------------------------------------------------ */
 /* nn.LayerNorm over the last dim (nets/ShfitScaleFormer.py:182-183, :902, :915, :926, :941;

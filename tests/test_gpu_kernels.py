@@ -362,3 +362,33 @@ def test_cross_entropy_matches_torch(B, K):
         np.testing.assert_allclose(xg.grad.cpu().numpy(), 1.5 * xr.grad.numpy(), rtol=2e-5, atol=1e-8)
     with pytest.raises(IndexError):
         ops.CrossEntropyFn.apply(x.to(DEV), torch.full((B,), K, dtype=torch.int64, device=DEV))
+
+
+@pytest.mark.parametrize("M,N,K", [(4096, 3072, 768), (4000, 3000, 704), (16384, 768, 64), (3968, 3080, 1088)])
+def test_gemm256_pipeline_exact_and_epilogues(M, N, K):
+    """Large bf16 forward products route to the 256x256 LDS-DMA pipeline (dm_gemm256.hip): exact on integer data,
+    ragged M / N edges zero-filled by the descriptor, every fused epilogue."""
+    ops = _ops()
+    from deepmerge_amd._lib import DM_EPI_GELU, DM_NT
+    g = torch.Generator(device=DEV); g.manual_seed(M + N + K)
+    a = torch.randint(-2, 3, (M, K), device=DEV, generator=g).to(torch.bfloat16)
+    b = torch.randint(-2, 3, (N, K), device=DEV, generator=g).to(torch.bfloat16)
+    ref = a.float() @ b.float().T
+    out = torch.empty((M, N), device=DEV, dtype=torch.bfloat16)
+    ops.gemm(DM_NT, a, b, out, M, N, K, lda=K, ldb=K, ldc=N)
+    assert torch.equal(out, ref.to(torch.bfloat16))
+    # bias + fp32 residual + fp32 output (proj / fc2 form)
+    bias = torch.randint(-3, 4, (N,), device=DEV, generator=g).float()
+    res = torch.randint(-5, 6, (M, N), device=DEV, generator=g).float()
+    out32 = torch.empty((M, N), device=DEV)
+    ops.gemm(DM_NT, a, b, out32, M, N, K, lda=K, ldb=K, ldc=N, bias=bias, residual=res)
+    assert torch.equal(out32, ref + bias + res)
+    # bias + GELU with the pre-activation saved (fc1 form)
+    a2 = (a.float() * 0.125).to(torch.bfloat16)
+    pre = torch.empty((M, N), device=DEV, dtype=torch.bfloat16)
+    h = torch.empty((M, N), device=DEV, dtype=torch.bfloat16)
+    ops.gemm(DM_NT, a2, b, h, M, N, K, lda=K, ldb=K, ldc=N, bias=bias, epilogue=DM_EPI_GELU, aux=pre, ldaux=N)
+    want_pre = ref * 0.125 + bias
+    assert torch.equal(pre, want_pre.to(torch.bfloat16))
+    want_h = torch.nn.functional.gelu(want_pre.double()).float()
+    assert float((h.float() - want_h).abs().max()) <= 2.0 ** -7 * float(want_h.abs().max())
