@@ -406,6 +406,16 @@ __global__ void relpos_gather_kernel(const float *__restrict__ table, const int 
     }
   }
 }
+// slab[0][e] = sum_c slab[c][e] in chunk order (coalesced 16-byte accesses); the gather below then works on one plane set
+// that stays L2-resident instead of touching `chunks` scattered cache lines per position.
+__global__ void chunk_sum_kernel(float *__restrict__ slab, long long plane4, int chunks) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < plane4; i += (long long)gridDim.x * blockDim.x) {
+    f32x4 v = dm_load4(slab + 4 * i);
+    for (int c = 1; c < chunks; ++c) v += dm_load4(slab + ((long long)c * plane4 + i) * 4);
+    dm_store4(slab + 4 * i, v);
+  }
+}
+
 // d(table)[bin][h] = sum over chunks and over the positions (q,key) whose relative_position_index is `bin` of the
 // dense d(bias) slab [chunks][H][N][N].  One wave per (bin, head); `pos` lists the flat positions q*N+key grouped by
 // bin (CSR: off[bin]..off[bin+1]); lanes take items in a fixed interleave and the wave sum is a fixed butterfly.
@@ -588,11 +598,17 @@ extern "C" int dm_relpos_bias_gather(const float *table, const int32_t *index, f
   DM_LAUNCH_CHECK("dm_relpos_bias_gather");
   return DM_OK;
 }
-extern "C" int dm_relpos_bias_reduce(const float *dbias_slab, const int32_t *positions, const int32_t *offsets, float *dtable,
+extern "C" int dm_relpos_bias_reduce(float *dbias_slab, const int32_t *positions, const int32_t *offsets, float *dtable,
                                      int32_t chunks, int32_t H, int32_t N, int32_t n_bins, int32_t accumulate, void *stream) {
   DM_REQUIRE(dbias_slab && positions && offsets && dtable && chunks > 0 && H > 0 && N > 0 && n_bins > 0, DM_ERR_BAD_SHAPE,
              "dm_relpos_bias_reduce: bad arguments");
   DM_REQUIRE(n_bins <= 65535 * 32, DM_ERR_BAD_SHAPE, "dm_relpos_bias_reduce: too many bins (%d)", n_bins);
+  const long long plane = (long long)H * N * N;
+  if (chunks > 1 && plane % 4 == 0 && dm_aligned16(dbias_slab)) {
+    hipLaunchKernelGGL(chunk_sum_kernel, dim3(grid_for(plane / 4, 256, 2048)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), dbias_slab,
+                       plane / 4, chunks);
+    chunks = 1;
+  }
   hipLaunchKernelGGL(relpos_reduce_kernel, dim3(n_bins, (H + 3) / 4), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), dbias_slab,
                      positions, offsets, dtable, chunks, H, N, n_bins, accumulate);
   DM_LAUNCH_CHECK("dm_relpos_bias_reduce");

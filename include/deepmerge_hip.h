@@ -128,8 +128,8 @@ int dm_relpos_bias_gather(const float *table, const int32_t *index, float *bias,
  *   dtable[bin,h] (+)= sum_c sum_{(i,j): index[i,j] == bin} dbias_slab[c][h][i][j]
  * `positions` (int32, flat i*N+j, ascending within a bin) and `offsets` (int32 [n_bins+1]) are the CSR inverse of the
  * index: positions[offsets[bin] .. offsets[bin+1]) are the entries that read table row `bin`.  Fixed summation
- * order: deterministic. */
-int dm_relpos_bias_reduce(const float *dbias_slab, const int32_t *positions, const int32_t *offsets, float *dtable,
+ * order: deterministic.  The slab is scratch: its first chunk is overwritten with the sum over chunks. */
+int dm_relpos_bias_reduce(float *dbias_slab, const int32_t *positions, const int32_t *offsets, float *dtable,
                           int32_t chunks, int32_t H, int32_t N, int32_t n_bins, int32_t accumulate, void *stream);
 
 /* ---- row kernels (HBM-bound) ------------------------------------------------------------ */
