@@ -363,7 +363,12 @@ __global__ __launch_bounds__(256) void cross_entropy_kernel(const float *__restr
 // ---------------------------------------------------------------------------------------------
 __global__ void adam_kernel(float *__restrict__ param, const float *__restrict__ grad, float *__restrict__ m,
                             float *__restrict__ v, bf16_t *__restrict__ lp, long long n, float beta1, float beta2,
-                            float omb1, float omb2, float eps, float step_size, float bc2_sqrt, float grad_scale) {
+                            float omb1, float omb2, float eps, float step_size, float bc2_sqrt, float grad_scale,
+                            const float *__restrict__ hyper) {
+  if (hyper) {   // captured in a hipGraph: the step-dependent scalars live in device memory, rewritten before each replay
+    step_size = hyper[0];
+    bc2_sqrt = hyper[1];
+  }
   const long long n4 = n >> 2;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
     f32x4 p = dm_load4(param + 4 * i), g = dm_load4(grad + 4 * i) * grad_scale, mm = dm_load4(m + 4 * i), vv = dm_load4(v + 4 * i);
@@ -586,8 +591,27 @@ extern "C" int dm_adam_step(float *param, const float *grad, float *m, float *v,
   const float bc2_sqrt = (float)sqrt(bc2);
   hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n / 4 + 1)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), param, grad, m, v,
                      (bf16_t *)param_lp, (long long)n, (float)beta1, (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2),
-                     (float)eps, step_size, bc2_sqrt, (float)grad_scale);
+                     (float)eps, step_size, bc2_sqrt, (float)grad_scale, (const float *)nullptr);
   DM_LAUNCH_CHECK("dm_adam_step");
+  return DM_OK;
+}
+
+extern "C" int dm_adam_hyper(int32_t step, double lr, double beta1, double beta2, float *hyper_host) {
+  DM_REQUIRE(step >= 1 && hyper_host, DM_ERR_BAD_SHAPE, "dm_adam_hyper: step is 1-based and hyper_host must be set");
+  hyper_host[0] = (float)(lr / (1.0 - pow(beta1, (double)step)));
+  hyper_host[1] = (float)sqrt(1.0 - pow(beta2, (double)step));
+  return DM_OK;
+}
+
+extern "C" int dm_adam_step_dev(float *param, const float *grad, float *m, float *v, void *param_lp, int64_t n, const float *hyper_dev,
+                                double beta1, double beta2, double eps, double grad_scale, void *stream) {
+  DM_REQUIRE(param && grad && m && v && hyper_dev && n > 0, DM_ERR_BAD_SHAPE, "dm_adam_step_dev: bad arguments");
+  DM_REQUIRE(dm_aligned16(param) && dm_aligned16(grad) && dm_aligned16(m) && dm_aligned16(v) && dm_aligned16(param_lp), DM_ERR_BAD_ALIGN,
+             "dm_adam_step_dev: buffers must be 16-byte aligned");
+  hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n / 4 + 1)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), param, grad, m, v,
+                     (bf16_t *)param_lp, (long long)n, (float)beta1, (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2),
+                     (float)eps, 0.f, 1.f, (float)grad_scale, hyper_dev);
+  DM_LAUNCH_CHECK("dm_adam_step_dev");
   return DM_OK;
 }
 

@@ -265,6 +265,20 @@ def adam_step(param, grad, m, v, step, lr=1e-4, beta1=0.9, beta2=0.999, eps=1e-8
                                   lr, beta1, beta2, eps, grad_scale, _stream()), "dm_adam_step")
 
 
+def adam_hyper(step: int, lr: float, beta1: float = 0.9, beta2: float = 0.999) -> torch.Tensor:
+    """Pinned-host fp32[2] = (lr / (1 - beta1^step), sqrt(1 - beta2^step)) for adam_step_dev."""
+    h = torch.empty(2, dtype=torch.float32).pin_memory() if torch.cuda.is_available() else torch.empty(2, dtype=torch.float32)
+    check(_lib.lib().dm_adam_hyper(step, lr, beta1, beta2, h.data_ptr()), "dm_adam_hyper")
+    return h
+
+
+def adam_step_dev(param, grad, m, v, hyper_dev, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0, param_lp=None):
+    """Adam with the step-dependent scalars read from device memory (capturable in a hipGraph)."""
+    _need_cuda(param, grad, m, v, hyper_dev)
+    check(_lib.lib().dm_adam_step_dev(param.data_ptr(), grad.data_ptr(), m.data_ptr(), v.data_ptr(), _ptr(param_lp), param.numel(),
+                                      hyper_dev.data_ptr(), beta1, beta2, eps, grad_scale, _stream()), "dm_adam_step_dev")
+
+
 def segment_mean(F: torch.Tensor, ptr: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
     _need_cuda(F, ptr, idx)
     S, D = ptr.numel() - 1, F.shape[1]
@@ -527,7 +541,6 @@ class CrossEntropyFn(torch.autograd.Function):
 # ------------------------------------------------------------------------------------------------
 # fused transformer block
 # ------------------------------------------------------------------------------------------------
-_GRAD_LP = {}     # data_ptr of an fp32 gradient -> its bf16 copy written by the producing LayerNorm backward
 
 
 def lp_weight(weight: torch.Tensor, dtype: torch.dtype, shape2d) -> torch.Tensor:
@@ -546,7 +559,7 @@ def _operand_grad(dy: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
     backward already wrote, if there is one."""
     if dy.dtype == dtype and dy.is_contiguous():
         return dy
-    lp = _GRAD_LP.pop(dy.data_ptr(), None)
+    lp = getattr(dy, "_dm_lp_copy", None)      # attached by the BlockFn.backward that produced this very tensor object
     if lp is not None and lp.dtype == dtype and lp.numel() == dy.numel():
         return lp.reshape(dy.shape)
     return _as_operand(dy, dtype)
@@ -619,7 +632,10 @@ class BlockFn(torch.autograd.Function):
         M = B * N
         dtype, dev = y1.dtype, x.device
         lp = dtype != torch.float32
+        lp_copy = getattr(dx2, "_dm_lp_copy", None)
         dx2 = dx2.contiguous().view(M, Cc)
+        if lp_copy is not None:
+            dx2._dm_lp_copy = lp_copy                # (.contiguous() is the same storage; the attribute rides along)
         dy = _operand_grad(dx2, dtype)
         # ---- MLP ---------------------------------------------------------------------------
         dw2, k_w2 = _grad_out(P_fc2_w, (Cc, Hd), dev)
@@ -666,12 +682,12 @@ class BlockFn(torch.autograd.Function):
         if k_n1 != k_n1b:
             dg1, dbt1, k_n1, k_n1b = torch.empty(Cc, device=dev), torch.empty(Cc, device=dev), False, False
         r = layernorm_bwd(dy1, x, n1w, mean1, rstd1, dres=dx1, dgamma=dg1, dbeta=dbt1, accumulate=k_n1, want_lp=lp)
-        dx = r[0]
+        dx = r[0].view(B, N, Cc)
         if lp:
-            if len(_GRAD_LP) > 64:
-                _GRAD_LP.clear()
-            _GRAD_LP[dx.data_ptr()] = r[1]
-        return (dx.view(B, N, Cc), _grad_done(P_n1w, dg1, k_n1), _grad_done(P_n1b, dbt1, k_n1b),
+            # The bf16 copy the LayerNorm backward wrote rides on the tensor object autograd hands to the next node (the
+            # engine preserves the Python object); a consumer that gets some other tensor simply casts.
+            dx._dm_lp_copy = r[1]
+        return (dx, _grad_done(P_n1w, dg1, k_n1), _grad_done(P_n1b, dbt1, k_n1b),
                 _grad_done(P_table, dtable, k_t) if want_table else None, None,
                 _grad_done(P_qkv_w, dwq, k_wq), _grad_done(P_qkv_b, dbq, k_bq),
                 _grad_done(P_proj_w, dwp, k_wp), _grad_done(P_proj_b, dbp, k_bp),

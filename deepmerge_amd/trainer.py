@@ -116,6 +116,8 @@ class PairTrainer:
         self._hooks_installed = False
         if self.world > 1:
             self._install_bucket_hooks()
+        self._graph = None          # captured step (enable_graph)
+        self._graph_warm = 0
 
     # -- gradient exchange -----------------------------------------------------------------------
     def _install_bucket_hooks(self):
@@ -172,10 +174,72 @@ class PairTrainer:
         self._seen.clear()
 
     # -- the step ----------------------------------------------------------------------------------
+    # -- hipGraph replay of the whole step ---------------------------------------------------------
+    def enable_graph(self, warmup: int = 3):
+        """Capture forward + loss + backward + Adam of one step into a hipGraph (torch.cuda.CUDAGraph) after `warmup`
+        eager steps, and replay it afterwards: ~330 launches per step collapse into one submission, which removes the
+        host-side gaps between the many small kernels.  Needs fixed input shapes; single-GPU only (the bucketed
+        exchange of the data-parallel path stays eager)."""
+        if self.world > 1:
+            raise RuntimeError("graph replay covers the single-GPU step; the data-parallel exchange runs eagerly")
+        if self.fp.flat.device.type != "cuda":
+            raise RuntimeError("graph capture needs the parameters on the GPU")
+        self._graph = {"warmup": warmup, "g": None}
+        self._graph_warm = 0
+
+    def _graph_step(self, left, left_designed, right, right_designed, flag, lr):
+        st = self._graph
+        args = (list(left), left_designed, list(right), right_designed, flag)
+        if st["g"] is None:
+            if self._graph_warm < st["warmup"]:           # eager steps first: lazy caches, workspaces, kernel attributes
+                self._graph_warm += 1
+                return self._eager_step(*args, lr)
+            dev = self.fp.flat.device
+            st["left"] = [t.clone() for t in left]
+            st["right"] = [t.clone() for t in right]
+            st["ld"] = None if left_designed is None else left_designed.clone()
+            st["rd"] = None if right_designed is None else right_designed.clone()
+            st["flag"] = flag.clone()
+            st["hyper"] = torch.zeros(2, dtype=torch.float32, device=dev)
+            st["shapes"] = [tuple(t.shape) for t in st["left"] + st["right"]]
+            g = torch.cuda.CUDAGraph()
+            torch.cuda.synchronize()
+            with torch.cuda.graph(g):
+                self.fp.zero_grad()
+                fa, fb = self.net(st["left"], st["ld"], st["right"], st["rd"])
+                loss = self.criterion(fa, fb, st["flag"])
+                loss.backward()
+                extra = {"param_lp": self.fp.flat_lp} if self.fp.flat_lp is not None else {}
+                ops.adam_step_dev(self.fp.flat, self.fp.grad, self.m, self.v, st["hyper"], beta1=self.betas[0], beta2=self.betas[1],
+                                  eps=self.eps, grad_scale=1.0, **extra)
+                st["loss"] = loss.detach()
+            st["g"] = g
+            # capture only records: nothing above has executed yet, the replay below is this step
+        if [tuple(t.shape) for t in list(left) + list(right)] != st["shapes"]:
+            raise ValueError("graph replay needs the input shapes it was captured with; call enable_graph() again for a new batch size")
+        for dst, src in zip(st["left"] + st["right"], list(left) + list(right)):
+            dst.copy_(src, non_blocking=True)
+        if st["ld"] is not None:
+            st["ld"].copy_(left_designed, non_blocking=True)
+            st["rd"].copy_(right_designed, non_blocking=True)
+        st["flag"].copy_(flag, non_blocking=True)
+        self.step_count += 1
+        st["hyper"].copy_(ops.adam_hyper(self.step_count, self.lr if lr is None else lr, self.betas[0], self.betas[1]), non_blocking=True)
+        st["g"].replay()
+        return st["loss"]
+
     def step(self, left: Sequence[torch.Tensor], left_designed, right: Sequence[torch.Tensor], right_designed, flag,
              lr: Optional[float] = None) -> torch.Tensor:
         """forward -> Loss -> zero_grad -> backward -> (all-reduce) -> Adam.  Returns the local loss tensor
-        (no host sync; the reference's per-step `.item()` at Train_SMT.py:301 is left to the caller)."""
+        (no host sync; the reference's per-step `.item()` at Train_SMT.py:301 is left to the caller).
+        After enable_graph() the same work is replayed from a captured hipGraph (the returned tensor is then a
+        static buffer that the next step overwrites)."""
+        if self._graph is not None:
+            self.net.train()
+            return self._graph_step(left, left_designed, right, right_designed, flag, lr)
+        return self._eager_step(left, left_designed, right, right_designed, flag, lr)
+
+    def _eager_step(self, left, left_designed, right, right_designed, flag, lr=None) -> torch.Tensor:
         self.net.train()
         self.fp.zero_grad()
         fa, fb = self.net(left, left_designed, right, right_designed)

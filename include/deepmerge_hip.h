@@ -189,6 +189,13 @@ int dm_cross_entropy(const float *logits, const int64_t *target_index, const flo
 int dm_adam_step(float *param, const float *grad, float *m, float *v, void *param_lp, int64_t n,
                  int32_t step, double lr, double beta1, double beta2, double eps, double grad_scale, void *stream);
 
+/* The same step for use inside a captured hipGraph: the two step-dependent scalars come from device memory,
+ * hyper_dev = {lr / (1 - beta1^step), sqrt(1 - beta2^step)} (fp32[2]), which the host rewrites before each replay;
+ * dm_adam_hyper computes that pair on the host exactly as dm_adam_step does. */
+int dm_adam_hyper(int32_t step, double lr, double beta1, double beta2, float *hyper_host);
+int dm_adam_step_dev(float *param, const float *grad, float *m, float *v, void *param_lp, int64_t n, const float *hyper_dev,
+                     double beta1, double beta2, double eps, double grad_scale, void *stream);
+
 /* ---- ExtractFeatures sweep ---------------------------------------------------------------- */
 /* Per-superpixel mean pooling (ExtractFeatures.py:190-212): F [P,D] fp32, CSR ptr[S+1] / idx[*]
  * (int32) -> pooled [S,D]; rows are added in idx order then divided by the count (np.mean axis 0). */

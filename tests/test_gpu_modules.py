@@ -314,3 +314,31 @@ def test_checkpoint_resume_continues_identically(tmp_path):
             assert torch.allclose(v, v2, rtol=0, atol=2.5e-4), k      # Adam turns a 1-ulp gradient difference into <= 2*lr
         else:
             assert torch.equal(v, v2), k
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+def test_graph_replayed_step_equals_eager_step(mode):
+    """PairTrainer.enable_graph: the captured hipGraph must do exactly what the eager step does (new inputs each step,
+    Adam bias corrections fed from device memory)."""
+    from deepmerge_amd.trainer import PairTrainer
+    tag = "v3_3s3c_111"
+    cfg = MODEL_CASES[tag]
+    batches = []
+    for i in range(5):
+        left, ld, right, rd, flag = model_inputs(f"{tag}", cfg.scales, cfg.in_c, 4)
+        g = torch.Generator().manual_seed(i)
+        left = [t * (0.5 + 0.1 * i) for t in left]
+        right = [t.roll(i, 0) for t in right]
+        batches.append(([t.to(DEV) for t in left], ld.to(DEV), [t.to(DEV) for t in right], rd.to(DEV), flag.roll(i).to(DEV)))
+    nets = [build_model(tag, mode)[1].train() for _ in range(2)]
+    eager, graphed = PairTrainer(nets[0], lr=1e-4), PairTrainer(nets[1], lr=1e-4)
+    graphed.enable_graph(warmup=1)
+    for i, b in enumerate(batches):
+        le = eager.step(*b)
+        lg = graphed.step(*b, lr=None)
+        assert float(le) == float(lg), f"step {i}: loss {float(le)} vs {float(lg)}"
+    assert graphed._graph["g"] is not None and graphed.step_count == eager.step_count == 5
+    assert torch.equal(eager.fp.flat, graphed.fp.flat)
+    assert torch.equal(eager.m, graphed.m) and torch.equal(eager.v, graphed.v)
+    with pytest.raises(ValueError):
+        graphed.step([t[:2] for t in batches[0][0]], batches[0][1][:2], [t[:2] for t in batches[0][2]], batches[0][3][:2], batches[0][4][:2])
