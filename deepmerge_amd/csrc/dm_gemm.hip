@@ -35,7 +35,9 @@
 #include "dm_mfma.h"
 #include "dm_prof.h"
 
-bool dm_gemm256_try(GemmParams &p, int layout, int ab_dtype, hipStream_t s, bool dry_run);   // dm_gemm256.hip
+// dm_gemm256.hip: the 256x256 LDS-DMA pipeline for large bf16 products
+bool dm_gemm256_plan(GemmParams &p, int layout, int ab_dtype, bool can_split, long long workspace_bytes, int user_split);
+void dm_gemm256_launch(const GemmParams &p, int layout, hipStream_t s);
 
 namespace {
 
@@ -512,23 +514,26 @@ extern "C" int dm_gemm(const DmGemmArgs *a, void *stream) {
     return DM_OK;
   }
 
-  const bool big = dm_gemm256_try(p, a->layout, a->ab_dtype, s, true);   // large forward products: 256x256 LDS-DMA pipeline
-  const int tile = big ? 256 : pick_tile(a->layout, a->M, a->N, a->K);
-  p.tiles_m = (a->M + tile - 1) / tile;
-  p.tiles_n = (a->N + tile - 1) / tile;
-  const int bk = (a->ab_dtype == DM_BF16) ? 64 : 32;
-  int split = a->split_k;
   const bool can_split = (a->layout == DM_TN) && a->epilogue == DM_EPI_NONE && !a->bias && !a->residual &&
                          a->c_dtype == DM_F32 && a->rows_per_group == 0 && a->workspace != nullptr;
-  if (split == 0) split = can_split ? choose_split(p.tiles_m * p.tiles_n, a->K, bk) : 1;
-  if (split > 1) {
+  if (a->split_k > 1)
     DM_REQUIRE(can_split, DM_ERR_UNSUPPORTED, "dm_gemm: split_k needs DM_TN, no epilogue, fp32 C and a workspace");
-    while (split > 1 && (int64_t)split * a->M * a->N * 4 > a->workspace_bytes) split >>= 1;
+  const bool big = dm_gemm256_plan(p, a->layout, a->ab_dtype, can_split, a->workspace_bytes, a->split_k);
+  const int tile = big ? 256 : pick_tile(a->layout, a->M, a->N, a->K);
+  int split = p.split_k;
+  if (!big) {
+    p.tiles_m = (a->M + tile - 1) / tile;
+    p.tiles_n = (a->N + tile - 1) / tile;
+    const int bk = (a->ab_dtype == DM_BF16) ? 64 : 32;
+    split = a->split_k;
+    if (split == 0) split = can_split ? choose_split(p.tiles_m * p.tiles_n, a->K, bk) : 1;
+    if (split > 1)
+      while (split > 1 && (int64_t)split * a->M * a->N * 4 > a->workspace_bytes) split >>= 1;
+    int kps = ((a->K + split - 1) / split + bk - 1) / bk * bk;
+    split = (a->K + kps - 1) / kps;
+    p.split_k = split;
+    p.k_per_split = kps;
   }
-  int kps = ((a->K + split - 1) / split + bk - 1) / bk * bk;
-  split = (a->K + kps - 1) / kps;
-  p.split_k = split;
-  p.k_per_split = kps;
   p.workspace = reinterpret_cast<float *>(a->workspace);
   {
     static const int forced = [] { const char *e = getenv("DM_GEMM_GROUP_M"); return e ? atoi(e) : -1; }();
@@ -553,7 +558,7 @@ extern "C" int dm_gemm(const DmGemmArgs *a, void *stream) {
                      esz * ((double)a->M * a->K + (double)a->N * a->K) + csz * mn * (a->accumulate ? 2.0 : 1.0) +
                          (a->residual ? 4.0 * mn : 0.0) + (a->aux ? ((a->aux_dtype == DM_BF16) ? 2.0 : 4.0) * mn : 0.0));
     if (big) {
-      dm_gemm256_try(p, a->layout, a->ab_dtype, s, false);
+      dm_gemm256_launch(p, a->layout, s);
     } else if (a->ab_dtype == DM_BF16) {
       if (tile == 128) launch_mfma<bf16_t, 4>(p, a->layout, grid, s); else launch_mfma<bf16_t, 2>(p, a->layout, grid, s);
     } else {

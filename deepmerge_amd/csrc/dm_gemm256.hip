@@ -1,4 +1,6 @@
-// 256x256x64 bf16 GEMM for the large forward products (NT: y = x W^T, both operands k-contiguous), gfx950.
+// 256x256x64 bf16 GEMM pipeline for the large products of the encoder, gfx950: NT (forward), NN (dgrad) and TN (wgrad,
+// split-K) from one template -- an operand is either k-contiguous (image rows = tile rows, read with ds_read_b128) or
+// m-contiguous (image = 4 bands of [64 k][64 columns], read with the hardware transpose ds_read_b64_tr_b16).
 //
 // Why a second kernel: the 128x128 register-staged tile of dm_gemm.hip tops out near 0.87 PFLOP/s (one barrier
 // per K stage, every wave waits for the whole stage).  This kernel keeps the matrix pipe fed with the structure
@@ -25,7 +27,7 @@
 #include "dm_gemm_common.h"
 #include "dm_mfma.h"
 
-namespace {
+namespace dm256 {
 
 constexpr int T256 = 256;                 // workgroup tile (rows and columns)
 constexpr int BK256 = 64;                 // K per tile
@@ -40,8 +42,97 @@ __device__ __forceinline__ int b_image_to_col(int rho) { return ((rho >> 5) & 3)
 #define DM_LDS_DMA(rsrc, dst, voff, soff) \
   __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void *)(dst), 16, voff, soff, 0, 0)
 
-template <bool FAST>
-__global__ __launch_bounds__(512) void gemm256_nt_kernel(const GemmParams p) {
+// One operand of the pipeline.  MM = false: k-contiguous [rows][K] (A of NT/NN, B of NT); MM = true: m-contiguous [K][cols]
+// (A of TN, B of NN/TN).  IS_B selects the image ordering of the B operand (sub-major, see b_image_to_col).
+template <bool MM, bool IS_B> struct Operand {
+  __amdgpu_buffer_rsrc_t rs;
+  unsigned vo[4];        // per-lane byte offset of DMA piece u (64 image rows, or one 64-column band)
+  unsigned tile_step;    // soffset advance per K tile
+  int frag[4];           // per-lane LDS byte offsets of the fragment reads (see load())
+
+  // base: operand pointer; ld: leading dimension; o0 / extent: first row (column) of this tile and the operand's extent in
+  // that dimension; kbeg / kend: K range of this workgroup.
+  __device__ __forceinline__ void setup(const bf16_t *base, long long ld, int o0, int extent, int kbeg, int kend, int wave, int lane,
+                                        int wrc /* wave row (A) or wave column (B) */) {
+    const int g = lane >> 4, li = lane & 15;
+    if constexpr (!MM) {
+      const bf16_t *pnl = base + (long long)o0 * ld + kbeg;
+      const long long bytes = ((long long)(min(T256, extent - o0) - 1) * ld + (kend - kbeg)) * 2;
+      rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t *>(pnl), 0, (int)min(bytes, 0x7fffffffLL), 0x00020000);
+      // a wave-instruction fills 8 image rows x 128 B; slot s of image row r holds the operand's 16-byte chunk s ^ (r & 7)
+      const int srow = 8 * wave + (lane >> 3);
+      const int chunk = (lane & 7) ^ (lane >> 3);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int img = 64 * u + srow;
+        const int row = IS_B ? b_image_to_col(img) : img;
+        vo[u] = (unsigned)(((long long)row * ld) * 2 + chunk * 16);
+      }
+      tile_step = BK256 * 2;
+      const int sw0 = (g ^ (li & 7)) << 4, sw1 = ((4 + g) ^ (li & 7)) << 4;
+      const int rowb = (IS_B ? wrc * 32 : wrc * 128) + li;
+      frag[0] = rowb * 128 + sw0;
+      frag[1] = rowb * 128 + sw1;
+      frag[2] = frag[3] = 0;
+    } else {
+      const bf16_t *pnl = base + (long long)kbeg * ld + o0;
+      const long long bytes = ((long long)(kend - kbeg - 1) * ld + (extent - o0)) * 2;
+      rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t *>(pnl), 0, (int)min(bytes, 0x7fffffffLL), 0x00020000);
+      // image = 4 bands of [64 k-rows][64 columns = 128 B]; a wave-instruction fills k-rows 8w..8w+7 of one band;
+      // the 32-byte slot index of k-row r is XORed with (r >> 3) & 3 (conflict-free transposed reads)
+      const int krow = 8 * wave + (lane >> 3);
+      const int csrc = (lane & 7) ^ ((wave & 3) << 1);         // source 16-byte chunk of this lane's LDS position
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int col = IS_B ? ((u & 1) * 2 + (csrc >> 2)) * 64 + (u >> 1) * 32 + (csrc & 3) * 8 : u * 64 + csrc * 8;
+        const unsigned kill = (o0 + col < extent) ? 0u : 0x80000000u;      // columns past the operand would alias the next row
+        vo[u] = (unsigned)(((long long)krow * ld + col) * 2) | kill;
+      }
+      tile_step = (unsigned)(BK256 * ld * 2);
+      // transposed read: lane 4q+p of a 16-lane group addresses k-row q, columns 4p..4p+3; group gq covers k = 8gq..8gq+7
+      const int q = li >> 2, pq = li & 3;
+      const int rbase = (8 * g + q) * 128 + 8 * pq;
+      if constexpr (!IS_B) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) frag[i] = rbase + ((i ^ g) << 5);       // m-tile i of the band = 32-byte slot i
+      } else {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) frag[j] = rbase + ((((wrc & 1) * 2 + j) ^ g) << 5);
+        frag[2] = frag[3] = 0;
+      }
+    }
+  }
+  // LDS byte offset (inside an operand image) of DMA piece u for this wave
+  __device__ __forceinline__ static int piece_offset(int u, int wave) { return MM ? u * 8192 + wave * 1024 : (64 * u + 8 * wave) * 128; }
+
+  // fragments of sub-tile `sub` (A: 64 rows = 4 tiles x 2 k-steps -> f[8]; B: 32 columns = 2 tiles x 2 k-steps -> f[4])
+  template <int NT_> __device__ __forceinline__ void load(u32x4 (&f)[2 * NT_], const char *img, int sub, int wrc) const {
+    if constexpr (!MM) {
+      const int stride = IS_B ? 128 : 64;                       // image rows per sub
+#pragma unroll
+      for (int i = 0; i < NT_; ++i) {
+        const char *r = img + (sub * stride + i * 16) * 128;
+        f[2 * i] = *reinterpret_cast<const u32x4 *>(r + frag[0]);
+        f[2 * i + 1] = *reinterpret_cast<const u32x4 *>(r + frag[1]);
+      }
+    } else {
+      const int band = IS_B ? 2 * sub + (wrc >> 1) : 2 * wrc + sub;
+      const char *b = img + band * 8192;
+#pragma unroll
+      for (int i = 0; i < NT_; ++i)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          const u32x2 lo = dm_ds_read_tr16(b + frag[i] + (32 * ks) * 128);
+          const u32x2 hi = dm_ds_read_tr16(b + frag[i] + (32 * ks + 4) * 128);
+          f[2 * i + ks] = (u32x4){lo[0], lo[1], hi[0], hi[1]};
+        }
+    }
+  }
+};
+
+template <int LAYOUT>
+__global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
+  constexpr bool AM = (LAYOUT == DM_TN), BMM = (LAYOUT != DM_NT);
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -50,6 +141,9 @@ __global__ __launch_bounds__(512) void gemm256_nt_kernel(const GemmParams p) {
 
   // ---- tile of this workgroup (XCD-contiguous ids, rows fastest inside bands of group_m row tiles) ----------
   int id = dm_xcd_remap(blockIdx.x, gridDim.x);
+  const int per_z = p.tiles_m * p.tiles_n;
+  const int z = id / per_z;
+  id -= z * per_z;
   int tm, tn;
   if (p.group_m > 0) {
     const int band = id / (p.group_m * p.tiles_n);
@@ -62,37 +156,19 @@ __global__ __launch_bounds__(512) void gemm256_nt_kernel(const GemmParams p) {
     tm = id / p.tiles_n;
   }
   const int m0 = tm * T256, n0 = tn * T256;
+  const int kbeg = z * p.k_per_split, kend = min(p.K, kbeg + p.k_per_split);
+  const int ntile = (kend - kbeg + BK256 - 1) / BK256;
 
-  // ---- descriptors of this tile's row panels (rows past the operand read zero) ------------------------------
-  const bf16_t *A = reinterpret_cast<const bf16_t *>(p.A) + (long long)m0 * p.lda;
-  const bf16_t *B = reinterpret_cast<const bf16_t *>(p.B) + (long long)n0 * p.ldb;
-  const long long bytesA = ((long long)(min(T256, p.M - m0) - 1) * p.lda + p.K) * 2;
-  const long long bytesB = ((long long)(min(T256, p.N - n0) - 1) * p.ldb + p.K) * 2;
-  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t *>(A), 0, (int)min(bytesA, 0x7fffffffLL), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t *>(B), 0, (int)min(bytesB, 0x7fffffffLL), 0x00020000);
+  Operand<AM, false> opA;
+  Operand<BMM, true> opB;
+  opA.setup(reinterpret_cast<const bf16_t *>(p.A), p.lda, m0, p.M, kbeg, kend, wave, lane, wr);
+  opB.setup(reinterpret_cast<const bf16_t *>(p.B), p.ldb, n0, p.N, kbeg, kend, wave, lane, wc);
 
-  // ---- DMA addressing: a wave-instruction fills 8 image rows x 128 B; lane -> (row lane>>3, slot lane&7);
-  //      slot s of image row r holds the operand's 16-byte chunk s ^ (r & 7) -------------------------------------
-  const int srow = 8 * wave + (lane >> 3);
-  const int chunk = (lane & 7) ^ (lane >> 3);
-  unsigned voA[4], voB[4];
-#pragma unroll
-  for (int u = 0; u < 4; ++u) {
-    voA[u] = (unsigned)(((long long)(64 * u + srow) * p.lda) * 2 + chunk * 16);
-    voB[u] = (unsigned)(((long long)b_image_to_col(64 * u + srow) * p.ldb) * 2 + chunk * 16);
-  }
-  const int ntile = p.K / BK256;
   // piece u of the A (which = 0) / B (which = 1) image of K tile kt
   auto stage = [&](int kt, int which, int u) {
-    char *dst = smem + (kt & 1) * BUF_BYTES + which * OPER_BYTES + (64 * u + 8 * wave) * 128;
-    if (which == 0) DM_LDS_DMA(rsA, dst, voA[u], kt * (BK256 * 2));
-    else DM_LDS_DMA(rsB, dst, voB[u], kt * (BK256 * 2));
+    if (which == 0) DM_LDS_DMA(opA.rs, smem + (kt & 1) * BUF_BYTES + opA.piece_offset(u, wave), opA.vo[u], kt * opA.tile_step);
+    else DM_LDS_DMA(opB.rs, smem + (kt & 1) * BUF_BYTES + OPER_BYTES + opB.piece_offset(u, wave), opB.vo[u], kt * opB.tile_step);
   };
-
-  // ---- fragment addressing ----------------------------------------------------------------------------------
-  const int sw0 = ((g) ^ (li & 7)) << 4, sw1 = ((4 + g) ^ (li & 7)) << 4;
-  const int aoff = (wr * 128 + li) * 128;                 // + (sub*64 + i*16) * 128
-  const int boff = OPER_BYTES + (wc * 32 + li) * 128;     // + (sub*128 + j*16) * 128
 
   f32x4 acc[8][4];
 #pragma unroll
@@ -101,22 +177,6 @@ __global__ __launch_bounds__(512) void gemm256_nt_kernel(const GemmParams p) {
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
   u32x4 fa[8], fb0[4], fb1[4];
 
-  auto load_a = [&](const char *buf, int sub) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const char *r = buf + aoff + (sub * 64 + i * 16) * 128;
-      fa[2 * i] = *reinterpret_cast<const u32x4 *>(r + sw0);
-      fa[2 * i + 1] = *reinterpret_cast<const u32x4 *>(r + sw1);
-    }
-  };
-  auto load_b = [&](const char *buf, int sub, u32x4(&fb)[4]) {
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const char *r = buf + boff + (sub * 128 + j * 16) * 128;
-      fb[2 * j] = *reinterpret_cast<const u32x4 *>(r + sw0);
-      fb[2 * j + 1] = *reinterpret_cast<const u32x4 *>(r + sw1);
-    }
-  };
 #define DM_QUAD(MI, NI, FB)                                                                \
   do {                                                                                     \
     __builtin_amdgcn_s_setprio(1);                                                         \
@@ -142,7 +202,7 @@ __global__ __launch_bounds__(512) void gemm256_nt_kernel(const GemmParams p) {
 #pragma unroll
   for (int u = 0; u < 4; ++u) { stage(0, 0, u); stage(0, 1, u); }
   if (ntile > 1) {
-    stage(1, 0, 0); stage(1, 0, 2);      // A sub0 pieces (rows 0-63 of each half)
+    stage(1, 0, 0); stage(1, 0, 2);      // A sub0 pieces
     stage(1, 1, 0); stage(1, 1, 1);      // B sub0
     stage(1, 1, 2); stage(1, 1, 3);      // B sub1
     asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
@@ -153,22 +213,23 @@ __global__ __launch_bounds__(512) void gemm256_nt_kernel(const GemmParams p) {
   if (wr == 1) __builtin_amdgcn_s_barrier();   // the second wave row runs one barrier behind the first
 
   for (int kt = 0; kt < ntile; ++kt) {
-    const char *buf = smem + (kt & 1) * BUF_BYTES;
+    const char *imgA = smem + (kt & 1) * BUF_BYTES;
+    const char *imgB = imgA + OPER_BYTES;
     // phase 0: quadrant (0,0)
-    load_b(buf, 0, fb0);
+    opB.template load<2>(fb0, imgB, 0, wc);
     __builtin_amdgcn_sched_barrier(0);
-    load_a(buf, 0);
+    opA.template load<4>(fa, imgA, 0, wr);
     if (kt + 1 < ntile) { stage(kt + 1, 0, 1); stage(kt + 1, 0, 3); }
     DM_PHASE_SYNC();
     DM_QUAD(0, 0, fb0);
     DM_PHASE_END();
     // phase 1: quadrant (0,1)
-    load_b(buf, 1, fb1);
+    opB.template load<2>(fb1, imgB, 1, wc);
     DM_PHASE_SYNC();
     DM_QUAD(0, 1, fb1);
     DM_PHASE_END();
     // phase 2: quadrant (1,1)
-    load_a(buf, 1);
+    opA.template load<4>(fa, imgA, 1, wr);
     if (kt + 2 < ntile) { stage(kt + 2, 0, 0); stage(kt + 2, 0, 2); stage(kt + 2, 1, 0); stage(kt + 2, 1, 1); }
     DM_PHASE_SYNC();
     DM_QUAD(1, 1, fb1);
@@ -187,6 +248,20 @@ __global__ __launch_bounds__(512) void gemm256_nt_kernel(const GemmParams p) {
   if (wr == 0) __builtin_amdgcn_s_barrier();   // balance the stagger
 
   // ---- epilogue ----------------------------------------------------------------------------------------------
+  if (p.split_k > 1) {          // K slice: fp32 partial tile into the slab, summed in slice order by splitk_reduce_kernel
+    float *W = p.workspace + (long long)z * p.M * p.N;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int m = m0 + wr * 128 + i * 16 + li;
+      if (m >= p.M) continue;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int n = n0 + wc * 64 + j * 16 + 4 * g;
+        if (n < p.N) dm_store4(W + (long long)m * p.N + n, acc[i][j]);
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     const int m = m0 + wr * 128 + i * 16 + li;
@@ -196,34 +271,74 @@ __global__ __launch_bounds__(512) void gemm256_nt_kernel(const GemmParams p) {
     for (int j = 0; j < 4; ++j) {
       const int n = n0 + wc * 64 + j * 16 + 4 * g;
       if (n >= p.N) continue;
-      dm_gemm_emit<FAST>(p, acc[i][j], rb, n);
+      dm_gemm_emit<true>(p, acc[i][j], rb, n);
     }
   }
 }
 
-}  // namespace
+}  // namespace dm256
 
-// Launches the 256x256 pipeline when the product suits it; returns false (nothing launched) otherwise.
-// Called by dm_gemm after argument validation (alignment, N % 4, ...); dry_run only answers the question.
-bool dm_gemm256_try(GemmParams &p, int layout, int ab_dtype, hipStream_t s, bool dry_run) {
-  static const int mode = [] { const char *e = getenv("DM_GEMM_256"); return e ? atoi(e) : 1; }();   // 0 = off (A/B runs)
-  if (mode == 0 || layout != DM_NT || ab_dtype != DM_BF16) return false;
-  if (p.K % BK256 != 0 || p.K < BK256) return false;
-  if (256LL * p.lda * 2 >= (1LL << 31) || 256LL * p.ldb * 2 >= (1LL << 31)) return false;
+namespace {
+template <int LAYOUT> bool set_lds_limit() {
+  return hipFuncSetAttribute(reinterpret_cast<const void *>(dm256::gemm256_kernel<LAYOUT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                             dm256::LDS256) == hipSuccess;
+}
+}  // namespace
+using namespace dm256;
+
+// Decides whether the 256x256 pipeline runs this product and, if so, fills p.tiles_m / tiles_n / split_k / k_per_split.
+// Called by dm_gemm after argument validation (alignment, N % 4, ...).
+bool dm_gemm256_plan(GemmParams &p, int layout, int ab_dtype, bool can_split, long long workspace_bytes, int user_split) {
+  static const int mode = [] { const char *e = getenv("DM_GEMM_256"); return e ? atoi(e) : 1; }();   // 0 = off, 2 = always (A/B runs)
+  if (mode == 0 || ab_dtype != DM_BF16) return false;
+  if (p.K < BK256) return false;
+  const bool am = layout == DM_TN, bm = layout != DM_NT;
+  if ((!am || !bm) && p.K % BK256 != 0) return false;                    // the K tail of k-contiguous rows is not masked
+  if (am && p.M % 8 != 0) return false;                                  // m-contiguous rows are fetched in 16-byte chunks
+  if (bm && p.N % 8 != 0) return false;
+  // 32-bit DMA offsets: a 256-row panel (k-contiguous) or the whole K extent (m-contiguous) of an operand
+  const long long spanA = am ? (long long)p.K * p.lda * 2 : 256LL * p.lda * 2;
+  const long long spanB = bm ? (long long)p.K * p.ldb * 2 : 256LL * p.ldb * 2;
+  if (spanA >= (1LL << 31) || spanB >= (1LL << 31)) return false;
   const int tiles_m = (p.M + T256 - 1) / T256, tiles_n = (p.N + T256 - 1) / T256;
   const long long tiles = (long long)tiles_m * tiles_n;
+  int split = 1;
+  if (layout == DM_TN && can_split && user_split != 1) {
+    // one workgroup per CU: pick the slice count whose tiles * slices fills whole rounds of the 256 CUs best (fewest slices
+    // among the near-best), with >= 8 K tiles per slice and the slab inside the caller's workspace
+    double best = 0.0;
+    for (int sp = 1; sp <= 32; ++sp) {
+      if (sp > 1 && ((long long)p.K / sp < 8 * BK256 || (long long)sp * p.M * p.N * 4 > workspace_bytes)) break;
+      const long long wg = tiles * sp;
+      const double eff = (double)wg / (double)(((wg + 255) / 256) * 256);
+      if (eff > best + 0.04) { best = eff; split = sp; }
+    }
+    if (user_split > 1) split = user_split;
+  }
+  const long long wgs = tiles * split;
   // Measured inside the encoder's step (activations are L2-cold there, unlike a warm microbenchmark): with one workgroup
   // per CU the ~1.5 K tiles of DMA in flight do not cover a first-touch miss, and the 256x256 epilogue cannot overlap
   // another workgroup's main loop.  The pipeline wins when every A panel is re-used by many column tiles (fc1: N = 3072,
-  // +15 %) or when there are several rounds of tiles; narrow products (N = 768 / 2304 at M = 16384) stay on the
+  // +15 %) or when there are several rounds of tiles; narrow forward products (N = 768 / 2304 at M = 16384) stay on the
   // 128x128 kernel, whose 12 waves per CU hide the misses (-20 % otherwise).  mode 2 forces the pipeline (benchmarks).
-  if (mode != 2 && !((tiles_n >= 10 && tiles >= 384) || tiles >= 1024)) return false;
-  static const bool attr_ok = [] {
-    return hipFuncSetAttribute(reinterpret_cast<const void *>(gemm256_nt_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS256) == hipSuccess;
-  }();
+  bool take;
+  if (layout == DM_TN) take = wgs >= 200 && (long long)p.K / split >= 16 * BK256;
+  else take = (tiles_n >= 10 && tiles >= 384) || tiles >= 1024;
+  if (mode == 2) take = true;
+  if (!take) return false;
+  static const bool attr_ok = set_lds_limit<DM_NT>() && set_lds_limit<DM_NN>() && set_lds_limit<DM_TN>();
   if (!attr_ok) return false;
-  if (dry_run) return true;
-  p.tiles_m = tiles_m; p.tiles_n = tiles_n; p.split_k = 1; p.k_per_split = p.K;
-  hipLaunchKernelGGL(gemm256_nt_kernel<true>, dim3((unsigned)tiles), dim3(512), LDS256, s, p);
+  int kps = (int)((((long long)p.K + split - 1) / split + BK256 - 1) / BK256 * BK256);
+  split = (p.K + kps - 1) / kps;
+  p.tiles_m = tiles_m; p.tiles_n = tiles_n; p.split_k = split; p.k_per_split = kps;
   return true;
+}
+
+void dm_gemm256_launch(const GemmParams &p, int layout, hipStream_t s) {
+  const dim3 grid((unsigned)(p.tiles_m * p.tiles_n * p.split_k));
+  switch (layout) {
+    case DM_NT: hipLaunchKernelGGL(dm256::gemm256_kernel<DM_NT>, grid, dim3(512), LDS256, s, p); break;
+    case DM_NN: hipLaunchKernelGGL(dm256::gemm256_kernel<DM_NN>, grid, dim3(512), LDS256, s, p); break;
+    default: hipLaunchKernelGGL(dm256::gemm256_kernel<DM_TN>, grid, dim3(512), LDS256, s, p); break;
+  }
 }
