@@ -45,7 +45,8 @@ __device__ __forceinline__ int b_image_to_col(int rho) { return ((rho >> 5) & 3)
 // One operand of the pipeline.  MM = false: k-contiguous [rows][K] (A of NT/NN, B of NT); MM = true: m-contiguous [K][cols]
 // (A of TN, B of NN/TN).  IS_B selects the image ordering of the B operand (sub-major, see b_image_to_col).
 template <bool MM, bool IS_B> struct Operand {
-  __amdgpu_buffer_rsrc_t rs;
+  const bf16_t *pnl;     // start of this tile's panel and its byte extent (the buffer descriptor is built from these at
+  int nbytes;            // the DMA sites: the descriptor type itself is device-only and cannot be a member here)
   unsigned vo[4];        // per-lane byte offset of DMA piece u (64 image rows, or one 64-column band)
   unsigned tile_step;    // soffset advance per K tile
   int frag[4];           // per-lane LDS byte offsets of the fragment reads (see load())
@@ -56,9 +57,9 @@ template <bool MM, bool IS_B> struct Operand {
                                         int wrc /* wave row (A) or wave column (B) */) {
     const int g = lane >> 4, li = lane & 15;
     if constexpr (!MM) {
-      const bf16_t *pnl = base + (long long)o0 * ld + kbeg;
+      pnl = base + (long long)o0 * ld + kbeg;
       const long long bytes = ((long long)(min(T256, extent - o0) - 1) * ld + (kend - kbeg)) * 2;
-      rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t *>(pnl), 0, (int)min(bytes, 0x7fffffffLL), 0x00020000);
+      nbytes = (int)min(bytes, 0x7fffffffLL);
       // a wave-instruction fills 8 image rows x 128 B; slot s of image row r holds the operand's 16-byte chunk s ^ (r & 7)
       const int srow = 8 * wave + (lane >> 3);
       const int chunk = (lane & 7) ^ (lane >> 3);
@@ -75,13 +76,15 @@ template <bool MM, bool IS_B> struct Operand {
       frag[1] = rowb * 128 + sw1;
       frag[2] = frag[3] = 0;
     } else {
-      const bf16_t *pnl = base + (long long)kbeg * ld + o0;
+      pnl = base + (long long)kbeg * ld + o0;
       const long long bytes = ((long long)(kend - kbeg - 1) * ld + (extent - o0)) * 2;
-      rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t *>(pnl), 0, (int)min(bytes, 0x7fffffffLL), 0x00020000);
-      // image = 4 bands of [64 k-rows][64 columns = 128 B]; a wave-instruction fills k-rows 8w..8w+7 of one band;
-      // the 32-byte slot index of k-row r is XORed with (r >> 3) & 3 (conflict-free transposed reads)
+      nbytes = (int)min(bytes, 0x7fffffffLL);
+      // image = 4 bands of [64 k-rows][64 columns = 128 B]; a wave-instruction fills k-rows 8w..8w+7 of one band.
+      // The 32-byte slot index of k-row r is XORed with f(r) = ((r >> 1) & 1) | (((r >> 3) & 1) << 1): the 8 k-rows a
+      // half-wave of a transposed read touches (r = 8g + q, g in {0,1} or {2,3}, q = 0..3) then cover all 64 banks once.
       const int krow = 8 * wave + (lane >> 3);
-      const int csrc = (lane & 7) ^ ((wave & 3) << 1);         // source 16-byte chunk of this lane's LDS position
+      const int fk = ((krow >> 1) & 1) | (((krow >> 3) & 1) << 1);
+      const int csrc = (lane & 7) ^ (fk << 1);                 // source 16-byte chunk of this lane's LDS position
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int col = IS_B ? ((u & 1) * 2 + (csrc >> 2)) * 64 + (u >> 1) * 32 + (csrc & 3) * 8 : u * 64 + csrc * 8;
@@ -92,12 +95,13 @@ template <bool MM, bool IS_B> struct Operand {
       // transposed read: lane 4q+p of a 16-lane group addresses k-row q, columns 4p..4p+3; group gq covers k = 8gq..8gq+7
       const int q = li >> 2, pq = li & 3;
       const int rbase = (8 * g + q) * 128 + 8 * pq;
+      const int fr = ((q >> 1) & 1) | ((g & 1) << 1);           // f(r) of every k-row this lane addresses (r = 32ks + 8g + q [+4])
       if constexpr (!IS_B) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) frag[i] = rbase + ((i ^ g) << 5);       // m-tile i of the band = 32-byte slot i
+        for (int i = 0; i < 4; ++i) frag[i] = rbase + ((i ^ fr) << 5);      // m-tile i of the band = 32-byte slot i
       } else {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) frag[j] = rbase + ((((wrc & 1) * 2 + j) ^ g) << 5);
+        for (int j = 0; j < 2; ++j) frag[j] = rbase + ((((wrc & 1) * 2 + j) ^ fr) << 5);
         frag[2] = frag[3] = 0;
       }
     }
@@ -164,10 +168,13 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
   opA.setup(reinterpret_cast<const bf16_t *>(p.A), p.lda, m0, p.M, kbeg, kend, wave, lane, wr);
   opB.setup(reinterpret_cast<const bf16_t *>(p.B), p.ldb, n0, p.N, kbeg, kend, wave, lane, wc);
 
-  // piece u of the A (which = 0) / B (which = 1) image of K tile kt
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t *>(opA.pnl), 0, opA.nbytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t *>(opB.pnl), 0, opB.nbytes, 0x00020000);
+  // piece u of the A (which = 0) / B (which = 1) image of K tile kt.  (The int casts matter: with unsigned arguments the
+  // builtin call fails to instantiate in the HOST pass of this template -- silently -- and no launch stub is emitted.)
   auto stage = [&](int kt, int which, int u) {
-    if (which == 0) DM_LDS_DMA(opA.rs, smem + (kt & 1) * BUF_BYTES + opA.piece_offset(u, wave), opA.vo[u], kt * opA.tile_step);
-    else DM_LDS_DMA(opB.rs, smem + (kt & 1) * BUF_BYTES + OPER_BYTES + opB.piece_offset(u, wave), opB.vo[u], kt * opB.tile_step);
+    if (which == 0) DM_LDS_DMA(rsA, smem + (kt & 1) * BUF_BYTES + opA.piece_offset(u, wave), (int)opA.vo[u], (int)(kt * opA.tile_step));
+    else DM_LDS_DMA(rsB, smem + (kt & 1) * BUF_BYTES + OPER_BYTES + opB.piece_offset(u, wave), (int)opB.vo[u], (int)(kt * opB.tile_step));
   };
 
   f32x4 acc[8][4];
@@ -321,8 +328,12 @@ bool dm_gemm256_plan(GemmParams &p, int layout, int ab_dtype, bool can_split, lo
   // another workgroup's main loop.  The pipeline wins when every A panel is re-used by many column tiles (fc1: N = 3072,
   // +15 %) or when there are several rounds of tiles; narrow forward products (N = 768 / 2304 at M = 16384) stay on the
   // 128x128 kernel, whose 12 waves per CU hide the misses (-20 % otherwise).  mode 2 forces the pipeline (benchmarks).
+  // Cold-operand microbenchmark (tools/mb_cold.py, 8 rotating operand sets): NT 98 us vs 113 us (128x128), TN 107 vs 117,
+  // NN 107 vs 103 -- the m-contiguous images lose most of their warm-cache lead, so dgrad only takes the pipeline when
+  // there are many rounds of tiles.
   bool take;
   if (layout == DM_TN) take = wgs >= 200 && (long long)p.K / split >= 16 * BK256;
+  else if (layout == DM_NN) take = tiles >= 1024;
   else take = (tiles_n >= 10 && tiles >= 384) || tiles >= 1024;
   if (mode == 2) take = true;
   if (!take) return false;

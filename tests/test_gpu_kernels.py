@@ -392,3 +392,28 @@ def test_gemm256_pipeline_exact_and_epilogues(M, N, K):
     assert torch.equal(pre, want_pre.to(torch.bfloat16))
     want_h = torch.nn.functional.gelu(want_pre.double()).float()
     assert float((h.float() - want_h).abs().max()) <= 2.0 ** -7 * float(want_h.abs().max())
+
+
+def test_gemm256_pipeline_wgrad_and_dgrad_layouts():
+    """The m-contiguous images of the 256x256 pipeline (hardware-transposed LDS reads): TN with split-K + accumulate
+    (wgrad of a 16384-token stage) and NN with many tiles, exact on integer data and run-to-run identical."""
+    ops = _ops()
+    from deepmerge_amd._lib import DM_NN, DM_TN
+    g = torch.Generator(device=DEV); g.manual_seed(9)
+    K, M, N = 16384, 776, 3072                                   # dy [K, M], x [K, N]; M is ragged against the 256 tile
+    dy = torch.randint(-1, 2, (K, M), device=DEV, generator=g).to(torch.bfloat16)
+    x = torch.randint(-1, 2, (K, N), device=DEV, generator=g).to(torch.bfloat16)
+    g0 = torch.randint(-4, 5, (M, N), device=DEV, generator=g).float()
+    want = g0 + dy.float().T @ x.float()
+    outs = []
+    for _ in range(2):
+        G = g0.clone()
+        ops.gemm(DM_TN, dy, x, G, M, N, K, lda=M, ldb=N, ldc=N, accumulate=True)
+        outs.append(G)
+    assert torch.equal(outs[0], want) and torch.equal(outs[0], outs[1])
+    Mr, Kd, Nd = 16384, 256, 4096                                # dgrad form: dx[Mr, Nd] = dy[Mr, Kd] @ W[Kd, Nd]
+    a = torch.randint(-2, 3, (Mr, Kd), device=DEV, generator=g).to(torch.bfloat16)
+    w = torch.randint(-2, 3, (Kd, Nd), device=DEV, generator=g).to(torch.bfloat16)
+    out = torch.empty((Mr, Nd), device=DEV, dtype=torch.bfloat16)
+    ops.gemm(DM_NN, a, w, out, Mr, Nd, Kd, lda=Kd, ldb=Nd, ldc=Nd)
+    assert torch.equal(out, (a.float() @ w.float()).to(torch.bfloat16))
