@@ -1,0 +1,239 @@
+// Region-adjacency graph and per-superpixel statistics from a label raster (gfx950).  SURVEY 8f rank 2: the step either
+// side of the ExtractFeatures sweep -- the reference reads the edge list (`LEFT_FID`, `RIGHT_FID` of lines.shp,
+// MyUtils2.py:155-193) and the 15 designed attributes (MyUtils1.py:79-114) from files written by external GIS software;
+// this build derives both on the device from the segmentation's label raster and the image tile.  The definitions are
+// the build's own (oracle/rag.py states them; every quantity is an exact integer or a fixed double-precision formula
+// of exact integers, so the GPU and the oracle agree bit for bit).
+//
+// HBM-bound integer work: one pass over the raster per kernel.  A thread walks a 16-pixel strip of one row (one 16-byte
+// load per band, 64 bytes of labels), run-length merges what it finds and flushes once per run, so the number of atomics
+// is ~10x below one per pixel; all atomics are on integers (exact, order-independent => deterministic).
+#include <climits>
+
+#include "dm_common.h"
+
+namespace {
+
+constexpr int STRIP = 16;
+constexpr long long EMPTY_KEY = -1;
+
+__global__ void rag_init_kernel(long long *count, long long *sum, long long *sumsq, int *bbox, long long *peri, int S, int bands3) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= S) return;
+  count[s] = 0;
+  for (int b = 0; b < bands3; ++b) { sum[(long long)s * bands3 + b] = 0; sumsq[(long long)s * bands3 + b] = 0; }
+  bbox[4 * s + 0] = INT_MAX; bbox[4 * s + 1] = INT_MAX; bbox[4 * s + 2] = -1; bbox[4 * s + 3] = -1;
+  peri[2 * s + 0] = 0; peri[2 * s + 1] = 0;
+}
+
+__device__ __forceinline__ void atomic_add64(long long *p, long long v) {
+  atomicAdd(reinterpret_cast<unsigned long long *>(p), (unsigned long long)v);
+}
+
+// Per label: pixel count, per-band sum and sum of squares (first NB <= 3 bands), bounding box, perimeter in pixel edges
+// (peri[2s] = edges shared with another label, peri[2s+1] = edges on the raster border).
+template <int NB>
+__global__ __launch_bounds__(256) void label_stats_kernel(const int *__restrict__ labels, const unsigned char *__restrict__ tile,
+                                                          int H, int W, int S, long long *__restrict__ count,
+                                                          long long *__restrict__ sum, long long *__restrict__ sumsq,
+                                                          int *__restrict__ bbox, long long *__restrict__ peri) {
+  const int strips = (W + STRIP - 1) / STRIP;
+  const long long total = (long long)H * strips;
+  for (long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x; id < total; id += (long long)gridDim.x * blockDim.x) {
+    const int y = (int)(id / strips), x0 = (int)(id % strips) * STRIP;
+    const int n = min(STRIP, W - x0);
+    const int *row = labels + (long long)y * W;
+    int cur = -1, run_x0 = 0;
+    long long c = 0, sm[NB], sq[NB], pin = 0, pbd = 0;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) { sm[b] = 0; sq[b] = 0; }
+    auto flush = [&](int xend) {
+      if (cur < 0 || cur >= S || c == 0) return;
+      atomic_add64(count + cur, c);
+#pragma unroll
+      for (int b = 0; b < NB; ++b) { atomic_add64(sum + (long long)cur * NB + b, sm[b]); atomic_add64(sumsq + (long long)cur * NB + b, sq[b]); }
+      atomicMin(bbox + 4 * cur + 0, run_x0); atomicMin(bbox + 4 * cur + 1, y);
+      atomicMax(bbox + 4 * cur + 2, xend); atomicMax(bbox + 4 * cur + 3, y);
+      if (pin) atomic_add64(peri + 2 * cur, pin);
+      if (pbd) atomic_add64(peri + 2 * cur + 1, pbd);
+    };
+    for (int i = 0; i < n; ++i) {
+      const int x = x0 + i;
+      const int l = row[x];
+      if (l != cur) {
+        flush(x - 1);
+        cur = l; run_x0 = x; c = 0; pin = 0; pbd = 0;
+#pragma unroll
+        for (int b = 0; b < NB; ++b) { sm[b] = 0; sq[b] = 0; }
+      }
+      ++c;
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        const long long v = tile[((long long)b * H + y) * W + x];
+        sm[b] += v; sq[b] += v * v;
+      }
+      // the four pixel edges: raster border, or a different label on the other side
+      if (x == 0) ++pbd; else if (row[x - 1] != l) ++pin;
+      if (x == W - 1) ++pbd; else if (row[x + 1] != l) ++pin;
+      if (y == 0) ++pbd; else if (row[x - W] != l) ++pin;
+      if (y == H - 1) ++pbd; else if (row[x + W] != l) ++pin;
+    }
+    flush(x0 + n - 1);
+  }
+}
+
+// The 15 designed attributes (order of MyUtils1.py:79-114) from the exact integer statistics, in double precision:
+//   area, peri, len, width, smooth, std0, std1, std2, mean0, mean1, mean2, shapeness, compact, bright, border
+__global__ void label_features_kernel(const long long *__restrict__ count, const long long *__restrict__ sum,
+                                      const long long *__restrict__ sumsq, const int *__restrict__ bbox,
+                                      const long long *__restrict__ peri, int S, int nb, float *__restrict__ feat) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= S) return;
+  float *f = feat + (long long)s * 15;
+  const double area = (double)count[s];
+  if (count[s] == 0) {
+    for (int i = 0; i < 15; ++i) f[i] = 0.f;
+    return;
+  }
+  const double pin = (double)peri[2 * s], pbd = (double)peri[2 * s + 1], per = pin + pbd;
+  const double bw = (double)(bbox[4 * s + 2] - bbox[4 * s + 0] + 1), bh = (double)(bbox[4 * s + 3] - bbox[4 * s + 1] + 1);
+  double mean[3] = {0.0, 0.0, 0.0}, sd[3] = {0.0, 0.0, 0.0};
+  for (int b = 0; b < nb; ++b) {
+    const double m = (double)sum[(long long)s * nb + b] / area;
+    const double var = (double)sumsq[(long long)s * nb + b] / area - m * m;
+    mean[b] = m;
+    sd[b] = sqrt(var > 0.0 ? var : 0.0);
+  }
+  f[0] = (float)area;
+  f[1] = (float)per;
+  f[2] = (float)(bw > bh ? bw : bh);
+  f[3] = (float)(bw > bh ? bh : bw);
+  f[4] = (float)(per / (2.0 * (bw + bh)));
+  f[5] = (float)sd[0]; f[6] = (float)sd[1]; f[7] = (float)sd[2];
+  f[8] = (float)mean[0]; f[9] = (float)mean[1]; f[10] = (float)mean[2];
+  f[11] = (float)(per / (4.0 * sqrt(area)));
+  f[12] = (float)(area / (bw * bh));
+  f[13] = (float)((mean[0] + mean[1] + mean[2]) / (double)(nb > 0 ? nb : 1));
+  f[14] = (float)pin;
+}
+
+// ---- adjacency: open-addressing table keyed by a * S + b (a < b), value = number of shared pixel edges --------------------
+__device__ __forceinline__ unsigned long long mix64(unsigned long long k) {
+  k ^= k >> 33; k *= 0xff51afd7ed558ccdULL; k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ULL; k ^= k >> 33;
+  return k;
+}
+__device__ __forceinline__ void table_add(long long *keys, int *cnt, unsigned mask, long long key, int c, int *overflow) {
+  unsigned slot = (unsigned)mix64((unsigned long long)key) & mask;
+  for (unsigned probe = 0; probe <= mask; ++probe) {
+    const long long seen = (long long)atomicCAS(reinterpret_cast<unsigned long long *>(keys + slot), (unsigned long long)EMPTY_KEY,
+                                                (unsigned long long)key);
+    if (seen == EMPTY_KEY || seen == key) {
+      atomicAdd(cnt + slot, c);
+      return;
+    }
+    slot = (slot + 1) & mask;
+    if (probe > 4096) break;
+  }
+  atomicExch(overflow, 1);
+}
+
+__global__ void table_clear_kernel(long long *keys, int *cnt, long long n, int *overflow, int *n_out) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    keys[i] = EMPTY_KEY;
+    cnt[i] = 0;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) { *overflow = 0; *n_out = 0; }
+}
+
+__global__ __launch_bounds__(256) void rag_edges_kernel(const int *__restrict__ labels, int H, int W, int S, long long *__restrict__ keys,
+                                                        int *__restrict__ cnt, unsigned mask, int *__restrict__ overflow) {
+  const int strips = (W + STRIP - 1) / STRIP;
+  const long long total = (long long)H * strips;
+  for (long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x; id < total; id += (long long)gridDim.x * blockDim.x) {
+    const int y = (int)(id / strips), x0 = (int)(id % strips) * STRIP;
+    const int n = min(STRIP, W - x0);
+    const int *row = labels + (long long)y * W;
+    long long run_key = EMPTY_KEY;
+    int run_cnt = 0;
+    auto emit = [&](int a, int b) {
+      if (a == b || a < 0 || b < 0 || a >= S || b >= S) return;
+      const long long key = (long long)min(a, b) * S + max(a, b);
+      if (key == run_key) { ++run_cnt; return; }
+      if (run_cnt) table_add(keys, cnt, mask, run_key, run_cnt, overflow);
+      run_key = key; run_cnt = 1;
+    };
+    for (int i = 0; i < n; ++i) {
+      const int x = x0 + i;
+      const int l = row[x];
+      if (y + 1 < H) emit(l, row[x + W]);          // vertical neighbour first: boundaries running along the row merge into one run
+    }
+    for (int i = 0; i < n; ++i) {
+      const int x = x0 + i;
+      if (x + 1 < W) emit(row[x], row[x + 1]);
+    }
+    if (run_cnt) table_add(keys, cnt, mask, run_key, run_cnt, overflow);
+  }
+}
+
+__global__ void table_compact_kernel(const long long *__restrict__ keys, const int *__restrict__ cnt, long long n,
+                                     long long *__restrict__ out_keys, int *__restrict__ out_cnt, int *__restrict__ n_out, int max_out) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const long long k = keys[i];
+    if (k == EMPTY_KEY) continue;
+    const int pos = atomicAdd(n_out, 1);
+    if (pos < max_out) { out_keys[pos] = k; out_cnt[pos] = cnt[i]; }
+  }
+}
+
+inline int grid_for(long long items, int cap = 8192) {
+  long long g = (items + 255) / 256;
+  return (int)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+}  // namespace
+
+extern "C" int dm_label_stats(const int32_t *labels, const uint8_t *tile, int32_t bands, int32_t H, int32_t W, int32_t S,
+                              int64_t *count, int64_t *sum, int64_t *sumsq, int32_t *bbox, int64_t *peri, void *stream) {
+  DM_REQUIRE(labels && tile && count && sum && sumsq && bbox && peri, DM_ERR_BAD_SHAPE, "dm_label_stats: null pointer");
+  DM_REQUIRE(H > 0 && W > 0 && S > 0 && bands >= 1, DM_ERR_BAD_SHAPE, "dm_label_stats: bad sizes (H=%d W=%d S=%d bands=%d)", H, W, S, bands);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const int nb = bands < 3 ? bands : 3;
+  hipLaunchKernelGGL(rag_init_kernel, dim3((S + 255) / 256), dim3(256), 0, s, (long long *)count, (long long *)sum, (long long *)sumsq, bbox,
+                     (long long *)peri, S, nb);
+  const long long items = (long long)H * ((W + STRIP - 1) / STRIP);
+  const dim3 grid(grid_for(items));
+  switch (nb) {
+    case 1: hipLaunchKernelGGL(label_stats_kernel<1>, grid, dim3(256), 0, s, labels, tile, H, W, S, (long long *)count, (long long *)sum, (long long *)sumsq, bbox, (long long *)peri); break;
+    case 2: hipLaunchKernelGGL(label_stats_kernel<2>, grid, dim3(256), 0, s, labels, tile, H, W, S, (long long *)count, (long long *)sum, (long long *)sumsq, bbox, (long long *)peri); break;
+    default: hipLaunchKernelGGL(label_stats_kernel<3>, grid, dim3(256), 0, s, labels, tile, H, W, S, (long long *)count, (long long *)sum, (long long *)sumsq, bbox, (long long *)peri); break;
+  }
+  DM_LAUNCH_CHECK("dm_label_stats");
+  return DM_OK;
+}
+
+extern "C" int dm_label_features(const int64_t *count, const int64_t *sum, const int64_t *sumsq, const int32_t *bbox, const int64_t *peri,
+                                 int32_t S, int32_t bands, float *features, void *stream) {
+  DM_REQUIRE(count && sum && sumsq && bbox && peri && features && S > 0 && bands >= 1, DM_ERR_BAD_SHAPE, "dm_label_features: bad arguments");
+  hipLaunchKernelGGL(label_features_kernel, dim3((S + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), (const long long *)count,
+                     (const long long *)sum, (const long long *)sumsq, bbox, (const long long *)peri, S, bands < 3 ? bands : 3, features);
+  DM_LAUNCH_CHECK("dm_label_features");
+  return DM_OK;
+}
+
+extern "C" int dm_rag_edges(const int32_t *labels, int32_t H, int32_t W, int32_t S, int64_t *table_keys, int32_t *table_counts,
+                            int32_t capacity_log2, int64_t *edge_keys, int32_t *edge_counts, int32_t max_edges, int32_t *n_edges,
+                            int32_t *overflow, void *stream) {
+  DM_REQUIRE(labels && table_keys && table_counts && edge_keys && edge_counts && n_edges && overflow, DM_ERR_BAD_SHAPE, "dm_rag_edges: null pointer");
+  DM_REQUIRE(H > 0 && W > 0 && S > 0 && capacity_log2 >= 8 && capacity_log2 <= 30 && max_edges > 0, DM_ERR_BAD_SHAPE,
+             "dm_rag_edges: bad sizes (H=%d W=%d S=%d capacity_log2=%d)", H, W, S, capacity_log2);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const long long cap = 1LL << capacity_log2;
+  hipLaunchKernelGGL(table_clear_kernel, dim3(grid_for(cap, 2048)), dim3(256), 0, s, (long long *)table_keys, table_counts, cap, overflow, n_edges);
+  const long long items = (long long)H * ((W + STRIP - 1) / STRIP);
+  hipLaunchKernelGGL(rag_edges_kernel, dim3(grid_for(items)), dim3(256), 0, s, labels, H, W, S, (long long *)table_keys, table_counts,
+                     (unsigned)(cap - 1), overflow);
+  hipLaunchKernelGGL(table_compact_kernel, dim3(grid_for(cap, 2048)), dim3(256), 0, s, (const long long *)table_keys, table_counts, cap,
+                     (long long *)edge_keys, edge_counts, n_edges, max_edges);
+  DM_LAUNCH_CHECK("dm_rag_edges");
+  return DM_OK;
+}

@@ -218,6 +218,29 @@ int dm_edge_similarity(const float *pooled, const int32_t *edges, float *simi, u
 int dm_patch_pyramid(const uint8_t *tile, int32_t bands, int32_t H, int32_t W, const int32_t *xy, const int32_t *windows,
                      int32_t max_window, int32_t P, int32_t target, float *out, void *stream);
 
+/* ---- region-adjacency graph + superpixel statistics from a label raster ---------------------------
+ * Replaces, on the device, the inputs the reference reads from files written by external GIS software: the RAG edge
+ * list (`LEFT_FID` / `RIGHT_FID` of lines.shp, MyUtils2.py:155-193, consumed at ExtractFeatures.py:188-219) and the 15
+ * designed attributes (MyUtils1.py:79-114).  The definitions are this build's (oracle/rag.py); all results are exact
+ * integers or fixed double-precision formulas of exact integers.
+ *   labels int32 [H,W] (superpixel id, ids outside [0,S) are ignored); tile uint8 [bands,H,W].
+ * dm_label_stats: count[S], sum / sumsq [S, min(bands,3)] (int64), bbox int32 [S,4] = xmin,ymin,xmax,ymax
+ *   (INT_MAX,INT_MAX,-1,-1 for an id that never occurs), peri int64 [S,2] = pixel edges shared with another label /
+ *   lying on the raster border.  All outputs are (re)initialised by the call.
+ * dm_label_features: float32 [S,15] = area, peri, len, width, smooth, std0..2, mean0..2, shapeness, compact, bright,
+ *   border (the attribute order of MyUtils1.py:79-114).
+ * dm_rag_edges: unique unordered 4-neighbour label pairs a < b as keys a*S+b with the number of shared pixel edges.
+ *   table_keys / table_counts: scratch of 2^capacity_log2 entries (int64 / int32); edge_keys / edge_counts: up to
+ *   max_edges results in ARBITRARY order (sort by key for a canonical list); n_edges[0] = number found (may exceed
+ *   max_edges: then the output is truncated); overflow[0] = 1 if the table was too small. */
+int dm_label_stats(const int32_t *labels, const uint8_t *tile, int32_t bands, int32_t H, int32_t W, int32_t S,
+                   int64_t *count, int64_t *sum, int64_t *sumsq, int32_t *bbox, int64_t *peri, void *stream);
+int dm_label_features(const int64_t *count, const int64_t *sum, const int64_t *sumsq, const int32_t *bbox, const int64_t *peri,
+                      int32_t S, int32_t bands, float *features, void *stream);
+int dm_rag_edges(const int32_t *labels, int32_t H, int32_t W, int32_t S, int64_t *table_keys, int32_t *table_counts,
+                 int32_t capacity_log2, int64_t *edge_keys, int32_t *edge_counts, int32_t max_edges, int32_t *n_edges,
+                 int32_t *overflow, void *stream);
+
 /* ---- optional in-library kernel timing ------------------------------------------------------
  * While enabled, the GEMM and attention entry points bracket their main kernel with hipEvents on
  * the caller's stream.  dm_prof_collect waits for the recorded events, aggregates them per kernel
