@@ -32,7 +32,7 @@ __device__ __forceinline__ void atomic_add64(long long *p, long long v) {
 
 // Per label: pixel count, per-band sum and sum of squares (first NB <= 3 bands), bounding box, perimeter in pixel edges
 // (peri[2s] = edges shared with another label, peri[2s+1] = edges on the raster border).
-template <int NB>
+template <int NB, bool VEC>
 __global__ __launch_bounds__(256) void label_stats_kernel(const int *__restrict__ labels, const unsigned char *__restrict__ tile,
                                                           int H, int W, int S, long long *__restrict__ count,
                                                           long long *__restrict__ sum, long long *__restrict__ sumsq,
@@ -43,6 +43,38 @@ __global__ __launch_bounds__(256) void label_stats_kernel(const int *__restrict_
     const int y = (int)(id / strips), x0 = (int)(id % strips) * STRIP;
     const int n = min(STRIP, W - x0);
     const int *row = labels + (long long)y * W;
+    // strip registers: this row's labels with one neighbour on each side, the rows above / below, the bands' bytes
+    int lab[STRIP + 2], up[STRIP], dn[STRIP];
+    unsigned char px[NB][STRIP];
+    if (VEC && n == STRIP) {
+#pragma unroll
+      for (int v = 0; v < STRIP / 4; ++v) {
+        const i32x4 a = *reinterpret_cast<const i32x4 *>(row + x0 + 4 * v);
+        const i32x4 u = (y > 0) ? *reinterpret_cast<const i32x4 *>(row - W + x0 + 4 * v) : (i32x4){-2, -2, -2, -2};
+        const i32x4 d = (y + 1 < H) ? *reinterpret_cast<const i32x4 *>(row + W + x0 + 4 * v) : (i32x4){-2, -2, -2, -2};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { lab[1 + 4 * v + e] = a[e]; up[4 * v + e] = u[e]; dn[4 * v + e] = d[e]; }
+      }
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        const u32x4 q = *reinterpret_cast<const u32x4 *>(tile + ((long long)b * H + y) * W + x0);
+#pragma unroll
+        for (int e = 0; e < STRIP; ++e) px[b][e] = (unsigned char)(q[e >> 2] >> (8 * (e & 3)));
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < STRIP; ++i) {
+        const bool in = i < n;
+        lab[1 + i] = in ? row[x0 + i] : -2;
+        up[i] = (in && y > 0) ? row[x0 + i - W] : -2;
+        dn[i] = (in && y + 1 < H) ? row[x0 + i + W] : -2;
+#pragma unroll
+        for (int b = 0; b < NB; ++b) px[b][i] = in ? tile[((long long)b * H + y) * W + x0 + i] : 0;
+      }
+    }
+    lab[0] = (x0 > 0) ? row[x0 - 1] : -2;                     // -2 = outside the raster
+    lab[STRIP + 1] = (x0 + STRIP < W) ? row[x0 + STRIP] : -2;
+    if (n < STRIP) lab[1 + n] = (x0 + n < W) ? row[x0 + n] : -2;
     int cur = -1, run_x0 = 0;
     long long c = 0, sm[NB], sq[NB], pin = 0, pbd = 0;
 #pragma unroll
@@ -57,9 +89,11 @@ __global__ __launch_bounds__(256) void label_stats_kernel(const int *__restrict_
       if (pin) atomic_add64(peri + 2 * cur, pin);
       if (pbd) atomic_add64(peri + 2 * cur + 1, pbd);
     };
-    for (int i = 0; i < n; ++i) {
+#pragma unroll
+    for (int i = 0; i < STRIP; ++i) {
+      if (i >= n) break;
       const int x = x0 + i;
-      const int l = row[x];
+      const int l = lab[1 + i];
       if (l != cur) {
         flush(x - 1);
         cur = l; run_x0 = x; c = 0; pin = 0; pbd = 0;
@@ -69,14 +103,15 @@ __global__ __launch_bounds__(256) void label_stats_kernel(const int *__restrict_
       ++c;
 #pragma unroll
       for (int b = 0; b < NB; ++b) {
-        const long long v = tile[((long long)b * H + y) * W + x];
+        const long long v = px[b][i];
         sm[b] += v; sq[b] += v * v;
       }
-      // the four pixel edges: raster border, or a different label on the other side
-      if (x == 0) ++pbd; else if (row[x - 1] != l) ++pin;
-      if (x == W - 1) ++pbd; else if (row[x + 1] != l) ++pin;
-      if (y == 0) ++pbd; else if (row[x - W] != l) ++pin;
-      if (y == H - 1) ++pbd; else if (row[x + W] != l) ++pin;
+      // the four pixel edges: raster border (-2), or a different label on the other side
+      const int nbr[4] = {lab[i], lab[2 + i], up[i], dn[i]};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (nbr[e] == -2) ++pbd; else if (nbr[e] != l) ++pin;
+      }
     }
     flush(x0 + n - 1);
   }
@@ -145,6 +180,7 @@ __global__ void table_clear_kernel(long long *keys, int *cnt, long long n, int *
   if (blockIdx.x == 0 && threadIdx.x == 0) { *overflow = 0; *n_out = 0; }
 }
 
+template <bool VEC>
 __global__ __launch_bounds__(256) void rag_edges_kernel(const int *__restrict__ labels, int H, int W, int S, long long *__restrict__ keys,
                                                         int *__restrict__ cnt, unsigned mask, int *__restrict__ overflow) {
   const int strips = (W + STRIP - 1) / STRIP;
@@ -153,6 +189,24 @@ __global__ __launch_bounds__(256) void rag_edges_kernel(const int *__restrict__ 
     const int y = (int)(id / strips), x0 = (int)(id % strips) * STRIP;
     const int n = min(STRIP, W - x0);
     const int *row = labels + (long long)y * W;
+    int lab[STRIP + 1], dn[STRIP];
+    if (VEC && n == STRIP) {
+#pragma unroll
+      for (int v = 0; v < STRIP / 4; ++v) {
+        const i32x4 a = *reinterpret_cast<const i32x4 *>(row + x0 + 4 * v);
+        const i32x4 d = (y + 1 < H) ? *reinterpret_cast<const i32x4 *>(row + W + x0 + 4 * v) : (i32x4){-2, -2, -2, -2};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { lab[4 * v + e] = a[e]; dn[4 * v + e] = d[e]; }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < STRIP; ++i) {
+        lab[i] = (i < n) ? row[x0 + i] : -2;
+        dn[i] = (i < n && y + 1 < H) ? row[x0 + i + W] : -2;
+      }
+    }
+    lab[STRIP] = (x0 + STRIP < W) ? row[x0 + STRIP] : -2;
+    if (n < STRIP) lab[n] = (x0 + n < W) ? row[x0 + n] : -2;
     long long run_key = EMPTY_KEY;
     int run_cnt = 0;
     auto emit = [&](int a, int b) {
@@ -162,15 +216,12 @@ __global__ __launch_bounds__(256) void rag_edges_kernel(const int *__restrict__ 
       if (run_cnt) table_add(keys, cnt, mask, run_key, run_cnt, overflow);
       run_key = key; run_cnt = 1;
     };
-    for (int i = 0; i < n; ++i) {
-      const int x = x0 + i;
-      const int l = row[x];
-      if (y + 1 < H) emit(l, row[x + W]);          // vertical neighbour first: boundaries running along the row merge into one run
-    }
-    for (int i = 0; i < n; ++i) {
-      const int x = x0 + i;
-      if (x + 1 < W) emit(row[x], row[x + 1]);
-    }
+#pragma unroll
+    for (int i = 0; i < STRIP; ++i)
+      if (i < n) emit(lab[i], dn[i]);                // vertical neighbours first: a boundary running along the row is one run
+#pragma unroll
+    for (int i = 0; i < STRIP; ++i)
+      if (i < n) emit(lab[i], lab[i + 1]);           // (ids < 0, incl. the -2 "outside" marker, are dropped by emit)
     if (run_cnt) table_add(keys, cnt, mask, run_key, run_cnt, overflow);
   }
 }
@@ -202,11 +253,21 @@ extern "C" int dm_label_stats(const int32_t *labels, const uint8_t *tile, int32_
                      (long long *)peri, S, nb);
   const long long items = (long long)H * ((W + STRIP - 1) / STRIP);
   const dim3 grid(grid_for(items));
+  // 16-byte strip loads need W % 16 == 0 and 16-byte aligned rasters
+  const bool vec = (W % STRIP == 0) && dm_aligned16(labels) && dm_aligned16(tile);
+#define DM_STATS(NB_)                                                                                                                      \
+  do {                                                                                                                                     \
+    if (vec) hipLaunchKernelGGL((label_stats_kernel<NB_, true>), grid, dim3(256), 0, s, labels, tile, H, W, S, (long long *)count,        \
+                                (long long *)sum, (long long *)sumsq, bbox, (long long *)peri);                                           \
+    else hipLaunchKernelGGL((label_stats_kernel<NB_, false>), grid, dim3(256), 0, s, labels, tile, H, W, S, (long long *)count,           \
+                            (long long *)sum, (long long *)sumsq, bbox, (long long *)peri);                                               \
+  } while (0)
   switch (nb) {
-    case 1: hipLaunchKernelGGL(label_stats_kernel<1>, grid, dim3(256), 0, s, labels, tile, H, W, S, (long long *)count, (long long *)sum, (long long *)sumsq, bbox, (long long *)peri); break;
-    case 2: hipLaunchKernelGGL(label_stats_kernel<2>, grid, dim3(256), 0, s, labels, tile, H, W, S, (long long *)count, (long long *)sum, (long long *)sumsq, bbox, (long long *)peri); break;
-    default: hipLaunchKernelGGL(label_stats_kernel<3>, grid, dim3(256), 0, s, labels, tile, H, W, S, (long long *)count, (long long *)sum, (long long *)sumsq, bbox, (long long *)peri); break;
+    case 1: DM_STATS(1); break;
+    case 2: DM_STATS(2); break;
+    default: DM_STATS(3); break;
   }
+#undef DM_STATS
   DM_LAUNCH_CHECK("dm_label_stats");
   return DM_OK;
 }
@@ -230,8 +291,12 @@ extern "C" int dm_rag_edges(const int32_t *labels, int32_t H, int32_t W, int32_t
   const long long cap = 1LL << capacity_log2;
   hipLaunchKernelGGL(table_clear_kernel, dim3(grid_for(cap, 2048)), dim3(256), 0, s, (long long *)table_keys, table_counts, cap, overflow, n_edges);
   const long long items = (long long)H * ((W + STRIP - 1) / STRIP);
-  hipLaunchKernelGGL(rag_edges_kernel, dim3(grid_for(items)), dim3(256), 0, s, labels, H, W, S, (long long *)table_keys, table_counts,
-                     (unsigned)(cap - 1), overflow);
+  if (W % STRIP == 0 && dm_aligned16(labels))
+    hipLaunchKernelGGL(rag_edges_kernel<true>, dim3(grid_for(items)), dim3(256), 0, s, labels, H, W, S, (long long *)table_keys, table_counts,
+                       (unsigned)(cap - 1), overflow);
+  else
+    hipLaunchKernelGGL(rag_edges_kernel<false>, dim3(grid_for(items)), dim3(256), 0, s, labels, H, W, S, (long long *)table_keys, table_counts,
+                       (unsigned)(cap - 1), overflow);
   hipLaunchKernelGGL(table_compact_kernel, dim3(grid_for(cap, 2048)), dim3(256), 0, s, (const long long *)table_keys, table_counts, cap,
                      (long long *)edge_keys, edge_counts, n_edges, max_edges);
   DM_LAUNCH_CHECK("dm_rag_edges");
