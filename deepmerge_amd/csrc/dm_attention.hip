@@ -27,6 +27,7 @@
 //      fetched in the same permuted order (rows 4g+16*half+q of the transposed read).
 #include "dm_common.h"
 #include "dm_mfma.h"
+#include "dm_attention_pipe.h"
 #include "dm_prof.h"
 
 namespace {
@@ -564,7 +565,14 @@ extern "C" int dm_attention_fwd(const void *qkv, const float *bias, void *out, f
     const double esz = (dtype == DM_BF16) ? 2.0 : 4.0;
     DmProfScope prof(dtype == DM_BF16 ? "attn_fwd_bf16" : "attn_fwd_f32", s, 4.0 * B * H * (double)N * N * HD,
                      esz * 4.0 * B * H * (double)N * HD);
-    if (dtype == DM_BF16) dispatch<bf16_t>(0, p, s); else dispatch<float>(0, p, s);
+    bool piped = false;
+    if (dtype == DM_BF16) {      // persistent LDS-DMA pipeline for the big stage (dm_attention_pipe.hip)
+      AttnPipeParams pp{qkv, bias, out, lse, B, N, H, scale};
+      piped = dm_attn_fwd_pipe(pp, s);
+    }
+    if (!piped) {
+      if (dtype == DM_BF16) dispatch<bf16_t>(0, p, s); else dispatch<float>(0, p, s);
+    }
   }
   DM_LAUNCH_CHECK("dm_attention_fwd");
   return DM_OK;

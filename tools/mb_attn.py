@@ -1,0 +1,17 @@
+"""Attention forward / backward timing at the encoder's stage-0 shape (B samples x 12 heads x N tokens, bf16, with bias)."""
+import os, sys, time
+import torch
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+from deepmerge_amd import ops
+dev = "cuda:0"
+B, N, H, D = int(os.environ.get("B", 64)), int(os.environ.get("N", 256)), 12, 64
+g = torch.Generator(device=dev); g.manual_seed(0)
+qkv = torch.randn((B, N, 3, H, D), device=dev, generator=g).to(torch.bfloat16)
+bias = torch.randn((H, N, N), device=dev, generator=g) * 0.3
+def timeit(f, n=30):
+    for _ in range(3): f()
+    torch.cuda.synchronize(); t = time.perf_counter()
+    for _ in range(n): f()
+    torch.cuda.synchronize(); return (time.perf_counter() - t) / n
+t = timeit(lambda: ops.attention_fwd(qkv, bias, B, N, H, D, 0.125))
+print(f"fwd B={B} N={N}: {t*1e6:7.1f} us  {4.0*B*H*N*N*D/t/1e12:6.1f} TFLOP/s")
