@@ -59,7 +59,7 @@ SIGNATURES = {
     "dm_gemm_workspace_bytes": (_L, [_I, _I, _I, _I]),
     "dm_attention_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _P]),
     "dm_attention_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _P]),
-    "dm_attention_bwd_batch_chunks": (_I, [_I, _I, _I]),
+    "dm_attention_bwd_batch_chunks": (_I, [_I, _I, _I, _I]),
     "dm_relpos_bias_gather": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
     "dm_relpos_bias_reduce": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "dm_layernorm_fwd": (_I, [_P, _P, _P, _P, _I, _P, _P, _I, _I, _F, _P]),

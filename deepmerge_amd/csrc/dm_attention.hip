@@ -548,7 +548,8 @@ static int batch_chunk(int B, int N, int H) {
   return 1;
 }
 
-extern "C" int32_t dm_attention_bwd_batch_chunks(int32_t B, int32_t N, int32_t H) {
+extern "C" int32_t dm_attention_bwd_batch_chunks(int32_t B, int32_t N, int32_t H, int32_t dtype) {
+  if (const int pc = dm_attn_bwd_pipe_chunks(B, N, H, dtype == DM_BF16)) return pc;     // pipelined kernels (dm_attention_pipe.hip)
   const int c = batch_chunk(B, N, H);
   return (B + c - 1) / c;
 }
@@ -595,8 +596,15 @@ extern "C" int dm_attention_bwd(const void *qkv, const float *bias, const float 
     const double esz = (dtype == DM_BF16) ? 2.0 : 4.0;
     DmProfScope prof(dtype == DM_BF16 ? "attn_bwd_bf16" : "attn_bwd_f32", s, 10.0 * B * H * (double)N * N * HD,
                      esz * 8.0 * B * H * (double)N * HD);
-    if (dtype == DM_BF16) { dispatch<bf16_t>(1, p, s); dispatch<bf16_t>(2, p, s); }
-    else { dispatch<float>(1, p, s); dispatch<float>(2, p, s); }
+    bool piped = false;
+    if (dtype == DM_BF16) {
+      AttnPipeBwdParams pp{qkv, bias, out, dout, lse, delta, dqkv, dbias_slab, B, N, H, scale};
+      piped = dm_attn_bwd_pipe(pp, s);
+    }
+    if (!piped) {
+      if (dtype == DM_BF16) { dispatch<bf16_t>(1, p, s); dispatch<bf16_t>(2, p, s); }
+      else { dispatch<float>(1, p, s); dispatch<float>(2, p, s); }
+    }
   }
   DM_LAUNCH_CHECK("dm_attention_bwd");
   return DM_OK;

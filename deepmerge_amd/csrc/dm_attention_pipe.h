@@ -13,3 +13,21 @@ struct AttnPipeParams {
 
 // true if the pipelined forward kernel took the call (bf16, N a multiple of 16 in [128, 256]); false: nothing launched
 bool dm_attn_fwd_pipe(const AttnPipeParams &p, hipStream_t s);
+
+struct AttnPipeBwdParams {
+  const void *qkv;      // [B, N, 3, H, 64] bf16
+  const float *bias;    // [H, N, N] fp32 or NULL
+  const void *out;      // [B, N, H*64] bf16 (forward output)
+  const void *dout;     // [B, N, H*64] bf16
+  const float *lse;     // [B, H, N]
+  float *delta;         // [B, H, N] scratch: written by the dQ kernel, read by the dK/dV kernel
+  void *dqkv;           // [B, N, 3, H, 64] bf16, fully written
+  float *slab;          // [chunks, H, N, N] fp32 or NULL: sum over the chunk's samples of dS
+  int B, N, H;
+  float scale;
+};
+
+// Number of batch chunks the pipelined backward uses (first dimension of `slab`); 0 if it does not take this shape.
+int dm_attn_bwd_pipe_chunks(int B, int N, int H, int dtype_is_bf16);
+// true if the pipelined dQ and dK/dV kernels took the call
+bool dm_attn_bwd_pipe(const AttnPipeBwdParams &p, hipStream_t s);

@@ -176,19 +176,350 @@ __global__ __launch_bounds__(512) void attn_fwd_pipe_kernel(const AttnPipeParams
   write_back(b1 - 1);
 }
 
+// =============================================================================================================================
+// backward.  Same skeleton as the forward kernel; all LDS images here are "dual-use" (row fragments for the QK^T-like
+// products, hardware-transposed fragments for the contractions over tokens): 16-byte chunk index XOR s(row),
+// s = ((t1^t2)<<2 | t0<<1 | t1), t = row >> 1 -- the image layout of dm_attention.hip, filled by DMA here.
+// =============================================================================================================================
+__device__ __forceinline__ int dual_swz(int row) {
+  const int t0 = (row >> 1) & 1, t1 = (row >> 2) & 1, t2 = (row >> 3) & 1;
+  return ((t1 ^ t2) << 2) | (t0 << 1) | t1;
+}
+
+// Per-lane constants of the two fragment kinds (see frag_row / frag_tr in dm_attention.hip).
+struct FragAddr {
+  int row[2];     // row fragment of tile row `li`, 64-byte block ks: + tile * 2048
+  int tr[4];      // transposed fragment of d-tile dt: + (32 * m + 16 * half) * 128
+  __device__ __forceinline__ void init(int lane) {
+    const int g = lane >> 4, li = lane & 15;
+    const int sl = dual_swz(li);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) row[ks] = li * 128 + (((ks * 4 + g) ^ sl) << 4);
+    const int qq = (lane >> 2) & 3, pp = lane & 3;
+    const int k = 4 * g + qq;                      // + 32 m + 16 half: does not change the swizzle bits
+    const int sk = dual_swz(k);
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) tr[dt] = k * 128 + (((2 * dt + (pp >> 1)) ^ sk) << 4) + (pp & 1) * 8;
+  }
+};
+__device__ __forceinline__ u32x4 read_row(const char *img, const FragAddr &fa, int tile, int ks) {
+  return *reinterpret_cast<const u32x4 *>(img + tile * 2048 + fa.row[ks]);
+}
+__device__ __forceinline__ u32x4 read_tr(const char *img, const FragAddr &fa, int m, int dt) {
+  const u32x2 lo = dm_ds_read_tr16(img + (32 * m) * 128 + fa.tr[dt]);
+  const u32x2 hi = dm_ds_read_tr16(img + (32 * m + 16) * 128 + fa.tr[dt]);
+  return (u32x4){lo[0], lo[1], hi[0], hi[1]};
+}
+__device__ __forceinline__ u32x4 pack2(const f32x4 &a, const f32x4 &b) {
+  const bf16x8 r = {(bf16_t)a[0], (bf16_t)a[1], (bf16_t)a[2], (bf16_t)a[3], (bf16_t)b[0], (bf16_t)b[1], (bf16_t)b[2], (bf16_t)b[3]};
+  return __builtin_bit_cast(u32x4, r);
+}
+// sum over the 8 bf16 pairs of two fragments
+__device__ __forceinline__ float dot8(const u32x4 &x, const u32x4 &y) {
+  const bf16x8 a = __builtin_bit_cast(bf16x8, x), b = __builtin_bit_cast(bf16x8, y);
+  float acc = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc += (float)a[i] * (float)b[i];
+  return acc;
+}
+
+// ---- dQ (rows of the workgroup are queries) ---------------------------------------------------------------------------------
+template <int NKT>
+__global__ __launch_bounds__(512) void attn_bwd_dq_pipe_kernel(const AttnPipeBwdParams p, int bchunk) {
+  constexpr int N = NKT * 16;
+  constexpr int IMG = N * 128;
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 buffers][K image | V image]
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int g = lane >> 4, li = lane & 15;
+  const int h = blockIdx.x, rb = blockIdx.y, chunk = blockIdx.z;
+  const int H = p.H;
+  const int b0 = chunk * bchunk, b1 = min(p.B, b0 + bchunk);
+  if (b0 >= b1) return;
+  const int q = rb * ROWS + wave * 16 + li;
+  const bool wave_live = rb * ROWS + wave * 16 < N;
+  const long long tok_stride = 3LL * H * HD;
+  const bf16_t *qkv = reinterpret_cast<const bf16_t *>(p.qkv);
+  const bf16_t *outp = reinterpret_cast<const bf16_t *>(p.out);
+  const bf16_t *dout = reinterpret_cast<const bf16_t *>(p.dout);
+  FragAddr fa;
+  fa.init(lane);
+
+  f32x4 bias[NKT];
+#pragma unroll
+  for (int kt = 0; kt < NKT; ++kt) bias[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  if (p.bias && wave_live) {
+    const float *brow = p.bias + ((long long)h * N + q) * N + 4 * g;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) bias[kt] = dm_load4(brow + 16 * kt);
+  }
+
+  const int dkey = lane >> 3;
+  auto stage = [&](int b, int buf) {
+    const bf16_t *base = qkv + (long long)b * N * tok_stride + (long long)h * HD;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t *>(base), 0, (int)(N * tok_stride * 2), 0x00020000);
+    char *kimg = smem + buf * (2 * IMG), *vimg = kimg + IMG;
+#pragma unroll
+    for (int j = 0; j < NKT / 4; ++j) {
+      const int inst = wave + 8 * j;
+      if (inst < N / 8) {
+        const int row = 8 * inst + dkey;
+        const unsigned src = (unsigned)(row * tok_stride * 2) + (unsigned)((((lane & 7) ^ dual_swz(row))) * 16);
+        DM_LDS_DMA(rs, kimg + inst * 1024, src + (unsigned)(1 * H * HD * 2), 0);
+        DM_LDS_DMA(rs, vimg + inst * 1024, src + (unsigned)(2 * H * HD * 2), 0);
+      }
+    }
+  };
+  // per-sample register inputs of this lane's query row: Q, dO, O fragments (d = 8g..8g+7 and 32+8g..) and lse
+  auto load_rows = [&](int b, u32x4 (&fq)[2], u32x4 (&fdo)[2], u32x4 (&fo)[2], float &lse) {
+    const bf16_t *qrow = qkv + ((long long)b * N + q) * tok_stride + (long long)h * HD;
+    const long long orow = ((long long)b * N + q) * H * HD + (long long)h * HD;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int c = (4 * ks + g) * 8;
+      fq[ks] = wave_live ? *reinterpret_cast<const u32x4 *>(qrow + c) : (u32x4){0u, 0u, 0u, 0u};
+      fdo[ks] = wave_live ? *reinterpret_cast<const u32x4 *>(dout + orow + c) : (u32x4){0u, 0u, 0u, 0u};
+      fo[ks] = wave_live ? *reinterpret_cast<const u32x4 *>(outp + orow + c) : (u32x4){0u, 0u, 0u, 0u};
+    }
+    lse = wave_live ? p.lse[((long long)b * H + h) * N + q] : 0.f;
+  };
+
+  u32x4 fq[2], fdo[2], fo[2], fq_n[2], fdo_n[2], fo_n[2];
+  float lse = 0.f, lse_n = 0.f;
+  f32x4 o_prev[4];
+  float delta_prev = 0.f;
+  auto write_back = [&](int b) {
+    if (!wave_live) return;
+    bf16_t *dq = reinterpret_cast<bf16_t *>(p.dqkv) + ((long long)b * N + q) * tok_stride + (long long)h * HD;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) dm_store4(dq + dt * 16 + 4 * g, o_prev[dt]);
+    if (g == 0) p.delta[((long long)b * H + h) * N + q] = delta_prev;
+  };
+
+  stage(b0, 0);
+  load_rows(b0, fq, fdo, fo, lse);
+  for (int b = b0; b < b1; ++b) {
+    const int buf = (b - b0) & 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (b + 1 < b1) {
+      stage(b + 1, buf ^ 1);
+      load_rows(b + 1, fq_n, fdo_n, fo_n, lse_n);
+    }
+    if (b > b0) write_back(b - 1);
+    const char *kimg = smem + buf * (2 * IMG), *vimg = kimg + IMG;
+    if (wave_live) {
+      const float dl = row_sum4(dot8(fdo[0], fo[0]) + dot8(fdo[1], fo[1]));      // delta[q] = sum_d dO O
+      f32x4 o[4];
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int m = 0; m < NKT / 2; ++m) {
+        f32x4 ds[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int kt = 2 * m + u;
+          f32x4 sc = {0.f, 0.f, 0.f, 0.f}, a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks) {
+            mma<bf16_t>(sc, fq[ks], read_row(kimg, fa, kt, ks));
+            mma<bf16_t>(a, fdo[ks], read_row(vimg, fa, kt, ks));
+          }
+          sc = sc * p.scale + bias[kt];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) ds[u][r] = __expf(sc[r] - lse) * (a[r] - dl);
+        }
+        const u32x4 fds = pack2(ds[0], ds[1]);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) mma<bf16_t>(o[dt], fds, read_tr(kimg, fa, m, dt));
+      }
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) o_prev[dt] = o[dt] * p.scale;
+      delta_prev = dl;
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) { fq[ks] = fq_n[ks]; fdo[ks] = fdo_n[ks]; fo[ks] = fo_n[ks]; }
+    lse = lse_n;
+  }
+  write_back(b1 - 1);
+}
+
+// ---- dK, dV (rows of the workgroup are keys; columns are queries), plus the chunk's summed dS for the bias gradient ----------
+template <int NKT>
+__global__ __launch_bounds__(512) void attn_bwd_dkv_pipe_kernel(const AttnPipeBwdParams p, int bchunk) {
+  constexpr int N = NKT * 16;
+  constexpr int IMG = N * 128;
+  constexpr int BUF = 2 * IMG + 2 * 1024;                        // Q image | dO image | lse[256] | delta[256]
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int g = lane >> 4, li = lane & 15;
+  const int h = blockIdx.x, rb = blockIdx.y, chunk = blockIdx.z;
+  const int H = p.H;
+  const int b0 = chunk * bchunk, b1 = min(p.B, b0 + bchunk);
+  if (b0 >= b1) return;
+  const int key = rb * ROWS + wave * 16 + li;
+  const bool wave_live = rb * ROWS + wave * 16 < N;
+  const long long tok_stride = 3LL * H * HD;
+  const bf16_t *qkv = reinterpret_cast<const bf16_t *>(p.qkv);
+  const bf16_t *dout = reinterpret_cast<const bf16_t *>(p.dout);
+  FragAddr fa;
+  fa.init(lane);
+
+  // bias^T rows of this wave's keys: biasT[qt][r] = bias[h][q = 16 qt + 4g + r][key]  (strided, once per workgroup)
+  f32x4 biasT[NKT], hacc[NKT];
+#pragma unroll
+  for (int qt = 0; qt < NKT; ++qt) { biasT[qt] = (f32x4){0.f, 0.f, 0.f, 0.f}; hacc[qt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+  if (p.bias && wave_live) {
+    const float *bcol = p.bias + (long long)h * N * N + key;
+#pragma unroll
+    for (int qt = 0; qt < NKT; ++qt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) biasT[qt][r] = bcol[(long long)(16 * qt + 4 * g + r) * N];
+  }
+
+  const int dkey = lane >> 3;
+  auto stage = [&](int b, int buf) {
+    const bf16_t *qbase = qkv + (long long)b * N * tok_stride + (long long)h * HD;
+    const bf16_t *dbase = dout + (long long)b * N * H * HD + (long long)h * HD;
+    const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t *>(qbase), 0, (int)(N * tok_stride * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t *>(dbase), 0, (int)(N * H * HD * 2), 0x00020000);
+    char *qimg = smem + buf * BUF, *dimg = qimg + IMG;
+#pragma unroll
+    for (int j = 0; j < NKT / 4; ++j) {
+      const int inst = wave + 8 * j;
+      if (inst < N / 8) {
+        const int row = 8 * inst + dkey;
+        const unsigned chunk16 = (unsigned)(((lane & 7) ^ dual_swz(row)) * 16);
+        DM_LDS_DMA(rq, qimg + inst * 1024, (unsigned)(row * tok_stride * 2) + chunk16, 0);
+        DM_LDS_DMA(rd, dimg + inst * 1024, (unsigned)(row * H * HD * 2) + chunk16, 0);
+      }
+    }
+    if (wave < 2) {     // the sample's lse / delta rows (N floats each; lanes past N read zero)
+      const float *src = (wave == 0 ? p.lse : p.delta) + ((long long)b * H + h) * N;
+      const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(src), 0, N * 4, 0x00020000);
+      DM_LDS_DMA(rv, qimg + 2 * IMG + wave * 1024, (unsigned)(lane * 16), 0);
+    }
+  };
+  auto load_rows = [&](int b, u32x4 (&fk)[2], u32x4 (&fv)[2]) {
+    const bf16_t *krow = qkv + ((long long)b * N + key) * tok_stride + (long long)H * HD + (long long)h * HD;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int c = (4 * ks + g) * 8;
+      fk[ks] = wave_live ? *reinterpret_cast<const u32x4 *>(krow + c) : (u32x4){0u, 0u, 0u, 0u};
+      fv[ks] = wave_live ? *reinterpret_cast<const u32x4 *>(krow + (long long)H * HD + c) : (u32x4){0u, 0u, 0u, 0u};
+    }
+  };
+
+  u32x4 fk[2], fv[2], fk_n[2], fv_n[2];
+  f32x4 dk_prev[4], dv_prev[4];
+  auto write_back = [&](int b) {
+    if (!wave_live) return;
+    bf16_t *dk = reinterpret_cast<bf16_t *>(p.dqkv) + ((long long)b * N + key) * tok_stride + (long long)H * HD + (long long)h * HD;
+    bf16_t *dv = dk + (long long)H * HD;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      dm_store4(dk + dt * 16 + 4 * g, dk_prev[dt]);
+      dm_store4(dv + dt * 16 + 4 * g, dv_prev[dt]);
+    }
+  };
+
+  stage(b0, 0);
+  load_rows(b0, fk, fv);
+  for (int b = b0; b < b1; ++b) {
+    const int buf = (b - b0) & 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (b + 1 < b1) {
+      stage(b + 1, buf ^ 1);
+      load_rows(b + 1, fk_n, fv_n);
+    }
+    if (b > b0) write_back(b - 1);
+    const char *qimg = smem + buf * BUF, *dimg = qimg + IMG;
+    const float *lse_l = reinterpret_cast<const float *>(qimg + 2 * IMG), *delta_l = lse_l + 256;
+    if (wave_live) {
+      f32x4 odk[4], odv[4];
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) { odk[dt] = (f32x4){0.f, 0.f, 0.f, 0.f}; odv[dt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+      for (int m = 0; m < NKT / 2; ++m) {
+        f32x4 pv[2], ds[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int qt = 2 * m + u;
+          f32x4 sc = {0.f, 0.f, 0.f, 0.f}, a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks) {
+            mma<bf16_t>(sc, fk[ks], read_row(qimg, fa, qt, ks));
+            mma<bf16_t>(a, fv[ks], read_row(dimg, fa, qt, ks));
+          }
+          sc = sc * p.scale + biasT[qt];
+          const f32x4 l4 = *reinterpret_cast<const f32x4 *>(lse_l + 16 * qt + 4 * g);
+          const f32x4 d4 = *reinterpret_cast<const f32x4 *>(delta_l + 16 * qt + 4 * g);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            pv[u][r] = __expf(sc[r] - l4[r]);
+            ds[u][r] = pv[u][r] * (a[r] - d4[r]);
+          }
+          if (p.slab) hacc[qt] += ds[u];
+        }
+        const u32x4 fpt = pack2(pv[0], pv[1]), fds = pack2(ds[0], ds[1]);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          mma<bf16_t>(odv[dt], fpt, read_tr(dimg, fa, m, dt));
+          mma<bf16_t>(odk[dt], fds, read_tr(qimg, fa, m, dt));
+        }
+      }
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) { dk_prev[dt] = odk[dt] * p.scale; dv_prev[dt] = odv[dt]; }
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) { fk[ks] = fk_n[ks]; fv[ks] = fv_n[ks]; }
+  }
+  write_back(b1 - 1);
+  if (p.slab && wave_live) {
+    // dbias[chunk][h][q][key] = the chunk's summed dS (this lane holds 4 consecutive q of one key: scattered 4-byte stores,
+    // once per chunk)
+    float *plane = p.slab + ((long long)chunk * H + h) * N * N + key;
+#pragma unroll
+    for (int qt = 0; qt < NKT; ++qt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) plane[(long long)(16 * qt + 4 * g + r) * N] = hacc[qt][r];
+  }
+}
+
+inline void pipe_grid(int B, int N, int H, int &nblk, int &chunks, int &bchunk) {
+  nblk = (N + ROWS - 1) / ROWS;
+  chunks = 256 / (H * nblk);
+  if (chunks < 1) chunks = 1;
+  if (chunks > B) chunks = B;
+  bchunk = (B + chunks - 1) / chunks;
+  chunks = (B + bchunk - 1) / bchunk;
+}
+
+template <int NKT> void launch_bwd(const AttnPipeBwdParams &p, hipStream_t s) {
+  constexpr int N = NKT * 16;
+  constexpr int LDS_DQ = 4 * N * 128, LDS_DKV = 2 * (2 * N * 128 + 2048);
+  static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void *>(attn_bwd_dq_pipe_kernel<NKT>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DQ) == hipSuccess &&
+                         hipFuncSetAttribute(reinterpret_cast<const void *>(attn_bwd_dkv_pipe_kernel<NKT>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DKV) == hipSuccess;
+  (void)ok;
+  int nblk, chunks, bchunk;
+  pipe_grid(p.B, N, p.H, nblk, chunks, bchunk);
+  hipLaunchKernelGGL(attn_bwd_dq_pipe_kernel<NKT>, dim3(p.H, nblk, chunks), dim3(512), LDS_DQ, s, p, bchunk);
+  hipLaunchKernelGGL(attn_bwd_dkv_pipe_kernel<NKT>, dim3(p.H, nblk, chunks), dim3(512), LDS_DKV, s, p, bchunk);
+}
+
 template <int NKT> void launch(const AttnPipeParams &p, hipStream_t s) {
   constexpr int N = NKT * 16;
   constexpr int LDS = 4 * N * 128;
   static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void *>(attn_fwd_pipe_kernel<NKT>),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS) == hipSuccess;
   (void)ok;
-  const int nblk = (N + ROWS - 1) / ROWS;
   // one workgroup per CU (two K/V buffers fill the LDS): as many chunks as fit one round of the 256 CUs
-  int chunks = 256 / (p.H * nblk);
-  if (chunks < 1) chunks = 1;
-  if (chunks > p.B) chunks = p.B;
-  const int bchunk = (p.B + chunks - 1) / chunks;
-  chunks = (p.B + bchunk - 1) / bchunk;
+  int nblk, chunks, bchunk;
+  pipe_grid(p.B, N, p.H, nblk, chunks, bchunk);
   hipLaunchKernelGGL(attn_fwd_pipe_kernel<NKT>, dim3(p.H, nblk, chunks), dim3(512), LDS, s, p, bchunk);
 }
 
@@ -205,6 +536,32 @@ bool dm_attn_fwd_pipe(const AttnPipeParams &p, hipStream_t s) {
     case 8: dmpipe::launch<8>(p, s); return true;
     case 12: dmpipe::launch<12>(p, s); return true;
     case 16: dmpipe::launch<16>(p, s); return true;
+    default: return false;
+  }
+}
+
+static bool pipe_shape_ok(int B, int N, int H) {
+  static const int mode = [] { const char *e = getenv("DM_ATTN_PIPE"); return e ? atoi(e) : 1; }();
+  if (mode == 0) return false;
+  if (N % 16 != 0 || N < 128 || N > 256) return false;
+  if ((long long)N * 3 * H * 64 * 2 >= (1LL << 31)) return false;
+  if (mode != 2 && B * H < 96) return false;
+  return true;
+}
+
+int dm_attn_bwd_pipe_chunks(int B, int N, int H, int dtype_is_bf16) {
+  if (!dtype_is_bf16 || !pipe_shape_ok(B, N, H)) return 0;
+  int nblk, chunks, bchunk;
+  dmpipe::pipe_grid(B, N, H, nblk, chunks, bchunk);
+  return chunks;
+}
+
+bool dm_attn_bwd_pipe(const AttnPipeBwdParams &p, hipStream_t s) {
+  if (!pipe_shape_ok(p.B, p.N, p.H)) return false;
+  switch (p.N / 16) {
+    case 8: dmpipe::launch_bwd<8>(p, s); return true;
+    case 12: dmpipe::launch_bwd<12>(p, s); return true;
+    case 16: dmpipe::launch_bwd<16>(p, s); return true;
     default: return false;
   }
 }

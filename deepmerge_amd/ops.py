@@ -213,7 +213,7 @@ def attention_bwd(qkv, bias, out, dout, lse, B, N, H, D, scale, index32=None, n_
     delta = torch.empty((B, H, N), dtype=torch.float32, device=qkv.device)
     slab, info = None, None
     if index32 is not None:
-        chunks = _lib.lib().dm_attention_bwd_batch_chunks(B, N, H)
+        chunks = _lib.lib().dm_attention_bwd_batch_chunks(B, N, H, _dt(qkv))
         slab = torch.empty((chunks, H, N, N), dtype=torch.float32, device=qkv.device)
         info = (chunks, N, relpos_index_csr(index32, n_bins))
     check(_lib.lib().dm_attention_bwd(qkv.data_ptr(), _ptr(bias), _ptr(bias_t), out.data_ptr(), dout.data_ptr(), lse.data_ptr(), dqkv.data_ptr(),

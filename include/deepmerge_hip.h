@@ -116,8 +116,8 @@ int dm_attention_fwd(const void *qkv, const float *bias, void *out, float *lse,
 int dm_attention_bwd(const void *qkv, const float *bias, const float *bias_t, const void *out, const void *dout,
                      const float *lse, void *dqkv, float *delta, float *dbias_slab, int32_t B, int32_t N, int32_t H,
                      int32_t D, float scale, int32_t dtype, void *stream);
-/* Number of batch chunks dm_attention_bwd uses for this problem size (first dimension of dbias_slab). */
-int32_t dm_attention_bwd_batch_chunks(int32_t B, int32_t N, int32_t H);
+/* Number of batch chunks dm_attention_bwd uses for this problem size and dtype (first dimension of dbias_slab). */
+int32_t dm_attention_bwd_batch_chunks(int32_t B, int32_t N, int32_t H, int32_t dtype);
 
 /* relative_position_bias_table[index.view(-1)].view(N,N,H).permute(2,0,1)
  * (nets/ShfitScaleFormer.py:123-128): table [n_bins,H] fp32, index int32 [N,N] -> bias [H,N,N] and,
