@@ -309,6 +309,17 @@ class ShfitScaleFormer_v3(nn.Module):
             return self.forward_once_design_feature(x1_patches, x1_designed_features)
         return self.forward_once(x1_patches)
 
+    def forward_pair_batched(self, both_patches, both_designed):
+        """The training forward on inputs that already hold both sides of every pair stacked along the batch
+        ([left; right], 2B samples): what forward() builds with torch.cat.  The trainer's graph replay copies the
+        step's inputs straight into such buffers.  Returns (feature1, feature2)."""
+        B = both_patches[0].shape[0] // 2
+        if self.is_designed_feature_embedding:
+            f = self.forward_once_design_feature(both_patches, both_designed)
+        else:
+            f = self.forward_once(both_patches)
+        return f[:B], f[B:]
+
     def _init_weights(self, m):
         if isinstance(m, nn.Linear):
             nn.init.trunc_normal_(m.weight, std=.02)

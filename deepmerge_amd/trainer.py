@@ -94,6 +94,11 @@ class FlatParams:
         return [slice(a, b) for a, b in zip(cuts[:-1], cuts[1:]) if b > a]
 
 
+def _v3_forward():
+    from .nets.ShfitScaleFormer import ShfitScaleFormer_v3
+    return ShfitScaleFormer_v3.forward
+
+
 class PairTrainer:
     """One training step of the Siamese encoder on this rank's shard of the pair batch."""
 
@@ -195,10 +200,26 @@ class PairTrainer:
                 self._graph_warm += 1
                 return self._eager_step(*args, lr)
             dev = self.fp.flat.device
-            st["left"] = [t.clone() for t in left]
-            st["right"] = [t.clone() for t in right]
-            st["ld"] = None if left_designed is None else left_designed.clone()
-            st["rd"] = None if right_designed is None else right_designed.clone()
+            # models that take the two sides pre-stacked ([left; right] along the batch) get static buffers of that form, so
+            # the step's inputs are copied once and the captured graph holds no torch.cat
+            batched = type(self.net).__dict__.get("forward_pair_batched") is not None or \
+                (hasattr(self.net, "forward_pair_batched") and type(self.net).forward is _v3_forward())
+            if batched:
+                both = [torch.cat((l, r), 0) for l, r in zip(left, right)]
+                Bp = left[0].shape[0]
+                st["left"], st["right"] = [t[:Bp] for t in both], [t[Bp:] for t in both]
+                st["both"] = both
+                if left_designed is not None:
+                    st["dboth"] = torch.cat((left_designed, right_designed), 0)
+                    st["ld"], st["rd"] = st["dboth"][:Bp], st["dboth"][Bp:]
+                else:
+                    st["dboth"] = st["ld"] = st["rd"] = None
+            else:
+                st["both"] = None
+                st["left"] = [t.clone() for t in left]
+                st["right"] = [t.clone() for t in right]
+                st["ld"] = None if left_designed is None else left_designed.clone()
+                st["rd"] = None if right_designed is None else right_designed.clone()
             st["flag"] = flag.clone()
             st["hyper"] = torch.zeros(2, dtype=torch.float32, device=dev)
             st["shapes"] = [tuple(t.shape) for t in st["left"] + st["right"]]
@@ -206,7 +227,10 @@ class PairTrainer:
             torch.cuda.synchronize()
             with torch.cuda.graph(g):
                 self.fp.zero_grad()
-                fa, fb = self.net(st["left"], st["ld"], st["right"], st["rd"])
+                if st["both"] is not None:
+                    fa, fb = self.net.forward_pair_batched(st["both"], st["dboth"])
+                else:
+                    fa, fb = self.net(st["left"], st["ld"], st["right"], st["rd"])
                 loss = self.criterion(fa, fb, st["flag"])
                 loss.backward()
                 extra = {"param_lp": self.fp.flat_lp} if self.fp.flat_lp is not None else {}

@@ -10,7 +10,7 @@ g = torch.Generator(device=dev); g.manual_seed(1)
 def rnd(shape): return torch.randn(shape, device=dev, generator=g).to(torch.bfloat16)
 cases = [("NT", 16384, 3072, 768), ("NT", 16384, 768, 3072), ("NT", 16384, 2304, 768), ("NN", 16384, 3072, 768), ("TN", 768, 3072, 16384), ("TN", 3072, 768, 16384)]
 for lay, M, N, K in cases:
-    for R in (1, 8):
+    for R in (1, 2, 3, 8):
         sets = []
         for _ in range(R):
             if lay == "NT": a, b, L, lda, ldb = rnd((M, K)), rnd((N, K)), DM_NT, K, K
