@@ -40,6 +40,7 @@ class DmGemmArgs(C.Structure):
         ("aux", C.c_void_p), ("ldaux", C.c_int64),
         ("rows_per_group", C.c_int32), ("group_stride", C.c_int64),
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
+        ("colsum_a", C.c_void_p), ("colsum_accumulate", C.c_int32),
     ]
 
 

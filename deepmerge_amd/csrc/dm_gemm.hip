@@ -341,6 +341,15 @@ __global__ void splitk_reduce_kernel(const float *__restrict__ slab, float *__re
   }
 }
 
+// out[m] (+)= sum_r rows[r][m], rows in index order (the pipeline's partial column sums of A)
+__global__ void colsum_rows_reduce_kernel(const float *__restrict__ rows, float *__restrict__ out, int M, int R, int accumulate) {
+  const int m = blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= M) return;
+  float s = accumulate ? out[m] : 0.f;
+  for (int r = 0; r < R; ++r) s += rows[(long long)r * M + m];
+  out[m] = s;
+}
+
 // Generic fp32 kernel for the small / odd-shaped products of the tail (K = 19, N = 100, M = batch): any
 // shape, any alignment.  These products have few output tiles and a long K, so they are latency-bound:
 // the four waves of a workgroup split K four ways for one 16x16 output tile (each wave stages its own
@@ -455,12 +464,19 @@ int choose_split(int tiles, int K, int bk) {
 
 }  // namespace
 
+// floats at the end of the workspace reserved for the column sums of A (colsum_a): the pipeline's [32 slices * 4][M] partial
+// rows, or the standalone kernels' scratch
+static int64_t colsum_region_floats(int M) {
+  const int64_t fused = 128LL * M, alone = dm_colsum_partial_floats(M);
+  return (fused > alone ? fused : alone) + 64;
+}
+
 extern "C" int64_t dm_gemm_workspace_bytes(int32_t layout, int32_t M, int32_t N, int32_t K) {
   if (layout != DM_TN) return 0;
   const int tile = pick_tile(layout, M, N, K);
   const int tiles = ((M + tile - 1) / tile) * ((N + tile - 1) / tile);
   const int s = choose_split(tiles, K, 32);
-  return s > 1 ? (int64_t)s * M * N * 4 : 0;
+  return (s > 1 ? (int64_t)s * M * N * 4 : 0) + colsum_region_floats(M) * 4;
 }
 
 extern "C" int dm_gemm(const DmGemmArgs *a, void *stream) {
@@ -481,6 +497,17 @@ extern "C" int dm_gemm(const DmGemmArgs *a, void *stream) {
   p.M = a->M; p.N = a->N; p.K = a->K;
   p.epilogue = a->epilogue; p.accumulate = a->accumulate; p.c_dtype = a->c_dtype; p.aux_dtype = a->aux_dtype;
 
+  // the tail of the workspace belongs to the column sums of A, the rest to the split-K slab
+  float *cs_region = nullptr;
+  int64_t slab_bytes = a->workspace_bytes;
+  if (a->colsum_a) {
+    DM_REQUIRE(a->layout == DM_TN, DM_ERR_UNSUPPORTED, "dm_gemm: colsum_a goes with DM_TN (column sums of A = dy)");
+    const int64_t need = colsum_region_floats(a->M) * 4;
+    DM_REQUIRE(a->workspace != nullptr && a->workspace_bytes >= need, DM_ERR_BAD_SHAPE,
+               "dm_gemm: colsum_a needs %lld bytes of workspace (got %lld)", (long long)need, (long long)a->workspace_bytes);
+    slab_bytes = (a->workspace_bytes - need) & ~15LL;
+    cs_region = reinterpret_cast<float *>(reinterpret_cast<char *>(a->workspace) + slab_bytes);
+  }
   // Which extents must be chunk (16-byte) multiples for the MFMA path.
   {
     const long long esz = (a->ab_dtype == DM_BF16) ? 2 : 4;
@@ -511,14 +538,15 @@ extern "C" int dm_gemm(const DmGemmArgs *a, void *stream) {
       default: hipLaunchKernelGGL((sgemm_small_kernel<DM_TN>), grid, dim3(256), 0, s, p); break;
     }
     DM_LAUNCH_CHECK("dm_gemm(generic)");
+    if (a->colsum_a) return dm_colsum(a->A, a->ab_dtype, a->lda, a->colsum_a, a->K, a->M, a->colsum_accumulate, cs_region, stream);
     return DM_OK;
   }
 
   const bool can_split = (a->layout == DM_TN) && a->epilogue == DM_EPI_NONE && !a->bias && !a->residual &&
-                         a->c_dtype == DM_F32 && a->rows_per_group == 0 && a->workspace != nullptr;
+                         a->c_dtype == DM_F32 && a->rows_per_group == 0 && a->workspace != nullptr && slab_bytes > 0;
   if (a->split_k > 1)
     DM_REQUIRE(can_split, DM_ERR_UNSUPPORTED, "dm_gemm: split_k needs DM_TN, no epilogue, fp32 C and a workspace");
-  const bool big = dm_gemm256_plan(p, a->layout, a->ab_dtype, can_split, a->workspace_bytes, a->split_k);
+  const bool big = dm_gemm256_plan(p, a->layout, a->ab_dtype, can_split, slab_bytes, a->split_k);
   const int tile = big ? 256 : pick_tile(a->layout, a->M, a->N, a->K);
   int split = p.split_k;
   if (!big) {
@@ -528,7 +556,7 @@ extern "C" int dm_gemm(const DmGemmArgs *a, void *stream) {
     split = a->split_k;
     if (split == 0) split = can_split ? choose_split(p.tiles_m * p.tiles_n, a->K, bk) : 1;
     if (split > 1)
-      while (split > 1 && (int64_t)split * a->M * a->N * 4 > a->workspace_bytes) split >>= 1;
+      while (split > 1 && (int64_t)split * a->M * a->N * 4 > slab_bytes) split >>= 1;
     int kps = ((a->K + split - 1) / split + bk - 1) / bk * bk;
     split = (a->K + kps - 1) / kps;
     p.split_k = split;
@@ -557,6 +585,7 @@ extern "C" int dm_gemm(const DmGemmArgs *a, void *stream) {
     DmProfScope prof(pname, s, 2.0 * a->M * a->N * a->K,
                      esz * ((double)a->M * a->K + (double)a->N * a->K) + csz * mn * (a->accumulate ? 2.0 : 1.0) +
                          (a->residual ? 4.0 * mn : 0.0) + (a->aux ? ((a->aux_dtype == DM_BF16) ? 2.0 : 4.0) * mn : 0.0));
+    p.colsum_slab = (big && cs_region) ? cs_region : nullptr;
     if (big) {
       dm_gemm256_launch(p, a->layout, s);
     } else if (a->ab_dtype == DM_BF16) {
@@ -573,6 +602,16 @@ extern "C" int dm_gemm(const DmGemmArgs *a, void *stream) {
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(rgrid), dim3(256), 0, s, p.workspace,
                        reinterpret_cast<float *>(a->C), (long long)a->ldc, a->M, a->N, split, a->accumulate);
     DM_LAUNCH_CHECK("dm_gemm(split-k reduce)");
+  }
+  if (a->colsum_a) {
+    if (big) {      // fold the pipeline's [split * 4][M] partial rows, in row order
+      hipLaunchKernelGGL(colsum_rows_reduce_kernel, dim3((a->M + 255) / 256), dim3(256), 0, s, cs_region, a->colsum_a, a->M, split * 4,
+                         a->colsum_accumulate);
+      DM_LAUNCH_CHECK("dm_gemm(colsum reduce)");
+    } else {
+      const int rc = dm_colsum(a->A, a->ab_dtype, a->lda, a->colsum_a, a->K, a->M, a->colsum_accumulate, cs_region, stream);
+      if (rc != DM_OK) return rc;
+    }
   }
   return DM_OK;
 }

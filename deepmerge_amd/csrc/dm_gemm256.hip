@@ -183,6 +183,23 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
   u32x4 fa[8], fb0[4], fb1[4];
+  // Column sums of A (the bias gradient that goes with a weight gradient): the workgroups of column tile 0 multiply their A
+  // fragments with a ones fragment; the four waves that hold the same A rows take every fourth K tile each (+6 % MFMAs).
+  const bool colsum = AM && p.colsum_slab != nullptr && tn == 0;
+  f32x4 accb[AM ? 8 : 1];
+#pragma unroll
+  for (int i = 0; i < (AM ? 8 : 1); ++i) accb[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const u32x4 ones = {0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};     // eight bf16 1.0
+#define DM_COLSUM(MI)                                                                      \
+  do {                                                                                     \
+    if constexpr (AM) {                                                                    \
+      if (colsum && (kt & 3) == wc) {                                                      \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                   \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                      \
+            mma<bf16_t>(accb[(MI) * 4 + i], fa[2 * i + ks], ones);                         \
+      }                                                                                    \
+    }                                                                                      \
+  } while (0)
 
 #define DM_QUAD(MI, NI, FB)                                                                \
   do {                                                                                     \
@@ -229,6 +246,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
     if (kt + 1 < ntile) { stage(kt + 1, 0, 1); stage(kt + 1, 0, 3); }
     DM_PHASE_SYNC();
     DM_QUAD(0, 0, fb0);
+    DM_COLSUM(0);
     DM_PHASE_END();
     // phase 1: quadrant (0,1)
     opB.template load<2>(fb1, imgB, 1, wc);
@@ -240,6 +258,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
     if (kt + 2 < ntile) { stage(kt + 2, 0, 0); stage(kt + 2, 0, 2); stage(kt + 2, 1, 0); stage(kt + 2, 1, 1); }
     DM_PHASE_SYNC();
     DM_QUAD(1, 1, fb1);
+    DM_COLSUM(1);
     DM_PHASE_END();
     // phase 3: quadrant (1,0); retire tile kt+1's DMA
     if (kt + 2 < ntile) {
@@ -255,6 +274,16 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
   if (wr == 0) __builtin_amdgcn_s_barrier();   // balance the stagger
 
   // ---- epilogue ----------------------------------------------------------------------------------------------
+  if constexpr (AM) {
+    if (colsum && g == 0) {      // every column of an accb tile holds the same sum: lanes g == 0 write element 0
+      float *row = p.colsum_slab + (long long)(z * 4 + wc) * p.M;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int m = m0 + wr * 128 + i * 16 + li;
+        if (m < p.M) row[m] = accb[i][0];
+      }
+    }
+  }
   if (p.split_k > 1) {          // K slice: fp32 partial tile into the slab, summed in slice order by splitk_reduce_kernel
     float *W = p.workspace + (long long)z * p.M * p.N;
 #pragma unroll

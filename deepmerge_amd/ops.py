@@ -84,9 +84,11 @@ def gemm(layout: int, A: torch.Tensor, B: torch.Tensor, C_out: torch.Tensor, M: 
          lda: Optional[int] = None, ldb: Optional[int] = None, ldc: Optional[int] = None,
          bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None, ldr: Optional[int] = None,
          epilogue: int = DM_EPI_NONE, aux: Optional[torch.Tensor] = None, ldaux: Optional[int] = None,
-         accumulate: bool = False, split_k: int = 0, rows_per_group: int = 0, group_stride: int = 0) -> torch.Tensor:
-    """dm_gemm.  A/B/C are 2-D (or flat) row-major tensors; leading dims default to their last-dim size."""
-    _need_cuda(A, B, C_out, bias, residual, aux)
+         accumulate: bool = False, split_k: int = 0, rows_per_group: int = 0, group_stride: int = 0,
+         colsum_out: Optional[torch.Tensor] = None, colsum_accumulate: bool = False) -> torch.Tensor:
+    """dm_gemm.  A/B/C are 2-D (or flat) row-major tensors; leading dims default to their last-dim size.
+    DM_TN only: colsum_out [M] fp32 (+)= column sums of A (the bias gradient that goes with dW = dy^T x)."""
+    _need_cuda(A, B, C_out, bias, residual, aux, colsum_out)
     if A.dtype != B.dtype:
         raise ValueError(f"A/B dtype mismatch: {A.dtype} vs {B.dtype}")
     a = DmGemmArgs()
@@ -105,7 +107,11 @@ def gemm(layout: int, A: torch.Tensor, B: torch.Tensor, C_out: torch.Tensor, M: 
         raise ValueError("residual must be fp32")
     a.aux, a.ldaux = _ptr(aux), (ldaux if ldaux is not None else N)
     a.rows_per_group, a.group_stride = rows_per_group, group_stride
-    ws_bytes = _lib.lib().dm_gemm_workspace_bytes(layout, M, N, K) if split_k != 1 else 0
+    if colsum_out is not None:
+        if colsum_out.dtype != torch.float32 or colsum_out.numel() < M or not colsum_out.is_contiguous():
+            raise ValueError("colsum_out must be a contiguous fp32 tensor with >= M elements")
+        a.colsum_a, a.colsum_accumulate = colsum_out.data_ptr(), int(colsum_accumulate)
+    ws_bytes = _lib.lib().dm_gemm_workspace_bytes(layout, M, N, K) if (split_k != 1 or colsum_out is not None) else 0
     if ws_bytes > 0:
         ws = workspace(ws_bytes, A.device, "gemm")
         a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
@@ -318,12 +324,13 @@ def _linear_backward(x, w, dy, need_dx, need_dw, need_db, wshape):
     if need_dx:
         dx = torch.empty((M, K), dtype=x.dtype, device=x.device)
         gemm(DM_NN, dy, w, dx, M, K, N, lda=N, ldb=K, ldc=K)
-    if need_dw:
-        dw = torch.empty((N, K), dtype=torch.float32, device=x.device)
-        gemm(DM_TN, dy, x, dw, N, K, M, lda=N, ldb=K, ldc=K)
-        dw = dw.reshape(wshape)
     if need_db:
         db = torch.empty(N, dtype=torch.float32, device=x.device)
+    if need_dw:
+        dw = torch.empty((N, K), dtype=torch.float32, device=x.device)
+        gemm(DM_TN, dy, x, dw, N, K, M, lda=N, ldb=K, ldc=K, colsum_out=db)       # db rides on the wgrad when it can
+        dw = dw.reshape(wshape)
+    elif need_db:
         colsum(dy, db)
     return dx, dw, db
 
@@ -639,15 +646,13 @@ class BlockFn(torch.autograd.Function):
         dy = _operand_grad(dx2, dtype)
         # ---- MLP ---------------------------------------------------------------------------
         dw2, k_w2 = _grad_out(P_fc2_w, (Cc, Hd), dev)
-        gemm(DM_TN, dy, h, dw2, Cc, Hd, M, lda=Cc, ldb=Hd, ldc=Hd, accumulate=k_w2)
         db2, k_b2 = _grad_out(P_fc2_b, (Cc,), dev)
-        colsum(dy, db2, accumulate=k_b2)
+        gemm(DM_TN, dy, h, dw2, Cc, Hd, M, lda=Cc, ldb=Hd, ldc=Hd, accumulate=k_w2, colsum_out=db2, colsum_accumulate=k_b2)
         dpre = torch.empty((M, Hd), dtype=dtype, device=dev)
         gemm(DM_NN, dy, w2, dpre, M, Hd, Cc, lda=Cc, ldb=Hd, ldc=Hd, epilogue=DM_EPI_DGELU, aux=pre, ldaux=Hd)
         dw1, k_w1 = _grad_out(P_fc1_w, (Hd, Cc), dev)
-        gemm(DM_TN, dpre, y2, dw1, Hd, Cc, M, lda=Hd, ldb=Cc, ldc=Cc, accumulate=k_w1)
         db1, k_b1 = _grad_out(P_fc1_b, (Hd,), dev)
-        colsum(dpre, db1, accumulate=k_b1)
+        gemm(DM_TN, dpre, y2, dw1, Hd, Cc, M, lda=Hd, ldb=Cc, ldc=Cc, accumulate=k_w1, colsum_out=db1, colsum_accumulate=k_b1)
         dy2 = torch.empty((M, Cc), dtype=dtype, device=dev)
         gemm(DM_NN, dpre, w1, dy2, M, Cc, Hd, lda=Hd, ldb=Cc, ldc=Cc)
         dg2, k_n2 = _grad_out(P_n2w, (Cc,), dev)
@@ -658,9 +663,8 @@ class BlockFn(torch.autograd.Function):
         dx1, dx1_lp = (r[0], r[1]) if lp else (r[0], r[0])
         # ---- attention -----------------------------------------------------------------------
         dwp, k_wp = _grad_out(P_proj_w, (Cc, Cc), dev)
-        gemm(DM_TN, dx1_lp, o.view(M, Cc), dwp, Cc, Cc, M, lda=Cc, ldb=Cc, ldc=Cc, accumulate=k_wp)
         dbp, k_bp = _grad_out(P_proj_b, (Cc,), dev)
-        colsum(dx1_lp, dbp, accumulate=k_bp)
+        gemm(DM_TN, dx1_lp, o.view(M, Cc), dwp, Cc, Cc, M, lda=Cc, ldb=Cc, ldc=Cc, accumulate=k_wp, colsum_out=dbp, colsum_accumulate=k_bp)
         do = torch.empty((M, Cc), dtype=dtype, device=dev)
         gemm(DM_NN, dx1_lp, wp, do, M, Cc, Cc, lda=Cc, ldb=Cc, ldc=Cc)
         want_table = bias is not None
@@ -672,9 +676,8 @@ class BlockFn(torch.autograd.Function):
             relpos_bias_scatter(slab, dtable, B, heads, rows, n_bins, accumulate=k_t)
         dqkv2 = dqkv.view(M, 3 * Cc)
         dwq, k_wq = _grad_out(P_qkv_w, (3 * Cc, Cc), dev)
-        gemm(DM_TN, dqkv2, y1, dwq, 3 * Cc, Cc, M, lda=3 * Cc, ldb=Cc, ldc=Cc, accumulate=k_wq)
         dbq, k_bq = _grad_out(P_qkv_b, (3 * Cc,), dev)
-        colsum(dqkv2, dbq, accumulate=k_bq)
+        gemm(DM_TN, dqkv2, y1, dwq, 3 * Cc, Cc, M, lda=3 * Cc, ldb=Cc, ldc=Cc, accumulate=k_wq, colsum_out=dbq, colsum_accumulate=k_bq)
         dy1 = torch.empty((M, Cc), dtype=dtype, device=dev)
         gemm(DM_NN, dqkv2, wq, dy1, M, Cc, 3 * Cc, lda=3 * Cc, ldb=Cc, ldc=Cc)
         dg1, k_n1 = _grad_out(P_n1w, (Cc,), dev)

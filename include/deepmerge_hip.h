@@ -90,6 +90,11 @@ typedef struct {
    * nets/ShfitScaleFormer.py:877). */
   int32_t rows_per_group; int64_t group_stride;
   void *workspace; int64_t workspace_bytes;
+  /* DM_TN only, optional: colsum_a[m] (+)= sum_k A[k,m], fp32 [M] -- the bias gradient that goes with a weight gradient
+   * dW = dy^T x (autograd of nn.Linear's bias: column sums of dy).  On the 256x256 wgrad pipeline it costs a few extra
+   * MFMAs against a ones fragment instead of another pass over dy; otherwise dm_gemm runs the column-sum kernels itself.
+   * Needs the workspace (dm_gemm_workspace_bytes covers it). */
+  float *colsum_a; int32_t colsum_accumulate;
 } DmGemmArgs;
 
 int dm_gemm(const DmGemmArgs *args, void *stream);

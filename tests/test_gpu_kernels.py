@@ -417,3 +417,24 @@ def test_gemm256_pipeline_wgrad_and_dgrad_layouts():
     out = torch.empty((Mr, Nd), device=DEV, dtype=torch.bfloat16)
     ops.gemm(DM_NN, a, w, out, Mr, Nd, Kd, lda=Kd, ldb=Nd, ldc=Nd)
     assert torch.equal(out, (a.float() @ w.float()).to(torch.bfloat16))
+
+
+@pytest.mark.parametrize("M,N,K", [(768, 3072, 16384), (2304, 768, 16384), (776, 3072, 16384), (768, 768, 4096), (104, 768, 640)])
+def test_gemm_wgrad_with_fused_column_sums(M, N, K):
+    """colsum_a: the bias gradient rides on the wgrad (ones-fragment MFMAs on the 256x256 pipeline, the column-sum kernels
+    otherwise); exact on integer data, accumulate honoured separately for dW and db."""
+    ops = _ops()
+    from deepmerge_amd._lib import DM_TN
+    g = torch.Generator(device=DEV); g.manual_seed(M + N)
+    dy = torch.randint(-1, 2, (K, M), device=DEV, generator=g).to(torch.bfloat16)
+    x = torch.randint(-1, 2, (K, N), device=DEV, generator=g).to(torch.bfloat16)
+    db0 = torch.randint(-3, 4, (M,), device=DEV, generator=g).float()
+    for acc_b in (False, True):
+        dw = torch.empty((M, N), device=DEV)
+        db = db0.clone()
+        ops.gemm(DM_TN, dy, x, dw, M, N, K, lda=M, ldb=N, ldc=N, colsum_out=db, colsum_accumulate=acc_b)
+        assert torch.equal(dw, dy.float().T @ x.float())
+        want = dy.float().sum(0) + (db0 if acc_b else 0)
+        assert torch.equal(db, want)
+    with pytest.raises(ValueError):
+        ops.gemm(DM_TN, dy, x, dw, M, N, K, lda=M, ldb=N, ldc=N, colsum_out=torch.empty(M - 1, device=DEV))
