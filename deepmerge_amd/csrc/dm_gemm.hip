@@ -345,9 +345,16 @@ __global__ void splitk_reduce_kernel(const float *__restrict__ slab, float *__re
 __global__ void colsum_rows_reduce_kernel(const float *__restrict__ rows, float *__restrict__ out, int M, int R, int accumulate) {
   const int m = blockIdx.x * blockDim.x + threadIdx.x;
   if (m >= M) return;
-  float s = accumulate ? out[m] : 0.f;
-  for (int r = 0; r < R; ++r) s += rows[(long long)r * M + m];
-  out[m] = s;
+  float s0 = accumulate ? out[m] : 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;     // independent accumulators: loads overlap
+  int r = 0;
+  for (; r + 3 < R; r += 4) {
+    s0 += rows[(long long)r * M + m];
+    s1 += rows[(long long)(r + 1) * M + m];
+    s2 += rows[(long long)(r + 2) * M + m];
+    s3 += rows[(long long)(r + 3) * M + m];
+  }
+  for (; r < R; ++r) s0 += rows[(long long)r * M + m];
+  out[m] = (s0 + s1) + (s2 + s3);
 }
 
 // Generic fp32 kernel for the small / odd-shaped products of the tail (K = 19, N = 100, M = batch): any
@@ -605,7 +612,7 @@ extern "C" int dm_gemm(const DmGemmArgs *a, void *stream) {
   }
   if (a->colsum_a) {
     if (big) {      // fold the pipeline's [split * 4][M] partial rows, in row order
-      hipLaunchKernelGGL(colsum_rows_reduce_kernel, dim3((a->M + 255) / 256), dim3(256), 0, s, cs_region, a->colsum_a, a->M, split * 4,
+      hipLaunchKernelGGL(colsum_rows_reduce_kernel, dim3((a->M + 63) / 64), dim3(64), 0, s, cs_region, a->colsum_a, a->M, split * 4,
                          a->colsum_accumulate);
       DM_LAUNCH_CHECK("dm_gemm(colsum reduce)");
     } else {

@@ -147,8 +147,19 @@ __global__ __launch_bounds__(256) void partial_reduce_kernel(const float *__rest
   const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
   const int j = blockIdx.x * 16 + tx;
   float s = 0.f;
-  if (j < width)
-    for (int r = ty; r < nrows; r += 16) s += partial[(long long)r * width + j];
+  if (j < width) {
+    // four independent accumulators: the loads of a slice are in flight together instead of one per round trip
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int r = ty;
+    for (; r + 48 < nrows; r += 64) {
+      s0 += partial[(long long)r * width + j];
+      s1 += partial[(long long)(r + 16) * width + j];
+      s2 += partial[(long long)(r + 32) * width + j];
+      s3 += partial[(long long)(r + 48) * width + j];
+    }
+    for (; r < nrows; r += 16) s0 += partial[(long long)r * width + j];
+    s = (s0 + s1) + (s2 + s3);
+  }
   red[ty][tx] = s;
   __syncthreads();
   if (ty == 0 && j < width) {

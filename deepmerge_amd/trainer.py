@@ -123,6 +123,7 @@ class PairTrainer:
             self._install_bucket_hooks()
         self._graph = None          # captured step (enable_graph)
         self._graph_warm = 0
+        self._capture = None        # {"side": stream, "hyper": tensor} while a graph with overlapped Adam is being captured
 
     # -- gradient exchange -----------------------------------------------------------------------
     def _install_bucket_hooks(self):
@@ -156,7 +157,22 @@ class PairTrainer:
 
     def _launch_bucket(self, bi: int):
         sl = self.bucket_slices[bi]
-        self._pending.append((bi, dist.all_reduce(self.fp.grad[sl], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)))
+        if self.world > 1:
+            self._pending.append((bi, dist.all_reduce(self.fp.grad[sl], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)))
+        elif self._capture is not None:
+            # single GPU, graph capture: this bucket's gradients are final and its weights are not read again in this
+            # backward -> its Adam update runs on a side stream next to the rest of the backward (Adam is HBM-bound, the
+            # GEMMs are not)
+            cap = self._capture
+            cap["side"].wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(cap["side"]):
+                self._adam_slice(sl, cap["hyper"])
+            self._pending.append((bi, None))
+
+    def _adam_slice(self, sl: slice, hyper_dev):
+        lp = self.fp.flat_lp[sl] if self.fp.flat_lp is not None else None
+        ops.adam_step_dev(self.fp.flat[sl], self.fp.grad[sl], self.m[sl], self.v[sl], hyper_dev, beta1=self.betas[0], beta2=self.betas[1],
+                          eps=self.eps, grad_scale=1.0, param_lp=lp)
 
     def _finish_exchange(self):
         launched = {bi for bi, _ in self._pending}
@@ -164,7 +180,8 @@ class PairTrainer:
             if bi not in launched:
                 self._launch_bucket(bi)
         for _, work in self._pending:
-            work.wait()
+            if work is not None:
+                work.wait()
         self._pending.clear()
         if not self._calibrated:
             # parameters that never receive a gradient (final_features.*, head.* on the designed-feature path) would
@@ -180,17 +197,30 @@ class PairTrainer:
 
     # -- the step ----------------------------------------------------------------------------------
     # -- hipGraph replay of the whole step ---------------------------------------------------------
-    def enable_graph(self, warmup: int = 3):
+    def enable_graph(self, warmup: int = 3, overlap_adam: bool = False, adam_buckets: int = 4):
         """Capture forward + loss + backward + Adam of one step into a hipGraph (torch.cuda.CUDAGraph) after `warmup`
         eager steps, and replay it afterwards: ~330 launches per step collapse into one submission, which removes the
         host-side gaps between the many small kernels.  Needs fixed input shapes; single-GPU only (the bucketed
         exchange of the data-parallel path stays eager)."""
+        # overlap_adam: run Adam bucket by bucket on a side stream (a second branch of the graph) as soon as a bucket's gradients
+        # are final.  Measured on MI355X: 7.10 - 7.26 ms/step against 6.84 ms with the single-branch graph -- the fork / join
+        # edges and the HBM contention cost more than the 0.26 ms of Adam they hide -- so it is off by default
+        # (DM_ADAM_OVERLAP=<buckets> switches it on for experiments).
         if self.world > 1:
             raise RuntimeError("graph replay covers the single-GPU step; the data-parallel exchange runs eagerly")
         if self.fp.flat.device.type != "cuda":
             raise RuntimeError("graph capture needs the parameters on the GPU")
-        self._graph = {"warmup": warmup, "g": None}
+        env = os.environ.get("DM_ADAM_OVERLAP")
+        if env is not None:
+            overlap_adam, adam_buckets = env != "0", (int(env) if env.isdigit() and int(env) > 1 else adam_buckets)
+        self._graph = {"warmup": warmup, "g": None, "overlap_adam": bool(overlap_adam)}
         self._graph_warm = 0
+        if overlap_adam:
+            # Adam per bucket of the flat buffer, launched from the gradient-ready hooks on a side stream of the captured graph
+            # (a graph branch that runs next to the remaining backward).  Bucket boundaries are 16-byte aligned views.
+            self.bucket_slices = self.fp.buckets(adam_buckets)
+            if not self._hooks_installed:
+                self._install_bucket_hooks()
 
     def _graph_step(self, left, left_designed, right, right_designed, flag, lr):
         st = self._graph
@@ -232,10 +262,17 @@ class PairTrainer:
                 else:
                     fa, fb = self.net(st["left"], st["ld"], st["right"], st["rd"])
                 loss = self.criterion(fa, fb, st["flag"])
-                loss.backward()
-                extra = {"param_lp": self.fp.flat_lp} if self.fp.flat_lp is not None else {}
-                ops.adam_step_dev(self.fp.flat, self.fp.grad, self.m, self.v, st["hyper"], beta1=self.betas[0], beta2=self.betas[1],
-                                  eps=self.eps, grad_scale=1.0, **extra)
+                if st["overlap_adam"]:
+                    self._capture = {"side": torch.cuda.Stream(), "hyper": st["hyper"]}
+                    try:
+                        loss.backward()                    # hooks launch Adam bucket by bucket on the side stream
+                        self._finish_exchange()            # buckets that saw no gradient (unused parameters)
+                        torch.cuda.current_stream().wait_stream(self._capture["side"])
+                    finally:
+                        self._capture = None
+                else:
+                    loss.backward()
+                    self._adam_slice(slice(0, self.fp.total), st["hyper"])
                 st["loss"] = loss.detach()
             st["g"] = g
             # capture only records: nothing above has executed yet, the replay below is this step
@@ -275,4 +312,6 @@ class PairTrainer:
         extra = {"param_lp": self.fp.flat_lp} if self.fp.flat_lp is not None else {}
         self.adam_fn(self.fp.flat, self.fp.grad, self.m, self.v, self.step_count, lr=self.lr if lr is None else lr,
                      beta1=self.betas[0], beta2=self.betas[1], eps=self.eps, grad_scale=1.0 / self.world, **extra)
+        if self.world == 1 and self._hooks_installed:
+            self._finish_exchange()        # gradient-ready hooks are installed for the graph's overlapped Adam: reset their counters
         return loss.detach()
