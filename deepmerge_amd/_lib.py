@@ -18,7 +18,7 @@ HEADER_PATH = os.path.join(ROOT, "include", "deepmerge_hip.h")
 
 DM_F32, DM_BF16 = 0, 1
 DM_NT, DM_NN, DM_TN = 0, 1, 2
-DM_EPI_NONE, DM_EPI_GELU, DM_EPI_DGELU = 0, 1, 2
+DM_EPI_NONE, DM_EPI_GELU, DM_EPI_DGELU, DM_EPI_GELU_GRAD, DM_EPI_MUL = 0, 1, 2, 3, 4
 
 _STATUS = {-1: "bad shape", -2: "bad dtype", -3: "bad alignment", -4: "workspace", -5: "HIP error", -6: "unsupported"}
 

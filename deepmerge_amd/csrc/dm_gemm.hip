@@ -433,6 +433,11 @@ __global__ __launch_bounds__(256) void sgemm_small_kernel(const GemmParams p) {
     v = dm_gelu(v);
   } else if (p.epilogue == DM_EPI_DGELU) {
     v *= dm_dgelu(reinterpret_cast<const float *>(p.aux)[ro * p.ldaux + n]);
+  } else if (p.epilogue == DM_EPI_GELU_GRAD) {
+    reinterpret_cast<float *>(p.aux)[ro * p.ldaux + n] = dm_dgelu(v);
+    v = dm_gelu(v);
+  } else if (p.epilogue == DM_EPI_MUL) {
+    v *= reinterpret_cast<const float *>(p.aux)[ro * p.ldaux + n];
   }
   if (p.residual) v += p.residual[ro * p.ldr + n];
   float *c = reinterpret_cast<float *>(p.C) + ro * p.ldc + n;

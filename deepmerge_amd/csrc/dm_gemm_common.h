@@ -47,11 +47,31 @@ __device__ __forceinline__ void dm_gemm_emit(const GemmParams &p, f32x4 v, const
     else dm_store4(reinterpret_cast<bf16_t *>(p.aux) + rb.x + n, v);
 #pragma unroll
     for (int e = 0; e < 4; ++e) v[e] = FAST ? dm_gelu_fast(v[e]) : dm_gelu(v[e]);
-  } else if (p.epilogue == DM_EPI_DGELU) {
+  } else if (p.epilogue == DM_EPI_GELU_GRAD) {
+    f32x4 d;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if constexpr (FAST) {
+        float cdf, pdf;
+        dm_gelu_parts_fast(v[e], cdf, pdf);          // one exp for both
+        d[e] = fmaf(v[e], pdf, cdf);
+        v[e] = v[e] * cdf;
+      } else {
+        d[e] = dm_dgelu(v[e]);
+        v[e] = dm_gelu(v[e]);
+      }
+    }
+    if (p.aux_dtype == DM_F32) dm_store4(reinterpret_cast<float *>(p.aux) + rb.x + n, d);
+    else dm_store4(reinterpret_cast<bf16_t *>(p.aux) + rb.x + n, d);
+  } else if (p.epilogue == DM_EPI_DGELU || p.epilogue == DM_EPI_MUL) {
     f32x4 u = (p.aux_dtype == DM_F32) ? dm_load4(reinterpret_cast<const float *>(p.aux) + rb.x + n)
                                       : dm_load4(reinterpret_cast<const bf16_t *>(p.aux) + rb.x + n);
+    if (p.epilogue == DM_EPI_MUL) {
+      v *= u;
+    } else {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] *= FAST ? dm_dgelu_fast(u[e]) : dm_dgelu(u[e]);
+      for (int e = 0; e < 4; ++e) v[e] *= FAST ? dm_dgelu_fast(u[e]) : dm_dgelu(u[e]);
+    }
   }
   if (p.residual) v += dm_load4(p.residual + rb.r + n);
   if (p.c_dtype == DM_F32) {

@@ -19,7 +19,7 @@ from typing import Optional
 import torch
 
 from . import _lib
-from ._lib import DM_BF16, DM_EPI_DGELU, DM_EPI_GELU, DM_EPI_NONE, DM_F32, DM_NN, DM_NT, DM_TN, DmGemmArgs, check
+from ._lib import DM_BF16, DM_EPI_DGELU, DM_EPI_GELU, DM_EPI_GELU_GRAD, DM_EPI_MUL, DM_EPI_NONE, DM_F32, DM_NN, DM_NT, DM_TN, DmGemmArgs, check
 
 _NUMERICS = "bf16"
 
@@ -379,7 +379,7 @@ class MlpFn(torch.autograd.Function):
         w2c = cast(w2.reshape(N, Hd), x.dtype)
         pre = torch.empty((M, Hd), dtype=x.dtype, device=x.device)
         h = torch.empty((M, Hd), dtype=x.dtype, device=x.device)
-        gemm(DM_NT, x, w1c, h, M, Hd, K, lda=K, ldb=K, ldc=Hd, bias=b1, epilogue=DM_EPI_GELU, aux=pre, ldaux=Hd)
+        gemm(DM_NT, x, w1c, h, M, Hd, K, lda=K, ldb=K, ldc=Hd, bias=b1, epilogue=DM_EPI_GELU_GRAD, aux=pre, ldaux=Hd)
         y = torch.empty((M, N), dtype=out_dtype, device=x.device)
         gemm(DM_NT, h, w2c, y, M, N, Hd, lda=Hd, ldb=Hd, ldc=N, bias=b2,
              residual=None if residual is None else residual.contiguous())
@@ -398,7 +398,7 @@ class MlpFn(torch.autograd.Function):
         # fc2: dW2 = dy^T h, db2 = colsum(dy); dpre = (dy W2) * gelu'(pre)  (DGELU epilogue)
         _, dw2, db2 = _linear_backward(h, w2c, dyo, False, need[3], need[4], ctx.shapes[1])
         dpre = torch.empty((M, Hd), dtype=x.dtype, device=x.device)
-        gemm(DM_NN, dyo, w2c, dpre, M, Hd, N, lda=N, ldb=Hd, ldc=Hd, epilogue=DM_EPI_DGELU, aux=pre, ldaux=Hd)
+        gemm(DM_NN, dyo, w2c, dpre, M, Hd, N, lda=N, ldb=Hd, ldc=Hd, epilogue=DM_EPI_MUL, aux=pre, ldaux=Hd)
         dx, dw1, db1 = _linear_backward(x, w1c, dpre, need[0], need[1], need[2], ctx.shapes[0])
         return dx, dw1, db1, dw2, db2, dres, None
 
@@ -621,7 +621,7 @@ class BlockFn(torch.autograd.Function):
         y2, mean2, rstd2 = layernorm_fwd(x1, n2w, n2b, eps, dtype)
         pre = torch.empty((M, Hd), dtype=dtype, device=dev)
         h = torch.empty((M, Hd), dtype=dtype, device=dev)
-        gemm(DM_NT, y2, w1, h, M, Hd, Cc, lda=Cc, ldb=Cc, ldc=Hd, bias=fc1_b, epilogue=DM_EPI_GELU, aux=pre, ldaux=Hd)
+        gemm(DM_NT, y2, w1, h, M, Hd, Cc, lda=Cc, ldb=Cc, ldc=Hd, bias=fc1_b, epilogue=DM_EPI_GELU_GRAD, aux=pre, ldaux=Hd)
         x2 = torch.empty((M, Cc), dtype=torch.float32, device=dev)
         gemm(DM_NT, h, w2, x2, M, Cc, Hd, lda=Hd, ldb=Hd, ldc=Cc, bias=fc2_b, residual=x1)
         ctx.save_for_backward(x2d, mean1, rstd1, y1, qkv, o, lse, bias, bias_t, index32, x1, mean2, rstd2, y2, pre, h,
@@ -649,7 +649,7 @@ class BlockFn(torch.autograd.Function):
         db2, k_b2 = _grad_out(P_fc2_b, (Cc,), dev)
         gemm(DM_TN, dy, h, dw2, Cc, Hd, M, lda=Cc, ldb=Hd, ldc=Hd, accumulate=k_w2, colsum_out=db2, colsum_accumulate=k_b2)
         dpre = torch.empty((M, Hd), dtype=dtype, device=dev)
-        gemm(DM_NN, dy, w2, dpre, M, Hd, Cc, lda=Cc, ldb=Hd, ldc=Hd, epilogue=DM_EPI_DGELU, aux=pre, ldaux=Hd)
+        gemm(DM_NN, dy, w2, dpre, M, Hd, Cc, lda=Cc, ldb=Hd, ldc=Hd, epilogue=DM_EPI_MUL, aux=pre, ldaux=Hd)
         dw1, k_w1 = _grad_out(P_fc1_w, (Hd, Cc), dev)
         db1, k_b1 = _grad_out(P_fc1_b, (Hd,), dev)
         gemm(DM_TN, dpre, y2, dw1, Hd, Cc, M, lda=Hd, ldb=Cc, ldc=Cc, accumulate=k_w1, colsum_out=db1, colsum_accumulate=k_b1)

@@ -59,6 +59,9 @@ const char *dm_arch(void);
  *   aux[m,n] = v (as aux_dtype)      if epilogue == DM_EPI_GELU     (pre-activation saved for backward)
  *   v  = gelu_erf(v)                 if epilogue == DM_EPI_GELU     (nn.GELU, erf form)
  *   v *= gelu_erf'(aux[m,n])         if epilogue == DM_EPI_DGELU    (backward through GELU)
+ *   aux[m,n] = gelu_erf'(v); v = gelu_erf(v)   if epilogue == DM_EPI_GELU_GRAD  (the derivative is saved instead of the
+ *                                       pre-activation: same bytes, and the backward epilogue becomes one multiply)
+ *   v *= aux[m,n]                    if epilogue == DM_EPI_MUL      (backward through GELU with the saved derivative)
  *   v += residual[m,n]               if residual != NULL (fp32)
  *   v += C_old[m,n]                  if accumulate (C must be fp32)
  *   C[m,n] = v (as c_dtype)
@@ -67,7 +70,7 @@ const char *dm_arch(void);
  * kernel that applies the epilogue.  split_k == 0 lets the library choose.
  */
 typedef enum { DM_NT = 0, DM_NN = 1, DM_TN = 2 } DmGemmLayout;
-typedef enum { DM_EPI_NONE = 0, DM_EPI_GELU = 1, DM_EPI_DGELU = 2 } DmEpilogue;
+typedef enum { DM_EPI_NONE = 0, DM_EPI_GELU = 1, DM_EPI_DGELU = 2, DM_EPI_GELU_GRAD = 3, DM_EPI_MUL = 4 } DmEpilogue;
 
 typedef struct {
   int32_t layout;        /* DmGemmLayout */

@@ -84,6 +84,18 @@ def test_gemm_epilogues(mode):
     x = aux.double().requires_grad_(True)
     torch.nn.functional.gelu(x).sum().backward()
     np.testing.assert_allclose(out2.cpu().double().numpy(), (base * x.grad).numpy(), rtol=1e-5, atol=1e-5 if mode == "fp32" else 1e-4)
+    # GELU with the derivative saved instead of the pre-activation, and the matching multiply epilogue
+    from deepmerge_amd._lib import DM_EPI_GELU_GRAD, DM_EPI_MUL
+    gp = torch.empty((M, N), device=DEV, dtype=dt)
+    h2 = torch.empty((M, N), device=DEV, dtype=dt)
+    ops.gemm(DM_NT, A, B_, h2, M, N, K, lda=K, ldb=K, ldc=N, bias=bias.to(DEV), epilogue=DM_EPI_GELU_GRAD, aux=gp, ldaux=N)
+    uu = u.clone().requires_grad_(True)
+    torch.nn.functional.gelu(uu).sum().backward()
+    np.testing.assert_allclose(h2.float().cpu().double().numpy(), torch.nn.functional.gelu(u).numpy(), rtol=tol, atol=tol)
+    np.testing.assert_allclose(gp.float().cpu().double().numpy(), uu.grad.numpy(), rtol=tol, atol=tol)
+    out4 = torch.empty((M, N), device=DEV)
+    ops.gemm(DM_NT, A, B_, out4, M, N, K, lda=K, ldb=K, ldc=N, epilogue=DM_EPI_MUL, aux=aux.to(DEV), ldaux=N)
+    np.testing.assert_allclose(out4.cpu().double().numpy(), (base * aux.double()).numpy(), rtol=1e-6, atol=1e-6)
     # accumulate
     out3 = res.clone().to(DEV)
     ops.gemm(DM_NT, A, B_, out3, M, N, K, lda=K, ldb=K, ldc=N, accumulate=True)
