@@ -316,22 +316,29 @@ def _as_operand(t: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
     raise ValueError(f"cannot use a {t.dtype} gradient with {dtype} operands")
 
 
-def _linear_backward(x, w, dy, need_dx, need_dw, need_db, wshape):
-    """dx = dy W (NN), dW = dy^T x (TN, split-K), db = column sums -- autograd of y = x W^T + b."""
+def _linear_backward(x, w, dy, need_dx, need_dw, need_db, wshape, wparam=None, bparam=None):
+    """dx = dy W (NN), dW = dy^T x (TN, split-K), db = column sums -- autograd of y = x W^T + b.
+    wparam / bparam: the nn.Parameters behind w / b; when they have a usable gradient sink the results are accumulated
+    there and None is returned for them."""
     M, K = x.shape
     N = w.shape[0]
     dx = dw = db = None
     if need_dx:
         dx = torch.empty((M, K), dtype=x.dtype, device=x.device)
         gemm(DM_NN, dy, w, dx, M, K, N, lda=N, ldb=K, ldc=K)
+    wsink = _multi_use_sink(wparam, (N, K)) if need_dw else None
+    bsink = _multi_use_sink(bparam, (N,)) if need_db else None
     if need_db:
-        db = torch.empty(N, dtype=torch.float32, device=x.device)
+        db = bsink if bsink is not None else torch.empty(N, dtype=torch.float32, device=x.device)
     if need_dw:
-        dw = torch.empty((N, K), dtype=torch.float32, device=x.device)
-        gemm(DM_TN, dy, x, dw, N, K, M, lda=N, ldb=K, ldc=K, colsum_out=db)       # db rides on the wgrad when it can
-        dw = dw.reshape(wshape)
+        dw = wsink if wsink is not None else torch.empty((N, K), dtype=torch.float32, device=x.device)
+        gemm(DM_TN, dy, x, dw, N, K, M, lda=N, ldb=K, ldc=K, accumulate=wsink is not None,
+             colsum_out=db, colsum_accumulate=bsink is not None)                   # db rides on the wgrad when it can
+        dw = None if wsink is not None else dw.reshape(wshape)
     elif need_db:
-        colsum(dy, db)
+        colsum(dy, db, accumulate=bsink is not None)
+    if bsink is not None:
+        db = None
     return dx, dw, db
 
 
@@ -347,12 +354,13 @@ class LinearFn(torch.autograd.Function):
         x = x.contiguous()
         M, K = x.shape
         N = weight.shape[0]
-        w = cast(weight.reshape(N, K), x.dtype)
+        w = lp_weight(weight, x.dtype, (N, K))           # the trainer's bf16 mirror when there is one, else a cast
         y = torch.empty((M, N), dtype=out_dtype, device=x.device)
         gemm(DM_NT, x, w, y, M, N, K, lda=K, ldb=K, ldc=N, bias=bias,
              residual=None if residual is None else residual.contiguous())
         ctx.save_for_backward(x, w)
         ctx.has_bias, ctx.wshape = bias is not None, weight.shape
+        ctx.params = (weight, bias)
         return y
 
     @staticmethod
@@ -361,7 +369,7 @@ class LinearFn(torch.autograd.Function):
         dres = dy if ctx.needs_input_grad[3] else None
         dyo = _as_operand(dy, x.dtype)
         dx, dw, db = _linear_backward(x, w, dyo, ctx.needs_input_grad[0], ctx.needs_input_grad[1],
-                                      ctx.has_bias and ctx.needs_input_grad[2], ctx.wshape)
+                                      ctx.has_bias and ctx.needs_input_grad[2], ctx.wshape, *ctx.params)
         return dx, dw, db, dres, None
 
 
@@ -411,11 +419,17 @@ class LayerNormFn(torch.autograd.Function):
         x = x.contiguous()
         y, mean, rstd = layernorm_fwd(x, gamma, beta, eps, out_dtype)
         ctx.save_for_backward(x, gamma, mean, rstd)
+        ctx.params = (gamma, beta)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, gamma, mean, rstd = ctx.saved_tensors
+        C = gamma.numel()
+        gs, bs = _multi_use_sink(ctx.params[0], (C,)), _multi_use_sink(ctx.params[1], (C,))
+        if gs is not None and bs is not None and ctx.needs_input_grad[1] and ctx.needs_input_grad[2]:
+            r = layernorm_bwd(dy.contiguous(), x, gamma, mean, rstd, dgamma=gs, dbeta=bs, accumulate=True)
+            return r[0], None, None, None, None
         dx, dg, db = layernorm_bwd(dy.contiguous(), x, gamma, mean, rstd)
         return dx, dg, db, None, None
 
@@ -579,6 +593,19 @@ def _grad_out(param: torch.Tensor, shape, device):
     if sink is not None:
         return sink.view(shape), True
     return torch.empty(shape, dtype=torch.float32, device=device), False
+
+
+def _multi_use_sink(param, shape):
+    """Gradient sink for the generic Functions (Linear, Mlp, LayerNorm), whose parameters may be used several times per step
+    (the shared `norm`, the aux heads): their contributions accumulate into the trainer's flat buffer directly -- but only
+    when no gradient-ready hooks are installed (single GPU).  With hooks (data parallel) the bucket exchange must see the
+    COMPLETE gradient, which only autograd's own accumulation guarantees for a multi-use parameter."""
+    if param is None:
+        return None
+    sink = getattr(param, "_dm_grad_sink", None)
+    if sink is None or getattr(param, "_dm_grad_ready", None) is not None:
+        return None
+    return sink.view(shape)
 
 
 def _grad_done(param: torch.Tensor, g: torch.Tensor, direct: bool):
