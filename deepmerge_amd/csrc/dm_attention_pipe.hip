@@ -55,11 +55,13 @@ __global__ __launch_bounds__(512) void attn_fwd_pipe_kernel(const AttnPipeParams
   f32x4 bias[NKT];
 #pragma unroll
   for (int kt = 0; kt < NKT; ++kt) bias[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
   if (p.bias && wave_live) {
     const float *brow = p.bias + ((long long)h * N + q) * N + 4 * g;
 #pragma unroll
-    for (int kt = 0; kt < NKT; ++kt) bias[kt] = dm_load4(brow + 16 * kt);
+    for (int kt = 0; kt < NKT; ++kt) bias[kt] = dm_load4(brow + 16 * kt) * LOG2E;     // scores are kept in log2 units: exp2 is one instruction
   }
+  const float scale2 = p.scale * LOG2E;
 
   // ---- DMA addressing: one wave-instruction = 8 keys x 128 B; every wave stages NKT/4 instructions of K and of V --------
   // lane -> key row (lane >> 3) of the instruction, 16-byte position lane & 7; the swizzles are applied on the source chunk
@@ -130,7 +132,7 @@ __global__ __launch_bounds__(512) void attn_fwd_pipe_kernel(const AttnPipeParams
         f32x4 a = {0.f, 0.f, 0.f, 0.f};
         mma<bf16_t>(a, fq[0], *reinterpret_cast<const u32x4 *>(krow + kswz0));
         mma<bf16_t>(a, fq[1], *reinterpret_cast<const u32x4 *>(krow + kswz1));
-        s[kt] = a * p.scale + bias[kt];
+        s[kt] = a * scale2 + bias[kt];
       }
       // ---- exact softmax over the row (64 values in this lane, 4 lanes per row) -----------------------------------------
       float m = -INFINITY;
@@ -142,20 +144,20 @@ __global__ __launch_bounds__(512) void attn_fwd_pipe_kernel(const AttnPipeParams
       for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float e = __expf(s[kt][r] - m);
+          const float e = __builtin_amdgcn_exp2f(s[kt][r] - m);
           s[kt][r] = e;
           l += e;
         }
       l = row_sum4(l);
       const float inv = 1.f / l;
-      lse_prev = m + logf(l);
+      lse_prev = (m + __builtin_amdgcn_logf(l)) * LN2;          // natural-log units for the backward kernels
       // ---- O = P V ---------------------------------------------------------------------------------------------------
       f32x4 o[4];
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int mb = 0; mb < NKT / 2; ++mb) {
-        const f32x4 pa = s[2 * mb] * inv, pb = s[2 * mb + 1] * inv;
+        const f32x4 pa = s[2 * mb], pb = s[2 * mb + 1];           // unnormalised (<= 1): O is scaled by 1 / l at the end
         const bf16x8 pk = {(bf16_t)pa[0], (bf16_t)pa[1], (bf16_t)pa[2], (bf16_t)pa[3], (bf16_t)pb[0], (bf16_t)pb[1], (bf16_t)pb[2], (bf16_t)pb[3]};
         const u32x4 pf = __builtin_bit_cast(u32x4, pk);
         const char *vblk = vimg + (32 * mb + vrow) * 128 + 8 * vp;
@@ -168,7 +170,7 @@ __global__ __launch_bounds__(512) void attn_fwd_pipe_kernel(const AttnPipeParams
         }
       }
 #pragma unroll
-      for (int dt = 0; dt < 4; ++dt) o_prev[dt] = o[dt];
+      for (int dt = 0; dt < 4; ++dt) o_prev[dt] = o[dt] * inv;
     }
     fq[0] = fq_next[0];
     fq[1] = fq_next[1];
@@ -248,11 +250,13 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_pipe_kernel(const AttnPipeBwd
   f32x4 bias[NKT];
 #pragma unroll
   for (int kt = 0; kt < NKT; ++kt) bias[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  constexpr float LOG2E = 1.4426950408889634f;
   if (p.bias && wave_live) {
     const float *brow = p.bias + ((long long)h * N + q) * N + 4 * g;
 #pragma unroll
-    for (int kt = 0; kt < NKT; ++kt) bias[kt] = dm_load4(brow + 16 * kt);
+    for (int kt = 0; kt < NKT; ++kt) bias[kt] = dm_load4(brow + 16 * kt) * LOG2E;     // log2 units, see the forward kernel
   }
+  const float scale2 = p.scale * LOG2E;
 
   const int dkey = lane >> 3;
   auto stage = [&](int b, int buf) {
@@ -281,7 +285,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_pipe_kernel(const AttnPipeBwd
       fdo[ks] = wave_live ? *reinterpret_cast<const u32x4 *>(dout + orow + c) : (u32x4){0u, 0u, 0u, 0u};
       fo[ks] = wave_live ? *reinterpret_cast<const u32x4 *>(outp + orow + c) : (u32x4){0u, 0u, 0u, 0u};
     }
-    lse = wave_live ? p.lse[((long long)b * H + h) * N + q] : 0.f;
+    lse = wave_live ? p.lse[((long long)b * H + h) * N + q] * LOG2E : 0.f;
   };
 
   u32x4 fq[2], fdo[2], fo[2], fq_n[2], fdo_n[2], fo_n[2];
@@ -325,9 +329,9 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_pipe_kernel(const AttnPipeBwd
             mma<bf16_t>(sc, fq[ks], read_row(kimg, fa, kt, ks));
             mma<bf16_t>(a, fdo[ks], read_row(vimg, fa, kt, ks));
           }
-          sc = sc * p.scale + bias[kt];
+          sc = sc * scale2 + bias[kt];
 #pragma unroll
-          for (int r = 0; r < 4; ++r) ds[u][r] = __expf(sc[r] - lse) * (a[r] - dl);
+          for (int r = 0; r < 4; ++r) ds[u][r] = __builtin_amdgcn_exp2f(sc[r] - lse) * (a[r] - dl);
         }
         const u32x4 fds = pack2(ds[0], ds[1]);
 #pragma unroll
@@ -366,7 +370,8 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_pipe_kernel(const AttnPipeBw
   FragAddr fa;
   fa.init(lane);
 
-  // bias^T rows of this wave's keys: biasT[qt][r] = bias[h][q = 16 qt + 4g + r][key]  (strided, once per workgroup)
+  // bias^T rows of this wave's keys: biasT[qt][r] = bias[h][q = 16 qt + 4g + r][key]  (strided, once per workgroup).
+  // (Natural-log units here: the log2-unit form of the other two kernels costs this one its last free registers.)
   f32x4 biasT[NKT], hacc[NKT];
 #pragma unroll
   for (int qt = 0; qt < NKT; ++qt) { biasT[qt] = (f32x4){0.f, 0.f, 0.f, 0.f}; hacc[qt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
