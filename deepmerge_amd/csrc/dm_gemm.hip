@@ -429,7 +429,7 @@ __global__ __launch_bounds__(256) void sgemm_small_kernel(const GemmParams p) {
   if (p.bias) v += p.bias[n];
   const long long ro = (long long)m;
   if (p.epilogue == DM_EPI_GELU) {
-    reinterpret_cast<float *>(p.aux)[ro * p.ldaux + n] = v;
+    if (p.aux) reinterpret_cast<float *>(p.aux)[ro * p.ldaux + n] = v;
     v = dm_gelu(v);
   } else if (p.epilogue == DM_EPI_DGELU) {
     v *= dm_dgelu(reinterpret_cast<const float *>(p.aux)[ro * p.ldaux + n]);
@@ -499,7 +499,8 @@ extern "C" int dm_gemm(const DmGemmArgs *a, void *stream) {
   DM_REQUIRE(a->c_dtype == DM_F32 || a->c_dtype == DM_BF16, DM_ERR_BAD_DTYPE, "dm_gemm: bad c_dtype %d", a->c_dtype);
   DM_REQUIRE(a->A && a->B && a->C, DM_ERR_BAD_SHAPE, "dm_gemm: null operand");
   DM_REQUIRE(!(a->accumulate && a->c_dtype != DM_F32), DM_ERR_BAD_DTYPE, "dm_gemm: accumulate needs an fp32 C");
-  DM_REQUIRE(a->epilogue == DM_EPI_NONE || a->aux != nullptr, DM_ERR_BAD_SHAPE, "dm_gemm: GELU epilogues need aux");
+  DM_REQUIRE(a->epilogue == DM_EPI_NONE || a->epilogue == DM_EPI_GELU || a->aux != nullptr, DM_ERR_BAD_SHAPE,
+             "dm_gemm: this epilogue needs aux (only DM_EPI_GELU may run without one: inference)");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
 
   GemmParams p{};

@@ -43,8 +43,10 @@ template <bool FAST>
 __device__ __forceinline__ void dm_gemm_emit(const GemmParams &p, f32x4 v, const DmGemmRow &rb, int n) {
   if (p.bias) v += dm_load4(p.bias + n);
   if (p.epilogue == DM_EPI_GELU) {
-    if (p.aux_dtype == DM_F32) dm_store4(reinterpret_cast<float *>(p.aux) + rb.x + n, v);
-    else dm_store4(reinterpret_cast<bf16_t *>(p.aux) + rb.x + n, v);
+    if (p.aux) {      // aux == NULL: inference, nothing is saved for a backward pass
+      if (p.aux_dtype == DM_F32) dm_store4(reinterpret_cast<float *>(p.aux) + rb.x + n, v);
+      else dm_store4(reinterpret_cast<bf16_t *>(p.aux) + rb.x + n, v);
+    }
 #pragma unroll
     for (int e = 0; e < 4; ++e) v[e] = FAST ? dm_gelu_fast(v[e]) : dm_gelu(v[e]);
   } else if (p.epilogue == DM_EPI_GELU_GRAD) {

@@ -646,9 +646,13 @@ class BlockFn(torch.autograd.Function):
         x1 = torch.empty((M, Cc), dtype=torch.float32, device=dev)
         gemm(DM_NT, o.view(M, Cc), wp, x1, M, Cc, Cc, lda=Cc, ldb=Cc, ldc=Cc, bias=proj_b, residual=x2d)
         y2, mean2, rstd2 = layernorm_fwd(x1, n2w, n2b, eps, dtype)
-        pre = torch.empty((M, Hd), dtype=dtype, device=dev)
         h = torch.empty((M, Hd), dtype=dtype, device=dev)
-        gemm(DM_NT, y2, w1, h, M, Hd, Cc, lda=Cc, ldb=Cc, ldc=Hd, bias=fc1_b, epilogue=DM_EPI_GELU_GRAD, aux=pre, ldaux=Hd)
+        if any(ctx.needs_input_grad):
+            pre = torch.empty((M, Hd), dtype=dtype, device=dev)       # GELU'(pre-activation), saved for backward
+            gemm(DM_NT, y2, w1, h, M, Hd, Cc, lda=Cc, ldb=Cc, ldc=Hd, bias=fc1_b, epilogue=DM_EPI_GELU_GRAD, aux=pre, ldaux=Hd)
+        else:                                                         # inference (torch.no_grad / frozen): nothing to save
+            pre = None
+            gemm(DM_NT, y2, w1, h, M, Hd, Cc, lda=Cc, ldb=Cc, ldc=Hd, bias=fc1_b, epilogue=DM_EPI_GELU)
         x2 = torch.empty((M, Cc), dtype=torch.float32, device=dev)
         gemm(DM_NT, h, w2, x2, M, Cc, Hd, lda=Hd, ldb=Hd, ldc=Cc, bias=fc2_b, residual=x1)
         ctx.save_for_backward(x2d, mean1, rstd1, y1, qkv, o, lse, bias, bias_t, index32, x1, mean2, rstd2, y2, pre, h,

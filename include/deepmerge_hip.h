@@ -56,7 +56,8 @@ const char *dm_arch(void);
  *         DM_TN  C[m,n] = sum_k A[k,m] * B[k,n]   (wgrad    dW = dy^T x)
  * epilogue, applied in this order on the fp32 accumulator v of element (m,n):
  *   v += bias[n]                     if bias != NULL
- *   aux[m,n] = v (as aux_dtype)      if epilogue == DM_EPI_GELU     (pre-activation saved for backward)
+ *   aux[m,n] = v (as aux_dtype)      if epilogue == DM_EPI_GELU     (pre-activation saved for backward; aux may be NULL:
+ *                                       inference, nothing saved)
  *   v  = gelu_erf(v)                 if epilogue == DM_EPI_GELU     (nn.GELU, erf form)
  *   v *= gelu_erf'(aux[m,n])         if epilogue == DM_EPI_DGELU    (backward through GELU)
  *   aux[m,n] = gelu_erf'(v); v = gelu_erf(v)   if epilogue == DM_EPI_GELU_GRAD  (the derivative is saved instead of the
