@@ -250,6 +250,18 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T *__restrict__ X, lo
   }
 }
 
+// any N / leading dimension (odd layer widths such as Nets.py's 250 and 10): one thread per column and row slice
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_generic_kernel(const T *__restrict__ X, long long ldx, float *__restrict__ partial,
+                                                             int M, int N, int rows_per_slice) {
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  if (n >= N) return;
+  const int r0 = blockIdx.y * rows_per_slice, r1 = min(M, r0 + rows_per_slice);
+  float s = 0.f;
+  for (int r = r0; r < r1; ++r) s += (float)X[(long long)r * ldx + n];
+  partial[(long long)blockIdx.y * N + n] = s;
+}
+
 // ---------------------------------------------------------------------------------------------
 // cast / patchify
 // ---------------------------------------------------------------------------------------------
@@ -534,17 +546,22 @@ extern "C" int64_t dm_colsum_partial_floats(int32_t N) { return (int64_t)CS_MAX_
 
 extern "C" int dm_colsum(const void *X, int32_t dtype, int64_t ldx, float *out, int32_t M, int32_t N, int32_t accumulate,
                          float *partial, void *stream) {
-  DM_REQUIRE(M > 0 && N > 0 && N % 4 == 0 && ldx % 4 == 0, DM_ERR_BAD_SHAPE, "dm_colsum: M=%d N=%d ldx=%lld", M, N, (long long)ldx);
+  DM_REQUIRE(M > 0 && N > 0 && ldx >= N, DM_ERR_BAD_SHAPE, "dm_colsum: M=%d N=%d ldx=%lld", M, N, (long long)ldx);
+  const bool vec = (N % 4 == 0) && (ldx % 4 == 0) && dm_aligned16(X);
   DM_REQUIRE(X && out && partial, DM_ERR_BAD_SHAPE, "dm_colsum: null pointer");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   int slices = (M + 255) / 256;
   if (slices > CS_MAX_SLICES) slices = CS_MAX_SLICES;
   const int rps = (M + slices - 1) / slices;
   slices = (M + rps - 1) / rps;
-  dim3 grid((N + 63) / 64, slices);
-  if (dtype == DM_F32) hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, s, (const float *)X, (long long)ldx, partial, M, N, rps);
-  else if (dtype == DM_BF16) hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t *)X, (long long)ldx, partial, M, N, rps);
-  else DM_REQUIRE(false, DM_ERR_BAD_DTYPE, "dm_colsum: bad dtype %d", dtype);
+  dim3 grid((N + 63) / 64, slices), ggrid((N + 255) / 256, slices);
+  if (dtype == DM_F32) {
+    if (vec) hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, s, (const float *)X, (long long)ldx, partial, M, N, rps);
+    else hipLaunchKernelGGL(colsum_generic_kernel<float>, ggrid, dim3(256), 0, s, (const float *)X, (long long)ldx, partial, M, N, rps);
+  } else if (dtype == DM_BF16) {
+    if (vec) hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t *)X, (long long)ldx, partial, M, N, rps);
+    else hipLaunchKernelGGL(colsum_generic_kernel<bf16_t>, ggrid, dim3(256), 0, s, (const bf16_t *)X, (long long)ldx, partial, M, N, rps);
+  } else DM_REQUIRE(false, DM_ERR_BAD_DTYPE, "dm_colsum: bad dtype %d", dtype);
   DM_LAUNCH_CHECK("dm_colsum");
   hipLaunchKernelGGL(partial_reduce_kernel, dim3((N + 15) / 16), dim3(256), 0, s, partial, out, out, slices, N, N, accumulate);
   DM_LAUNCH_CHECK("dm_colsum(reduce)");

@@ -418,12 +418,38 @@ def gen_vit(vit_model, Losses):
     print("model_vit.npz", len(fx))
 
 
+def gen_nets():
+    """Nets.MLP / Nets.FC (MNIST sandbox); Nets.py only needs torch."""
+    sys.path.insert(0, REF)
+    import Nets  # noqa
+    fx = {}
+    m = Nets.MLP()
+    load_det_weights(m, "nets.mlp.")
+    x = t("nets.x", (37, 784), "unit").requires_grad_(True)
+    a, b = m(x)
+    (a.sum() * 1.5 + (b * b).sum()).backward()
+    add(fx, "mlp/fc3_map", a); add(fx, "mlp/fc2_map", b); add(fx, "mlp/dx", x.grad)
+    for n, p in m.named_parameters():
+        add(fx, "mlp/grad/" + n, p.grad)
+    fx["mlp/keys"] = np.array(list(m.state_dict().keys()))
+    f = Nets.FC()
+    load_det_weights(f, "nets.fc.")
+    y = t("nets.y", (37, 250), "normal").requires_grad_(True)
+    o = f(y)
+    (o * o).sum().backward()
+    add(fx, "fc/out", o); add(fx, "fc/dy", y.grad)
+    for n, p in f.named_parameters():
+        add(fx, "fc/grad/" + n, p.grad)
+    np.savez_compressed(os.path.join(HERE, "model_nets.npz"), **fx)
+    print("model_nets.npz", len(fx))
+
+
 def main():
     warnings.filterwarnings("ignore")
     torch.manual_seed(0)
     torch.set_num_threads(8)
     S2F, vit_model, Losses = import_reference()
-    which = sys.argv[1:] or ["relpos", "ops", "model", "vit", "variants", "aux"]
+    which = sys.argv[1:] or ["relpos", "ops", "model", "vit", "variants", "aux", "nets"]
     if "relpos" in which:
         gen_relpos(S2F)
     if "ops" in which:
@@ -436,7 +462,10 @@ def main():
         gen_variants(S2F, Losses)
     if "aux" in which:
         gen_aux(S2F, Losses)
+    if "nets" in which:
+        gen_nets()
 
 
 if __name__ == "__main__":
     main()
+
