@@ -34,10 +34,12 @@ __device__ __forceinline__ float row_sum4(float v) {
   return v + __shfl_xor(v, 32, 64);
 }
 
-template <int NKT>
+// RAGGED: N is not NKT * 16 (ViT's 197 / 198, v5's 193): tokens >= N are zero-filled by the DMA descriptor and masked.
+template <int NKT, bool RAGGED>
 __global__ __launch_bounds__(512) void attn_fwd_pipe_kernel(const AttnPipeParams p, int bchunk) {
-  constexpr int N = NKT * 16;
-  constexpr int IMG = N * 128;                    // one K or V image
+  constexpr int NP = NKT * 16;                    // padded token count (LDS images, tile loops)
+  const int N = RAGGED ? p.N : NP;
+  constexpr int IMG = NP * 128;                   // one K or V image
   extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 buffers][K image | V image]
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -47,7 +49,8 @@ __global__ __launch_bounds__(512) void attn_fwd_pipe_kernel(const AttnPipeParams
   const int b0 = chunk * bchunk, b1 = min(p.B, b0 + bchunk);
   if (b0 >= b1) return;
   const int q = rb * ROWS + wave * 16 + li;       // this lane's query row
-  const bool wave_live = rb * ROWS + wave * 16 < N;          // N % 16 == 0: a wave is entirely live or entirely idle
+  const bool wave_live = rb * ROWS + wave * 16 < N;          // a wave with no valid row only takes part in the DMA / barriers
+  const bool row_ok = q < N;                                // (ragged N: the last live wave has some invalid rows)
   const long long tok_stride = 3LL * H * HD;     // elements between consecutive tokens of qkv
   const bf16_t *qkv = reinterpret_cast<const bf16_t *>(p.qkv);
 
@@ -56,10 +59,18 @@ __global__ __launch_bounds__(512) void attn_fwd_pipe_kernel(const AttnPipeParams
 #pragma unroll
   for (int kt = 0; kt < NKT; ++kt) bias[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
   constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
-  if (p.bias && wave_live) {
+  if (p.bias && wave_live && row_ok) {
     const float *brow = p.bias + ((long long)h * N + q) * N + 4 * g;
 #pragma unroll
-    for (int kt = 0; kt < NKT; ++kt) bias[kt] = dm_load4(brow + 16 * kt) * LOG2E;     // scores are kept in log2 units: exp2 is one instruction
+    for (int kt = 0; kt < NKT; ++kt) {               // scores are kept in log2 units: exp2 is one instruction
+      if constexpr (!RAGGED) {
+        bias[kt] = dm_load4(brow + 16 * kt) * LOG2E;
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (16 * kt + 4 * g + r < N) bias[kt][r] = brow[16 * kt + r] * LOG2E;
+      }
+    }
   }
   const float scale2 = p.scale * LOG2E;
 
@@ -74,9 +85,9 @@ __global__ __launch_bounds__(512) void attn_fwd_pipe_kernel(const AttnPipeParams
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t *>(base), 0, (int)(N * tok_stride * 2), 0x00020000);
     char *kimg = smem + buf * (2 * IMG), *vimg = kimg + IMG;
 #pragma unroll
-    for (int j = 0; j < NKT / 4; ++j) {
+    for (int j = 0; j < (NKT + 3) / 4; ++j) {
       const int inst = wave + 8 * j;                                // instruction index: keys 8*inst .. 8*inst+7
-      if (inst < N / 8) {
+      if (inst < NP / 8) {
         const unsigned rowoff = (unsigned)((8 * inst + dkey) * tok_stride * 2);
         DM_LDS_DMA(rs, kimg + inst * 1024, rowoff + (unsigned)(1 * H * HD * 2) + srcK, 0);
         DM_LDS_DMA(rs, vimg + inst * 1024, rowoff + (unsigned)(2 * H * HD * 2) + srcV, 0);
@@ -87,7 +98,7 @@ __global__ __launch_bounds__(512) void attn_fwd_pipe_kernel(const AttnPipeParams
     const bf16_t *qrow = qkv + ((long long)b * N + q) * tok_stride + (long long)h * HD;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
-      fq[ks] = wave_live ? *reinterpret_cast<const u32x4 *>(qrow + (4 * ks + g) * 8) : (u32x4){0u, 0u, 0u, 0u};
+      fq[ks] = (wave_live && row_ok) ? *reinterpret_cast<const u32x4 *>(qrow + (4 * ks + g) * 8) : (u32x4){0u, 0u, 0u, 0u};
   };
 
   // fragment offsets inside the images
@@ -104,7 +115,7 @@ __global__ __launch_bounds__(512) void attn_fwd_pipe_kernel(const AttnPipeParams
   f32x4 o_prev[4];
   float lse_prev = 0.f;
   auto write_back = [&](int b) {
-    if (!wave_live) return;
+    if (!wave_live || !row_ok) return;
     bf16_t *orow = reinterpret_cast<bf16_t *>(p.out) + ((long long)b * N + q) * H * HD + (long long)h * HD;
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) dm_store4(orow + dt * 16 + 4 * g, o_prev[dt]);
@@ -133,6 +144,13 @@ __global__ __launch_bounds__(512) void attn_fwd_pipe_kernel(const AttnPipeParams
         mma<bf16_t>(a, fq[0], *reinterpret_cast<const u32x4 *>(krow + kswz0));
         mma<bf16_t>(a, fq[1], *reinterpret_cast<const u32x4 *>(krow + kswz1));
         s[kt] = a * scale2 + bias[kt];
+        if constexpr (RAGGED) {                      // keys past N (zero rows of the image) take no probability mass
+          if (16 * kt + 16 > N) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (16 * kt + 4 * g + r >= N) s[kt][r] = -INFINITY;
+          }
+        }
       }
       // ---- exact softmax over the row (64 values in this lane, 4 lanes per row) -----------------------------------------
       float m = -INFINITY;
@@ -226,10 +244,11 @@ __device__ __forceinline__ float dot8(const u32x4 &x, const u32x4 &y) {
 }
 
 // ---- dQ (rows of the workgroup are queries) ---------------------------------------------------------------------------------
-template <int NKT>
+template <int NKT, bool RAGGED>
 __global__ __launch_bounds__(512) void attn_bwd_dq_pipe_kernel(const AttnPipeBwdParams p, int bchunk) {
-  constexpr int N = NKT * 16;
-  constexpr int IMG = N * 128;
+  constexpr int NP = NKT * 16;
+  const int N = RAGGED ? p.N : NP;
+  constexpr int IMG = NP * 128;
   extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 buffers][K image | V image]
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -240,6 +259,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_pipe_kernel(const AttnPipeBwd
   if (b0 >= b1) return;
   const int q = rb * ROWS + wave * 16 + li;
   const bool wave_live = rb * ROWS + wave * 16 < N;
+  const bool row_ok = q < N;
   const long long tok_stride = 3LL * H * HD;
   const bf16_t *qkv = reinterpret_cast<const bf16_t *>(p.qkv);
   const bf16_t *outp = reinterpret_cast<const bf16_t *>(p.out);
@@ -251,10 +271,18 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_pipe_kernel(const AttnPipeBwd
 #pragma unroll
   for (int kt = 0; kt < NKT; ++kt) bias[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
   constexpr float LOG2E = 1.4426950408889634f;
-  if (p.bias && wave_live) {
+  if (p.bias && wave_live && row_ok) {
     const float *brow = p.bias + ((long long)h * N + q) * N + 4 * g;
 #pragma unroll
-    for (int kt = 0; kt < NKT; ++kt) bias[kt] = dm_load4(brow + 16 * kt) * LOG2E;     // log2 units, see the forward kernel
+    for (int kt = 0; kt < NKT; ++kt) {               // log2 units, see the forward kernel
+      if constexpr (!RAGGED) {
+        bias[kt] = dm_load4(brow + 16 * kt) * LOG2E;
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (16 * kt + 4 * g + r < N) bias[kt][r] = brow[16 * kt + r] * LOG2E;
+      }
+    }
   }
   const float scale2 = p.scale * LOG2E;
 
@@ -264,9 +292,9 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_pipe_kernel(const AttnPipeBwd
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t *>(base), 0, (int)(N * tok_stride * 2), 0x00020000);
     char *kimg = smem + buf * (2 * IMG), *vimg = kimg + IMG;
 #pragma unroll
-    for (int j = 0; j < NKT / 4; ++j) {
+    for (int j = 0; j < (NKT + 3) / 4; ++j) {
       const int inst = wave + 8 * j;
-      if (inst < N / 8) {
+      if (inst < NP / 8) {
         const int row = 8 * inst + dkey;
         const unsigned src = (unsigned)(row * tok_stride * 2) + (unsigned)((((lane & 7) ^ dual_swz(row))) * 16);
         DM_LDS_DMA(rs, kimg + inst * 1024, src + (unsigned)(1 * H * HD * 2), 0);
@@ -281,11 +309,12 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_pipe_kernel(const AttnPipeBwd
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       const int c = (4 * ks + g) * 8;
-      fq[ks] = wave_live ? *reinterpret_cast<const u32x4 *>(qrow + c) : (u32x4){0u, 0u, 0u, 0u};
-      fdo[ks] = wave_live ? *reinterpret_cast<const u32x4 *>(dout + orow + c) : (u32x4){0u, 0u, 0u, 0u};
-      fo[ks] = wave_live ? *reinterpret_cast<const u32x4 *>(outp + orow + c) : (u32x4){0u, 0u, 0u, 0u};
+      const bool ok = wave_live && row_ok;
+      fq[ks] = ok ? *reinterpret_cast<const u32x4 *>(qrow + c) : (u32x4){0u, 0u, 0u, 0u};
+      fdo[ks] = ok ? *reinterpret_cast<const u32x4 *>(dout + orow + c) : (u32x4){0u, 0u, 0u, 0u};
+      fo[ks] = ok ? *reinterpret_cast<const u32x4 *>(outp + orow + c) : (u32x4){0u, 0u, 0u, 0u};
     }
-    lse = wave_live ? p.lse[((long long)b * H + h) * N + q] * LOG2E : 0.f;
+    lse = (wave_live && row_ok) ? p.lse[((long long)b * H + h) * N + q] * LOG2E : 0.f;
   };
 
   u32x4 fq[2], fdo[2], fo[2], fq_n[2], fdo_n[2], fo_n[2];
@@ -293,7 +322,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_pipe_kernel(const AttnPipeBwd
   f32x4 o_prev[4];
   float delta_prev = 0.f;
   auto write_back = [&](int b) {
-    if (!wave_live) return;
+    if (!wave_live || !row_ok) return;
     bf16_t *dq = reinterpret_cast<bf16_t *>(p.dqkv) + ((long long)b * N + q) * tok_stride + (long long)h * HD;
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) dm_store4(dq + dt * 16 + 4 * g, o_prev[dt]);
@@ -332,6 +361,13 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_pipe_kernel(const AttnPipeBwd
           sc = sc * scale2 + bias[kt];
 #pragma unroll
           for (int r = 0; r < 4; ++r) ds[u][r] = __builtin_amdgcn_exp2f(sc[r] - lse) * (a[r] - dl);
+          if constexpr (RAGGED) {                    // keys past N: no probability, no gradient
+            if (16 * kt + 16 > N) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r)
+                if (16 * kt + 4 * g + r >= N) ds[u][r] = 0.f;
+            }
+          }
         }
         const u32x4 fds = pack2(ds[0], ds[1]);
 #pragma unroll
@@ -349,10 +385,12 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_pipe_kernel(const AttnPipeBwd
 }
 
 // ---- dK, dV (rows of the workgroup are keys; columns are queries), plus the chunk's summed dS for the bias gradient ----------
-template <int NKT>
+// BIAS = false (vit_model.py attention: no bias table): no transposed-bias rows and no dS accumulator in registers
+template <int NKT, bool RAGGED, bool BIAS>
 __global__ __launch_bounds__(512) void attn_bwd_dkv_pipe_kernel(const AttnPipeBwdParams p, int bchunk) {
-  constexpr int N = NKT * 16;
-  constexpr int IMG = N * 128;
+  constexpr int NP = NKT * 16;
+  const int N = RAGGED ? p.N : NP;
+  constexpr int IMG = NP * 128;
   constexpr int BUF = 2 * IMG + 2 * 1024;                        // Q image | dO image | lse[256] | delta[256]
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int t = threadIdx.x, lane = t & 63;
@@ -364,6 +402,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_pipe_kernel(const AttnPipeBw
   if (b0 >= b1) return;
   const int key = rb * ROWS + wave * 16 + li;
   const bool wave_live = rb * ROWS + wave * 16 < N;
+  const bool row_ok = key < N;
   const long long tok_stride = 3LL * H * HD;
   const bf16_t *qkv = reinterpret_cast<const bf16_t *>(p.qkv);
   const bf16_t *dout = reinterpret_cast<const bf16_t *>(p.dout);
@@ -372,15 +411,17 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_pipe_kernel(const AttnPipeBw
 
   // bias^T rows of this wave's keys: biasT[qt][r] = bias[h][q = 16 qt + 4g + r][key]  (strided, once per workgroup).
   // (Natural-log units here: the log2-unit form of the other two kernels costs this one its last free registers.)
-  f32x4 biasT[NKT], hacc[NKT];
+  constexpr int NBR = BIAS ? NKT : 1;
+  f32x4 biasT[NBR], hacc[NBR];
 #pragma unroll
-  for (int qt = 0; qt < NKT; ++qt) { biasT[qt] = (f32x4){0.f, 0.f, 0.f, 0.f}; hacc[qt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
-  if (p.bias && wave_live) {
+  for (int qt = 0; qt < NBR; ++qt) { biasT[qt] = (f32x4){0.f, 0.f, 0.f, 0.f}; hacc[qt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+  if (BIAS && p.bias && wave_live && row_ok) {
     const float *bcol = p.bias + (long long)h * N * N + key;
 #pragma unroll
     for (int qt = 0; qt < NKT; ++qt)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) biasT[qt][r] = bcol[(long long)(16 * qt + 4 * g + r) * N];
+      for (int r = 0; r < 4; ++r)
+        if (!RAGGED || 16 * qt + 4 * g + r < N) biasT[qt][r] = bcol[(long long)(16 * qt + 4 * g + r) * N];
   }
 
   const int dkey = lane >> 3;
@@ -391,9 +432,9 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_pipe_kernel(const AttnPipeBw
     const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t *>(dbase), 0, (int)(N * H * HD * 2), 0x00020000);
     char *qimg = smem + buf * BUF, *dimg = qimg + IMG;
 #pragma unroll
-    for (int j = 0; j < NKT / 4; ++j) {
+    for (int j = 0; j < (NKT + 3) / 4; ++j) {
       const int inst = wave + 8 * j;
-      if (inst < N / 8) {
+      if (inst < NP / 8) {
         const int row = 8 * inst + dkey;
         const unsigned chunk16 = (unsigned)(((lane & 7) ^ dual_swz(row)) * 16);
         DM_LDS_DMA(rq, qimg + inst * 1024, (unsigned)(row * tok_stride * 2) + chunk16, 0);
@@ -411,15 +452,15 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_pipe_kernel(const AttnPipeBw
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       const int c = (4 * ks + g) * 8;
-      fk[ks] = wave_live ? *reinterpret_cast<const u32x4 *>(krow + c) : (u32x4){0u, 0u, 0u, 0u};
-      fv[ks] = wave_live ? *reinterpret_cast<const u32x4 *>(krow + (long long)H * HD + c) : (u32x4){0u, 0u, 0u, 0u};
+      fk[ks] = (wave_live && row_ok) ? *reinterpret_cast<const u32x4 *>(krow + c) : (u32x4){0u, 0u, 0u, 0u};
+      fv[ks] = (wave_live && row_ok) ? *reinterpret_cast<const u32x4 *>(krow + (long long)H * HD + c) : (u32x4){0u, 0u, 0u, 0u};
     }
   };
 
   u32x4 fk[2], fv[2], fk_n[2], fv_n[2];
   f32x4 dk_prev[4], dv_prev[4];
   auto write_back = [&](int b) {
-    if (!wave_live) return;
+    if (!wave_live || !row_ok) return;
     bf16_t *dk = reinterpret_cast<bf16_t *>(p.dqkv) + ((long long)b * N + key) * tok_stride + (long long)H * HD + (long long)h * HD;
     bf16_t *dv = dk + (long long)H * HD;
 #pragma unroll
@@ -458,7 +499,8 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_pipe_kernel(const AttnPipeBw
             mma<bf16_t>(sc, fk[ks], read_row(qimg, fa, qt, ks));
             mma<bf16_t>(a, fv[ks], read_row(dimg, fa, qt, ks));
           }
-          sc = sc * p.scale + biasT[qt];
+          sc = sc * p.scale;
+          if constexpr (BIAS) sc += biasT[qt];
           const f32x4 l4 = *reinterpret_cast<const f32x4 *>(lse_l + 16 * qt + 4 * g);
           const f32x4 d4 = *reinterpret_cast<const f32x4 *>(delta_l + 16 * qt + 4 * g);
 #pragma unroll
@@ -466,7 +508,16 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_pipe_kernel(const AttnPipeBw
             pv[u][r] = __expf(sc[r] - l4[r]);
             ds[u][r] = pv[u][r] * (a[r] - d4[r]);
           }
-          if (p.slab) hacc[qt] += ds[u];
+          if constexpr (RAGGED) {                    // queries past N (zero rows of the images, lse = 0) contribute nothing
+            if (16 * qt + 16 > N) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r)
+                if (16 * qt + 4 * g + r >= N) { pv[u][r] = 0.f; ds[u][r] = 0.f; }
+            }
+          }
+          if constexpr (BIAS) {
+            if (p.slab) hacc[qt] += ds[u];
+          }
         }
         const u32x4 fpt = pack2(pv[0], pv[1]), fds = pack2(ds[0], ds[1]);
 #pragma unroll
@@ -482,14 +533,15 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_pipe_kernel(const AttnPipeBw
     for (int ks = 0; ks < 2; ++ks) { fk[ks] = fk_n[ks]; fv[ks] = fv_n[ks]; }
   }
   write_back(b1 - 1);
-  if (p.slab && wave_live) {
+  if (BIAS && p.slab && wave_live && row_ok) {
     // dbias[chunk][h][q][key] = the chunk's summed dS (this lane holds 4 consecutive q of one key: scattered 4-byte stores,
     // once per chunk)
     float *plane = p.slab + ((long long)chunk * H + h) * N * N + key;
 #pragma unroll
     for (int qt = 0; qt < NKT; ++qt)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) plane[(long long)(16 * qt + 4 * g + r) * N] = hacc[qt][r];
+      for (int r = 0; r < 4; ++r)
+        if (!RAGGED || 16 * qt + 4 * g + r < N) plane[(long long)(16 * qt + 4 * g + r) * N] = hacc[BIAS ? qt : 0][r];
   }
 }
 
@@ -502,60 +554,73 @@ inline void pipe_grid(int B, int N, int H, int &nblk, int &chunks, int &bchunk) 
   chunks = (B + bchunk - 1) / bchunk;
 }
 
-template <int NKT> void launch_bwd(const AttnPipeBwdParams &p, hipStream_t s) {
-  constexpr int N = NKT * 16;
-  constexpr int LDS_DQ = 4 * N * 128, LDS_DKV = 2 * (2 * N * 128 + 2048);
-  static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void *>(attn_bwd_dq_pipe_kernel<NKT>),
+template <int NKT, bool RAGGED> void launch_bwd(const AttnPipeBwdParams &p, hipStream_t s) {
+  constexpr int NP = NKT * 16;
+  constexpr int LDS_DQ = 4 * NP * 128, LDS_DKV = 2 * (2 * NP * 128 + 2048);
+  static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void *>(attn_bwd_dq_pipe_kernel<NKT, RAGGED>),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DQ) == hipSuccess &&
-                         hipFuncSetAttribute(reinterpret_cast<const void *>(attn_bwd_dkv_pipe_kernel<NKT>),
+                         hipFuncSetAttribute(reinterpret_cast<const void *>(attn_bwd_dkv_pipe_kernel<NKT, RAGGED, true>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DKV) == hipSuccess &&
+                         hipFuncSetAttribute(reinterpret_cast<const void *>(attn_bwd_dkv_pipe_kernel<NKT, RAGGED, false>),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DKV) == hipSuccess;
   (void)ok;
   int nblk, chunks, bchunk;
-  pipe_grid(p.B, N, p.H, nblk, chunks, bchunk);
-  hipLaunchKernelGGL(attn_bwd_dq_pipe_kernel<NKT>, dim3(p.H, nblk, chunks), dim3(512), LDS_DQ, s, p, bchunk);
-  hipLaunchKernelGGL(attn_bwd_dkv_pipe_kernel<NKT>, dim3(p.H, nblk, chunks), dim3(512), LDS_DKV, s, p, bchunk);
+  pipe_grid(p.B, p.N, p.H, nblk, chunks, bchunk);
+  hipLaunchKernelGGL((attn_bwd_dq_pipe_kernel<NKT, RAGGED>), dim3(p.H, nblk, chunks), dim3(512), LDS_DQ, s, p, bchunk);
+  if (p.bias || p.slab)
+    hipLaunchKernelGGL((attn_bwd_dkv_pipe_kernel<NKT, RAGGED, true>), dim3(p.H, nblk, chunks), dim3(512), LDS_DKV, s, p, bchunk);
+  else
+    hipLaunchKernelGGL((attn_bwd_dkv_pipe_kernel<NKT, RAGGED, false>), dim3(p.H, nblk, chunks), dim3(512), LDS_DKV, s, p, bchunk);
 }
 
-template <int NKT> void launch(const AttnPipeParams &p, hipStream_t s) {
-  constexpr int N = NKT * 16;
-  constexpr int LDS = 4 * N * 128;
-  static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void *>(attn_fwd_pipe_kernel<NKT>),
+template <int NKT, bool RAGGED> void launch(const AttnPipeParams &p, hipStream_t s) {
+  constexpr int NP = NKT * 16;
+  constexpr int LDS = 4 * NP * 128;
+  static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void *>(attn_fwd_pipe_kernel<NKT, RAGGED>),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS) == hipSuccess;
   (void)ok;
   // one workgroup per CU (two K/V buffers fill the LDS): as many chunks as fit one round of the 256 CUs
   int nblk, chunks, bchunk;
-  pipe_grid(p.B, N, p.H, nblk, chunks, bchunk);
-  hipLaunchKernelGGL(attn_fwd_pipe_kernel<NKT>, dim3(p.H, nblk, chunks), dim3(512), LDS, s, p, bchunk);
+  pipe_grid(p.B, p.N, p.H, nblk, chunks, bchunk);
+  hipLaunchKernelGGL((attn_fwd_pipe_kernel<NKT, RAGGED>), dim3(p.H, nblk, chunks), dim3(512), LDS, s, p, bchunk);
 }
 
 }  // namespace dmpipe
 
-bool dm_attn_fwd_pipe(const AttnPipeParams &p, hipStream_t s) {
+// Which instance serves N tokens: exact tilings 128 / 192 / 256 use the unmasked kernels, every other N in (128, 256]
+// (ViT's 197 / 198, v5's 193, ...) the masked ones with the tile count rounded up to an even number.
+static bool pipe_shape_ok(int B, int N, int H) {
   static const int mode = [] { const char *e = getenv("DM_ATTN_PIPE"); return e ? atoi(e) : 1; }();
   if (mode == 0) return false;
-  if (p.N % 16 != 0 || p.N < 128 || p.N > 256) return false;
-  if ((long long)p.B * p.N * 3 * p.H * 64 * 2 >= (1LL << 40)) return false;
-  if ((long long)p.N * 3 * p.H * 64 * 2 >= (1LL << 31)) return false;      // one sample's rows must fit a 32-bit DMA offset
-  if (mode != 2 && p.B * p.H < 96) return false;                             // too little work for persistent workgroups
-  switch (p.N / 16) {
-    case 8: dmpipe::launch<8>(p, s); return true;
-    case 12: dmpipe::launch<12>(p, s); return true;
-    case 16: dmpipe::launch<16>(p, s); return true;
+  if (N < 128 || N > 256) return false;
+  if ((long long)N * 3 * H * 64 * 2 >= (1LL << 31)) return false;            // one sample's rows must fit a 32-bit DMA offset
+  if (mode != 2 && B * H < 96) return false;                                  // too little work for persistent workgroups
+  return true;
+}
+static int pipe_tiles(int N, bool &ragged) {
+  ragged = !(N == 128 || N == 192 || N == 256);
+  const int nkt = (N + 15) / 16;
+  return ragged ? (nkt + 1) / 2 * 2 : nkt;
+}
+
+bool dm_attn_fwd_pipe(const AttnPipeParams &p, hipStream_t s) {
+  if (!pipe_shape_ok(p.B, p.N, p.H)) return false;
+  bool ragged;
+  switch (pipe_tiles(p.N, ragged)) {
+    case 8: dmpipe::launch<8, false>(p, s); return true;
+    case 10: dmpipe::launch<10, true>(p, s); return true;
+    case 12: if (ragged) dmpipe::launch<12, true>(p, s); else dmpipe::launch<12, false>(p, s); return true;
+    case 14: dmpipe::launch<14, true>(p, s); return true;
+    case 16: if (ragged) dmpipe::launch<16, true>(p, s); else dmpipe::launch<16, false>(p, s); return true;
     default: return false;
   }
 }
 
-static bool pipe_shape_ok(int B, int N, int H) {
-  static const int mode = [] { const char *e = getenv("DM_ATTN_PIPE"); return e ? atoi(e) : 1; }();
-  if (mode == 0) return false;
-  if (N % 16 != 0 || N < 128 || N > 256) return false;
-  if ((long long)N * 3 * H * 64 * 2 >= (1LL << 31)) return false;
-  if (mode != 2 && B * H < 96) return false;
-  return true;
-}
-
 int dm_attn_bwd_pipe_chunks(int B, int N, int H, int dtype_is_bf16) {
   if (!dtype_is_bf16 || !pipe_shape_ok(B, N, H)) return 0;
+  bool ragged;
+  pipe_tiles(N, ragged);
+  if (ragged) return 0;          // a masked backward only runs without a bias (below), where no slab exists
   int nblk, chunks, bchunk;
   dmpipe::pipe_grid(B, N, H, nblk, chunks, bchunk);
   return chunks;
@@ -563,10 +628,16 @@ int dm_attn_bwd_pipe_chunks(int B, int N, int H, int dtype_is_bf16) {
 
 bool dm_attn_bwd_pipe(const AttnPipeBwdParams &p, hipStream_t s) {
   if (!pipe_shape_ok(p.B, p.N, p.H)) return false;
-  switch (p.N / 16) {
-    case 8: dmpipe::launch_bwd<8>(p, s); return true;
-    case 12: dmpipe::launch_bwd<12>(p, s); return true;
-    case 16: dmpipe::launch_bwd<16>(p, s); return true;
+  bool ragged;
+  const int nkt = pipe_tiles(p.N, ragged);
+  // masked + bias (v5's N = 193): the dK/dV kernel would need > 256 registers (it spills); the generic kernels take it
+  if (ragged && (p.bias || p.slab)) return false;
+  switch (nkt) {
+    case 8: dmpipe::launch_bwd<8, false>(p, s); return true;
+    case 10: dmpipe::launch_bwd<10, true>(p, s); return true;
+    case 12: if (ragged) dmpipe::launch_bwd<12, true>(p, s); else dmpipe::launch_bwd<12, false>(p, s); return true;
+    case 14: dmpipe::launch_bwd<14, true>(p, s); return true;
+    case 16: if (ragged) dmpipe::launch_bwd<16, true>(p, s); else dmpipe::launch_bwd<16, false>(p, s); return true;
     default: return false;
   }
 }

@@ -205,12 +205,20 @@ def _attn_ref(qkv, bias, scale):
     return o, torch.logsumexp(s, -1)
 
 
+@pytest.mark.parametrize("N,with_bias", [(256, True), (192, True), (128, False), (197, False), (198, False), (193, True), (160, True)])
+def test_attention_pipelined_kernels(N, with_bias):
+    """B * H >= 96 routes bf16 attention with 128 <= N <= 256 to the persistent LDS-DMA kernels (dm_attention_pipe.hip):
+    exact tilings, masked (ragged) N without a bias (vit_model.py), and ragged N with a bias (forward pipelined, backward
+    on the generic kernels)."""
+    test_attention_forward_backward("bf16", N, with_bias, B=8, H=12)
+
+
 @pytest.mark.parametrize("mode", ["fp32", "bf16"])
 @pytest.mark.parametrize("N,with_bias", [(12, True), (16, True), (48, True), (64, True), (192, True), (256, True), (197, False), (198, False), (100, True), (37, True), (250, True)])
-def test_attention_forward_backward(mode, N, with_bias):
+def test_attention_forward_backward(mode, N, with_bias, B=3, H=4):
     ops = _ops()
     rng = np.random.default_rng(N)
-    B, H, D = 3, 4, 64
+    D = 64
     dt = DT[mode]
     qkv = torch.from_numpy(rng.normal(size=(B, N, 3, H, D)).astype(np.float32))
     qkv = qkv.to(dt).float()                     # operands exactly representable in the mode's dtype
