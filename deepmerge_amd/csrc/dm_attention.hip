@@ -283,13 +283,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
 }
 
 // =============================================================================================
-// backward, dQ + delta + bias-gradient histogram
+// backward, dQ + delta + the chunk's summed dS (dense bias gradient)
 // =============================================================================================
 template <typename T, int NKT, bool FAST>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnParams p) {
   // grid = (query block, head, batch chunk).  The workgroup walks the `bchunk` samples of its chunk and
-  // sums dS over them in registers, so the (slow, ~0.4 lanes/clk) LDS float atomics of the bias-table
-  // histogram are paid once per chunk instead of once per sample.
+  // sums dS over them in registers; the sum is written once per chunk as a dense [N][N] plane
+  // (dm_relpos_bias_reduce folds it into the table's gradient: no atomics, deterministic).
   using L = AL<T>;
   constexpr int NK = NKT * 16;
   constexpr int IMG = NK * L::RB;
