@@ -70,7 +70,7 @@ def cpu_criterion(a, b, flag):
     return OL.contrastive_loss(a, b, flag, 50.0)    # large margin so the hinge branch is live
 
 
-def _worker(rank, world, port, out):
+def _worker(rank, world, port, out, steps=2):
     sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -83,7 +83,7 @@ def _worker(rank, world, port, out):
     l, ld, r, rd, flag = make_batch(8, cfg, 99)
     sl = shard_slice(8, rank, world)
     losses = []
-    for _ in range(2):
+    for _ in range(steps):
         losses.append(float(tr.step([t[sl] for t in l], ld[sl], [t[sl] for t in r], rd[sl], flag[sl])))
     if rank == 0:
         torch.save({"flat": tr.fp.flat.clone(), "grad": tr.fp.grad.clone() / world, "losses": losses}, out)
@@ -108,6 +108,22 @@ def test_two_rank_step_equals_single_process_global_batch(tmp_path):
     assert shard_slice(8, 1, 2) == slice(4, 8)
     with pytest.raises(ValueError):
         shard_slice(9, 0, 2)
+
+
+def test_four_rank_step_with_calibrated_bucket_hooks(tmp_path):
+    """world_size 4, three steps: from the second step on the bucket hooks count only the parameters that received a gradient
+    (buckets are exchanged from inside backward), which must stay equivalent to the single-process global batch."""
+    from deepmerge_amd.trainer import PairTrainer
+    out = str(tmp_path / "rank0.pt")
+    mp.spawn(_worker, args=(4, _free_port(), out, 3), nprocs=4, join=True)
+    got = torch.load(out)
+    cfg = tiny_cfg()
+    tr = PairTrainer(OracleNet(cfg), lr=1e-3, criterion=cpu_criterion, adam_fn=cpu_adam)
+    batch = make_batch(8, cfg, 99)
+    for _ in range(3):
+        tr.step(*batch)
+    np.testing.assert_allclose(got["grad"].numpy(), tr.fp.grad.numpy(), rtol=2e-4, atol=1e-6)
+    np.testing.assert_allclose(got["flat"].numpy(), tr.fp.flat.numpy(), rtol=2e-4, atol=5e-5)
 
 
 def test_flat_params_views_and_buckets():
