@@ -302,3 +302,49 @@ extern "C" int dm_rag_edges(const int32_t *labels, int32_t H, int32_t W, int32_t
   DM_LAUNCH_CHECK("dm_rag_edges");
   return DM_OK;
 }
+
+// ---- merge step of the region-adjacency sweep: connected components over the edges flagged `merge` ------------------------
+// (optional: the reference stops at writing `simi` and leaves the merging to external GIS tooling.)
+// Min-id union-find: roots are hooked under the smaller root with atomicMin, so every component ends up labelled with its
+// smallest member id whatever the order of the updates (deterministic result).  One round = hook over all merging edges +
+// full path compression; the host repeats rounds until the `changed` flag stays 0.
+namespace {
+__device__ __forceinline__ int uf_find(const int *parent, int x) {
+  int p = parent[x];
+  while (p != x) { x = p; p = parent[x]; }
+  return x;
+}
+__global__ void uf_init_kernel(int *parent, int S) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < S) parent[i] = i;
+}
+__global__ void uf_hook_kernel(const int *__restrict__ edges, const unsigned char *__restrict__ merge, int E, int S, int *parent,
+                               int *changed) {
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < E; e += (long long)gridDim.x * blockDim.x) {
+    if (!merge[e]) continue;
+    const int a = edges[2 * e], b = edges[2 * e + 1];
+    if (a < 0 || b < 0 || a >= S || b >= S) continue;
+    const int ra = uf_find(parent, a), rb = uf_find(parent, b);
+    if (ra == rb) continue;
+    const int lo = min(ra, rb), hi = max(ra, rb);
+    atomicMin(parent + hi, lo);
+    *changed = 1;
+  }
+}
+__global__ void uf_compress_kernel(int *parent, int S) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < S) parent[i] = uf_find(parent, i);
+}
+}  // namespace
+
+extern "C" int dm_merge_round(const int32_t *edges, const uint8_t *merge, int32_t E, int32_t S, int32_t *parent, int32_t *changed,
+                              int32_t init, void *stream) {
+  DM_REQUIRE(parent && changed && E >= 0 && S > 0 && (E == 0 || (edges && merge)), DM_ERR_BAD_SHAPE, "dm_merge_round: bad arguments");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (init) hipLaunchKernelGGL(uf_init_kernel, dim3((S + 255) / 256), dim3(256), 0, s, parent, S);
+  hipMemsetAsync(changed, 0, sizeof(int32_t), s);
+  if (E > 0) hipLaunchKernelGGL(uf_hook_kernel, dim3(grid_for(E, 2048)), dim3(256), 0, s, edges, merge, E, S, parent, changed);
+  hipLaunchKernelGGL(uf_compress_kernel, dim3((S + 255) / 256), dim3(256), 0, s, parent, S);
+  DM_LAUNCH_CHECK("dm_merge_round");
+  return DM_OK;
+}

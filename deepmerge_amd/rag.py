@@ -85,3 +85,44 @@ def points_to_csr(labels: torch.Tensor, xy: torch.Tensor, n_labels: int) -> Tupl
     ptr = torch.zeros(n_labels + 1, dtype=torch.int64, device=labels.device)
     ptr[1:] = torch.cumsum(counts, 0)
     return ptr.to(torch.int32), order.to(torch.int32)
+
+
+def merge_components(edges: torch.Tensor, merge: torch.Tensor, n_labels: int, max_rounds: int = 64) -> torch.Tensor:
+    """Connected components of the superpixel graph restricted to the edges flagged `merge` (the step after the sweep; the
+    reference hands this to external GIS tooling).  Returns int32 [S]: the smallest superpixel id of each one's component."""
+    _need_cuda(edges, merge)
+    edges = edges.to(torch.int32).contiguous()
+    m8 = merge.to(torch.uint8).contiguous()
+    dev = edges.device
+    parent = torch.empty(n_labels, dtype=torch.int32, device=dev)
+    changed = torch.zeros(1, dtype=torch.int32, device=dev)
+    for r in range(max_rounds):
+        check(_lib.lib().dm_merge_round(edges.data_ptr(), m8.data_ptr(), edges.shape[0], n_labels, parent.data_ptr(), changed.data_ptr(),
+                                        int(r == 0), _stream()), "dm_merge_round")
+        if int(changed.item()) == 0:
+            return parent
+    raise RuntimeError(f"merge_components did not converge in {max_rounds} rounds")
+
+
+def merge_partition(ptr: torch.Tensor, idx: torch.Tensor, edges: torch.Tensor, root: torch.Tensor):
+    """Apply a component labelling: merged CSR point lists (members in ascending old id, their points in the old order) and
+    the edge list between the merged regions (self edges dropped, duplicates folded, sorted).
+    Returns (new_id int32 [S] dense 0..C-1 in order of the component's smallest member, ptr', idx', edges')."""
+    S = root.numel()
+    root = root.long()
+    is_root = root == torch.arange(S, device=root.device)
+    dense = torch.cumsum(is_root.to(torch.int64), 0) - 1               # id of a root among the roots
+    new_id = dense[root]
+    C = int(is_root.sum())
+    counts = (ptr[1:] - ptr[:-1]).long()
+    owner = torch.repeat_interleave(new_id, counts)                    # new region of every entry of idx (old CSR order)
+    order = torch.argsort(owner, stable=True)
+    new_idx = idx.long()[order].to(torch.int32)
+    new_ptr = torch.zeros(C + 1, dtype=torch.int64, device=root.device)
+    new_ptr[1:] = torch.cumsum(torch.bincount(owner, minlength=C), 0)
+    a, b = new_id[edges[:, 0].long()], new_id[edges[:, 1].long()]
+    keep = a != b
+    lo, hi = torch.minimum(a[keep], b[keep]), torch.maximum(a[keep], b[keep])
+    keys = torch.unique(lo * C + hi)
+    new_edges = torch.stack((keys // C, keys % C), 1).to(torch.int32)
+    return new_id.to(torch.int32), new_ptr.to(torch.int32), new_idx, new_edges

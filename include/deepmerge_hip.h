@@ -250,6 +250,13 @@ int dm_rag_edges(const int32_t *labels, int32_t H, int32_t W, int32_t S, int64_t
                  int32_t capacity_log2, int64_t *edge_keys, int32_t *edge_counts, int32_t max_edges, int32_t *n_edges,
                  int32_t *overflow, void *stream);
 
+/* One round of the merge step that follows the sweep (optional; the reference leaves merging to external
+ * GIS tooling): union-find over the edges with merge[e] != 0.  parent int32 [S] (init != 0: reset to the identity first);
+ * after the call parent[s] is a root candidate and changed[0] tells whether any root was hooked -- repeat with init = 0
+ * until changed[0] == 0; then parent[s] = the smallest superpixel id of s's component (order-independent). */
+int dm_merge_round(const int32_t *edges, const uint8_t *merge, int32_t E, int32_t S, int32_t *parent, int32_t *changed,
+                   int32_t init, void *stream);
+
 /* ---- optional in-library kernel timing ------------------------------------------------------
  * While enabled, the GEMM and attention entry points bracket their main kernel with hipEvents on
  * the caller's stream.  dm_prof_collect waits for the recorded events, aggregates them per kernel

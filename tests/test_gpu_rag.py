@@ -78,3 +78,56 @@ def test_points_to_csr_feeds_the_sweep():
     feats = torch.randn((xy.shape[0], 100), device=DEV)
     pooled, simi, merge = rag_similarity_sweep(feats, ptr, idx, edges)
     assert pooled.shape == (S, 100) and simi.shape[0] == edges.shape[0] == merge.shape[0]
+
+
+@pytest.mark.parametrize("S,E,frac", [(50, 120, 0.3), (5000, 20000, 0.2), (20000, 60000, 0.05), (300, 0, 0.5)])
+def test_merge_components_matches_scipy(S, E, frac):
+    from scipy.sparse import coo_matrix
+    from scipy.sparse.csgraph import connected_components
+    from deepmerge_amd import rag
+    rng = np.random.default_rng(S + E)
+    edges = rng.integers(0, S, size=(max(E, 1), 2)).astype(np.int32)[:E].reshape(E, 2)
+    merge = (rng.random(E) < frac)
+    ea, eb = edges[merge, 0], edges[merge, 1]
+    _, comp = connected_components(coo_matrix((np.ones(len(ea)), (ea, eb)), shape=(S, S)), directed=False)
+    want = np.zeros(S, dtype=np.int64)
+    first = {}
+    for s in range(S):
+        first.setdefault(comp[s], s)
+        want[s] = first[comp[s]]                           # smallest member id of the component
+    te = torch.from_numpy(edges).to(DEV) if E else torch.zeros((0, 2), dtype=torch.int32, device=DEV)
+    tm = torch.from_numpy(merge).to(DEV) if E else torch.zeros((0,), dtype=torch.bool, device=DEV)
+    got = rag.merge_components(te, tm, S)
+    assert np.array_equal(got.cpu().numpy().astype(np.int64), want)
+
+
+def test_merge_loop_on_a_raster():
+    """sweep -> merge -> re-pool -> re-score until nothing merges: every round's partition stays consistent."""
+    from deepmerge_amd import rag
+    from deepmerge_amd.ExtractFeatures import rag_similarity_sweep
+    lab, S = superpixels(128, 128, 8, 11)
+    tl = torch.from_numpy(lab).to(DEV)
+    ys, xs = np.mgrid[1:128:2, 1:128:2]
+    xy = torch.from_numpy(np.stack((xs.reshape(-1), ys.reshape(-1)), 1).astype(np.int32)).to(DEV)
+    ptr, idx = rag.points_to_csr(tl, xy, S)
+    edges, _ = rag.rag_edges(tl, S)
+    g = torch.Generator(device=DEV); g.manual_seed(0)
+    group = torch.randint(0, 12, (S,), device=DEV, generator=g)          # superpixels of one group embed alike
+    centers = torch.randn((12, 100), device=DEV, generator=g) * 2.0
+    member = tl[xy[:, 1].long(), xy[:, 0].long()].long()
+    feats = centers[group[member]] + 0.01 * torch.randn((xy.shape[0], 100), device=DEV, generator=g)
+    n_regions, rounds = S, 0
+    while True:
+        pooled, simi, merge = rag_similarity_sweep(feats, ptr, idx, edges, margin=1.0)
+        if not bool(merge.any()):
+            break
+        root = rag.merge_components(edges, merge, n_regions)
+        new_id, ptr, idx, edges = rag.merge_partition(ptr, idx, edges, root)
+        assert int(ptr[-1]) == xy.shape[0] and sorted(idx.cpu().tolist()) == list(range(xy.shape[0]))
+        assert int(new_id.max()) + 1 == ptr.numel() - 1 < n_regions
+        n_regions = ptr.numel() - 1
+        rounds += 1
+        assert rounds < 20
+    assert rounds >= 1 and n_regions < S
+    # what is left are regions of different groups only: no remaining edge joins two regions that embed alike
+    assert float(simi.min()) >= 1.0 if simi.numel() else True
