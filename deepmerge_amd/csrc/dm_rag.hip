@@ -16,6 +16,8 @@ namespace {
 
 constexpr int STRIP = 16;
 constexpr long long EMPTY_KEY = -1;
+constexpr int TSLOTS_LOG2 = 6, TSLOTS = 1 << TSLOTS_LOG2;      // labels per 64x64 tile kept in LDS (more: global atomics)
+constexpr int ESLOTS_LOG2 = 7, ESLOTS = 1 << ESLOTS_LOG2;      // label pairs per tile kept in LDS
 
 __global__ void rag_init_kernel(long long *count, long long *sum, long long *sumsq, int *bbox, long long *peri, int S, int bands3) {
   const int s = blockIdx.x * blockDim.x + threadIdx.x;
@@ -37,12 +39,26 @@ __global__ __launch_bounds__(256) void label_stats_kernel(const int *__restrict_
                                                           int H, int W, int S, long long *__restrict__ count,
                                                           long long *__restrict__ sum, long long *__restrict__ sumsq,
                                                           int *__restrict__ bbox, long long *__restrict__ peri) {
-  const int strips = (W + STRIP - 1) / STRIP;
-  const long long total = (long long)H * strips;
-  for (long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x; id < total; id += (long long)gridDim.x * blockDim.x) {
-    const int y = (int)(id / strips), x0 = (int)(id % strips) * STRIP;
-    const int n = min(STRIP, W - x0);
-    const int *row = labels + (long long)y * W;
+  // A workgroup owns a 64x64-pixel tile (thread = one 16-pixel strip of one row).  A tile meets only a handful of superpixels,
+  // so the per-run statistics are first folded in an LDS-private table (integer LDS atomics) and every label of the tile then
+  // costs ONE set of global atomics: ~25x fewer global atomics than flushing every run.
+  __shared__ int t_key[TSLOTS];
+  __shared__ unsigned t_cnt[TSLOTS], t_sum[TSLOTS][NB], t_sq[TSLOTS][NB], t_per[TSLOTS][2];
+  __shared__ int t_box[TSLOTS][4];
+  for (int i = threadIdx.x; i < TSLOTS; i += blockDim.x) {
+    t_key[i] = -1; t_cnt[i] = 0; t_per[i][0] = 0; t_per[i][1] = 0;
+    t_box[i][0] = INT_MAX; t_box[i][1] = INT_MAX; t_box[i][2] = -1; t_box[i][3] = -1;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) { t_sum[i][b] = 0; t_sq[i][b] = 0; }
+  }
+  __syncthreads();
+  const int tiles_x = (W + 63) / 64;
+  const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+  {
+    const int y = ty * 64 + (threadIdx.x >> 2), x0 = tx * 64 + (threadIdx.x & 3) * STRIP;
+    const bool live = y < H && x0 < W;
+    const int n = live ? min(STRIP, W - x0) : 0;
+    const int *row = labels + (long long)(live ? y : 0) * W;
     // strip registers: this row's labels with one neighbour on each side, the rows above / below, the bands' bytes
     int lab[STRIP + 2], up[STRIP], dn[STRIP];
     unsigned char px[NB][STRIP];
@@ -72,15 +88,33 @@ __global__ __launch_bounds__(256) void label_stats_kernel(const int *__restrict_
         for (int b = 0; b < NB; ++b) px[b][i] = in ? tile[((long long)b * H + y) * W + x0 + i] : 0;
       }
     }
-    lab[0] = (x0 > 0) ? row[x0 - 1] : -2;                     // -2 = outside the raster
-    lab[STRIP + 1] = (x0 + STRIP < W) ? row[x0 + STRIP] : -2;
-    if (n < STRIP) lab[1 + n] = (x0 + n < W) ? row[x0 + n] : -2;
+    lab[0] = (live && x0 > 0) ? row[x0 - 1] : -2;             // -2 = outside the raster
+    lab[STRIP + 1] = (live && x0 + STRIP < W) ? row[x0 + STRIP] : -2;
+    if (n < STRIP) lab[1 + n] = (live && x0 + n < W) ? row[x0 + n] : -2;
     int cur = -1, run_x0 = 0;
     long long c = 0, sm[NB], sq[NB], pin = 0, pbd = 0;
 #pragma unroll
     for (int b = 0; b < NB; ++b) { sm[b] = 0; sq[b] = 0; }
     auto flush = [&](int xend) {
       if (cur < 0 || cur >= S || c == 0) return;
+      // slot of this label in the tile's table (open addressing); a full table falls back to global atomics
+      unsigned slot = ((unsigned)cur * 2654435761u) >> (32 - TSLOTS_LOG2);
+      bool found = false;
+      for (int probe = 0; probe < TSLOTS; ++probe) {
+        const int seen = atomicCAS(&t_key[slot], -1, cur);
+        if (seen == -1 || seen == cur) { found = true; break; }
+        slot = (slot + 1) & (TSLOTS - 1);
+      }
+      if (found) {
+        atomicAdd(&t_cnt[slot], (unsigned)c);
+#pragma unroll
+        for (int b = 0; b < NB; ++b) { atomicAdd(&t_sum[slot][b], (unsigned)sm[b]); atomicAdd(&t_sq[slot][b], (unsigned)sq[b]); }
+        atomicMin(&t_box[slot][0], run_x0); atomicMin(&t_box[slot][1], y);
+        atomicMax(&t_box[slot][2], xend); atomicMax(&t_box[slot][3], y);
+        if (pin) atomicAdd(&t_per[slot][0], (unsigned)pin);
+        if (pbd) atomicAdd(&t_per[slot][1], (unsigned)pbd);
+        return;
+      }
       atomic_add64(count + cur, c);
 #pragma unroll
       for (int b = 0; b < NB; ++b) { atomic_add64(sum + (long long)cur * NB + b, sm[b]); atomic_add64(sumsq + (long long)cur * NB + b, sq[b]); }
@@ -113,7 +147,22 @@ __global__ __launch_bounds__(256) void label_stats_kernel(const int *__restrict_
         if (nbr[e] == -2) ++pbd; else if (nbr[e] != l) ++pin;
       }
     }
-    flush(x0 + n - 1);
+    if (live) flush(x0 + n - 1);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < TSLOTS; i += blockDim.x) {      // one set of global atomics per label of the tile
+    const int l = t_key[i];
+    if (l < 0) continue;
+    atomic_add64(count + l, (long long)t_cnt[i]);
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      atomic_add64(sum + (long long)l * NB + b, (long long)t_sum[i][b]);
+      atomic_add64(sumsq + (long long)l * NB + b, (long long)t_sq[i][b]);
+    }
+    atomicMin(bbox + 4 * l + 0, t_box[i][0]); atomicMin(bbox + 4 * l + 1, t_box[i][1]);
+    atomicMax(bbox + 4 * l + 2, t_box[i][2]); atomicMax(bbox + 4 * l + 3, t_box[i][3]);
+    if (t_per[i][0]) atomic_add64(peri + 2 * l, (long long)t_per[i][0]);
+    if (t_per[i][1]) atomic_add64(peri + 2 * l + 1, (long long)t_per[i][1]);
   }
 }
 
@@ -183,12 +232,29 @@ __global__ void table_clear_kernel(long long *keys, int *cnt, long long n, int *
 template <bool VEC>
 __global__ __launch_bounds__(256) void rag_edges_kernel(const int *__restrict__ labels, int H, int W, int S, long long *__restrict__ keys,
                                                         int *__restrict__ cnt, unsigned mask, int *__restrict__ overflow) {
-  const int strips = (W + STRIP - 1) / STRIP;
-  const long long total = (long long)H * strips;
-  for (long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x; id < total; id += (long long)gridDim.x * blockDim.x) {
-    const int y = (int)(id / strips), x0 = (int)(id % strips) * STRIP;
-    const int n = min(STRIP, W - x0);
-    const int *row = labels + (long long)y * W;
+  // same 64x64 tiling as label_stats_kernel: pairs are first counted in an LDS-private table, then every distinct pair of the
+  // tile is added to the global table once
+  __shared__ long long e_key[ESLOTS];
+  __shared__ int e_cnt[ESLOTS];
+  for (int i = threadIdx.x; i < ESLOTS; i += blockDim.x) { e_key[i] = EMPTY_KEY; e_cnt[i] = 0; }
+  __syncthreads();
+  const int tiles_x = (W + 63) / 64;
+  const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+  auto tile_add = [&](long long key, int c) {
+    unsigned slot = (unsigned)mix64((unsigned long long)key) & (ESLOTS - 1);
+    for (int probe = 0; probe < ESLOTS; ++probe) {
+      const long long seen = (long long)atomicCAS(reinterpret_cast<unsigned long long *>(&e_key[slot]), (unsigned long long)EMPTY_KEY,
+                                                  (unsigned long long)key);
+      if (seen == EMPTY_KEY || seen == key) { atomicAdd(&e_cnt[slot], c); return; }
+      slot = (slot + 1) & (ESLOTS - 1);
+    }
+    table_add(keys, cnt, mask, key, c, overflow);            // tile table full: straight to the global table
+  };
+  {
+    const int y = ty * 64 + (threadIdx.x >> 2), x0 = tx * 64 + (threadIdx.x & 3) * STRIP;
+    const bool live = y < H && x0 < W;
+    const int n = live ? min(STRIP, W - x0) : 0;
+    const int *row = labels + (long long)(live ? y : 0) * W;
     int lab[STRIP + 1], dn[STRIP];
     if (VEC && n == STRIP) {
 #pragma unroll
@@ -205,15 +271,15 @@ __global__ __launch_bounds__(256) void rag_edges_kernel(const int *__restrict__ 
         dn[i] = (i < n && y + 1 < H) ? row[x0 + i + W] : -2;
       }
     }
-    lab[STRIP] = (x0 + STRIP < W) ? row[x0 + STRIP] : -2;
-    if (n < STRIP) lab[n] = (x0 + n < W) ? row[x0 + n] : -2;
+    lab[STRIP] = (live && x0 + STRIP < W) ? row[x0 + STRIP] : -2;
+    if (n < STRIP) lab[n] = (live && x0 + n < W) ? row[x0 + n] : -2;
     long long run_key = EMPTY_KEY;
     int run_cnt = 0;
     auto emit = [&](int a, int b) {
       if (a == b || a < 0 || b < 0 || a >= S || b >= S) return;
       const long long key = (long long)min(a, b) * S + max(a, b);
       if (key == run_key) { ++run_cnt; return; }
-      if (run_cnt) table_add(keys, cnt, mask, run_key, run_cnt, overflow);
+      if (run_cnt) tile_add(run_key, run_cnt);
       run_key = key; run_cnt = 1;
     };
 #pragma unroll
@@ -222,8 +288,11 @@ __global__ __launch_bounds__(256) void rag_edges_kernel(const int *__restrict__ 
 #pragma unroll
     for (int i = 0; i < STRIP; ++i)
       if (i < n) emit(lab[i], lab[i + 1]);           // (ids < 0, incl. the -2 "outside" marker, are dropped by emit)
-    if (run_cnt) table_add(keys, cnt, mask, run_key, run_cnt, overflow);
+    if (run_cnt) tile_add(run_key, run_cnt);
   }
+  __syncthreads();
+  for (int i = threadIdx.x; i < ESLOTS; i += blockDim.x)
+    if (e_key[i] != EMPTY_KEY) table_add(keys, cnt, mask, e_key[i], e_cnt[i], overflow);
 }
 
 __global__ void table_compact_kernel(const long long *__restrict__ keys, const int *__restrict__ cnt, long long n,
@@ -251,8 +320,7 @@ extern "C" int dm_label_stats(const int32_t *labels, const uint8_t *tile, int32_
   const int nb = bands < 3 ? bands : 3;
   hipLaunchKernelGGL(rag_init_kernel, dim3((S + 255) / 256), dim3(256), 0, s, (long long *)count, (long long *)sum, (long long *)sumsq, bbox,
                      (long long *)peri, S, nb);
-  const long long items = (long long)H * ((W + STRIP - 1) / STRIP);
-  const dim3 grid(grid_for(items));
+  const dim3 grid((unsigned)(((W + 63) / 64) * ((H + 63) / 64)));     // one workgroup per 64x64-pixel tile
   // 16-byte strip loads need W % 16 == 0 and 16-byte aligned rasters
   const bool vec = (W % STRIP == 0) && dm_aligned16(labels) && dm_aligned16(tile);
 #define DM_STATS(NB_)                                                                                                                      \
@@ -290,12 +358,12 @@ extern "C" int dm_rag_edges(const int32_t *labels, int32_t H, int32_t W, int32_t
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const long long cap = 1LL << capacity_log2;
   hipLaunchKernelGGL(table_clear_kernel, dim3(grid_for(cap, 2048)), dim3(256), 0, s, (long long *)table_keys, table_counts, cap, overflow, n_edges);
-  const long long items = (long long)H * ((W + STRIP - 1) / STRIP);
+  const dim3 tgrid((unsigned)(((W + 63) / 64) * ((H + 63) / 64)));
   if (W % STRIP == 0 && dm_aligned16(labels))
-    hipLaunchKernelGGL(rag_edges_kernel<true>, dim3(grid_for(items)), dim3(256), 0, s, labels, H, W, S, (long long *)table_keys, table_counts,
+    hipLaunchKernelGGL(rag_edges_kernel<true>, tgrid, dim3(256), 0, s, labels, H, W, S, (long long *)table_keys, table_counts,
                        (unsigned)(cap - 1), overflow);
   else
-    hipLaunchKernelGGL(rag_edges_kernel<false>, dim3(grid_for(items)), dim3(256), 0, s, labels, H, W, S, (long long *)table_keys, table_counts,
+    hipLaunchKernelGGL(rag_edges_kernel<false>, tgrid, dim3(256), 0, s, labels, H, W, S, (long long *)table_keys, table_counts,
                        (unsigned)(cap - 1), overflow);
   hipLaunchKernelGGL(table_compact_kernel, dim3(grid_for(cap, 2048)), dim3(256), 0, s, (const long long *)table_keys, table_counts, cap,
                      (long long *)edge_keys, edge_counts, n_edges, max_edges);
