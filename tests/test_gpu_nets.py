@@ -41,3 +41,29 @@ def test_mlp_and_fc_match_reference():
         recipe.check_summary("fc/grad/" + n, p.grad.cpu().numpy(), fx, 1e-4)
     with pytest.raises(NotImplementedError):
         Nets.RNN()
+
+
+def test_networks_api_surface():
+    """Networks.SpatiallyMmemorizedNetwork: constructor signature, arity dispatch, reduction conv as a GEMM, L2-normalised head."""
+    from deepmerge_amd import Networks
+    torch.manual_seed(0)
+    base = torch.nn.Sequential(torch.nn.Conv2d(3, 64, 3, padding=1), torch.nn.ReLU())
+    net = Networks.SpatiallyMmemorizedNetwork(base, "gap", 64, 64, 32).to(DEV)
+    x1, x2, x3 = (torch.randn(5, 3, 16, 16, device=DEV) for _ in range(3))
+    y = net(x1)
+    f = base(x1).mean(dim=(2, 3))
+    w, b = net.reduce_conv.weight.view(32, 64), net.reduce_conv.bias
+    z = f @ w.T + b
+    want = z / (z.norm(dim=1, keepdim=True) + 1e-6)
+    assert y.shape == (5, 32) and torch.allclose(y, want, rtol=1e-4, atol=1e-6)
+    a, b2 = net(x1, x2)
+    assert torch.allclose(a, y, rtol=0, atol=0) and b2.shape == (5, 32)
+    assert len(net(x1, x2, x3)) == 3
+    y.sum().backward()
+    assert net.reduce_conv.weight.grad is not None and base[0].weight.grad is not None
+    with pytest.raises(ValueError):
+        net(x1, x2, x3, x1)
+    with pytest.raises(NotImplementedError):
+        net(*([x1] * 6))
+    with pytest.raises(NotImplementedError):
+        Networks.SpatiallyMmemorizedNetwork("VGG16", "gap", 512, 512, 256)
