@@ -361,7 +361,8 @@ bool dm_gemm256_plan(GemmParams &p, int layout, int ab_dtype, bool can_split, lo
   // NN 107 vs 103 -- the m-contiguous images lose most of their warm-cache lead, so dgrad only takes the pipeline when
   // there are many rounds of tiles.
   bool take;
-  if (layout == DM_TN) take = wgs >= 200 && (long long)p.K / split >= 16 * BK256;
+  static const int tn_min_tiles = [] { const char *e = getenv("DM_GEMM_256_TN_MINK"); return e ? atoi(e) : 8; }();   // K tiles per slice (8: the 4096-token stage's wgrads gain 12-30 % in the step; 16 left them on the 64x64 kernel)
+  if (layout == DM_TN) take = wgs >= 200 && (long long)p.K / split >= (long long)tn_min_tiles * BK256;
   else if (layout == DM_NN) take = tiles >= 1024;
   else take = (tiles_n >= 10 && tiles >= 384) || tiles >= 1024;
   if (mode == 2) take = true;
