@@ -379,7 +379,10 @@ bool dm_gemm256_plan(GemmParams &p, int layout, int ab_dtype, bool can_split, lo
   return true;
 }
 
-void dm_gemm256_launch(const GemmParams &p, int layout, hipStream_t s) {
+void dm_gemm256_launch(const GemmParams &p_in, int layout, hipStream_t s) {
+  GemmParams p = p_in;
+  static const int gm = [] { const char *e = getenv("DM_GEMM_256_GROUP_M"); return e ? atoi(e) : -1; }();
+  if (gm >= 0) p.group_m = gm;
   const dim3 grid((unsigned)(p.tiles_m * p.tiles_n * p.split_k));
   switch (layout) {
     case DM_NT: hipLaunchKernelGGL(dm256::gemm256_kernel<DM_NT>, grid, dim3(512), LDS256, s, p); break;
