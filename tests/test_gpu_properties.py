@@ -157,3 +157,32 @@ def test_sweep_patch_and_rag_properties_config4_size():
     assert int(st["peri"][:, 1].sum()) == 4 * 4096                       # the raster's own border
     root = rag.merge_components(e, torch.ones(e.shape[0], dtype=torch.bool, device=DEV), Sr)
     assert int(root.max()) == 0                                          # merging along every edge leaves one region
+
+
+def test_whole_model_side_swap_symmetry_full_size():
+    """configs[1] model and batch (32 pairs, 4 scales x 4 channels, bf16): swapping the two sides of every pair swaps the
+    two embeddings bit for bit (no kernel mixes samples, and a row's arithmetic does not depend on its position in the batch),
+    leaves the loss unchanged, and the parameter gradients agree to rounding (their summation order over samples changes)."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    from bench import synth_batch
+    from deepmerge_amd.Losses import Loss
+    from deepmerge_amd.nets.ShfitScaleFormer import ShfitScaleFormer_v3
+    scales, in_c = [32, 64, 128, 256], 4
+    torch.manual_seed(0)
+    net = ShfitScaleFormer_v3(cube_size=[8, 8], input_image_scales=list(scales), depth=[3, 2, 1], in_c=in_c, numerics="bf16").to(DEV).train()
+    left, ld, right, rd, flag = synth_batch(32, scales, in_c, DEV, 77)
+    crit = Loss(1.0, 0.1, 0)
+    fa, fb = net(left, ld, right, rd)
+    l1 = crit(fa, fb, flag); l1.backward()
+    g1 = {n: p.grad.clone() for n, p in net.named_parameters() if p.grad is not None}
+    net.zero_grad(set_to_none=True)
+    fb2, fa2 = net(right, rd, left, ld)
+    l2 = crit(fb2, fa2, flag); l2.backward()
+    assert torch.equal(fa, fa2) and torch.equal(fb, fb2)
+    assert float(l1.detach()) == float(l2.detach())
+    for n, p in net.named_parameters():
+        if p.grad is None:
+            continue
+        a, b = g1[n].float(), p.grad.float()
+        assert float((a - b).norm()) <= 2e-2 * float(a.norm()) + 1e-7, n
