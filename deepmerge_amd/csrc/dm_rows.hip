@@ -2,6 +2,8 @@
 // token pooling, column sums, casts, patch extraction, contrastive loss, Adam, and the
 // relative-position-bias gather / gradient reduction.  All loads/stores are 16-byte vectors
 // along the contiguous (channel) axis; reductions are wave64 butterflies.
+#include <cstdlib>
+
 #include "dm_common.h"
 
 namespace {
@@ -475,6 +477,11 @@ inline int grid_for(long long work_items, int block = 256, int cap = 4096) {
   return (int)g;
 }
 
+static int adam_grid(long long n) {
+  static const int cap = [] { const char *e = getenv("DM_ADAM_GRID"); return e ? atoi(e) : 16384; }();   // 4096 -> 16384 workgroups: 293 -> 258 us for 48.7 M parameters (5.7 TB/s)
+  return grid_for(n / 4 + 1, 256, cap);
+}
+
 }  // namespace
 
 // =============================================================================================
@@ -617,7 +624,7 @@ extern "C" int dm_adam_step(float *param, const float *grad, float *m, float *v,
   const double bc2 = 1.0 - pow(beta2, (double)step);
   const float step_size = (float)(lr / bc1);
   const float bc2_sqrt = (float)sqrt(bc2);
-  hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n / 4 + 1)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), param, grad, m, v,
+  hipLaunchKernelGGL(adam_kernel, dim3(adam_grid(n)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), param, grad, m, v,
                      (bf16_t *)param_lp, (long long)n, (float)beta1, (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2),
                      (float)eps, step_size, bc2_sqrt, (float)grad_scale, (const float *)nullptr);
   DM_LAUNCH_CHECK("dm_adam_step");
@@ -636,7 +643,7 @@ extern "C" int dm_adam_step_dev(float *param, const float *grad, float *m, float
   DM_REQUIRE(param && grad && m && v && hyper_dev && n > 0, DM_ERR_BAD_SHAPE, "dm_adam_step_dev: bad arguments");
   DM_REQUIRE(dm_aligned16(param) && dm_aligned16(grad) && dm_aligned16(m) && dm_aligned16(v) && dm_aligned16(param_lp), DM_ERR_BAD_ALIGN,
              "dm_adam_step_dev: buffers must be 16-byte aligned");
-  hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n / 4 + 1)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), param, grad, m, v,
+  hipLaunchKernelGGL(adam_kernel, dim3(adam_grid(n)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), param, grad, m, v,
                      (bf16_t *)param_lp, (long long)n, (float)beta1, (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2),
                      (float)eps, 0.f, 1.f, (float)grad_scale, hyper_dev);
   DM_LAUNCH_CHECK("dm_adam_step_dev");
