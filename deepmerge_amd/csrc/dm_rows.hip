@@ -9,7 +9,10 @@
 namespace {
 
 constexpr int MAXCH = 4;          // float4 chunks per lane per row -> cols <= 1024
-constexpr int LN_MAX_WG = 512;    // 2 workgroups (8 waves) per CU keep enough loads in flight
+static int ln_max_wg() {           // workgroups of the LayerNorm backward (each writes one partial row pair)
+  static const int v = [] { const char *e = getenv("DM_LN_WG"); return e ? atoi(e) : 512; }();
+  return v;
+}
 constexpr int CS_MAX_SLICES = 64;
 
 // ---------------------------------------------------------------------------------------------
@@ -501,7 +504,7 @@ extern "C" int dm_layernorm_fwd(const float *x, const float *gamma, const float 
   return DM_OK;
 }
 
-extern "C" int64_t dm_layernorm_bwd_partial_floats(int32_t cols) { return (int64_t)LN_MAX_WG * 2 * cols; }
+extern "C" int64_t dm_layernorm_bwd_partial_floats(int32_t cols) { return (int64_t)ln_max_wg() * 2 * cols; }
 
 extern "C" int dm_layernorm_bwd(const void *dy, int32_t dy_dtype, const float *x, const float *gamma, const float *mean,
                                 const float *rstd, const float *dres, float *dx, void *dx_lp, float *dgamma, float *dbeta,
@@ -510,7 +513,7 @@ extern "C" int dm_layernorm_bwd(const void *dy, int32_t dy_dtype, const float *x
              "dm_layernorm_bwd: rows=%d cols=%d", rows, cols);
   DM_REQUIRE(dy && x && gamma && mean && rstd && dx && dgamma && dbeta && partial, DM_ERR_BAD_SHAPE, "dm_layernorm_bwd: null pointer");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  const int grid = grid_for((long long)rows, 4, LN_MAX_WG);
+  const int grid = grid_for((long long)rows, 4, ln_max_wg());
   if (dy_dtype == DM_F32)
     hipLaunchKernelGGL(layernorm_bwd_kernel<float>, dim3(grid), dim3(256), 0, s, (const float *)dy, x, gamma, mean, rstd, dres, dx, (bf16_t *)dx_lp, partial, rows, cols);
   else if (dy_dtype == DM_BF16)
