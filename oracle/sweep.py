@@ -1,7 +1,8 @@
 """Oracle (test infrastructure): the ExtractFeatures region-adjacency similarity sweep.
 
-The reference module needs h5py/osgeo (absent here), so this file restates its pure-numpy
-arithmetic from source:
+Restatement of the reference's pure-numpy arithmetic, PINNED to the reference's own outputs
+(tests/golden/sweep.npz, produced by tests/golden/make_golden.py::gen_sweep which imports the unmodified
+ExtractFeatures.py and calls these very functions; checked by tests/test_oracle_sweep.py):
   Euclidean_distance        ExtractFeatures.py:119-147  (= Train_SMT.py:115-131 = MC_Lyu_2020 :228-237)
   per-edge loop body        ExtractFeatures.py:188-219  (gather point rows, np.mean(axis=0), distance, .max())
   RAG edge filtering        MyUtils2.py:177-192         (edges with LEFT_FID == -1 or RIGHT_FID == -1 skipped)

@@ -444,12 +444,178 @@ def gen_nets():
     print("model_nets.npz", len(fx))
 
 
+def import_sweep_reference():
+    """ExtractFeatures.py / MyUtils1.py import h5py, osgeo (gdal, ogr) and cv2 at module level (storage, GIS I/O and
+    the band resize: none installed here).  Same mechanism as the timm entry above: empty in-process module objects
+    satisfy the import statements; no function of those packages is ever called by what the fixtures exercise
+    (Euclidean_distance, MC_Lyu_2020, get_scales, calculate_left_top_point_and_size, cut_image, get_designed_features,
+    get_all_features with duck-typed feature / raster objects).  cv2.resize is NOT emulated: the resize stays unpinned."""
+    for name in ("h5py", "cv2", "osgeo", "osgeo.gdal", "osgeo.ogr", "osgeo.osr"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    for sub in ("gdal", "ogr", "osr"):
+        setattr(sys.modules["osgeo"], sub, sys.modules["osgeo." + sub])
+    sys.path.insert(0, REF)
+    import ExtractFeatures  # noqa
+    import MyUtils1  # noqa
+    return ExtractFeatures, MyUtils1
+
+
+class _Raster:
+    """Duck-typed stand-in for the gdal.Dataset METHODS cut_image / get_all_features call (data holder, no arithmetic)."""
+
+    def __init__(self, img, gt):
+        self.img = img
+        self.gt = gt
+        self.RasterCount, self.RasterYSize, self.RasterXSize = img.shape
+
+    def ReadAsArray(self, x, y, w, h):
+        assert 0 <= x and 0 <= y and w >= 0 and h >= 0 and x + w <= self.RasterXSize and y + h <= self.RasterYSize, (x, y, w, h)
+        return self.img[:, y:y + h, x:x + w]
+
+    def GetGeoTransform(self):
+        return self.gt
+
+
+class _Point:
+    """Duck-typed ogr.Feature: attribute table row + point geometry."""
+
+    def __init__(self, fields, x, y):
+        self.fields, self.x, self.y = fields, x, y
+
+    def GetField(self, k):
+        return self.fields[k]
+
+    def GetGeometryRef(self):
+        return self
+
+    def GetX(self):
+        return self.x
+
+    def GetY(self):
+        return self.y
+
+
+def gen_sweep():
+    """ExtractFeatures sweep arithmetic and loader window arithmetic from the reference's own functions
+    (VERDICT r1 item 1)."""
+    EF, MU1 = import_sweep_reference()
+    fx = {}
+    rng = np.random.default_rng(20240)
+    # ---- Euclidean_distance / MC_Lyu_2020 on float32 rows, D = 100 (the feature store's row width) ---------------
+    cases = {}
+    cases["n1m1"] = (rng.normal(size=(1, 100)) * 0.08, rng.normal(size=(1, 100)) * 0.08)
+    cases["n5m7"] = (rng.normal(size=(5, 100)) * 0.1, rng.normal(size=(7, 100)) * 0.1)
+    x = rng.normal(size=(6, 100)) * 0.3
+    cases["cancel"] = (x, x + rng.normal(size=(6, 100)) * 1e-4)               # x ~ y: expanded form is cancellation noise
+    cases["self"] = (x, x.copy())
+    a = rng.normal(size=(64, 100)); b = rng.normal(size=(64, 100))
+    a /= np.linalg.norm(a, axis=1, keepdims=True); b /= np.linalg.norm(b, axis=1, keepdims=True)
+    # distances laid on both sides of the margin 1.0: |a - t*b| swept through 1 (unit vectors, random angle)
+    tt = np.linspace(0.0, 1.6, 64)[:, None]
+    cases["near_margin"] = (a * 0.75, a * 0.75 - tt * b * 0.9)
+    cases["p3"] = (rng.normal(size=(4, 3)), rng.normal(size=(2, 3)))
+    for tag, (X, Y) in cases.items():
+        X = np.ascontiguousarray(X, np.float32); Y = np.ascontiguousarray(Y, np.float32)
+        D1 = EF.Euclidean_distance(X.copy(), Y.copy())
+        D2 = EF.MC_Lyu_2020(X.copy(), Y.copy())
+        assert D1.dtype == np.float32 and np.array_equal(D1, D2)
+        fx[f"dist/{tag}/X"] = X; fx[f"dist/{tag}/Y"] = Y; fx[f"dist/{tag}/D"] = D1
+    fx["dist/tags"] = np.array(list(cases.keys()))
+    # ---- the per-edge loop body of test_for_shp (ExtractFeatures.py:188-216) on an in-memory feature store ----------
+    # rows fetched one by one and np.concatenate'd, np.mean(axis=0), [np.newaxis,:], Euclidean_distance, .max();
+    # edges with LEFT_FID/RIGHT_FID == -1 never reach the loop (MyUtils2.py:184-186).
+    S, Dm = 60, 100
+    counts = rng.integers(1, 6, size=S)
+    ptr = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
+    P = int(ptr[-1])
+    idx = rng.permutation(P).astype(np.int32)
+    base = rng.normal(size=(S, Dm)) * 0.05
+    # neighbouring polygons share a slowly varying component so simi straddles the margin
+    drift = np.cumsum(rng.normal(size=(S, Dm)) * 0.055, axis=0)
+    F = np.zeros((P, Dm), np.float32)
+    for s in range(S):
+        F[idx[ptr[s]:ptr[s + 1]]] = (base[s] + drift[s] + rng.normal(size=(counts[s], Dm)) * 0.02).astype(np.float32)
+    E = 400
+    edges = np.stack([rng.integers(0, S, size=E), rng.integers(0, S, size=E)], 1).astype(np.int32)
+    near = rng.random(E) < 0.7
+    edges[near, 1] = np.clip(edges[near, 0] + rng.integers(1, 4, size=int(near.sum())), 0, S - 1)
+    same = edges[:, 0] == edges[:, 1]
+    edges[same, 1] = (edges[same, 0] + 1) % S
+    edges[::19, 0] = -1
+    edges[7::29, 1] = -1
+    simi = np.full(E, np.nan, np.float32)
+    pooled = np.zeros((S, Dm), np.float32)
+    for e in range(E):
+        L, R = int(edges[e, 0]), int(edges[e, 1])
+        if L == -1 or R == -1:
+            continue
+        sides = []
+        for poly in (L, R):
+            out = []
+            for m, pid in enumerate(idx[ptr[poly]:ptr[poly + 1]]):
+                row = F[int(pid)][np.newaxis, :]
+                out = row if m == 0 else np.concatenate((out, row), axis=0)
+            out = np.mean(out, axis=0)
+            pooled[poly] = out
+            sides.append(out[np.newaxis, :])
+        simi[e] = EF.Euclidean_distance(sides[0], sides[1]).max()
+    live = ~np.isnan(simi)
+    fx["sweep/F"] = F; fx["sweep/ptr"] = ptr; fx["sweep/idx"] = idx; fx["sweep/edges"] = edges
+    fx["sweep/simi"] = simi; fx["sweep/pooled"] = pooled
+    fx["sweep/pooled_valid"] = np.isin(np.arange(S), edges[live].ravel())
+    print("sweep: live", int(live.sum()), "merge fraction", float((simi[live] < 1.0).mean()),
+          "min |simi-1|", float(np.abs(simi[live] - 1).min()))
+    # ---- loader window arithmetic (MyUtils1.py): get_scales, calculate_left_top_point_and_size, cut_image, and the whole
+    # get_all_features chain (designed-feature order, geo -> pixel, windows) with resize_data replaced ON THE INSTANCE by a
+    # pass-through so the zero-padded uint8 crops are observable (cv2 is absent; the resize itself stays unpinned) -----
+    ds = object.__new__(MU1.MergingSegmensPairDataset)
+    io = np.array([[16, 24], [24, 48], [64, 112], [20, 21], [33, 90], [50, 50]], np.int64)
+    fx["win/inner_object"] = io
+    sc, fc = zip(*(ds.get_scales(int(i), int(o)) for i, o in io))
+    fx["win/scales"] = np.array(sc, np.int64); fx["win/factors"] = np.array(fc, np.float64)
+    mids = np.array([[10, 10, 8], [10, 10, 7], [2, 1, 7], [0, 0, 1], [5, 9, 24], [100, 3, 33], [0, 0, 6]], np.int64)
+    fx["win/mid_len"] = mids
+    fx["win/left_top"] = np.array([ds.calculate_left_top_point_and_size(int(a), int(b), int(c)) for a, b, c in mids], np.int64)
+    img = rng.integers(0, 256, size=(4, 37, 53), dtype=np.uint8)
+    gt = (500000.0, 0.5, 0.0, 4100000.0, 0.0, -0.5)
+    raster = _Raster(img, gt)
+    fx["crop/img"] = img; fx["crop/gt"] = np.array(gt, np.float64)
+    boxes = np.array([[-3, -2, 8], [0, 0, 5], [48, 30, 9], [50, 35, 6], [-10, 10, 12], [20, -4, 11], [-5, -5, 70], [30, 20, 1]], np.int64)
+    fx["crop/boxes"] = boxes
+    for k, (x0, y0, L) in enumerate(boxes):
+        fx[f"crop/out{k}"] = ds.cut_image(raster, (int(x0), int(y0), int(L), int(L)))
+    # identity-size windows (L == target, so the resize is the identity whatever its rule): mid-point -> crop, what the GPU
+    # gather must reproduce exactly through calculate_left_top_point_and_size + cut_image
+    ident = np.array([[3, 3, 32], [50, 35, 32], [26, 18, 32], [0, 36, 64], [52, 0, 64], [26, 18, 64], [-2, 40, 32]], np.int64)
+    fx["ident/mid_len"] = ident
+    for k, (mx, my, L) in enumerate(ident):
+        fx[f"ident/out{k}"] = ds.cut_image(raster, ds.calculate_left_top_point_and_size(int(mx), int(my), int(L)))
+    names = ["area", "peri", "len", "width", "smooth", "std0", "std1", "std2", "mean0", "mean1", "mean2", "shapeness", "compact", "bright", "border"]
+    fx["point/field_order"] = np.array(names)
+    ds.resize_data = lambda region, h, w: region
+    pts = []
+    for k, (inner, obj, gx, gy) in enumerate(((16, 24, 500003.3, 4099995.2), (24, 48, 500020.75, 4099983.0), (8, 40, 500000.1, 4099999.9))):
+        fields = {n: str(round(float(v), 4)) for n, v in zip(names, np.exp(rng.uniform(np.log(1e-2), np.log(1e3), 15)))}
+        fields.update(inner=str(inner), object=str(obj))
+        designed, scales_t, patches = ds.get_all_features(raster, _Point(fields, gx, gy))
+        fx[f"point/{k}/fields"] = np.array([float(fields[n]) for n in names], np.float64)
+        fx[f"point/{k}/inner_object_xy"] = np.array([inner, obj, gx, gy], np.float64)
+        fx[f"point/{k}/designed"] = designed.numpy()
+        fx[f"point/{k}/scales"] = scales_t.numpy()
+        for i, p in enumerate(patches):
+            fx[f"point/{k}/crop{i}"] = p
+        pts.append(k)
+    fx["point/n"] = np.int64(len(pts))
+    np.savez_compressed(os.path.join(HERE, "sweep.npz"), **fx)
+    print("sweep.npz", len(fx))
+
+
 def main():
     warnings.filterwarnings("ignore")
     torch.manual_seed(0)
     torch.set_num_threads(8)
     S2F, vit_model, Losses = import_reference()
-    which = sys.argv[1:] or ["relpos", "ops", "model", "vit", "variants", "aux", "nets"]
+    which = sys.argv[1:] or ["relpos", "ops", "model", "vit", "variants", "aux", "nets", "sweep"]
     if "relpos" in which:
         gen_relpos(S2F)
     if "ops" in which:
@@ -464,6 +630,8 @@ def main():
         gen_aux(S2F, Losses)
     if "nets" in which:
         gen_nets()
+    if "sweep" in which:
+        gen_sweep()
 
 
 if __name__ == "__main__":

@@ -81,3 +81,36 @@ def test_patch_pyramid_full_tile_properties():
     assert float(ops.patch_pyramid(const, far, torch.tensor([50], dtype=torch.int32, device=DEV), 32).abs().max()) == 0.0
     with pytest.raises(ValueError):
         ops.patch_pyramid(const, inside, torch.tensor([500], dtype=torch.int32, device=DEV), 32)
+
+
+def test_identity_windows_match_reference_crops():
+    """tests/golden/sweep.npz `ident/*`: the reference's calculate_left_top_point_and_size + cut_image for windows whose
+    length equals the target (the resize is then the identity under any rule), including windows hanging over every border."""
+    from deepmerge_amd import ops
+    from util import load_fx
+    fx = load_fx("sweep.npz")
+    tile = torch.from_numpy(fx["crop/img"]).to(DEV)
+    for k, (mx, my, L) in enumerate(fx["ident/mid_len"]):
+        xy = torch.tensor([[int(mx), int(my)]], dtype=torch.int32, device=DEV)
+        got = ops.patch_pyramid(tile, xy, torch.tensor([int(L)], dtype=torch.int32, device=DEV), int(L))[0].cpu().numpy()
+        assert np.array_equal(got, fx[f"ident/out{k}"].astype(np.float32) / 255.0), k
+
+
+def test_point_chain_matches_reference_fixture():
+    """get_all_features through the device helpers: geo -> pixel (+1), windows, factors, designed-feature layout."""
+    from deepmerge_amd.patches import geo_to_pixel, get_scales
+    from util import load_fx
+    fx = load_fx("sweep.npz")
+    gt = fx["crop/gt"].tolist()
+    for k in range(int(fx["point/n"])):
+        inner, obj, gx, gy = fx[f"point/{k}/inner_object_xy"]
+        windows, factors = get_scales(torch.tensor([int(inner)]), torch.tensor([int(obj)]))
+        assert np.array_equal(windows.numpy().astype(np.float32), fx[f"point/{k}/scales"])
+        want = fx[f"point/{k}/designed"]
+        assert np.array_equal(factors.numpy(), want[:, 15:])
+        px = geo_to_pixel(gt, torch.tensor([gx], dtype=torch.float64), torch.tensor([gy], dtype=torch.float64))[0].tolist()
+        # the pixel the reference centred its crops on: recover it from the identity between its crop and cut_image at that pixel
+        img = fx["crop/img"]
+        for i, L in enumerate(windows[0].tolist()):
+            x0, y0 = OP.top_left(px[0], px[1], L)
+            assert np.array_equal(OP.cut_image(img, x0, y0, L), fx[f"point/{k}/crop{i}"])

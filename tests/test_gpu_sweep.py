@@ -97,3 +97,43 @@ def test_sweep_rejects_unpinned_dims():
     from deepmerge_amd import ops
     with pytest.raises(ValueError):
         ops.edge_similarity(torch.zeros(4, 200, device=DEV), torch.zeros(2, 2, dtype=torch.int32, device=DEV))
+
+
+# ---- against the reference's own outputs (tests/golden/sweep.npz: ExtractFeatures.Euclidean_distance + the loop body) ----
+def test_sweep_matches_reference_fixture():
+    from test_oracle_sweep import assert_simi_close
+    from util import load_fx
+    fx = load_fx("sweep.npz")
+    F, ptr, idx, edges, simi, pooled = (fx["sweep/" + k] for k in ("F", "ptr", "idx", "edges", "simi", "pooled"))
+    valid = fx["sweep/pooled_valid"]
+    got_pooled, got_simi, got_merge = run_gpu(F, ptr, idx, edges)
+    assert np.array_equal(got_pooled[valid], pooled[valid]), "pooled rows must equal the reference's np.mean bit for bit"
+    live = ~np.isnan(simi)
+    assert np.array_equal(np.isnan(got_simi), ~live) and not got_merge[~live].any()
+    tol = assert_simi_close(got_simi[live], simi[live], pooled[edges[live, 0]], pooled[edges[live, 1]])
+    assert (np.abs(simi[live] - 1.0) > tol).all()
+    assert np.array_equal(got_merge[live], simi[live] < 1.0), "merge decisions must equal the reference's bit for bit"
+    assert 0.1 < got_merge[live].mean() < 0.9
+
+
+def test_edge_similarity_matches_reference_distance_cases():
+    from deepmerge_amd import ops
+    from test_oracle_sweep import assert_simi_close
+    from util import load_fx
+    fx = load_fx("sweep.npz")
+    n_near = 0
+    for tag in fx["dist/tags"]:
+        X, Y, D = fx[f"dist/{tag}/X"], fx[f"dist/{tag}/Y"], fx[f"dist/{tag}/D"]
+        if X.shape[1] != 100:
+            continue
+        n, m = X.shape[0], Y.shape[0]
+        pooled = torch.from_numpy(np.concatenate([X, Y])).to(DEV)
+        ii, jj = np.meshgrid(np.arange(n), np.arange(m), indexing="ij")
+        edges = np.stack([ii.ravel(), n + jj.ravel()], 1).astype(np.int32)
+        simi, merge = ops.edge_similarity(pooled, torch.from_numpy(edges).to(DEV), 1.0)
+        simi = simi.cpu().numpy().reshape(n, m); merge = merge.cpu().numpy().reshape(n, m).astype(bool)
+        tol = assert_simi_close(simi, D, X[:, None, :], Y[None, :, :])
+        near = np.abs(D - 1.0) <= tol
+        n_near += int(near.sum())
+        assert np.array_equal(merge[~near], (D < 1.0)[~near]), tag
+    assert n_near <= 2

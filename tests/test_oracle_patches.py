@@ -57,3 +57,48 @@ def test_patch_pyramid_shapes_and_range():
     assert [o.shape for o in out] == [(4, 32, 32), (4, 64, 64), (4, 128, 128)]
     assert all(o.dtype == np.float32 and 0 <= o.min() and o.max() <= 1 for o in out)
     assert all(np.array_equal(np.round(o * 255), o * 255) for o in out)                # values on the uint8/255 grid
+
+
+# ---- pinned against the reference's own MyUtils1 functions (tests/golden/sweep.npz, make_golden.py gen_sweep) --------------
+def _fx():
+    from util import load_fx
+    return load_fx("sweep.npz")
+
+
+def test_window_arithmetic_matches_reference():
+    fx = _fx()
+    for (inner, obj), sc, fc in zip(fx["win/inner_object"], fx["win/scales"], fx["win/factors"]):
+        w, f = OP.get_scales(int(inner), int(obj))
+        assert w == sc.tolist() and f == fc.tolist()
+    for (mx, my, L), lt in zip(fx["win/mid_len"], fx["win/left_top"]):
+        assert OP.top_left(int(mx), int(my), int(L)) == (int(lt[0]), int(lt[1])) and int(lt[2]) == int(lt[3]) == int(L)
+
+
+def test_cut_image_matches_reference():
+    fx = _fx()
+    img = fx["crop/img"]
+    for k, (x0, y0, L) in enumerate(fx["crop/boxes"]):
+        assert np.array_equal(OP.cut_image(img, int(x0), int(y0), int(L)), fx[f"crop/out{k}"]), k
+    for k, (mx, my, L) in enumerate(fx["ident/mid_len"]):
+        x0, y0 = OP.top_left(int(mx), int(my), int(L))
+        want = fx[f"ident/out{k}"]
+        assert np.array_equal(OP.cut_image(img, x0, y0, int(L)), want), k
+        # L == target: every resize rule is the identity there, so the whole pyramid stage is pinned for such windows
+        assert np.array_equal(OP.patch_pyramid(img, int(mx), int(my), [int(L)], (int(L),))[0], want.astype(np.float32) / 255.0)
+
+
+def test_point_chain_matches_reference():
+    """get_all_features (MyUtils1.py:60-77): designed-feature order (D1), factors (D2), geo -> pixel with its +1 (D3),
+    windows and zero-padded crops (D4, before the unpinned resize)."""
+    fx = _fx()
+    img, gt = fx["crop/img"], fx["crop/gt"]
+    for k in range(int(fx["point/n"])):
+        inner, obj, gx, gy = fx[f"point/{k}/inner_object_xy"]
+        w, f = OP.get_scales(int(inner), int(obj))
+        assert np.array_equal(np.array(w, np.float32)[None], fx[f"point/{k}/scales"])
+        designed = np.concatenate([fx[f"point/{k}/fields"], f]).astype(np.float32)[None]
+        assert np.array_equal(designed, fx[f"point/{k}/designed"])
+        px, py = OP.geo_to_pixel(gt, float(gx), float(gy))
+        for i, L in enumerate(w):
+            x0, y0 = OP.top_left(px, py, L)
+            assert np.array_equal(OP.cut_image(img, x0, y0, L), fx[f"point/{k}/crop{i}"]), (k, i)
