@@ -38,6 +38,8 @@
 // dm_gemm256.hip: the 256x256 LDS-DMA pipeline for large bf16 products
 bool dm_gemm256_plan(GemmParams &p, int layout, int ab_dtype, bool can_split, long long workspace_bytes, int user_split);
 void dm_gemm256_launch(const GemmParams &p, int layout, hipStream_t s);
+int dm_gemm_ring_plan(GemmParams &p, int layout, int ab_dtype, bool aligned8);      // dm_gemm_ring.hip
+void dm_gemm_ring_launch(const GemmParams &p, int wm, hipStream_t s);
 
 namespace {
 
@@ -559,10 +561,14 @@ extern "C" int dm_gemm(const DmGemmArgs *a, void *stream) {
                          a->c_dtype == DM_F32 && a->rows_per_group == 0 && a->workspace != nullptr && slab_bytes > 0;
   if (a->split_k > 1)
     DM_REQUIRE(can_split, DM_ERR_UNSUPPORTED, "dm_gemm: split_k needs DM_TN, no epilogue, fp32 C and a workspace");
-  const bool big = dm_gemm256_plan(p, a->layout, a->ab_dtype, can_split, slab_bytes, a->split_k);
-  const int tile = big ? 256 : pick_tile(a->layout, a->M, a->N, a->K);
-  int split = p.split_k;
-  if (!big) {
+  // two-workgroups-per-CU ring kernel (k-contiguous operands, 16-byte row pieces in the epilogue)
+  const bool ring_aligned = (a->ldc % 8 == 0) && (a->aux == nullptr || a->ldaux % 8 == 0) &&
+                            (a->rows_per_group == 0 || a->group_stride % 8 == 0) && a->split_k <= 1 && !a->colsum_a;
+  const int ring = dm_gemm_ring_plan(p, a->layout, a->ab_dtype, ring_aligned);
+  const bool big = !ring && dm_gemm256_plan(p, a->layout, a->ab_dtype, can_split, slab_bytes, a->split_k);
+  const int tile = ring ? (ring == 8 ? 2568 : 1288) : big ? 256 : pick_tile(a->layout, a->M, a->N, a->K);
+  int split = ring ? 1 : p.split_k;
+  if (!big && !ring) {
     p.tiles_m = (a->M + tile - 1) / tile;
     p.tiles_n = (a->N + tile - 1) / tile;
     const int bk = (a->ab_dtype == DM_BF16) ? 64 : 32;
@@ -599,7 +605,9 @@ extern "C" int dm_gemm(const DmGemmArgs *a, void *stream) {
                      esz * ((double)a->M * a->K + (double)a->N * a->K) + csz * mn * (a->accumulate ? 2.0 : 1.0) +
                          (a->residual ? 4.0 * mn : 0.0) + (a->aux ? ((a->aux_dtype == DM_BF16) ? 2.0 : 4.0) * mn : 0.0));
     p.colsum_slab = (big && cs_region) ? cs_region : nullptr;
-    if (big) {
+    if (ring) {
+      dm_gemm_ring_launch(p, ring, s);
+    } else if (big) {
       dm_gemm256_launch(p, a->layout, s);
     } else if (a->ab_dtype == DM_BF16) {
       if (tile == 128) launch_mfma<bf16_t, 4>(p, a->layout, grid, s); else launch_mfma<bf16_t, 2>(p, a->layout, grid, s);

@@ -15,6 +15,7 @@ struct GemmParams {
   int tiles_m, tiles_n, split_k, k_per_split;
   int group_m;   // > 0: tiles are walked in bands of group_m row tiles, rows fastest inside a band (L2 reuse)
   float *workspace;
+  int debug;     // ring kernel ablations (-DDM_RING_ABLATE builds, DM_RING_DEBUG: 1 no DMA in the loop, 2 no MFMA, 4 no fragment reads, 8 no stores); 0 in production
   float *colsum_slab;   // TN pipeline: partial column sums of A, [split_k * 4][M] (NULL: not wanted)
 };
 

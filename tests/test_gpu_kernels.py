@@ -51,6 +51,50 @@ def test_gemm_exact_integers(mode, layout, M, N, K):
     assert torch.equal(got, want), f"max diff {(got - want).abs().max()}"
 
 
+@pytest.fixture
+def ring_env():
+    """Route every legal bf16 NT product to the two-workgroups-per-CU ring kernel (dm_gemm_ring.hip) for one test."""
+    import os
+    old = {k: os.environ.get(k) for k in ("DM_GEMM_RING", "DM_GEMM_RING_WM")}
+
+    def set_(wm):
+        os.environ["DM_GEMM_RING"] = "2"
+        os.environ["DM_GEMM_RING_WM"] = str(wm)
+    yield set_
+    for k, v in old.items():
+        if v is None:
+            os.environ.pop(k, None)
+        else:
+            os.environ[k] = v
+
+
+@pytest.mark.parametrize("wm", [8, 4])
+@pytest.mark.parametrize("M,N,K", [(256, 128, 64), (512, 384, 96), (1000, 136, 768), (16, 768, 3072), (4096, 2304, 768), (300, 8, 160), (257, 264, 2304)])
+def test_gemm_ring_exact_integers(ring_env, wm, M, N, K):
+    """Exact small-integer products through the ring kernel: ragged M (zero-filled by the DMA descriptor, masked stores),
+    N tails (N % 8 == 0), 2 .. 96 K steps, both tile heights; bf16 and fp32 outputs."""
+    ops = _ops()
+    from deepmerge_amd._lib import DM_NT
+    ring_env(wm)
+    rng = np.random.default_rng(M + 3 * N + 7 * K + wm)
+    a, b = _ints(rng, (M, K)), _ints(rng, (N, K))
+    want = a.double() @ b.double().T
+    A, B_ = a.to(DEV).to(torch.bfloat16), b.to(DEV).to(torch.bfloat16)
+    Cc = torch.full((M + 3, N), float("nan"), device=DEV)
+    ops.gemm(DM_NT, A, B_, Cc, M, N, K, lda=K, ldb=K, ldc=N)
+    assert torch.equal(Cc[:M].cpu().double(), want), f"max diff {(Cc[:M].cpu().double() - want).abs().max()}"
+    assert torch.isnan(Cc[M:]).all(), "rows past M must not be written"
+    Ch = torch.zeros((M, N), device=DEV, dtype=torch.bfloat16)
+    ops.gemm(DM_NT, A, B_, Ch, M, N, K, lda=K, ldb=K, ldc=N)
+    assert torch.equal(Ch.cpu().double(), want.to(torch.bfloat16).double())
+
+
+@pytest.mark.parametrize("wm", [8, 4])
+def test_gemm_ring_epilogues(ring_env, wm):
+    ring_env(wm)
+    test_gemm_epilogues("bf16")
+
+
 @pytest.mark.parametrize("mode", ["fp32", "bf16"])
 def test_gemm_epilogues(mode):
     """bias, GELU (+saved pre-activation), DGELU, residual, accumulate, bf16 output, grouped rows."""
