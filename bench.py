@@ -21,6 +21,26 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+# profiler row (a class of launches) -> the device symbols behind it, as rocprofv3 prints them
+KERNEL_SYMBOLS = {
+    "gemm_bf16_NT": ["dmring::gemm_ring_kernel<8|4, 0> (wide outputs)", "dm256::gemm256_kernel<0> (long K)", "gemm_kernel<__bf16, 0, 4|2> (128x128 / 64x64 tiles)"],
+    "gemm_bf16_NN": ["gemm_kernel<__bf16, 1, 4|2>", "dm256::gemm256_kernel<1>"],
+    "gemm_bf16_TN": ["dm256::gemm256_kernel<2> (+ splitk_reduce_kernel)", "gemm_kernel<__bf16, 2, 4|2>"],
+    "attn_fwd_bf16": ["dmpipe::attn_fwd_pipe_kernel<NKT, RAGGED>", "attn_fwd_kernel<__bf16, ...> (N < 128)"],
+    "attn_bwd_bf16": ["dmpipe::attn_bwd_dq_pipe_kernel", "dmpipe::attn_bwd_dkv_pipe_kernel", "attn_bwd_dq_kernel / attn_bwd_dkv_kernel (N < 128)"],
+}
+
+
+def csrc_hash():
+    """sha256 over the kernel sources (the stamp profiles/pmc_traffic.json must carry to be quoted)."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "deepmerge_amd", "csrc", "*.h*")) + glob.glob(os.path.join(ROOT, "deepmerge_amd", "csrc", "*.cpp"))):
+        h.update(os.path.basename(f).encode()); h.update(open(f, "rb").read())
+    return h.hexdigest()
+
+
 PEAK_BF16_TFLOPS = 2500.0    # dense bf16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
 PEAK_HBM_TBPS = 8.0
 PEAK_F32_TFLOPS = 157.3
@@ -100,21 +120,67 @@ def cpu_baseline(cfg_scales, in_c, depth, pairs, steps):
             "sample": f"{steps} timed steps (+1 warm-up) of {pairs} pairs, same model/inputs shape, torch CPU fp32 oracle"}
 
 
+def extras(args, scales, in_c, depth, dev):
+    """Secondary numbers of the same build on the same box (builder-run in round 1, driver-run from round 2 on): the fp32 parity
+    mode of the headline config, and BASELINE configs 3 / 4 / 5 (one GPU).  Outside the timed region of the headline metric."""
+    import torch
+    out = {}
+    try:
+        from deepmerge_amd.nets.ShfitScaleFormer import ShfitScaleFormer_v3
+        from deepmerge_amd.trainer import PairTrainer
+        log("extras: fp32 parity mode, 5 steps")
+        torch.manual_seed(0)
+        net = ShfitScaleFormer_v3(cube_size=[8, 8], input_image_scales=list(scales), depth=list(depth), in_c=in_c, numerics="fp32").to(dev)
+        tr = PairTrainer(net, margin=1.0, lr=1e-4)
+        batch = synth_batch(args.pairs, scales, in_c, dev, 1000)
+        for _ in range(2):
+            tr.step(*batch)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(5):
+            tr.step(*batch)
+        torch.cuda.synchronize(); d = (time.perf_counter() - t0) / 5
+        out["fp32_parity_pairs_per_s"] = round(args.pairs / d, 1)
+        out["fp32_parity_ms_per_step"] = round(1e3 * d, 2)
+        del net, tr, batch
+        torch.cuda.empty_cache()
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import bench_configs as BC
+        log("extras: config 3 (ViT-B/16 pairs)")
+        c3 = BC.config3(steps=5)
+        out["config3_vit_pairs_per_s"], out["config3"] = c3["pairs_per_s"], c3
+        torch.cuda.empty_cache()
+        log("extras: config 5 per GPU (v3 [6,4,2], 120 pairs)")
+        c5 = BC.config5(steps=5, graph=True)
+        out["config5_per_gpu_pairs_per_s"], out["config5"] = c5["pairs_per_s"], c5
+        torch.cuda.empty_cache()
+        log("extras: config 4 (ExtractFeatures tile)")
+        c4 = BC.config4(passes=1)
+        out["config4_points_per_s"] = c4["encode(gather + v3[6,4,2] eval, batch 2000)"]["points_per_s"]
+        out["config4_edges_per_s"] = c4["edge_similarity"]["edges_per_s"]
+        out["config4"] = c4
+    except Exception as e:      # secondary numbers must never take the headline line down
+        out["error"] = f"{type(e).__name__}: {e}"
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--pairs", type=int, default=32, help="pairs per GPU per step")
     ap.add_argument("--depth", type=str, default="3,2,1")
     ap.add_argument("--numerics", type=str, default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-pairs", type=int, default=8)
-    ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--cpu-pairs", type=int, default=0, help="pairs per CPU-baseline step (0 = the same batch as --pairs, SURVEY 8d)")
+    ap.add_argument("--cpu-steps", type=int, default=3, help="timed CPU-baseline steps after one warm-up")
+    ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements (fp32 parity mode, BASELINE configs 3 / 4 / 5) that "
+                    "the default one-GPU run appends to the JSON line")
     ap.add_argument("--backend", type=str, default="nccl", choices=["nccl", "gloo"],
                     help="collective backend for --gpus > 1 (gloo only to rehearse the DP path with several ranks on ONE GPU)")
     ap.add_argument("--graph", type=str, default="auto", choices=["auto", "on", "off"],
-                    help="replay the step from a captured hipGraph (auto: on for one GPU; the data-parallel exchange runs eagerly)")
+                    help="replay the step's compute from captured hipGraphs (auto = on; with several ranks one graph per backward segment, "
+                         "the bucket all-reduces are launched eagerly between them)")
     args = ap.parse_args()
 
     import torch
@@ -157,7 +223,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    use_graph = (args.graph == "on") or (args.graph == "auto" and world == 1)
+    use_graph = args.graph in ("on", "auto")
     n_warm = args.warmup
     if use_graph:
         n_warm = max(args.warmup, 2)                     # >= 1 eager step (lazy caches) + the capturing step, all untimed
@@ -188,10 +254,40 @@ def main():
             trainer._eager_step(*batch)
         torch.cuda.synchronize()
         lib.dm_prof_enable(0)
+    dp = None
     if world > 1:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+        # what the exchange costs: (a) the same steps with the collectives skipped (compute only), (b) the bucketed all-reduce
+        # of the gradient buffer alone, back to back -- both outside the timed region, same process, same buffers
+        calls0, bytes0 = trainer.stats["allreduce_calls"], trainer.stats["allreduce_bytes"]
+        steps_seen = max(1, trainer.step_count)
+        trainer.exchange = False
+        sync(); t1 = time.perf_counter()
+        for _ in range(args.steps):
+            trainer.step(*batch)
+        sync(); dt_compute = time.perf_counter() - t1
+        trainer.exchange = True
+        sync(); t1 = time.perf_counter()
+        for _ in range(args.steps):
+            for bi in range(len(trainer.bucket_slices)):
+                trainer._launch_bucket(bi)
+            trainer._wait_exchange()
+        sync(); dt_xchg = time.perf_counter() - t1
+        tx = torch.tensor([dt_compute, dt_xchg], device=dev, dtype=torch.float64)
+        dist.all_reduce(tx, op=dist.ReduceOp.MAX)
+        try:
+            nccl_version = ".".join(str(v) for v in torch.cuda.nccl.version()) if args.backend == "nccl" else None
+        except Exception:
+            nccl_version = None
+        dp = {"world": world, "backend": args.backend, "nccl_version": nccl_version, "n_buckets": len(trainer.bucket_slices),
+              "bucket_MB": [round((b.stop - b.start) * 4 / 1e6, 1) for b in trainer.bucket_slices],
+              "allreduce_calls_per_step": round(calls0 / steps_seen, 2), "allreduce_bytes_per_step": int(bytes0 / steps_seen),
+              "exchange_ms_per_step": round(1e3 * float(tx[1]) / args.steps, 3),
+              "compute_only_ms_per_step": round(1e3 * float(tx[0]) / args.steps, 3),
+              "exposed_exchange_ms_per_step": round(1e3 * (dt - float(tx[0])) / args.steps, 3),
+              "segmented_backward": bool(trainer.segmented)}
     rows = (_lib.DmProfRow * 256)()
     n = lib.dm_prof_collect(rows, 256)
     prof = {rows[i].name.decode(): (rows[i].launches, rows[i].total_ms, rows[i].total_flops, rows[i].total_bytes) for i in range(n)}
@@ -206,14 +302,19 @@ def main():
             launches, ms, flops, _ = prof[dom]
             peak = PEAK_BF16_TFLOPS if "bf16" in dom else PEAK_F32_TFLOPS
             ach = flops / (ms * 1e-3) / 1e12
-            traffic = None      # HBM bytes per launch from the committed PMC passes (profiles/pmc_traffic.json), if any
+            # HBM bytes per launch from the committed PMC passes (profiles/pmc_traffic.json): only valid for the kernel sources
+            # they were collected on -- the file carries a hash of deepmerge_amd/csrc and is ignored when that differs
+            traffic, traffic_note = None, "no profiles/pmc_traffic.json"
             try:
                 pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-                if dom in pmc:
+                if pmc.get("_csrc_sha256") != csrc_hash():
+                    traffic_note = "profiles/pmc_traffic.json was collected on other kernel sources (stamp mismatch): not reported"
+                elif dom in pmc:
                     traffic = round(pmc[dom]["fetch_bytes"] + pmc[dom]["write_bytes"])
+                    traffic_note = "rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE, separate passes, same sources (tools/pmc_traffic.py)"
             except Exception:
                 pass
-            roof = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
+            roof = {"bound": "mfma", "kernel": dom, "kernel_symbols": KERNEL_SYMBOLS.get(dom, []), "traffic_note": traffic_note, "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
                     "frac": round(ach / peak, 4), "traffic": traffic, "algorithmic_bytes_per_launch": round(prof[dom][3] / launches),
                     "launches": launches,
                     # roofline position of this launch mix: FLOP per algorithmic HBM byte against the 312 FLOP/B ridge
@@ -235,12 +336,15 @@ def main():
                        "gflop_per_pair_step": round(flop_pair / 1e9, 2)},
             "model_tflops_per_gpu": round(value / world * flop_pair / 1e12, 2),
             "loss": float(loss.item()), "backend": args.backend if world > 1 else None, "hip_graph": bool(use_graph),
+            "data_parallel": dp,
             "roofline": roof,
         }
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(scales, in_c, depth, args.cpu_pairs, args.cpu_steps)
+            out["cpu_baseline"] = cpu_baseline(scales, in_c, depth, args.cpu_pairs or args.pairs, args.cpu_steps)
         else:
             out["cpu_baseline"] = None
+        if world == 1 and not args.no_extras:
+            out["extras"] = extras(args, scales, in_c, depth, dev)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -263,9 +263,15 @@ class ShfitScaleFormer_v3(nn.Module):
     def _ln(self, x, out_dtype=torch.float32):
         return ops.LayerNormFn.apply(x, self.norm.weight, self.norm.bias, self.norm.eps, out_dtype)
 
+    _dp_cut = None      # set by PairTrainer for one forward pass: autograd cut points for the segmented (data-parallel) backward
+
     def backbone(self, x):
         S, side = self.input_scales_num, self.cube_size[1]
-        x = self.blocks0(x)
+        if self._dp_cut is None:
+            x = self.blocks0(x)
+        else:                                    # stage 0 holds ~55 % of the step: one backward segment per block
+            for blk in self.blocks0:
+                x = self._dp_cut(blk(x), blk)
         x = self._ln(ops.TokenPoolFn.apply(x, S, side))
         x = self.blocks1(x)
         x = self._ln(ops.TokenPoolFn.apply(x, S, side // 2))

@@ -68,13 +68,20 @@ def _need_cuda(*ts):
 # workspace (grow-only scratch per device; stream-ordered reuse on the current stream)
 # ------------------------------------------------------------------------------------------------
 _ws = {}
+_ws_retired = []     # replaced workspaces stay allocated: a captured hipGraph (PairTrainer.enable_graph) has their raw addresses
+                     # baked into its kernel arguments, so handing the memory back to the caching allocator would let a later
+                     # tensor alias the split-K slabs / LayerNorm partials of every replay.  Growth is geometric, so the
+                     # retired buffers of a slot sum to less than its live one.
 
 
 def workspace(nbytes: int, device, slot: str = "main") -> torch.Tensor:
     key = (torch.device(device).index, slot)
     buf = _ws.get(key)
     if buf is None or buf.numel() < nbytes:
-        buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        want = max(int(nbytes), 1 << 20, 2 * buf.numel() if buf is not None else 0)
+        if buf is not None:
+            _ws_retired.append(buf)
+        buf = torch.empty(want, dtype=torch.uint8, device=device)
         _ws[key] = buf
     return buf
 
@@ -287,17 +294,27 @@ def adam_step_dev(param, grad, m, v, hyper_dev, beta1=0.9, beta2=0.999, eps=1e-8
                                       hyper_dev.data_ptr(), beta1, beta2, eps, grad_scale, _stream()), "dm_adam_step_dev")
 
 
-def segment_mean(F: torch.Tensor, ptr: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
+def segment_mean(F: torch.Tensor, ptr: torch.Tensor, idx: torch.Tensor, validate: bool = True) -> torch.Tensor:
+    """validate: one host check per call that the CSR is well formed (an out-of-range id would be an out-of-bounds device read,
+    i.e. a GPU fault rather than a Python error); pass False when the caller has already checked."""
     _need_cuda(F, ptr, idx)
     S, D = ptr.numel() - 1, F.shape[1]
+    if validate and S > 0:
+        bad = (ptr[1:] < ptr[:-1]).any() | (ptr[0] != 0) | (ptr[-1] > idx.numel())
+        if idx.numel():
+            bad = bad | (idx.min() < 0) | (idx.max() >= F.shape[0])
+        if bool(bad):
+            raise ValueError("segment_mean: ptr must be non-decreasing from 0 to <= len(idx) and idx must index rows of F")
     pooled = torch.empty((S, D), dtype=torch.float32, device=F.device)
     check(_lib.lib().dm_segment_mean(F.data_ptr(), ptr.data_ptr(), idx.data_ptr(), pooled.data_ptr(), S, D, _stream()), "dm_segment_mean")
     return pooled
 
 
-def edge_similarity(pooled: torch.Tensor, edges: torch.Tensor, margin: float = 1.0):
+def edge_similarity(pooled: torch.Tensor, edges: torch.Tensor, margin: float = 1.0, validate: bool = True):
     _need_cuda(pooled, edges)
     E, D = edges.shape[0], pooled.shape[1]
+    if validate and E > 0 and int(edges.max()) >= pooled.shape[0]:
+        raise ValueError(f"edge_similarity: edge endpoint {int(edges.max())} is not a row of pooled (S = {pooled.shape[0]}); negative ids mean 'no polygon'")
     simi = torch.empty(E, dtype=torch.float32, device=pooled.device)
     merge = torch.empty(E, dtype=torch.uint8, device=pooled.device)
     check(_lib.lib().dm_edge_similarity(pooled.data_ptr(), edges.data_ptr(), simi.data_ptr(), merge.data_ptr(), E, D, margin, _stream()),
@@ -599,24 +616,18 @@ def _grad_out(param: torch.Tensor, shape, device):
 
 def _multi_use_sink(param, shape):
     """Gradient sink for the generic Functions (Linear, Mlp, LayerNorm), whose parameters may be used several times per step
-    (the shared `norm`, the aux heads): their contributions accumulate into the trainer's flat buffer directly -- but only
-    when no gradient-ready hooks are installed (single GPU).  With hooks (data parallel) the bucket exchange must see the
-    COMPLETE gradient, which only autograd's own accumulation guarantees for a multi-use parameter."""
+    (the shared `norm`, the aux heads): their contributions accumulate into the trainer's flat buffer directly.  (The
+    data-parallel exchange works on whole backward segments, so it never needs to know when one parameter is complete.)"""
     if param is None:
         return None
     sink = getattr(param, "_dm_grad_sink", None)
-    if sink is None or getattr(param, "_dm_grad_ready", None) is not None:
-        return None
-    return sink.view(shape)
+    return None if sink is None else sink.view(shape)
 
 
 def _grad_done(param: torch.Tensor, g: torch.Tensor, direct: bool):
-    """Value to return to autograd for this parameter (None when it went to the sink) + trainer notification."""
+    """Value to return to autograd for this parameter (None when it went to the sink)."""
     if not direct:
         return g.view(param.shape) if g.shape != param.shape else g
-    hook = getattr(param, "_dm_grad_ready", None)
-    if hook is not None:
-        hook(param)
     return None
 
 

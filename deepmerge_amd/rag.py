@@ -93,6 +93,10 @@ def merge_components(edges: torch.Tensor, merge: torch.Tensor, n_labels: int, ma
     _need_cuda(edges, merge)
     edges = edges.to(torch.int32).contiguous()
     m8 = merge.to(torch.uint8).contiguous()
+    if edges.numel() and int(edges.max()) >= n_labels:
+        raise ValueError(f"merge_components: edge endpoint {int(edges.max())} >= n_labels {n_labels}")
+    if edges.numel() and bool(((edges < 0).any(1) & (m8 != 0)).any()):
+        raise ValueError("merge_components: an edge with a -1 ('no polygon') endpoint is flagged for merging")
     dev = edges.device
     parent = torch.empty(n_labels, dtype=torch.int32, device=dev)
     changed = torch.zeros(1, dtype=torch.int32, device=dev)
@@ -120,6 +124,10 @@ def merge_partition(ptr: torch.Tensor, idx: torch.Tensor, edges: torch.Tensor, r
     new_idx = idx.long()[order].to(torch.int32)
     new_ptr = torch.zeros(C + 1, dtype=torch.int64, device=root.device)
     new_ptr[1:] = torch.cumsum(torch.bincount(owner, minlength=C), 0)
+    live = (edges >= 0).all(1)                                         # -1 = "no polygon" (MyUtils2.py:184-186): never relabelled
+    edges = edges[live]
+    if edges.numel() and int(edges.max()) >= S:
+        raise ValueError(f"edge endpoint {int(edges.max())} is not a superpixel id (S = {S})")
     a, b = new_id[edges[:, 0].long()], new_id[edges[:, 1].long()]
     keep = a != b
     lo, hi = torch.minimum(a[keep], b[keep]), torch.maximum(a[keep], b[keep])

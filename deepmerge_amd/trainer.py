@@ -7,8 +7,8 @@ Memory layout (288 GB HBM3E per GPU makes replication free: 88 M params = 0.35 G
     each nn.Parameter (and its .grad) is a view into them.  Parameters are laid out in REVERSE
     forward order, so the gradients that backward produces first sit at the front of the buffer.
   * the gradient all-reduce runs on a few large contiguous buckets of that buffer (xGMI rings are
-    per-link bound: few large transfers, not many small ones), each launched as soon as backward has
-    written every gradient in it, overlapping the rest of backward;
+    per-link bound: few large transfers, not many small ones): the backward pass runs in segments (cut
+    after every stage-0 block) and a segment's bucket is exchanged while the earlier layers' backward runs;
   * Adam is a single fused launch over the flat buffers (dm_adam_step), which also applies the
     1/world_size averaging.
 Pairs shard by contiguous equal slices of the global batch; the loss is a mean over pairs, so the
@@ -99,13 +99,39 @@ def _v3_forward():
     return ShfitScaleFormer_v3.forward
 
 
+class _Cuts:
+    """Autograd cut points of one forward pass.  The model calls `net._dp_cut(x)` at its segment boundaries (after every stage-0
+    block for the v3 family); the value that flows on is a detached leaf, so the backward pass can be run segment by segment:
+    loss.backward() stops at the last cut, then `x.backward(leaf.grad)` continues through the segment before it, and so on."""
+
+    def __init__(self):
+        self.pairs = []            # (tensor produced by the segment, detached leaf the next segment consumed), forward order
+        self.owners = []           # the module after which each cut was taken
+
+    def __call__(self, x, owner=None):
+        leaf = x.detach().requires_grad_(True)
+        self.pairs.append((x, leaf))
+        self.owners.append(owner)
+        return leaf
+
+
 class PairTrainer:
-    """One training step of the Siamese encoder on this rank's shard of the pair batch."""
+    """One training step of the Siamese encoder on this rank's shard of the pair batch.
+
+    Data-parallel exchange (world > 1): the backward pass runs in SEGMENTS (see _Cuts); the flat gradient buffer is cut into
+    one bucket per segment (parameters are laid out in reverse forward order, so a segment's parameters are one contiguous
+    range), and a bucket's all-reduce is launched as soon as its segment's backward has been enqueued -- it then runs on the
+    collective's stream next to the backward of the earlier layers.  Which parameters received a gradient plays no role (a
+    bucket is exchanged whole; an unused parameter contributes zeros), so the schedule is identical on every rank and every
+    step by construction.  With enable_graph() every compute piece between two exchange launches (forward + loss + first backward
+    segment, each further backward segment, Adam) is a captured hipGraph; the collectives themselves stay eager."""
 
     def __init__(self, net: torch.nn.Module, margin: float = 1.0, lr: float = 1e-4, lamda: float = 0.1, belta: float = 0,
-                 betas=(0.9, 0.999), eps: float = 1e-8, n_buckets: int = 4, process_group=None, criterion=None, adam_fn=None):
+                 betas=(0.9, 0.999), eps: float = 1e-8, n_buckets: int = 4, process_group=None, criterion=None, adam_fn=None,
+                 segmented: Optional[bool] = None):
         """`criterion` / `adam_fn` default to the HIP loss and fused Adam; tests of the exchange logic may
-        inject stand-ins with the same signatures."""
+        inject stand-ins with the same signatures.  `segmented`: run the backward pass in segments (default: world > 1 and
+        the model supports cuts); `n_buckets` is the bucket count for models without cut support."""
         self.net = net
         self.criterion = criterion if criterion is not None else Loss(margin, lamda, belta)
         self.adam_fn = adam_fn if adam_fn is not None else ops.adam_step
@@ -116,111 +142,166 @@ class PairTrainer:
         self.m = torch.zeros_like(self.fp.flat)
         self.v = torch.zeros_like(self.fp.flat)
         self.step_count = 0
-        self.bucket_slices = self.fp.buckets(n_buckets if self.world > 1 else 1)
+        self.can_cut = hasattr(net, "_dp_cut")
+        self.segmented = (self.world > 1 and self.can_cut) if segmented is None else (bool(segmented) and self.can_cut)
+        self.n_buckets = max(1, n_buckets)
+        self.bucket_slices = self.fp.buckets(self.n_buckets if self.world > 1 else 1)     # re-derived from the cuts when segmented
         self._pending = []
-        self._hooks_installed = False
-        if self.world > 1:
-            self._install_bucket_hooks()
         self._graph = None          # captured step (enable_graph)
         self._graph_warm = 0
-        self._capture = None        # {"side": stream, "hyper": tensor} while a graph with overlapped Adam is being captured
+        self.exchange = True        # False: skip the collectives (bench.py uses it to price the exposed exchange time)
+        self.trace = os.environ.get("DM_DP_TRACE") == "1"
+        self.stats = {"allreduce_calls": 0, "allreduce_bytes": 0}
 
     # -- gradient exchange -----------------------------------------------------------------------
-    def _install_bucket_hooks(self):
-        """Launch a bucket's all-reduce from autograd as soon as its last gradient has been accumulated."""
-        fp = self.fp
-        self._bucket_of, self._remaining0 = {}, []
-        for bi, sl in enumerate(self.bucket_slices):
-            members = [p for p, o in zip(fp.params, fp.offsets) if sl.start <= o < sl.stop]
-            self._remaining0.append(len(members))
-            for p in members:
-                self._bucket_of[p] = bi
-        self._remaining = list(self._remaining0)
-
-        self._seen = set()
-        self._calibrated = False
-
-        def hook(p):
-            # idempotent per step: a parameter whose gradient went straight to the sink is reported by the fused
-            # backward AND may be reported again by autograd's own post-accumulate hook
-            if id(p) in self._seen:
-                return
-            self._seen.add(id(p))
-            bi = self._bucket_of[p]
-            self._remaining[bi] -= 1
-            if self._remaining[bi] == 0:
-                self._launch_bucket(bi)
-        for p in fp.params:
-            p.register_post_accumulate_grad_hook(hook)
-            p._dm_grad_ready = hook          # same notification when a fused backward wrote the sink directly
-        self._hooks_installed = True
+    def _log(self, msg):
+        if self.trace:
+            import sys
+            import time
+            rank = dist.get_rank(self.pg) if self.world > 1 else 0
+            print(f"[dp {time.strftime('%H:%M:%S')}.{int(time.time() * 1000) % 1000:03d} rank {rank}] {msg}", file=sys.stderr, flush=True)
 
     def _launch_bucket(self, bi: int):
         sl = self.bucket_slices[bi]
-        if self.world > 1:
+        if self.world > 1 and self.exchange:
+            self._log(f"launch bucket {bi} [{sl.start}:{sl.stop}] ({(sl.stop - sl.start) * 4 / 1e6:.1f} MB)")
             self._pending.append((bi, dist.all_reduce(self.fp.grad[sl], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)))
-        elif self._capture is not None:
-            # single GPU, graph capture: this bucket's gradients are final and its weights are not read again in this
-            # backward -> its Adam update runs on a side stream next to the rest of the backward (Adam is HBM-bound, the
-            # GEMMs are not)
-            cap = self._capture
-            cap["side"].wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(cap["side"]):
-                self._adam_slice(sl, cap["hyper"])
-            self._pending.append((bi, None))
+            self.stats["allreduce_calls"] += 1
+            self.stats["allreduce_bytes"] += (sl.stop - sl.start) * 4
 
-    def _adam_slice(self, sl: slice, hyper_dev):
-        lp = self.fp.flat_lp[sl] if self.fp.flat_lp is not None else None
-        ops.adam_step_dev(self.fp.flat[sl], self.fp.grad[sl], self.m[sl], self.v[sl], hyper_dev, beta1=self.betas[0], beta2=self.betas[1],
-                          eps=self.eps, grad_scale=1.0, param_lp=lp)
-
-    def _finish_exchange(self):
-        launched = {bi for bi, _ in self._pending}
-        for bi in range(len(self.bucket_slices)):        # buckets whose params got no gradient this step
-            if bi not in launched:
-                self._launch_bucket(bi)
-        for _, work in self._pending:
-            if work is not None:
-                work.wait()
+    def _wait_exchange(self):
+        for bi, work in self._pending:
+            self._log(f"wait bucket {bi}")
+            work.wait()
+        self._log("exchange complete")
         self._pending.clear()
-        if not self._calibrated:
-            # parameters that never receive a gradient (final_features.*, head.* on the designed-feature path) would
-            # hold their bucket back until the end of backward: after the first step, count only the used ones
-            counts = [0] * len(self.bucket_slices)
-            for p in self.fp.params:
-                if id(p) in self._seen:
-                    counts[self._bucket_of[p]] += 1
-            self._remaining0 = counts
-            self._calibrated = True
-        self._remaining = list(self._remaining0)
-        self._seen.clear()
 
-    # -- the step ----------------------------------------------------------------------------------
+    def _segment_buckets(self, cuts: _Cuts):
+        """One bucket per distinct cut owner + one for the tail.  A cut taken after module `owner` ends the segment that
+        contains `owner`: in the flat buffer (reverse forward order) that segment starts at the lowest offset of owner's
+        parameters.  Returns (slices, ready_after): bucket j may be exchanged after backward piece ready_after[j] (piece 0 =
+        loss.backward() down to the last cuts, piece k = the k-th cut from the end).  A model that runs its encoder once per
+        side meets every owner twice; its bucket is ready after the LAST piece that touches it."""
+        off = {id(p): o for p, o in zip(self.fp.params, self.fp.offsets)}
+        start_of, last_piece = {}, {}
+        for k, owner in enumerate(reversed(cuts.owners)):
+            ps = [off[id(p)] for p in owner.parameters() if id(p) in off] if owner is not None else []
+            if not ps:
+                raise RuntimeError("a DP cut needs an owner module with trainable parameters to place the bucket boundary")
+            start_of[id(owner)] = min(ps)
+            last_piece[id(owner)] = k + 1
+        order = sorted(start_of, key=lambda o: start_of[o])
+        starts = [start_of[o] for o in order]
+        if starts and starts[0] <= 0:
+            raise RuntimeError(f"DP cuts do not follow the flat parameter order: {starts}")
+        edges = [0] + starts + [self.fp.total]
+        slices = [slice(a, b) for a, b in zip(edges[:-1], edges[1:])]
+        ready = [0] + [last_piece[o] for o in order]
+        if len(ready) > 1:
+            ready[-1] = len(cuts.pairs)          # the last range also holds everything in front of the first cut
+        if any(y < x for x, y in zip(ready[:-1], ready[1:])):
+            raise RuntimeError(f"DP cuts: buckets would complete out of order {ready}")
+        return slices, ready
+
+    def _launch_ready(self, piece: int):
+        for bi, r in enumerate(self._ready_after):
+            if r == piece:
+                self._launch_bucket(bi)
+
+    def _backward_segments(self, loss, cuts: _Cuts):
+        """Generator over the backward pieces: yields the index of the piece that has just been enqueued."""
+        loss.backward()
+        yield 0
+        for k, (x, leaf) in enumerate(reversed(cuts.pairs)):
+            x.backward(leaf.grad)
+            yield k + 1
+
     # -- hipGraph replay of the whole step ---------------------------------------------------------
-    def enable_graph(self, warmup: int = 3, overlap_adam: bool = False, adam_buckets: int = 4):
-        """Capture forward + loss + backward + Adam of one step into a hipGraph (torch.cuda.CUDAGraph) after `warmup`
-        eager steps, and replay it afterwards: ~330 launches per step collapse into one submission, which removes the
-        host-side gaps between the many small kernels.  Needs fixed input shapes; single-GPU only (the bucketed
-        exchange of the data-parallel path stays eager)."""
-        # overlap_adam: run Adam bucket by bucket on a side stream (a second branch of the graph) as soon as a bucket's gradients
-        # are final.  Measured on MI355X: 7.10 - 7.26 ms/step against 6.84 ms with the single-branch graph -- the fork / join
-        # edges and the HBM contention cost more than the 0.26 ms of Adam they hide -- so it is off by default
-        # (DM_ADAM_OVERLAP=<buckets> switches it on for experiments).
-        if self.world > 1:
-            raise RuntimeError("graph replay covers the single-GPU step; the data-parallel exchange runs eagerly")
+    def enable_graph(self, warmup: int = 3):
+        """Capture the step's compute into hipGraphs (torch.cuda.CUDAGraph) after `warmup` eager steps and replay them afterwards:
+        ~330 launches per step collapse into one submission per piece, which removes the host-side gaps between the many small
+        kernels.  One GPU: a single graph (forward + loss + backward + Adam).  Data parallel: one graph per backward segment
+        (the first also holds zero_grad + forward + loss) and one for Adam, with the bucket all-reduces launched eagerly in
+        between -- the exchange overlaps the graphs that follow.  Needs fixed input shapes."""
         if self.fp.flat.device.type != "cuda":
             raise RuntimeError("graph capture needs the parameters on the GPU")
-        env = os.environ.get("DM_ADAM_OVERLAP")
-        if env is not None:
-            overlap_adam, adam_buckets = env != "0", (int(env) if env.isdigit() and int(env) > 1 else adam_buckets)
-        self._graph = {"warmup": warmup, "g": None, "overlap_adam": bool(overlap_adam)}
+        self._graph = {"warmup": warmup, "g": None}
         self._graph_warm = 0
-        if overlap_adam:
-            # Adam per bucket of the flat buffer, launched from the gradient-ready hooks on a side stream of the captured graph
-            # (a graph branch that runs next to the remaining backward).  Bucket boundaries are 16-byte aligned views.
-            self.bucket_slices = self.fp.buckets(adam_buckets)
-            if not self._hooks_installed:
-                self._install_bucket_hooks()
+
+    def _static_inputs(self, st, left, left_designed, right, right_designed, flag):
+        # models that take the two sides pre-stacked ([left; right] along the batch) get static buffers of that form, so
+        # the step's inputs are copied once and the captured graph holds no torch.cat
+        batched = type(self.net).__dict__.get("forward_pair_batched") is not None or \
+            (hasattr(self.net, "forward_pair_batched") and type(self.net).forward is _v3_forward())
+        if batched:
+            both = [torch.cat((l, r), 0) for l, r in zip(left, right)]
+            Bp = left[0].shape[0]
+            st["left"], st["right"] = [t[:Bp] for t in both], [t[Bp:] for t in both]
+            st["both"] = both
+            if left_designed is not None:
+                st["dboth"] = torch.cat((left_designed, right_designed), 0)
+                st["ld"], st["rd"] = st["dboth"][:Bp], st["dboth"][Bp:]
+            else:
+                st["dboth"] = st["ld"] = st["rd"] = None
+        else:
+            st["both"] = None
+            st["left"] = [t.clone() for t in left]
+            st["right"] = [t.clone() for t in right]
+            st["ld"] = None if left_designed is None else left_designed.clone()
+            st["rd"] = None if right_designed is None else right_designed.clone()
+        st["flag"] = flag.clone()
+        st["hyper"] = torch.zeros(2, dtype=torch.float32, device=self.fp.flat.device)
+        st["shapes"] = [tuple(t.shape) for t in st["left"] + st["right"]]
+
+    def _forward_loss(self, st):
+        if st["both"] is not None:
+            fa, fb = self.net.forward_pair_batched(st["both"], st["dboth"])
+        else:
+            fa, fb = self.net(st["left"], st["ld"], st["right"], st["rd"])
+        return self.criterion(fa, fb, st["flag"])
+
+    def _capture(self, st):
+        torch.cuda.synchronize()
+        if not self.segmented:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self.fp.zero_grad()
+                loss = self._forward_loss(st)
+                loss.backward()
+                if self.world == 1:
+                    self._adam_slice(slice(0, self.fp.total), st["hyper"], 1.0)
+                st["loss"] = loss.detach()
+            st["pieces"] = [g]
+            if self.world > 1:                       # no cut support: exchange the whole buffer after the one backward graph
+                ga = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(ga, pool=g.pool()):
+                    self._adam_slice(slice(0, self.fp.total), st["hyper"], 1.0 / self.world)
+                st["adam"] = ga
+            return
+        cuts = _Cuts()
+        self.net._dp_cut = cuts
+        pieces = []
+        try:
+            g0 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g0):
+                self.fp.zero_grad()
+                loss = self._forward_loss(st)
+                loss.backward()
+                st["loss"] = loss.detach()
+            pieces.append(g0)
+            for x, leaf in reversed(cuts.pairs):
+                gk = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gk, pool=g0.pool()):
+                    x.backward(leaf.grad)
+                pieces.append(gk)
+            ga = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(ga, pool=g0.pool()):
+                self._adam_slice(slice(0, self.fp.total), st["hyper"], 1.0 / self.world)
+        finally:
+            self.net._dp_cut = None
+        st["pieces"], st["adam"], st["cuts"] = pieces, ga, cuts           # the cut tensors keep the autograd segments alive
+        self.bucket_slices, self._ready_after = self._segment_buckets(cuts)
+        # the retired-workspace list of ops.workspace keeps every scratch buffer these graphs point into alive
 
     def _graph_step(self, left, left_designed, right, right_designed, flag, lr):
         st = self._graph
@@ -229,52 +310,9 @@ class PairTrainer:
             if self._graph_warm < st["warmup"]:           # eager steps first: lazy caches, workspaces, kernel attributes
                 self._graph_warm += 1
                 return self._eager_step(*args, lr)
-            dev = self.fp.flat.device
-            # models that take the two sides pre-stacked ([left; right] along the batch) get static buffers of that form, so
-            # the step's inputs are copied once and the captured graph holds no torch.cat
-            batched = type(self.net).__dict__.get("forward_pair_batched") is not None or \
-                (hasattr(self.net, "forward_pair_batched") and type(self.net).forward is _v3_forward())
-            if batched:
-                both = [torch.cat((l, r), 0) for l, r in zip(left, right)]
-                Bp = left[0].shape[0]
-                st["left"], st["right"] = [t[:Bp] for t in both], [t[Bp:] for t in both]
-                st["both"] = both
-                if left_designed is not None:
-                    st["dboth"] = torch.cat((left_designed, right_designed), 0)
-                    st["ld"], st["rd"] = st["dboth"][:Bp], st["dboth"][Bp:]
-                else:
-                    st["dboth"] = st["ld"] = st["rd"] = None
-            else:
-                st["both"] = None
-                st["left"] = [t.clone() for t in left]
-                st["right"] = [t.clone() for t in right]
-                st["ld"] = None if left_designed is None else left_designed.clone()
-                st["rd"] = None if right_designed is None else right_designed.clone()
-            st["flag"] = flag.clone()
-            st["hyper"] = torch.zeros(2, dtype=torch.float32, device=dev)
-            st["shapes"] = [tuple(t.shape) for t in st["left"] + st["right"]]
-            g = torch.cuda.CUDAGraph()
-            torch.cuda.synchronize()
-            with torch.cuda.graph(g):
-                self.fp.zero_grad()
-                if st["both"] is not None:
-                    fa, fb = self.net.forward_pair_batched(st["both"], st["dboth"])
-                else:
-                    fa, fb = self.net(st["left"], st["ld"], st["right"], st["rd"])
-                loss = self.criterion(fa, fb, st["flag"])
-                if st["overlap_adam"]:
-                    self._capture = {"side": torch.cuda.Stream(), "hyper": st["hyper"]}
-                    try:
-                        loss.backward()                    # hooks launch Adam bucket by bucket on the side stream
-                        self._finish_exchange()            # buckets that saw no gradient (unused parameters)
-                        torch.cuda.current_stream().wait_stream(self._capture["side"])
-                    finally:
-                        self._capture = None
-                else:
-                    loss.backward()
-                    self._adam_slice(slice(0, self.fp.total), st["hyper"])
-                st["loss"] = loss.detach()
-            st["g"] = g
+            self._static_inputs(st, *args)
+            self._capture(st)
+            st["g"] = True
             # capture only records: nothing above has executed yet, the replay below is this step
         if [tuple(t.shape) for t in list(left) + list(right)] != st["shapes"]:
             raise ValueError("graph replay needs the input shapes it was captured with; call enable_graph() again for a new batch size")
@@ -286,14 +324,32 @@ class PairTrainer:
         st["flag"].copy_(flag, non_blocking=True)
         self.step_count += 1
         st["hyper"].copy_(ops.adam_hyper(self.step_count, self.lr if lr is None else lr, self.betas[0], self.betas[1]), non_blocking=True)
-        st["g"].replay()
+        if self.world == 1 and not self.segmented:
+            st["pieces"][0].replay()                     # Adam is inside the one graph
+            return st["loss"]
+        if not self.segmented:                       # one backward graph, then the bucketed exchange of the whole buffer
+            st["pieces"][0].replay()
+            for bi in range(len(self.bucket_slices)):
+                self._launch_bucket(bi)
+        else:
+            for piece, g in enumerate(st["pieces"]):
+                g.replay()
+                self._launch_ready(piece)                # the exchange runs next to the graphs replayed after it
+        self._wait_exchange()
+        st["adam"].replay()
         return st["loss"]
 
+    def _adam_slice(self, sl: slice, hyper_dev, grad_scale: float):
+        lp = self.fp.flat_lp[sl] if self.fp.flat_lp is not None else None
+        ops.adam_step_dev(self.fp.flat[sl], self.fp.grad[sl], self.m[sl], self.v[sl], hyper_dev, beta1=self.betas[0], beta2=self.betas[1],
+                          eps=self.eps, grad_scale=grad_scale, param_lp=lp)
+
+    # -- the step ----------------------------------------------------------------------------------
     def step(self, left: Sequence[torch.Tensor], left_designed, right: Sequence[torch.Tensor], right_designed, flag,
              lr: Optional[float] = None) -> torch.Tensor:
         """forward -> Loss -> zero_grad -> backward -> (all-reduce) -> Adam.  Returns the local loss tensor
         (no host sync; the reference's per-step `.item()` at Train_SMT.py:301 is left to the caller).
-        After enable_graph() the same work is replayed from a captured hipGraph (the returned tensor is then a
+        After enable_graph() the same work is replayed from captured hipGraphs (the returned tensor is then a
         static buffer that the next step overwrites)."""
         if self._graph is not None:
             self.net.train()
@@ -303,15 +359,28 @@ class PairTrainer:
     def _eager_step(self, left, left_designed, right, right_designed, flag, lr=None) -> torch.Tensor:
         self.net.train()
         self.fp.zero_grad()
-        fa, fb = self.net(left, left_designed, right, right_designed)
+        cuts = None
+        if self.segmented:
+            cuts = _Cuts()
+            self.net._dp_cut = cuts
+        try:
+            fa, fb = self.net(left, left_designed, right, right_designed)
+        finally:
+            if cuts is not None:
+                self.net._dp_cut = None
         loss = self.criterion(fa, fb, flag)
-        loss.backward()
-        if self.world > 1:
-            self._finish_exchange()
+        if cuts is not None and cuts.pairs:
+            self.bucket_slices, self._ready_after = self._segment_buckets(cuts)
+            for piece in self._backward_segments(loss, cuts):
+                self._launch_ready(piece)
+        else:
+            loss.backward()
+            if self.world > 1:
+                for bi in range(len(self.bucket_slices)):
+                    self._launch_bucket(bi)
+        self._wait_exchange()
         self.step_count += 1
         extra = {"param_lp": self.fp.flat_lp} if self.fp.flat_lp is not None else {}
         self.adam_fn(self.fp.flat, self.fp.grad, self.m, self.v, self.step_count, lr=self.lr if lr is None else lr,
                      beta1=self.betas[0], beta2=self.betas[1], eps=self.eps, grad_scale=1.0 / self.world, **extra)
-        if self.world == 1 and self._hooks_installed:
-            self._finish_exchange()        # gradient-ready hooks are installed for the graph's overlapped Adam: reset their counters
         return loss.detach()

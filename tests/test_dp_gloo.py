@@ -110,9 +110,9 @@ def test_two_rank_step_equals_single_process_global_batch(tmp_path):
         shard_slice(9, 0, 2)
 
 
-def test_four_rank_step_with_calibrated_bucket_hooks(tmp_path):
-    """world_size 4, three steps: from the second step on the bucket hooks count only the parameters that received a gradient
-    (buckets are exchanged from inside backward), which must stay equivalent to the single-process global batch."""
+def test_four_rank_step_bucketed_exchange(tmp_path):
+    """world_size 4, three steps, a model without cut support: one backward, then the bucketed exchange of the whole buffer;
+    must stay equivalent to the single-process global batch."""
     from deepmerge_amd.trainer import PairTrainer
     out = str(tmp_path / "rank0.pt")
     mp.spawn(_worker, args=(4, _free_port(), out, 3), nprocs=4, join=True)
@@ -124,6 +124,96 @@ def test_four_rank_step_with_calibrated_bucket_hooks(tmp_path):
         tr.step(*batch)
     np.testing.assert_allclose(got["grad"].numpy(), tr.fp.grad.numpy(), rtol=2e-4, atol=1e-6)
     np.testing.assert_allclose(got["flat"].numpy(), tr.fp.flat.numpy(), rtol=2e-4, atol=5e-5)
+
+
+class CutNet(torch.nn.Module):
+    """CPU stand-in WITH cut support (the v3 contract: `_dp_cut(x, owner)` after every stage-0 block): 3 "stage-0" blocks, a tail,
+    a parameter that is only used on odd steps (the used-parameter set changes between steps) and one that is never used."""
+    _dp_cut = None
+
+    def __init__(self):
+        super().__init__()
+        g = torch.Generator().manual_seed(3)
+        mk = lambda i, o: torch.nn.Linear(i, o)
+        self.embed = mk(24, 32)
+        self.blocks0 = torch.nn.ModuleList([mk(32, 32) for _ in range(3)])
+        self.tail = mk(32, 12)
+        self.sometimes = mk(32, 32)
+        self.never = mk(4, 4)
+        for p in self.parameters():
+            with torch.no_grad():
+                p.copy_(torch.randn(p.shape, generator=g) * 0.2)
+        self.odd = False
+
+    def once(self, x):
+        x = torch.tanh(self.embed(x))
+        for blk in self.blocks0:
+            x = x + torch.tanh(blk(x))
+            if self._dp_cut is not None:
+                x = self._dp_cut(x, blk)
+        if self.odd:
+            x = x + 0.1 * torch.tanh(self.sometimes(x))
+        return self.tail(x)
+
+    def forward(self, l, ld, r, rd):
+        return self.once(l[0]), self.once(r[0])
+
+
+def _cut_batch(B):
+    g = torch.Generator().manual_seed(11)
+    return [torch.randn(B, 24, generator=g)], None, [torch.randn(B, 24, generator=g)], None, (torch.arange(B) % 2).to(torch.int64)
+
+
+def _cut_worker(rank, world, port, out, steps):
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    from deepmerge_amd.trainer import PairTrainer, shard_slice
+    net = CutNet()
+    tr = PairTrainer(net, lr=1e-3, criterion=cpu_criterion, adam_fn=cpu_adam)
+    assert tr.world == world and tr.segmented
+    l, _, r, _, flag = _cut_batch(8)
+    sl = shard_slice(8, rank, world)
+    for i in range(steps):
+        net.odd = bool(i % 2)
+        tr.step([l[0][sl]], None, [r[0][sl]], None, flag[sl])
+    if rank == 0:
+        torch.save({"flat": tr.fp.flat.clone(), "grad": tr.fp.grad.clone() / world, "buckets": [(b.start, b.stop) for b in tr.bucket_slices],
+                    "calls": tr.stats["allreduce_calls"]}, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_segmented_backward_exchange(tmp_path, world):
+    """The data-parallel schedule of the v3 family: backward in segments (one per stage-0 block + tail), one bucket per segment
+    exchanged right after its segment, used-parameter set changing from step to step.  Result == single-process global batch."""
+    from deepmerge_amd.trainer import PairTrainer
+    out = str(tmp_path / "rank0.pt")
+    steps = 4
+    mp.spawn(_cut_worker, args=(world, _free_port(), out, steps), nprocs=world, join=True)
+    got = torch.load(out)
+    net = CutNet()
+    tr = PairTrainer(net, lr=1e-3, criterion=cpu_criterion, adam_fn=cpu_adam)
+    assert not tr.segmented                                   # one process: plain backward
+    batch = _cut_batch(8)
+    for i in range(steps):
+        net.odd = bool(i % 2)
+        tr.step(*batch)
+    np.testing.assert_allclose(got["grad"].numpy(), tr.fp.grad.numpy(), rtol=2e-4, atol=1e-6)
+    np.testing.assert_allclose(got["flat"].numpy(), tr.fp.flat.numpy(), rtol=2e-4, atol=2e-5)
+    # 4 buckets (tail incl. `sometimes` / `never`, block 2, block 1, block 0 + embed), contiguous, whole buffer
+    b = got["buckets"]
+    assert len(b) == 4 and b[0][0] == 0 and b[-1][1] == tr.fp.total and all(x[1] == y[0] for x, y in zip(b[:-1], b[1:]))
+    assert got["calls"] == 4 * steps
+    # the segmented schedule on ONE process gives bit-identical gradients to the plain backward
+    net2 = CutNet()
+    tr2 = PairTrainer(net2, lr=1e-3, criterion=cpu_criterion, adam_fn=cpu_adam, segmented=True)
+    for i in range(steps):
+        net2.odd = bool(i % 2)
+        tr2.step(*batch)
+    assert torch.equal(tr2.fp.grad, tr.fp.grad) and torch.equal(tr2.fp.flat, tr.fp.flat)
 
 
 def test_flat_params_views_and_buckets():

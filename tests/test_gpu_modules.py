@@ -309,11 +309,7 @@ def test_checkpoint_resume_continues_identically(tmp_path):
     l3b = tr2.step(*args)
     assert float(l3) == float(l3b)
     for (k, v), (_, v2) in zip(net.state_dict().items(), net2.state_dict().items()):
-        if k.endswith("relative_position_bias_table"):
-            # the bias-table gradient is binned with LDS float atomics (order varies run to run, ~1 ulp)
-            assert torch.allclose(v, v2, rtol=0, atol=2.5e-4), k      # Adam turns a 1-ulp gradient difference into <= 2*lr
-        else:
-            assert torch.equal(v, v2), k
+        assert torch.equal(v, v2), k       # every kernel of the step is run-to-run deterministic (no float atomics anywhere)
 
 
 @pytest.mark.parametrize("mode", ["fp32", "bf16"])
@@ -342,3 +338,60 @@ def test_graph_replayed_step_equals_eager_step(mode):
     assert torch.equal(eager.m, graphed.m) and torch.equal(eager.v, graphed.v)
     with pytest.raises(ValueError):
         graphed.step([t[:2] for t in batches[0][0]], batches[0][1][:2], [t[:2] for t in batches[0][2]], batches[0][3][:2], batches[0][4][:2])
+
+
+def test_graph_survives_workspace_growth():
+    """the captured step has the raw addresses of the split-K / partial-reduction workspaces baked in.  A later,
+    larger eager GEMM replaces those workspaces; the old buffers must stay allocated (ops._ws_retired), otherwise fresh
+    tensors alias them and every replay silently corrupts.  Capture, grow, allocate over the freed space, replay, compare."""
+    from deepmerge_amd import ops
+    from deepmerge_amd._lib import DM_TN
+    from deepmerge_amd.trainer import PairTrainer
+    tag = "v3_3s3c_111"
+    cfg = MODEL_CASES[tag]
+    left, ld, right, rd, flag = model_inputs(tag, cfg.scales, cfg.in_c, 4)
+    b = ([t.to(DEV) for t in left], ld.to(DEV), [t.to(DEV) for t in right], rd.to(DEV), flag.to(DEV))
+    nets = [build_model(tag, "bf16")[1].train() for _ in range(2)]
+    eager, graphed = PairTrainer(nets[0], lr=1e-4), PairTrainer(nets[1], lr=1e-4)
+    graphed.enable_graph(warmup=1)
+    for _ in range(3):
+        eager.step(*b); graphed.step(*b)
+    before = {k: v.data_ptr() for k, v in ops._ws.items()}
+    # grow every workspace slot (what a later, larger eager GEMM / LayerNorm does: other tests of this process may already have
+    # grown them past any single product, so the growth is requested directly) and use the new "gemm" slab once
+    for (_, slot), buf in list(ops._ws.items()):
+        ops.workspace(buf.numel() + 1, DEV, slot)
+    assert all(ops._ws[k].data_ptr() != p for k, p in before.items()) and len(ops._ws_retired) >= len(before)
+    M, N, K = 768, 768, 16384
+    dy = torch.randn(K, M, device=DEV).to(torch.bfloat16); x = torch.randn(K, N, device=DEV).to(torch.bfloat16)
+    G = torch.zeros(M, N, device=DEV)
+    ops.gemm(DM_TN, dy, x, G, M, N, K, lda=M, ldb=N, ldc=N)
+    del dy, x, G
+    junk = [torch.full((64 << 20,), float("nan"), device=DEV) for _ in range(8)]      # would land on freed workspace memory
+    for _ in range(2):
+        le = eager.step(*b); lg = graphed.step(*b)
+        assert float(le) == float(lg)
+    assert torch.equal(eager.fp.flat, graphed.fp.flat)
+    del junk
+
+
+def test_segmented_graphs_equal_plain_step():
+    """The data-parallel schedule on one process: backward in segments, one hipGraph per segment + one for Adam, buckets derived
+    from the cuts -- weights after 4 steps are bit-identical to the single-graph and to the eager step."""
+    from deepmerge_amd.trainer import PairTrainer
+    tag = "v3_3s3c_642"
+    cfg = MODEL_CASES[tag]
+    left, ld, right, rd, flag = model_inputs(tag, cfg.scales, cfg.in_c, 4)
+    b = ([t.to(DEV) for t in left], ld.to(DEV), [t.to(DEV) for t in right], rd.to(DEV), flag.to(DEV))
+    nets = [build_model(tag, "bf16")[1].train() for _ in range(3)]
+    eager = PairTrainer(nets[0], lr=1e-4)
+    seg_eager = PairTrainer(nets[1], lr=1e-4, segmented=True)
+    seg_graph = PairTrainer(nets[2], lr=1e-4, segmented=True)
+    seg_graph.enable_graph(warmup=1)
+    for _ in range(4):
+        l0 = eager.step(*b); l1 = seg_eager.step(*b); l2 = seg_graph.step(*b)
+        assert float(l0) == float(l1) == float(l2)
+    assert torch.equal(eager.fp.flat, seg_eager.fp.flat) and torch.equal(eager.fp.flat, seg_graph.fp.flat)
+    assert len(seg_graph._graph["pieces"]) == 1 + 6 and len(seg_graph.bucket_slices) == 7       # tail + the six stage-0 blocks
+    sl = seg_graph.bucket_slices
+    assert sl[0].start == 0 and sl[-1].stop == seg_graph.fp.total and all(x.stop == y.start for x, y in zip(sl[:-1], sl[1:]))

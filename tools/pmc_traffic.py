@@ -41,7 +41,10 @@ def collect(path, counter):
 fetch, nf = collect(sys.argv[1], "FETCH_SIZE")
 write, nw = collect(sys.argv[2], "WRITE_SIZE")
 launches_per_profiler_row = {"attn_bwd_bf16": 2, "attn_bwd_f32": 2}          # dQ and dK/dV kernels are one profiled call
-out = {"_note": "HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, `bench.py --steps 3 --warmup 1 "
+import os
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from bench import csrc_hash  # noqa: E402
+out = {"_csrc_sha256": csrc_hash(), "_note": "HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, `bench.py --steps 3 --warmup 1 "
                 "--graph off`), averaged over the launches of the step; FETCH_SIZE doubled per the gfx950 correction of "
                 "/opt/skills/guides/MI355X_MICROARCH.md (validated on adam_kernel, whose traffic is known exactly). Units: bytes.",
        "_command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --graph off ; same with WRITE_SIZE ; tools/pmc_traffic.py"}
