@@ -372,8 +372,11 @@ class AuxBolck(nn.Module):
     """Auxiliary head on an intermediate stage (reference :329-368): per scale Conv2d(k=2, no bias) ->
     BatchNorm2d -> ReLU -> Dropout2d(0.3) -> Conv2d(1x1, C/S) -> mean over positions; concatenated ->
     LayerNorm -> Linear(C, 100).  Both convolutions run as MFMA GEMMs (the 2x2 one over gathered windows);
-    BatchNorm2d / ReLU / Dropout2d are the torch modules themselves on the device (they own the running
-    statistics and the RNG stream the reference uses)."""
+    BatchNorm2d + ReLU + the Dropout2d mask are one HIP kernel family (dm_batchnorm_fwd / _bwd) on the channels-last
+    GEMM output; the torch modules only own the parameters, the running statistics and the dropout probability.
+    Data parallel: statistics are PER RANK, like the reference under plain DataParallel-free training on one GPU per
+    process (no SyncBN: the aux heads see >= 120 x 49 positions per rank at the reference batch size, and SyncBN would
+    add two collectives per head per step); gamma / beta gradients are averaged with all the others."""
     _v5 = False
 
     def __init__(self, in_c=768, out_c=100, cube_size=[3, 8, 8], norm_layer=nn.LayerNorm, numerics=None):
@@ -401,8 +404,18 @@ class AuxBolck(nn.Module):
         cols = torch.stack([t4[:, ky:ky + o, kx:kx + o, :] for ky in (0, 1) for kx in (0, 1)], dim=-1).reshape(B * o * o, Cc * 4)
         dt = ops.act_dtype(self.numerics)
         y = ops.LinearFn.apply(_CastFn.apply(cols, dt), self.aux[0].weight, None, None, torch.float32)
-        y = self.aux[3](self.aux[2](self.aux[1](y.view(B, o, o, Cc).permute(0, 3, 1, 2))))
-        y = y.permute(0, 2, 3, 1).reshape(B * o * o, Cc)
+        # BatchNorm2d -> ReLU -> Dropout2d in one HIP pass over the channels-last GEMM output (no NCHW round trip).  The
+        # dropout mask is drawn the way torch's feature dropout draws it (bernoulli(1 - p) per (sample, channel), / (1 - p))
+        bn, drop = self.aux[1], self.aux[3]
+        if bn.momentum is None or not bn.track_running_stats or not bn.affine:
+            raise ValueError("the HIP BatchNorm path implements the reference's default BatchNorm2d (affine, momentum 0.1, running stats)")
+        training = self.training
+        mask = None
+        if training and drop.p > 0:
+            mask = torch.empty((B, Cc), dtype=torch.float32, device=y.device).bernoulli_(1.0 - drop.p).div_(1.0 - drop.p)
+        y = ops.BatchNormReluFn.apply(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, mask, o * o, bn.eps, bn.momentum, training, True)
+        if training:
+            bn.num_batches_tracked += 1
         y = ops.LinearFn.apply(_CastFn.apply(y, dt), self.aux[4].weight, self.aux[4].bias, None, torch.float32)
         return ops.GroupMeanFn.apply(y.view(B, o * o, -1), o * o).view(B, -1)
 

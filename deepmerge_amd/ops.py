@@ -482,6 +482,49 @@ class AttentionFn(torch.autograd.Function):
         return dqkv, dtable, None, None, None, None, None, None
 
 
+class BatchNormReluFn(torch.autograd.Function):
+    """BatchNorm2d -> ReLU -> Dropout2d of the auxiliary heads (reference nets/ShfitScaleFormer.py:340-346) on the channels-last
+    matrix x [samples * rows_per_sample, C] the convolution GEMM produces.  `mask`: None or [samples, C] multipliers (0 or
+    1 / (1 - p)); running statistics are updated in place when training, exactly as torch.nn.BatchNorm2d does."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, mask, rows_per_sample, eps, momentum, training, relu):
+        _need_cuda(x, gamma, beta, running_mean, running_var, mask)
+        x = x.float().contiguous()
+        M, Cc = x.shape
+        y = torch.empty_like(x)
+        mean = torch.empty(Cc, dtype=torch.float32, device=x.device)
+        rstd = torch.empty(Cc, dtype=torch.float32, device=x.device)
+        if mask is not None:
+            mask = mask.float().contiguous()
+            if mask.shape != (M // rows_per_sample, Cc):
+                raise ValueError(f"mask must be [samples, C] = {(M // rows_per_sample, Cc)}, got {tuple(mask.shape)}")
+        ws = workspace(_lib.lib().dm_batchnorm_workspace_bytes(M, Cc), x.device, "bn")
+        check(_lib.lib().dm_batchnorm_fwd(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), _ptr(running_mean), _ptr(running_var), _ptr(mask),
+                                          rows_per_sample, y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), M, Cc, eps, momentum, int(training),
+                                          int(relu), ws.data_ptr(), _stream()), "dm_batchnorm_fwd")
+        ctx.save_for_backward(x, y, gamma, mask, mean, rstd)
+        ctx.cfg = (rows_per_sample, bool(training))
+        ctx.params = (gamma, beta)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, gamma, mask, mean, rstd = ctx.saved_tensors
+        rows_per_sample, training = ctx.cfg
+        M, Cc = x.shape
+        dx = torch.empty_like(x)
+        gs, bs = _multi_use_sink(ctx.params[0], (Cc,)), _multi_use_sink(ctx.params[1], (Cc,))
+        direct = gs is not None and bs is not None
+        dg = gs if direct else torch.empty(Cc, dtype=torch.float32, device=x.device)
+        db = bs if direct else torch.empty(Cc, dtype=torch.float32, device=x.device)
+        ws = workspace(_lib.lib().dm_batchnorm_workspace_bytes(M, Cc), x.device, "bn")
+        check(_lib.lib().dm_batchnorm_bwd(dy.float().contiguous().data_ptr(), x.data_ptr(), y.data_ptr(), gamma.data_ptr(), _ptr(mask), rows_per_sample,
+                                          mean.data_ptr(), rstd.data_ptr(), dx.data_ptr(), dg.data_ptr(), db.data_ptr(), int(direct), M, Cc,
+                                          int(training), ws.data_ptr(), _stream()), "dm_batchnorm_bwd")
+        return dx, (None if direct else dg), (None if direct else db), None, None, None, None, None, None, None, None
+
+
 class TokenPoolFn(torch.autograd.Function):
     """Per-scale AvgPool2d(2,2) over the token grid (nets/ShfitScaleFormer.py:892-901, :905-914)."""
 

@@ -257,6 +257,23 @@ int dm_rag_edges(const int32_t *labels, int32_t H, int32_t W, int32_t S, int64_t
 int dm_merge_round(const int32_t *edges, const uint8_t *merge, int32_t E, int32_t S, int32_t *parent, int32_t *changed,
                    int32_t init, void *stream);
 
+/* BatchNorm2d (+ ReLU, + Dropout2d mask) of the auxiliary heads (reference nets/ShfitScaleFormer.py:329-368: Conv2d ->
+ * BatchNorm2d -> ReLU -> Dropout2d(0.3)) on the channels-last matrix the convolution GEMM produces: x, y fp32 [M, C] with
+ * M = samples * rows_per_sample.  training != 0: batch statistics (biased variance, eps inside the sqrt), running_mean /
+ * running_var updated in place with `momentum` (unbiased variance), as torch.nn.BatchNorm2d; training == 0: the running
+ * statistics.  mask: NULL or fp32 [samples, C] multipliers (0 or 1/(1-p): Dropout2d drops whole channels of a sample);
+ * relu != 0 applies max(0, .) between the normalisation and the mask.  save_mean / save_rstd [C] are kept for backward.
+ * workspace: dm_batchnorm_workspace_bytes(M, C), 8-byte aligned. */
+int64_t dm_batchnorm_workspace_bytes(int32_t M, int32_t C);
+int dm_batchnorm_fwd(const float *x, const float *gamma, const float *beta, float *running_mean, float *running_var,
+                     const float *mask, int32_t rows_per_sample, float *y, float *save_mean, float *save_rstd, int32_t M,
+                     int32_t C, float eps, float momentum, int32_t training, int32_t relu, void *workspace, void *stream);
+/* Gradient of the above (relu on: y > 0 decides the ReLU branch): dx [M, C]; dgamma / dbeta [C] written, or added to when
+ * accumulate != 0. */
+int dm_batchnorm_bwd(const float *dy, const float *x, const float *y, const float *gamma, const float *mask, int32_t rows_per_sample,
+                     const float *save_mean, const float *save_rstd, float *dx, float *dgamma, float *dbeta, int32_t accumulate,
+                     int32_t M, int32_t C, int32_t training, void *workspace, void *stream);
+
 /* ---- optional in-library kernel timing ------------------------------------------------------
  * While enabled, the GEMM and attention entry points bracket their main kernel with hipEvents on
  * the caller's stream.  dm_prof_collect waits for the recorded events, aggregates them per kernel

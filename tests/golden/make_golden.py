@@ -189,7 +189,8 @@ def gen_model(S2F, Losses):
     fx = {}
     for tag, scales, in_c, depth in (("v3_3s3c_642", [32, 64, 128], 3, [6, 4, 2]),
                                      ("v3_4s4c_321", [32, 64, 128, 256], 4, [3, 2, 1]),
-                                     ("v3_3s3c_111", [32, 64, 128], 3, [1, 1, 1])):
+                                     ("v3_3s3c_111", [32, 64, 128], 3, [1, 1, 1]),
+                                     ("v3_4s4c_642", [32, 64, 128, 256], 4, [6, 4, 2])):      # BASELINE configs[4]'s model
         PE = S2F.PatchEmbed if in_c == 3 else (
             lambda img_size, patch_size, in_c, out_c, _c=in_c: S2F.PatchEmbed(img_size=img_size, patch_size=patch_size, in_c=_c, out_c=out_c))
         net = S2F.ShfitScaleFormer_v3(is_designed_feature_embedding=True, PatchEmbed=PE, cube_size=[8, 8],
@@ -235,7 +236,13 @@ def gen_model(S2F, Losses):
                 for n in watch:
                     add(fx, tag + f"/adam{step}/" + n, named[n], k=1024)
         print(tag, "loss", fx[tag + "/loss"], "dist", fx[tag + "/dist"], "none", list(fx[tag + "/grad_none"]))
-    np.savez_compressed(os.path.join(HERE, "model_v3.npz"), **fx)
+    # (the values after three Adam steps move by ~3e-5 relative from run to run: CPU reductions are thread-order dependent.
+    # Keys already committed keep their committed values, so re-running this script only ADDS cases.)
+    path = os.path.join(HERE, "model_v3.npz")
+    if os.path.exists(path):
+        old = np.load(path)
+        fx.update({k: old[k] for k in old.files})
+    np.savez_compressed(path, **fx)
     print("model_v3.npz", len(fx))
 
 

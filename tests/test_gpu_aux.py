@@ -66,3 +66,59 @@ def test_v5_bf16_runs_and_is_close():
         ev = net([t.to(DEV) for t in left], ld.to(DEV))
     l2, _ = recipe.summary_error("v5_111/eval_out", ev.float().cpu().numpy(), fx)
     assert l2 < 0.05, l2
+
+
+@pytest.mark.parametrize("training", [True, False])
+@pytest.mark.parametrize("samples,rows,C", [(6, 49, 768), (3, 9, 256), (1, 1, 64)])
+def test_batchnorm_relu_dropout_kernel_vs_torch(training, samples, rows, C):
+    """dm_batchnorm_fwd / _bwd through ops.BatchNormReluFn against torch's own BatchNorm2d -> ReLU -> channel mask in float64:
+    output, running statistics, dx, dgamma, dbeta; Dropout2d semantics (whole channels of a sample are zeroed or scaled)."""
+    from deepmerge_amd import ops
+    g = torch.Generator().manual_seed(samples * 100 + rows)
+    M = samples * rows
+    x = torch.randn(M, C, generator=g) * 1.7 + 0.3
+    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.2
+    rm, rv = torch.randn(C, generator=g) * 0.1, torch.rand(C, generator=g) + 0.5
+    mask = (torch.rand(samples, C, generator=g) > 0.3).float() / 0.7 if training else None
+    go = torch.randn(M, C, generator=g)
+    # torch reference on [samples, C, rows, 1] in float64
+    bn = torch.nn.BatchNorm2d(C).double()
+    with torch.no_grad():
+        bn.weight.copy_(gamma); bn.bias.copy_(beta); bn.running_mean.copy_(rm); bn.running_var.copy_(rv)
+    bn.train(training)
+    xr = x.double().view(samples, rows, C).permute(0, 2, 1).unsqueeze(-1).contiguous().requires_grad_(True)
+    yr = torch.relu(bn(xr))
+    if mask is not None:
+        yr = yr * mask.double()[:, :, None, None]
+    (yr * go.double().view(samples, rows, C).permute(0, 2, 1).unsqueeze(-1)).sum().backward()
+    if samples * rows == 1 and training:
+        return      # (torch refuses a single value per channel in training mode before reaching here for M == 1)
+    xd = x.to(DEV).requires_grad_(True)
+    gd, bd = gamma.to(DEV).requires_grad_(True), beta.to(DEV).requires_grad_(True)
+    rmd, rvd = rm.to(DEV), rv.to(DEV)
+    y = ops.BatchNormReluFn.apply(xd, gd, bd, rmd, rvd, None if mask is None else mask.to(DEV), rows, 1e-5, 0.1, training, True)
+    (y * go.to(DEV)).sum().backward()
+    back = lambda t: t.detach().squeeze(-1).permute(0, 2, 1).reshape(M, C)
+    np.testing.assert_allclose(y.detach().cpu().double().numpy(), back(yr).numpy(), rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(xd.grad.cpu().double().numpy(), back(xr.grad).numpy(), rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(gd.grad.cpu().double().numpy(), bn.weight.grad.numpy(), rtol=2e-4, atol=2e-4)
+    np.testing.assert_allclose(bd.grad.cpu().double().numpy(), bn.bias.grad.numpy(), rtol=2e-4, atol=2e-4)
+    np.testing.assert_allclose(rmd.cpu().double().numpy(), bn.running_mean.numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(rvd.cpu().double().numpy(), bn.running_var.numpy(), rtol=1e-5, atol=1e-6)
+    if mask is not None:
+        dropped = (mask == 0)[:, None, :].expand(samples, rows, C).reshape(M, C)
+        assert float(y.detach().cpu()[dropped].abs().max()) == 0.0
+
+
+def test_aux_head_dropout_is_live_in_training():
+    """p = 0.3 (the reference default): in training every (sample, channel) of the BatchNorm output is either dropped or scaled
+    by 1/0.7, so two forward passes differ; in eval the head is deterministic."""
+    net = S2F().ShfitScaleFormer_v4(cube_size=[8, 8], input_image_scales=[32, 64, 128], depth=[1, 1, 1], numerics="fp32")
+    net = load_recipe_weights(net).to(DEV).train()
+    left, ld, right, rd, _ = model_inputs("v4_111", (32, 64, 128), 3, 4)
+    args = ([t.to(DEV) for t in left], ld.to(DEV), [t.to(DEV) for t in right], rd.to(DEV))
+    with torch.no_grad():
+        (x1, a1, _), _ = net(*args)
+        (x2, a2, _), _ = net(*args)
+    assert torch.equal(x1, x2) and not torch.equal(a1, a2)
+    assert int(net.aux0.aux[1].num_batches_tracked) == 2 * 2 * 3     # 2 passes x 2 sides x 3 scales (one BatchNorm call each)

@@ -135,7 +135,7 @@ def build_model(tag, mode):
     return cfg, load_recipe_weights(net).to(DEV)
 
 
-@pytest.mark.parametrize("tag", ["v3_3s3c_111", "v3_4s4c_321", "v3_3s3c_642"])
+@pytest.mark.parametrize("tag", ["v3_3s3c_111", "v3_4s4c_321", "v3_3s3c_642", "v3_4s4c_642"])
 def test_whole_model_parity_fp32(tag):
     from deepmerge_amd.Losses import Loss
     fx = load_fx("model_v3.npz")
@@ -185,8 +185,10 @@ def test_whole_model_bf16_drift_is_bounded():
     worst = max(errs, key=errs.get)
     print(f"bf16 drift: embeddings rel-L2 {e_out[0]:.2e}; median grad rel-L2 {np.median(list(errs.values())):.2e}; "
           f"worst {worst} {errs[worst]:.2e}; loss {loss.item():.4f} vs {float(fx[tag + '/loss']):.4f}")
-    assert e_out[0] < 3e-2
-    assert np.median(list(errs.values())) < 8e-2
+    # measured on MI355X: 4.3e-3 / 2.2e-2 (the reference itself under bf16 autocast: 6.6e-3 / 2.6e-2);
+    # the gates sit ~1.6x above the measurement so that a regression shows
+    assert e_out[0] < 8e-3
+    assert np.median(list(errs.values())) < 3.5e-2
 
 
 @pytest.mark.parametrize("mode", ["fp32", "bf16"])

@@ -186,3 +186,34 @@ def test_whole_model_side_swap_symmetry_full_size():
             continue
         a, b = g1[n].float(), p.grad.float()
         assert float((a - b).norm()) <= 2e-2 * float(a.norm()) + 1e-7, n
+
+
+def test_config5_model_full_size_properties():
+    """BASELINE configs[4]'s per-GPU step: v3 depth [6,4,2], 4 scales x 4 channels, 120 pairs (config.py:20), bf16, through
+    PairTrainer.  Size-independent checks: side swap swaps the embeddings bit for bit; the captured (hipGraph) step and the
+    segmented data-parallel schedule give bit-identical weights to the eager step; loss is finite and moves."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    from bench import synth_batch
+    from deepmerge_amd.nets.ShfitScaleFormer import ShfitScaleFormer_v3
+    from deepmerge_amd.trainer import PairTrainer
+    scales, in_c, depth, B = [32, 64, 128, 256], 4, [6, 4, 2], 120
+    nets = []
+    for _ in range(3):
+        torch.manual_seed(0)
+        nets.append(ShfitScaleFormer_v3(cube_size=[8, 8], input_image_scales=list(scales), depth=list(depth), in_c=in_c, numerics="bf16").to(DEV).train())
+    left, ld, right, rd, flag = synth_batch(B, scales, in_c, DEV, 5)
+    with torch.no_grad():
+        fa, fb = nets[0](left, ld, right, rd)
+        fb2, fa2 = nets[0](right, rd, left, ld)
+    assert torch.equal(fa, fa2) and torch.equal(fb, fb2) and fa.shape == (B, 100) and bool(torch.isfinite(fa).all())
+    eager, graph, seg = PairTrainer(nets[0], lr=1e-4), PairTrainer(nets[1], lr=1e-4), PairTrainer(nets[2], lr=1e-4, segmented=True)
+    graph.enable_graph(warmup=1)
+    seg.enable_graph(warmup=1)
+    losses = []
+    for _ in range(3):
+        le, lg, ls = eager.step(left, ld, right, rd, flag), graph.step(left, ld, right, rd, flag), seg.step(left, ld, right, rd, flag)
+        assert float(le) == float(lg) == float(ls)
+        losses.append(float(le))
+    assert torch.equal(eager.fp.flat, graph.fp.flat) and torch.equal(eager.fp.flat, seg.fp.flat)
+    assert len(seg.bucket_slices) == 7 and all(np.isfinite(losses)) and losses[2] != losses[0]

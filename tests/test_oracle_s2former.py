@@ -148,7 +148,7 @@ def test_contrastive_loss_both_branches_and_flag_dtypes():
     assert abs(OL.class_loss(ll, lt, rl, rt).item() - float(fx["classloss/value"])) < 1e-5
 
 
-@pytest.mark.parametrize("tag", ["v3_3s3c_111", "v3_4s4c_321", "v3_3s3c_642"])
+@pytest.mark.parametrize("tag", ["v3_3s3c_111", "v3_4s4c_321", "v3_3s3c_642", "v3_4s4c_642"])
 def test_whole_model_forward_backward_adam(tag):
     fx = load_fx("model_v3.npz")
     cfg = MODEL_CASES[tag]

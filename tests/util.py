@@ -61,4 +61,5 @@ MODEL_CASES = {
     "v3_3s3c_642": O.S2Config(scales=(32, 64, 128), in_c=3, depth=(6, 4, 2)),
     "v3_4s4c_321": O.S2Config(scales=(32, 64, 128, 256), in_c=4, depth=(3, 2, 1)),
     "v3_3s3c_111": O.S2Config(scales=(32, 64, 128), in_c=3, depth=(1, 1, 1)),
+    "v3_4s4c_642": O.S2Config(scales=(32, 64, 128, 256), in_c=4, depth=(6, 4, 2)),
 }

@@ -1,0 +1,99 @@
+#!/usr/bin/env python3
+"""Train_SMT counterpart on synthetic data (Train_SMT.py:212-351): epochs of steps, MultiStepLR([40, 80], 0.2) stepped per
+epoch, FRESH pairs every step generated on the device -- patch pyramids cut from resident uint8 tiles by dm_patch_pyramid
+(patches.point_batch), positives = two jittered windows of the same spot, negatives = spots of different tiles -- through
+PairTrainer (hipGraph replay).  Prints a loss curve; BASELINE configs[4] shape by default (depth [6,4,2], 4 scales x 4 ch,
+120 pairs per GPU).        python tools/train_synth.py [--epochs 3] [--steps-per-epoch 20] [--pairs 120] [--depth 6,4,2]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from deepmerge_amd.nets.ShfitScaleFormer import ShfitScaleFormer_v3  # noqa: E402
+from deepmerge_amd.patches import point_batch  # noqa: E402
+from deepmerge_amd.trainer import PairTrainer, multistep_lr  # noqa: E402
+
+DEV = "cuda:0"
+
+
+def smooth_tiles(n, bands, size, g):
+    """Spatially correlated uint8 tiles (so that two nearby windows look alike and two tiles do not)."""
+    low = torch.rand((n, bands, size // 32, size // 32), generator=g, device=DEV)
+    t = torch.nn.functional.interpolate(low, size=(size, size), mode="bilinear", align_corners=False)
+    t = t + 0.08 * torch.rand((n, bands, size, size), generator=g, device=DEV)
+    return (t.clamp(0, 1) * 255).to(torch.uint8)
+
+
+def make_pairs(tiles, B, scales, g):
+    n, bands, size, _ = tiles.shape
+    flag = (torch.arange(B, device=DEV) % 2 == 0).to(torch.int64)
+    tl = torch.randint(0, n, (B,), generator=g, device=DEV)
+    tr = torch.where(flag == 1, tl, (tl + 1 + torch.randint(0, n - 1, (B,), generator=g, device=DEV)) % n)
+    xy_l = torch.randint(96, size - 96, (B, 2), generator=g, device=DEV)
+    xy_r = torch.where(flag[:, None] == 1, xy_l + torch.randint(-6, 7, (B, 2), generator=g, device=DEV),
+                       torch.randint(96, size - 96, (B, 2), generator=g, device=DEV))
+    inner = torch.randint(16, 65, (B,), generator=g, device=DEV)
+    obj = inner + torch.randint(8, 49, (B,), generator=g, device=DEV)
+    feats_l = torch.exp(torch.empty((B, 15), device=DEV).uniform_(-2.0, 3.0, generator=g))
+    feats_r = torch.where(flag[:, None] == 1, feats_l * 1.05, torch.exp(torch.empty((B, 15), device=DEV).uniform_(-2.0, 3.0, generator=g)))
+
+    def side(tid, xy, feats):
+        patches = [torch.empty((B, bands, s, s), device=DEV) for s in scales]
+        designed = torch.empty((B, 1, 19), device=DEV)
+        for t in range(n):                                  # one gather launch per (tile, scale)
+            sel = torch.nonzero(tid == t).reshape(-1)
+            if sel.numel() == 0:
+                continue
+            p, d = point_batch(tiles[t], xy[sel].to(torch.int32), inner[sel].cpu(), obj[sel].cpu(), feats[sel], scales=scales)
+            for i in range(len(scales)):
+                patches[i][sel] = p[i]
+            designed[sel] = d
+        return patches, designed
+    pl, dl = side(tl, xy_l, feats_l)
+    pr, dr = side(tr, xy_r, feats_r)
+    return pl, dl, pr, dr, flag
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--epochs", type=int, default=3)
+    ap.add_argument("--steps-per-epoch", type=int, default=20)
+    ap.add_argument("--pairs", type=int, default=120)
+    ap.add_argument("--depth", type=str, default="6,4,2")
+    ap.add_argument("--lr", type=float, default=1e-4)
+    ap.add_argument("--milestones", type=str, default="40,80")
+    args = ap.parse_args()
+    scales, bands = [32, 64, 128, 256], 4
+    depth = [int(d) for d in args.depth.split(",")]
+    ms = tuple(int(m) for m in args.milestones.split(","))
+    g = torch.Generator(device=DEV); g.manual_seed(0)
+    torch.manual_seed(0)
+    tiles = smooth_tiles(6, bands, 1024, g)
+    net = ShfitScaleFormer_v3(cube_size=[8, 8], input_image_scales=list(scales), depth=depth, in_c=bands, numerics="bf16").to(DEV)
+    tr = PairTrainer(net, margin=1.0, lr=args.lr)
+    tr.enable_graph(warmup=1)
+    curve = []
+    t0 = time.perf_counter()
+    for epoch in range(args.epochs):
+        lr = multistep_lr(args.lr, epoch, ms)
+        tot = 0.0
+        for _ in range(args.steps_per_epoch):
+            batch = make_pairs(tiles, args.pairs, scales, g)
+            tot += float(tr.step(*batch, lr=lr))            # (.item() per step, as Train_SMT.py:301 does)
+        curve.append(round(tot / args.steps_per_epoch, 5))
+        print(f"epoch {epoch}: lr {lr:.2e} mean loss {curve[-1]:.5f}", flush=True)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    n = args.epochs * args.steps_per_epoch
+    print(json.dumps({"tool": "train_synth", "depth": depth, "pairs_per_step": args.pairs, "steps": n, "loss_curve": curve,
+                      "pairs_per_s_incl_data_generation": round(n * args.pairs / dt, 1)}))
+
+
+if __name__ == "__main__":
+    main()
