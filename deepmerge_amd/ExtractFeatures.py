@@ -46,6 +46,32 @@ class FeatureIO:
         self.features = out
         return out
 
+    @torch.no_grad()
+    def extract_features_from_tile(self, tile: torch.Tensor, points_xy: torch.Tensor, inner: torch.Tensor, obj: torch.Tensor,
+                                   region_features: torch.Tensor, batch_size: int = 2000, geotransform=None) -> torch.Tensor:
+        """`extract_features(image_path, point_path, h5_file_path, batch_size)` (ExtractFeatures.py:45-86) with the raster and the
+        point table already in memory: `tile` uint8 [bands, H, W] on the GPU (what GDAL's ReadAsArray returns), one row per
+        sample point in FID order -- pixel position (or geo coordinates when `geotransform` is given: the reference's own
+        conversion with its +1, MyUtils1.py:67-73), the `inner` / `object` window fields and the 15 designed attributes.  The
+        per-point window arithmetic, crop, resize and patch-embed operand layout run on the device (patches.point_batch_cols);
+        returns / keeps F [P, 100] fp32, rows in point order, as the HDF5 `dataset` would hold them."""
+        from .patches import geo_to_pixel, point_batch_cols
+        if geotransform is not None:
+            points_xy = geo_to_pixel(geotransform, points_xy[:, 0], points_xy[:, 1])
+        P = points_xy.shape[0]
+        scales = list(self.net.input_image_scales)
+        grid = self.net.cube_size[1]
+        dtype = ops.act_dtype(getattr(self.net, "numerics", "bf16"))
+        out = torch.empty((P, 100), dtype=torch.float32, device=self.device)
+        xy = points_xy.to(self.device).to(torch.int32)
+        feats = region_features.to(self.device)
+        for s in range(0, P, batch_size):
+            e = min(P, s + batch_size)
+            patches, designed = point_batch_cols(tile, xy[s:e], inner[s:e], obj[s:e], feats[s:e], scales=scales, grid=grid, dtype=dtype)
+            out[s:e] = self.net(patches, designed)
+        self.features = out
+        return out
+
     def GetFeaturesByID(self, idx: int) -> torch.Tensor:
         if self.features is None or idx >= self.features.shape[0]:
             raise IndexError("index error!")

@@ -85,6 +85,7 @@ SIGNATURES = {
     "dm_segment_mean": (_I, [_P, _P, _P, _P, _I, _I, _P]),
     "dm_edge_similarity": (_I, [_P, _P, _P, _P, _I, _I, _F, _P]),
     "dm_patch_pyramid": (_I, [_P, _I, _I, _I, _P, _P, _I, _I, _I, _P, _P]),
+    "dm_patch_pyramid_cols": (_I, [_P, _I, _I, _I, _P, _P, _I, _I, _I, _I, _P, _I, _P]),
     "dm_label_stats": (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
     "dm_label_features": (_I, [_P, _P, _P, _P, _P, _I, _I, _P, _P]),
     "dm_rag_edges": (_I, [_P, _I, _I, _I, _P, _P, _I, _P, _P, _I, _P, _P, _P]),

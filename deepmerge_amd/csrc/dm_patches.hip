@@ -14,10 +14,14 @@ constexpr int MAX_WINDOW = 384;   // L*L bytes of LDS (147 KB)
 // TLOG2 >= 0: the target side is 2^TLOG2 (32 / 64 / 128 in the reference's config.py:32): every division by T is a shift.
 // TLOG2 < 0: any T.  The rounded quotient num / L^2 is taken with one float reciprocal and an exact integer fix-up
 // (num < 256 L^2, so the estimate is off by at most one).
-template <int TLOG2>
+// OUT = float: planar patches [P, bands, T, T] (the tensor contract of the reference's loaders).
+// OUT = bf16_t / float with COLS: the patch-embed GEMM's operand rows directly -- row (p * G + py) * G + px, column
+// (c * ps + dy) * ps + dx with ps = T / G (the im2col order of Conv2d(k = ps, stride = ps), nets/ShfitScaleFormer.py:28-37) --
+// so the fp32 patch tensor and the separate im2col pass (dm_patchify) never exist.
+template <int TLOG2, typename OUT, bool COLS>
 __global__ __launch_bounds__(256) void patch_pyramid_kernel(const unsigned char *__restrict__ tile, int bands, int H, int W,
                                                             const int *__restrict__ xy, const int *__restrict__ wins,
-                                                            int Trt, float *__restrict__ out) {
+                                                            int Trt, int G, OUT *__restrict__ out) {
   extern __shared__ unsigned char win[];
   const int T = TLOG2 >= 0 ? (1 << TLOG2) : Trt;
   auto divT = [&](int v) { return TLOG2 >= 0 ? (v >> TLOG2) : v / T; };
@@ -39,7 +43,9 @@ __global__ __launch_bounds__(256) void patch_pyramid_kernel(const unsigned char 
   __syncthreads();
   const int den = L * L;
   const float rden = 1.0f / (float)den;
-  float *dst = out + ((long long)p * bands + c) * T * T;
+  OUT *dst = COLS ? out : out + ((long long)p * bands + c) * T * T;
+  const int ps = COLS ? T / G : 1;
+  const long long Kc = (long long)bands * ps * ps;
   for (int o = t; o < T * T; o += 256) {
     const int oy = divT(o), ox = o - oy * T;
     const int ylo = oy * L, yhi = ylo + L, xlo = ox * L, xhi = xlo + L;       // footprints in 1/T input-pixel units
@@ -58,10 +64,30 @@ __global__ __launch_bounds__(256) void patch_pyramid_kernel(const unsigned char 
     int r = num - q * den;
     if (r < 0) { --q; r += den; } else if (r >= den) { ++q; r -= den; }       // ... made exact
     if (2 * r > den || (2 * r == den && (q & 1))) ++q;        // round half to even
-    dst[o] = (float)q / 255.0f;
+    const float v = (float)q / 255.0f;
+    if constexpr (COLS) {
+      const int py = oy / ps, dy = oy - py * ps, px = ox / ps, dx = ox - px * ps;
+      dst[(((long long)p * G + py) * G + px) * Kc + ((long long)c * ps + dy) * ps + dx] = (OUT)v;
+    } else {
+      dst[o] = (OUT)v;
+    }
   }
 }
 
+}  // namespace
+
+namespace {
+template <typename OUT, bool COLS>
+void launch_pyramid(dim3 grid, size_t lds, hipStream_t s, const uint8_t *tile, int bands, int H, int W, const int32_t *xy, const int32_t *windows,
+                    int target, int G, OUT *out) {
+  switch (target) {
+    case 32: hipLaunchKernelGGL((patch_pyramid_kernel<5, OUT, COLS>), grid, dim3(256), lds, s, tile, bands, H, W, xy, windows, target, G, out); break;
+    case 64: hipLaunchKernelGGL((patch_pyramid_kernel<6, OUT, COLS>), grid, dim3(256), lds, s, tile, bands, H, W, xy, windows, target, G, out); break;
+    case 128: hipLaunchKernelGGL((patch_pyramid_kernel<7, OUT, COLS>), grid, dim3(256), lds, s, tile, bands, H, W, xy, windows, target, G, out); break;
+    case 256: hipLaunchKernelGGL((patch_pyramid_kernel<8, OUT, COLS>), grid, dim3(256), lds, s, tile, bands, H, W, xy, windows, target, G, out); break;
+    default: hipLaunchKernelGGL((patch_pyramid_kernel<-1, OUT, COLS>), grid, dim3(256), lds, s, tile, bands, H, W, xy, windows, target, G, out); break;
+  }
+}
 }  // namespace
 
 extern "C" int dm_patch_pyramid(const uint8_t *tile, int32_t bands, int32_t H, int32_t W, const int32_t *xy, const int32_t *windows,
@@ -71,16 +97,26 @@ extern "C" int dm_patch_pyramid(const uint8_t *tile, int32_t bands, int32_t H, i
   DM_REQUIRE(max_window > 0 && max_window <= MAX_WINDOW, DM_ERR_UNSUPPORTED,
              "dm_patch_pyramid: window side %d outside 1..%d", max_window, MAX_WINDOW);
   DM_REQUIRE(bands <= 65535, DM_ERR_BAD_SHAPE, "dm_patch_pyramid: too many bands");
+  launch_pyramid<float, false>(dim3(P, bands), (size_t)max_window * max_window, reinterpret_cast<hipStream_t>(stream), tile, bands, H, W, xy, windows,
+                               target, 1, out);
+  DM_LAUNCH_CHECK("dm_patch_pyramid");
+  return DM_OK;
+}
+
+extern "C" int dm_patch_pyramid_cols(const uint8_t *tile, int32_t bands, int32_t H, int32_t W, const int32_t *xy, const int32_t *windows,
+                                     int32_t max_window, int32_t P, int32_t target, int32_t grid, void *cols, int32_t dtype, void *stream) {
+  DM_REQUIRE(tile && xy && windows && cols && bands > 0 && H > 0 && W > 0 && P > 0 && target > 0, DM_ERR_BAD_SHAPE,
+             "dm_patch_pyramid_cols: bad arguments");
+  DM_REQUIRE(grid > 0 && target % grid == 0, DM_ERR_BAD_SHAPE, "dm_patch_pyramid_cols: target %d is not a multiple of the token grid %d", target, grid);
+  DM_REQUIRE(max_window > 0 && max_window <= MAX_WINDOW, DM_ERR_UNSUPPORTED,
+             "dm_patch_pyramid_cols: window side %d outside 1..%d", max_window, MAX_WINDOW);
+  DM_REQUIRE(bands <= 65535, DM_ERR_BAD_SHAPE, "dm_patch_pyramid_cols: too many bands");
+  const dim3 g(P, bands);
   const size_t lds = (size_t)max_window * max_window;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  const dim3 grid(P, bands);
-  switch (target) {
-    case 32: hipLaunchKernelGGL(patch_pyramid_kernel<5>, grid, dim3(256), lds, s, tile, bands, H, W, xy, windows, target, out); break;
-    case 64: hipLaunchKernelGGL(patch_pyramid_kernel<6>, grid, dim3(256), lds, s, tile, bands, H, W, xy, windows, target, out); break;
-    case 128: hipLaunchKernelGGL(patch_pyramid_kernel<7>, grid, dim3(256), lds, s, tile, bands, H, W, xy, windows, target, out); break;
-    case 256: hipLaunchKernelGGL(patch_pyramid_kernel<8>, grid, dim3(256), lds, s, tile, bands, H, W, xy, windows, target, out); break;
-    default: hipLaunchKernelGGL(patch_pyramid_kernel<-1>, grid, dim3(256), lds, s, tile, bands, H, W, xy, windows, target, out); break;
-  }
-  DM_LAUNCH_CHECK("dm_patch_pyramid");
+  if (dtype == DM_BF16) launch_pyramid<bf16_t, true>(g, lds, s, tile, bands, H, W, xy, windows, target, grid, reinterpret_cast<bf16_t *>(cols));
+  else if (dtype == DM_F32) launch_pyramid<float, true>(g, lds, s, tile, bands, H, W, xy, windows, target, grid, reinterpret_cast<float *>(cols));
+  else DM_REQUIRE(false, DM_ERR_BAD_DTYPE, "dm_patch_pyramid_cols: bad dtype %d", dtype);
+  DM_LAUNCH_CHECK("dm_patch_pyramid_cols");
   return DM_OK;
 }

@@ -61,7 +61,12 @@ class PatchEmbed(nn.Module):
         B, C, H, W = x.shape
         assert H == self.img_size[0] and W == self.img_size[1], \
             f"Input image size ({H}*{W}) doesn't match model ({self.img_size[0]}*{self.img_size[1]})."
-        cols = ops.patchify(x.float(), self.patch_size[0], ops.act_dtype(self.numerics))
+        if isinstance(x, ops.PatchCols):          # operand rows gathered straight from a tile (patches.point_batch_cols)
+            if x.patch != self.patch_size[0] or x.cols.dtype != ops.act_dtype(self.numerics):
+                raise ValueError("PatchCols were built for another patch size / numerics mode")
+            cols = x.cols
+        else:
+            cols = ops.patchify(x.float(), self.patch_size[0], ops.act_dtype(self.numerics))
         y = ops.LinearFn.apply(cols, self.proj.weight, self.proj.bias, None, torch.float32)
         return self.norm(y.view(B, self.num_patches, -1))
 

@@ -274,6 +274,49 @@ def patch_pyramid(tile: torch.Tensor, xy: torch.Tensor, windows: torch.Tensor, t
     return out
 
 
+class PatchCols:
+    """Patch-embed operand rows of one scale for P samples, produced straight from a uint8 tile by dm_patch_pyramid_cols:
+    cols [P * grid * grid, bands * ps * ps] (bf16 / fp32).  PatchEmbed.forward accepts it in place of the [P, C, s, s] image
+    tensor, so model code is unchanged while the fp32 patch tensor and the im2col pass never exist."""
+
+    def __init__(self, cols: torch.Tensor, batch: int, side: int, patch: int, bands: int):
+        self.cols, self.batch, self.side, self.patch, self.bands = cols, batch, side, patch, bands
+
+    @property
+    def shape(self):            # what the image tensor's shape would have been (PatchEmbed's size assertion reads it)
+        return (self.batch, self.bands, self.side, self.side)
+
+    def __getitem__(self, sl):  # batch slicing (FeatureIO walks points in chunks)
+        g2 = (self.side // self.patch) ** 2
+        if not isinstance(sl, slice) or sl.step not in (None, 1):
+            raise TypeError("PatchCols supports contiguous batch slices only")
+        a, b, _ = sl.indices(self.batch)
+        return PatchCols(self.cols[a * g2:b * g2], b - a, self.side, self.patch, self.bands)
+
+    def to(self, *_a, **_k):
+        return self
+
+
+def patch_pyramid_cols(tile: torch.Tensor, xy: torch.Tensor, windows: torch.Tensor, target: int, grid: int = 8,
+                       dtype: torch.dtype = torch.bfloat16, max_window: Optional[int] = None) -> PatchCols:
+    """One scale of the patch pyramid as patch-embed GEMM rows (dm_patch_pyramid_cols)."""
+    _need_cuda(tile, xy, windows)
+    if tile.dtype != torch.uint8:
+        raise ValueError("tile must be uint8")
+    bands, H, W = tile.shape
+    P = xy.shape[0]
+    if target % grid:
+        raise ValueError(f"target {target} is not a multiple of the token grid {grid}")
+    ps = target // grid
+    if max_window is None:
+        max_window = int(windows.max().item())
+    cols = torch.empty((P * grid * grid, bands * ps * ps), dtype=dtype, device=tile.device)
+    check(_lib.lib().dm_patch_pyramid_cols(tile.contiguous().data_ptr(), bands, H, W, xy.to(torch.int32).contiguous().data_ptr(),
+                                           windows.to(torch.int32).contiguous().data_ptr(), max_window, P, target, grid, cols.data_ptr(),
+                                           _dt(cols), _stream()), "dm_patch_pyramid_cols")
+    return PatchCols(cols, P, target, ps, bands)
+
+
 def adam_step(param, grad, m, v, step, lr=1e-4, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0, param_lp=None):
     _need_cuda(param, grad, m, v)
     check(_lib.lib().dm_adam_step(param.data_ptr(), grad.data_ptr(), m.data_ptr(), v.data_ptr(), _ptr(param_lp), param.numel(), step,
@@ -492,6 +535,8 @@ class BatchNormReluFn(torch.autograd.Function):
         _need_cuda(x, gamma, beta, running_mean, running_var, mask)
         x = x.float().contiguous()
         M, Cc = x.shape
+        if training and M <= 1:
+            raise ValueError(f"Expected more than 1 value per channel when training, got input size {tuple(x.shape)}")
         y = torch.empty_like(x)
         mean = torch.empty(Cc, dtype=torch.float32, device=x.device)
         rstd = torch.empty(Cc, dtype=torch.float32, device=x.device)

@@ -41,3 +41,16 @@ def point_batch(tile: torch.Tensor, xy: torch.Tensor, inner: torch.Tensor, obj: 
     patches = [ops.patch_pyramid(tile, xy, windows[:, i].contiguous(), int(t)) for i, t in enumerate(scales)]
     designed = torch.cat((region_features.to(torch.float32), factors.to(region_features.device)), dim=1).unsqueeze(1)
     return patches, designed
+
+
+def point_batch_cols(tile: torch.Tensor, xy: torch.Tensor, inner: torch.Tensor, obj: torch.Tensor, region_features: torch.Tensor,
+                     scales: Sequence[int] = (32, 64, 128), grid: int = 8, dtype: torch.dtype = torch.bfloat16):
+    """point_batch with the gather FUSED into the patch-embed operand load: per scale an ops.PatchCols
+    (bf16 im2col rows written by the gather kernel itself) instead of the fp32 [P, bands, s, s] tensor + dm_patchify.
+    Bytes per point and scale: window in (L^2 * bands, uint8) + s^2 * bands * 2 out -- against + s^2 * bands * (4 + 4 + 2) for the
+    unfused chain.  The model consumes the list exactly like image tensors; results are bit-identical."""
+    windows, factors = get_scales(inner, obj)
+    windows = windows.to(tile.device)
+    patches = [ops.patch_pyramid_cols(tile, xy, windows[:, i].contiguous(), int(t), grid, dtype) for i, t in enumerate(scales)]
+    designed = torch.cat((region_features.to(torch.float32), factors.to(region_features.device)), dim=1).unsqueeze(1)
+    return patches, designed

@@ -226,6 +226,12 @@ int dm_edge_similarity(const float *pooled, const int32_t *edges, float *simi, u
  *   every L <= max_window <= 384; out float32 [P, bands, target, target]. */
 int dm_patch_pyramid(const uint8_t *tile, int32_t bands, int32_t H, int32_t W, const int32_t *xy, const int32_t *windows,
                      int32_t max_window, int32_t P, int32_t target, float *out, void *stream);
+/* The same gather emitting the patch-embed GEMM's operand rows directly ("patch pyramid gather fused into
+ * patch-embed"): cols [P * grid * grid, bands * ps * ps] with ps = target / grid, row (p * grid + py) * grid + px, column
+ * (c * ps + dy) * ps + dx -- the im2col order of Conv2d(k = ps, stride = ps) (nets/ShfitScaleFormer.py:28-37) -- in bf16 or
+ * fp32.  Equal, bit for bit, to dm_patch_pyramid followed by dm_patchify. */
+int dm_patch_pyramid_cols(const uint8_t *tile, int32_t bands, int32_t H, int32_t W, const int32_t *xy, const int32_t *windows,
+                          int32_t max_window, int32_t P, int32_t target, int32_t grid, void *cols, int32_t dtype, void *stream);
 
 /* ---- region-adjacency graph + superpixel statistics from a label raster ---------------------------
  * Replaces, on the device, the inputs the reference reads from files written by external GIS software: the RAG edge

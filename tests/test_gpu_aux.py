@@ -81,6 +81,10 @@ def test_batchnorm_relu_dropout_kernel_vs_torch(training, samples, rows, C):
     rm, rv = torch.randn(C, generator=g) * 0.1, torch.rand(C, generator=g) + 0.5
     mask = (torch.rand(samples, C, generator=g) > 0.3).float() / 0.7 if training else None
     go = torch.randn(M, C, generator=g)
+    if M == 1 and training:        # torch: "Expected more than 1 value per channel when training"; same contract here
+        with pytest.raises(ValueError):
+            ops.BatchNormReluFn.apply(x.to(DEV), gamma.to(DEV), beta.to(DEV), rm.to(DEV), rv.to(DEV), None, rows, 1e-5, 0.1, True, True)
+        return
     # torch reference on [samples, C, rows, 1] in float64
     bn = torch.nn.BatchNorm2d(C).double()
     with torch.no_grad():
@@ -91,8 +95,6 @@ def test_batchnorm_relu_dropout_kernel_vs_torch(training, samples, rows, C):
     if mask is not None:
         yr = yr * mask.double()[:, :, None, None]
     (yr * go.double().view(samples, rows, C).permute(0, 2, 1).unsqueeze(-1)).sum().backward()
-    if samples * rows == 1 and training:
-        return      # (torch refuses a single value per channel in training mode before reaching here for M == 1)
     xd = x.to(DEV).requires_grad_(True)
     gd, bd = gamma.to(DEV).requires_grad_(True), beta.to(DEV).requires_grad_(True)
     rmd, rvd = rm.to(DEV), rv.to(DEV)

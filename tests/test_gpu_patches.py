@@ -114,3 +114,51 @@ def test_point_chain_matches_reference_fixture():
         for i, L in enumerate(windows[0].tolist()):
             x0, y0 = OP.top_left(px[0], px[1], L)
             assert np.array_equal(OP.cut_image(img, x0, y0, L), fx[f"point/{k}/crop{i}"])
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_fused_gather_rows_equal_pyramid_then_patchify(dtype):
+    """dm_patch_pyramid_cols == dm_patch_pyramid -> dm_patchify, bit for bit (windows over every border, 4 bands, all four targets)."""
+    from deepmerge_amd import ops
+    rng = np.random.default_rng(9)
+    bands, H, W, P = 4, 300, 340, 24
+    tile = torch.from_numpy(rng.integers(0, 256, size=(bands, H, W), dtype=np.uint8)).to(DEV)
+    xy = torch.from_numpy(np.stack([rng.integers(-5, W + 5, P), rng.integers(-5, H + 5, P)], 1).astype(np.int32)).to(DEV)
+    for t, lo, hi in ((32, 7, 90), (64, 20, 130), (128, 40, 200), (256, 60, 300)):
+        wins = torch.from_numpy(rng.integers(lo, hi, P).astype(np.int32)).to(DEV)
+        wins[0] = t
+        planar = ops.patch_pyramid(tile, xy, wins, t)
+        want = ops.patchify(planar, t // 8, dtype)
+        got = ops.patch_pyramid_cols(tile, xy, wins, t, 8, dtype)
+        assert got.cols.shape == want.shape == (P * 64, bands * (t // 8) ** 2) and got.shape == (P, bands, t, t)
+        assert torch.equal(got.cols.view(torch.int16 if dtype == torch.bfloat16 else torch.int32), want.view(torch.int16 if dtype == torch.bfloat16 else torch.int32)), t
+
+
+def test_extract_from_tile_equals_image_path():
+    """FeatureIO.extract_features_from_tile (fused gather) == gather to images then the ordinary eval forward, bit for bit, and
+    feeds the sweep; geo coordinates go through the reference's own pixel conversion."""
+    from deepmerge_amd.ExtractFeatures import FeatureIO, rag_similarity_sweep
+    from deepmerge_amd.nets.ShfitScaleFormer import ShfitScaleFormer_v3
+    from deepmerge_amd.patches import point_batch
+    torch.manual_seed(0)
+    rng = np.random.default_rng(3)
+    bands = 4
+    tile = torch.from_numpy(rng.integers(0, 256, size=(bands, 400, 400), dtype=np.uint8)).to(DEV)
+    net = ShfitScaleFormer_v3(cube_size=[8, 8], input_image_scales=[32, 64, 128], depth=[1, 1, 1], in_c=bands, numerics="bf16")
+    fio = FeatureIO(net, None, DEV)
+    P = 50
+    xy = torch.from_numpy(rng.integers(1, 400, (P, 2)).astype(np.int32))
+    inner = torch.from_numpy(rng.integers(16, 64, P).astype(np.int32)); obj = inner + torch.from_numpy(rng.integers(8, 48, P).astype(np.int32))
+    feats = torch.from_numpy(np.exp(rng.uniform(-2, 3, (P, 15))).astype(np.float32))
+    F = fio.extract_features_from_tile(tile, xy, inner, obj, feats, batch_size=16)
+    patches, designed = point_batch(tile, xy.to(DEV), inner, obj, feats.to(DEV))
+    F_img = fio.extract_features(patches, designed, batch_size=16)
+    assert F.shape == (P, 100) and torch.equal(F, F_img)
+    assert torch.equal(fio.GetFeaturesByID(7), F[7])
+    gt = (1000.0, 0.5, 0.0, 5000.0, 0.0, -0.5)
+    geo = torch.stack([gt[0] + (xy[:, 0].double() - 0.75) * gt[1], gt[3] + (xy[:, 1].double() - 0.75) * gt[5]], 1)   # int(|d|/res + 1) == xy
+    assert torch.equal(fio.extract_features_from_tile(tile, geo, inner, obj, feats, batch_size=16, geotransform=gt), F)   # (same batching: the GEMM tile choice depends on M)
+    ptr = torch.arange(0, P + 1, 5, dtype=torch.int32, device=DEV); idx = torch.arange(P, dtype=torch.int32, device=DEV)
+    edges = torch.tensor([[0, 1], [1, 2], [-1, 3], [8, 9]], dtype=torch.int32, device=DEV)
+    pooled, simi, merge = rag_similarity_sweep(F, ptr, idx, edges, 1.0)
+    assert pooled.shape == (10, 100) and bool(torch.isnan(simi[2])) and not bool(merge[2])

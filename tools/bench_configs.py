@@ -107,17 +107,25 @@ def config4(passes=2):
     out_bytes = bs * bands * (32 * 32 + 64 * 64 + 128 * 128) * 4
     out["patch_gather"] = {"points_per_s": round(bs / t_g), "GBps_algorithmic(read window bytes + write fp32 patches)": round((win_bytes + out_bytes) / t_g / 1e9, 1)}
 
-    def encode_all():
+    from deepmerge_amd.patches import point_batch_cols
+    t_gf = ev(lambda: point_batch_cols(tile, xy[:bs], inner[:bs], obj[:bs], feats[:bs]), 5)
+    out["patch_gather_fused(bf16 patch-embed rows, no fp32 patches / im2col pass)"] = {
+        "points_per_s": round(bs / t_gf), "GBps_algorithmic(read window bytes + write bf16 rows)": round((win_bytes + out_bytes / 2) / t_gf / 1e9, 1)}
+
+    def encode_all(fused):
         F = torch.empty((P, 100), device=DEV)
+        gather = point_batch_cols if fused else point_batch
         with torch.no_grad():
             for s in range(0, P, bs):
                 e = min(P, s + bs)
-                patches, designed = point_batch(tile, xy[s:e], inner[s:e], obj[s:e], feats[s:e])
+                patches, designed = gather(tile, xy[s:e], inner[s:e], obj[s:e], feats[s:e])
                 F[s:e] = net(patches, designed)
         return F
-    for _ in range(passes):
-        t0 = time.perf_counter(); F = encode_all(); torch.cuda.synchronize(); t_enc = time.perf_counter() - t0
-    out["encode(gather + v3[6,4,2] eval, batch 2000)"] = {"points_per_s": round(P / t_enc), "seconds_for_tile": round(t_enc, 2)}
+    for fused in (False, True):
+        for _ in range(passes):
+            t0 = time.perf_counter(); F = encode_all(fused); torch.cuda.synchronize(); t_enc = time.perf_counter() - t0
+        key = "encode(gather + v3[6,4,2] eval, batch 2000)" if fused else "encode_unfused(fp32 patches -> im2col -> embed)"
+        out[key] = {"points_per_s": round(P / t_enc), "seconds_for_tile": round(t_enc, 2)}
     t_p = ev(lambda: ops.segment_mean(F, ptr, idx, validate=False), 20)      # (the CSR was validated by the call below)
     out["segment_mean"] = {"us": round(t_p * 1e6, 1), "GBps_algorithmic": round((P * 404 + S * 400) / t_p / 1e9, 1)}
     pooled = ops.segment_mean(F, ptr, idx)
