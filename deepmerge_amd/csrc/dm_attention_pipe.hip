@@ -196,6 +196,13 @@ __global__ __launch_bounds__(512) void attn_fwd_pipe_kernel(const AttnPipeParams
   write_back(b1 - 1);
 }
 
+// (Round 2, tried and removed: a variant of the kernel above that software-pipelines ACROSS samples inside a wave -- raw scores of
+// sample b + 1 on the matrix pipe while the VALU exponentiates sample b, scale / bias / max of b + 1 under P(b).V(b), K one
+// sample ahead of V in the same four LDS images.  Correct (all attention tests), but 59 us against 47 us at N = 256 with a bias:
+// two live score arrays + the bias rows need > 256 VGPRs (scratch spills), and hipcc places each K fragment read directly in
+// front of its MFMA behind an `s_waitcnt lgkmcnt(0)`, so the LDS latency is exposed 16 times per sample either way.  At N = 197
+// without spills it tied (182 us vs 186 us).  Counters of the kernels that ship: profiles/r02_attn_mfma_util.md.)
+
 // =============================================================================================================================
 // backward.  Same skeleton as the forward kernel; all LDS images here are "dual-use" (row fragments for the QK^T-like
 // products, hardware-transposed fragments for the contractions over tokens): 16-byte chunk index XOR s(row),

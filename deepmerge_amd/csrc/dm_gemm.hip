@@ -559,8 +559,14 @@ extern "C" int dm_gemm(const DmGemmArgs *a, void *stream) {
 
   const bool can_split = (a->layout == DM_TN) && a->epilogue == DM_EPI_NONE && !a->bias && !a->residual &&
                          a->c_dtype == DM_F32 && a->rows_per_group == 0 && a->workspace != nullptr && slab_bytes > 0;
-  if (a->split_k > 1)
+  if (a->split_k > 1) {
     DM_REQUIRE(can_split, DM_ERR_UNSUPPORTED, "dm_gemm: split_k needs DM_TN, no epilogue, fp32 C and a workspace");
+    // a caller-chosen slice count writes split_k fp32 copies of C into the workspace: refuse rather than run past its end
+    // (found by tools/mb_wgrad_group.py: a user split above the automatic one faulted on the GPU)
+    DM_REQUIRE((int64_t)a->split_k * a->M * a->N * 4 <= slab_bytes, DM_ERR_BAD_SHAPE,
+               "dm_gemm: split_k=%d needs %lld bytes of split-K workspace, got %lld", a->split_k,
+               (long long)((int64_t)a->split_k * a->M * a->N * 4), (long long)slab_bytes);
+  }
   // two-workgroups-per-CU ring kernel (k-contiguous operands, 16-byte row pieces in the epilogue)
   const bool ring_aligned = (a->ldc % 8 == 0) && (a->aux == nullptr || a->ldaux % 8 == 0) &&
                             (a->rows_per_group == 0 || a->group_stride % 8 == 0) && a->split_k <= 1 && !a->colsum_a;

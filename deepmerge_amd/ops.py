@@ -121,6 +121,8 @@ def gemm(layout: int, A: torch.Tensor, B: torch.Tensor, C_out: torch.Tensor, M: 
             raise ValueError("colsum_out must be a contiguous fp32 tensor with >= M elements")
         a.colsum_a, a.colsum_accumulate = colsum_out.data_ptr(), int(colsum_accumulate)
     ws_bytes = _lib.lib().dm_gemm_workspace_bytes(layout, M, N, K) if (split_k != 1 or colsum_out is not None) else 0
+    if split_k > 1:                       # caller-chosen slice count: its slab may be larger than the automatic one
+        ws_bytes = max(ws_bytes, _lib.lib().dm_gemm_workspace_bytes(layout, M, N, K) + split_k * M * N * 4)
     if ws_bytes > 0:
         ws = workspace(ws_bytes, A.device, ws_slot)
         a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()

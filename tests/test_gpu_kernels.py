@@ -502,3 +502,29 @@ def test_gemm_wgrad_with_fused_column_sums(M, N, K):
         assert torch.equal(db, want)
     with pytest.raises(ValueError):
         ops.gemm(DM_TN, dy, x, dw, M, N, K, lda=M, ldb=N, ldc=N, colsum_out=torch.empty(M - 1, device=DEV))
+
+
+def test_gemm_user_split_k_is_bounds_checked():
+    """A caller-chosen split_k above the automatic one used to write past the split-K slab (GPU fault, round 2).  The library now
+    refuses a workspace that is too small, and ops.gemm sizes the workspace for the requested slice count."""
+    ops = _ops()
+    from deepmerge_amd import _lib
+    from deepmerge_amd._lib import DM_BF16, DM_F32, DM_TN, DmGemmArgs
+    import ctypes as C
+    rng = np.random.default_rng(2)
+    T, M, N = 4096, 768, 768
+    dy, x = _ints(rng, (T, M), -1, 2).to(DEV).to(torch.bfloat16), _ints(rng, (T, N), -1, 2).to(DEV).to(torch.bfloat16)
+    want = dy.double().T @ x.double()
+    for split in (2, 3, 8):
+        G = torch.zeros((M, N), device=DEV)
+        ops.gemm(DM_TN, dy, x, G, M, N, T, lda=M, ldb=N, ldc=N, split_k=split)
+        assert torch.equal(G.double(), want), split
+    a = DmGemmArgs()
+    a.layout, a.ab_dtype, a.c_dtype, a.aux_dtype = DM_TN, DM_BF16, DM_F32, DM_F32
+    a.M, a.N, a.K, a.split_k = M, N, T, 8
+    G = torch.zeros((M, N), device=DEV)
+    small = torch.empty(2 * M * N * 4, dtype=torch.uint8, device=DEV)
+    a.A, a.lda, a.B, a.ldb, a.C, a.ldc = dy.data_ptr(), M, x.data_ptr(), N, G.data_ptr(), N
+    a.workspace, a.workspace_bytes = small.data_ptr(), small.numel()
+    rc = _lib.lib().dm_gemm(C.byref(a), torch.cuda.current_stream().cuda_stream)
+    assert rc != 0 and b"split_k" in _lib.lib().dm_last_error()
