@@ -3,7 +3,8 @@
 Reference flow (ExtractFeatures.py:45-86, :150-225): embed every sample point in batches of 2000
 (eval forward), append the [P,100] float32 rows to an HDF5 dataset, then for each region-adjacency
 edge gather the point rows of both polygons, mean-pool them and write the Euclidean distance as
-`simi`.  Storage (HDF5 / shapefile fields, GDAL rasters) is out of scope; this module keeps the
+`simi`.  GDAL rasters / shapefiles are out of scope (tensors in, tensors out); the HDF5 feature store exists as a writer /
+reader of the same layout (deepmerge_amd/h5store.py, save_h5 / ReadFeatures below).  This module keeps the
 features resident in HBM and runs the sweep as two kernels:
     dm_segment_mean      per-polygon mean over its sample points (CSR: ptr[S+1], idx[P])
     dm_edge_similarity   per-edge simi + merge = simi < margin
@@ -72,7 +73,38 @@ class FeatureIO:
         self.features = out
         return out
 
-    def GetFeaturesByID(self, idx: int) -> torch.Tensor:
+    # -- the HDF5 feature store of the reference (ExtractFeatures.py:88-117), without h5py: deepmerge_amd/h5store.py ----------
+    def save_h5(self, h5_file_path: str, batch_size: int = 2000) -> int:
+        """Write the resident features as the reference's `dataset` ([P, 100] float32, first dimension unlimited, chunked),
+        appended `batch_size` rows at a time like the upstream loop.  Returns the number of rows written."""
+        from .h5store import H5FeatureWriter
+        if self.features is None:
+            raise RuntimeError("no features to save: run extract_features / extract_features_from_tile first")
+        F = self.features
+        with H5FeatureWriter(h5_file_path, width=F.shape[1]) as w:
+            for s in range(0, F.shape[0], batch_size):
+                w.append(F[s:s + batch_size].float().cpu().numpy())
+        return int(F.shape[0])
+
+    def ReadFeatures(self, h5_file_path: str):
+        """Open a feature store for GetFeaturesByID (ExtractFeatures.py:103-107)."""
+        from .h5store import H5FeatureReader
+        self.Close()
+        self.h5py_file = H5FeatureReader(h5_file_path)
+        self.dataset = self.h5py_file
+
+    def Close(self):
+        if getattr(self, "h5py_file", None) is not None:
+            self.h5py_file.close()
+            self.h5py_file = None
+            self.dataset = None
+
+    def GetFeaturesByID(self, idx: int):
+        """Row `idx` of the opened store (numpy float32 [100], as h5py returns it) or, without one, of the resident tensor."""
+        if getattr(self, "dataset", None) is not None:
+            if idx >= len(self.dataset):
+                raise IndexError("index error!")
+            return self.dataset[idx]
         if self.features is None or idx >= self.features.shape[0]:
             raise IndexError("index error!")
         return self.features[idx]

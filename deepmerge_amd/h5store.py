@@ -1,0 +1,329 @@
+"""HDF5-layout feature store: the on-disk format `FeatureIO.save_h5` produces upstream (ExtractFeatures.py:88-101:
+`h5f.create_dataset("dataset", data=..., maxshape=(None, 100), chunks=True)` then `dataset.resize` + append per batch, read back
+with `f["dataset"][idx]`), written and read WITHOUT h5py (absent in this image) straight from the HDF5 File Format
+Specification (version 0 superblock, version 1 object headers, symbol-table root group, version 1 B-tree chunk index --
+the "earliest" layout h5py / libhdf5 emit by default for such a file and the one every libhdf5 can read).
+
+    H5FeatureWriter(path, width=100)      .append(rows [n, width] float32) ... .close()
+    H5FeatureReader(path)                 .shape, [i] -> row, .rows(a, b) -> [b-a, width]
+
+One 2-D little-endian IEEE float32 dataset named "dataset", dimension 0 unlimited (max dims (UNLIMITED, width)), chunked
+(chunk_rows x width), no filters, fill value undefined / incremental allocation.  The chunk index is a single leaf node for up
+to 64 chunks and a two-level tree above (default indexed-storage K = 32).  The file is rewritten index-last on close(), so an
+interrupted run leaves no half-valid index.
+
+Parity status: h5py is not available here or on the GPU box, so libhdf5 has never read these bytes: tests/test_h5store.py checks
+the structure field by field with an independent walk of the specification (H5FeatureReader shares no layout constants with
+the writer: it takes every size and address from the file) -- "structurally validated", not library-validated.
+"""
+from __future__ import annotations
+
+import struct
+from typing import List, Tuple
+
+import numpy as np
+
+UNDEF = 0xFFFFFFFFFFFFFFFF
+SIGNATURE = b"\x89HDF\r\n\x1a\n"
+GROUP_LEAF_K, GROUP_INTERNAL_K, ISTORE_K = 4, 16, 32
+
+
+def _pad8(b: bytes) -> bytes:
+    return b + b"\0" * (-len(b) % 8)
+
+
+def _message(mtype: int, data: bytes, flags: int = 0) -> bytes:
+    data = _pad8(data)
+    return struct.pack("<HHB3x", mtype, len(data), flags) + data
+
+
+def _object_header(messages: List[bytes]) -> bytes:
+    body = b"".join(messages)
+    return struct.pack("<BBHII4x", 1, 0, len(messages), 1, len(body)) + body
+
+
+class H5FeatureWriter:
+    def __init__(self, path: str, width: int = 100, chunk_rows: int = 1024, name: str = "dataset"):
+        if width <= 0 or chunk_rows <= 0:
+            raise ValueError("width and chunk_rows must be positive")
+        self.path, self.width, self.chunk_rows, self.name = path, int(width), int(chunk_rows), name
+        self.f = open(path, "wb")
+        self.rows = 0
+        self._tail = np.zeros((0, self.width), np.float32)      # rows of the last, partially filled chunk
+        self._chunks: List[int] = []                            # file address of every full chunk written so far
+        # ---- fixed metadata block; addresses are known up front, the dataset header and the index are patched in close() ----
+        self.addr_root = 96
+        root = _object_header([_message(0x0011, struct.pack("<QQ", 0, 0))])        # patched below once addresses are known
+        self.addr_btree = self.addr_root + len(root)
+        self.group_btree_size = 24 + (2 * GROUP_INTERNAL_K + 1) * 8 + 2 * GROUP_INTERNAL_K * 8
+        self.addr_heap = self.addr_btree + self.group_btree_size
+        self.heap_data_size = 88
+        self.addr_heap_data = self.addr_heap + 32
+        self.addr_snod = self.addr_heap_data + self.heap_data_size
+        self.snod_size = 8 + 2 * GROUP_LEAF_K * 40
+        self.addr_dset = self.addr_snod + self.snod_size
+        self.dset_header_size = len(self._dataset_header(0, 0))
+        self.addr_data = (self.addr_dset + self.dset_header_size + 7) // 8 * 8
+        self.f.write(b"\0" * self.addr_data)
+        self.chunk_bytes = self.chunk_rows * self.width * 4
+
+    # ---- metadata pieces -----------------------------------------------------------------------------------------------
+    def _dataset_header(self, rows: int, index_addr: int) -> bytes:
+        dataspace = struct.pack("<BBB5x", 1, 2, 1) + struct.pack("<QQ", rows, self.width) + struct.pack("<QQ", UNDEF, self.width)
+        # IEEE binary32, little-endian: class 1 (floating point), version 1; bit field: LE, no padding, mantissa normalisation 2
+        # (implied leading one), sign at bit 31; properties: bit offset 0, precision 32, exponent at 23 (8 bits), mantissa at 0
+        # (23 bits), bias 127
+        datatype = struct.pack("<BBBBI", 0x11, 0x20, 0x1F, 0x00, 4) + struct.pack("<HHBBBBI", 0, 32, 23, 8, 0, 23, 127)
+        fill = struct.pack("<BBBB", 2, 3, 0, 0)                 # version 2, incremental allocation, fill written on allocation, undefined value
+        layout = struct.pack("<BBB", 3, 2, 3) + struct.pack("<Q", index_addr) + struct.pack("<III", self.chunk_rows, self.width, 4)
+        return _object_header([_message(0x0001, dataspace), _message(0x0003, datatype, 1), _message(0x0005, fill), _message(0x0008, layout)])
+
+    def _chunk_key(self, i: int, size: int) -> bytes:
+        return struct.pack("<II", size, 0) + struct.pack("<QQQ", i * self.chunk_rows, 0, 0)
+
+    def _chunk_node(self, level: int, entries: List[Tuple[int, int]], last_row_chunk: int) -> bytes:
+        """entries: (first chunk index, child address).  A node is allocated at full size (2K entries) as libhdf5 does."""
+        body = b"TREE" + struct.pack("<BBH", 1, level, len(entries)) + struct.pack("<QQ", UNDEF, UNDEF)
+        for ci, addr in entries:
+            body += self._chunk_key(ci, self.chunk_bytes) + struct.pack("<Q", addr)
+        body += self._chunk_key(last_row_chunk, 0)              # final key: the offset just past the last chunk of this node
+        full = 24 + (2 * ISTORE_K + 1) * 32 + 2 * ISTORE_K * 8
+        return body + b"\0" * (full - len(body))
+
+    # ---- data ------------------------------------------------------------------------------------------------------------
+    def append(self, rows) -> None:
+        a = np.ascontiguousarray(np.asarray(rows, dtype=np.float32))
+        if a.ndim != 2 or a.shape[1] != self.width:
+            raise ValueError(f"rows must be [n, {self.width}], got {a.shape}")
+        self.rows += a.shape[0]
+        buf = np.concatenate([self._tail, a]) if self._tail.shape[0] else a
+        n_full = buf.shape[0] // self.chunk_rows
+        for c in range(n_full):
+            self._chunks.append(self.f.tell())
+            self.f.write(buf[c * self.chunk_rows:(c + 1) * self.chunk_rows].astype("<f4").tobytes())
+        self._tail = buf[n_full * self.chunk_rows:].copy()
+
+    def close(self) -> None:
+        if self.f is None:
+            return
+        f = self.f
+        chunks = list(self._chunks)
+        if self._tail.shape[0]:                                   # the last chunk is stored whole; rows past `rows` are never read
+            chunks.append(f.tell())
+            pad = np.zeros((self.chunk_rows, self.width), "<f4")
+            pad[:self._tail.shape[0]] = self._tail
+            f.write(pad.tobytes())
+        n = len(chunks)
+        index_addr = UNDEF
+        if n:
+            per = 2 * ISTORE_K
+            if n <= per:
+                index_addr = f.tell()
+                f.write(self._chunk_node(0, list(enumerate(chunks)), n))
+            else:
+                if n > per * per:
+                    raise ValueError("more than 4096 chunks: raise chunk_rows")
+                leaves = []
+                for s in range(0, n, per):
+                    leaves.append((s, f.tell()))
+                    f.write(self._chunk_node(0, [(s + i, a) for i, a in enumerate(chunks[s:s + per])], min(n, s + per)))
+                index_addr = f.tell()
+                f.write(self._chunk_node(1, leaves, n))
+        eof = f.tell()
+        # ---- metadata ----------------------------------------------------------------------------------------------------
+        f.seek(0)
+        sb = SIGNATURE + struct.pack("<BBBBBBBB", 0, 0, 0, 0, 0, 8, 8, 0) + struct.pack("<HHI", GROUP_LEAF_K, GROUP_INTERNAL_K, 0)
+        sb += struct.pack("<QQQQ", 0, UNDEF, eof, UNDEF)
+        sb += struct.pack("<QQII", 0, self.addr_root, 1, 0) + struct.pack("<QQ", self.addr_btree, self.addr_heap)      # root symbol table entry
+        assert len(sb) == 96
+        f.write(sb)
+        f.write(_object_header([_message(0x0011, struct.pack("<QQ", self.addr_btree, self.addr_heap))]))
+        name_off = 8
+        node = b"TREE" + struct.pack("<BBH", 0, 0, 1) + struct.pack("<QQ", UNDEF, UNDEF) + struct.pack("<QQQ", 0, self.addr_snod, name_off)
+        f.write(node + b"\0" * (self.group_btree_size - len(node)))
+        name = self.name.encode() + b"\0"
+        seg = b"\0" * 8 + _pad8(name)                              # offset 0: the empty name of the root; offset 8: the dataset's
+        free_off = len(seg)
+        if free_off + 16 > self.heap_data_size:
+            raise ValueError("dataset name too long for the heap segment")
+        seg += struct.pack("<QQ", 1, self.heap_data_size - free_off)      # one free block: next = 1 (none), its size
+        f.write(b"HEAP" + struct.pack("<B3x", 0) + struct.pack("<QQQ", self.heap_data_size, free_off, self.addr_heap_data))
+        f.write(seg + b"\0" * (self.heap_data_size - len(seg)))
+        f.seek(self.addr_snod)
+        snod = b"SNOD" + struct.pack("<BBH", 1, 0, 1) + struct.pack("<QQII16x", name_off, self.addr_dset, 0, 0)
+        f.write(snod + b"\0" * (self.snod_size - len(snod)))
+        hdr = self._dataset_header(self.rows, index_addr)
+        assert len(hdr) == self.dset_header_size
+        f.write(hdr)
+        f.close()
+        self.f = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+
+class H5FeatureReader:
+    """Walks the file the way the specification describes it: superblock -> root symbol-table entry -> group B-tree / local heap
+    -> symbol node -> dataset object header (dataspace, datatype, layout) -> chunk B-tree -> raw chunks."""
+
+    def __init__(self, path: str, name: str = "dataset"):
+        self.f = open(path, "rb")
+        self.info = {}
+        self._parse(name)
+
+    def _at(self, addr: int, n: int) -> bytes:
+        self.f.seek(addr)
+        b = self.f.read(n)
+        if len(b) != n:
+            raise ValueError(f"truncated file: {n} bytes at {addr}")
+        return b
+
+    def _parse(self, name: str) -> None:
+        sb = self._at(0, 96)
+        if sb[:8] != SIGNATURE:
+            raise ValueError("not an HDF5 file")
+        ver, _fs, _rg, _r, _sh, so, sl = struct.unpack("<BBBBBBB", sb[8:15])
+        if ver != 0 or so != 8 or sl != 8:
+            raise ValueError("this reader handles version-0 superblocks with 8-byte offsets / lengths")
+        leaf_k, int_k = struct.unpack("<HH", sb[16:20])
+        base, _free, eof, _drv = struct.unpack("<QQQQ", sb[24:56])
+        _lno, root_hdr, cache, _res = struct.unpack("<QQII", sb[56:80])
+        btree, heap = struct.unpack("<QQ", sb[80:96])
+        self.info.update(superblock_version=ver, group_leaf_k=leaf_k, group_internal_k=int_k, eof=eof, root_header=root_hdr)
+        if cache != 1:                                       # not cached: take B-tree / heap from the root header's symbol-table message
+            btree, heap = self._symbol_table_message(root_hdr)
+        elif self._symbol_table_message(root_hdr) != (btree, heap):
+            raise ValueError("root symbol-table entry cache disagrees with the root object header")
+        # local heap
+        hp = self._at(heap, 32)
+        if hp[:4] != b"HEAP":
+            raise ValueError("bad local heap signature")
+        seg_size, free_head, seg_addr = struct.unpack("<QQQ", hp[8:32])
+        heap_data = self._at(seg_addr, seg_size)
+        self.info.update(heap_segment=seg_size, heap_free_head=free_head)
+
+        def heap_str(off):
+            end = heap_data.index(b"\0", off)
+            return heap_data[off:end].decode()
+        # group B-tree (leaf level only is needed for one dataset, but follow levels generically)
+        target = None
+        stack = [btree]
+        while stack:
+            node = stack.pop()
+            hd = self._at(node, 24)
+            if hd[:4] != b"TREE" or hd[4] != 0:
+                raise ValueError("bad group B-tree node")
+            level, used = hd[5], struct.unpack("<H", hd[6:8])[0]
+            body = self._at(node + 24, (2 * used + 1) * 8)
+            children = [struct.unpack("<Q", body[8 + 16 * i:16 + 16 * i])[0] for i in range(used)]
+            if level > 0:
+                stack.extend(children)
+                continue
+            for sn in children:
+                sh = self._at(sn, 8)
+                if sh[:4] != b"SNOD":
+                    raise ValueError("bad symbol table node")
+                nsym = struct.unpack("<H", sh[6:8])[0]
+                for i in range(nsym):
+                    e = self._at(sn + 8 + 40 * i, 40)
+                    noff, ohdr = struct.unpack("<QQ", e[:16])
+                    if heap_str(noff) == name:
+                        target = ohdr
+        if target is None:
+            raise KeyError(name)
+        self.info["dataset_header"] = target
+        msgs = self._messages(target)
+        sp = msgs[0x0001]
+        sver, rank, flags = sp[0], sp[1], sp[2]
+        if sver != 1 or rank != 2:
+            raise ValueError("expected a version-1 rank-2 dataspace")
+        dims = struct.unpack("<QQ", sp[8:24])
+        maxdims = struct.unpack("<QQ", sp[24:40]) if flags & 1 else dims
+        dt = msgs[0x0003]
+        cls, ver_dt = dt[0] & 0x0F, dt[0] >> 4
+        size = struct.unpack("<I", dt[4:8])[0]
+        boff, prec, eloc, esz, mloc, msz, bias = struct.unpack("<HHBBBBI", dt[8:20])
+        if not (cls == 1 and size == 4 and (dt[1] & 1) == 0 and prec == 32 and eloc == 23 and esz == 8 and mloc == 0 and msz == 23 and bias == 127 and dt[2] == 31):
+            raise ValueError("dataset is not little-endian IEEE float32")
+        lay = msgs[0x0008]
+        if lay[0] != 3 or lay[1] != 2:
+            raise ValueError("expected a version-3 chunked layout")
+        ndim = lay[2]
+        index = struct.unpack("<Q", lay[3:11])[0]
+        cdims = struct.unpack("<" + "I" * ndim, lay[11:11 + 4 * ndim])
+        if ndim != 3 or cdims[2] != 4 or cdims[1] != dims[1]:
+            raise ValueError(f"unsupported chunk shape {cdims}")
+        self.shape = (int(dims[0]), int(dims[1]))
+        self.maxshape = (None if maxdims[0] == UNDEF else int(maxdims[0]), int(maxdims[1]))
+        self.chunk_rows = int(cdims[0])
+        self.info.update(datatype_version=ver_dt, fill=tuple(msgs[0x0005][:4]) if 0x0005 in msgs else None, chunk_dims=cdims, index=index)
+        # chunk index
+        self.chunks = {}
+        if index != UNDEF:
+            self._walk_chunks(index)
+        need = (self.shape[0] + self.chunk_rows - 1) // self.chunk_rows
+        missing = [c for c in range(need) if c * self.chunk_rows not in self.chunks]
+        if missing:
+            raise ValueError(f"chunks missing from the index: {missing[:5]}")
+
+    def _symbol_table_message(self, hdr: int):
+        m = self._messages(hdr)
+        return struct.unpack("<QQ", m[0x0011][:16])
+
+    def _messages(self, addr: int) -> dict:
+        ver, _r, nmsg, _ref, size = struct.unpack("<BBHII", self._at(addr, 12))
+        if ver != 1:
+            raise ValueError("expected a version-1 object header")
+        body = self._at(addr + 16, size)
+        out, off = {}, 0
+        for _ in range(nmsg):
+            mtype, msize, _flags = struct.unpack("<HHB", body[off:off + 5])
+            out[mtype] = body[off + 8:off + 8 + msize]
+            off += 8 + msize
+        return out
+
+    def _walk_chunks(self, node: int) -> None:
+        hd = self._at(node, 24)
+        if hd[:4] != b"TREE" or hd[4] != 1:
+            raise ValueError("bad chunk B-tree node")
+        level, used = hd[5], struct.unpack("<H", hd[6:8])[0]
+        body = self._at(node + 24, used * 40 + 32)
+        for i in range(used):
+            key = body[40 * i:40 * i + 32]
+            size, mask = struct.unpack("<II", key[:8])
+            r0, c0, _e = struct.unpack("<QQQ", key[8:32])
+            child = struct.unpack("<Q", body[40 * i + 32:40 * i + 40])[0]
+            if level > 0:
+                self._walk_chunks(child)
+            else:
+                if mask != 0 or c0 != 0 or size != self.chunk_rows * self.shape[1] * 4:
+                    raise ValueError("filtered / partial chunks are not supported")
+                self.chunks[int(r0)] = child
+
+    def rows(self, a: int, b: int) -> np.ndarray:
+        if not (0 <= a <= b <= self.shape[0]):
+            raise IndexError("index error!")
+        out = np.empty((b - a, self.shape[1]), np.float32)
+        r = a
+        while r < b:
+            c0 = r // self.chunk_rows * self.chunk_rows
+            n = min(b, c0 + self.chunk_rows) - r
+            raw = self._at(self.chunks[c0] + (r - c0) * self.shape[1] * 4, n * self.shape[1] * 4)
+            out[r - a:r - a + n] = np.frombuffer(raw, "<f4").reshape(n, self.shape[1])
+            r += n
+        return out
+
+    def __getitem__(self, i: int) -> np.ndarray:
+        i = int(i)
+        if i < 0:
+            i += self.shape[0]
+        return self.rows(i, i + 1)[0]
+
+    def __len__(self):
+        return self.shape[0]
+
+    def close(self):
+        self.f.close()
