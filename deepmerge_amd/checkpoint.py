@@ -5,7 +5,9 @@
 `net` keys / shapes / dtypes are those of the reference modules (parity-tested manifests), so a reference `.pth`
 loads into the drop-in modules unchanged.  The optimizer entry is `torch.optim.Adam.state_dict()` layout over
 `filter(requires_grad, net.parameters())` (Train_SMT.py:192-193); PairTrainer keeps Adam's moments in flat buffers,
-and this module converts both ways.
+and this module converts both ways.  Entries exist only for parameters that have received a gradient, like upstream.
+Known difference: the fused Adam keeps ONE step count, so a parameter whose first gradient arrives late (after un-freezing,
+say) is bias-corrected with the global step rather than its own; the reference's train() never does that.
 """
 from __future__ import annotations
 
@@ -30,6 +32,11 @@ def optimizer_state_dict(trainer) -> Dict[str, Any]:
     if trainer.step_count > 0:
         for i, p in enumerate(params):
             o, n = where[id(p)], p.numel()
+            # torch.optim.Adam creates a parameter's state lazily, at its first step WITH a gradient: parameters that never
+            # receive one (final_features.*, head.* on the designed-feature path) have no entry upstream.  Here their moments are
+            # exactly zero forever (zero gradient in, zero out), which is how they are recognised.
+            if not bool(trainer.v[o:o + n].any()) and not bool(trainer.m[o:o + n].any()):
+                continue
             state[i] = {"step": torch.tensor(float(trainer.step_count)),
                         "exp_avg": trainer.m[o:o + n].view_as(p).detach().clone().cpu(),
                         "exp_avg_sq": trainer.v[o:o + n].view_as(p).detach().clone().cpu()}

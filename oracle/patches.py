@@ -17,7 +17,13 @@ fixes its output.  This build therefore DEFINES the resize as the ex
 where, in units of 1/t of an input pixel, input pixel i covers [i*t, (i+1)*t) and output pixel o covers
 [o*L, (o+1)*L); ov = length of the intersection (an integer), so sum_i ov(o, i) = L.  The same rule is used for
 L > t (box filter, the case INTER_AREA is meant for), L == t (identity) and L < t (a footprint inside one or two
-input pixels).  Everything is integer arithmetic, hence bit-exact between this oracle and the GPU kernel
+input pixels).  KNOWN DIFFERENCES from OpenCV's uint8 INTER_AREA, as far as its published algorithm goes (cv::resize,
+imgproc/resize.cpp): (1) the exact 2x reduction rounds half UP there ((a+b+c+d+2)>>2), other integer ratios multiply an integer
+sum by a float reciprocal and round half to even, non-integer ratios accumulate float weights -- so ties and near-ties can differ by
+one LSB from the exact rational rounding used here; (2) for L < t (enlarging) OpenCV does not area-average at all: it switches to a
+bilinear interpolation with area-style coordinates, which this spec does not imitate.  Windows with L < t occur (inner ~ 16..31 px
+into the 32 px target); a checkpoint trained on OpenCV-made patches therefore sees slightly different inputs for those windows.
+Pinned by the reference itself: L == t (identity) and everything AROUND the resize -- tests/golden/sweep.npz.  Everything is integer arithmetic, hence bit-exact between this oracle and the GPU kernel
 (dm_patch_pyramid).  Everything else above (windows, truncation, clipping, zero padding, /255) is restated 1:1.
 """
 from __future__ import annotations

@@ -52,6 +52,12 @@ def test_optimizer_state_round_trips_through_torch_adam(tmp_path):
     assert torch.equal(tr2.m[o:o + 35], opt.state[net2.a.weight]["exp_avg"].reshape(-1))
     o = where2[id(net2.b.weight)]
     assert float(tr2.m[o:o + 21].abs().max()) == 0.0
+    # ... and writing it out again gives torch's own key set back: no entries for the parameters that never had a gradient
+    again = ck.optimizer_state_dict(tr2)
+    assert sorted(again["state"].keys()) == sorted(opt.state_dict()["state"].keys()) == [0, 1]
+    for i in (0, 1):
+        assert torch.equal(again["state"][i]["exp_avg"], opt.state_dict()["state"][i]["exp_avg"])
+        assert float(again["state"][i]["step"]) == float(opt.state_dict()["state"][i]["step"]) == 2.0
 
 
 def test_checkpoint_dict_keys_and_reload(tmp_path):
