@@ -7,6 +7,8 @@ from collections import defaultdict
 
 def bench_name(k):
     """rocprof kernel name -> in-library profiler row name (None: not a profiled kernel)."""
+    if "gemm_ring_kernel" in k:
+        return "gemm_bf16_NT"
     m = re.search(r"gemm256_kernel<(\d)>", k) or re.search(r"gemm256_kernelILi(\d)E", k)
     if m:
         return "gemm_bf16_" + ("NT", "NN", "TN")[int(m.group(1))]
