@@ -33,7 +33,8 @@ constexpr int T256 = 256;                 // workgroup tile (rows and columns)
 constexpr int BK256 = 64;                 // K per tile
 constexpr int OPER_BYTES = T256 * 128;    // one operand's image of a K tile: 256 rows x 128 B
 constexpr int BUF_BYTES = 2 * OPER_BYTES; // A image + B image
-constexpr int LDS256 = 2 * BUF_BYTES;     // two K-tile buffers = 128 KiB
+constexpr int EPI256 = 8 * 64 * DM_EPI_PITCH;   // whole-line epilogue staging: 64 rows x 272 B per wave
+constexpr int LDS256 = (2 * BUF_BYTES > EPI256) ? 2 * BUF_BYTES : EPI256;     // two K-tile buffers = 128 KiB; staging 136 KiB
 
 // image row of the B operand -> column of the tile.  Image rows are ordered [sub][wave column][32] so that the
 // columns the waves read in the same phase are contiguous pieces (see the hazard table above).
@@ -283,6 +284,23 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
         if (m < p.M) row[m] = accb[i][0];
       }
     }
+  }
+  // whole-line epilogue (dm_gemm_common.h): every wave transposes its 128 x 64 block through a private LDS region.  N % 8 != 0
+  // (only possible for fp32 outputs here) keeps the 4-column form.
+  const bool rows_ok = (p.N % 8 == 0) && (p.ldc % 8 == 0) && (p.aux == nullptr || p.ldaux % 8 == 0) && (p.rows_per_group == 0 || p.group_stride % 8 == 0);
+  if (rows_ok) {
+    __builtin_amdgcn_s_barrier();               // every wave is done reading the K-tile buffers
+    char *mine = smem + wave * (64 * DM_EPI_PITCH);
+    if (p.split_k > 1) {                        // K slice: fp32 partial tile into the slab, summed in slice order by splitk_reduce_kernel
+      GemmParams q = p;
+      q.C = p.workspace + (long long)z * p.M * p.N;
+      q.ldc = p.N; q.c_dtype = DM_F32; q.bias = nullptr; q.residual = nullptr; q.aux = nullptr; q.epilogue = DM_EPI_NONE;
+      q.accumulate = 0; q.rows_per_group = 0;
+      dm_epilogue_rows<8, 64>(q, acc, mine, m0 + wr * 128, n0 + wc * 64, lane);
+    } else {
+      dm_epilogue_rows<8, 64>(p, acc, mine, m0 + wr * 128, n0 + wc * 64, lane);
+    }
+    return;
   }
   if (p.split_k > 1) {          // K slice: fp32 partial tile into the slab, summed in slice order by splitk_reduce_kernel
     float *W = p.workspace + (long long)z * p.M * p.N;

@@ -35,7 +35,6 @@ namespace dmring {
 
 constexpr int BK = 64;
 constexpr int BN = 128;
-constexpr int EPI_PITCH = 272;      // bytes per staged row: 64 fp32 + 16 B pad (ds_write_b128 of 8 consecutive lanes: 8 distinct slots)
 
 template <int WM> struct Cfg {
   static constexpr int BM = 2 * WM * 16;
@@ -44,7 +43,7 @@ template <int WM> struct Cfg {
   static constexpr int B_OFF = 2 * A_BYTES;
   static constexpr int RING = 2 * A_BYTES + B_BYTES;        // 80 KiB (WM = 8) / 48 KiB (WM = 4)
   static constexpr int EPI_ROWS = WM * 8;                    // rows staged per pass and wave
-  static constexpr int EPI = 4 * EPI_ROWS * EPI_PITCH;
+  static constexpr int EPI = 4 * EPI_ROWS * DM_EPI_PITCH;
   static constexpr int LDS = RING > EPI ? RING : EPI;
   static constexpr int NA = BM / 32;                         // A pieces (8 rows each) per wave and K tile
   static constexpr int NB = BN / 32;
@@ -52,62 +51,6 @@ template <int WM> struct Cfg {
 
 #define DM_RING_DMA(rsrc, dst, voff, soff) \
   __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void *)(dst), 16, voff, soff, 0, 0)
-
-// 8 consecutive outputs of row (rb) starting at column n through the fused epilogue (same semantics as dm_gemm_emit).
-__device__ __forceinline__ void emit8(const GemmParams &p, f32x4 lo, f32x4 hi, const DmGemmRow &rb, int n) {
-  if (p.bias) { lo += dm_load4(p.bias + n); hi += dm_load4(p.bias + n + 4); }
-  if (p.epilogue == DM_EPI_GELU) {
-    if (p.aux) {
-      if (p.aux_dtype == DM_F32) { dm_store4(reinterpret_cast<float *>(p.aux) + rb.x + n, lo); dm_store4(reinterpret_cast<float *>(p.aux) + rb.x + n + 4, hi); }
-      else {
-        bf16x8 o = {(bf16_t)lo[0], (bf16_t)lo[1], (bf16_t)lo[2], (bf16_t)lo[3], (bf16_t)hi[0], (bf16_t)hi[1], (bf16_t)hi[2], (bf16_t)hi[3]};
-        *reinterpret_cast<bf16x8 *>(reinterpret_cast<bf16_t *>(p.aux) + rb.x + n) = o;
-      }
-    }
-#pragma unroll
-    for (int e = 0; e < 4; ++e) { lo[e] = dm_gelu_fast(lo[e]); hi[e] = dm_gelu_fast(hi[e]); }
-  } else if (p.epilogue == DM_EPI_GELU_GRAD) {
-    f32x4 dl, dh;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      float cdf, pdf;
-      dm_gelu_parts_fast(lo[e], cdf, pdf);
-      dl[e] = fmaf(lo[e], pdf, cdf);
-      lo[e] = lo[e] * cdf;
-      dm_gelu_parts_fast(hi[e], cdf, pdf);
-      dh[e] = fmaf(hi[e], pdf, cdf);
-      hi[e] = hi[e] * cdf;
-    }
-    if (p.aux_dtype == DM_F32) { dm_store4(reinterpret_cast<float *>(p.aux) + rb.x + n, dl); dm_store4(reinterpret_cast<float *>(p.aux) + rb.x + n + 4, dh); }
-    else {
-      bf16x8 o = {(bf16_t)dl[0], (bf16_t)dl[1], (bf16_t)dl[2], (bf16_t)dl[3], (bf16_t)dh[0], (bf16_t)dh[1], (bf16_t)dh[2], (bf16_t)dh[3]};
-      *reinterpret_cast<bf16x8 *>(reinterpret_cast<bf16_t *>(p.aux) + rb.x + n) = o;
-    }
-  } else if (p.epilogue == DM_EPI_DGELU || p.epilogue == DM_EPI_MUL) {
-    f32x4 ul, uh;
-    if (p.aux_dtype == DM_F32) { ul = dm_load4(reinterpret_cast<const float *>(p.aux) + rb.x + n); uh = dm_load4(reinterpret_cast<const float *>(p.aux) + rb.x + n + 4); }
-    else {
-      const bf16x8 u = *reinterpret_cast<const bf16x8 *>(reinterpret_cast<const bf16_t *>(p.aux) + rb.x + n);
-      ul = (f32x4){(float)u[0], (float)u[1], (float)u[2], (float)u[3]};
-      uh = (f32x4){(float)u[4], (float)u[5], (float)u[6], (float)u[7]};
-    }
-    if (p.epilogue == DM_EPI_MUL) { lo *= ul; hi *= uh; }
-    else {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) { lo[e] *= dm_dgelu_fast(ul[e]); hi[e] *= dm_dgelu_fast(uh[e]); }
-    }
-  }
-  if (p.residual) { lo += dm_load4(p.residual + rb.r + n); hi += dm_load4(p.residual + rb.r + n + 4); }
-  if (p.c_dtype == DM_F32) {
-    float *c = reinterpret_cast<float *>(p.C) + rb.c + n;
-    if (p.accumulate) { lo += dm_load4(c); hi += dm_load4(c + 4); }
-    dm_store4(c, lo);
-    dm_store4(c + 4, hi);
-  } else {
-    bf16x8 o = {(bf16_t)lo[0], (bf16_t)lo[1], (bf16_t)lo[2], (bf16_t)lo[3], (bf16_t)hi[0], (bf16_t)hi[1], (bf16_t)hi[2], (bf16_t)hi[3]};
-    *reinterpret_cast<bf16x8 *>(reinterpret_cast<bf16_t *>(p.C) + rb.c + n) = o;
-  }
-}
 
 template <int WM, int DBG = 0>
 __global__ __launch_bounds__(256, 2) void gemm_ring_kernel(const GemmParams p) {
@@ -214,30 +157,8 @@ __global__ __launch_bounds__(256, 2) void gemm_ring_kernel(const GemmParams p) {
 
   // ---- epilogue: transpose through a wave-private LDS region, then whole-line row accesses ---------------------
   __builtin_amdgcn_s_barrier();                       // every wave is done with the ring
-  char *mine = smem + wave * (C::EPI_ROWS * EPI_PITCH);
-  constexpr int PASS_TILES = C::EPI_ROWS / 16;        // m-tiles per pass
-#pragma unroll
-  for (int ps = 0; ps < WM / PASS_TILES; ++ps) {
-#pragma unroll
-    for (int ii = 0; ii < PASS_TILES; ++ii)
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        *reinterpret_cast<f32x4 *>(mine + (ii * 16 + li) * EPI_PITCH + (j * 16 + 4 * g) * 4) = acc[ps * PASS_TILES + ii][j];
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-    const int n = n0 + wc * 64 + (lane & 7) * 8;
-#pragma unroll
-    for (int r = 0; r < C::EPI_ROWS / 8; ++r) {
-      const int row = r * 8 + (lane >> 3);
-      const int m = m0 + wr * (WM * 16) + ps * C::EPI_ROWS + row;
-      const f32x4 lo = *reinterpret_cast<const f32x4 *>(mine + row * EPI_PITCH + (lane & 7) * 32);
-      const f32x4 hi = *reinterpret_cast<const f32x4 *>(mine + row * EPI_PITCH + (lane & 7) * 32 + 16);
-      if constexpr ((DBG & 8) != 0) { if (lo[0] == 12345.678f && m < p.M) emit8(p, lo, hi, dm_gemm_row(p, m), n); }
-      else if (m < p.M && n < p.N) emit8(p, lo, hi, dm_gemm_row(p, m), n);
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the next pass overwrites the region
-    __builtin_amdgcn_sched_barrier(0);
-  }
+  char *mine = smem + wave * (C::EPI_ROWS * DM_EPI_PITCH);
+  dm_epilogue_rows<WM, C::EPI_ROWS, (DBG & 8) != 0>(p, acc, mine, m0 + wr * (WM * 16), n0 + wc * 64, lane);
 }
 
 template <int WM> bool set_lds_limit() {

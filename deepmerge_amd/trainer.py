@@ -228,6 +228,15 @@ class PairTrainer:
         self._graph = {"warmup": warmup, "g": None}
         self._graph_warm = 0
 
+    def graph_inputs(self):
+        """The static input tensors of the captured step, (left list, left_designed, right list, right_designed, flag), or None
+        before capture.  A data pipeline that writes the next batch straight into them (e.g. the patch gather kernels) and then
+        calls step() with these very tensors skips the per-step device-to-device input copies."""
+        st = self._graph
+        if not st or st.get("g") is None:
+            return None
+        return st["left"], st["ld"], st["right"], st["rd"], st["flag"]
+
     def _static_inputs(self, st, left, left_designed, right, right_designed, flag):
         # models that take the two sides pre-stacked ([left; right] along the batch) get static buffers of that form, so
         # the step's inputs are copied once and the captured graph holds no torch.cat
@@ -316,12 +325,15 @@ class PairTrainer:
             # capture only records: nothing above has executed yet, the replay below is this step
         if [tuple(t.shape) for t in list(left) + list(right)] != st["shapes"]:
             raise ValueError("graph replay needs the input shapes it was captured with; call enable_graph() again for a new batch size")
+        def put(dst, src):                                    # a loader that fills graph_inputs() directly pays no copy
+            if src is not dst and (src.data_ptr() != dst.data_ptr() or src.dtype != dst.dtype):
+                dst.copy_(src, non_blocking=True)
         for dst, src in zip(st["left"] + st["right"], list(left) + list(right)):
-            dst.copy_(src, non_blocking=True)
+            put(dst, src)
         if st["ld"] is not None:
-            st["ld"].copy_(left_designed, non_blocking=True)
-            st["rd"].copy_(right_designed, non_blocking=True)
-        st["flag"].copy_(flag, non_blocking=True)
+            put(st["ld"], left_designed)
+            put(st["rd"], right_designed)
+        put(st["flag"], flag)
         self.step_count += 1
         st["hyper"].copy_(ops.adam_hyper(self.step_count, self.lr if lr is None else lr, self.betas[0], self.betas[1]), non_blocking=True)
         if self.world == 1 and not self.segmented:

@@ -341,6 +341,13 @@ def test_graph_replayed_step_equals_eager_step(mode):
         lg = graphed.step(*b, lr=None)
         assert float(le) == float(lg), f"step {i}: loss {float(le)} vs {float(lg)}"
     assert graphed._graph["g"] is not None and graphed.step_count == eager.step_count == 5
+    # zero-copy inputs: write a batch straight into the static tensors and step with those very tensors
+    gl, gld, gr, grd, gf = graphed.graph_inputs()
+    b = batches[2]
+    for dst, src in zip(gl + gr, b[0] + b[2]):
+        dst.copy_(src)
+    gld.copy_(b[1]); grd.copy_(b[3]); gf.copy_(b[4])
+    assert float(eager.step(*b)) == float(graphed.step(gl, gld, gr, grd, gf))
     assert torch.equal(eager.fp.flat, graphed.fp.flat)
     assert torch.equal(eager.m, graphed.m) and torch.equal(eager.v, graphed.v)
     with pytest.raises(ValueError):
