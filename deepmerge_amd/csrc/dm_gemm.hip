@@ -329,11 +329,29 @@ __global__ __launch_bounds__(NTHREADS, (TM == 4 ? WG_PER_CU : 4)) void gemm_kern
   }
 }
 
-// out[i] = (accumulate ? out[i] : 0) + sum_s slab[s][i], slices summed in index order.
+// out[i] = (accumulate ? out[i] : 0) + sum_s slab[s][i], slices summed in index order.  Workgroups past `main_blocks` fold the
+// pipeline's partial column sums of A (cs_rows [cs_R][cs_M] -> cs_out, rows in index order) in the same launch: the bias
+// gradient that rides on a weight gradient used to cost a launch of its own (19 per step).
 __global__ void splitk_reduce_kernel(const float *__restrict__ slab, float *__restrict__ out, long long ldc,
-                                     int M, int N, int S, int accumulate) {
+                                     int M, int N, int S, int accumulate, int main_blocks, const float *__restrict__ cs_rows,
+                                     float *__restrict__ cs_out, int cs_M, int cs_R, int cs_accumulate) {
+  if ((int)blockIdx.x >= main_blocks) {
+    const int m = ((int)blockIdx.x - main_blocks) * blockDim.x + threadIdx.x;
+    if (m >= cs_M) return;
+    float s0 = cs_accumulate ? cs_out[m] : 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int r = 0;
+    for (; r + 3 < cs_R; r += 4) {
+      s0 += cs_rows[(long long)r * cs_M + m];
+      s1 += cs_rows[(long long)(r + 1) * cs_M + m];
+      s2 += cs_rows[(long long)(r + 2) * cs_M + m];
+      s3 += cs_rows[(long long)(r + 3) * cs_M + m];
+    }
+    for (; r < cs_R; ++r) s0 += cs_rows[(long long)r * cs_M + m];
+    cs_out[m] = (s0 + s1) + (s2 + s3);
+    return;
+  }
   const long long n4 = (long long)M * N / 4;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)main_blocks * blockDim.x) {
     const long long e = i * 4;
     const int m = (int)(e / N), n = (int)(e % N);
     float *o = out + (long long)m * ldc + n;
@@ -626,9 +644,13 @@ extern "C" int dm_gemm(const DmGemmArgs *a, void *stream) {
     const long long n4 = (long long)a->M * a->N / 4;
     const long long want = (n4 + 255) / 256;
     const int rgrid = (int)(want < 2048 ? want : 2048);
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(rgrid), dim3(256), 0, s, p.workspace,
-                       reinterpret_cast<float *>(a->C), (long long)a->ldc, a->M, a->N, split, a->accumulate);
+    const bool fold_cs = a->colsum_a && big;          // the pipeline's [split * 4][M] partial column sums ride along
+    const int cs_blocks = fold_cs ? (a->M + 255) / 256 : 0;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(rgrid + cs_blocks), dim3(256), 0, s, p.workspace,
+                       reinterpret_cast<float *>(a->C), (long long)a->ldc, a->M, a->N, split, a->accumulate, rgrid,
+                       fold_cs ? cs_region : nullptr, fold_cs ? a->colsum_a : nullptr, a->M, split * 4, a->colsum_accumulate);
     DM_LAUNCH_CHECK("dm_gemm(split-k reduce)");
+    if (fold_cs) return DM_OK;
   }
   if (a->colsum_a) {
     if (big) {      // fold the pipeline's [split * 4][M] partial rows, in row order

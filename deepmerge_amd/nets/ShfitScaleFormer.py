@@ -57,16 +57,20 @@ class PatchEmbed(nn.Module):
         self.norm = norm_layer(out_c) if norm_layer else nn.Identity()
         self.numerics = _mode(numerics)
 
-    def forward(self, x):
+    def operand_rows(self, x):
+        """The patch-embed GEMM's A rows [B * num_patches, in_c * p * p] of an image batch (or of pre-gathered ops.PatchCols)."""
         B, C, H, W = x.shape
         assert H == self.img_size[0] and W == self.img_size[1], \
             f"Input image size ({H}*{W}) doesn't match model ({self.img_size[0]}*{self.img_size[1]})."
         if isinstance(x, ops.PatchCols):          # operand rows gathered straight from a tile (patches.point_batch_cols)
             if x.patch != self.patch_size[0] or x.cols.dtype != ops.act_dtype(self.numerics):
                 raise ValueError("PatchCols were built for another patch size / numerics mode")
-            cols = x.cols
-        else:
-            cols = ops.patchify(x.float(), self.patch_size[0], ops.act_dtype(self.numerics))
+            return x.cols
+        return ops.patchify(x.float(), self.patch_size[0], ops.act_dtype(self.numerics))
+
+    def forward(self, x):
+        B = x.shape[0]
+        cols = self.operand_rows(x)
         y = ops.LinearFn.apply(cols, self.proj.weight, self.proj.bias, None, torch.float32)
         return self.norm(y.view(B, self.num_patches, -1))
 
@@ -260,7 +264,12 @@ class ShfitScaleFormer_v3(nn.Module):
 
     # -- pieces (public names as in the reference) ------------------------------------------------
     def patch_embed(self, x: List[torch.Tensor]):
-        return torch.cat([layer(x[i]) for i, layer in enumerate(self.patch_embed_blocks)], 1)
+        layers = list(self.patch_embed_blocks)
+        if not all(type(l) is PatchEmbed and isinstance(l.norm, nn.Identity) and l.num_patches == layers[0].num_patches for l in layers):
+            return torch.cat([layer(x[i]) for i, layer in enumerate(layers)], 1)          # caller-supplied embed class: generic form
+        # every scale's GEMM writes its tokens at their offset of the token cube: no cat (reference :869-882)
+        cols = [l.operand_rows(x[i]) for i, l in enumerate(layers)]
+        return ops.PatchEmbedCatFn.apply(len(layers), layers[0].num_patches, *cols, *[l.proj.weight for l in layers], *[l.proj.bias for l in layers])
 
     def designed_feature_embed(self, x):
         return self.feature_embed(x)

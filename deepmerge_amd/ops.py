@@ -437,6 +437,49 @@ class LinearFn(torch.autograd.Function):
         return dx, dw, db, dres, None
 
 
+class PatchEmbedCatFn(torch.autograd.Function):
+    """`torch.cat([PatchEmbed_i(x_i) for i], dim=1)` (v3.patch_embed, nets/ShfitScaleFormer.py:869-882) without the cat: every
+    scale's patch-embed GEMM writes its 64 tokens per sample straight into the token cube [B, S * T, C] through the GEMM's
+    grouped-row addressing (rows_per_group = T, group_stride = S * T * C).  Arguments: n_scales, tokens per scale, then the S
+    operand-row matrices cols_i [B * T, K_i], the S weights [C, K_i...] and the S biases."""
+
+    @staticmethod
+    def forward(ctx, S, T, *args):
+        cols, weights, biases = args[:S], args[S:2 * S], args[2 * S:3 * S]
+        B = cols[0].shape[0] // T
+        Cc = weights[0].shape[0]
+        cube = torch.empty((B, S * T, Cc), dtype=torch.float32, device=cols[0].device)
+        flat = cube.view(-1)
+        ws = []
+        for i in range(S):
+            c = cols[i].contiguous()
+            K = c.shape[1]
+            w = lp_weight(weights[i], c.dtype, (Cc, K))
+            ws.append(w)
+            gemm(DM_NT, c, w, flat[i * T * Cc:], B * T, Cc, K, lda=K, ldb=K, ldc=Cc, bias=biases[i], rows_per_group=T, group_stride=S * T * Cc)
+        ctx.save_for_backward(*cols, *ws)
+        ctx.cfg = (S, T, B, Cc)
+        ctx.params = (weights, biases)
+        return cube
+
+    @staticmethod
+    def backward(ctx, dcube):
+        S, T, B, Cc = ctx.cfg
+        saved = ctx.saved_tensors
+        cols, ws = saved[:S], saved[S:]
+        weights, biases = ctx.params
+        grads_w, grads_b = [], []
+        for i in range(S):
+            c = cols[i]
+            K = c.shape[1]
+            dy = dcube[:, i * T:(i + 1) * T, :].to(c.dtype).reshape(B * T, Cc)      # one strided cast-copy
+            need_w, need_b = ctx.needs_input_grad[2 + S + i], ctx.needs_input_grad[2 + 2 * S + i]
+            _, dw, db = _linear_backward(c, ws[i], dy, False, need_w, need_b and biases[i] is not None, weights[i].shape, weights[i], biases[i])
+            grads_w.append(dw)
+            grads_b.append(db)
+        return (None, None) + (None,) * S + tuple(grads_w) + tuple(grads_b)
+
+
 class MlpFn(torch.autograd.Function):
     """y = fc2(GELU_erf(fc1(x))) [+ residual]  (Mlp, nets/ShfitScaleFormer.py:52-58; also the
     proj0 -> GELU -> proj1 head of FeatureEmbed, :76-78).  GELU is fused into fc1's epilogue and its
