@@ -183,6 +183,13 @@ def main():
                          "the bucket all-reduces are launched eagerly between them)")
     args = ap.parse_args()
 
+    # Exactly ONE line may reach stdout (the JSON result of rank 0), but native libraries write there too (RCCL prints a
+    # five-line version banner at communicator creation): everything this process prints to file descriptor 1 goes to stderr,
+    # and the result line is written to the saved descriptor at the end.
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))
@@ -197,8 +204,10 @@ def main():
         local_rank = local_rank % max(1, torch.cuda.device_count())     # rehearsal: ranks may share a GPU
     torch.cuda.set_device(local_rank)
     dev = f"cuda:{local_rank}"
-    if world > 1:
+    force_dp = os.environ.get("DM_DP_FORCE") == "1"     # rehearsal: the RCCL code path with one rank on a one-GPU box
+    if world > 1 or force_dp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         if args.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(dev))
         else:
@@ -219,7 +228,7 @@ def main():
     batch = synth_batch(args.pairs, scales, in_c, dev, 1000 + rank)
 
     def sync():
-        if world > 1:
+        if world > 1 or force_dp:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -259,7 +268,7 @@ def main():
         torch.cuda.synchronize()
         lib.dm_prof_enable(0)
     dp = None
-    if world > 1:
+    if world > 1 or force_dp:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -291,7 +300,8 @@ def main():
               "exchange_ms_per_step": round(1e3 * float(tx[1]) / args.steps, 3),
               "compute_only_ms_per_step": round(1e3 * float(tx[0]) / args.steps, 3),
               "exposed_exchange_ms_per_step": round(1e3 * (dt - float(tx[0])) / args.steps, 3),
-              "segmented_backward": bool(trainer.segmented)}
+              "segmented_backward": bool(trainer.segmented), "graph_capture_error": trainer.graph_error,
+              "rehearsal_single_rank": bool(force_dp and world == 1)}
     rows = (_lib.DmProfRow * 256)()
     n = lib.dm_prof_collect(rows, 256)
     prof = {rows[i].name.decode(): (rows[i].launches, rows[i].total_ms, rows[i].total_flops, rows[i].total_bytes) for i in range(n)}
@@ -339,7 +349,8 @@ def main():
                        "pairs_per_gpu": args.pairs, "global_batch": world * args.pairs, "parallelism": f"dp{world}",
                        "gflop_per_pair_step": round(flop_pair / 1e9, 2)},
             "model_tflops_per_gpu": round(value / world * flop_pair / 1e12, 2),
-            "loss": float(loss.item()), "backend": args.backend if world > 1 else None, "hip_graph": bool(use_graph),
+            "loss": float(loss.item()), "backend": args.backend if (world > 1 or force_dp) else None,
+            "hip_graph": bool(use_graph and trainer.graph_error is None),
             "data_parallel": dp,
             "roofline": roof,
         }
@@ -349,8 +360,9 @@ def main():
             out["cpu_baseline"] = None
         if world == 1 and not args.no_extras:
             out["extras"] = extras(args, scales, in_c, depth, dev)
-        print(json.dumps(out), flush=True)
-    if world > 1:
+        sys.stdout.flush()
+        os.write(result_fd, (json.dumps(out) + "\n").encode())
+    if world > 1 or force_dp:
         dist.destroy_process_group()
 
 

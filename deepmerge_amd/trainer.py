@@ -138,20 +138,25 @@ class PairTrainer:
         self.lr, self.betas, self.eps = lr, betas, eps
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
+        # DM_DP_FORCE=1 (rehearsal): run the data-parallel schedule -- segmented backward, bucket all-reduces through the
+        # initialised backend, per-segment graphs -- even with ONE rank, so that a one-GPU box exercises the RCCL calls
+        self.force_dp = os.environ.get("DM_DP_FORCE") == "1" and dist.is_available() and dist.is_initialized()
         self.fp = FlatParams(net, lp_mirror=(getattr(net, "numerics", "bf16") == "bf16"))
         self.m = torch.zeros_like(self.fp.flat)
         self.v = torch.zeros_like(self.fp.flat)
         self.step_count = 0
         self.can_cut = hasattr(net, "_dp_cut")
-        self.segmented = (self.world > 1 and self.can_cut) if segmented is None else (bool(segmented) and self.can_cut)
+        self.dp = self.world > 1 or self.force_dp
+        self.segmented = (self.dp and self.can_cut) if segmented is None else (bool(segmented) and self.can_cut)
         self.n_buckets = max(1, n_buckets)
-        self.bucket_slices = self.fp.buckets(self.n_buckets if self.world > 1 else 1)     # re-derived from the cuts when segmented
+        self.bucket_slices = self.fp.buckets(self.n_buckets if self.dp else 1)     # re-derived from the cuts when segmented
         self._pending = []
         self._graph = None          # captured step (enable_graph)
         self._graph_warm = 0
         self.exchange = True        # False: skip the collectives (bench.py uses it to price the exposed exchange time)
         self.trace = os.environ.get("DM_DP_TRACE") == "1"
         self.stats = {"allreduce_calls": 0, "allreduce_bytes": 0}
+        self.graph_error = None     # set when enable_graph() had to fall back to eager launches
 
     # -- gradient exchange -----------------------------------------------------------------------
     def _log(self, msg):
@@ -163,7 +168,7 @@ class PairTrainer:
 
     def _launch_bucket(self, bi: int):
         sl = self.bucket_slices[bi]
-        if self.world > 1 and self.exchange:
+        if self.dp and self.exchange:
             self._log(f"launch bucket {bi} [{sl.start}:{sl.stop}] ({(sl.stop - sl.start) * 4 / 1e6:.1f} MB)")
             self._pending.append((bi, dist.all_reduce(self.fp.grad[sl], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)))
             self.stats["allreduce_calls"] += 1
@@ -273,17 +278,17 @@ class PairTrainer:
         torch.cuda.synchronize()
         if not self.segmented:
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
                 self.fp.zero_grad()
                 loss = self._forward_loss(st)
                 loss.backward()
-                if self.world == 1:
+                if not self.dp:
                     self._adam_slice(slice(0, self.fp.total), st["hyper"], 1.0)
                 st["loss"] = loss.detach()
             st["pieces"] = [g]
-            if self.world > 1:                       # no cut support: exchange the whole buffer after the one backward graph
+            if self.dp:                              # no cut support: exchange the whole buffer after the one backward graph
                 ga = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(ga, pool=g.pool()):
+                with torch.cuda.graph(ga, pool=g.pool(), capture_error_mode="thread_local"):
                     self._adam_slice(slice(0, self.fp.total), st["hyper"], 1.0 / self.world)
                 st["adam"] = ga
             return
@@ -292,7 +297,7 @@ class PairTrainer:
         pieces = []
         try:
             g0 = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g0):
+            with torch.cuda.graph(g0, capture_error_mode="thread_local"):
                 self.fp.zero_grad()
                 loss = self._forward_loss(st)
                 loss.backward()
@@ -300,11 +305,11 @@ class PairTrainer:
             pieces.append(g0)
             for x, leaf in reversed(cuts.pairs):
                 gk = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(gk, pool=g0.pool()):
+                with torch.cuda.graph(gk, pool=g0.pool(), capture_error_mode="thread_local"):
                     x.backward(leaf.grad)
                 pieces.append(gk)
             ga = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(ga, pool=g0.pool()):
+            with torch.cuda.graph(ga, pool=g0.pool(), capture_error_mode="thread_local"):
                 self._adam_slice(slice(0, self.fp.total), st["hyper"], 1.0 / self.world)
         finally:
             self.net._dp_cut = None
@@ -320,7 +325,17 @@ class PairTrainer:
                 self._graph_warm += 1
                 return self._eager_step(*args, lr)
             self._static_inputs(st, *args)
-            self._capture(st)
+            try:
+                self._capture(st)
+            except Exception as e:                        # e.g. a collective backend whose helper threads break stream capture
+                import sys
+                print(f"[deepmerge_amd] hipGraph capture failed ({type(e).__name__}: {e}); the step stays eager", file=sys.stderr, flush=True)
+                torch.cuda.synchronize()
+                if getattr(self.net, "_dp_cut", None) is not None:
+                    self.net._dp_cut = None
+                self._graph = None
+                self.graph_error = f"{type(e).__name__}: {e}"
+                return self._eager_step(*args, lr)
             st["g"] = True
             # capture only records: nothing above has executed yet, the replay below is this step
         if [tuple(t.shape) for t in list(left) + list(right)] != st["shapes"]:
@@ -336,7 +351,7 @@ class PairTrainer:
         put(st["flag"], flag)
         self.step_count += 1
         st["hyper"].copy_(ops.adam_hyper(self.step_count, self.lr if lr is None else lr, self.betas[0], self.betas[1]), non_blocking=True)
-        if self.world == 1 and not self.segmented:
+        if not self.dp and not self.segmented:
             st["pieces"][0].replay()                     # Adam is inside the one graph
             return st["loss"]
         if not self.segmented:                       # one backward graph, then the bucketed exchange of the whole buffer
@@ -387,7 +402,7 @@ class PairTrainer:
                 self._launch_ready(piece)
         else:
             loss.backward()
-            if self.world > 1:
+            if self.dp:
                 for bi in range(len(self.bucket_slices)):
                     self._launch_bucket(bi)
         self._wait_exchange()
