@@ -115,3 +115,77 @@ def test_two_ranks_segmented_graphs(tmp_path):
     keep = torch.ones_like(g, dtype=torch.bool); keep[o:o + pb.numel()] = False
     assert float(((got["grad"] - g).abs() * keep).max()) <= 5e-5 * scale
     assert float((got["flat"] - tr.fp.flat.cpu()).abs().max()) <= 6.5e-4      # <= 3 Adam steps of +-lr where the gradient is rounding noise
+
+
+def _v4_build():
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import recipe
+    from deepmerge_amd.nets.ShfitScaleFormer import ShfitScaleFormer_v4
+    net = ShfitScaleFormer_v4(cube_size=[8, 8], input_image_scales=[32, 64, 128], depth=[1, 1, 1], numerics="fp32")
+    sd = {k: (torch.from_numpy(recipe.det_weight(k, v.shape)) if v.dtype.is_floating_point else v) for k, v in net.state_dict().items()}
+    net.load_state_dict(sd)
+    for m in net.modules():
+        if isinstance(m, torch.nn.Dropout2d):
+            m.p = 0.0                      # deterministic comparison; the mask path has its own test (test_gpu_aux.py)
+    return net.to("cuda:0")
+
+
+def _v4_criterion():
+    from deepmerge_amd.Losses import Loss
+    crit = Loss(1.0, 0.1, 0)
+    return lambda a, b, flag: crit(a[0], b[0], flag) + 0.1 * crit(a[1], b[1], flag) + 0.2 * crit(a[2], b[2], flag)
+
+
+def _v4_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    net = _v4_build()
+    from deepmerge_amd.trainer import PairTrainer, shard_slice
+    tr = PairTrainer(net, lr=1e-4, n_buckets=3, criterion=_v4_criterion(), adam_fn=lambda *a, **k: None)
+    left, ld, right, rd, flag = _batch(8)
+    sl = shard_slice(8, rank, world)
+    mv = lambda t: t[sl].to("cuda:0")
+    tr.step([mv(t) for t in left], mv(ld), [mv(t) for t in right], mv(rd), mv(flag))
+    torch.cuda.synchronize()
+    torch.save({"grad": (tr.fp.grad / world).cpu(), "rm": net.aux0.aux[1].running_mean.cpu()}, out + f".{rank}")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_v4_batchnorm_statistics_are_per_rank(tmp_path):
+    """The SyncBN decision: under data parallel the aux heads' BatchNorm2d normalises with ITS RANK's shard
+    statistics (no cross-rank statistics exchange), gamma / beta / every other gradient is averaged over ranks, and each rank
+    keeps its own running statistics.  Equivalent single-process computation: the two shards as two micro-batches."""
+    out = str(tmp_path / "v4.pt")
+    mp.spawn(_v4_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    got = [torch.load(out + f".{r}") for r in (0, 1)]
+    assert torch.equal(got[0]["grad"], got[1]["grad"]), "after the exchange every rank holds the same averaged gradient"
+    assert not torch.equal(got[0]["rm"], got[1]["rm"]), "running statistics are per rank (different shards)"
+    from deepmerge_amd.trainer import PairTrainer
+    crit = _v4_criterion()
+    left, ld, right, rd, flag = _batch(8)
+    mv = lambda t, sl: t[sl].to("cuda:0")
+    # reference: two micro-batches through ONE model (fresh running statistics per shard do not influence training-mode outputs)
+    net = _v4_build()
+    tr = PairTrainer(net, lr=1e-4, criterion=crit, adam_fn=lambda *a, **k: None)
+    g = torch.zeros_like(tr.fp.grad)
+    rms = []
+    for sl in (slice(0, 4), slice(4, 8)):
+        rm0 = net.aux0.aux[1].running_mean.clone()
+        tr.step([mv(t, sl) for t in left], mv(ld, sl), [mv(t, sl) for t in right], mv(rd, sl), mv(flag, sl))
+        g += tr.fp.grad
+        rms.append(net.aux0.aux[1].running_mean.clone())
+        net.aux0.aux[1].running_mean.copy_(rm0)              # each rank starts from the same running statistics
+    g = (g / 2).cpu()
+    scale = float(g.abs().max())
+    assert float((got[0]["grad"] - g).abs().max()) <= 5e-5 * scale
+    assert torch.allclose(got[0]["rm"], rms[0].cpu(), rtol=1e-5, atol=1e-6) and torch.allclose(got[1]["rm"], rms[1].cpu(), rtol=1e-5, atol=1e-6)
+    # whereas the single-process GLOBAL batch (statistics over all 8 pairs) is a different computation
+    net2 = _v4_build()
+    tr2 = PairTrainer(net2, lr=1e-4, criterion=crit, adam_fn=lambda *a, **k: None)
+    tr2.step([t.to("cuda:0") for t in left], ld.to("cuda:0"), [t.to("cuda:0") for t in right], rd.to("cuda:0"), flag.to("cuda:0"))
+    w = dict(net2.named_parameters())["aux0.aux.0.weight"]
+    o = tr2.fp.offsets[[q is w for q in tr2.fp.params].index(True)]
+    a, b = tr2.fp.grad[o:o + w.numel()].cpu(), g[o:o + w.numel()]
+    assert float((a - b).abs().max()) > 1e-3 * float(b.abs().max()), "global-batch statistics would change the aux-head gradients"
