@@ -7,7 +7,7 @@ dev = "cuda:0"
 B, N, H, D = int(os.environ.get("B", 64)), int(os.environ.get("N", 256)), 12, 64
 g = torch.Generator(device=dev); g.manual_seed(0)
 qkv = torch.randn((B, N, 3, H, D), device=dev, generator=g).to(torch.bfloat16)
-bias = torch.randn((H, N, N), device=dev, generator=g) * 0.3
+bias = None if os.environ.get("NOBIAS") == "1" else torch.randn((H, N, N), device=dev, generator=g) * 0.3      # ViT (config 3) has no bias table
 def timeit(f, n=30):
     for _ in range(3): f()
     torch.cuda.synchronize(); t = time.perf_counter()
@@ -17,6 +17,6 @@ t = timeit(lambda: ops.attention_fwd(qkv, bias, B, N, H, D, 0.125))
 print(f"fwd B={B} N={N}: {t*1e6:7.1f} us  {4.0*B*H*N*N*D/t/1e12:6.1f} TFLOP/s")
 out, lse = ops.attention_fwd(qkv, bias, B, N, H, D, 0.125)
 dout = torch.randn_like(out)
-idx = torch.randint(0, 1575, (N, N), device=dev, dtype=torch.int32)
-t = timeit(lambda: ops.attention_bwd(qkv, bias, out, dout, lse, B, N, H, D, 0.125, idx, 1575))
+idx = None if bias is None else torch.randint(0, 1575, (N, N), device=dev, dtype=torch.int32)
+t = timeit(lambda: ops.attention_bwd(qkv, bias, out, dout, lse, B, N, H, D, 0.125, idx, 1575 if bias is not None else 0))
 print(f"bwd B={B} N={N}: {t*1e6:7.1f} us  {10.0*B*H*N*N*D/t/1e12:6.1f} TFLOP/s (incl. slab alloc)")
