@@ -32,11 +32,14 @@ KERNEL_SYMBOLS = {
 
 
 def csrc_hash():
-    """sha256 over the kernel sources (the stamp profiles/pmc_traffic.json must carry to be quoted)."""
+    """sha256 over the sources of the kernels profiles/pmc_traffic.json has rows for (GEMM family, attention, Adam / row
+    kernels and the headers they share): the stamp that file must carry to be quoted."""
     import glob
     import hashlib
     h = hashlib.sha256()
-    for f in sorted(glob.glob(os.path.join(ROOT, "deepmerge_amd", "csrc", "*.h*")) + glob.glob(os.path.join(ROOT, "deepmerge_amd", "csrc", "*.cpp"))):
+    pats = ("dm_gemm*.hip", "dm_attention*.hip", "dm_rows.hip", "dm_gemm_common.h", "dm_attention_pipe.h", "dm_mfma.h", "dm_common.h")
+    files = sorted(f for pat in pats for f in glob.glob(os.path.join(ROOT, "deepmerge_amd", "csrc", pat)))
+    for f in files:
         h.update(os.path.basename(f).encode()); h.update(open(f, "rb").read())
     return h.hexdigest()
 

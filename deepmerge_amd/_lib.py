@@ -78,7 +78,7 @@ SIGNATURES = {
     "dm_cross_entropy": (_I, [_P, _P, _P, _F, _P, _P, _I, _I, _P]),
     "dm_batchnorm_workspace_bytes": (_L, [_I, _I]),
     "dm_batchnorm_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _I, _I, _F, _F, _I, _I, _P, _P]),
-    "dm_batchnorm_bwd": (_I, [_P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P]),
+    "dm_batchnorm_bwd": (_I, [_P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P]),
     "dm_adam_step": (_I, [_P, _P, _P, _P, _P, _L, _I, _D, _D, _D, _D, _D, _P]),
     "dm_adam_hyper": (_I, [_I, _D, _D, _D, _P]),
     "dm_adam_step_dev": (_I, [_P, _P, _P, _P, _P, _L, _P, _D, _D, _D, _D, _P]),

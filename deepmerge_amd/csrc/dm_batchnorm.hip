@@ -15,7 +15,7 @@ constexpr int BN_GROUPS = 4;     // row groups per workgroup (256 threads)
 template <int MODE>
 __global__ __launch_bounds__(256) void bn_partial_kernel(const float *__restrict__ x, const float *__restrict__ dy, const float *__restrict__ y,
                                                          const float *__restrict__ mask, const float *__restrict__ mean, const float *__restrict__ rstd,
-                                                         double *__restrict__ partial, int M, int C, int rows_per_sample, int rows_per_slice) {
+                                                         double *__restrict__ partial, int M, int C, int rows_per_sample, int rows_per_slice, int relu) {
   __shared__ double sh[2][BN_GROUPS][BN_COLS];
   const int c = blockIdx.x * BN_COLS + (threadIdx.x & (BN_COLS - 1));
   const int grp = threadIdx.x / BN_COLS;
@@ -31,7 +31,7 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const float *__restrict
         a += v;
         b += (double)v * v;
       } else {
-        float g = (y[i] > 0.f) ? dy[i] : 0.f;
+        float g = (!relu || y[i] > 0.f) ? dy[i] : 0.f;
         if (mask) g *= mask[(long long)(r / rows_per_sample) * C + c];
         a += g;
         b += (double)g * ((x[i] - mu) * rs);
@@ -107,7 +107,7 @@ __global__ void bn_finalize_bwd_kernel(const double *__restrict__ partial, int s
 __global__ void bn_bwd_apply_kernel(const float *__restrict__ x, const float *__restrict__ dy, const float *__restrict__ y,
                                     const float *__restrict__ mask, const float *__restrict__ mean, const float *__restrict__ rstd,
                                     const float *__restrict__ gamma, const float *__restrict__ mean_g, const float *__restrict__ mean_gx,
-                                    float *__restrict__ dx, long long n4, int C, int rows_per_sample, int batch_stats) {
+                                    float *__restrict__ dx, long long n4, int C, int rows_per_sample, int batch_stats, int relu) {
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
     const long long e = i * 4;
     const int c = (int)(e % C);
@@ -115,7 +115,7 @@ __global__ void bn_bwd_apply_kernel(const float *__restrict__ x, const float *__
     const f32x4 yy = dm_load4(y + e);
     f32x4 g = dm_load4(dy + e);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) g[k] = (yy[k] > 0.f) ? g[k] : 0.f;
+    for (int k = 0; k < 4; ++k) g[k] = (!relu || yy[k] > 0.f) ? g[k] : 0.f;
     if (mask) g *= dm_load4(mask + (r / rows_per_sample) * C + c);
     const f32x4 rs = dm_load4(rstd + c), ga = dm_load4(gamma + c);
     f32x4 o = g;
@@ -159,7 +159,7 @@ extern "C" int dm_batchnorm_fwd(const float *x, const float *gamma, const float 
     const int slices = bn_slices(M), rps = (M + slices - 1) / slices;
     double *partial = reinterpret_cast<double *>(workspace);
     hipLaunchKernelGGL(bn_partial_kernel<0>, dim3((C + BN_COLS - 1) / BN_COLS, slices), dim3(256), 0, s, x, nullptr, nullptr, nullptr, nullptr, nullptr,
-                       partial, M, C, rows_per_sample, rps);
+                       partial, M, C, rows_per_sample, rps, 0);
     hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3((C + 255) / 256), dim3(256), 0, s, partial, slices, M, C, eps, momentum, save_mean, save_rstd,
                        running_mean, running_var);
   } else {
@@ -174,7 +174,7 @@ extern "C" int dm_batchnorm_fwd(const float *x, const float *gamma, const float 
 
 extern "C" int dm_batchnorm_bwd(const float *dy, const float *x, const float *y, const float *gamma, const float *mask, int32_t rows_per_sample,
                                 const float *save_mean, const float *save_rstd, float *dx, float *dgamma, float *dbeta, int32_t accumulate,
-                                int32_t M, int32_t C, int32_t training, void *workspace, void *stream) {
+                                int32_t M, int32_t C, int32_t training, int32_t relu, void *workspace, void *stream) {
   DM_REQUIRE(M > 0 && C > 0 && C % 4 == 0 && rows_per_sample > 0 && M % rows_per_sample == 0, DM_ERR_BAD_SHAPE,
              "dm_batchnorm_bwd: M=%d C=%d rows_per_sample=%d", M, C, rows_per_sample);
   DM_REQUIRE(dy && x && y && gamma && save_mean && save_rstd && dx && dgamma && dbeta && workspace, DM_ERR_BAD_SHAPE, "dm_batchnorm_bwd: null pointer");
@@ -183,10 +183,10 @@ extern "C" int dm_batchnorm_bwd(const float *dy, const float *x, const float *y,
   double *partial = reinterpret_cast<double *>(workspace);
   float *mean_g = reinterpret_cast<float *>(partial + (long long)slices * 2 * C), *mean_gx = mean_g + C;
   hipLaunchKernelGGL(bn_partial_kernel<1>, dim3((C + BN_COLS - 1) / BN_COLS, slices), dim3(256), 0, s, x, dy, y, mask, save_mean, save_rstd, partial,
-                     M, C, rows_per_sample, rps);
+                     M, C, rows_per_sample, rps, relu);
   hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3((C + 255) / 256), dim3(256), 0, s, partial, slices, M, C, dgamma, dbeta, accumulate, mean_g, mean_gx);
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(bn_grid((long long)M * C / 4)), dim3(256), 0, s, x, dy, y, mask, save_mean, save_rstd, gamma, mean_g,
-                     mean_gx, dx, (long long)M * C / 4, C, rows_per_sample, training);
+                     mean_gx, dx, (long long)M * C / 4, C, rows_per_sample, training, relu);
   DM_LAUNCH_CHECK("dm_batchnorm_bwd");
   return DM_OK;
 }

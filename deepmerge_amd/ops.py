@@ -594,14 +594,14 @@ class BatchNormReluFn(torch.autograd.Function):
                                           rows_per_sample, y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), M, Cc, eps, momentum, int(training),
                                           int(relu), ws.data_ptr(), _stream()), "dm_batchnorm_fwd")
         ctx.save_for_backward(x, y, gamma, mask, mean, rstd)
-        ctx.cfg = (rows_per_sample, bool(training))
+        ctx.cfg = (rows_per_sample, bool(training), bool(relu))
         ctx.params = (gamma, beta)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, y, gamma, mask, mean, rstd = ctx.saved_tensors
-        rows_per_sample, training = ctx.cfg
+        rows_per_sample, training, relu = ctx.cfg
         M, Cc = x.shape
         dx = torch.empty_like(x)
         gs, bs = _multi_use_sink(ctx.params[0], (Cc,)), _multi_use_sink(ctx.params[1], (Cc,))
@@ -611,7 +611,7 @@ class BatchNormReluFn(torch.autograd.Function):
         ws = workspace(_lib.lib().dm_batchnorm_workspace_bytes(M, Cc), x.device, "bn")
         check(_lib.lib().dm_batchnorm_bwd(dy.float().contiguous().data_ptr(), x.data_ptr(), y.data_ptr(), gamma.data_ptr(), _ptr(mask), rows_per_sample,
                                           mean.data_ptr(), rstd.data_ptr(), dx.data_ptr(), dg.data_ptr(), db.data_ptr(), int(direct), M, Cc,
-                                          int(training), ws.data_ptr(), _stream()), "dm_batchnorm_bwd")
+                                          int(training), int(relu), ws.data_ptr(), _stream()), "dm_batchnorm_bwd")
         return dx, (None if direct else dg), (None if direct else db), None, None, None, None, None, None, None, None
 
 

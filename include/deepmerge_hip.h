@@ -274,11 +274,11 @@ int64_t dm_batchnorm_workspace_bytes(int32_t M, int32_t C);
 int dm_batchnorm_fwd(const float *x, const float *gamma, const float *beta, float *running_mean, float *running_var,
                      const float *mask, int32_t rows_per_sample, float *y, float *save_mean, float *save_rstd, int32_t M,
                      int32_t C, float eps, float momentum, int32_t training, int32_t relu, void *workspace, void *stream);
-/* Gradient of the above (relu on: y > 0 decides the ReLU branch): dx [M, C]; dgamma / dbeta [C] written, or added to when
- * accumulate != 0. */
+/* Gradient of the above (relu != 0: y > 0 decides the ReLU branch; pass the forward call's relu / training / mask): dx [M, C];
+ * dgamma / dbeta [C] written, or added to when accumulate != 0. */
 int dm_batchnorm_bwd(const float *dy, const float *x, const float *y, const float *gamma, const float *mask, int32_t rows_per_sample,
                      const float *save_mean, const float *save_rstd, float *dx, float *dgamma, float *dbeta, int32_t accumulate,
-                     int32_t M, int32_t C, int32_t training, void *workspace, void *stream);
+                     int32_t M, int32_t C, int32_t training, int32_t relu, void *workspace, void *stream);
 
 /* ---- optional in-library kernel timing ------------------------------------------------------
  * While enabled, the GEMM and attention entry points bracket their main kernel with hipEvents on

@@ -110,6 +110,15 @@ def test_batchnorm_relu_dropout_kernel_vs_torch(training, samples, rows, C):
     if mask is not None:
         dropped = (mask == 0)[:, None, :].expand(samples, rows, C).reshape(M, C)
         assert float(y.detach().cpu()[dropped].abs().max()) == 0.0
+    # the same without the ReLU (plain BatchNorm2d): the backward must not gate on y > 0
+    bn.zero_grad(); xr2 = x.double().view(samples, rows, C).permute(0, 2, 1).unsqueeze(-1).contiguous().requires_grad_(True)
+    with torch.no_grad():
+        bn.running_mean.copy_(rm); bn.running_var.copy_(rv)
+    (bn(xr2) * go.double().view(samples, rows, C).permute(0, 2, 1).unsqueeze(-1)).sum().backward()
+    xd2 = x.to(DEV).requires_grad_(True)
+    y2 = ops.BatchNormReluFn.apply(xd2, gamma.to(DEV), beta.to(DEV), rm.to(DEV), rv.to(DEV), None, rows, 1e-5, 0.1, training, False)
+    (y2 * go.to(DEV)).sum().backward()
+    np.testing.assert_allclose(xd2.grad.cpu().double().numpy(), back(xr2.grad).numpy(), rtol=2e-4, atol=2e-5)
 
 
 def test_aux_head_dropout_is_live_in_training():
