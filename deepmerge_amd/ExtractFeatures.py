@@ -49,7 +49,8 @@ class FeatureIO:
 
     @torch.no_grad()
     def extract_features_from_tile(self, tile: torch.Tensor, points_xy: torch.Tensor, inner: torch.Tensor, obj: torch.Tensor,
-                                   region_features: torch.Tensor, batch_size: int = 2000, geotransform=None) -> torch.Tensor:
+                                   region_features: torch.Tensor, batch_size: int = 2000, geotransform=None,
+                                   process_group=None) -> torch.Tensor:
         """`extract_features(image_path, point_path, h5_file_path, batch_size)` (ExtractFeatures.py:45-86) with the raster and the
         point table already in memory: `tile` uint8 [bands, H, W] on the GPU (what GDAL's ReadAsArray returns), one row per
         sample point in FID order -- pixel position (or geo coordinates when `geotransform` is given: the reference's own
@@ -57,8 +58,30 @@ class FeatureIO:
         per-point window arithmetic, crop, resize and patch-embed operand layout run on the device (patches.point_batch_cols);
         returns / keeps F [P, 100] fp32, rows in point order, as the HDF5 `dataset` would hold them."""
         from .patches import geo_to_pixel, point_batch_cols
+        import torch.distributed as dist
         if geotransform is not None:
             points_xy = geo_to_pixel(geotransform, points_xy[:, 0], points_xy[:, 1])
+        world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
+        if world > 1:
+            # SURVEY 8e: points are independent -> contiguous equal shards per rank (the tile is replicated: 64 MiB), no exchange
+            # during the encode, ONE all-gather of the [P, 100] rows (24 MB for a 4096^2 tile) before the sweep
+            rank = dist.get_rank(process_group)
+            P = points_xy.shape[0]
+            per = (P + world - 1) // world
+            lo, hi = min(P, rank * per), min(P, (rank + 1) * per)
+            local = self._extract_local(tile, points_xy[lo:hi], inner[lo:hi], obj[lo:hi], region_features[lo:hi], batch_size) \
+                if hi > lo else torch.empty((0, 100), dtype=torch.float32, device=self.device)
+            padded = torch.zeros((per, 100), dtype=torch.float32, device=self.device)
+            padded[:hi - lo] = local
+            parts = [torch.empty_like(padded) for _ in range(world)]
+            dist.all_gather(parts, padded, group=process_group)
+            self.features = torch.cat(parts)[:P].contiguous()
+            return self.features
+        return self._extract_local(tile, points_xy, inner, obj, region_features, batch_size)
+
+    @torch.no_grad()
+    def _extract_local(self, tile, points_xy, inner, obj, region_features, batch_size):
+        from .patches import point_batch_cols
         P = points_xy.shape[0]
         scales = list(self.net.input_image_scales)
         grid = self.net.cube_size[1]

@@ -189,3 +189,44 @@ def test_two_ranks_v4_batchnorm_statistics_are_per_rank(tmp_path):
     o = tr2.fp.offsets[[q is w for q in tr2.fp.params].index(True)]
     a, b = tr2.fp.grad[o:o + w.numel()].cpu(), g[o:o + w.numel()]
     assert float((a - b).abs().max()) > 1e-3 * float(b.abs().max()), "global-batch statistics would change the aux-head gradients"
+
+
+def _extract_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    F = _extract(sharded=True)
+    if rank == 1:
+        torch.save(F.cpu(), out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _extract(sharded):
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import recipe
+    from deepmerge_amd.ExtractFeatures import FeatureIO
+    from deepmerge_amd.nets.ShfitScaleFormer import ShfitScaleFormer_v3
+    net = ShfitScaleFormer_v3(cube_size=[8, 8], input_image_scales=[32, 64, 128], depth=[1, 1, 1], in_c=4, numerics="bf16")
+    sd = {k: (torch.from_numpy(recipe.det_weight(k, v.shape)) if v.dtype.is_floating_point else v) for k, v in net.state_dict().items()}
+    net.load_state_dict(sd)
+    fio = FeatureIO(net, None, "cuda:0")
+    rng = np.random.default_rng(8)
+    tile = torch.from_numpy(rng.integers(0, 256, size=(4, 300, 300), dtype=np.uint8)).to("cuda:0")
+    P = 37                                                    # not a multiple of the world size
+    xy = torch.from_numpy(rng.integers(0, 300, (P, 2)).astype(np.int32))
+    inner = torch.from_numpy(rng.integers(16, 64, P).astype(np.int32)); obj = inner + 20
+    feats = torch.from_numpy(np.exp(rng.uniform(-2, 3, (P, 15))).astype(np.float32))
+    return fio.extract_features_from_tile(tile, xy, inner, obj, feats, batch_size=19)
+
+
+def test_extract_features_shards_over_ranks(tmp_path):
+    """ExtractFeatures under data parallel (SURVEY 8e): points split into contiguous shards, one all-gather of the [P, 100] rows;
+    every rank ends with the full matrix in point order.  Rows agree with the single-process run to bf16 rounding (the GEMM tile
+    choice depends on the batch a rank sees)."""
+    out = str(tmp_path / "F.pt")
+    mp.spawn(_extract_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    got = torch.load(out)
+    want = _extract(sharded=False).cpu()
+    assert got.shape == want.shape == (37, 100)
+    assert float((got - want).norm() / want.norm()) < 2e-2
