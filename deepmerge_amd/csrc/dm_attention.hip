@@ -531,8 +531,8 @@ template <typename T> int dispatch(int which, const AttnParams &p, hipStream_t s
 }
 
 int check_common(const char *who, int B, int N, int H, int D, int dtype) {
-  DM_REQUIRE(B > 0 && H > 0 && N > 0 && N <= 256, DM_ERR_BAD_SHAPE, "%s: need 0 < N <= 256 tokens (got N=%d, B=%d, H=%d)", who, N, B, H);
-  DM_REQUIRE(D == HD, DM_ERR_BAD_SHAPE, "%s: head dim must be %d (got %d)", who, HD, D);
+  DM_REQUIRE(B > 0 && H > 0 && N > 0 && N <= 256, DM_ERR_BAD_SHAPE, "%s: need 0 < N <= 4096 tokens and head dim <= 128 (got N=%d, D=%d, B=%d, H=%d)", who, N, D, B, H);
+  DM_REQUIRE(D == HD, DM_ERR_BAD_SHAPE, "%s: head dim must be in 1..128 (got %d)", who, D);
   DM_REQUIRE(dtype == DM_F32 || dtype == DM_BF16, DM_ERR_BAD_DTYPE, "%s: bad dtype %d", who, dtype);
   DM_REQUIRE(H <= 65535 && B <= 65535, DM_ERR_BAD_SHAPE, "%s: grid too large", who);
   return DM_OK;
@@ -554,8 +554,22 @@ extern "C" int32_t dm_attention_bwd_batch_chunks(int32_t B, int32_t N, int32_t H
   return (B + c - 1) / c;
 }
 
+// dm_attention_generic.hip: any head dim <= 128 / up to 4096 tokens, fp32 arithmetic (ViT-H/14: D = 80, N = 257)
+bool dm_attn_generic_shape(int N, int D);
+int dm_attn_generic_fwd(const void *qkv, const float *bias, void *out, float *lse, int B, int N, int H, int D, float scale, int dtype, hipStream_t s);
+int dm_attn_generic_bwd(const void *qkv, const float *bias, const void *out, const void *dout, const float *lse, void *dqkv, float *delta,
+                        int B, int N, int H, int D, float scale, int dtype, hipStream_t s);
+
 extern "C" int dm_attention_fwd(const void *qkv, const float *bias, void *out, float *lse, int32_t B, int32_t N, int32_t H,
                                 int32_t D, float scale, int32_t dtype, void *stream) {
+  if (dm_attn_generic_shape(N, D)) {
+    DM_REQUIRE(B > 0 && H > 0 && H <= 65535 && B <= 65535 && (dtype == DM_F32 || dtype == DM_BF16) && qkv && out && lse, DM_ERR_BAD_SHAPE,
+               "dm_attention_fwd: bad arguments (B=%d H=%d dtype=%d)", B, H, dtype);
+    const int rc = dm_attn_generic_fwd(qkv, bias, out, lse, B, N, H, D, scale, dtype, reinterpret_cast<hipStream_t>(stream));
+    DM_REQUIRE(rc == DM_OK, rc, "dm_attention_fwd: generic kernel could not be configured");
+    DM_LAUNCH_CHECK("dm_attention_fwd(generic)");
+    return DM_OK;
+  }
   if (int rc = check_common("dm_attention_fwd", B, N, H, D, dtype)) return rc;
   DM_REQUIRE(qkv && out && lse, DM_ERR_BAD_SHAPE, "dm_attention_fwd: null pointer");
   DM_REQUIRE(dm_aligned16(qkv) && dm_aligned16(out) && dm_aligned16(bias), DM_ERR_BAD_ALIGN, "dm_attention_fwd: qkv/out/bias must be 16-byte aligned");
@@ -582,6 +596,15 @@ extern "C" int dm_attention_fwd(const void *qkv, const float *bias, void *out, f
 extern "C" int dm_attention_bwd(const void *qkv, const float *bias, const float *bias_t, const void *out, const void *dout,
                                 const float *lse, void *dqkv, float *delta, float *dbias_slab, int32_t B, int32_t N, int32_t H, int32_t D, float scale, int32_t dtype,
                                 void *stream) {
+  if (dm_attn_generic_shape(N, D)) {
+    DM_REQUIRE(B > 0 && H > 0 && H <= 65535 && B <= 65535 && (dtype == DM_F32 || dtype == DM_BF16) && qkv && out && dout && lse && dqkv && delta,
+               DM_ERR_BAD_SHAPE, "dm_attention_bwd: bad arguments (B=%d H=%d dtype=%d)", B, H, dtype);
+    DM_REQUIRE(dbias_slab == nullptr, DM_ERR_UNSUPPORTED, "dm_attention_bwd: the bias-table gradient needs head dim 64 and N <= 256 (got D=%d N=%d)", D, N);
+    const int rc = dm_attn_generic_bwd(qkv, bias, out, dout, lse, dqkv, delta, B, N, H, D, scale, dtype, reinterpret_cast<hipStream_t>(stream));
+    DM_REQUIRE(rc == DM_OK, rc, "dm_attention_bwd: generic kernel could not be configured");
+    DM_LAUNCH_CHECK("dm_attention_bwd(generic)");
+    return DM_OK;
+  }
   if (int rc = check_common("dm_attention_bwd", B, N, H, D, dtype)) return rc;
   DM_REQUIRE(qkv && out && dout && lse && dqkv && delta, DM_ERR_BAD_SHAPE, "dm_attention_bwd: null pointer");
   DM_REQUIRE(dm_aligned16(qkv) && dm_aligned16(out) && dm_aligned16(dout) && dm_aligned16(dqkv) && dm_aligned16(bias) &&

@@ -230,6 +230,8 @@ def attention_bwd(qkv, bias, out, dout, lse, B, N, H, D, scale, index32=None, n_
     delta = torch.empty((B, H, N), dtype=torch.float32, device=qkv.device)
     slab, info = None, None
     if index32 is not None:
+        if D != 64 or N > 256:
+            raise ValueError(f"the relative-position bias gradient needs head dim 64 and N <= 256 (got D={D}, N={N})")
         chunks = _lib.lib().dm_attention_bwd_batch_chunks(B, N, H, _dt(qkv))
         slab = torch.empty((chunks, H, N, N), dtype=torch.float32, device=qkv.device)
         info = (chunks, N, relpos_index_csr(index32, n_bins))

@@ -6,7 +6,8 @@ the reference.  Blocks run through the fused `ops.BlockFn` (no bias table: plain
 after q @ k^T upstream, which is bit-identical for the power-of-two 64^-0.5); LayerNorm eps = 1e-6.
 torch nn.Linear/Conv/LayerNorm objects are parameter containers only.
 
-Supported on the accelerated path: head dim 64 (ViT-B, ViT-L) and embed dims <= 1024.  ViT-H (dim 1280,
+Supported on the accelerated path: head dims <= 128 (64 on the MFMA attention kernels, others on the generic fp32 family) and
+embed dims <= 1024.  ViT-H (dim 1280,
 head dim 80, patch 14) is declared by the reference but its weights were never available upstream
 (vit_model.py:649); its factory raises NotImplementedError here.
 """
@@ -75,8 +76,8 @@ class Attention(nn.Module):
             raise ValueError("dropout > 0 is not part of the accelerated path (reference uses 0)")
         self.num_heads = num_heads
         head_dim = dim // num_heads
-        if head_dim != 64:
-            raise NotImplementedError(f"the fused attention kernel is built for head dim 64 (got {head_dim})")
+        if head_dim > 128:
+            raise NotImplementedError(f"attention kernels cover head dims up to 128 (got {head_dim})")
         self.scale = qk_scale or head_dim ** -0.5
         self.qkv = nn.Linear(dim, dim * 3, bias=qkv_bias)
         self.attn_drop = nn.Dropout(attn_drop_ratio)
@@ -370,5 +371,6 @@ def vit_large_patch32_224_in21k(num_classes: int = 21843, has_logits: bool = Tru
 
 
 def vit_huge_patch14_224_in21k(num_classes: int = 21843, has_logits: bool = True, numerics=None):
-    raise NotImplementedError("ViT-H/14 (dim 1280, head dim 80, patch 14) is outside the accelerated kernels' range; "
-                              "the reference never shipped its weights either (vit_model.py:649)")
+    raise NotImplementedError("ViT-H/14 (vit_model.py:649-662: dim 1280, 14-pixel patches, head dim 80, 257 tokens) is not built: its "
+                              "attention shape runs (generic kernels, dm_attention_generic.hip), but the LayerNorm kernels stop at 1024 "
+                              "columns and the patch extraction needs a patch side that is a multiple of 4; upstream never shipped its weights")

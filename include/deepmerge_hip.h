@@ -109,7 +109,8 @@ int64_t dm_gemm_workspace_bytes(int32_t layout, int32_t M, int32_t N, int32_t K)
  * Replaces nets/ShfitScaleFormer.py:119-133 (reshape/permute, q*scale, q@k^T, bias add, softmax,
  * attn@v, transpose/reshape) and vit_model.py:119-133 (bias == NULL; the scale 64^-0.5 = 2^-3 is
  * exact, so applying it before or after q@k^T is bit-identical).
- *   qkv   [B, N, 3, H, D]  T   (output of the qkv Linear; D = 64)
+ *   qkv   [B, N, 3, H, D]  T   (output of the qkv Linear).  D = 64 and N <= 256 run the MFMA kernels; any other head dim <= 128 /
+ *                            N <= 4096 (ViT-H/14: D = 80, N = 257) a plain fp32 kernel family (no bias-table gradient there)
  *   bias  [H, N, N] fp32 or NULL  (dense, from dm_relpos_bias_gather)
  *   out   [B, N, H*D]      T
  *   lse   [B, H, N] fp32   row log-sum-exp of the biased scores (saved for backward)

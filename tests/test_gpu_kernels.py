@@ -528,3 +528,38 @@ def test_gemm_user_split_k_is_bounds_checked():
     a.workspace, a.workspace_bytes = small.data_ptr(), small.numel()
     rc = _lib.lib().dm_gemm(C.byref(a), torch.cuda.current_stream().cuda_stream)
     assert rc != 0 and b"split_k" in _lib.lib().dm_last_error()
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+@pytest.mark.parametrize("B,N,H,D,with_bias", [(2, 257, 3, 80, False), (1, 300, 2, 32, True), (2, 70, 2, 128, False), (1, 64, 2, 48, True)])
+def test_attention_generic_shapes(mode, B, N, H, D, with_bias):
+    """Head dims other than 64 / more than 256 tokens (ViT-H/14's 80 x 257 among them) run the generic fp32 kernel family
+    (dm_attention_generic.hip): forward, lse and the three gradients against a float64 reference."""
+    ops = _ops()
+    dt = DT[mode]
+    g = torch.Generator().manual_seed(N + D)
+    qkv = (torch.randn(B, N, 3, H, D, generator=g) * 0.7).to(dt)
+    bias = torch.randn(H, N, N, generator=g) * 0.5 if with_bias else None
+    dout = torch.randn(B, N, H * D, generator=g).to(dt)
+    scale = D ** -0.5
+    q, k, v = [qkv.double()[:, :, i].permute(0, 2, 1, 3).clone().requires_grad_(True) for i in range(3)]      # [B,H,N,D]
+    s = q @ k.transpose(-1, -2) * scale
+    if bias is not None:
+        s = s + bias.double()[None]
+    p = torch.softmax(s, -1)
+    o = (p @ v).permute(0, 2, 1, 3).reshape(B, N, H * D)
+    (o * dout.double()).sum().backward()
+    out, lse = ops.attention_fwd(qkv.to(DEV), None if bias is None else bias.to(DEV), B, N, H, D, scale)
+    tol = 2e-5 if mode == "fp32" else 2e-2
+    np.testing.assert_allclose(out.float().cpu().double().numpy(), o.detach().numpy(), rtol=tol, atol=tol)
+    np.testing.assert_allclose(lse.cpu().double().numpy(), torch.logsumexp(s, -1).detach().numpy(), rtol=1e-5, atol=1e-5)
+    # backward from the reference's own (rounded) forward output so both sides differentiate the same function
+    dqkv, slab, _ = ops.attention_bwd(qkv.to(DEV), None if bias is None else bias.to(DEV), out, dout.to(DEV), lse, B, N, H, D, scale)
+    assert slab is None
+    want = torch.stack([t.grad.permute(0, 2, 1, 3) for t in (q, k, v)], 2)                                      # [B,N,3,H,D]
+    got = dqkv.float().cpu().double()
+    err = float((got - want).norm() / want.norm())
+    assert err < (1e-4 if mode == "fp32" else 2e-2), err
+    if with_bias:
+        with pytest.raises(ValueError):
+            ops.attention_bwd(qkv.to(DEV), bias.to(DEV), out, dout.to(DEV), lse, B, N, H, D, scale, torch.zeros(N, N, dtype=torch.int32, device=DEV), 10)
