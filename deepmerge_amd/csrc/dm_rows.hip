@@ -6,9 +6,19 @@
 
 #include "dm_common.h"
 
+// dm_rows_wide.hip: streamed variants for rows wider than the register-resident kernels hold, and patch sides that are not
+// multiples of 4 (ViT-H/14).
+int dm_layernorm_wide_fwd(const float *x, const float *gamma, const float *beta, void *y, int y_dtype, float *mean, float *rstd, int rows,
+                          int cols, float eps, hipStream_t s);
+int dm_layernorm_wide_bwd(const void *dy, int dy_dtype, const float *x, const float *gamma, const float *mean, const float *rstd,
+                          const float *dres, float *dx, void *dx_lp, float *partial, int max_slices, int *slices, int rows, int cols,
+                          hipStream_t s);
+int dm_patchify_any(const float *x, void *cols, int dtype, int B, int C, int side, int p, hipStream_t s);
+
 namespace {
 
-constexpr int MAXCH = 4;          // float4 chunks per lane per row -> cols <= 1024
+constexpr int MAXCH = 4;          // float4 chunks per lane per row -> cols <= 1024 in the register-resident kernels
+constexpr int LN_WIDE_MAX = 8192; // widest row of the streamed kernels
 static int ln_max_wg() {           // workgroups of the LayerNorm backward (each writes one partial row pair)
   static const int v = [] { const char *e = getenv("DM_LN_WG"); return e ? atoi(e) : 512; }();
   return v;
@@ -490,10 +500,16 @@ static int adam_grid(long long n) {
 // =============================================================================================
 extern "C" int dm_layernorm_fwd(const float *x, const float *gamma, const float *beta, void *y, int32_t y_dtype,
                                 float *mean, float *rstd, int32_t rows, int32_t cols, float eps, void *stream) {
-  DM_REQUIRE(rows > 0 && cols > 0 && cols % 4 == 0 && cols <= MAXCH * 256, DM_ERR_BAD_SHAPE,
-             "dm_layernorm_fwd: rows=%d cols=%d (cols must be a multiple of 4, <= %d)", rows, cols, MAXCH * 256);
+  DM_REQUIRE(rows > 0 && cols > 0 && cols % 4 == 0 && cols <= LN_WIDE_MAX, DM_ERR_BAD_SHAPE,
+             "dm_layernorm_fwd: rows=%d cols=%d (cols must be a multiple of 4, <= %d)", rows, cols, LN_WIDE_MAX);
   DM_REQUIRE(x && gamma && beta && y && mean && rstd, DM_ERR_BAD_SHAPE, "dm_layernorm_fwd: null pointer");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (cols > MAXCH * 256) {
+    const int rc = dm_layernorm_wide_fwd(x, gamma, beta, y, y_dtype, mean, rstd, rows, cols, eps, s);
+    DM_REQUIRE(rc == DM_OK, rc, "dm_layernorm_fwd: bad y_dtype %d", y_dtype);
+    DM_LAUNCH_CHECK("dm_layernorm_fwd(wide)");
+    return DM_OK;
+  }
   const int grid = grid_for((long long)rows, 4, 2048);
   if (y_dtype == DM_F32)
     hipLaunchKernelGGL(layernorm_fwd_kernel<float>, dim3(grid), dim3(256), 0, s, x, gamma, beta, (float *)y, mean, rstd, rows, cols, eps);
@@ -509,10 +525,19 @@ extern "C" int64_t dm_layernorm_bwd_partial_floats(int32_t cols) { return (int64
 extern "C" int dm_layernorm_bwd(const void *dy, int32_t dy_dtype, const float *x, const float *gamma, const float *mean,
                                 const float *rstd, const float *dres, float *dx, void *dx_lp, float *dgamma, float *dbeta,
                                 int32_t accumulate_params, float *partial, int32_t rows, int32_t cols, void *stream) {
-  DM_REQUIRE(rows > 0 && cols > 0 && cols % 4 == 0 && cols <= MAXCH * 256, DM_ERR_BAD_SHAPE,
+  DM_REQUIRE(rows > 0 && cols > 0 && cols % 4 == 0 && cols <= LN_WIDE_MAX, DM_ERR_BAD_SHAPE,
              "dm_layernorm_bwd: rows=%d cols=%d", rows, cols);
   DM_REQUIRE(dy && x && gamma && mean && rstd && dx && dgamma && dbeta && partial, DM_ERR_BAD_SHAPE, "dm_layernorm_bwd: null pointer");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (cols > MAXCH * 256) {
+    int slices = 0;
+    const int rc = dm_layernorm_wide_bwd(dy, dy_dtype, x, gamma, mean, rstd, dres, dx, dx_lp, partial, ln_max_wg(), &slices, rows, cols, s);
+    DM_REQUIRE(rc == DM_OK, rc, "dm_layernorm_bwd: bad dy_dtype %d", dy_dtype);
+    DM_LAUNCH_CHECK("dm_layernorm_bwd(wide)");
+    hipLaunchKernelGGL(partial_reduce_kernel, dim3((2 * cols + 15) / 16), dim3(256), 0, s, partial, dgamma, dbeta, slices, 2 * cols, cols, accumulate_params);
+    DM_LAUNCH_CHECK("dm_layernorm_bwd(reduce)");
+    return DM_OK;
+  }
   const int grid = grid_for((long long)rows, 4, ln_max_wg());
   if (dy_dtype == DM_F32)
     hipLaunchKernelGGL(layernorm_bwd_kernel<float>, dim3(grid), dim3(256), 0, s, (const float *)dy, x, gamma, mean, rstd, dres, dx, (bf16_t *)dx_lp, partial, rows, cols);
@@ -589,9 +614,15 @@ extern "C" int dm_cast(const float *src, void *dst, int32_t dst_dtype, int64_t n
 }
 
 extern "C" int dm_patchify(const float *x, void *cols, int32_t dtype, int32_t B, int32_t C, int32_t side, int32_t p, void *stream) {
-  DM_REQUIRE(B > 0 && C > 0 && p > 0 && p % 4 == 0 && side % p == 0, DM_ERR_BAD_SHAPE,
-             "dm_patchify: B=%d C=%d side=%d patch=%d (patch must be a multiple of 4 dividing side)", B, C, side, p);
+  DM_REQUIRE(B > 0 && C > 0 && p > 0 && side % p == 0, DM_ERR_BAD_SHAPE,
+             "dm_patchify: B=%d C=%d side=%d patch=%d (patch must divide side)", B, C, side, p);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (p % 4 != 0) {
+    const int rc = dm_patchify_any(x, cols, dtype, B, C, side, p, s);
+    DM_REQUIRE(rc == DM_OK, rc, "dm_patchify: bad dtype %d", dtype);
+    DM_LAUNCH_CHECK("dm_patchify(any)");
+    return DM_OK;
+  }
   const long long total = (long long)B * (side / p) * (side / p) * ((long long)C * p * p / 4);
   if (dtype == DM_F32) hipLaunchKernelGGL(patchify_kernel<float>, dim3(grid_for(total)), dim3(256), 0, s, x, (float *)cols, B, C, side, p);
   else if (dtype == DM_BF16) hipLaunchKernelGGL(patchify_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, s, x, (bf16_t *)cols, B, C, side, p);

@@ -7,9 +7,9 @@ after q @ k^T upstream, which is bit-identical for the power-of-two 64^-0.5); La
 torch nn.Linear/Conv/LayerNorm objects are parameter containers only.
 
 Supported on the accelerated path: head dims <= 128 (64 on the MFMA attention kernels, others on the generic fp32 family) and
-embed dims <= 1024.  ViT-H (dim 1280,
-head dim 80, patch 14) is declared by the reference but its weights were never available upstream
-(vit_model.py:649); its factory raises NotImplementedError here.
+embed dims <= 8192 (<= 1024 on the register-resident LayerNorm kernels, wider rows on the streamed ones of dm_rows_wide.hip).
+ViT-H/14 (dim 1280, head dim 80, 14-pixel patches, 257 tokens; vit_model.py:649-662) therefore runs, on those secondary
+kernels: a correctness path, not a tuned one (upstream never shipped its weights).
 """
 from __future__ import annotations
 
@@ -58,7 +58,9 @@ class PatchEmbed(nn.Module):
         B, C, H, W = x.shape
         assert H == self.img_size[0] and W == self.img_size[1], \
             f"Input image size ({H}*{W}) doesn't match model ({self.img_size[0]}*{self.img_size[1]})."
-        cols = ops.patchify(x.float(), self.patch_size[0], ops.act_dtype(self.numerics))
+        K = C * self.patch_size[0] * self.patch_size[1]
+        # bf16 GEMM operands need 16-byte rows (K % 8 == 0); a 14-pixel patch (K = 588) keeps this one small GEMM in fp32
+        cols = ops.patchify(x.float(), self.patch_size[0], ops.act_dtype(self.numerics) if K % 8 == 0 else torch.float32)
         y = ops.LinearFn.apply(cols, self.proj.weight, self.proj.bias, None, torch.float32)
         return self.norm(y.view(B, self.num_patches, -1))
 
@@ -124,8 +126,8 @@ class Block(nn.Module):
 
 
 def _check_dim(embed_dim):
-    if embed_dim > 1024:
-        raise NotImplementedError(f"embed_dim {embed_dim} > 1024 is outside the row kernels' range (ViT-H is not built)")
+    if embed_dim > 8192 or embed_dim % 4:
+        raise NotImplementedError(f"embed_dim {embed_dim}: the row kernels take multiples of 4 up to 8192")
 
 
 class _Head(nn.Module):
@@ -371,6 +373,6 @@ def vit_large_patch32_224_in21k(num_classes: int = 21843, has_logits: bool = Tru
 
 
 def vit_huge_patch14_224_in21k(num_classes: int = 21843, has_logits: bool = True, numerics=None):
-    raise NotImplementedError("ViT-H/14 (vit_model.py:649-662: dim 1280, 14-pixel patches, head dim 80, 257 tokens) is not built: its "
-                              "attention shape runs (generic kernels, dm_attention_generic.hip), but the LayerNorm kernels stop at 1024 "
-                              "columns and the patch extraction needs a patch side that is a multiple of 4; upstream never shipped its weights")
+    """vit_model.py:649-662.  Runs on the secondary kernels (generic attention for head dim 80 / 257 tokens, streamed LayerNorm
+    for 1280 columns, element-wise patch extraction for the 14-pixel patches)."""
+    return _vit(14, 1280, 32, 16, num_classes, has_logits, numerics)

@@ -351,11 +351,20 @@ def gen_aux(S2F, Losses):
 def gen_vit(vit_model, Losses):
     """vit_model.py pair encoders (BASELINE configs[2])."""
     fx = {}
+    path = os.path.join(HERE, "model_vit.npz")
+    old = np.load(path) if os.path.exists(path) else None       # cases already committed are kept as they are (only ADD)
+    have = (lambda tag: old is not None and tag + "/loss" in old.files)
     crit = Losses.Loss(margin=1.0, lamda=0.1, belta=0)
     flag = torch.tensor([1, 0], dtype=torch.int64)
-    # ---- VisionTransformer ViT-B/16 (num_classes=100, has_logits=False), depth 12 and a 2-block cut ----
-    for tag, depth in (("vitb16_d12", 12), ("vitb16_d2", 2)):
-        if depth == 12:
+    # ---- VisionTransformer ViT-B/16 (num_classes=100, has_logits=False), depth 12 and a 2-block cut;
+    #      ViT-H/14 geometry (vit_model.py:649-662: dim 1280, 16 heads of 80, 14-pixel patches, 257 tokens), 2 blocks ----
+    for tag, depth in (("vitb16_d12", 12), ("vitb16_d2", 2), ("vith14_d2", 2)):
+        if have(tag):
+            continue
+        if tag == "vith14_d2":
+            net = vit_model.VisionTransformer(img_size=224, patch_size=14, embed_dim=1280, depth=depth, num_heads=16,
+                                              representation_size=None, num_classes=100)
+        elif depth == 12:
             net = vit_model.vit_base_patch16_224_in21k(num_classes=100, has_logits=False)
         else:
             net = vit_model.VisionTransformer(img_size=224, patch_size=16, embed_dim=768, depth=depth, num_heads=12,
@@ -387,6 +396,8 @@ def gen_vit(vit_model, Losses):
         print(tag, "loss", fx[tag + "/loss"], "dist", fx[tag + "/dist"], "params", int(fx[tag + "/n_params"]))
     # ---- ScaleEmbedTransformer (multi-scale + designed-feature token) --------------------------------
     for tag, depth in (("vitscale_d12", 12), ("vitscale_d2", 2)):
+        if have(tag):
+            continue
         if depth == 12:
             net = vit_model.vit_base_patch_scales_224_in21k(num_classes=512, has_logits=False)
         else:
@@ -421,7 +432,9 @@ def gen_vit(vit_model, Losses):
         two = net(xa, fa)                      # 2 args = (patches, designed), NOT a pair (:544-545)
         fx[tag + "/two_args_equals_left"] = np.bool_(torch.equal(two, ya))
         print(tag, "loss", fx[tag + "/loss"], "dist", fx[tag + "/dist"], "none", none)
-    np.savez_compressed(os.path.join(HERE, "model_vit.npz"), **fx)
+    if old is not None:
+        fx.update({k: old[k] for k in old.files})
+    np.savez_compressed(path, **fx)
     print("model_vit.npz", len(fx))
 
 

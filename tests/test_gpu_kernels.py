@@ -307,7 +307,8 @@ def test_attention_forward_backward(mode, N, with_bias, B=3, H=4):
 
 
 @pytest.mark.parametrize("out_dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("rows,cols", [(1, 768), (37, 768), (4096, 768), (50, 128), (9, 1024)])
+@pytest.mark.parametrize("rows,cols", [(1, 768), (37, 768), (4096, 768), (50, 128), (9, 1024),
+                                       (1, 1280), (514, 1280), (5000, 1028), (33, 8192)])      # > 1024 columns: dm_rows_wide.hip
 def test_layernorm(rows, cols, out_dtype):
     ops = _ops()
     rng = np.random.default_rng(rows + cols)
@@ -355,10 +356,14 @@ def test_pooling_patchify_colsum_cast():
     np.testing.assert_allclose(zd.grad.cpu().numpy(), np.full(z.shape, 0.25, np.float32))
     # patchify == unfold with (c, dy, dx) column order
     img = torch.from_numpy(rng.normal(size=(2, 4, 64, 64)).astype(np.float32))
-    for p in (4, 8, 16, 32):
+    for p in (4, 8, 16, 32, 1, 2):
         cols = ops.patchify(img.to(DEV), p, torch.float32).cpu()
         want = torch.nn.functional.unfold(img, kernel_size=p, stride=p).transpose(1, 2).reshape(-1, 4 * p * p)
         assert torch.equal(cols, want), p
+    img14 = torch.from_numpy(rng.normal(size=(3, 3, 56, 56)).astype(np.float32))      # ViT-H/14 patch side (element-wise kernel)
+    for p, dt in ((14, torch.float32), (7, torch.bfloat16)):
+        cols = ops.patchify(img14.to(DEV), p, dt).cpu()
+        assert torch.equal(cols, torch.nn.functional.unfold(img14, kernel_size=p, stride=p).transpose(1, 2).reshape(-1, 3 * p * p).to(dt)), p
     colsb = ops.patchify(img.to(DEV), 8, torch.bfloat16).cpu()
     assert torch.equal(colsb, torch.nn.functional.unfold(img, kernel_size=8, stride=8).transpose(1, 2).reshape(-1, 256).bfloat16())
     # colsum

@@ -19,12 +19,15 @@ def VM():
     return vit_model
 
 
-@pytest.mark.parametrize("tag,depth", [("vitb16_d2", 2), ("vitb16_d12", 12)])
+@pytest.mark.parametrize("tag,depth", [("vitb16_d2", 2), ("vitb16_d12", 12), ("vith14_d2", 2)])
 def test_vision_transformer_parity_fp32(tag, depth):
     from deepmerge_amd.Losses import Loss
     fx = load_fx("model_vit.npz")
     vm = VM()
-    if depth == 12:
+    if tag == "vith14_d2":       # ViT-H/14 geometry: generic attention (head dim 80, 257 tokens), streamed LayerNorm, 14-pixel patches
+        net = vm.VisionTransformer(img_size=224, patch_size=14, embed_dim=1280, depth=depth, num_heads=16, representation_size=None,
+                                   num_classes=100, numerics="fp32")
+    elif depth == 12:
         net = vm.vit_base_patch16_224_in21k(num_classes=100, has_logits=False, numerics="fp32")
     else:
         net = vm.VisionTransformer(img_size=224, patch_size=16, embed_dim=768, depth=depth, num_heads=12, representation_size=None,
@@ -102,6 +105,24 @@ def test_vit_bf16_drift_bounded():
     assert e[0] < 3e-2 and np.median(errs) < 0.25
 
 
-def test_vit_huge_is_declared_unsupported():
-    with pytest.raises(NotImplementedError):
-        VM().vit_huge_patch14_224_in21k()
+def test_vit_huge_factory_and_bf16_mode():
+    """The ViT-H/14 factory (vit_model.py:649-662) builds the reference's module tree; a 2-block cut of that geometry also runs
+    in bf16 mode (patch-embed GEMM stays fp32 because K = 588 is not a multiple of 8) and stays near the reference vectors."""
+    from deepmerge_amd.Losses import Loss
+    vm = VM()
+    net = vm.vit_huge_patch14_224_in21k(num_classes=100, has_logits=False)
+    assert len(net.blocks) == 32 and net.embed_dim == 1280 and net.patch_embed.num_patches == 256
+    assert net.blocks[0].attn.num_heads == 16 and sum(p.numel() for p in net.parameters()) == 630_892_900
+    del net
+    fx = load_fx("model_vit.npz")
+    tag = "vith14_d2"
+    net = vm.VisionTransformer(img_size=224, patch_size=14, embed_dim=1280, depth=2, num_heads=16, representation_size=None,
+                               num_classes=100, numerics="bf16")
+    net = load_recipe_weights(net).to(DEV).train()
+    x1, x2, flag = vit_inputs(tag)
+    ya, yb = net(x1.to(DEV), x2.to(DEV))
+    Loss(1.0, 0.1, 0)(ya, yb, flag.to(DEV)).backward()
+    e = recipe.summary_error(tag + "/out_a", ya.detach().cpu().numpy(), fx)
+    errs = [recipe.summary_error(tag + "/grad/" + n, p.grad.cpu().numpy(), fx, k=512)[0] for n, p in net.named_parameters()]
+    print(f"ViT-H/14 (2 blocks) bf16 drift: embeddings rel-L2 {e[0]:.2e}; median grad rel-L2 {np.median(errs):.2e}")
+    assert e[0] < 3e-2 and np.median(errs) < 0.25

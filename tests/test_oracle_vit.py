@@ -28,10 +28,13 @@ def scale_inputs(tag):
     return xa, fa, xb, fb, torch.tensor([1, 0], dtype=torch.int64)
 
 
-@pytest.mark.parametrize("tag,depth", [("vitb16_d2", 2), ("vitb16_d12", 12)])
+VITH = dict(patch=14, dim=1280, heads=16, hidden=5120)       # vit_model.py:649-662 geometry (head dim 80, 257 tokens)
+
+
+@pytest.mark.parametrize("tag,depth", [("vitb16_d2", 2), ("vitb16_d12", 12), ("vith14_d2", 2)])
 def test_vision_transformer_pair(tag, depth):
     fx = load_fx("model_vit.npz")
-    cfg = OV.VitConfig(depth=depth, num_classes=100)
+    cfg = OV.VitConfig(depth=depth, num_classes=100, **(VITH if tag.startswith("vith") else {}))
     spec = OV.vit_param_spec(cfg)
     assert list(spec.keys()) == [str(k) for k in fx[tag + "/manifest_keys"]]
     assert [",".join(map(str, s)) for s, _ in spec.values()] == [str(s) for s in fx[tag + "/manifest_shapes"]]
