@@ -50,8 +50,12 @@ def test_argument_validation_needs_no_gpu(built_lib):
     a.M, a.N, a.K = 0, 8, 8
     assert lib.dm_gemm(ctypes.byref(a), None) == -1
     assert b"M,N,K" in lib.dm_last_error()
-    assert lib.dm_attention_fwd(None, None, None, None, 1, 300, 12, 64, 0.125, 0, None) == -1
-    assert b"N <= 256" in lib.dm_last_error()
+    assert lib.dm_attention_fwd(None, None, None, None, 1, 5000, 12, 64, 0.125, 0, None) == -1
+    assert b"N <= 4096" in lib.dm_last_error()
+    assert lib.dm_attention_fwd(None, None, None, None, 1, 300, 12, 80, 0.125, 0, None) == -1     # generic family: null pointers
+    assert b"bad arguments" in lib.dm_last_error()
+    assert lib.dm_layernorm_fwd(None, None, None, None, 0, None, None, 4, 8196, 1e-5, None) == -1
+    assert b"<= 8192" in lib.dm_last_error()
     assert lib.dm_edge_similarity(1, 1, 1, None, 4, 1000, 1.0, None) == -6
 
 
