@@ -40,6 +40,10 @@ bool dm_gemm256_plan(GemmParams &p, int layout, int ab_dtype, bool can_split, lo
 void dm_gemm256_launch(const GemmParams &p, int layout, hipStream_t s);
 int dm_gemm_ring_plan(GemmParams &p, int layout, int ab_dtype, bool aligned8);      // dm_gemm_ring.hip
 void dm_gemm_ring_launch(const GemmParams &p, int wm, hipStream_t s);
+int dm_gemm_p192_plan(GemmParams &p, int layout, int ab_dtype, bool aligned8);      // dm_gemm_p192.hip (returns the grid size, 0 = not taken)
+void dm_gemm_p192_launch(const GemmParams &p, int layout, int grid, hipStream_t s);
+int dm_gemm_w4_plan(GemmParams &p, int layout, int ab_dtype, bool aligned8);        // dm_gemm_w4.hip (returns the grid size, 0 = not taken)
+void dm_gemm_w4_launch(const GemmParams &p, int layout, int grid, hipStream_t s);
 
 namespace {
 
@@ -588,11 +592,15 @@ extern "C" int dm_gemm(const DmGemmArgs *a, void *stream) {
   // two-workgroups-per-CU ring kernel (k-contiguous operands, 16-byte row pieces in the epilogue)
   const bool ring_aligned = (a->ldc % 8 == 0) && (a->aux == nullptr || a->ldaux % 8 == 0) &&
                             (a->rows_per_group == 0 || a->group_stride % 8 == 0) && a->split_k <= 1 && !a->colsum_a;
-  const int ring = dm_gemm_ring_plan(p, a->layout, a->ab_dtype, ring_aligned);
-  const bool big = !ring && dm_gemm256_plan(p, a->layout, a->ab_dtype, can_split, slab_bytes, a->split_k);
-  const int tile = ring ? (ring == 8 ? 2568 : 1288) : big ? 256 : pick_tile(a->layout, a->M, a->N, a->K);
-  int split = ring ? 1 : p.split_k;
-  if (!big && !ring) {
+  // persistent 256x192 pipeline (whole rounds of tiles on the 16384-token stage), then the ring kernel, then the 256x256 pipeline
+  const int w4 = dm_gemm_w4_plan(p, a->layout, a->ab_dtype, ring_aligned);
+  const int p192 = w4 ? 0 : dm_gemm_p192_plan(p, a->layout, a->ab_dtype, ring_aligned);
+  const bool persistent = w4 || p192;
+  const int ring = persistent ? 0 : dm_gemm_ring_plan(p, a->layout, a->ab_dtype, ring_aligned);
+  const bool big = !persistent && !ring && dm_gemm256_plan(p, a->layout, a->ab_dtype, can_split, slab_bytes, a->split_k);
+  const int tile = w4 ? 1924 : p192 ? 192 : ring ? (ring == 8 ? 2568 : 1288) : big ? 256 : pick_tile(a->layout, a->M, a->N, a->K);
+  int split = (ring || persistent) ? 1 : p.split_k;
+  if (!big && !ring && !persistent) {
     p.tiles_m = (a->M + tile - 1) / tile;
     p.tiles_n = (a->N + tile - 1) / tile;
     const int bk = (a->ab_dtype == DM_BF16) ? 64 : 32;
@@ -629,7 +637,11 @@ extern "C" int dm_gemm(const DmGemmArgs *a, void *stream) {
                      esz * ((double)a->M * a->K + (double)a->N * a->K) + csz * mn * (a->accumulate ? 2.0 : 1.0) +
                          (a->residual ? 4.0 * mn : 0.0) + (a->aux ? ((a->aux_dtype == DM_BF16) ? 2.0 : 4.0) * mn : 0.0));
     p.colsum_slab = (big && cs_region) ? cs_region : nullptr;
-    if (ring) {
+    if (w4) {
+      dm_gemm_w4_launch(p, a->layout, w4, s);
+    } else if (p192) {
+      dm_gemm_p192_launch(p, a->layout, p192, s);
+    } else if (ring) {
       dm_gemm_ring_launch(p, ring, s);
     } else if (big) {
       dm_gemm256_launch(p, a->layout, s);

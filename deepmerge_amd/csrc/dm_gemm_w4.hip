@@ -1,0 +1,444 @@
+// Persistent 256x192x64 bf16 GEMM, four 512-register waves per CU (gfx950): forward (NT) and dgrad (NN) products of the
+// 16384-token stage.
+//
+// Why this shape of kernel.  Ablations of the LDS-DMA pipelines (profiles/r02_p192_ablations.txt) show the matrix pipe alone
+// runs a K step in 0.64 us and the operand fill alone in 0.6-0.9 us, but with two LDS buffers only ~1.3 K steps of fill are
+// in flight, every step waits for its slowest piece (a first-touch L2 miss is ~1.5 us under load), and the 8-wave ping-pong
+// exposes its fragment reads: ~1.15 us per step whatever the tile.  LDS (160 KiB) cannot hold a third buffer; the register
+// file (512 KiB per CU) can.  So, like the vendor library's kernels for these shapes (tools/mb_yardstick.py):
+//   * 4 waves (2 x 2), one per SIMD, 128 x 96 outputs each (48 accumulator tiles = 192 registers): 30 % fewer LDS fragment
+//     bytes per MFMA than 8 waves of 64 x 96;
+//   * operands go global -> registers -> LDS; two register sets hold the K steps s+2 and s+3 while step s+1 sits in the second
+//     LDS buffer: 2-3 K steps of fill in flight;
+//   * one barrier per K step, in the middle of it: [ks 0 MFMAs | fragment reads of ks 1, ds_write of step s+1, global loads of
+//     step s+3] barrier [ks 1 MFMAs | fragment reads of step s+1, ks 0];
+//   * persistent: grid = min(tiles, CUs), a workgroup walks its tiles (L, L + grid, ...) as one flattened sequence of K steps,
+//     so the fill never drains at a tile boundary; 256 x 192 tiles make N = 768 / 2304 / 3072 at M = 16384 whole rounds of
+//     the 256 CUs;
+//   * fused epilogue through a per-wave LDS staging region that is not shared with the K-step buffers.
+// Loads past the end of the sequence use a null buffer descriptor (zero-filled, no traffic): no tail special cases.
+#include <cstdlib>
+#include <type_traits>
+
+#include "dm_common.h"
+#include "dm_gemm_common.h"
+#include "dm_mfma.h"
+
+namespace dmw4 {
+
+constexpr int TM = 256, TN = 192, BK = 64;
+constexpr int A_BYTES = TM * 128;              // 32 KiB
+constexpr int B_BYTES = TN * 128;              // 24 KiB
+constexpr int BUF_BYTES = A_BYTES + B_BYTES;   // 56 KiB
+constexpr int EPI_WAVE = 16 * 96 * 4;          // 16 rows x 96 fp32, XOR-swizzled
+constexpr int LDS_BYTES = 2 * BUF_BYTES + 4 * EPI_WAVE;   // 136 KiB
+
+template <int V> using IC = std::integral_constant<int, V>;
+
+// The accumulator tile stays in the SAME four AGPRs ("+a": destination tied to the addend).  With the builtin the register
+// allocator, under this kernel's pressure, splits the 48 accumulator live ranges and shuffles them AGPR <-> VGPR around every MFMA.
+// Operand order as in dm_mfma.h (swapped: a lane ends with 4 consecutive n of row m = lane & 15).
+// acc = 0 in place (0 * 0 + 0 on the matrix pipe).  A plain assignment makes the compiler materialise all 48 zero tiles in AGPR-class
+// registers next to the live accumulators (384 > 256 -> scratch spills inside the K loop).
+__device__ __forceinline__ void zero_pinned(f32x4 &acc, const u32x4 &z) {
+  asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %1, 0" : "=a"(acc) : "v"(z));      // (the compiler cannot see the MFMA: its VALU-write -> MFMA-read wait states are inserted by hand)
+}
+__device__ __forceinline__ void mma_pinned(f32x4 &acc, const u32x4 &a, const u32x4 &b) {
+  asm volatile("s_nop 0\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(b), "v"(a));
+}
+
+// DBG (ablation builds only, -DDM_W4_ABLATE): 1 no epilogue, 4 no global loads, 8 no LDS writes, 16 no fragment reads, 32 no MFMAs
+template <int LAYOUT, int DBG = 0>
+__global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmParams p) {
+  constexpr bool BMM = (LAYOUT == DM_NN);      // B m-contiguous [K][N] (dgrad) or k-contiguous [N][K] (forward)
+  constexpr int NB = BMM ? 8 : 6;              // global loads of B per thread and K step
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = wave & 1, wn = wave >> 1;
+  const int g = lane >> 4, li = lane & 15;
+
+  const int G = gridDim.x;
+  const int L = dm_xcd_remap(blockIdx.x, G);
+  const int tiles = p.tiles_m * p.tiles_n;
+  const int ntile = p.K / BK;
+  const int n_my = (tiles - L + G - 1) / G;    // tiles L, L + G, ...
+  const int total = n_my * ntile;
+
+  // ---- global -> register mapping -----------------------------------------------------------------------------------------------
+  // k-contiguous operand: load u of a thread is the 16-byte chunk (t & 7) of tile row (t >> 3) + 32 u; LDS image = rows of 128 B,
+  // slot s of row r holds chunk s ^ (r & 7).
+  const int lrow = t >> 3, lchunk = t & 7;
+  const int voA = (int)(((long long)lrow * p.lda + lchunk * 8) * 2);
+  const int strideA = (int)(32 * p.lda * 2);
+  const int wA = lrow * 128 + ((lchunk ^ (lrow & 7)) << 4);           // + u * 4096
+  int voB, strideB, stepB, wB0, wB1;
+  if constexpr (!BMM) {
+    voB = (int)(((long long)lrow * p.ldb + lchunk * 8) * 2);
+    strideB = (int)(32 * p.ldb * 2);
+    stepB = BK * 2;
+    wB0 = wB1 = wA;                                                   // + u * 4096
+  } else {
+    // m-contiguous operand [K][N]: threads 0..191 load chunk c24 = t % 24 (8 columns) of k-row t / 24 + 8 u.  LDS image = 3 bands of
+    // [64 k-rows][64 columns = 128 B]; the 32-byte slot index of k-row r is XORed with f(r) = ((r >> 1) & 1) | (((r >> 3) & 1) << 1).
+    const int krow = t / 24, c24 = t - krow * 24, band = c24 >> 3, c8 = c24 & 7;
+    voB = (int)(((long long)krow * p.ldb + c24 * 8) * 2);
+    strideB = (int)(8 * p.ldb * 2);
+    stepB = (int)(BK * p.ldb * 2);
+    const int f0 = (krow >> 1) & 1;
+    wB0 = band * 8192 + krow * 128 + (((c8 >> 1) ^ f0) << 5) + ((c8 & 1) << 4);          // even u: + u * 1024
+    wB1 = band * 8192 + krow * 128 + (((c8 >> 1) ^ (f0 | 2)) << 5) + ((c8 & 1) << 4);    // odd u
+  }
+  const bool b_loader = !BMM || t < 192;
+
+  // ---- fragment offsets -----------------------------------------------------------------------------------------------------------
+  const int offA0 = (wm * 128 + li) * 128 + ((g ^ (li & 7)) << 4), offA1 = (wm * 128 + li) * 128 + (((4 + g) ^ (li & 7)) << 4);
+  int offB[6];      // NT: [0], [1] = the two k-steps (+ j * 2048); NN: one per column tile (+ ks * 4096, + 512 for the upper 4 k-rows)
+  if constexpr (!BMM) {
+    offB[0] = (wn * 96 + li) * 128 + ((g ^ (li & 7)) << 4);
+    offB[1] = (wn * 96 + li) * 128 + (((4 + g) ^ (li & 7)) << 4);
+    offB[2] = offB[3] = offB[4] = offB[5] = 0;
+  } else {
+    const int q = li >> 2, pq = li & 3;
+    const int rbase = (8 * g + q) * 128 + 8 * pq;
+    const int fr = ((q >> 1) & 1) | ((g & 1) << 1);
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      const int cb = wn * 6 + j;
+      offB[j] = (cb >> 2) * 8192 + rbase + (((cb & 3) ^ fr) << 5);
+    }
+  }
+
+  // ---- tile cursors (uniform) -------------------------------------------------------------------------------------------------------
+  const bf16_t *Ab = reinterpret_cast<const bf16_t *>(p.A), *Bb = reinterpret_cast<const bf16_t *>(p.B);
+  auto tile_mn = [&](int r, int &m0, int &n0) __attribute__((always_inline)) {
+    const int tid = (DBG & 64) ? (L & 7) : L + r * G;        // (ablation 64: every workgroup reads the same few L2-resident tiles)
+    const int tm = tid / p.tiles_n;
+    m0 = tm * TM;
+    n0 = (tid - tm * p.tiles_n) * TN;
+  };
+  auto make_a = [&](int m0, bool live) __attribute__((always_inline)) {
+    const long long bytes = ((long long)(min(TM, p.M - m0) - 1) * p.lda + p.K) * 2;
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t *>(Ab + (long long)m0 * p.lda), 0, live ? (int)min(bytes, 0x7fffffffLL) : 0, 0x00020000);
+  };
+  auto make_b = [&](int n0, bool live) __attribute__((always_inline)) {
+    if constexpr (!BMM) {
+      const long long bytes = ((long long)(min(TN, p.N - n0) - 1) * p.ldb + p.K) * 2;
+      return __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t *>(Bb + (long long)n0 * p.ldb), 0, live ? (int)min(bytes, 0x7fffffffLL) : 0, 0x00020000);
+    } else {
+      const long long bytes = ((long long)(p.K - 1) * p.ldb + (p.N - n0)) * 2;
+      return __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t *>(Bb + n0), 0, live ? (int)min(bytes, 0x7fffffffLL) : 0, 0x00020000);
+    }
+  };
+  int m_cur, n_cur;
+  tile_mn(0, m_cur, n_cur);
+  // Staging schedule.  The 8 + NB pieces (16-byte-per-thread loads) of a K step are split into two groups of PH = (8 + NB) / 2:
+  // group X (pieces 0 .. PH-1) and group Y (the rest); piece q is A load q for q < 8, else B load q - 8.  K step j waits in register
+  // set j & 1.  During K step s:
+  //   k-step 0 (before the mid-step barrier): group Y of step s + 1 goes set -> LDS buffer (s + 1) & 1, the set entry is refilled
+  //            with step s + 3;
+  //   k-step 1 (after the barrier, when nobody reads buffer s & 1 any more): group X of step s + 2 goes set -> buffer s & 1, refilled
+  //            with step s + 4.
+  // So the ds_write_b128 (the VGPR -> LDS path moves ~79 B/clk per CU: 56 KiB of a step = ~730 cycles) are spread one per row tile
+  // over the WHOLE step instead of two per row tile over half of it.  Two load cursors (one per group); past the end of the
+  // sequence: null descriptors, the loads return zeros.
+  constexpr int PH = (8 + NB) / 2;
+  struct Cursor { int r, k; };
+  Cursor cx{0, 0}, cy{0, 0};
+  __amdgpu_buffer_rsrc_t rsAx = make_a(m_cur, true), rsBx = make_b(n_cur, true), rsAy = rsAx, rsBy = rsBx;
+  auto advance_x = [&]() __attribute__((always_inline)) {
+    if (++cx.k == ntile) {
+      cx.k = 0; ++cx.r;
+      int m0 = 0, n0 = 0;
+      const bool live = cx.r < n_my;
+      if (live) tile_mn(cx.r, m0, n0);
+      rsAx = make_a(m0, live);
+      rsBx = make_b(n0, live);
+    }
+  };
+  auto advance_y = [&]() __attribute__((always_inline)) {
+    if (++cy.k == ntile) {
+      cy.k = 0; ++cy.r;
+      int m0 = 0, n0 = 0;
+      const bool live = cy.r < n_my;
+      if (live) tile_mn(cy.r, m0, n0);
+      rsAy = make_a(m0, live);
+      rsBy = make_b(n0, live);
+    }
+  };
+
+  u32x4 ga[2][8], gb[2][NB];
+  u32x4 vzero;
+  asm volatile("v_mov_b32 %0, 0" : "=v"(vzero[0]));
+  vzero[1] = vzero[2] = vzero[3] = vzero[0];
+  asm volatile("s_nop 7" ::: "memory");
+  if constexpr (DBG & 4) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) ga[0][u] = ga[1][u] = vzero;
+#pragma unroll
+    for (int u = 0; u < NB; ++u) gb[0][u] = gb[1][u] = vzero;
+  }
+  // fetch piece q of the group cursor's K step into register set `set`
+  auto gload = [&](auto set_tag, auto grp_tag, int q) __attribute__((always_inline)) {
+    if constexpr (DBG & 4) return;
+    constexpr int set = decltype(set_tag)::value;
+    constexpr bool GX = decltype(grp_tag)::value == 0;
+    const int k = GX ? cx.k : cy.k;
+    if (q < 8) ga[set][q] = __builtin_amdgcn_raw_buffer_load_b128(GX ? rsAx : rsAy, voA, k * (BK * 2) + q * strideA, 0);
+    else if (b_loader) gb[set][q - 8] = __builtin_amdgcn_raw_buffer_load_b128(GX ? rsBx : rsBy, voB, k * stepB + (q - 8) * strideB, 0);
+  };
+  // piece q: register set -> LDS buffer
+  auto lwrite = [&](auto set_tag, auto buf_tag, int q) __attribute__((always_inline)) {
+    if constexpr (DBG & 8) return;
+    constexpr int set = decltype(set_tag)::value;
+    char *a = smem + decltype(buf_tag)::value * BUF_BYTES;
+    if (q < 8) {
+      *reinterpret_cast<u32x4 *>(a + wA + q * 4096) = ga[set][q];
+    } else if (b_loader) {
+      const int u = q - 8;
+      if constexpr (!BMM) *reinterpret_cast<u32x4 *>(a + A_BYTES + wB0 + u * 4096) = gb[set][u];
+      else *reinterpret_cast<u32x4 *>(a + A_BYTES + ((u & 1) ? wB1 : wB0) + u * 1024) = gb[set][u];
+    }
+  };
+
+  f32x4 acc[8][6];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 6; ++j) zero_pinned(acc[i][j], vzero);
+  // Fragments: B double-buffered (the next k-step's six tiles load while this one's are in use); A rotates in place (row tile i's
+  // fragment is dead after its six MFMAs and is reloaded for the next k-step at once) -- the arch-VGPR budget is 256.
+  u32x4 fa[8], fb[2][6];
+  if constexpr (DBG & 16) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) fa[i] = vzero;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) fb[0][j] = fb[1][j] = vzero;
+  }
+
+  auto read_a = [&](int i, auto ks_tag, auto buf_tag) __attribute__((always_inline)) {
+    constexpr int ks = decltype(ks_tag)::value;
+    if constexpr (DBG & 16) return fa[i];
+    const char *a = smem + decltype(buf_tag)::value * BUF_BYTES;
+    return *reinterpret_cast<const u32x4 *>(a + i * 2048 + (ks ? offA1 : offA0));
+  };
+  auto load_b1 = [&](int j, auto ks_tag, auto buf_tag) __attribute__((always_inline)) {
+    constexpr int ks = decltype(ks_tag)::value;
+    if constexpr (DBG & 16) return;
+    const char *b = smem + decltype(buf_tag)::value * BUF_BYTES + A_BYTES;
+    if constexpr (!BMM) {
+      fb[ks][j] = *reinterpret_cast<const u32x4 *>(b + j * 2048 + offB[ks]);
+    } else {
+      const u32x2 lo = dm_ds_read_tr16(b + offB[j] + ks * 4096);
+      const u32x2 hi = dm_ds_read_tr16(b + offB[j] + ks * 4096 + 512);
+      fb[ks][j] = (u32x4){lo[0], lo[1], hi[0], hi[1]};
+    }
+  };
+  // 48 MFMAs of k-step KS, row tile by row tile.  A wave issues in order, so everything else is placed BETWEEN the MFMAs (one
+  // piece after each, scheduling fences in between): the matrix pipe takes 16 cycles per MFMA, the pieces fit in its shadow.
+  //   after MFMA 0: read the row tile's A fragment of the NEXT k-step (NKS of buffer NBUF; it replaces fa[i] after the row)
+  //   after MFMA 2: staging piece i of this phase's group (GRP: 0 = X, 1 = Y): register set SSET -> LDS buffer SBUF
+  //   after MFMA 3: the freed set entry is refilled from global memory
+  //   after MFMA 5: B fragment i of the next k-step (rows 0..5)
+  auto mfmas = [&](auto ks_tag, auto nks_tag, auto nbuf_tag, auto grp_tag, auto sset_tag, auto sbuf_tag) __attribute__((always_inline)) {
+    constexpr int ks = decltype(ks_tag)::value;
+    constexpr int q0 = decltype(grp_tag)::value == 0 ? 0 : PH;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+#define mma_pinned(A_, B_, C_) do { if constexpr (!(DBG & 32)) (mma_pinned)(A_, B_, C_); } while (0)
+      mma_pinned(acc[i][0], fa[i], fb[ks][0]);
+      const u32x4 na = read_a(i, nks_tag, nbuf_tag);
+      __builtin_amdgcn_sched_barrier(0);
+      mma_pinned(acc[i][1], fa[i], fb[ks][1]);
+      __builtin_amdgcn_sched_barrier(0);
+      mma_pinned(acc[i][2], fa[i], fb[ks][2]);
+      if (i < PH) lwrite(sset_tag, sbuf_tag, q0 + i);
+      __builtin_amdgcn_sched_barrier(0);
+      mma_pinned(acc[i][3], fa[i], fb[ks][3]);
+      if (i < PH) gload(sset_tag, grp_tag, q0 + i);
+      __builtin_amdgcn_sched_barrier(0);
+      mma_pinned(acc[i][4], fa[i], fb[ks][4]);
+      __builtin_amdgcn_sched_barrier(0);
+      mma_pinned(acc[i][5], fa[i], fb[ks][5]);
+      if (i < 6) load_b1(i, nks_tag, nbuf_tag);
+      fa[i] = na;
+      __builtin_amdgcn_sched_barrier(0);
+#undef mma_pinned
+    }
+    if constexpr (decltype(grp_tag)::value == 0) advance_x(); else advance_y();
+  };
+
+  int kt = 0, r = 0;
+  const int lane_outer = lane;
+  // Tile finished: fused epilogue.  The two waves that share the tile's rows (wn = 0 / 1) transpose 16 rows x 192 columns through a
+  // common LDS slab and then each walks 8 of the rows whole: a row is 24 lanes x 8 columns, so bias / residual / aux reads and the C
+  // stores are complete 128-byte lines (a wave's own 96 columns = 192 B of bf16 would end in half lines, which the memory system
+  // pays for with read-modify-writes: measured 2.6 TB/s of stores).  K-step buffers untouched: the staging of the next tile goes on.
+  auto epilogue = [&]() __attribute__((always_inline)) {
+    char *slab = smem + 2 * BUF_BYTES + wm * (2 * EPI_WAVE);           // 16 rows x 768 B, XOR-swizzled 16-byte chunks
+    const int m_pair = m_cur + wm * 128;
+    // the lane-dependent addresses of the epilogue are recomputed here from an opaque copy of the lane id: hoisted out of the K
+    // loop they would occupy ~30 registers that the fragment / staging sets need
+    int lane = lane_outer;
+    asm volatile("" : "+v"(lane));
+    const int g = lane >> 4, li = lane & 15;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+        *reinterpret_cast<f32x4 *>(slab + li * 768 + (((wn * 24 + j * 4 + g) ^ (li & 7)) << 4)) = acc[i][j];
+        zero_pinned(acc[i][j], vzero);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+#pragma nounroll
+      for (int q3 = 0; q3 < 3; ++q3) {               // (a real loop: unrolled, its three bodies' temporaries overlap and spill)
+        const int item = q3 * 64 + lane;             // 8 rows x 24 groups of 8 columns
+        const int rr = item / 24, cg = item - rr * 24;
+        const int row = wn * 8 + rr;
+        const f32x4 lo = *reinterpret_cast<const f32x4 *>(slab + row * 768 + (((2 * cg) ^ (row & 7)) << 4));
+        const f32x4 hi = *reinterpret_cast<const f32x4 *>(slab + row * 768 + (((2 * cg + 1) ^ (row & 7)) << 4));
+        int m = m_pair + i * 16 + row;
+        if constexpr (DBG & 256) m = wm * 128 + i * 16 + row;         // (ablation: every workgroup stores to the same 256 rows)
+        if constexpr (DBG & 128) { if (lo[0] == 12345.678f) dm_gemm_emit8(p, lo, hi, dm_gemm_row(p, m), n_cur + cg * 8); }
+        else if (m < p.M) dm_gemm_emit8(p, lo, hi, dm_gemm_row(p, m), (DBG & 256) ? cg * 8 : n_cur + cg * 8);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the next row tile overwrites the slab
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    kt = 0;
+    ++r;
+    if (r < n_my) tile_mn(r, m_cur, n_cur);
+  };
+
+  // One K step.  PAR = step & 1 = its LDS buffer; step s + 1 waits in register set (s + 1) & 1 = 1 - PAR and goes to buffer 1 - PAR;
+  // the freed set then fetches step s + 3.
+  auto body = [&](auto par_tag) __attribute__((always_inline)) {
+    constexpr int PAR = decltype(par_tag)::value;
+    mfmas(IC<0>{}, IC<1>{}, IC<PAR>{}, IC<1>{}, IC<1 - PAR>{}, IC<1 - PAR>{});     // k-step 0 (+ fragments of k-step 1; group Y of step s + 1)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    mfmas(IC<1>{}, IC<0>{}, IC<1 - PAR>{}, IC<0>{}, IC<PAR>{}, IC<PAR>{});         // k-step 1 (+ fragments of step s + 1; group X of step s + 2)
+  };
+
+  // ---- prologue: the state the schedule above expects at step 0 (buffer 0 complete, X(1) in buffer 1, Y(1) / X(2) / Y(2) / X(3) in flight) ----
+#pragma unroll
+  for (int q = 0; q < PH; ++q) gload(IC<0>{}, IC<0>{}, q);                 // X(0) -> set 0
+  advance_x();
+#pragma unroll
+  for (int q = PH; q < 2 * PH; ++q) gload(IC<0>{}, IC<1>{}, q);            // Y(0) -> set 0
+  advance_y();
+#pragma unroll
+  for (int q = 0; q < PH; ++q) gload(IC<1>{}, IC<0>{}, q);                 // X(1) -> set 1
+  advance_x();
+#pragma unroll
+  for (int q = PH; q < 2 * PH; ++q) gload(IC<1>{}, IC<1>{}, q);            // Y(1) -> set 1
+  advance_y();
+#pragma unroll
+  for (int q = 0; q < PH; ++q) { lwrite(IC<0>{}, IC<0>{}, q); gload(IC<0>{}, IC<0>{}, q); }               // X(0) -> buffer 0; X(2) -> set 0
+  advance_x();
+#pragma unroll
+  for (int q = PH; q < 2 * PH; ++q) { lwrite(IC<0>{}, IC<0>{}, q); gload(IC<0>{}, IC<1>{}, q); }          // Y(0) -> buffer 0; Y(2) -> set 0
+  advance_y();
+#pragma unroll
+  for (int q = 0; q < PH; ++q) { lwrite(IC<1>{}, IC<1>{}, q); gload(IC<1>{}, IC<0>{}, q); }               // X(1) -> buffer 1; X(3) -> set 1
+  advance_x();
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+#pragma unroll
+  for (int j = 0; j < 6; ++j) load_b1(j, IC<0>{}, IC<0>{});
+#pragma unroll
+  for (int i = 0; i < 8; ++i) fa[i] = read_a(i, IC<0>{}, IC<0>{});
+
+  // K % 128 == 0 (plan): a tile is an even number of K steps, so tiles end after an odd step only
+  for (int step = 0; step < total; step += 2) {
+    body(IC<0>{});
+    body(IC<1>{});
+    kt += 2;
+    if (kt == ntile) {
+      if constexpr (DBG & 1) { kt = 0; ++r; if (r < n_my) tile_mn(r, m_cur, n_cur); } else
+      epilogue();
+      // The next step's k-step-0 fragments were prefetched during the last MFMAs; holding their 56 registers across the epilogue
+      // (on top of the 88 staging registers in flight) overflows the register file, so they are read again here instead.
+#pragma unroll
+      for (int j = 0; j < 6; ++j) load_b1(j, IC<0>{}, IC<0>{});
+#pragma unroll
+      for (int i = 0; i < 8; ++i) fa[i] = read_a(i, IC<0>{}, IC<0>{});
+    }
+  }
+}
+
+}  // namespace dmw4
+
+namespace {
+template <int LAYOUT, int DBG = 0> bool w4_set_lds_limit() {
+  return hipFuncSetAttribute(reinterpret_cast<const void *>(dmw4::gemm_w4_kernel<LAYOUT, DBG>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                             dmw4::LDS_BYTES) == hipSuccess;
+}
+int w4_cu_count() {
+  static const int n = [] {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+    return cus;
+  }();
+  return n;
+}
+}  // namespace
+
+// Decides whether the 4-wave persistent kernel runs this product (bf16 NT / NN); fills p.tiles_m / tiles_n and returns the grid
+// size (0 = not taken).  `aligned8`: the 8-column epilogue (dm_gemm_emit8) is legal for C / aux / grouped rows.
+int dm_gemm_w4_plan(GemmParams &p, int layout, int ab_dtype, bool aligned8) {
+  using namespace dmw4;
+  const char *env = getenv("DM_GEMM_W4");         // 0 = off, 1 = routing rule, 2 = every legal product, 3 = every whole-round shape (read per call: tests flip it)
+  const int mode = env ? atoi(env) : 1;
+  if (mode == 0 || ab_dtype != DM_BF16 || !aligned8) return 0;
+  if (layout != DM_NT && layout != DM_NN) return 0;
+  if (p.K < 2 * BK || p.K % (2 * BK) != 0 || p.N % TN != 0) return 0;
+  const long long spanA = 256LL * p.lda * 2 + 2LL * p.K;
+  const long long spanB = (layout == DM_NN) ? (long long)p.K * p.ldb * 2 : 192LL * p.ldb * 2 + 2LL * p.K;
+  if (spanA >= (1LL << 31) || spanB >= (1LL << 31)) return 0;
+  const int tiles_m = (p.M + TM - 1) / TM, tiles_n = p.N / TN;
+  const long long tiles = (long long)tiles_m * tiles_n;
+  const int cus = w4_cu_count();
+  if (cus <= 0) return 0;
+  if (mode == 1) {
+    // One workgroup per CU, all of them in lockstep: a tile's stores (25 MB per round of the chip) are not hidden by anybody's MFMAs,
+    // ~10 us per round (tools/mb_w4_loop.py).  With ONE tile per workgroup that is paid once and the deep operand pipeline wins
+    // (dgrads into N = 768: -13 .. -15 %, fc2 forward: -3 %); with 3-4 tiles per workgroup the older kernels, whose 2-3 workgroups
+    // per CU overlap each other's epilogues, stay ahead (+14 .. +19 %).  mode 3 = every whole-round shape (for measurements).
+    if (tiles > cus || (double)tiles / (double)cus < 0.85) return 0;
+    // Inside the training step (tools/prof_shapes.py, per launch): dgrad 16384 x 768 x 3072 87 -> 79 us, x 2304 69 -> 62 us; the
+    // forward products of that shape write fp32 rows with a residual (epilogue-bound: 106 -> 106 us) and the K = 768 ones are all
+    // fill and epilogue (49 -> 57 us): those stay on the older kernels.
+    if (layout != DM_NN || p.K < 1536) return 0;
+  } else if (mode == 3) {
+    if (tiles < cus) return 0;
+    const long long rounds = (tiles + cus - 1) / cus;
+    if ((double)tiles / (double)(rounds * cus) < 0.85) return 0;
+  }
+  static const bool attr_ok = w4_set_lds_limit<DM_NT>() && w4_set_lds_limit<DM_NN>();
+  if (!attr_ok) return 0;
+  p.tiles_m = tiles_m;
+  p.tiles_n = tiles_n;
+  p.split_k = 1;
+  p.k_per_split = p.K;
+  return (int)(tiles < cus ? tiles : cus);
+}
+
+void dm_gemm_w4_launch(const GemmParams &p, int layout, int grid, hipStream_t s) {
+#ifdef DM_W4_ABLATE
+  if (layout == DM_NT) {
+    const char *denv = getenv("DM_W4_DEBUG");
+    const int dbg = denv ? atoi(denv) : 0;
+#define W4_CASE(D) case D: { static const bool ok = w4_set_lds_limit<DM_NT, D>(); (void)ok; \
+      hipLaunchKernelGGL((dmw4::gemm_w4_kernel<DM_NT, D>), dim3(grid), dim3(256), dmw4::LDS_BYTES, s, p); return; }
+    switch (dbg) { W4_CASE(1) W4_CASE(5) W4_CASE(13) W4_CASE(29) W4_CASE(33) W4_CASE(17) W4_CASE(9) W4_CASE(61) W4_CASE(45) W4_CASE(65) W4_CASE(73) W4_CASE(3) W4_CASE(128) W4_CASE(256) W4_CASE(320) W4_CASE(64) default: break; }
+#undef W4_CASE
+  }
+#endif
+  if (layout == DM_NT) hipLaunchKernelGGL((dmw4::gemm_w4_kernel<DM_NT, 0>), dim3(grid), dim3(256), dmw4::LDS_BYTES, s, p);
+  else hipLaunchKernelGGL((dmw4::gemm_w4_kernel<DM_NN, 0>), dim3(grid), dim3(256), dmw4::LDS_BYTES, s, p);
+}

@@ -68,6 +68,72 @@ def ring_env():
             os.environ[k] = v
 
 
+@pytest.fixture
+def p192_env():
+    """Route every legal bf16 NT / NN product to the persistent 256x192 pipeline (dm_gemm_p192.hip) for one test."""
+    import os
+    old = os.environ.get("DM_GEMM_P192")
+    os.environ["DM_GEMM_P192"] = "2"
+    yield
+    if old is None:
+        os.environ.pop("DM_GEMM_P192", None)
+    else:
+        os.environ["DM_GEMM_P192"] = old
+
+
+@pytest.fixture
+def w4_env():
+    """Route every legal bf16 NT / NN product to the 4-wave persistent kernel (dm_gemm_w4.hip) for one test."""
+    import os
+    old = os.environ.get("DM_GEMM_W4")
+    os.environ["DM_GEMM_W4"] = "2"
+    yield
+    if old is None:
+        os.environ.pop("DM_GEMM_W4", None)
+    else:
+        os.environ["DM_GEMM_W4"] = old
+
+
+@pytest.mark.parametrize("layout", ["NT", "NN"])
+@pytest.mark.parametrize("M,N,K", [(256, 192, 128), (512, 384, 256), (1000, 192, 768), (16, 768, 3072), (4096, 2304, 768),
+                                   (66000, 192, 128), (33000, 384, 256), (16384, 768, 128)])
+def test_gemm_w4_exact_integers(w4_env, layout, M, N, K):
+    """Exact small-integer products through the 4-wave persistent kernel (register-staged operands, tiles chained into one K-step
+    sequence): one to several tiles per workgroup, ragged M, 2 .. 48 K steps, both layouts of B."""
+    test_gemm_p192_exact_integers(None, layout, M, N, K)
+
+
+def test_gemm_w4_epilogues(w4_env):
+    test_gemm_epilogues("bf16", M=512, N=384)
+
+
+@pytest.mark.parametrize("layout", ["NT", "NN"])
+@pytest.mark.parametrize("M,N,K", [(256, 192, 128), (512, 384, 192), (1000, 192, 768), (16, 768, 3072), (4096, 2304, 768),
+                                   (66000, 192, 128), (33000, 384, 256), (16384, 768, 128)])
+def test_gemm_p192_exact_integers(p192_env, layout, M, N, K):
+    """Exact small-integer products through the persistent kernel: one to several tiles per workgroup (the flattened K-step
+    sequence crosses tile boundaries), ragged M, 2 .. 48 K steps, both operand layouts of B; fp32 and bf16 outputs."""
+    ops = _ops()
+    from deepmerge_amd._lib import DM_NN, DM_NT
+    rng = np.random.default_rng(M + 3 * N + 7 * K)
+    a = _ints(rng, (M, K))
+    b = _ints(rng, (N, K) if layout == "NT" else (K, N))
+    want = a.double() @ (b.double().T if layout == "NT" else b.double())
+    A, B_ = a.to(DEV).to(torch.bfloat16), b.to(DEV).to(torch.bfloat16)
+    lay, ldb = (DM_NT, K) if layout == "NT" else (DM_NN, N)
+    Cc = torch.full((M + 3, N), float("nan"), device=DEV)
+    ops.gemm(lay, A, B_, Cc, M, N, K, lda=K, ldb=ldb, ldc=N)
+    assert torch.equal(Cc[:M].cpu().double(), want), f"max diff {(Cc[:M].cpu().double() - want).abs().max()}"
+    assert torch.isnan(Cc[M:]).all(), "rows past M must not be written"
+    Ch = torch.zeros((M, N), device=DEV, dtype=torch.bfloat16)
+    ops.gemm(lay, A, B_, Ch, M, N, K, lda=K, ldb=ldb, ldc=N)
+    assert torch.equal(Ch.cpu().double(), want.to(torch.bfloat16).double())
+
+
+def test_gemm_p192_epilogues(p192_env):
+    test_gemm_epilogues("bf16", M=512, N=384)
+
+
 @pytest.mark.parametrize("wm", [8, 4])
 @pytest.mark.parametrize("M,N,K", [(256, 128, 64), (512, 384, 96), (1000, 136, 768), (16, 768, 3072), (4096, 2304, 768), (300, 8, 160), (257, 264, 2304)])
 def test_gemm_ring_exact_integers(ring_env, wm, M, N, K):
@@ -96,12 +162,12 @@ def test_gemm_ring_epilogues(ring_env, wm):
 
 
 @pytest.mark.parametrize("mode", ["fp32", "bf16"])
-def test_gemm_epilogues(mode):
+def test_gemm_epilogues(mode, M=192, N=256):
     """bias, GELU (+saved pre-activation), DGELU, residual, accumulate, bf16 output, grouped rows."""
     ops = _ops()
     from deepmerge_amd._lib import DM_EPI_DGELU, DM_EPI_GELU, DM_NN, DM_NT
     rng = np.random.default_rng(5)
-    M, N, K = 192, 256, 128
+    K = 128
     dt = DT[mode]
     a, b = _ints(rng, (M, K), -2, 3), _ints(rng, (N, K), -2, 3)
     bias = torch.from_numpy(rng.normal(size=N).astype(np.float32))
@@ -145,7 +211,7 @@ def test_gemm_epilogues(mode):
     ops.gemm(DM_NT, A, B_, out3, M, N, K, lda=K, ldb=K, ldc=N, accumulate=True)
     np.testing.assert_allclose(out3.cpu().double().numpy(), (base + res.double()).numpy(), rtol=0, atol=2e-6)
     # grouped rows: groups of 64 rows land in slices of a [3, 100, N] cube at token offset 36
-    cube = torch.zeros((3, 100, N), device=DEV)
+    cube = torch.zeros((M // 64, 100, N), device=DEV)
     ops.gemm(DM_NT, A, B_, cube[:, 36:], M, N, K, lda=K, ldb=K, ldc=N, rows_per_group=64, group_stride=100 * N)
     np.testing.assert_allclose(cube[:, 36:].cpu().double().numpy().reshape(M, N), base.numpy(), rtol=0, atol=2e-6)
     assert float(cube[:, :36].abs().max()) == 0.0
