@@ -48,7 +48,7 @@ __device__ __forceinline__ void mma_pinned(f32x4 &acc, const u32x4 &a, const u32
 }
 
 // DBG (ablation builds only, -DDM_W4_ABLATE): 1 no epilogue, 4 no global loads, 8 no LDS writes, 16 no fragment reads, 32 no MFMAs
-template <int LAYOUT, int DBG = 0>
+template <int LAYOUT, int DBG = 0, int EPIU = 0>
 __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmParams p) {
   constexpr bool BMM = (LAYOUT == DM_NN);      // B m-contiguous [K][N] (dgrad) or k-contiguous [N][K] (forward)
   constexpr int NB = BMM ? 8 : 6;              // global loads of B per thread and K step
@@ -270,6 +270,29 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmParams p) {
 
   int kt = 0, r = 0;
   const int lane_outer = lane;
+  // Two K steps before a tile ends, one 4-byte load per 128-byte line pulls the tile of the epilogue's READ operands (fp32 residual;
+  // aux of the multiply / GELU' epilogues) towards L2: the epilogue walks rows with few bytes in flight and would otherwise pay an
+  // HBM round trip per pass (fc2 forward: 39 us of epilogue for 67 us of K loop).  The loads are younger than every staged piece
+  // that is waited for in the meantime, so the in-order vmcnt of the operand pipeline never waits for them.
+  float tv[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};        // the touch loads' destinations: not read before the epilogue
+  auto touch_epilogue_operands = [&]() __attribute__((always_inline)) {
+    const int m = m_cur + t;                            // one row per thread
+    if (m >= p.M) return;
+    const DmGemmRow rb = dm_gemm_row(p, m);
+    if (p.residual) {
+#pragma unroll
+      for (int j = 0; j < 6; ++j) tv[j] = p.residual[rb.r + n_cur + j * 32];
+    } else if (p.aux && (p.epilogue == DM_EPI_DGELU || p.epilogue == DM_EPI_MUL)) {
+      if (p.aux_dtype == DM_F32) {
+#pragma unroll
+        for (int j = 0; j < 6; ++j) tv[j] = reinterpret_cast<const float *>(p.aux)[rb.x + n_cur + j * 32];
+      } else {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) tv[j] = __builtin_bit_cast(float, (unsigned)reinterpret_cast<const unsigned short *>(p.aux)[rb.x + n_cur + j * 64]);
+      }
+    }
+  };
+
   // Tile finished: fused epilogue.  The two waves that share the tile's rows (wn = 0 / 1) transpose 16 rows x 192 columns through a
   // common LDS slab and then each walks 8 of the rows whole: a row is 24 lanes x 8 columns, so bias / residual / aux reads and the C
   // stores are complete 128-byte lines (a wave's own 96 columns = 192 B of bf16 would end in half lines, which the memory system
@@ -280,7 +303,7 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmParams p) {
     // the lane-dependent addresses of the epilogue are recomputed here from an opaque copy of the lane id: hoisted out of the K
     // loop they would occupy ~30 registers that the fragment / staging sets need
     int lane = lane_outer;
-    asm volatile("" : "+v"(lane));
+    asm volatile("" : "+v"(lane) : "v"(tv[0]), "v"(tv[1]), "v"(tv[2]), "v"(tv[3]), "v"(tv[4]), "v"(tv[5]));   // (the use that keeps the touch loads alive)
     const int g = lane >> 4, li = lane & 15;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -292,8 +315,7 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmParams p) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
-#pragma nounroll
-      for (int q3 = 0; q3 < 3; ++q3) {               // (a real loop: unrolled, its three bodies' temporaries overlap and spill)
+      auto pass = [&](int q3) __attribute__((always_inline)) {               // (unrolled: the three bodies' residual / aux loads are in flight together)
         const int item = q3 * 64 + lane;             // 8 rows x 24 groups of 8 columns
         const int rr = item / 24, cg = item - rr * 24;
         const int row = wn * 8 + rr;
@@ -303,6 +325,12 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmParams p) {
         if constexpr (DBG & 256) m = wm * 128 + i * 16 + row;         // (ablation: every workgroup stores to the same 256 rows)
         if constexpr (DBG & 128) { if (lo[0] == 12345.678f) dm_gemm_emit8(p, lo, hi, dm_gemm_row(p, m), n_cur + cg * 8); }
         else if (m < p.M) dm_gemm_emit8(p, lo, hi, dm_gemm_row(p, m), (DBG & 256) ? cg * 8 : n_cur + cg * 8);
+            };
+      if constexpr (EPIU) {        // unrolled: the three bodies' residual / aux loads are in flight together
+        pass(0); pass(1); pass(2);
+      } else {
+#pragma nounroll
+        for (int q3 = 0; q3 < 3; ++q3) pass(q3);
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the next row tile overwrites the slab
       __builtin_amdgcn_s_barrier();
@@ -354,6 +382,7 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmParams p) {
 
   // K % 128 == 0 (plan): a tile is an even number of K steps, so tiles end after an odd step only
   for (int step = 0; step < total; step += 2) {
+    if (kt + 2 == ntile) touch_epilogue_operands();
     body(IC<0>{});
     body(IC<1>{});
     kt += 2;
@@ -373,8 +402,8 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmParams p) {
 }  // namespace dmw4
 
 namespace {
-template <int LAYOUT, int DBG = 0> bool w4_set_lds_limit() {
-  return hipFuncSetAttribute(reinterpret_cast<const void *>(dmw4::gemm_w4_kernel<LAYOUT, DBG>), hipFuncAttributeMaxDynamicSharedMemorySize,
+template <int LAYOUT, int DBG = 0, int EPIU = 0> bool w4_set_lds_limit() {
+  return hipFuncSetAttribute(reinterpret_cast<const void *>(dmw4::gemm_w4_kernel<LAYOUT, DBG, EPIU>), hipFuncAttributeMaxDynamicSharedMemorySize,
                              dmw4::LDS_BYTES) == hipSuccess;
 }
 int w4_cu_count() {
@@ -404,22 +433,22 @@ int dm_gemm_w4_plan(GemmParams &p, int layout, int ab_dtype, bool aligned8) {
   const long long tiles = (long long)tiles_m * tiles_n;
   const int cus = w4_cu_count();
   if (cus <= 0) return 0;
-  if (mode == 1) {
+  if (mode == 1 || mode == 4 || mode == 5) {
     // One workgroup per CU, all of them in lockstep: a tile's stores (25 MB per round of the chip) are not hidden by anybody's MFMAs,
     // ~10 us per round (tools/mb_w4_loop.py).  With ONE tile per workgroup that is paid once and the deep operand pipeline wins
     // (dgrads into N = 768: -13 .. -15 %, fc2 forward: -3 %); with 3-4 tiles per workgroup the older kernels, whose 2-3 workgroups
     // per CU overlap each other's epilogues, stay ahead (+14 .. +19 %).  mode 3 = every whole-round shape (for measurements).
     if (tiles > cus || (double)tiles / (double)cus < 0.85) return 0;
-    // Inside the training step (tools/prof_shapes.py, per launch): dgrad 16384 x 768 x 3072 87 -> 79 us, x 2304 69 -> 62 us; the
-    // forward products of that shape write fp32 rows with a residual (epilogue-bound: 106 -> 106 us) and the K = 768 ones are all
-    // fill and epilogue (49 -> 57 us): those stay on the older kernels.
-    if (layout != DM_NN || p.K < 1536) return 0;
+    // Inside the training step (tools/prof_shapes.py, per launch, same box): dgrad 16384 x 768 x 3072 90 -> 77 us, x 2304 71 -> 64 us,
+    // fc2 forward (fp32 rows + residual, touched towards L2 two K steps ahead) 103 -> 99 us; the K = 768 products are all fill and
+    // epilogue (49 -> 57 us) and stay on the older kernels.
+    if (mode != 5 && p.K < 1536) return 0;        // (5: every one-round shape)
   } else if (mode == 3) {
     if (tiles < cus) return 0;
     const long long rounds = (tiles + cus - 1) / cus;
     if ((double)tiles / (double)(rounds * cus) < 0.85) return 0;
   }
-  static const bool attr_ok = w4_set_lds_limit<DM_NT>() && w4_set_lds_limit<DM_NN>();
+  static const bool attr_ok = w4_set_lds_limit<DM_NT>() && w4_set_lds_limit<DM_NN>() && w4_set_lds_limit<DM_NT, 0, 1>() && w4_set_lds_limit<DM_NN, 0, 1>();
   if (!attr_ok) return 0;
   p.tiles_m = tiles_m;
   p.tiles_n = tiles_n;
@@ -439,6 +468,15 @@ void dm_gemm_w4_launch(const GemmParams &p, int layout, int grid, hipStream_t s)
 #undef W4_CASE
   }
 #endif
-  if (layout == DM_NT) hipLaunchKernelGGL((dmw4::gemm_w4_kernel<DM_NT, 0>), dim3(grid), dim3(256), dmw4::LDS_BYTES, s, p);
-  else hipLaunchKernelGGL((dmw4::gemm_w4_kernel<DM_NN, 0>), dim3(grid), dim3(256), dmw4::LDS_BYTES, s, p);
+  // EPIU = 1 unrolls the epilogue's three row passes (their residual / aux loads in flight together).  Measured inside the training
+  // step it LOSES 12-15 % on every shape, with or without epilogue reads (tools/prof_shapes.py, same box): experiment knob only.
+  const char *uenv = getenv("DM_W4_EPI_UNROLL");
+  const bool unroll = uenv && atoi(uenv) != 0;
+  if (layout == DM_NT) {
+    if (unroll) hipLaunchKernelGGL((dmw4::gemm_w4_kernel<DM_NT, 0, 1>), dim3(grid), dim3(256), dmw4::LDS_BYTES, s, p);
+    else hipLaunchKernelGGL((dmw4::gemm_w4_kernel<DM_NT, 0, 0>), dim3(grid), dim3(256), dmw4::LDS_BYTES, s, p);
+  } else {
+    if (unroll) hipLaunchKernelGGL((dmw4::gemm_w4_kernel<DM_NN, 0, 1>), dim3(grid), dim3(256), dmw4::LDS_BYTES, s, p);
+    else hipLaunchKernelGGL((dmw4::gemm_w4_kernel<DM_NN, 0, 0>), dim3(grid), dim3(256), dmw4::LDS_BYTES, s, p);
+  }
 }
