@@ -42,7 +42,7 @@ int dm_gemm_ring_plan(GemmParams &p, int layout, int ab_dtype, bool aligned8);  
 void dm_gemm_ring_launch(const GemmParams &p, int wm, hipStream_t s);
 int dm_gemm_p192_plan(GemmParams &p, int layout, int ab_dtype, bool aligned8);      // dm_gemm_p192.hip (returns the grid size, 0 = not taken)
 void dm_gemm_p192_launch(const GemmParams &p, int layout, int grid, hipStream_t s);
-int dm_gemm_w4_plan(GemmParams &p, int layout, int ab_dtype, bool aligned8);        // dm_gemm_w4.hip (returns the grid size, 0 = not taken)
+int dm_gemm_w4_plan(GemmParams &p, int layout, int ab_dtype, bool aligned8, bool can_split, long long workspace_bytes);   // dm_gemm_w4.hip (grid size, 0 = not taken)
 void dm_gemm_w4_launch(const GemmParams &p, int layout, int grid, hipStream_t s);
 
 namespace {
@@ -593,13 +593,15 @@ extern "C" int dm_gemm(const DmGemmArgs *a, void *stream) {
   const bool ring_aligned = (a->ldc % 8 == 0) && (a->aux == nullptr || a->ldaux % 8 == 0) &&
                             (a->rows_per_group == 0 || a->group_stride % 8 == 0) && a->split_k <= 1 && !a->colsum_a;
   // persistent 256x192 pipeline (whole rounds of tiles on the 16384-token stage), then the ring kernel, then the 256x256 pipeline
-  const int w4 = dm_gemm_w4_plan(p, a->layout, a->ab_dtype, ring_aligned);
+  p.workspace = reinterpret_cast<float *>(a->workspace);
+  const bool w4_ok = (a->layout == DM_TN) ? (a->split_k == 0 && a->ldc % 4 == 0) : ring_aligned;     // wgrad: automatic slice count only
+  const int w4 = w4_ok ? dm_gemm_w4_plan(p, a->layout, a->ab_dtype, true, can_split, slab_bytes) : 0;
   const int p192 = w4 ? 0 : dm_gemm_p192_plan(p, a->layout, a->ab_dtype, ring_aligned);
   const bool persistent = w4 || p192;
   const int ring = persistent ? 0 : dm_gemm_ring_plan(p, a->layout, a->ab_dtype, ring_aligned);
   const bool big = !persistent && !ring && dm_gemm256_plan(p, a->layout, a->ab_dtype, can_split, slab_bytes, a->split_k);
   const int tile = w4 ? 1924 : p192 ? 192 : ring ? (ring == 8 ? 2568 : 1288) : big ? 256 : pick_tile(a->layout, a->M, a->N, a->K);
-  int split = (ring || persistent) ? 1 : p.split_k;
+  int split = w4 ? p.split_k : (ring || persistent) ? 1 : p.split_k;
   if (!big && !ring && !persistent) {
     p.tiles_m = (a->M + tile - 1) / tile;
     p.tiles_n = (a->N + tile - 1) / tile;
@@ -636,7 +638,7 @@ extern "C" int dm_gemm(const DmGemmArgs *a, void *stream) {
     DmProfScope prof(pname, s, 2.0 * a->M * a->N * a->K,
                      esz * ((double)a->M * a->K + (double)a->N * a->K) + csz * mn * (a->accumulate ? 2.0 : 1.0) +
                          (a->residual ? 4.0 * mn : 0.0) + (a->aux ? ((a->aux_dtype == DM_BF16) ? 2.0 : 4.0) * mn : 0.0));
-    p.colsum_slab = (big && cs_region) ? cs_region : nullptr;
+    p.colsum_slab = ((big || (w4 && a->layout == DM_TN)) && cs_region) ? cs_region : nullptr;
     if (w4) {
       dm_gemm_w4_launch(p, a->layout, w4, s);
     } else if (p192) {
@@ -652,21 +654,23 @@ extern "C" int dm_gemm(const DmGemmArgs *a, void *stream) {
     }
   }
   DM_LAUNCH_CHECK("dm_gemm");
+  const bool cs_fused = big || (w4 && a->layout == DM_TN);      // these kernels produce the partial column sums of A themselves
+  const int cs_rows_per_slice = big ? 4 : 2;
   if (split > 1) {
     const long long n4 = (long long)a->M * a->N / 4;
     const long long want = (n4 + 255) / 256;
     const int rgrid = (int)(want < 2048 ? want : 2048);
-    const bool fold_cs = a->colsum_a && big;          // the pipeline's [split * 4][M] partial column sums ride along
+    const bool fold_cs = a->colsum_a && cs_fused;     // the pipelines' [split * 4 | 2][M] partial column sums ride along
     const int cs_blocks = fold_cs ? (a->M + 255) / 256 : 0;
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(rgrid + cs_blocks), dim3(256), 0, s, p.workspace,
                        reinterpret_cast<float *>(a->C), (long long)a->ldc, a->M, a->N, split, a->accumulate, rgrid,
-                       fold_cs ? cs_region : nullptr, fold_cs ? a->colsum_a : nullptr, a->M, split * 4, a->colsum_accumulate);
+                       fold_cs ? cs_region : nullptr, fold_cs ? a->colsum_a : nullptr, a->M, split * cs_rows_per_slice, a->colsum_accumulate);
     DM_LAUNCH_CHECK("dm_gemm(split-k reduce)");
     if (fold_cs) return DM_OK;
   }
   if (a->colsum_a) {
-    if (big) {      // fold the pipeline's [split * 4][M] partial rows, in row order
-      hipLaunchKernelGGL(colsum_rows_reduce_kernel, dim3((a->M + 63) / 64), dim3(64), 0, s, cs_region, a->colsum_a, a->M, split * 4,
+    if (cs_fused) {      // fold the pipeline's partial rows, in row order
+      hipLaunchKernelGGL(colsum_rows_reduce_kernel, dim3((a->M + 63) / 64), dim3(64), 0, s, cs_region, a->colsum_a, a->M, split * cs_rows_per_slice,
                          a->colsum_accumulate);
       DM_LAUNCH_CHECK("dm_gemm(colsum reduce)");
     } else {

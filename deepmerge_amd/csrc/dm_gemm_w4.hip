@@ -50,7 +50,8 @@ __device__ __forceinline__ void mma_pinned(f32x4 &acc, const u32x4 &a, const u32
 // DBG (ablation builds only, -DDM_W4_ABLATE): 1 no epilogue, 4 no global loads, 8 no LDS writes, 16 no fragment reads, 32 no MFMAs
 template <int LAYOUT, int DBG = 0, int EPIU = 0>
 __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmParams p) {
-  constexpr bool BMM = (LAYOUT == DM_NN);      // B m-contiguous [K][N] (dgrad) or k-contiguous [N][K] (forward)
+  constexpr bool AMM = (LAYOUT == DM_TN);      // A m-contiguous [K][M] (wgrad) or k-contiguous [M][K]
+  constexpr bool BMM = (LAYOUT != DM_NT);      // B m-contiguous [K][N] (dgrad, wgrad) or k-contiguous [N][K] (forward)
   constexpr int NB = BMM ? 8 : 6;              // global loads of B per thread and K step
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int t = threadIdx.x, lane = t & 63;
@@ -61,17 +62,36 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmParams p) {
   const int G = gridDim.x;
   const int L = dm_xcd_remap(blockIdx.x, G);
   const int tiles = p.tiles_m * p.tiles_n;
-  const int ntile = p.K / BK;
-  const int n_my = (tiles - L + G - 1) / G;    // tiles L, L + G, ...
+  // wgrad (TN): one (tile, K slice) per workgroup, slices of k_per_split (the last one may be shorter); the partial tile goes to
+  // slab z of the split-K workspace.  Forward / dgrad: whole K, tiles L, L + G, ...
+  const int zslice = AMM ? L / tiles : 0;
+  const int kbeg = AMM ? zslice * p.k_per_split : 0;
+  const int kend = AMM ? min(p.K, kbeg + p.k_per_split) : p.K;
+  const int ntile = (kend - kbeg) / BK;
+  const int n_my = AMM ? 1 : (tiles - L + G - 1) / G;
   const int total = n_my * ntile;
 
   // ---- global -> register mapping -----------------------------------------------------------------------------------------------
   // k-contiguous operand: load u of a thread is the 16-byte chunk (t & 7) of tile row (t >> 3) + 32 u; LDS image = rows of 128 B,
   // slot s of row r holds chunk s ^ (r & 7).
   const int lrow = t >> 3, lchunk = t & 7;
-  const int voA = (int)(((long long)lrow * p.lda + lchunk * 8) * 2);
-  const int strideA = (int)(32 * p.lda * 2);
   const int wA = lrow * 128 + ((lchunk ^ (lrow & 7)) << 4);           // + u * 4096
+  int voA, strideA, stepA, wA0, wA1;
+  if constexpr (!AMM) {
+    voA = (int)(((long long)lrow * p.lda + lchunk * 8) * 2);
+    strideA = (int)(32 * p.lda * 2);
+    stepA = BK * 2;
+    wA0 = wA1 = wA;
+  } else {
+    // m-contiguous A [K][M]: chunk c32 = t % 32 (8 rows of the tile) of k-row t / 32 + 8 u; image = 4 bands of [64 k-rows][64 m], as B below
+    const int krow = t >> 5, c32 = t & 31, band = c32 >> 3, c8 = c32 & 7;
+    voA = (int)(((long long)krow * p.lda + c32 * 8) * 2);
+    strideA = (int)(8 * p.lda * 2);
+    stepA = (int)(BK * p.lda * 2);
+    const int f0 = (krow >> 1) & 1;
+    wA0 = band * 8192 + krow * 128 + (((c8 >> 1) ^ f0) << 5) + ((c8 & 1) << 4);          // even u: + u * 1024
+    wA1 = band * 8192 + krow * 128 + (((c8 >> 1) ^ (f0 | 2)) << 5) + ((c8 & 1) << 4);    // odd u
+  }
   int voB, strideB, stepB, wB0, wB1;
   if constexpr (!BMM) {
     voB = (int)(((long long)lrow * p.ldb + lchunk * 8) * 2);
@@ -92,7 +112,21 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmParams p) {
   const bool b_loader = !BMM || t < 192;
 
   // ---- fragment offsets -----------------------------------------------------------------------------------------------------------
-  const int offA0 = (wm * 128 + li) * 128 + ((g ^ (li & 7)) << 4), offA1 = (wm * 128 + li) * 128 + (((4 + g) ^ (li & 7)) << 4);
+  // A fragments.  k-contiguous: two offsets (k-steps), + i * 2048 per row tile.  m-contiguous: row tile i of this wave is column block
+  // wm * 8 + i of the image = band wm * 2 + (i >> 2), 32-byte slot i & 3: four offsets (slot), + (i >> 2) * 8192 + ks * 4096 (+ 512).
+  int offA0, offA1, xsA[4];
+  if constexpr (!AMM) {
+    offA0 = (wm * 128 + li) * 128 + ((g ^ (li & 7)) << 4);
+    offA1 = (wm * 128 + li) * 128 + (((4 + g) ^ (li & 7)) << 4);
+    xsA[0] = xsA[1] = xsA[2] = xsA[3] = 0;
+  } else {
+    const int q = li >> 2, pq = li & 3;
+    const int rbase = wm * 16384 + (8 * g + q) * 128 + 8 * pq;
+    const int fr = ((q >> 1) & 1) | ((g & 1) << 1);
+#pragma unroll
+    for (int sl = 0; sl < 4; ++sl) xsA[sl] = rbase + ((sl ^ fr) << 5);
+    offA0 = offA1 = 0;
+  }
   int offB[6];      // NT: [0], [1] = the two k-steps (+ j * 2048); NN: one per column tile (+ ks * 4096, + 512 for the upper 4 k-rows)
   if constexpr (!BMM) {
     offB[0] = (wn * 96 + li) * 128 + ((g ^ (li & 7)) << 4);
@@ -112,22 +146,27 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmParams p) {
   // ---- tile cursors (uniform) -------------------------------------------------------------------------------------------------------
   const bf16_t *Ab = reinterpret_cast<const bf16_t *>(p.A), *Bb = reinterpret_cast<const bf16_t *>(p.B);
   auto tile_mn = [&](int r, int &m0, int &n0) __attribute__((always_inline)) {
-    const int tid = (DBG & 64) ? (L & 7) : L + r * G;        // (ablation 64: every workgroup reads the same few L2-resident tiles)
+    const int tid = (DBG & 64) ? (L & 7) : AMM ? L - zslice * tiles : L + r * G;        // (ablation 64: every workgroup reads the same few L2-resident tiles)
     const int tm = tid / p.tiles_n;
     m0 = tm * TM;
     n0 = (tid - tm * p.tiles_n) * TN;
   };
   auto make_a = [&](int m0, bool live) __attribute__((always_inline)) {
-    const long long bytes = ((long long)(min(TM, p.M - m0) - 1) * p.lda + p.K) * 2;
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t *>(Ab + (long long)m0 * p.lda), 0, live ? (int)min(bytes, 0x7fffffffLL) : 0, 0x00020000);
+    if constexpr (!AMM) {
+      const long long bytes = ((long long)(min(TM, p.M - m0) - 1) * p.lda + p.K) * 2;
+      return __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t *>(Ab + (long long)m0 * p.lda), 0, live ? (int)min(bytes, 0x7fffffffLL) : 0, 0x00020000);
+    } else {
+      const long long bytes = ((long long)(kend - kbeg - 1) * p.lda + (p.M - m0)) * 2;
+      return __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t *>(Ab + (long long)kbeg * p.lda + m0), 0, live ? (int)min(bytes, 0x7fffffffLL) : 0, 0x00020000);
+    }
   };
   auto make_b = [&](int n0, bool live) __attribute__((always_inline)) {
     if constexpr (!BMM) {
       const long long bytes = ((long long)(min(TN, p.N - n0) - 1) * p.ldb + p.K) * 2;
       return __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t *>(Bb + (long long)n0 * p.ldb), 0, live ? (int)min(bytes, 0x7fffffffLL) : 0, 0x00020000);
     } else {
-      const long long bytes = ((long long)(p.K - 1) * p.ldb + (p.N - n0)) * 2;
-      return __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t *>(Bb + n0), 0, live ? (int)min(bytes, 0x7fffffffLL) : 0, 0x00020000);
+      const long long bytes = ((long long)(kend - kbeg - 1) * p.ldb + (p.N - n0)) * 2;
+      return __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t *>(Bb + (long long)kbeg * p.ldb + n0), 0, live ? (int)min(bytes, 0x7fffffffLL) : 0, 0x00020000);
     }
   };
   int m_cur, n_cur;
@@ -184,7 +223,7 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmParams p) {
     constexpr int set = decltype(set_tag)::value;
     constexpr bool GX = decltype(grp_tag)::value == 0;
     const int k = GX ? cx.k : cy.k;
-    if (q < 8) ga[set][q] = __builtin_amdgcn_raw_buffer_load_b128(GX ? rsAx : rsAy, voA, k * (BK * 2) + q * strideA, 0);
+    if (q < 8) ga[set][q] = __builtin_amdgcn_raw_buffer_load_b128(GX ? rsAx : rsAy, voA, k * stepA + q * strideA, 0);
     else if (b_loader) gb[set][q - 8] = __builtin_amdgcn_raw_buffer_load_b128(GX ? rsBx : rsBy, voB, k * stepB + (q - 8) * strideB, 0);
   };
   // piece q: register set -> LDS buffer
@@ -193,7 +232,8 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmParams p) {
     constexpr int set = decltype(set_tag)::value;
     char *a = smem + decltype(buf_tag)::value * BUF_BYTES;
     if (q < 8) {
-      *reinterpret_cast<u32x4 *>(a + wA + q * 4096) = ga[set][q];
+      if constexpr (!AMM) *reinterpret_cast<u32x4 *>(a + wA + q * 4096) = ga[set][q];
+      else *reinterpret_cast<u32x4 *>(a + ((q & 1) ? wA1 : wA0) + q * 1024) = ga[set][q];
     } else if (b_loader) {
       const int u = q - 8;
       if constexpr (!BMM) *reinterpret_cast<u32x4 *>(a + A_BYTES + wB0 + u * 4096) = gb[set][u];
@@ -206,6 +246,17 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmParams p) {
   for (int i = 0; i < 8; ++i)
 #pragma unroll
     for (int j = 0; j < 6; ++j) zero_pinned(acc[i][j], vzero);
+  // wgrad: column sums of A (the bias gradient that goes with dW = dy^T x) ride along in the workgroups of column tile 0: their waves
+  // multiply the A fragments with a ones fragment (every column of the 16 x 16 result = the row sums); the two waves that hold the
+  // same A rows take one k-step each (+8 % MFMAs there).  Partial rows [z * 2 + wn][M] in p.colsum_slab.
+  const bool colsum = AMM && p.colsum_slab != nullptr && n_cur == 0;
+  f32x4 accb[AMM ? 8 : 1];
+  u32x4 ones = {0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};     // eight bf16 1.0
+  if constexpr (AMM) {
+    asm volatile("" : "+v"(ones));
+#pragma unroll
+    for (int i = 0; i < 8; ++i) zero_pinned(accb[i], vzero);
+  }
   // Fragments: B double-buffered (the next k-step's six tiles load while this one's are in use); A rotates in place (row tile i's
   // fragment is dead after its six MFMAs and is reloaded for the next k-step at once) -- the arch-VGPR budget is 256.
   u32x4 fa[8], fb[2][6];
@@ -220,7 +271,13 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmParams p) {
     constexpr int ks = decltype(ks_tag)::value;
     if constexpr (DBG & 16) return fa[i];
     const char *a = smem + decltype(buf_tag)::value * BUF_BYTES;
-    return *reinterpret_cast<const u32x4 *>(a + i * 2048 + (ks ? offA1 : offA0));
+    if constexpr (!AMM) {
+      return *reinterpret_cast<const u32x4 *>(a + i * 2048 + (ks ? offA1 : offA0));
+    } else {
+      const u32x2 lo = dm_ds_read_tr16(a + xsA[i & 3] + (i >> 2) * 8192 + ks * 4096);
+      const u32x2 hi = dm_ds_read_tr16(a + xsA[i & 3] + (i >> 2) * 8192 + ks * 4096 + 512);
+      return (u32x4){lo[0], lo[1], hi[0], hi[1]};
+    }
   };
   auto load_b1 = [&](int j, auto ks_tag, auto buf_tag) __attribute__((always_inline)) {
     constexpr int ks = decltype(ks_tag)::value;
@@ -261,6 +318,11 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmParams p) {
       __builtin_amdgcn_sched_barrier(0);
       mma_pinned(acc[i][5], fa[i], fb[ks][5]);
       if (i < 6) load_b1(i, nks_tag, nbuf_tag);
+      if constexpr (AMM) {
+        if (colsum && wn == ks) {
+          mma_pinned(accb[i], fa[i], ones);
+        }
+      }
       fa[i] = na;
       __builtin_amdgcn_sched_barrier(0);
 #undef mma_pinned
@@ -309,6 +371,7 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmParams p) {
     for (int i = 0; i < 8; ++i) {
 #pragma unroll
       for (int j = 0; j < 6; ++j) {
+        asm volatile("" : "+a"(acc[i][j]));             // (no stale register copy of an accumulator can be stored: see accb below)
         *reinterpret_cast<f32x4 *>(slab + li * 768 + (((wn * 24 + j * 4 + g) ^ (li & 7)) << 4)) = acc[i][j];
         zero_pinned(acc[i][j], vzero);
       }
@@ -322,10 +385,29 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmParams p) {
         const f32x4 lo = *reinterpret_cast<const f32x4 *>(slab + row * 768 + (((2 * cg) ^ (row & 7)) << 4));
         const f32x4 hi = *reinterpret_cast<const f32x4 *>(slab + row * 768 + (((2 * cg + 1) ^ (row & 7)) << 4));
         int m = m_pair + i * 16 + row;
+        if constexpr (AMM) {
+          // wgrad: fp32 partial tile into slab z of the split-K workspace (summed in slice order by splitk_reduce_kernel), or,
+          // unsplit, straight into the gradient
+          if (m < p.M) {
+            const int n = n_cur + cg * 8;
+            if (p.split_k > 1) {
+              float *d = p.workspace + ((long long)zslice * p.M + m) * p.N + n;
+              dm_store4(d, lo);
+              dm_store4(d + 4, hi);
+            } else {
+              float *d = reinterpret_cast<float *>(p.C) + (long long)m * p.ldc + n;
+              f32x4 l2 = lo, h2 = hi;
+              if (p.accumulate) { l2 += dm_load4(d); h2 += dm_load4(d + 4); }
+              dm_store4(d, l2);
+              dm_store4(d + 4, h2);
+            }
+          }
+        } else {
         if constexpr (DBG & 256) m = wm * 128 + i * 16 + row;         // (ablation: every workgroup stores to the same 256 rows)
         if constexpr (DBG & 128) { if (lo[0] == 12345.678f) dm_gemm_emit8(p, lo, hi, dm_gemm_row(p, m), n_cur + cg * 8); }
         else if (m < p.M) dm_gemm_emit8(p, lo, hi, dm_gemm_row(p, m), (DBG & 256) ? cg * 8 : n_cur + cg * 8);
-            };
+        }
+      };
       if constexpr (EPIU) {        // unrolled: the three bodies' residual / aux loads are in flight together
         pass(0); pass(1); pass(2);
       } else {
@@ -335,6 +417,18 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmParams p) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the next row tile overwrites the slab
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
+    }
+    if constexpr (AMM) {
+      // The compiler does not know the asm statements are MFMAs: it copies accb[i] out of the AGPRs right behind the conditional MFMA
+      // (no wait states -> the copy misses the last update) and would store that copy here.  Re-reading through an asm operand forces
+      // a fresh copy, long after the last MFMA has retired.
+#pragma unroll
+      for (int i = 0; i < 8; ++i) asm volatile("" : "+a"(accb[i]));
+      if (colsum && g == 0) {        // every column of an accb tile holds the same sum: lanes g == 0 write element 0
+        float *row = p.colsum_slab + (long long)(zslice * 2 + wn) * p.M;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) row[m_cur + wm * 128 + i * 16 + li] = accb[i][0];
+      }
     }
     kt = 0;
     ++r;
@@ -382,7 +476,7 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmParams p) {
 
   // K % 128 == 0 (plan): a tile is an even number of K steps, so tiles end after an odd step only
   for (int step = 0; step < total; step += 2) {
-    if (kt + 2 == ntile) touch_epilogue_operands();
+    if constexpr (!AMM) { if (kt + 2 == ntile) touch_epilogue_operands(); }
     body(IC<0>{});
     body(IC<1>{});
     kt += 2;
@@ -419,11 +513,42 @@ int w4_cu_count() {
 
 // Decides whether the 4-wave persistent kernel runs this product (bf16 NT / NN); fills p.tiles_m / tiles_n and returns the grid
 // size (0 = not taken).  `aligned8`: the 8-column epilogue (dm_gemm_emit8) is legal for C / aux / grouped rows.
-int dm_gemm_w4_plan(GemmParams &p, int layout, int ab_dtype, bool aligned8) {
+int dm_gemm_w4_plan(GemmParams &p, int layout, int ab_dtype, bool aligned8, bool can_split, long long workspace_bytes) {
   using namespace dmw4;
   const char *env = getenv("DM_GEMM_W4");         // 0 = off, 1 = routing rule, 2 = every legal product, 3 = every whole-round shape (read per call: tests flip it)
   const int mode = env ? atoi(env) : 1;
   if (mode == 0 || ab_dtype != DM_BF16 || !aligned8) return 0;
+  if (layout == DM_TN) {
+    // wgrad: one (256 x 192 tile, K slice) per workgroup; slices of an even number of K steps chosen so that tiles x slices fills the CUs
+    const char *tenv = getenv("DM_GEMM_W4_TN");     // 0 = off, 1 = routing rule (default), 2 = every legal product
+    const int tmode = tenv ? atoi(tenv) : 1;
+    if (tmode == 0 || p.M % TM != 0 || p.N % TN != 0 || p.K % (2 * BK) != 0 || p.M % 8 != 0 || p.N % 8 != 0) return 0;
+    if (!can_split || p.c_dtype != DM_F32) return 0;
+    if ((long long)p.K * p.lda * 2 >= (1LL << 31) || (long long)p.K * p.ldb * 2 >= (1LL << 31)) return 0;
+    const int cus = w4_cu_count();
+    const long long tiles = (long long)(p.M / TM) * (p.N / TN);
+    if (cus <= 0 || tiles > cus) return 0;
+    const int steps = p.K / BK;
+    int split = (int)(cus / tiles);
+    if (split > 16) split = 16;
+    int per = (steps + split - 1) / split;
+    per += per & 1;
+    if (per < 16) per = 16;
+    split = (steps + per - 1) / per;
+    while (split > 1 && (long long)split * p.M * p.N * 4 > workspace_bytes) {       // slab must fit the caller's workspace
+      per += 2;
+      split = (steps + per - 1) / per;
+    }
+    if (split > 1 && (long long)split * p.M * p.N * 4 > workspace_bytes) return 0;
+    if (tmode == 1 && (tiles < 24 || (double)(tiles * split) / cus < 0.8)) return 0;
+    static const bool attr_tn = w4_set_lds_limit<DM_TN>();
+    if (!attr_tn) return 0;
+    p.tiles_m = p.M / TM;
+    p.tiles_n = p.N / TN;
+    p.split_k = split;
+    p.k_per_split = per * BK;
+    return (int)(tiles * split);
+  }
   if (layout != DM_NT && layout != DM_NN) return 0;
   if (p.K < 2 * BK || p.K % (2 * BK) != 0 || p.N % TN != 0) return 0;
   const long long spanA = 256LL * p.lda * 2 + 2LL * p.K;
@@ -472,7 +597,9 @@ void dm_gemm_w4_launch(const GemmParams &p, int layout, int grid, hipStream_t s)
   // step it LOSES 12-15 % on every shape, with or without epilogue reads (tools/prof_shapes.py, same box): experiment knob only.
   const char *uenv = getenv("DM_W4_EPI_UNROLL");
   const bool unroll = uenv && atoi(uenv) != 0;
-  if (layout == DM_NT) {
+  if (layout == DM_TN) {
+    hipLaunchKernelGGL((dmw4::gemm_w4_kernel<DM_TN, 0, 0>), dim3(grid), dim3(256), dmw4::LDS_BYTES, s, p);
+  } else if (layout == DM_NT) {
     if (unroll) hipLaunchKernelGGL((dmw4::gemm_w4_kernel<DM_NT, 0, 1>), dim3(grid), dim3(256), dmw4::LDS_BYTES, s, p);
     else hipLaunchKernelGGL((dmw4::gemm_w4_kernel<DM_NT, 0, 0>), dim3(grid), dim3(256), dmw4::LDS_BYTES, s, p);
   } else {

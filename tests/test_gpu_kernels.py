@@ -103,6 +103,41 @@ def test_gemm_w4_exact_integers(w4_env, layout, M, N, K):
     test_gemm_p192_exact_integers(None, layout, M, N, K)
 
 
+@pytest.mark.parametrize("Mrows,N,K,acc", [(16384, 768, 768, True), (4096, 2304, 768, False), (16384, 3072, 768, True), (256, 256, 192, True),
+                                          (1280, 768, 3072, False)])
+def test_gemm_w4_wgrad(Mrows, N, K, acc):
+    """TN through the 4-wave kernel (DM_GEMM_W4_TN=2: every legal product): both operands m-contiguous (transposed LDS reads), one
+    (tile, K slice) per workgroup with a shorter last slice, slab reduction in slice order; unsplit products write the gradient
+    directly (with and without accumulation).  Exact in small integers, run-to-run identical."""
+    import os
+    ops = _ops()
+    from deepmerge_amd._lib import DM_TN
+    old = os.environ.get("DM_GEMM_W4_TN")
+    os.environ["DM_GEMM_W4_TN"] = "2"
+    try:
+        rng = np.random.default_rng(Mrows + N + K)
+        dy = _ints(rng, (Mrows, N), -1, 2)
+        x = _ints(rng, (Mrows, K), -1, 2)
+        g0 = torch.from_numpy(rng.integers(-5, 6, size=(N, K)).astype(np.float32))
+        want = (g0.double() if acc else 0) + dy.double().T @ x.double()
+        dyd, xd = dy.to(DEV).to(torch.bfloat16), x.to(DEV).to(torch.bfloat16)
+        G = g0.clone().to(DEV)
+        ops.gemm(DM_TN, dyd, xd, G, N, K, Mrows, lda=N, ldb=K, ldc=K, accumulate=acc)
+        assert torch.equal(G.cpu().double(), want), f"max diff {(G.cpu().double() - want).abs().max()}"
+        G2 = g0.clone().to(DEV)
+        ops.gemm(DM_TN, dyd, xd, G2, N, K, Mrows, lda=N, ldb=K, ldc=K, accumulate=acc)
+        assert torch.equal(G, G2)
+        # with the bias gradient (column sums of dy) riding along
+        G3, cs = g0.clone().to(DEV), torch.ones(N, device=DEV)
+        ops.gemm(DM_TN, dyd, xd, G3, N, K, Mrows, lda=N, ldb=K, ldc=K, accumulate=acc, colsum_out=cs, colsum_accumulate=True)
+        assert torch.equal(G3, G) and torch.equal(cs.cpu().double(), 1.0 + dy.double().sum(0))
+    finally:
+        if old is None:
+            os.environ.pop("DM_GEMM_W4_TN", None)
+        else:
+            os.environ["DM_GEMM_W4_TN"] = old
+
+
 def test_gemm_w4_epilogues(w4_env):
     test_gemm_epilogues("bf16", M=512, N=384)
 

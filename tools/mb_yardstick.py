@@ -36,6 +36,13 @@ def case(name, layout, M, N, K):
         elif layout == DM_NN: torch.matmul(a, b, out=o)
         else:                 torch.matmul(a.t(), b, out=o)
     tm, tl = timeit(mine), timeit(lib)
+    if layout == DM_TN and os.environ.get("W4TN_AB"):
+        os.environ["DM_GEMM_W4_TN"] = "0"
+        t0 = timeit(mine)
+        os.environ["DM_GEMM_W4_TN"] = "2"
+        t2 = timeit(mine)
+        os.environ.pop("DM_GEMM_W4_TN")
+        print(f"      wgrad A/B: 256x256 pipeline {t0*1e6:7.1f} us | 4-wave kernel {t2*1e6:7.1f} us", flush=True)
     fl = 2.0 * M * N * K
     print(f"{name:12s} {M:6d}x{N:5d}x{K:6d}  dm_gemm {tm*1e6:7.1f} us {fl/tm/1e12:6.0f} TF/s | torch.matmul {tl*1e6:7.1f} us {fl/tl/1e12:6.0f} TF/s | ratio {tm/tl:5.2f}", flush=True)
     return tm, tl
