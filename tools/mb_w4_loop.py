@@ -9,10 +9,11 @@ dev = "cuda:0"
 g = torch.Generator(device=dev); g.manual_seed(1)
 def rnd(shape): return torch.randn(shape, device=dev, generator=g).to(torch.bfloat16)
 R, IT = 3, 30
+PAD = int(os.environ.get("PAD", "0"))       # extra elements per row of A (leading dimension K + PAD): DRAM / L2 channel spread
 def bench(M, N, K):
-    sets = [(rnd((M, K)), rnd((N, K)), torch.empty((M, N), device=dev, dtype=torch.bfloat16)) for _ in range(R)]
+    sets = [(rnd((M, K + PAD)), rnd((N, K)), torch.empty((M, N), device=dev, dtype=torch.bfloat16)) for _ in range(R)]
     def run(i):
-        a, b, o = sets[i % R]; ops.gemm(DM_NT, a, b, o, M, N, K, lda=K, ldb=K, ldc=N)
+        a, b, o = sets[i % R]; ops.gemm(DM_NT, a, b, o, M, N, K, lda=K + PAD, ldb=K, ldc=N)
     for dbg in [int(x) for x in os.environ.get('DBGS', '0 1 5 13 29 61 33 17 9 45').split()]:
         os.environ["DM_W4_DEBUG"] = str(dbg)
         for i in range(6): run(i)
