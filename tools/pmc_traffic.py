@@ -9,6 +9,9 @@ def bench_name(k):
     """rocprof kernel name -> in-library profiler row name (None: not a profiled kernel)."""
     if "gemm_ring_kernel" in k:
         return "gemm_bf16_NT"
+    m = re.search(r"gemm_(?:w4|p192)_kernel<(\d)", k) or re.search(r"gemm_(?:w4|p192)_kernelILi(\d)E", k)
+    if m:
+        return "gemm_bf16_" + ("NT", "NN", "TN")[int(m.group(1))]
     m = re.search(r"gemm256_kernel<(\d)>", k) or re.search(r"gemm256_kernelILi(\d)E", k)
     if m:
         return "gemm_bf16_" + ("NT", "NN", "TN")[int(m.group(1))]
