@@ -540,7 +540,9 @@ int dm_gemm_w4_plan(GemmParams &p, int layout, int ab_dtype, bool aligned8, bool
       split = (steps + per - 1) / per;
     }
     if (split > 1 && (long long)split * p.M * p.N * 4 > workspace_bytes) return 0;
-    if (tmode == 1 && (tiles < 24 || (double)(tiles * split) / cus < 0.8)) return 0;
+    // in-step per launch (tools/prof_shapes.py): K = 16384: 100 -> 84, 92 -> 83, 80 -> 67, 41 -> 38 us; K = 4096 with 48 tiles x 4 slices:
+    // 26 -> 24 us; fewer workgroups than 0.7 of the CUs, or the 1024-token stage, lose
+    if (tmode == 1 && ((double)(tiles * split) / cus < 0.7 || tiles < 12 || (tiles < 24 && p.K < 8192))) return 0;
     static const bool attr_tn = w4_set_lds_limit<DM_TN>();
     if (!attr_tn) return 0;
     p.tiles_m = p.M / TM;
