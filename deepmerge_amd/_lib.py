@@ -90,6 +90,8 @@ SIGNATURES = {
     "dm_label_features": (_I, [_P, _P, _P, _P, _P, _I, _I, _P, _P]),
     "dm_rag_edges": (_I, [_P, _I, _I, _I, _P, _P, _I, _P, _P, _I, _P, _P, _P]),
     "dm_merge_round": (_I, [_P, _P, _I, _I, _P, _P, _I, _P]),
+    "dm_gru_cell_fwd": (_I, [_P, _L, _P, _P, _P, _P, _I, _I, _P]),
+    "dm_gru_cell_bwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _P]),
     "dm_prof_enable": (_I, [_I]),
     "dm_prof_collect": (_I, [C.POINTER(DmProfRow), _I]),
 }

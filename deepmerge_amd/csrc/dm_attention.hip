@@ -531,8 +531,8 @@ template <typename T> int dispatch(int which, const AttnParams &p, hipStream_t s
 }
 
 int check_common(const char *who, int B, int N, int H, int D, int dtype) {
-  DM_REQUIRE(B > 0 && H > 0 && N > 0 && N <= 256, DM_ERR_BAD_SHAPE, "%s: need 0 < N <= 4096 tokens and head dim <= 128 (got N=%d, D=%d, B=%d, H=%d)", who, N, D, B, H);
-  DM_REQUIRE(D == HD, DM_ERR_BAD_SHAPE, "%s: head dim must be in 1..128 (got %d)", who, D);
+  DM_REQUIRE(B > 0 && H > 0 && N > 0 && N <= 256, DM_ERR_BAD_SHAPE, "%s: need 0 < N <= 4096 tokens and head dim <= 256 (got N=%d, D=%d, B=%d, H=%d)", who, N, D, B, H);
+  DM_REQUIRE(D == HD, DM_ERR_BAD_SHAPE, "%s: head dim must be in 1..256 (got %d)", who, D);
   DM_REQUIRE(dtype == DM_F32 || dtype == DM_BF16, DM_ERR_BAD_DTYPE, "%s: bad dtype %d", who, dtype);
   DM_REQUIRE(H <= 65535 && B <= 65535, DM_ERR_BAD_SHAPE, "%s: grid too large", who);
   return DM_OK;
@@ -554,7 +554,7 @@ extern "C" int32_t dm_attention_bwd_batch_chunks(int32_t B, int32_t N, int32_t H
   return (B + c - 1) / c;
 }
 
-// dm_attention_generic.hip: any head dim <= 128 / up to 4096 tokens, fp32 arithmetic (ViT-H/14: D = 80, N = 257)
+// dm_attention_generic.hip: any head dim <= 256 / up to 4096 tokens, fp32 arithmetic (ViT-H/14: D = 80, N = 257)
 bool dm_attn_generic_shape(int N, int D);
 int dm_attn_generic_fwd(const void *qkv, const float *bias, void *out, float *lse, int B, int N, int H, int D, float scale, int dtype, hipStream_t s);
 int dm_attn_generic_bwd(const void *qkv, const float *bias, const void *out, const void *dout, const float *lse, void *dqkv, float *delta,

@@ -2,13 +2,13 @@
 // factories (vit_model.py:649-662) has head dim 80 and 257 tokens.  Same contract as dm_attention_fwd / _bwd (packed qkv
 // [B, N, 3, H, D], optional dense bias [H, N, N], out [B, N, H*D], lse [B, H, N]); fp32 arithmetic throughout, no MFMA, no
 // atomics.  A correctness path: one wave per query row (forward, dQ) or per key row (dK/dV), O(N * D) work per row with the row's
-// scores staged in LDS.  D <= 128, N <= 4096.
+// scores staged in LDS.  D <= 256, N <= 4096.
 #include "dm_common.h"
 
 namespace {
 
 constexpr int GEN_MAX_N = 4096;
-constexpr int GEN_MAX_D = 128;
+constexpr int GEN_MAX_D = 256;     // (Nets.RNN's attention_net: one head of 160)
 constexpr int ROWS_PER_WG = 4;
 
 struct GenParams {

@@ -572,6 +572,36 @@ class AttentionFn(torch.autograd.Function):
         return dqkv, dtable, None, None, None, None, None, None
 
 
+class GRUCellFn(torch.autograd.Function):
+    """One GRU step (torch.nn.GRU semantics, gate order r, z, n; reference Nets.py:60-66): gi [B, 3H] (may be a strided time slice of the
+    all-steps input projection), gh [B, 3H] = h W_hh^T + b_hh, h [B, H] -> h_new [B, H].  Kernels: csrc/dm_gru.hip."""
+
+    @staticmethod
+    def forward(ctx, gi, gh, h):
+        _need_cuda(gi, gh, h)
+        B, H = h.shape
+        if gi.shape != (B, 3 * H) or gh.shape != (B, 3 * H) or gi.stride(1) != 1:
+            raise ValueError(f"GRUCellFn: gi {tuple(gi.shape)} / gh {tuple(gh.shape)} do not fit h {tuple(h.shape)}")
+        gh, h = gh.contiguous(), h.contiguous()
+        h_new = torch.empty_like(h)
+        saved = torch.empty((B, 4 * H), dtype=torch.float32, device=h.device)
+        check(_lib.lib().dm_gru_cell_fwd(gi.data_ptr(), gi.stride(0), gh.data_ptr(), h.data_ptr(), h_new.data_ptr(), saved.data_ptr(), B, H,
+                                         _stream()), "dm_gru_cell_fwd")
+        ctx.save_for_backward(saved, h)
+        return h_new
+
+    @staticmethod
+    def backward(ctx, dh_new):
+        saved, h = ctx.saved_tensors
+        B, H = h.shape
+        dh_new = dh_new.contiguous()
+        dgi = torch.empty((B, 3 * H), dtype=torch.float32, device=h.device)
+        dgh, dh = torch.empty_like(dgi), torch.empty_like(h)
+        check(_lib.lib().dm_gru_cell_bwd(dh_new.data_ptr(), saved.data_ptr(), h.data_ptr(), dgi.data_ptr(), dgh.data_ptr(), dh.data_ptr(), B, H,
+                                         _stream()), "dm_gru_cell_bwd")
+        return dgi, dgh, dh
+
+
 class BatchNormReluFn(torch.autograd.Function):
     """BatchNorm2d -> ReLU -> Dropout2d of the auxiliary heads (reference nets/ShfitScaleFormer.py:340-346) on the channels-last
     matrix x [samples * rows_per_sample, C] the convolution GEMM produces.  `mask`: None or [samples, C] multipliers (0 or

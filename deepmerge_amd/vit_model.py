@@ -6,7 +6,7 @@ the reference.  Blocks run through the fused `ops.BlockFn` (no bias table: plain
 after q @ k^T upstream, which is bit-identical for the power-of-two 64^-0.5); LayerNorm eps = 1e-6.
 torch nn.Linear/Conv/LayerNorm objects are parameter containers only.
 
-Supported on the accelerated path: head dims <= 128 (64 on the MFMA attention kernels, others on the generic fp32 family) and
+Supported on the accelerated path: head dims <= 256 (64 on the MFMA attention kernels, others on the generic fp32 family) and
 embed dims <= 8192 (<= 1024 on the register-resident LayerNorm kernels, wider rows on the streamed ones of dm_rows_wide.hip).
 ViT-H/14 (dim 1280, head dim 80, 14-pixel patches, 257 tokens; vit_model.py:649-662) therefore runs, on those secondary
 kernels: a correctness path, not a tuned one (upstream never shipped its weights).
@@ -78,8 +78,8 @@ class Attention(nn.Module):
             raise ValueError("dropout > 0 is not part of the accelerated path (reference uses 0)")
         self.num_heads = num_heads
         head_dim = dim // num_heads
-        if head_dim > 128:
-            raise NotImplementedError(f"attention kernels cover head dims up to 128 (got {head_dim})")
+        if head_dim > 256:
+            raise NotImplementedError(f"attention kernels cover head dims up to 256 (got {head_dim})")
         self.scale = qk_scale or head_dim ** -0.5
         self.qkv = nn.Linear(dim, dim * 3, bias=qkv_bias)
         self.attn_drop = nn.Dropout(attn_drop_ratio)

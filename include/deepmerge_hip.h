@@ -281,6 +281,16 @@ int dm_batchnorm_bwd(const float *dy, const float *x, const float *y, const floa
                      const float *save_mean, const float *save_rstd, float *dx, float *dgamma, float *dbeta, int32_t accumulate,
                      int32_t M, int32_t C, int32_t training, int32_t relu, void *workspace, void *stream);
 
+/* ---- GRU cell (reference Nets.py:60-66: `nn.GRU(28, 80, num_layers=4, bidirectional=True)` of the MNIST sandbox net `RNN`) ----
+ * PyTorch gate order r, z, n.  gi [B, 3H] with row stride gi_stride floats (a time slice of x W_ih^T + b_ih for all steps),
+ * gh [B, 3H] = h W_hh^T + b_hh, h [B, H]:  r = sigmoid(gi_r + gh_r), z = sigmoid(gi_z + gh_z), n = tanh(gi_n + r * gh_n),
+ * h_new = (1 - z) * n + z * h.  saved [B, 4H] keeps r, z, n, gh_n for the backward call, which returns dgi, dgh [B, 3H] and
+ * dh [B, H] (the direct path to the previous state; the caller adds the path through gh). */
+int dm_gru_cell_fwd(const float *gi, int64_t gi_stride, const float *gh, const float *h, float *h_new, float *saved,
+                    int32_t B, int32_t H, void *stream);
+int dm_gru_cell_bwd(const float *dh_new, const float *saved, const float *h, float *dgi, float *dgh, float *dh, int32_t B,
+                    int32_t H, void *stream);
+
 /* ---- optional in-library kernel timing ------------------------------------------------------
  * While enabled, the GEMM and attention entry points bracket their main kernel with hipEvents on
  * the caller's stream.  dm_prof_collect waits for the recorded events, aggregates them per kernel

@@ -460,7 +460,24 @@ def gen_nets():
     add(fx, "fc/out", o); add(fx, "fc/dy", y.grad)
     for n, p in f.named_parameters():
         add(fx, "fc/grad/" + n, p.grad)
-    np.savez_compressed(os.path.join(HERE, "model_nets.npz"), **fx)
+    # ---- RNN (4-layer bidirectional GRU + attention pooling, Nets.py:48-111); eval mode: its Dropout(0.5) draws from torch's RNG ----
+    import contextlib, io
+    r = Nets.RNN()
+    load_det_weights(r, "nets.rnn.")
+    r.eval()
+    xr = t("nets.rnn.x", (9, 28, 28), "unit").requires_grad_(True)
+    with contextlib.redirect_stdout(io.StringIO()):           # the reference prints tensor sizes
+        o = r(xr)
+    (o * o).sum().backward()
+    add(fx, "rnn/out", o); add(fx, "rnn/dx", xr.grad)
+    for n, p in r.named_parameters():
+        add(fx, "rnn/grad/" + n, p.grad)
+    fx["rnn/keys"] = np.array(list(r.state_dict().keys()))
+    path = os.path.join(HERE, "model_nets.npz")
+    if os.path.exists(path):                                   # committed cases keep their values: re-running only ADDS
+        old = np.load(path)
+        fx.update({k: old[k] for k in old.files})
+    np.savez_compressed(path, **fx)
     print("model_nets.npz", len(fx))
 
 
