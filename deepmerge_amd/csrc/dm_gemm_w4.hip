@@ -501,11 +501,16 @@ template <int LAYOUT, int DBG = 0, int EPIU = 0> bool w4_set_lds_limit() {
                              dmw4::LDS_BYTES) == hipSuccess;
 }
 int w4_cu_count() {
+  // DM_GEMM_CUS_RESERVED = n plans the one-workgroup-per-CU grids for n CUs fewer than the device has: a collective running next to
+  // the backward pass (RCCL kernels hold CUs for the length of an all-reduce) otherwise pushes the last workgroups of such a grid
+  // into a second round.  Default 0 -- to be tuned on a multi-GPU node, none was available to this build.
   static const int n = [] {
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) != hipSuccess) return 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
-    return cus;
+    const char *e = getenv("DM_GEMM_CUS_RESERVED");
+    const int r = e ? atoi(e) : 0;
+    return (r > 0 && r < cus) ? cus - r : cus;
   }();
   return n;
 }
