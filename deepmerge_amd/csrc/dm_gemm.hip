@@ -319,6 +319,19 @@ __global__ __launch_bounds__(NTHREADS, (TM == 4 ? WG_PER_CU : 4)) void gemm_kern
     }
     return;
   }
+  if constexpr (TM == 4 && sizeof(T) == 2) {
+    // whole-line epilogue (dm_gemm_common.h, shared with the LDS-DMA kernels): every wave transposes its 64 x 64 block 16 rows at a time
+    // through a private piece of the (now idle) operand stage, so bias / residual / aux reads and the C stores are 128-byte rows instead
+    // of 8-byte strips of 16 different rows (the dgrad of fc2 reads 100 MB of GELU' that way): in the step 137 -> 120 us for that
+    // product, 53 -> 47 us for the proj forward.  (The 64 x 64 variant gained nothing from the same change and keeps its strips.)
+    const bool rows_ok = !(p.debug & 0x100) && (p.N % 8 == 0) && (p.ldc % 8 == 0) && (p.aux == nullptr || p.ldaux % 8 == 0) &&
+                         (p.rows_per_group == 0 || p.group_stride % 8 == 0) && (p.residual == nullptr || p.ldr % 8 == 0);
+    if (rows_ok) {
+      static_assert(2 * LDS_STAGES * G::STAGE >= 4 * 16 * DM_EPI_PITCH, "epilogue staging must fit the operand stage");
+      dm_epilogue_rows<4, 16>(p, acc, smem + wave * (16 * DM_EPI_PITCH), m0 + wm * WT, n0 + wn * WT, lane);
+      return;
+    }
+  }
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
     const int m = m0 + wm * WT + i * 16 + li;
@@ -616,6 +629,10 @@ extern "C" int dm_gemm(const DmGemmArgs *a, void *stream) {
     p.k_per_split = kps;
   }
   p.workspace = reinterpret_cast<float *>(a->workspace);
+  {
+    static const bool rows_off = [] { const char *e = getenv("DM_GEMM_T128_ROWS"); return e && e[0] == '0'; }();   // A/B aid: 4-column epilogue in the 128x128 kernel
+    if (rows_off && !ring) p.debug |= 0x100;
+  }
   {
     static const int forced = [] { const char *e = getenv("DM_GEMM_GROUP_M"); return e ? atoi(e) : -1; }();
     p.group_m = forced >= 0 ? forced : 8;   // measured over the encoder's step: 8 > 4 > 0 (column-fastest) > 16 > 32, within 2 %
