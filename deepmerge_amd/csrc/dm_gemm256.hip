@@ -386,6 +386,9 @@ bool dm_gemm256_plan(GemmParams &p, int layout, int ab_dtype, bool can_split, lo
     // long-K forward products (fc2: K = 3072, 192 tiles) amortise the fill / epilogue: -0.03 ms/step measured
     static const int longk = [] { const char *e = getenv("DM_GEMM_256_NT_LONGK"); return e ? atoi(e) : 1; }();
     take = (tiles_n >= 10 && tiles >= 384) || tiles >= 1024 || (longk && p.K >= 2048 && tiles >= 180);
+    // since the 128x128 kernel has the whole-line epilogue too it is ahead on the short-K wide products whose 128x128 tiles make whole
+    // rounds of 3 workgroups per CU (fc1 forward in the step: 122 us here, 116 us there)
+    if (p.K < 2048 && ((long long)((p.M + 127) / 128) * ((p.N + 127) / 128)) % 768 == 0) take = false;
   }
   if (mode == 2) take = true;
   if (!take) return false;

@@ -182,6 +182,10 @@ int dm_gemm_ring_plan(GemmParams &p, int layout, int ab_dtype, bool aligned8) {
   //   M =  4096: qkv 23 / 31, fc1 36 / 38, proj 19 / 16, fc2 45 / 42          M = 1024: never ahead
   // -> wide outputs (several rounds of tiles, so the two workgroups of a CU drift apart and overlap) take it
   if (mode == 1 && !(p.N >= 2048 && p.M >= 2048)) return 0;
+  // ... until the 128x128 kernel got the same whole-line epilogue (dm_gemm.hip): where its tiles make whole rounds of 3 workgroups per
+  // CU it is now ahead inside the training step (tools/prof_shapes.py, per launch, same box: 16384 x 2304 90 -> 79 us,
+  // 16384 x 3072 + GELU' 121 -> 116 us, 4096 x 3072 + GELU' 44 -> 36 us); 4096 x 2304 (576 tiles = 0.75 round) stays here (29 vs 31 us)
+  if (mode == 1 && ((long long)((p.M + 127) / 128) * ((p.N + 127) / 128)) % 768 == 0) return 0;
   int wm = t256 >= 384 ? 8 : 4;
   if (force == 8 || force == 4) wm = force;
   static const bool ok = dmring::set_lds_limit<8>() && dmring::set_lds_limit<4>();
