@@ -252,6 +252,53 @@ def test_gemm_epilogues(mode, M=192, N=256):
     assert float(cube[:, :36].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("layout", ["NT", "NN"])
+@pytest.mark.parametrize("M,N,K", [(4096, 768, 3072), (1024, 768, 2304), (1000, 776, 2048)])
+def test_gemm_forward_split_k(layout, M, N, K):
+    """Forward / dgrad products whose 128x128 grid under-fills the chip and whose K is long are cut into K slices; the slices are summed in
+    order and sent through the fused epilogue by splitk_epilogue_kernel.  Exact in small integers (plain, fp32 and bf16 outputs), and the
+    bias + residual / GELU epilogues agree with float64."""
+    import os
+    ops = _ops()
+    from deepmerge_amd._lib import DM_EPI_GELU, DM_NN, DM_NT
+    old = os.environ.get("DM_GEMM_FWD_SPLIT")
+    os.environ["DM_GEMM_FWD_SPLIT"] = "1"
+    try:
+        _forward_split_body(ops, layout, M, N, K, DM_EPI_GELU, DM_NN, DM_NT)
+    finally:
+        if old is None:
+            os.environ.pop("DM_GEMM_FWD_SPLIT", None)
+        else:
+            os.environ["DM_GEMM_FWD_SPLIT"] = old
+
+
+def _forward_split_body(ops, layout, M, N, K, DM_EPI_GELU, DM_NN, DM_NT):
+    rng = np.random.default_rng(M + N + K)
+    a = _ints(rng, (M, K), -2, 3)
+    b = _ints(rng, (N, K) if layout == "NT" else (K, N), -2, 3)
+    want = a.double() @ (b.double().T if layout == "NT" else b.double())
+    A, B_ = a.to(DEV).to(torch.bfloat16), b.to(DEV).to(torch.bfloat16)
+    lay, ldb = (DM_NT, K) if layout == "NT" else (DM_NN, N)
+    C32 = torch.full((M + 2, N), float("nan"), device=DEV)
+    ops.gemm(lay, A, B_, C32, M, N, K, lda=K, ldb=ldb, ldc=N)
+    assert torch.equal(C32[:M].cpu().double(), want) and torch.isnan(C32[M:]).all()
+    C16 = torch.empty((M, N), device=DEV, dtype=torch.bfloat16)
+    ops.gemm(lay, A, B_, C16, M, N, K, lda=K, ldb=ldb, ldc=N)
+    assert torch.equal(C16.cpu().double(), want.to(torch.bfloat16).double())
+    bias = torch.from_numpy(rng.normal(size=N).astype(np.float32))
+    res = torch.from_numpy(rng.normal(size=(M, N)).astype(np.float32))
+    out = torch.empty((M, N), device=DEV)
+    As = (a * 0.0078125).to(DEV).to(torch.bfloat16)          # exact in bf16
+    ops.gemm(lay, As, B_, out, M, N, K, lda=K, ldb=ldb, ldc=N, bias=bias.to(DEV), residual=res.to(DEV))
+    np.testing.assert_allclose(out.cpu().double().numpy(), (want * 0.0078125 + bias.double() + res.double()).numpy(), rtol=0, atol=3e-5)
+    pre = torch.empty((M, N), device=DEV, dtype=torch.bfloat16)
+    h = torch.empty((M, N), device=DEV, dtype=torch.bfloat16)
+    ops.gemm(lay, As, B_, h, M, N, K, lda=K, ldb=ldb, ldc=N, bias=bias.to(DEV), epilogue=DM_EPI_GELU, aux=pre, ldaux=N)
+    u = want * 0.0078125 + bias.double()
+    np.testing.assert_allclose(h.float().cpu().double().numpy(), torch.nn.functional.gelu(u).numpy(), rtol=1.6e-2, atol=1.6e-2)
+    np.testing.assert_allclose(pre.float().cpu().double().numpy(), u.numpy(), rtol=1.6e-2, atol=1.6e-2)
+
+
 @pytest.mark.parametrize("mode", ["fp32", "bf16"])
 @pytest.mark.parametrize("Mrows,N,K", [(16384, 768, 768), (4096, 2304, 768), (777 * 8, 768, 3072)])
 def test_gemm_wgrad_split_k(mode, Mrows, N, K):
