@@ -297,35 +297,36 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmParams p) {
   //   after MFMA 2: staging piece i of this phase's group (GRP: 0 = X, 1 = Y): register set SSET -> LDS buffer SBUF
   //   after MFMA 3: the freed set entry is refilled from global memory
   //   after MFMA 5: B fragment i of the next k-step (rows 0..5)
+  auto mm = [&](f32x4 &c, const u32x4 &a, const u32x4 &b) __attribute__((always_inline)) {
+    if constexpr (!(DBG & 32)) mma_pinned(c, a, b);
+  };
   auto mfmas = [&](auto ks_tag, auto nks_tag, auto nbuf_tag, auto grp_tag, auto sset_tag, auto sbuf_tag) __attribute__((always_inline)) {
     constexpr int ks = decltype(ks_tag)::value;
     constexpr int q0 = decltype(grp_tag)::value == 0 ? 0 : PH;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-#define mma_pinned(A_, B_, C_) do { if constexpr (!(DBG & 32)) (mma_pinned)(A_, B_, C_); } while (0)
-      mma_pinned(acc[i][0], fa[i], fb[ks][0]);
+      mm(acc[i][0], fa[i], fb[ks][0]);
       const u32x4 na = read_a(i, nks_tag, nbuf_tag);
       __builtin_amdgcn_sched_barrier(0);
-      mma_pinned(acc[i][1], fa[i], fb[ks][1]);
+      mm(acc[i][1], fa[i], fb[ks][1]);
       __builtin_amdgcn_sched_barrier(0);
-      mma_pinned(acc[i][2], fa[i], fb[ks][2]);
+      mm(acc[i][2], fa[i], fb[ks][2]);
       if (i < PH) lwrite(sset_tag, sbuf_tag, q0 + i);
       __builtin_amdgcn_sched_barrier(0);
-      mma_pinned(acc[i][3], fa[i], fb[ks][3]);
+      mm(acc[i][3], fa[i], fb[ks][3]);
       if (i < PH) gload(sset_tag, grp_tag, q0 + i);
       __builtin_amdgcn_sched_barrier(0);
-      mma_pinned(acc[i][4], fa[i], fb[ks][4]);
+      mm(acc[i][4], fa[i], fb[ks][4]);
       __builtin_amdgcn_sched_barrier(0);
-      mma_pinned(acc[i][5], fa[i], fb[ks][5]);
+      mm(acc[i][5], fa[i], fb[ks][5]);
       if (i < 6) load_b1(i, nks_tag, nbuf_tag);
       if constexpr (AMM) {
         if (colsum && wn == ks) {
-          mma_pinned(accb[i], fa[i], ones);
+          mm(accb[i], fa[i], ones);
         }
       }
       fa[i] = na;
       __builtin_amdgcn_sched_barrier(0);
-#undef mma_pinned
     }
     if constexpr (decltype(grp_tag)::value == 0) advance_x(); else advance_y();
   };

@@ -188,6 +188,7 @@ class CrossScaleAttention(nn.Module):
 
 
 class CrossScaleBlock(nn.Module):
+    _dm_fused_block = True      # every parameter gets its gradient from ops.BlockFn.backward only (see trainer.FlatParams: first-write sinks)
     """Pre-norm block x += attn(LN(x)); x += mlp(LN(x)) (reference :158-184).  The residual stream stays
     fp32; both residual additions are fused into the proj / fc2 GEMM epilogues."""
 
@@ -219,6 +220,7 @@ class CrossScaleBlock(nn.Module):
 
 
 class ShfitScaleFormer_v3(nn.Module):
+    _dm_first_write_blocks = True     # the blocks are only ever run through their fused forward: FlatParams need not zero their gradients
     """Multi-scale Siamese encoder, the variant the reference trains and serves (reference :772-1010)."""
 
     def __init__(self, num_classes=11, is_designed_feature_embedding=True, FeatureEmbed=FeatureEmbed, PatchEmbed=PatchEmbed,
@@ -450,6 +452,7 @@ class AuxBolck_v5(AuxBolck):
 
 
 class ShfitScaleFormer_v4(ShfitScaleFormer_v3):
+    _dm_first_write_blocks = False    # (not inherited: the auxiliary heads are separate autograd nodes; plain zero + accumulate)
     """v3 backbone + two auxiliary heads after blocks0 / blocks1 (reference :1013-1261).  Training returns
     ((x, aux0, aux1), (x, aux0, aux1)); eval returns x.  Three scales / 3 channels, as upstream.
 

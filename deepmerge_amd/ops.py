@@ -398,11 +398,11 @@ def _linear_backward(x, w, dy, need_dx, need_dw, need_db, wshape, wparam=None, b
         db = bsink if bsink is not None else torch.empty(N, dtype=torch.float32, device=x.device)
     if need_dw:
         dw = wsink if wsink is not None else torch.empty((N, K), dtype=torch.float32, device=x.device)
-        gemm(DM_TN, dy, x, dw, N, K, M, lda=N, ldb=K, ldc=K, accumulate=wsink is not None,
-             colsum_out=db, colsum_accumulate=bsink is not None)                   # db rides on the wgrad when it can
+        gemm(DM_TN, dy, x, dw, N, K, M, lda=N, ldb=K, ldc=K, accumulate=_acc(wparam, wsink is not None),
+             colsum_out=db, colsum_accumulate=_acc(bparam, bsink is not None))     # db rides on the wgrad when it can
         dw = None if wsink is not None else dw.reshape(wshape)
     elif need_db:
-        colsum(dy, db, accumulate=bsink is not None)
+        colsum(dy, db, accumulate=_acc(bparam, bsink is not None))
     if bsink is not None:
         db = None
     return dx, dw, db
@@ -537,7 +537,9 @@ class LayerNormFn(torch.autograd.Function):
         C = gamma.numel()
         gs, bs = _multi_use_sink(ctx.params[0], (C,)), _multi_use_sink(ctx.params[1], (C,))
         if gs is not None and bs is not None and ctx.needs_input_grad[1] and ctx.needs_input_grad[2]:
-            r = layernorm_bwd(dy.contiguous(), x, gamma, mean, rstd, dgamma=gs, dbeta=bs, accumulate=True)
+            acc = _acc(ctx.params[0], True)
+            _acc(ctx.params[1], True)
+            r = layernorm_bwd(dy.contiguous(), x, gamma, mean, rstd, dgamma=gs, dbeta=bs, accumulate=acc)
             return r[0], None, None, None, None
         dx, dg, db = layernorm_bwd(dy.contiguous(), x, gamma, mean, rstd)
         return dx, dg, db, None, None
@@ -641,8 +643,10 @@ class BatchNormReluFn(torch.autograd.Function):
         dg = gs if direct else torch.empty(Cc, dtype=torch.float32, device=x.device)
         db = bs if direct else torch.empty(Cc, dtype=torch.float32, device=x.device)
         ws = workspace(_lib.lib().dm_batchnorm_workspace_bytes(M, Cc), x.device, "bn")
+        acc = _acc(ctx.params[0], direct)
+        _acc(ctx.params[1], direct)
         check(_lib.lib().dm_batchnorm_bwd(dy.float().contiguous().data_ptr(), x.data_ptr(), y.data_ptr(), gamma.data_ptr(), _ptr(mask), rows_per_sample,
-                                          mean.data_ptr(), rstd.data_ptr(), dx.data_ptr(), dg.data_ptr(), db.data_ptr(), int(direct), M, Cc,
+                                          mean.data_ptr(), rstd.data_ptr(), dx.data_ptr(), dg.data_ptr(), db.data_ptr(), int(acc), M, Cc,
                                           int(training), int(relu), ws.data_ptr(), _stream()), "dm_batchnorm_bwd")
         return dx, (None if direct else dg), (None if direct else db), None, None, None, None, None, None, None, None
 
@@ -779,6 +783,19 @@ def _grad_out(param: torch.Tensor, shape, device):
     return torch.empty(shape, dtype=torch.float32, device=device), False
 
 
+def _acc(param, direct) -> bool:
+    """`accumulate` flag for a gradient write into `param`'s sink.  Parameters the trainer tracks (`_dm_gw`, set by FlatParams for the
+    parameters of the fused blocks) are not zeroed at the start of a step: their FIRST write of the step stores, later ones (a block
+    applied twice, gradient accumulation over several backward passes) add.  Untracked parameters: the buffer was zeroed, always add."""
+    if not direct:
+        return False
+    st = getattr(param, "_dm_gw", None)
+    if st is None or st[0]:
+        return True
+    st[0] = True
+    return False
+
+
 def _multi_use_sink(param, shape):
     """Gradient sink for the generic Functions (Linear, Mlp, LayerNorm), whose parameters may be used several times per step
     (the shared `norm`, the aux heads): their contributions accumulate into the trainer's flat buffer directly.  (The
@@ -881,24 +898,26 @@ class BlockFn(torch.autograd.Function):
             side.wait_stream(torch.cuda.current_stream())          # the operands' producers
             with torch.cuda.stream(side):
                 return gemm(*a, ws_slot="gemm_side", **kw)
-        wgrad(DM_TN, dy, h, dw2, Cc, Hd, M, lda=Cc, ldb=Hd, ldc=Hd, accumulate=k_w2, colsum_out=db2, colsum_accumulate=k_b2)
+        wgrad(DM_TN, dy, h, dw2, Cc, Hd, M, lda=Cc, ldb=Hd, ldc=Hd, accumulate=_acc(P_fc2_w, k_w2), colsum_out=db2, colsum_accumulate=_acc(P_fc2_b, k_b2))
         dpre = torch.empty((M, Hd), dtype=dtype, device=dev)
         gemm(DM_NN, dy, w2, dpre, M, Hd, Cc, lda=Cc, ldb=Hd, ldc=Hd, epilogue=DM_EPI_MUL, aux=pre, ldaux=Hd)
         dw1, k_w1 = _grad_out(P_fc1_w, (Hd, Cc), dev)
         db1, k_b1 = _grad_out(P_fc1_b, (Hd,), dev)
-        wgrad(DM_TN, dpre, y2, dw1, Hd, Cc, M, lda=Hd, ldb=Cc, ldc=Cc, accumulate=k_w1, colsum_out=db1, colsum_accumulate=k_b1)
+        wgrad(DM_TN, dpre, y2, dw1, Hd, Cc, M, lda=Hd, ldb=Cc, ldc=Cc, accumulate=_acc(P_fc1_w, k_w1), colsum_out=db1, colsum_accumulate=_acc(P_fc1_b, k_b1))
         dy2 = torch.empty((M, Cc), dtype=dtype, device=dev)
         gemm(DM_NN, dpre, w1, dy2, M, Cc, Hd, lda=Hd, ldb=Cc, ldc=Cc)
         dg2, k_n2 = _grad_out(P_n2w, (Cc,), dev)
         dbt2, k_n2b = _grad_out(P_n2b, (Cc,), dev)
         if k_n2 != k_n2b:      # mixed sinks: fall back to fresh tensors for both
             dg2, dbt2, k_n2, k_n2b = torch.empty(Cc, device=dev), torch.empty(Cc, device=dev), False, False
-        r = layernorm_bwd(dy2, x1, n2w, mean2, rstd2, dres=dx2, dgamma=dg2, dbeta=dbt2, accumulate=k_n2, want_lp=lp)
+        a_n2 = _acc(P_n2w, k_n2)
+        _acc(P_n2b, k_n2b)                              # (gamma and beta are written by the same launch)
+        r = layernorm_bwd(dy2, x1, n2w, mean2, rstd2, dres=dx2, dgamma=dg2, dbeta=dbt2, accumulate=a_n2, want_lp=lp)
         dx1, dx1_lp = (r[0], r[1]) if lp else (r[0], r[0])
         # ---- attention -----------------------------------------------------------------------
         dwp, k_wp = _grad_out(P_proj_w, (Cc, Cc), dev)
         dbp, k_bp = _grad_out(P_proj_b, (Cc,), dev)
-        wgrad(DM_TN, dx1_lp, o.view(M, Cc), dwp, Cc, Cc, M, lda=Cc, ldb=Cc, ldc=Cc, accumulate=k_wp, colsum_out=dbp, colsum_accumulate=k_bp)
+        wgrad(DM_TN, dx1_lp, o.view(M, Cc), dwp, Cc, Cc, M, lda=Cc, ldb=Cc, ldc=Cc, accumulate=_acc(P_proj_w, k_wp), colsum_out=dbp, colsum_accumulate=_acc(P_proj_b, k_bp))
         do = torch.empty((M, Cc), dtype=dtype, device=dev)
         gemm(DM_NN, dx1_lp, wp, do, M, Cc, Cc, lda=Cc, ldb=Cc, ldc=Cc)
         want_table = bias is not None
@@ -907,18 +926,20 @@ class BlockFn(torch.autograd.Function):
         dtable, k_t = None, False
         if want_table:
             dtable, k_t = _grad_out(P_table, (n_bins, heads), dev)
-            relpos_bias_scatter(slab, dtable, B, heads, rows, n_bins, accumulate=k_t)
+            relpos_bias_scatter(slab, dtable, B, heads, rows, n_bins, accumulate=_acc(P_table, k_t))
         dqkv2 = dqkv.view(M, 3 * Cc)
         dwq, k_wq = _grad_out(P_qkv_w, (3 * Cc, Cc), dev)
         dbq, k_bq = _grad_out(P_qkv_b, (3 * Cc,), dev)
-        wgrad(DM_TN, dqkv2, y1, dwq, 3 * Cc, Cc, M, lda=3 * Cc, ldb=Cc, ldc=Cc, accumulate=k_wq, colsum_out=dbq, colsum_accumulate=k_bq)
+        wgrad(DM_TN, dqkv2, y1, dwq, 3 * Cc, Cc, M, lda=3 * Cc, ldb=Cc, ldc=Cc, accumulate=_acc(P_qkv_w, k_wq), colsum_out=dbq, colsum_accumulate=_acc(P_qkv_b, k_bq))
         dy1 = torch.empty((M, Cc), dtype=dtype, device=dev)
         gemm(DM_NN, dqkv2, wq, dy1, M, Cc, 3 * Cc, lda=3 * Cc, ldb=Cc, ldc=Cc)
         dg1, k_n1 = _grad_out(P_n1w, (Cc,), dev)
         dbt1, k_n1b = _grad_out(P_n1b, (Cc,), dev)
         if k_n1 != k_n1b:
             dg1, dbt1, k_n1, k_n1b = torch.empty(Cc, device=dev), torch.empty(Cc, device=dev), False, False
-        r = layernorm_bwd(dy1, x, n1w, mean1, rstd1, dres=dx1, dgamma=dg1, dbeta=dbt1, accumulate=k_n1, want_lp=lp)
+        a_n1 = _acc(P_n1w, k_n1)
+        _acc(P_n1b, k_n1b)
+        r = layernorm_bwd(dy1, x, n1w, mean1, rstd1, dres=dx1, dgamma=dg1, dbeta=dbt1, accumulate=a_n1, want_lp=lp)
         if side is not None:
             torch.cuda.current_stream().wait_stream(side)          # join: every weight gradient of this block is complete
         dx = r[0].view(B, N, Cc)

@@ -46,7 +46,11 @@ def shard_slice(global_batch: int, rank: int, world: int) -> slice:
 class FlatParams:
     """Re-homes a module's parameters and gradients into flat fp32 buffers (views keep autograd working)."""
 
-    def __init__(self, module: torch.nn.Module, align: int = 64, lp_mirror: bool = True):
+    def __init__(self, module: torch.nn.Module, align: int = 64, lp_mirror: bool = True, first_write: Optional[bool] = None):
+        """first_write (default: on unless DM_GRAD_FIRST_WRITE=0): for models whose fused blocks are the only writers of their
+        parameters' gradients (`_dm_first_write_blocks` on the model class, `_dm_fused_block` on the block class) those gradients
+        are not zeroed at the start of a step; the first write of the step stores instead (ops._acc).  Saves the 195 MB memset and
+        the read of every weight gradient by its own first accumulation."""
         params = [p for p in module.parameters() if p.requires_grad]
         params.reverse()                      # backward order: last-used parameters first
         self.params = params
@@ -70,6 +74,31 @@ class FlatParams:
             if dev.type == "cuda":
                 # fused backward kernels accumulate straight into the flat gradient buffer (ops._grad_out)
                 p._dm_grad_sink = self.grad[o:o + n].view_as(p)
+        # ---- first-write gradient sinks ----------------------------------------------------------------------------------
+        if first_write is None:
+            first_write = os.environ.get("DM_GRAD_FIRST_WRITE", "1") != "0"
+        self.tracked = []                     # (param, offset, numel) of the parameters that are not zeroed by zero_grad()
+        if first_write and dev.type == "cuda" and getattr(module, "_dm_first_write_blocks", False):
+            ids = set()
+            for sub in module.modules():
+                if getattr(sub, "_dm_fused_block", False):
+                    ids.update(id(q) for q in sub.parameters())
+            for p, o in zip(params, offs):
+                if id(p) in ids:
+                    p._dm_gw = [False]
+                    self.tracked.append((p, o, p.numel()))
+        # what zero_grad() still has to clear: the maximal runs of untracked parameters (alignment gaps included)
+        self._zero_ranges, tr = [], {o for _, o, _ in self.tracked}
+        run = None
+        for p, o in zip(params, offs):
+            end = o + (p.numel() + align - 1) // align * align
+            if o in tr:
+                if run is not None:
+                    self._zero_ranges.append(tuple(run)); run = None
+            else:
+                run = [o, end] if run is None else [run[0], end]
+        if run is not None:
+            self._zero_ranges.append(tuple(run))
         self.refresh_lp()
 
     def refresh_lp(self):
@@ -78,10 +107,28 @@ class FlatParams:
             self.flat_lp.copy_(ops.cast(self.flat, torch.bfloat16))
 
     def zero_grad(self):
-        self.grad.zero_()
+        if self.tracked:
+            for lo, hi in self._zero_ranges:
+                self.grad[lo:hi].zero_()
+            for p, _, _ in self.tracked:
+                p._dm_gw[0] = False
+        else:
+            self.grad.zero_()
         for p, o in zip(self.params, self.offsets):      # re-attach views if something replaced them
             if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + 4 * o:
                 p.grad = self.grad[o:o + p.numel()].view_as(p)
+
+    def finish_grads(self, lo: int = 0, hi: Optional[int] = None) -> int:
+        """Call after the backward pass (of the range [lo, hi) of the flat buffer) and before its gradients are used: a tracked
+        parameter that received no gradient this step still holds last step's values -- clear it.  Returns how many there were."""
+        hi = self.total if hi is None else hi
+        n = 0
+        for p, o, cnt in self.tracked:
+            if lo <= o < hi and not p._dm_gw[0]:
+                self.grad[o:o + cnt].zero_()
+                p._dm_gw[0] = True
+                n += 1
+        return n
 
     def buckets(self, n_buckets: int) -> List[slice]:
         """Contiguous ranges of the flat buffer with roughly equal sizes, cut at parameter boundaries."""
@@ -128,8 +175,8 @@ class PairTrainer:
 
     def __init__(self, net: torch.nn.Module, margin: float = 1.0, lr: float = 1e-4, lamda: float = 0.1, belta: float = 0,
                  betas=(0.9, 0.999), eps: float = 1e-8, n_buckets: int = 4, process_group=None, criterion=None, adam_fn=None,
-                 segmented: Optional[bool] = None):
-        """`criterion` / `adam_fn` default to the HIP loss and fused Adam; tests of the exchange logic may
+                 segmented: Optional[bool] = None, first_write: Optional[bool] = None):
+        """`first_write`: see FlatParams.  `criterion` / `adam_fn` default to the HIP loss and fused Adam; tests of the exchange logic may
         inject stand-ins with the same signatures.  `segmented`: run the backward pass in segments (default: world > 1 and
         the model supports cuts); `n_buckets` is the bucket count for models without cut support."""
         self.net = net
@@ -141,7 +188,7 @@ class PairTrainer:
         # DM_DP_FORCE=1 (rehearsal): run the data-parallel schedule -- segmented backward, bucket all-reduces through the
         # initialised backend, per-segment graphs -- even with ONE rank, so that a one-GPU box exercises the RCCL calls
         self.force_dp = os.environ.get("DM_DP_FORCE") == "1" and dist.is_available() and dist.is_initialized()
-        self.fp = FlatParams(net, lp_mirror=(getattr(net, "numerics", "bf16") == "bf16"))
+        self.fp = FlatParams(net, lp_mirror=(getattr(net, "numerics", "bf16") == "bf16"), first_write=first_write)
         self.m = torch.zeros_like(self.fp.flat)
         self.v = torch.zeros_like(self.fp.flat)
         self.step_count = 0
@@ -168,6 +215,7 @@ class PairTrainer:
 
     def _launch_bucket(self, bi: int):
         sl = self.bucket_slices[bi]
+        self.fp.finish_grads(sl.start, sl.stop)
         if self.dp and self.exchange:
             self._log(f"launch bucket {bi} [{sl.start}:{sl.stop}] ({(sl.stop - sl.start) * 4 / 1e6:.1f} MB)")
             self._pending.append((bi, dist.all_reduce(self.fp.grad[sl], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)))
@@ -282,6 +330,7 @@ class PairTrainer:
                 self.fp.zero_grad()
                 loss = self._forward_loss(st)
                 loss.backward()
+                self.fp.finish_grads()
                 if not self.dp:
                     self._adam_slice(slice(0, self.fp.total), st["hyper"], 1.0)
                 st["loss"] = loss.detach()
@@ -313,6 +362,7 @@ class PairTrainer:
                 self._adam_slice(slice(0, self.fp.total), st["hyper"], 1.0 / self.world)
         finally:
             self.net._dp_cut = None
+        self.fp.finish_grads()      # (a tracked parameter no captured piece writes is cleared once here and stays clear: nothing replays a write to it)
         st["pieces"], st["adam"], st["cuts"] = pieces, ga, cuts           # the cut tensors keep the autograd segments alive
         self.bucket_slices, self._ready_after = self._segment_buckets(cuts)
         # the retired-workspace list of ops.workspace keeps every scratch buffer these graphs point into alive
@@ -406,6 +456,7 @@ class PairTrainer:
                 for bi in range(len(self.bucket_slices)):
                     self._launch_bucket(bi)
         self._wait_exchange()
+        self.fp.finish_grads()
         self.step_count += 1
         extra = {"param_lp": self.fp.flat_lp} if self.fp.flat_lp is not None else {}
         self.adam_fn(self.fp.flat, self.fp.grad, self.m, self.v, self.step_count, lr=self.lr if lr is None else lr,

@@ -97,6 +97,7 @@ class Attention(nn.Module):
 
 
 class Block(nn.Module):
+    _dm_fused_block = True      # see nets/ShfitScaleFormer.py CrossScaleBlock
     """Pre-norm block (vit_model.py:160-185) as ONE fused autograd node."""
 
     def __init__(self, dim, num_heads, mlp_ratio=4., qkv_bias=False, qk_scale=None, drop_ratio=0., attn_drop_ratio=0.,
@@ -139,6 +140,7 @@ class _Head(nn.Module):
 
 
 class VisionTransformer(nn.Module):
+    _dm_first_write_blocks = True
     """vit_model.py:188-317.  forward(*args): 1 / 2 / 3 tensors -> once / twice / thrice, else ValueError."""
 
     def __init__(self, img_size=224, patch_size=16, in_c=3, num_classes=1000, embed_dim=768, depth=12, num_heads=12,
@@ -221,6 +223,7 @@ class VisionTransformer(nn.Module):
 
 
 class ScaleEmbedTransformer(nn.Module):
+    _dm_first_write_blocks = True
     """vit_model.py:321-549: four per-scale patch embeds (28/4, 56/8, 112/16, 224/32 -> 49 tokens each) with
     learned positional embeddings, a cls token and a designed-feature token, 12 blocks, `my_head` 768 -> 100.
     forward(*args): 1 -> forward_once, 2 -> (patches, designed) [NOT a pair], 4 -> pair, else ValueError."""

@@ -354,6 +354,47 @@ def test_graph_replayed_step_equals_eager_step(mode):
         graphed.step([t[:2] for t in batches[0][0]], batches[0][1][:2], [t[:2] for t in batches[0][2]], batches[0][3][:2], batches[0][4][:2])
 
 
+@pytest.mark.parametrize("graph", [False, True])
+def test_first_write_gradient_sinks(graph):
+    """FlatParams(first_write=True): the fused blocks' gradients are not zeroed per step, their first write stores.  Three steps must
+    leave exactly the weights / Adam state of the zero-then-accumulate protocol; a tracked parameter that gets no gradient in a step is
+    cleared by finish_grads; a second backward without zero_grad accumulates."""
+    from deepmerge_amd.trainer import PairTrainer
+    tag = "v3_3s3c_111"
+    cfg = MODEL_CASES[tag]
+    left, ld, right, rd, flag = model_inputs(tag, cfg.scales, cfg.in_c, 4)
+    b = ([t.to(DEV) for t in left], ld.to(DEV), [t.to(DEV) for t in right], rd.to(DEV), flag.to(DEV))
+    nets = [build_model(tag, "bf16")[1].train() for _ in range(2)]
+    fw, plain = PairTrainer(nets[0], lr=1e-4, first_write=True), PairTrainer(nets[1], lr=1e-4, first_write=False)
+    assert len(fw.fp.tracked) >= 13 * sum(cfg.depth) and not plain.fp.tracked
+    assert sum(hi - lo for lo, hi in fw.fp._zero_ranges) < 0.2 * fw.fp.total
+    if graph:
+        fw.enable_graph(warmup=1); plain.enable_graph(warmup=1)
+    for i in range(4):
+        assert float(fw.step(*b)) == float(plain.step(*b))
+    assert torch.equal(fw.fp.flat, plain.fp.flat) and torch.equal(fw.fp.grad, plain.fp.grad)
+    assert torch.equal(fw.m, plain.m) and torch.equal(fw.v, plain.v)
+    if graph:
+        return
+    # a tracked parameter without a gradient this step: stale values are cleared before they are used
+    p, o, n = fw.fp.tracked[0]
+    fw.fp.zero_grad()
+    fw.fp.grad[o:o + n].fill_(7.0)
+    assert fw.fp.finish_grads() == len(fw.fp.tracked) and float(fw.fp.grad[o:o + n].abs().max()) == 0.0
+    # gradient accumulation over two backward passes (no zero_grad in between)
+    from deepmerge_amd.Losses import Loss
+    crit = Loss(1.0, 0.1, 0)
+    def grads(times):
+        fw.fp.zero_grad()
+        for _ in range(times):
+            fa, fb = fw.net(b[0], b[1], b[2], b[3])
+            crit(fa, fb, b[4]).backward()
+        fw.fp.finish_grads()
+        return fw.fp.grad.clone()
+    g1, g2 = grads(1), grads(2)
+    torch.testing.assert_close(g2, 2 * g1, rtol=1e-5, atol=1e-6)
+
+
 def test_graph_survives_workspace_growth():
     """the captured step has the raw addresses of the split-K / partial-reduction workspaces baked in.  A later,
     larger eager GEMM replaces those workspaces; the old buffers must stay allocated (ops._ws_retired), otherwise fresh
