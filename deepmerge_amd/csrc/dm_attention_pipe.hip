@@ -21,6 +21,28 @@ namespace dmpipe {
 
 constexpr int HD = 64;          // head dim
 constexpr int ROWS = 128;       // query rows per workgroup (8 waves x 16)
+constexpr int WB_PITCH = 144;   // write-back staging: 16 rows x (128 B + 16 B pad) per wave
+constexpr int WB_BYTES = 8 * 16 * WB_PITCH;
+
+// A wave holds a 16-row x 64-column result as v[dt] = columns dt * 16 + 4 g .. + 3 of row li (the MFMA layout): stored from there,
+// an instruction writes 8 bytes to each of 16 rows x 4 places.  Through a wave-private LDS block (no barrier: one wave, in-order LDS)
+// lane L ends up with the 16-byte chunk L & 7 of rows L >> 3 and 8 + (L >> 3): two stores, each covering eight whole 128-byte rows.
+// row0 = pointer to the wave's first row, stride = elements between rows, nvalid = rows of the 16 that exist.
+__device__ __forceinline__ void wb_rows16(char *stage, const f32x4 (&v)[4], bf16_t *row0, long long stride, int lane, int nvalid) {
+  const int g = lane >> 4, li = lane & 15;
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) {
+    const bf16x4 r = {(bf16_t)v[dt][0], (bf16_t)v[dt][1], (bf16_t)v[dt][2], (bf16_t)v[dt][3]};
+    *reinterpret_cast<bf16x4 *>(stage + li * WB_PITCH + (dt * 16 + 4 * g) * 2) = r;
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  const int r = lane >> 3, c = lane & 7;
+  const u32x4 a = *reinterpret_cast<const u32x4 *>(stage + r * WB_PITCH + c * 16);
+  const u32x4 b = *reinterpret_cast<const u32x4 *>(stage + (r + 8) * WB_PITCH + c * 16);
+  if (r < nvalid) *reinterpret_cast<u32x4 *>(row0 + (long long)r * stride + c * 8) = a;
+  if (r + 8 < nvalid) *reinterpret_cast<u32x4 *>(row0 + (long long)(r + 8) * stride + c * 8) = b;
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // (the block is reused by the next call)
+}
 
 #define DM_LDS_DMA(rsrc, dst, voff, soff) \
   __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void *)(dst), 16, (int)(voff), (int)(soff), 0, 0)
@@ -114,12 +136,13 @@ __global__ __launch_bounds__(512) void attn_fwd_pipe_kernel(const AttnPipeParams
   // for memory operations issued a whole sample earlier (never for stores it has just issued)
   f32x4 o_prev[4];
   float lse_prev = 0.f;
+  char *wb_stage = smem + 4 * IMG + wave * (16 * WB_PITCH);
+  const int q_wave = rb * ROWS + wave * 16;
   auto write_back = [&](int b) {
-    if (!wave_live || !row_ok) return;
-    bf16_t *orow = reinterpret_cast<bf16_t *>(p.out) + ((long long)b * N + q) * H * HD + (long long)h * HD;
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt) dm_store4(orow + dt * 16 + 4 * g, o_prev[dt]);
-    if (g == 0) p.lse[((long long)b * H + h) * N + q] = lse_prev;
+    if (!wave_live) return;
+    bf16_t *orow0 = reinterpret_cast<bf16_t *>(p.out) + ((long long)b * N + q_wave) * H * HD + (long long)h * HD;
+    wb_rows16(wb_stage, o_prev, orow0, (long long)H * HD, lane, N - q_wave);
+    if (g == 0 && row_ok) p.lse[((long long)b * H + h) * N + q] = lse_prev;
   };
   stage(b0, 0);
   load_q(b0, fq);
@@ -328,12 +351,13 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_pipe_kernel(const AttnPipeBwd
   float lse = 0.f, lse_n = 0.f;
   f32x4 o_prev[4];
   float delta_prev = 0.f;
+  char *wb_stage = smem + 4 * NP * 128 + wave * (16 * WB_PITCH);
+  const int q_wave = rb * ROWS + wave * 16;
   auto write_back = [&](int b) {
-    if (!wave_live || !row_ok) return;
-    bf16_t *dq = reinterpret_cast<bf16_t *>(p.dqkv) + ((long long)b * N + q) * tok_stride + (long long)h * HD;
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt) dm_store4(dq + dt * 16 + 4 * g, o_prev[dt]);
-    if (g == 0) p.delta[((long long)b * H + h) * N + q] = delta_prev;
+    if (!wave_live) return;
+    bf16_t *dq0 = reinterpret_cast<bf16_t *>(p.dqkv) + ((long long)b * N + q_wave) * tok_stride + (long long)h * HD;
+    wb_rows16(wb_stage, o_prev, dq0, tok_stride, lane, N - q_wave);
+    if (g == 0 && row_ok) p.delta[((long long)b * H + h) * N + q] = delta_prev;
   };
 
   stage(b0, 0);
@@ -466,14 +490,23 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_pipe_kernel(const AttnPipeBw
 
   u32x4 fk[2], fv[2], fk_n[2], fv_n[2];
   f32x4 dk_prev[4], dv_prev[4];
+  char *wb_stage = smem + 2 * (2 * NP * 128 + 2048) + wave * (16 * WB_PITCH);
+  const int key_wave = rb * ROWS + wave * 16;
   auto write_back = [&](int b) {
-    if (!wave_live || !row_ok) return;
-    bf16_t *dk = reinterpret_cast<bf16_t *>(p.dqkv) + ((long long)b * N + key) * tok_stride + (long long)H * HD + (long long)h * HD;
-    bf16_t *dv = dk + (long long)H * HD;
+    if (!wave_live) return;
+    bf16_t *dk0 = reinterpret_cast<bf16_t *>(p.dqkv) + ((long long)b * N + key_wave) * tok_stride + (long long)H * HD + (long long)h * HD;
+    // Measured (tools/mb_attn.py, one box): whole-row write-back makes the bias-free kernel faster (ViT, N = 197: backward
+    // 418 -> 398 us) and the one that also carries the bias-gradient accumulators slower (N = 256: 139 -> 149 us): strips stay there.
+    if constexpr (!BIAS) {
+      wb_rows16(wb_stage, dk_prev, dk0, tok_stride, lane, N - key_wave);
+      wb_rows16(wb_stage, dv_prev, dk0 + (long long)H * HD, tok_stride, lane, N - key_wave);
+    } else if (row_ok) {
+      bf16_t *dk = dk0 + (long long)li * tok_stride, *dv = dk + (long long)H * HD;
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt) {
-      dm_store4(dk + dt * 16 + 4 * g, dk_prev[dt]);
-      dm_store4(dv + dt * 16 + 4 * g, dv_prev[dt]);
+      for (int dt = 0; dt < 4; ++dt) {
+        dm_store4(dk + dt * 16 + 4 * g, dk_prev[dt]);
+        dm_store4(dv + dt * 16 + 4 * g, dv_prev[dt]);
+      }
     }
   };
 
@@ -563,7 +596,7 @@ inline void pipe_grid(int B, int N, int H, int &nblk, int &chunks, int &bchunk) 
 
 template <int NKT, bool RAGGED> void launch_bwd(const AttnPipeBwdParams &p, hipStream_t s) {
   constexpr int NP = NKT * 16;
-  constexpr int LDS_DQ = 4 * NP * 128, LDS_DKV = 2 * (2 * NP * 128 + 2048);
+  constexpr int LDS_DQ = 4 * NP * 128 + WB_BYTES, LDS_DKV = 2 * (2 * NP * 128 + 2048) + WB_BYTES;
   static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void *>(attn_bwd_dq_pipe_kernel<NKT, RAGGED>),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DQ) == hipSuccess &&
                          hipFuncSetAttribute(reinterpret_cast<const void *>(attn_bwd_dkv_pipe_kernel<NKT, RAGGED, true>),
@@ -582,7 +615,7 @@ template <int NKT, bool RAGGED> void launch_bwd(const AttnPipeBwdParams &p, hipS
 
 template <int NKT, bool RAGGED> void launch(const AttnPipeParams &p, hipStream_t s) {
   constexpr int NP = NKT * 16;
-  constexpr int LDS = 4 * NP * 128;
+  constexpr int LDS = 4 * NP * 128 + WB_BYTES;
   static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void *>(attn_fwd_pipe_kernel<NKT, RAGGED>),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS) == hipSuccess;
   (void)ok;
