@@ -126,3 +126,23 @@ def test_vit_huge_factory_and_bf16_mode():
     errs = [recipe.summary_error(tag + "/grad/" + n, p.grad.cpu().numpy(), fx, k=512)[0] for n, p in net.named_parameters()]
     print(f"ViT-H/14 (2 blocks) bf16 drift: embeddings rel-L2 {e[0]:.2e}; median grad rel-L2 {np.median(errs):.2e}")
     assert e[0] < 3e-2 and np.median(errs) < 0.25
+
+
+def test_scale_embed_trainer_first_write_sinks():
+    """ScaleEmbedTransformer under PairTrainer: its blocks' gradients take the first-write path (FlatParams.tracked); three steps leave
+    the same weights and Adam state, bit for bit, as zero-then-accumulate."""
+    from deepmerge_amd.trainer import PairTrainer
+    vm = VM()
+    xa, fa, xb, fb, flag = scale_inputs("vitscale_d2")
+    b = ([t.to(DEV) for t in xa], fa.to(DEV), [t.to(DEV) for t in xb], fb.to(DEV), flag.to(DEV))
+    nets = []
+    for _ in range(2):
+        net = vm.ScaleEmbedTransformer(img_size=224, patch_size=16, embed_dim=768, depth=2, num_heads=12, representation_size=None,
+                                       num_classes=512, numerics="bf16")
+        nets.append(load_recipe_weights(net).to(DEV).train())
+    fw, plain = PairTrainer(nets[0], lr=1e-4, first_write=True), PairTrainer(nets[1], lr=1e-4, first_write=False)
+    assert len(fw.fp.tracked) >= 2 * 11 and not plain.fp.tracked
+    for _ in range(3):
+        assert float(fw.step(*b)) == float(plain.step(*b))
+    assert torch.equal(fw.fp.flat, plain.fp.flat) and torch.equal(fw.m, plain.m) and torch.equal(fw.v, plain.v)
+
