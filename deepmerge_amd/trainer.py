@@ -78,11 +78,13 @@ class FlatParams:
         if first_write is None:
             first_write = os.environ.get("DM_GRAD_FIRST_WRITE", "1") != "0"
         self.tracked = []                     # (param, offset, numel) of the parameters that are not zeroed by zero_grad()
-        if first_write and dev.type == "cuda" and getattr(module, "_dm_first_write_blocks", False):
+        if first_write and dev.type == "cuda":
             ids = set()
-            for sub in module.modules():
-                if getattr(sub, "_dm_fused_block", False):
-                    ids.update(id(q) for q in sub.parameters())
+            for model in module.modules():          # the module itself or a model wrapped inside it (adapters around the pair signature)
+                if getattr(model, "_dm_first_write_blocks", False):
+                    for sub in model.modules():
+                        if getattr(sub, "_dm_fused_block", False):
+                            ids.update(id(q) for q in sub.parameters())
             for p, o in zip(params, offs):
                 if id(p) in ids:
                     p._dm_gw = [False]
