@@ -234,8 +234,8 @@ class ScaleEmbedTransformer(nn.Module):
                  is_feature_embed=True, feature_embed=FeatureEmbed, is_label_embed=False, norm_layer=None, act_layer=None,
                  numerics=None):
         super().__init__()
-        if distilled or is_label_embed:
-            raise NotImplementedError("distilled / label-token variants are not used by the reference's drivers")
+        if distilled:
+            raise NotImplementedError("the distillation-token variant is not used by the reference's drivers")
         _check_dim(embed_dim)
         self.numerics = _mode(numerics)
         self.num_classes = num_classes
@@ -254,6 +254,8 @@ class ScaleEmbedTransformer(nn.Module):
         self.patch_embed3 = mk(224, 32) if is_multiscale_embed else None
         self.cls_token = nn.Parameter(torch.zeros(1, 1, embed_dim))
         self.is_label_embed = is_label_embed
+        if is_label_embed:                       # vit_model.py:369-371
+            self.label_token = nn.Parameter(torch.zeros(1, 1, embed_dim))
         self.dist_token = None
         self.is_feature_embed = is_feature_embed
         self.feature_embed = feature_embed(feature_size=19, embed_dim=768) if is_feature_embed else None
@@ -275,14 +277,26 @@ class ScaleEmbedTransformer(nn.Module):
         else:
             self.has_logits = False
             self.pre_logits = nn.Identity()
-        self.class_logits = nn.Identity()
+        self.class_logits = nn.Linear(100, 11) if is_label_embed else nn.Identity()          # :408-412
         self.head = nn.Linear(self.num_features, num_classes) if num_classes > 0 else nn.Identity()
         self.head_dist = None
         self.my_head = nn.Linear(768, 100)
-        self.my_class_head = nn.Identity()
+        # :422-432 -- parameter containers; the arithmetic is in _class_head below
+        self.my_class_head = nn.Sequential(nn.Linear(embed_dim, 100), nn.GELU(), nn.Dropout(0.3), nn.Linear(100, 100)) \
+            if is_label_embed else nn.Identity()
         for pe in (self.pos_embed_non_multiscale, self.pos_embed0, self.pos_embed1, self.pos_embed2, self.pos_embed3, self.cls_token):
             nn.init.trunc_normal_(pe, std=0.02)
+        if is_label_embed:
+            nn.init.trunc_normal_(self.label_token, std=0.02)
         self.apply(_init_vit_weights)
+
+    def _class_head(self, x):
+        """my_class_head on the label token's row: Linear -> GELU -> Dropout(0.3) -> Linear (vit_model.py:424-429); the two
+        products run on the library, GELU / dropout on [rows, 100] values stay torch element-wise calls."""
+        h = self.my_class_head
+        y = torch.nn.functional.gelu(_Head.linear(x, h[0]))
+        y = torch.nn.functional.dropout(y, h[2].p, self.training)
+        return _Head.linear(y, h[3])
 
     def forward_features(self, x, designed_feature):
         if self.is_multiscale_embed:
@@ -293,7 +307,12 @@ class ScaleEmbedTransformer(nn.Module):
             x = self.patch_embed(x) + self.pos_embed_non_multiscale
         cls_token = self.cls_token.expand(x.shape[0], -1, -1)
         if self.is_feature_embed:
-            x = torch.cat((cls_token, self.feature_embed(designed_feature), x), dim=1)
+            f = self.feature_embed(designed_feature)
+            x = torch.cat((cls_token, f, x), dim=1)
+            if self.is_label_embed:
+                # vit_model.py:480-483 concatenates onto the ALREADY prefixed sequence: cls, label, designed, cls, designed,
+                # patches (201 tokens) -- kept as the reference does it
+                x = torch.cat((cls_token, self.label_token.expand(x.shape[0], -1, -1), f, x), dim=1)
         else:
             x = torch.cat((cls_token, x), dim=1)
         x = self.blocks(self.pos_drop(x))
@@ -301,6 +320,9 @@ class ScaleEmbedTransformer(nn.Module):
         y = _Head.linear(x[:, 0], self.my_head)
         if self.has_logits:
             y = torch.tanh(_Head.linear(y, self.pre_logits.fc))
+        if self.is_label_embed:                  # :503-506 -> (embedding, class logits [*, 11], class features [*, 100])
+            x_class = self._class_head(x[:, 1])
+            return y, _Head.linear(x_class, self.class_logits), x_class
         return y
 
     def forward_once(self, x):
@@ -318,6 +340,8 @@ class ScaleEmbedTransformer(nn.Module):
         else:
             xs = torch.cat((x1, x3), 0)
         y = self.forward_features(xs, torch.cat((x2, x4), 0))
+        if self.is_label_embed:
+            return tuple(v[:B] for v in y), tuple(v[B:] for v in y)
         return y[:B], y[B:]
 
     def forward(self, *args):

@@ -114,11 +114,13 @@ SCALE_EMBEDS = ((28, 4), (56, 8), (112, 16), (224, 32))       # (img_size, patch
 
 
 def scale_param_spec(depth: int = 12, dim: int = 768, hidden: int = 3072, in_c: int = 3, num_classes: int = 512,
-                     representation_size: int = 0) -> "OrderedDict[str, Tuple[Tuple[int, ...], str]]":
-    """state_dict manifest for is_multiscale_embed=True, is_feature_embed=True, is_label_embed=False."""
+                     representation_size: int = 0, label: bool = False) -> "OrderedDict[str, Tuple[Tuple[int, ...], str]]":
+    """state_dict manifest for is_multiscale_embed=True, is_feature_embed=True; label = is_label_embed (:369-371, :408-432)."""
     C = dim
     spec: "OrderedDict[str, Tuple[Tuple[int, ...], str]]" = OrderedDict()
     spec["cls_token"] = ((1, 1, C), "float32")
+    if label:
+        spec["label_token"] = ((1, 1, C), "float32")
     for i in range(4):
         spec[f"pos_embed{i}"] = ((1, 49, C), "float32")
     spec["pos_embed_non_multiscale"] = ((1, 196, C), "float32")
@@ -136,26 +138,40 @@ def scale_param_spec(depth: int = 12, dim: int = 768, hidden: int = 3072, in_c: 
         spec["pre_logits.fc.weight"] = ((representation_size, C), "float32")
         spec["pre_logits.fc.bias"] = ((representation_size,), "float32")
         feat = representation_size
+    if label:
+        spec["class_logits.weight"] = ((11, 100), "float32"); spec["class_logits.bias"] = ((11,), "float32")
     spec["head.weight"] = ((num_classes, feat), "float32"); spec["head.bias"] = ((num_classes,), "float32")
     spec["my_head.weight"] = ((100, 768), "float32"); spec["my_head.bias"] = ((100,), "float32")
+    if label:
+        spec["my_class_head.0.weight"] = ((100, C), "float32"); spec["my_class_head.0.bias"] = ((100,), "float32")
+        spec["my_class_head.3.weight"] = ((100, 100), "float32"); spec["my_class_head.3.bias"] = ((100,), "float32")
     return spec
 
 
 def scale_forward_features(p: Params, patches: Sequence[torch.Tensor], designed: torch.Tensor, depth: int = 12, heads: int = 12,
-                           scales=(1, 1, 1, 1), representation_size: int = 0) -> torch.Tensor:
-    """forward_features (:448-511): 4 scaled patch embeds + cls + designed-feature token -> blocks -> norm -> my_head(x[:,0])."""
+                           scales=(1, 1, 1, 1), representation_size: int = 0, label: bool = False):
+    """forward_features (:448-511): 4 scaled patch embeds + cls + designed-feature token -> blocks -> norm -> my_head(x[:,0]).
+    label (is_label_embed, :480-483, :503-506): the sequence becomes cls, label, designed, cls, designed, patches and the
+    result (embedding, class_logits(x_class), x_class) with x_class = my_class_head(x[:,1]); Dropout(0.3) is the identity here
+    (the fixture sets p = 0 on the reference instance: its RNG stream is not reproducible)."""
     C = p["cls_token"].shape[-1]
     xs = [(_patch_tokens(p, f"patch_embed{i}.", patches[i], ps) + p[f"pos_embed{i}"]) * scales[i]
           for i, (_, ps) in enumerate(SCALE_EMBEDS)]
     x = torch.cat(xs, 1)
     f = feature_embed(p, "feature_embed.", designed)
     x = torch.cat((p["cls_token"].expand(x.shape[0], -1, -1), f, x), dim=1)
+    if label:
+        x = torch.cat((p["cls_token"].expand(x.shape[0], -1, -1), p["label_token"].expand(x.shape[0], -1, -1), f, x), dim=1)
     for j in range(depth):
         x = block(p, f"blocks.{j}.", x, heads)
     x = F.layer_norm(x, (C,), p["norm.weight"], p["norm.bias"], EPS)
     y = F.linear(x[:, 0], p["my_head.weight"], p["my_head.bias"])
     if representation_size:
         y = torch.tanh(F.linear(y, p["pre_logits.fc.weight"], p["pre_logits.fc.bias"]))
+    if label:
+        c = F.gelu(F.linear(x[:, 1], p["my_class_head.0.weight"], p["my_class_head.0.bias"]))
+        c = F.linear(c, p["my_class_head.3.weight"], p["my_class_head.3.bias"])
+        return y, F.linear(c, p["class_logits.weight"], p["class_logits.bias"]), c
     return y
 
 

@@ -432,6 +432,48 @@ def gen_vit(vit_model, Losses):
         two = net(xa, fa)                      # 2 args = (patches, designed), NOT a pair (:544-545)
         fx[tag + "/two_args_equals_left"] = np.bool_(torch.equal(two, ya))
         print(tag, "loss", fx[tag + "/loss"], "dist", fx[tag + "/dist"], "none", none)
+    # ---- ScaleEmbedTransformer with is_label_embed=True (vit_model.py:369-371, :408-432, :480-483, :503-506): label token,
+    #      my_class_head / class_logits, 3-tuple result.  Dropout(0.3) of my_class_head is set to p = 0 on the instance (its RNG
+    #      stream is not reproducible); loss = contrastive(embeddings) + cross entropy of both sides' class logits
+    #      + 0.01 * sum(x_class^2), so every returned value carries gradient ------------------------------------------------
+    tag = "vitscale_label_d2"
+    if not have(tag):
+        net = vit_model.ScaleEmbedTransformer(img_size=224, patch_size=16, embed_dim=768, depth=2, num_heads=12,
+                                              representation_size=None, num_classes=512, is_label_embed=True)
+        net.my_class_head[2].p = 0.0
+        load_det_weights(net, "")
+        sd = net.state_dict()
+        fx[tag + "/manifest_keys"] = np.array(list(sd.keys()))
+        fx[tag + "/manifest_shapes"] = np.array([",".join(map(str, v.shape)) for v in sd.values()])
+        fx[tag + "/n_params"] = np.int64(sum(p.numel() for p in net.parameters()))
+        sizes = (28, 56, 112, 224)
+        xa = [t(f"{tag}.xa{i}", (2, 3, s, s), "unit") for i, s in enumerate(sizes)]
+        xb = [t(f"{tag}.xb{i}", (2, 3, s, s), "unit") for i, s in enumerate(sizes)]
+        fa = t(tag + ".fa", (2, 1, 19), "designed"); fb = t(tag + ".fb", (2, 1, 19), "designed")
+        for i in range(4):
+            xb[i][1] = xa[i][1] * 0.8 + 0.2 * xb[i][1]
+        fb[1] = fa[1] * 1.2
+        la, lb = torch.tensor([3, 7]), torch.tensor([0, 10])
+        net.train()
+        ra, rb = net(xa, fa, xb, fb)
+        assert len(ra) == 3 and len(rb) == 3
+        ce = torch.nn.functional.cross_entropy
+        loss = crit(ra[0], rb[0], flag) + ce(ra[1], la) + ce(rb[1], lb) + 0.01 * (ra[2].pow(2).sum() + rb[2].pow(2).sum())
+        loss.backward()
+        for side, r in (("a", ra), ("b", rb)):
+            add(fx, f"{tag}/out_{side}", r[0]); add(fx, f"{tag}/logits_{side}", r[1]); add(fx, f"{tag}/class_{side}", r[2])
+        fx[tag + "/loss"] = np.float64(loss.item())
+        fx[tag + "/tokens"] = np.int64(201)
+        none = []
+        for n, p in net.named_parameters():
+            if p.grad is None:
+                none.append(n)
+            else:
+                add(fx, tag + "/grad/" + n, p.grad, k=512)
+        fx[tag + "/grad_none"] = np.array(none)
+        two = net(xa, fa)
+        fx[tag + "/two_args_equals_left"] = np.bool_(all(torch.equal(u, v) for u, v in zip(two, ra)))
+        print(tag, "loss", fx[tag + "/loss"], "none", none, "params", int(fx[tag + "/n_params"]))
     if old is not None:
         fx.update({k: old[k] for k in old.files})
     np.savez_compressed(path, **fx)

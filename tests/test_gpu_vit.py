@@ -146,3 +146,48 @@ def test_scale_embed_trainer_first_write_sinks():
         assert float(fw.step(*b)) == float(plain.step(*b))
     assert torch.equal(fw.fp.flat, plain.fp.flat) and torch.equal(fw.m, plain.m) and torch.equal(fw.v, plain.v)
 
+
+
+def test_scale_embed_transformer_label_token_parity_fp32():
+    """is_label_embed=True (vit_model.py:369-371, :408-432, :480-483, :503-506): label token, my_class_head / class_logits,
+    (embedding, class logits, class features) per side; Dropout(0.3) at p = 0 on both sides as in the fixture."""
+    from deepmerge_amd.Losses import Loss
+    from test_oracle_vit import label_inputs, label_loss
+    tag = "vitscale_label_d2"
+    fx = load_fx("model_vit.npz")
+    net = VM().ScaleEmbedTransformer(img_size=224, patch_size=16, embed_dim=768, depth=2, num_heads=12, representation_size=None,
+                                     num_classes=512, is_label_embed=True, numerics="fp32")
+    sd = net.state_dict()
+    assert list(sd.keys()) == [str(k) for k in fx[tag + "/manifest_keys"]]
+    assert [",".join(map(str, v.shape)) for v in sd.values()] == [str(s) for s in fx[tag + "/manifest_shapes"]]
+    assert sum(p.numel() for p in net.parameters()) == int(fx[tag + "/n_params"])
+    assert net.my_class_head[2].p == 0.3
+    net.my_class_head[2].p = 0.0
+    net = load_recipe_weights(net).to(DEV).train()
+    xa, fa, xb, fb, flag, la, lb = label_inputs(tag)
+    ra, rb = net([t.to(DEV) for t in xa], fa.to(DEV), [t.to(DEV) for t in xb], fb.to(DEV))
+    assert len(ra) == 3 and len(rb) == 3 and ra[1].shape == (2, 11) and ra[2].shape == (2, 100)
+    loss = label_loss(ra, rb, flag.to(DEV), la.to(DEV), lb.to(DEV), Loss(1.0, 0.1, 0))
+    loss.backward()
+    for side, r in (("a", ra), ("b", rb)):
+        recipe.check_summary(f"{tag}/out_{side}", r[0].detach().cpu().numpy(), fx, GATE)
+        recipe.check_summary(f"{tag}/logits_{side}", r[1].detach().cpu().numpy(), fx, GATE)
+        recipe.check_summary(f"{tag}/class_{side}", r[2].detach().cpu().numpy(), fx, GATE)
+    assert abs(loss.item() - float(fx[tag + "/loss"])) <= GATE * abs(float(fx[tag + "/loss"]))
+    none = sorted(n for n, p in net.named_parameters() if p.grad is None)
+    assert none == sorted(str(s) for s in fx[tag + "/grad_none"])
+    worst = 0.0
+    for n, p in net.named_parameters():
+        if p.grad is not None:
+            recipe.check_summary(tag + "/grad/" + n, p.grad.cpu().numpy(), fx, GATE, k=512, atol=1e-7)
+            worst = max(worst, recipe.summary_error(tag + "/grad/" + n, p.grad.cpu().numpy(), fx, k=512)[0])
+    print(f"{tag}: worst gradient rel-L2 error {worst:.2e}")
+    with torch.no_grad():
+        two = net([t.to(DEV) for t in xa], fa.to(DEV))
+    for v, key in zip(two, ("out_a", "logits_a", "class_a")):
+        recipe.check_summary(f"{tag}/{key}", v.cpu().numpy(), fx, GATE)
+    # train-mode dropout at the reference's p = 0.3 zeroes entries of the hidden layer (smoke check of the wiring)
+    net.my_class_head[2].p = 0.3
+    with torch.no_grad():
+        r1 = net([t.to(DEV) for t in xa], fa.to(DEV))
+    assert not torch.equal(r1[2], two[2]) and torch.equal(r1[0], two[0])

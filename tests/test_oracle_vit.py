@@ -77,3 +77,40 @@ def test_scale_embed_transformer_pair(tag, depth):
     assert bool(fx[tag + "/two_args_equals_left"])
     if depth == 12:
         assert int(fx[tag + "/n_params"]) == 90161508
+
+
+def label_inputs(tag="vitscale_label_d2"):
+    xa, fa, xb, fb, flag = scale_inputs(tag)
+    return xa, fa, xb, fb, flag, torch.tensor([3, 7]), torch.tensor([0, 10])
+
+
+def label_loss(ra, rb, flag, la, lb, contrastive):
+    """The fixture's loss (tests/golden/make_golden.py): every value of the 3-tuple result carries gradient."""
+    ce = torch.nn.functional.cross_entropy
+    return contrastive(ra[0], rb[0], flag) + ce(ra[1], la) + ce(rb[1], lb) + 0.01 * (ra[2].pow(2).sum() + rb[2].pow(2).sum())
+
+
+def test_scale_embed_transformer_label_token():
+    """is_label_embed=True (vit_model.py:369-371, :408-432, :480-483, :503-506): 201-token sequence, 3-tuple result."""
+    tag = "vitscale_label_d2"
+    fx = load_fx("model_vit.npz")
+    spec = OV.scale_param_spec(depth=2, num_classes=512, label=True)
+    assert list(spec.keys()) == [str(k) for k in fx[tag + "/manifest_keys"]]
+    assert [",".join(map(str, s)) for s, _ in spec.values()] == [str(s) for s in fx[tag + "/manifest_shapes"]]
+    p = det_params(spec.items())
+    xa, fa, xb, fb, flag, la, lb = label_inputs(tag)
+    ra = OV.scale_forward_features(p, xa, fa, depth=2, label=True)
+    rb = OV.scale_forward_features(p, xb, fb, depth=2, label=True)
+    loss = label_loss(ra, rb, flag, la, lb, lambda a, b, f: OL.contrastive_loss(a, b, f, 1.0))
+    loss.backward()
+    for side, r in (("a", ra), ("b", rb)):
+        recipe.check_summary(f"{tag}/out_{side}", r[0].detach().numpy(), fx, RTOL)
+        recipe.check_summary(f"{tag}/logits_{side}", r[1].detach().numpy(), fx, RTOL)
+        recipe.check_summary(f"{tag}/class_{side}", r[2].detach().numpy(), fx, RTOL)
+    assert abs(loss.item() - float(fx[tag + "/loss"])) <= 5e-5 * abs(float(fx[tag + "/loss"]))
+    none = sorted(str(s) for s in fx[tag + "/grad_none"])
+    assert sorted(k for k in spec if p[k].grad is None) == none
+    for k in spec:
+        if p[k].grad is not None:
+            recipe.check_summary(tag + "/grad/" + k, p[k].grad.numpy(), fx, 1e-4, k=512, atol=1e-9)
+    assert bool(fx[tag + "/two_args_equals_left"])
