@@ -145,7 +145,26 @@ def extras(args, scales, in_c, depth, dev):
         torch.cuda.synchronize(); d = (time.perf_counter() - t0) / 5
         out["fp32_parity_pairs_per_s"] = round(args.pairs / d, 1)
         out["fp32_parity_ms_per_step"] = round(1e3 * d, 2)
-        del net, tr, batch
+        del net, tr
+        torch.cuda.empty_cache()
+        log("extras: bf16x3 mode (fp32 path, large products as split-bf16 triples on the bf16 matrix pipe), 5 steps")
+        from deepmerge_amd import ops
+        try:
+            torch.manual_seed(0)
+            net = ShfitScaleFormer_v3(cube_size=[8, 8], input_image_scales=list(scales), depth=list(depth), in_c=in_c, numerics="bf16x3").to(dev)
+            tr = PairTrainer(net, margin=1.0, lr=1e-4)
+            for _ in range(2):
+                tr.step(*batch)
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            for _ in range(5):
+                tr.step(*batch)
+            torch.cuda.synchronize(); d = (time.perf_counter() - t0) / 5
+            out["bf16x3_pairs_per_s"] = round(args.pairs / d, 1)
+            out["bf16x3_ms_per_step"] = round(1e3 * d, 2)
+            del net, tr
+        finally:
+            ops.set_fp32_products("mfma_f32")
+        del batch
         torch.cuda.empty_cache()
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         import bench_configs as BC
@@ -174,7 +193,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--pairs", type=int, default=32, help="pairs per GPU per step")
     ap.add_argument("--depth", type=str, default="3,2,1")
-    ap.add_argument("--numerics", type=str, default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--numerics", type=str, default="bf16", choices=["bf16", "fp32", "bf16x3"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-pairs", type=int, default=0, help="pairs per CPU-baseline step (0 = the same batch as --pairs, SURVEY 8d)")
     ap.add_argument("--cpu-steps", type=int, default=3, help="timed CPU-baseline steps after one warm-up")
@@ -347,7 +366,7 @@ def main():
             "metric": "superpixel-pairs/sec (train step)", "value": round(value, 2), "unit": "pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16" if args.numerics == "bf16" else "f32", "data": "synthetic",
+            "dtype": {"bf16": "bf16", "fp32": "f32", "bf16x3": "bf16x3 (split-bf16 triples, fp32 accumulate)"}[args.numerics], "data": "synthetic",
             "config": {"workload": f"ShfitScaleFormer_v3 depth {depth}, scales {scales} x {in_c}ch (256x256x4 patches), "
                                    f"{args.pairs} pairs/GPU/step, fwd+loss+bwd+allreduce+Adam (BASELINE configs[1])",
                        "pairs_per_gpu": args.pairs, "global_batch": world * args.pairs, "parallelism": f"dp{world}",

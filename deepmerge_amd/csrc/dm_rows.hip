@@ -289,6 +289,25 @@ __global__ void cast_bf16_kernel(const float *__restrict__ src, bf16_t *__restri
   }
   if (blockIdx.x == 0 && threadIdx.x < (n & 7)) dst[(n8 << 3) + threadIdx.x] = (bf16_t)src[(n8 << 3) + threadIdx.x];
 }
+// hi / lo bf16 pieces of fp32 values for the split-bf16 ("bf16x3") products: see dm_split_bf16 in the header.
+__global__ void split_bf16_kernel(const float *__restrict__ src, long long ld, long long rows, long long cols, bf16_t *__restrict__ dst,
+                                  int stack, int pattern) {
+  const long long c4 = cols >> 2, total = rows * c4;
+  const long long piece = stack ? rows * cols : cols, ldd = stack ? cols : 3 * cols;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const long long r = i / c4, c = (i - r * c4) << 2;
+    const f32x4 x = dm_load4(src + r * ld + c);
+    bf16x4 hi, lo;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      hi[j] = (bf16_t)x[j];
+      lo[j] = (bf16_t)(x[j] - (float)hi[j]);
+    }
+    bf16_t *d = dst + r * ldd + c;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) *reinterpret_cast<bf16x4 *>(d + j * piece) = ((pattern >> j) & 1) ? lo : hi;
+  }
+}
 __global__ void copy_f32_kernel(const float *__restrict__ src, float *__restrict__ dst, long long n) {
   const long long n4 = n >> 2;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x)
@@ -610,6 +629,18 @@ extern "C" int dm_cast(const float *src, void *dst, int32_t dst_dtype, int64_t n
   else if (dst_dtype == DM_F32) hipLaunchKernelGGL(copy_f32_kernel, dim3(grid_for(n / 4 + 1)), dim3(256), 0, s, src, (float *)dst, (long long)n);
   else DM_REQUIRE(false, DM_ERR_BAD_DTYPE, "dm_cast: bad dtype %d", dst_dtype);
   DM_LAUNCH_CHECK("dm_cast");
+  return DM_OK;
+}
+
+extern "C" int dm_split_bf16(const float *src, int64_t ld, int64_t rows, int64_t cols, void *dst, int32_t stack, int32_t pattern,
+                             void *stream) {
+  DM_REQUIRE(src && dst && rows > 0 && cols > 0 && cols % 4 == 0 && ld >= cols && ld % 4 == 0, DM_ERR_BAD_SHAPE,
+             "dm_split_bf16: rows=%lld cols=%lld ld=%lld (cols and ld must be multiples of 4)", (long long)rows, (long long)cols, (long long)ld);
+  DM_REQUIRE(pattern >= 0 && pattern < 8, DM_ERR_BAD_SHAPE, "dm_split_bf16: pattern %d", pattern);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(split_bf16_kernel, dim3(grid_for(rows * (cols / 4))), dim3(256), 0, s, src, (long long)ld, (long long)rows,
+                     (long long)cols, (bf16_t *)dst, stack ? 1 : 0, pattern);
+  DM_LAUNCH_CHECK("dm_split_bf16");
   return DM_OK;
 }
 

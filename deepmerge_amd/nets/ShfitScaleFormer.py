@@ -26,10 +26,7 @@ __all__ = ["PatchEmbed", "Mlp", "FeatureEmbed", "CrossScaleAttention", "CrossSca
 
 
 def _mode(numerics: Optional[str]) -> str:
-    m = numerics or ops.get_numerics()
-    if m not in ("bf16", "fp32"):
-        raise ValueError(f"numerics must be 'bf16' or 'fp32', got {m!r}")
-    return m
+    return ops.check_numerics(numerics or ops.get_numerics())
 
 
 def relative_position_index(cube: Sequence[int]) -> torch.Tensor:

@@ -26,16 +26,59 @@ from ._lib import DM_BF16, DM_EPI_DGELU, DM_EPI_GELU, DM_EPI_GELU_GRAD, DM_EPI_M
 _NUMERICS = "bf16"
 
 
+NUMERICS_MODES = ("bf16", "fp32", "bf16x3")
+_FP32_PRODUCTS = "mfma_f32"     # how gemm() multiplies fp32 operands: "mfma_f32" (exact fmaf chains) or "bf16x3" (split-bf16)
+_SPLIT_MIN_WORK = 1 << 24       # products below this many multiply-adds stay on the fp32 MFMA kernel
+
+
 def set_numerics(mode: str) -> None:
-    """Default numerics mode for modules constructed afterwards ("bf16" or "fp32")."""
+    """Default numerics mode for modules constructed afterwards ("bf16", "fp32" or "bf16x3")."""
     global _NUMERICS
-    if mode not in ("bf16", "fp32"):
-        raise ValueError(f"numerics must be 'bf16' or 'fp32', got {mode!r}")
+    check_numerics(mode)
     _NUMERICS = mode
 
 
 def get_numerics() -> str:
     return _NUMERICS
+
+
+def check_numerics(mode: str) -> str:
+    """Validate a module's numerics mode.  "bf16x3" = the fp32 mode (fp32 activations, gradients, attention, row kernels) with
+    its large products on the bf16 matrix pipe as split-bf16 triples (dm_split_bf16: ~2^-17 relative per product instead of
+    bf16's 2^-9).  How fp32 operands are multiplied is a process-wide switch (both the forward and the backward pass of every
+    fp32 module read it at call time): building a "bf16x3" module turns it on, `fp32_products(...)` scopes it."""
+    if mode not in NUMERICS_MODES:
+        raise ValueError(f"numerics must be one of {NUMERICS_MODES}, got {mode!r}")
+    if mode == "bf16x3":
+        set_fp32_products("bf16x3")
+    return mode
+
+
+def set_fp32_products(kind: str) -> None:
+    global _FP32_PRODUCTS
+    if kind not in ("mfma_f32", "bf16x3"):
+        raise ValueError(f"fp32 products are 'mfma_f32' or 'bf16x3', got {kind!r}")
+    _FP32_PRODUCTS = kind
+
+
+def get_fp32_products() -> str:
+    return _FP32_PRODUCTS
+
+
+class fp32_products:
+    """with ops.fp32_products("bf16x3"): ...   (forward AND backward of the fp32-mode modules inside the block)"""
+
+    def __init__(self, kind: str):
+        self.kind = kind
+
+    def __enter__(self):
+        self.prev = _FP32_PRODUCTS
+        set_fp32_products(self.kind)
+        return self
+
+    def __exit__(self, *exc):
+        set_fp32_products(self.prev)
+        return False
 
 
 def act_dtype(mode: str) -> torch.dtype:
@@ -100,13 +143,32 @@ def gemm(layout: int, A: torch.Tensor, B: torch.Tensor, C_out: torch.Tensor, M: 
     _need_cuda(A, B, C_out, bias, residual, aux, colsum_out)
     if A.dtype != B.dtype:
         raise ValueError(f"A/B dtype mismatch: {A.dtype} vs {B.dtype}")
+    if lda is None:
+        lda = A.stride(-2) if A.dim() >= 2 else K
+    if ldb is None:
+        ldb = B.stride(-2) if B.dim() >= 2 else K
+    if (_FP32_PRODUCTS == "bf16x3" and A.dtype == torch.float32 and M * N * K >= _SPLIT_MIN_WORK
+            and M % 8 == 0 and N % 8 == 0 and K % 8 == 0 and lda % 4 == 0 and ldb % 4 == 0):     # 16-byte rows of the bf16 images
+        # split-bf16: one bf16 product over a 3x longer contraction, [Ah | Ah | Al] . [Bh | Bl | Bh] (include/deepmerge_hip.h)
+        a_rows, a_cols = (M, K) if layout != DM_TN else (K, M)          # the operands as row-major matrices
+        b_rows, b_cols = (N, K) if layout == DM_NT else (K, N)
+        a_stack, b_stack = int(layout == DM_TN), int(layout != DM_NT)
+        A3 = workspace(6 * a_rows * a_cols, A.device, ws_slot + ".split_a").view(torch.bfloat16)    # per slot: the side stream
+        B3 = workspace(6 * b_rows * b_cols, A.device, ws_slot + ".split_b").view(torch.bfloat16)    # has its own images
+        check(_lib.lib().dm_split_bf16(A.data_ptr(), lda, a_rows, a_cols, A3.data_ptr(), a_stack, 0b100, _stream()), "dm_split_bf16")
+        check(_lib.lib().dm_split_bf16(B.data_ptr(), ldb, b_rows, b_cols, B3.data_ptr(), b_stack, 0b010, _stream()), "dm_split_bf16")
+        if colsum_out is not None:           # column sums of the fp32 operand itself (the stacked image would count hi twice)
+            colsum(torch.as_strided(A, (a_rows, a_cols), (lda, 1)), colsum_out, accumulate=colsum_accumulate, ws_slot=ws_slot + ".partial")
+        return gemm(layout, A3, B3, C_out, M, N, 3 * K, lda=(a_cols if a_stack else 3 * a_cols), ldb=(b_cols if b_stack else 3 * b_cols),
+                    ldc=ldc, bias=bias, residual=residual, ldr=ldr, epilogue=epilogue, aux=aux, ldaux=ldaux, accumulate=accumulate,
+                    split_k=split_k, rows_per_group=rows_per_group, group_stride=group_stride, ws_slot=ws_slot)
     a = DmGemmArgs()
     a.layout, a.ab_dtype, a.c_dtype = layout, _dt(A), _dt(C_out)
     a.aux_dtype = _dt(aux) if aux is not None else DM_F32
     a.M, a.N, a.K = M, N, K
     a.epilogue, a.accumulate, a.split_k = epilogue, int(accumulate), split_k
-    a.A, a.lda = A.data_ptr(), (lda if lda is not None else A.stride(-2) if A.dim() >= 2 else K)
-    a.B, a.ldb = B.data_ptr(), (ldb if ldb is not None else B.stride(-2) if B.dim() >= 2 else K)
+    a.A, a.lda = A.data_ptr(), lda
+    a.B, a.ldb = B.data_ptr(), ldb
     a.C, a.ldc = C_out.data_ptr(), (ldc if ldc is not None else N)
     a.bias = _ptr(bias)
     if bias is not None and (bias.dtype != torch.float32 or bias.numel() < N):
@@ -143,10 +205,10 @@ def cast(src: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
     return dst
 
 
-def colsum(X: torch.Tensor, out: torch.Tensor, accumulate: bool = False) -> torch.Tensor:
+def colsum(X: torch.Tensor, out: torch.Tensor, accumulate: bool = False, ws_slot: str = "partial") -> torch.Tensor:
     _need_cuda(X, out)
     M, N = X.shape
-    part = workspace(_lib.lib().dm_colsum_partial_floats(N) * 4, X.device, "partial")
+    part = workspace(_lib.lib().dm_colsum_partial_floats(N) * 4, X.device, ws_slot)
     check(_lib.lib().dm_colsum(X.data_ptr(), _dt(X), X.stride(0), out.data_ptr(), M, N, int(accumulate), part.data_ptr(), _stream()), "dm_colsum")
     return out
 

@@ -173,6 +173,16 @@ int64_t dm_colsum_partial_floats(int32_t N);
 /* fp32 -> T element-wise copy (weights / activations), n elements. */
 int dm_cast(const float *src, void *dst, int32_t dst_dtype, int64_t n, void *stream);
 
+/* Split-bf16 operand image for the "bf16x3" numerics mode: x = hi + lo with hi = bf16(x), lo = bf16(x - hi), so that an fp32
+ * product A.B is recovered to ~2^-17 relative by ONE bf16 GEMM over a 3x longer contraction, [Ah | Ah | Al] . [Bh | Bl | Bh]
+ * (the lo.lo term is dropped).  This replaces the reference's plain fp32 `nn.Linear` arithmetic (nets/ShfitScaleFormer.py:58-66,
+ * :115-132) where bf16 alone misses the 1e-3 tolerance.  src fp32 [rows, cols] with leading dimension ld; dst bf16:
+ *   stack = 0: [rows, 3*cols], piece j at column offset j*cols (the contraction runs along a row: NT's A and B, NN's A);
+ *   stack = 1: [3*rows, cols], piece j at row offset j*rows    (the contraction runs down the rows: NN's B, TN's A and B).
+ * pattern bit j set = piece j is the lo part: 0b100 for the left operand (hi, hi, lo), 0b010 for the right (hi, lo, hi).
+ * cols % 4 == 0. */
+int dm_split_bf16(const float *src, int64_t ld, int64_t rows, int64_t cols, void *dst, int32_t stack, int32_t pattern, void *stream);
+
 /* Patch extraction for the k=stride Conv2d of PatchEmbed (nets/ShfitScaleFormer.py:25, :35):
  * x [B, C, side, side] fp32 -> cols [B*(side/p)^2, C*p*p] T, column order (c, dy, dx) = the
  * conv weight's [out, C, p, p] flattening, row order (b, py, px) = flatten(2).transpose(1,2). */

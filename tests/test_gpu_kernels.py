@@ -716,3 +716,83 @@ def test_attention_generic_shapes(mode, B, N, H, D, with_bias):
     if with_bias:
         with pytest.raises(ValueError):
             ops.attention_bwd(qkv.to(DEV), bias.to(DEV), out, dout.to(DEV), lse, B, N, H, D, scale, torch.zeros(N, N, dtype=torch.int32, device=DEV), 10)
+
+
+# ---- split-bf16 ("bf16x3") products ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("stack,pattern", [(0, 0b100), (0, 0b010), (1, 0b100), (1, 0b010)])
+def test_split_bf16_images(stack, pattern):
+    """dm_split_bf16: hi = bf16(x), lo = bf16(x - hi), three pieces side by side (stack 0) or one under the other (stack 1)."""
+    from deepmerge_amd import _lib
+    torch.manual_seed(3)
+    rows, cols, ld = 37, 24, 32
+    src = (torch.randn(rows, ld, device=DEV) * torch.logspace(-3, 3, ld, device=DEV)).contiguous()
+    dst = torch.full((3 * rows * cols,), float("nan"), dtype=torch.bfloat16, device=DEV)
+    rc = _lib.lib().dm_split_bf16(src.data_ptr(), ld, rows, cols, dst.data_ptr(), stack, pattern, torch.cuda.current_stream().cuda_stream)
+    assert rc == 0
+    torch.cuda.synchronize()
+    x = src[:, :cols]
+    hi = x.bfloat16()
+    lo = (x - hi.float()).bfloat16()
+    pieces = [lo if (pattern >> j) & 1 else hi for j in range(3)]
+    want = torch.cat(pieces, dim=0 if stack else 1)
+    got = dst.view(3 * rows, cols) if stack else dst.view(rows, 3 * cols)
+    assert torch.equal(got, want)
+    # the pair carries x to ~2^-17 relative
+    assert ((hi.float() + lo.float() - x).abs() <= x.abs() * 2.0 ** -16).all()
+    assert _lib.lib().dm_split_bf16(src.data_ptr(), ld, rows, 22, dst.data_ptr(), stack, pattern, None) != 0     # cols % 4
+
+
+@pytest.mark.parametrize("layout", ["NT", "NN", "TN"])
+def test_split_bf16_gemm_against_float64(layout):
+    """ops.gemm under fp32_products("bf16x3"): every layout, with bias / GELU / residual epilogues and the fused column sums,
+    against float64 -- error ~1e-5 of the result's scale where one bf16 pass gives ~3e-3."""
+    from deepmerge_amd import ops
+    from deepmerge_amd._lib import DM_EPI_GELU, DM_EPI_NONE, DM_NN, DM_NT, DM_TN
+    torch.manual_seed(11)
+    M, N, K = 512, 384, 1024
+    if layout == "NT":
+        A, B, lay = torch.randn(M, K, device=DEV), torch.randn(N, K, device=DEV), DM_NT
+        ref = A.double() @ B.double().t()
+    elif layout == "NN":
+        A, B, lay = torch.randn(M, K, device=DEV), torch.randn(K, N, device=DEV), DM_NN
+        ref = A.double() @ B.double()
+    else:
+        A, B, lay = torch.randn(K, M, device=DEV), torch.randn(K, N, device=DEV), DM_TN
+        ref = A.double().t() @ B.double()
+    bias = torch.randn(N, device=DEV)
+    res = torch.randn(M, N, device=DEV)
+    scale = ref.abs().max().item()
+
+    def run(kind, **kw):
+        out = torch.empty(M, N, device=DEV)
+        with ops.fp32_products(kind):
+            ops.gemm(lay, A, B, out, M, N, K, **kw)
+        return out
+
+    exact = run("mfma_f32")
+    split = run("bf16x3")
+    one_pass = torch.empty(M, N, device=DEV)
+    ops.gemm(lay, A.bfloat16(), B.bfloat16(), one_pass, M, N, K)
+    e_exact = (exact.double() - ref).abs().max().item() / scale
+    e_split = (split.double() - ref).abs().max().item() / scale
+    e_bf16 = (one_pass.double() - ref).abs().max().item() / scale
+    print(f"{layout}: max error / scale  fp32 MFMA {e_exact:.1e}   split-bf16 {e_split:.1e}   one bf16 pass {e_bf16:.1e}")
+    assert e_split < 2e-5 and e_bf16 > 20 * e_split
+    if layout != "TN":
+        y = run("bf16x3", bias=bias, residual=res)
+        assert ((y.double() - (ref + bias.double() + res.double())).abs().max().item() / scale) < 2e-5
+        g = run("bf16x3", bias=bias, epilogue=DM_EPI_GELU)
+        want = torch.nn.functional.gelu(ref + bias.double())
+        assert ((g.double() - want).abs().max().item() / scale) < 2e-5
+    else:
+        cs = torch.zeros(M, device=DEV)
+        with ops.fp32_products("bf16x3"):
+            out = torch.empty(M, N, device=DEV)
+            ops.gemm(lay, A, B, out, M, N, K, colsum_out=cs)
+        assert torch.allclose(cs.double(), A.double().sum(0), rtol=0, atol=1e-4 * K ** 0.5)
+        assert ((out.double() - ref).abs().max().item() / scale) < 2e-5
+        acc = split.clone()
+        with ops.fp32_products("bf16x3"):
+            ops.gemm(lay, A, B, acc, M, N, K, accumulate=True)
+        assert ((acc.double() - 2 * ref).abs().max().item() / scale) < 4e-5
+    assert ops.get_fp32_products() == "mfma_f32"

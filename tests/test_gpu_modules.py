@@ -169,6 +169,39 @@ def test_whole_model_parity_fp32(tag):
     recipe.check_summary(tag + "/out_a", ev.cpu().numpy(), fx, GATE)
 
 
+@pytest.mark.parametrize("tag", ["v3_4s4c_321", "v3_4s4c_642"])
+def test_whole_model_parity_bf16x3(tag):
+    """Third numerics mode: the fp32 path with its large products on the bf16 matrix pipe as split-bf16 triples
+    (dm_split_bf16 + one bf16 GEMM over a 3x longer contraction).  Must meet north_star's 1e-3 like the fp32 mode does."""
+    from deepmerge_amd import ops
+    from deepmerge_amd.Losses import Loss
+    fx = load_fx("model_v3.npz")
+    try:
+        cfg, net = build_model(tag, "bf16x3")
+        assert ops.get_fp32_products() == "bf16x3" and net.numerics == "bf16x3"
+        left, ld, right, rd, flag = model_inputs(tag, cfg.scales, cfg.in_c, 4)
+        left = [t.to(DEV) for t in left]; right = [t.to(DEV) for t in right]
+        net.train()
+        fa, fb = net(left, ld.to(DEV), right, rd.to(DEV))
+        loss = Loss(1.0, 0.1, 0)(fa, fb, flag.to(DEV))
+        loss.backward()
+    finally:
+        ops.set_fp32_products("mfma_f32")
+    recipe.check_summary(tag + "/out_a", fa.detach().cpu().numpy(), fx, GATE)
+    recipe.check_summary(tag + "/out_b", fb.detach().cpu().numpy(), fx, GATE)
+    assert abs(loss.item() - float(fx[tag + "/loss"])) <= GATE * abs(float(fx[tag + "/loss"]))
+    e_out = recipe.summary_error(tag + "/out_a", fa.detach().cpu().numpy(), fx)
+    errs = {}
+    for n, p in net.named_parameters():
+        if p.grad is not None:
+            recipe.check_summary(tag + "/grad/" + n, p.grad.cpu().numpy(), fx, GATE, k=1024, atol=1e-6)
+            if float(fx[tag + "/grad/" + n + "/l2"]) > 1e-4:
+                errs[n] = recipe.summary_error(tag + "/grad/" + n, p.grad.cpu().numpy(), fx, k=1024)[0]
+    worst = max(errs, key=errs.get)
+    print(f"{tag} bf16x3: embeddings rel-L2 {e_out[0]:.2e}; median grad rel-L2 {np.median(list(errs.values())):.2e}; "
+          f"worst {worst} {errs[worst]:.2e}")
+
+
 def test_whole_model_bf16_drift_is_bounded():
     from deepmerge_amd.Losses import Loss
     tag = "v3_4s4c_321"

@@ -180,7 +180,8 @@ def test_scale_embed_transformer_label_token_parity_fp32():
     for n, p in net.named_parameters():
         if p.grad is not None:
             recipe.check_summary(tag + "/grad/" + n, p.grad.cpu().numpy(), fx, GATE, k=512, atol=1e-7)
-            worst = max(worst, recipe.summary_error(tag + "/grad/" + n, p.grad.cpu().numpy(), fx, k=512)[0])
+            if float(fx[tag + "/grad/" + n + "/l2"]) > 1e-4:
+                worst = max(worst, recipe.summary_error(tag + "/grad/" + n, p.grad.cpu().numpy(), fx, k=512)[0])
     print(f"{tag}: worst gradient rel-L2 error {worst:.2e}")
     with torch.no_grad():
         two = net([t.to(DEV) for t in xa], fa.to(DEV))
