@@ -219,6 +219,185 @@ __global__ __launch_bounds__(512) void attn_fwd_pipe_kernel(const AttnPipeParams
   write_back(b1 - 1);
 }
 
+// ---- forward, two independent workgroups per CU ------------------------------------------------------------------------------
+// The kernel above keeps one 8-wave workgroup per CU (two K / V buffers fill the LDS) and its two waves per SIMD meet at the one
+// barrier per sample, so they run their MFMA phases together and their softmax phases together (profiles/r02_attn_mfma_util.md: the
+// matrix pipe is busy 10 % of the time, the waves are parked or issue-stalled 75 %).  Here a workgroup is 4 waves x 16 query rows
+// with ONE K and ONE V image (64 KiB + write-back staging): two workgroups share a CU, one wave of each per SIMD, and nothing ties
+// their phases together -- one's softmax runs under the other's QK^T / P.V.  The images are refilled in place as soon as their last
+// reader is done: K(b+1) right after the QK^T of sample b (lands under softmax + P.V), V(b) at the top of sample b (lands under QK^T +
+// softmax).  Three 4-wave barriers per sample:
+//   T: K(b) has landed for every wave; every wave has finished P.V(b-1)  -> issue V(b) DMA, write back O(b-1)
+//   M: every wave has finished QK^T(b)                                   -> issue K(b+1) DMA, Q(b+1) loads
+//   P: V(b) has landed for every wave (counted wait: only the M group, all loads, is younger)
+constexpr int ROWS2 = 64;
+template <int NKT, bool RAGGED>
+__global__ __launch_bounds__(256, 2) void attn_fwd_pipe2_kernel(const AttnPipeParams p, int bchunk) {
+  constexpr int NP = NKT * 16;
+  const int N = RAGGED ? p.N : NP;
+  constexpr int IMG = NP * 128;
+  constexpr int NDMA = (2 * NKT + 3) / 4;          // K (or V) DMA instructions per wave: 2 NKT instructions of 8 keys over 4 waves
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // [K image | V image | write-back staging]
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int g = lane >> 4, li = lane & 15;
+  const int h = blockIdx.x, rb = blockIdx.y, chunk = blockIdx.z;
+  const int H = p.H;
+  const int b0 = chunk * bchunk, b1 = min(p.B, b0 + bchunk);
+  if (b0 >= b1) return;
+  const int q_wave = rb * ROWS2 + wave * 16;
+  const int q = q_wave + li;
+  const bool wave_live = q_wave < N;
+  const bool row_ok = q < N;
+  const long long tok_stride = 3LL * H * HD;
+  const bf16_t *qkv = reinterpret_cast<const bf16_t *>(p.qkv);
+
+  f32x4 bias[NKT];
+#pragma unroll
+  for (int kt = 0; kt < NKT; ++kt) bias[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
+  if (p.bias && wave_live && row_ok) {
+    const float *brow = p.bias + ((long long)h * N + q) * N + 4 * g;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+      if constexpr (!RAGGED) {
+        bias[kt] = dm_load4(brow + 16 * kt) * LOG2E;
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (16 * kt + 4 * g + r < N) bias[kt][r] = brow[16 * kt + r] * LOG2E;
+      }
+    }
+  }
+  const float scale2 = p.scale * LOG2E;
+
+  char *kimg = smem, *vimg = smem + IMG;
+  const int dkey = lane >> 3;
+  const unsigned srcK = (unsigned)(((lane & 7) ^ dkey) * 16);
+  const unsigned srcV = (unsigned)(((lane & 7) ^ (((dkey >> 1) & 3) << 1)) * 16);
+  // which: 1 = K, 2 = V (the slot of the packed qkv row)
+  auto stage = [&](int b, int which) {
+    const bf16_t *base = qkv + (long long)b * N * tok_stride + (long long)h * HD;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t *>(base), 0, (int)(N * tok_stride * 2), 0x00020000);
+    char *img = which == 1 ? kimg : vimg;
+    const unsigned colo = (unsigned)(which * H * HD * 2) + (which == 1 ? srcK : srcV);
+#pragma unroll
+    for (int j = 0; j < NDMA; ++j) {
+      // every wave issues exactly NDMA instructions (the counted wait at P relies on it): a wave whose last instruction falls
+      // past the image repeats the image's last one (same bytes to the same place)
+      const int inst = min(wave + 4 * j, NP / 8 - 1);
+      DM_LDS_DMA(rs, img + inst * 1024, (unsigned)((8 * inst + dkey) * tok_stride * 2) + colo, 0);
+    }
+  };
+  auto load_q = [&](int b, u32x4 (&fq)[2]) {
+    // unconditional loads (clamped row): the counted wait at P needs the same number of vector-memory instructions in every wave
+    const int qr = min(q, N - 1);
+    const bf16_t *qrow = qkv + ((long long)b * N + qr) * tok_stride + (long long)h * HD;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) fq[ks] = *reinterpret_cast<const u32x4 *>(qrow + (4 * ks + g) * 8);
+  };
+
+  const int kswz0 = ((g) ^ (li & 7)) << 4, kswz1 = ((4 + g) ^ (li & 7)) << 4;
+  const int vq = li >> 2, vp = li & 3;
+  const int vrow = 4 * g + vq;
+  const int vf = ((vrow >> 1) & 3);
+
+  u32x4 fq[2], fq_next[2];
+  f32x4 o_prev[4];
+  float lse_prev = 0.f;
+  char *wb_stage = smem + 2 * IMG + wave * (16 * WB_PITCH);
+  auto write_back = [&](int b) {
+    if (!wave_live) return;
+    bf16_t *orow0 = reinterpret_cast<bf16_t *>(p.out) + ((long long)b * N + q_wave) * H * HD + (long long)h * HD;
+    wb_rows16(wb_stage, o_prev, orow0, (long long)H * HD, lane, N - q_wave);
+    if (g == 0 && row_ok) p.lse[((long long)b * H + h) * N + q] = lse_prev;
+  };
+  stage(b0, 1);
+  load_q(b0, fq);
+  fq_next[0] = fq[0];
+  fq_next[1] = fq[1];
+  for (int b = b0; b < b1; ++b) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // K(b), Q(b): issued at M of the previous sample
+    __builtin_amdgcn_s_barrier();                                  // T
+    stage(b, 2);
+    if (b > b0) write_back(b - 1);
+
+    f32x4 s[NKT];
+    if (wave_live) {
+#pragma unroll
+      for (int kt = 0; kt < NKT; ++kt) {
+        const char *krow = kimg + (16 * kt + li) * 128;
+        f32x4 a = {0.f, 0.f, 0.f, 0.f};
+        mma<bf16_t>(a, fq[0], *reinterpret_cast<const u32x4 *>(krow + kswz0));
+        mma<bf16_t>(a, fq[1], *reinterpret_cast<const u32x4 *>(krow + kswz1));
+        s[kt] = a * scale2 + bias[kt];
+        if constexpr (RAGGED) {
+          if (16 * kt + 16 > N) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (16 * kt + 4 * g + r >= N) s[kt][r] = -INFINITY;
+          }
+        }
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");             // this wave's K fragment reads have returned
+    __builtin_amdgcn_s_barrier();                                  // M
+    if (b + 1 < b1) {
+      stage(b + 1, 1);
+      load_q(b + 1, fq_next);
+    }
+    float inv = 0.f;
+    if (wave_live) {
+      float m = -INFINITY;
+#pragma unroll
+      for (int kt = 0; kt < NKT; ++kt) m = fmaxf(fmaxf(m, fmaxf(s[kt][0], s[kt][1])), fmaxf(s[kt][2], s[kt][3]));
+      m = row_max4(m);
+      float l = 0.f;
+#pragma unroll
+      for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float e = __builtin_amdgcn_exp2f(s[kt][r] - m);
+          s[kt][r] = e;
+          l += e;
+        }
+      l = row_sum4(l);
+      inv = 1.f / l;
+      lse_prev = (m + __builtin_amdgcn_logf(l)) * LN2;
+    }
+    // V(b) (issued at T) has landed: at most the M group -- NDMA K instructions + 2 Q loads, all loads, all younger -- may still
+    // be in flight (loads return in order among themselves; an outstanding store only makes the wait stricter)
+    if (b + 1 < b1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA + 2) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                                  // P
+    if (wave_live) {
+      f32x4 o[4];
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int mb = 0; mb < NKT / 2; ++mb) {
+        const f32x4 pa = s[2 * mb], pb = s[2 * mb + 1];
+        const bf16x8 pk = {(bf16_t)pa[0], (bf16_t)pa[1], (bf16_t)pa[2], (bf16_t)pa[3], (bf16_t)pb[0], (bf16_t)pb[1], (bf16_t)pb[2], (bf16_t)pb[3]};
+        const u32x4 pf = __builtin_bit_cast(u32x4, pk);
+        const char *vblk = vimg + (32 * mb + vrow) * 128 + 8 * vp;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          const int slot = (dt ^ vf) << 5;
+          const u32x2 lo = dm_ds_read_tr16(vblk + slot);
+          const u32x2 hi = dm_ds_read_tr16(vblk + 16 * 128 + slot);
+          mma<bf16_t>(o[dt], pf, (u32x4){lo[0], lo[1], hi[0], hi[1]});
+        }
+      }
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) o_prev[dt] = o[dt] * inv;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");             // this wave's V fragment reads have returned (V is refilled after T)
+    fq[0] = fq_next[0];
+    fq[1] = fq_next[1];
+  }
+  write_back(b1 - 1);
+}
+
 // (Round 2, tried and removed: a variant of the kernel above that software-pipelines ACROSS samples inside a wave -- raw scores of
 // sample b + 1 on the matrix pipe while the VALU exponentiates sample b, scale / bias / max of b + 1 under P(b).V(b), K one
 // sample ahead of V in the same four LDS images.  Correct (all attention tests), but 59 us against 47 us at N = 256 with a bias:
@@ -613,6 +792,26 @@ template <int NKT, bool RAGGED> void launch_bwd(const AttnPipeBwdParams &p, hipS
     hipLaunchKernelGGL((attn_bwd_dkv_pipe_kernel<NKT, RAGGED, false>), dim3(p.H, nblk, chunks), dim3(512), LDS_DKV, s, p, bchunk);
 }
 
+inline void pipe2_grid(int B, int N, int H, int &nblk, int &chunks, int &bchunk) {
+  nblk = (N + ROWS2 - 1) / ROWS2;
+  chunks = 512 / (H * nblk);                     // two workgroups per CU
+  if (chunks < 1) chunks = 1;
+  if (chunks > B) chunks = B;
+  bchunk = (B + chunks - 1) / chunks;
+  chunks = (B + bchunk - 1) / bchunk;
+}
+
+template <int NKT, bool RAGGED> void launch2(const AttnPipeParams &p, hipStream_t s) {
+  constexpr int NP = NKT * 16;
+  constexpr int LDS = 2 * NP * 128 + 4 * 16 * WB_PITCH;
+  static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void *>(attn_fwd_pipe2_kernel<NKT, RAGGED>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, LDS) == hipSuccess;
+  (void)ok;
+  int nblk, chunks, bchunk;
+  pipe2_grid(p.B, p.N, p.H, nblk, chunks, bchunk);
+  hipLaunchKernelGGL((attn_fwd_pipe2_kernel<NKT, RAGGED>), dim3(p.H, nblk, chunks), dim3(256), LDS, s, p, bchunk);
+}
+
 template <int NKT, bool RAGGED> void launch(const AttnPipeParams &p, hipStream_t s) {
   constexpr int NP = NKT * 16;
   constexpr int LDS = 4 * NP * 128 + WB_BYTES;
@@ -643,9 +842,24 @@ static int pipe_tiles(int N, bool &ragged) {
   return ragged ? (nkt + 1) / 2 * 2 : nkt;
 }
 
+static int pipe_fwd_variant() {
+  static const int v = [] { const char *e = getenv("DM_ATTN_FWD2"); return e ? atoi(e) : 0; }();
+  return v;
+}
+
 bool dm_attn_fwd_pipe(const AttnPipeParams &p, hipStream_t s) {
   if (!pipe_shape_ok(p.B, p.N, p.H)) return false;
   bool ragged;
+  if (pipe_fwd_variant() == 1) {
+    switch (pipe_tiles(p.N, ragged)) {
+      case 8: dmpipe::launch2<8, false>(p, s); return true;
+      case 10: dmpipe::launch2<10, true>(p, s); return true;
+      case 12: if (ragged) dmpipe::launch2<12, true>(p, s); else dmpipe::launch2<12, false>(p, s); return true;
+      case 14: dmpipe::launch2<14, true>(p, s); return true;
+      case 16: if (ragged) dmpipe::launch2<16, true>(p, s); else dmpipe::launch2<16, false>(p, s); return true;
+      default: return false;
+    }
+  }
   switch (pipe_tiles(p.N, ragged)) {
     case 8: dmpipe::launch<8, false>(p, s); return true;
     case 10: dmpipe::launch<10, true>(p, s); return true;
