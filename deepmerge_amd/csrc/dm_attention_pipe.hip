@@ -44,6 +44,8 @@ __device__ __forceinline__ void wb_rows16(char *stage, const f32x4 (&v)[4], bf16
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // (the block is reused by the next call)
 }
 
+__device__ __forceinline__ u32x4 pack2(const f32x4 &a, const f32x4 &b);
+
 #define DM_LDS_DMA(rsrc, dst, voff, soff) \
   __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void *)(dst), 16, (int)(voff), (int)(soff), 0, 0)
 
@@ -56,9 +58,37 @@ __device__ __forceinline__ float row_sum4(float v) {
   return v + __shfl_xor(v, 32, 64);
 }
 
+// Workgroup -> (head, row block, sample chunk) from a 1-D grid.  The row blocks of one (head, chunk) stage the SAME K / V (Q / dO)
+// rows; the hardware deals consecutive workgroup ids round-robin over the 8 XCDs, each with its own L2, so with the plain
+// (head, block, chunk) order those workgroups landed on different XCDs and every image was fetched from the Infinity Cache / HBM once
+// per row block (timing ablation, tools/mb_attn_abl.sh: without the K / V DMA the forward kernel takes 112 instead of 157 us --
+// the largest single component).  Here ids L and L + 8 .. L + 8 (nblk - 1) -- same XCD, dispatched together -- are the row blocks
+// of one group, so the second reader of a row hits that XCD's L2.
+__device__ __forceinline__ bool pipe_coords(int nblk, int H, int chunks, int &h, int &rb, int &chunk) {
+  if (chunks < 0) {                              // DM_ATTN_XCD=0: the plain order, for A/B runs
+    const int L = blockIdx.x;
+    h = L % H;
+    rb = (L / H) % nblk;
+    chunk = L / (H * nblk);
+    return chunk < -chunks;
+  }
+  const int L = blockIdx.x, xcd = L & 7, j = L >> 3;
+  rb = j % nblk;
+  const int group = xcd + 8 * (j / nblk);
+  if (group >= H * chunks) return false;
+  h = group % H;
+  chunk = group / H;
+  return true;
+}
+inline bool pipe_xcd_map() {
+  static const bool on = [] { const char *e = getenv("DM_ATTN_XCD"); return !(e && atoi(e) == 0); }();
+  return on;
+}
+inline int pipe_grid_size(int nblk, int H, int chunks) { return pipe_xcd_map() ? (H * chunks + 7) / 8 * 8 * nblk : H * chunks * nblk; }
+
 // RAGGED: N is not NKT * 16 (ViT's 197 / 198, v5's 193): tokens >= N are zero-filled by the DMA descriptor and masked.
-template <int NKT, bool RAGGED>
-__global__ __launch_bounds__(512) void attn_fwd_pipe_kernel(const AttnPipeParams p, int bchunk) {
+template <int NKT, bool RAGGED, bool PF>
+__global__ __launch_bounds__(512) void attn_fwd_pipe_kernel(const AttnPipeParams p, int bchunk, int nblk, int chunks) {
   constexpr int NP = NKT * 16;                    // padded token count (LDS images, tile loops)
   const int N = RAGGED ? p.N : NP;
   constexpr int IMG = NP * 128;                   // one K or V image
@@ -66,7 +96,8 @@ __global__ __launch_bounds__(512) void attn_fwd_pipe_kernel(const AttnPipeParams
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int g = lane >> 4, li = lane & 15;
-  const int h = blockIdx.x, rb = blockIdx.y, chunk = blockIdx.z;
+  int h, rb, chunk;
+  if (!pipe_coords(nblk, p.H, chunks, h, rb, chunk)) return;
   const int H = p.H;
   const int b0 = chunk * bchunk, b1 = min(p.B, b0 + bchunk);
   if (b0 >= b1) return;
@@ -157,6 +188,101 @@ __global__ __launch_bounds__(512) void attn_fwd_pipe_kernel(const AttnPipeParams
     if (b > b0) write_back(b - 1);
     const char *kimg = smem + buf * (2 * IMG), *vimg = kimg + IMG;
 
+    if constexpr (PF) {
+      if (wave_live) {
+        // Hand-pipelined form (timing ablation of the plain form, tools/mb_attn_abl.sh: fragment reads 11 us, softmax 9.5 us, DMA 5 us
+        // on top of a 20 us floor, and the parts ADD -- hipcc issues every batch of fragment reads right in front of its MFMAs).
+        // Here the fragments of batch i + 1 are requested before the MFMAs of batch i, the scale / bias of batch i - 1 and the
+        // exponentials of block mb + 1 sit in the same scheduling group as the MFMAs of batch i / block mb.
+        constexpr int NB = NKT / 2;                                  // batches of two 16-key tiles (NKT is even for every instance)
+        f32x4 s[NKT];
+        u32x4 kf[2][4];
+        auto read_k = [&](int i, u32x4 (&f)[4]) {
+          const char *r0 = kimg + (32 * i + li) * 128;
+          f[0] = *reinterpret_cast<const u32x4 *>(r0 + kswz0);
+          f[1] = *reinterpret_cast<const u32x4 *>(r0 + kswz1);
+          f[2] = *reinterpret_cast<const u32x4 *>(r0 + 2048 + kswz0);
+          f[3] = *reinterpret_cast<const u32x4 *>(r0 + 2048 + kswz1);
+        };
+        auto finish = [&](int kt, const f32x4 &a) {
+          s[kt] = a * scale2 + bias[kt];
+          if constexpr (RAGGED) {
+            if (16 * kt + 16 > N) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r)
+                if (16 * kt + 4 * g + r >= N) s[kt][r] = -INFINITY;
+            }
+          }
+        };
+        f32x4 acc[2][2];
+        read_k(0, kf[0]);
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+          if (i + 1 < NB) read_k(i + 1, kf[(i + 1) & 1]);
+          __builtin_amdgcn_sched_barrier(0);
+          f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+          mma<bf16_t>(a0, fq[0], kf[i & 1][0]);
+          mma<bf16_t>(a1, fq[0], kf[i & 1][2]);
+          mma<bf16_t>(a0, fq[1], kf[i & 1][1]);
+          mma<bf16_t>(a1, fq[1], kf[i & 1][3]);
+          acc[i & 1][0] = a0;
+          acc[i & 1][1] = a1;
+          if (i > 0) {
+            finish(2 * i - 2, acc[(i - 1) & 1][0]);
+            finish(2 * i - 1, acc[(i - 1) & 1][1]);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        finish(NKT - 2, acc[(NB - 1) & 1][0]);
+        finish(NKT - 1, acc[(NB - 1) & 1][1]);
+        float m = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt) m = fmaxf(fmaxf(m, fmaxf(s[kt][0], s[kt][1])), fmaxf(s[kt][2], s[kt][3]));
+        m = row_max4(m);
+        float l0 = 0.f, l1 = 0.f;
+        auto exp_block = [&](int mb) {                               // tiles 2 mb, 2 mb + 1 -> unnormalised probabilities
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float e0 = __builtin_amdgcn_exp2f(s[2 * mb][r] - m), e1 = __builtin_amdgcn_exp2f(s[2 * mb + 1][r] - m);
+            s[2 * mb][r] = e0;
+            s[2 * mb + 1][r] = e1;
+            l0 += e0;
+            l1 += e1;
+          }
+        };
+        u32x2 vfr[2][8];
+        auto read_v = [&](int mb, u32x2 (&f)[8]) {
+          const char *vblk = vimg + (32 * mb + vrow) * 128 + 8 * vp;
+#pragma unroll
+          for (int dt = 0; dt < 4; ++dt) {
+            const int slot = (dt ^ vf) << 5;
+            f[2 * dt] = dm_ds_read_tr16(vblk + slot);
+            f[2 * dt + 1] = dm_ds_read_tr16(vblk + 16 * 128 + slot);
+          }
+        };
+        f32x4 o[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        read_v(0, vfr[0]);
+        exp_block(0);
+#pragma unroll
+        for (int mb = 0; mb < NB; ++mb) {
+          if (mb + 1 < NB) read_v(mb + 1, vfr[(mb + 1) & 1]);
+          const u32x4 pf = pack2(s[2 * mb], s[2 * mb + 1]);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int dt = 0; dt < 4; ++dt)
+            mma<bf16_t>(o[dt], pf, (u32x4){vfr[mb & 1][2 * dt][0], vfr[mb & 1][2 * dt][1], vfr[mb & 1][2 * dt + 1][0], vfr[mb & 1][2 * dt + 1][1]});
+          if (mb + 1 < NB) exp_block(mb + 1);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        const float l = row_sum4(l0 + l1);
+        const float inv = 1.f / l;
+        lse_prev = (m + __builtin_amdgcn_logf(l)) * LN2;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) o_prev[dt] = o[dt] * inv;
+      }
+    } else
     if (wave_live) {
       // ---- S = scale * Q K^T + bias ---------------------------------------------------------------------------------
       f32x4 s[NKT];
@@ -219,7 +345,12 @@ __global__ __launch_bounds__(512) void attn_fwd_pipe_kernel(const AttnPipeParams
   write_back(b1 - 1);
 }
 
-// ---- forward, two independent workgroups per CU ------------------------------------------------------------------------------
+// ---- forward, two independent workgroups per CU (experiment + timing-ablation vehicle; built only with EXTRA=-DDM_ATTN_ABLATIONS) ----
+// Measured (profiles/r02_attn_ablations.txt): correct, and no faster than the 8-wave kernel (42.0 vs 40.9 us at B = 64, tie at
+// B = 240) -- decoupling the two waves of a SIMD was not the limiter.  Its compile-time ablations are what showed where the time
+// goes: a 20 us floor (MFMAs, bias / scale, write-back, prologue) + 11 us of K / V fragment reads (= the LDS's 128 B/clk for the
+// 3.6 MB a CU reads per launch: every wave reads all of K and V) + 9.5 us of softmax arithmetic + 5 us of DMA, and the parts add.
+#ifdef DM_ATTN_ABLATIONS
 // The kernel above keeps one 8-wave workgroup per CU (two K / V buffers fill the LDS) and its two waves per SIMD meet at the one
 // barrier per sample, so they run their MFMA phases together and their softmax phases together (profiles/r02_attn_mfma_util.md: the
 // matrix pipe is busy 10 % of the time, the waves are parked or issue-stalled 75 %).  Here a workgroup is 4 waves x 16 query rows
@@ -231,8 +362,8 @@ __global__ __launch_bounds__(512) void attn_fwd_pipe_kernel(const AttnPipeParams
 //   M: every wave has finished QK^T(b)                                   -> issue K(b+1) DMA, Q(b+1) loads
 //   P: V(b) has landed for every wave (counted wait: only the M group, all loads, is younger)
 constexpr int ROWS2 = 64;
-template <int NKT, bool RAGGED>
-__global__ __launch_bounds__(256, 2) void attn_fwd_pipe2_kernel(const AttnPipeParams p, int bchunk) {
+template <int NKT, bool RAGGED, int ABL = 0>
+__global__ __launch_bounds__(256, 2) void attn_fwd_pipe2_kernel(const AttnPipeParams p, int bchunk, int nblk, int chunks) {
   constexpr int NP = NKT * 16;
   const int N = RAGGED ? p.N : NP;
   constexpr int IMG = NP * 128;
@@ -241,7 +372,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_pipe2_kernel(const AttnPipePa
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int g = lane >> 4, li = lane & 15;
-  const int h = blockIdx.x, rb = blockIdx.y, chunk = blockIdx.z;
+  int h, rb, chunk;
+  if (!pipe_coords(nblk, p.H, chunks, h, rb, chunk)) return;
   const int H = p.H;
   const int b0 = chunk * bchunk, b1 = min(p.B, b0 + bchunk);
   if (b0 >= b1) return;
@@ -319,8 +451,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_pipe2_kernel(const AttnPipePa
   for (int b = b0; b < b1; ++b) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // K(b), Q(b): issued at M of the previous sample
     __builtin_amdgcn_s_barrier();                                  // T
-    stage(b, 2);
-    if (b > b0) write_back(b - 1);
+    if (!(ABL & 16) || b == b0) stage((ABL & 64) ? b0 : b, 2);
+    if (b > b0 && !(ABL & 128)) write_back(b - 1);
 
     f32x4 s[NKT];
     if (wave_live) {
@@ -328,8 +460,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_pipe2_kernel(const AttnPipePa
       for (int kt = 0; kt < NKT; ++kt) {
         const char *krow = kimg + (16 * kt + li) * 128;
         f32x4 a = {0.f, 0.f, 0.f, 0.f};
-        mma<bf16_t>(a, fq[0], *reinterpret_cast<const u32x4 *>(krow + kswz0));
-        mma<bf16_t>(a, fq[1], *reinterpret_cast<const u32x4 *>(krow + kswz1));
+        if constexpr (ABL & 2) {
+          mma<bf16_t>(a, fq[0], fq[1]);
+          mma<bf16_t>(a, fq[1], fq[0]);
+        } else {
+          mma<bf16_t>(a, fq[0], *reinterpret_cast<const u32x4 *>(krow + kswz0));
+          mma<bf16_t>(a, fq[1], *reinterpret_cast<const u32x4 *>(krow + kswz1));
+        }
         s[kt] = a * scale2 + bias[kt];
         if constexpr (RAGGED) {
           if (16 * kt + 16 > N) {
@@ -341,13 +478,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_pipe2_kernel(const AttnPipePa
       }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");             // this wave's K fragment reads have returned
-    __builtin_amdgcn_s_barrier();                                  // M
+    if (!(ABL & 32)) __builtin_amdgcn_s_barrier();                 // M
     if (b + 1 < b1) {
-      stage(b + 1, 1);
-      load_q(b + 1, fq_next);
+      if (!(ABL & 16)) stage((ABL & 64) ? b0 : b + 1, 1);
+      load_q((ABL & 64) ? b0 : b + 1, fq_next);
     }
     float inv = 0.f;
-    if (wave_live) {
+    if (wave_live && !(ABL & 8)) {
       float m = -INFINITY;
 #pragma unroll
       for (int kt = 0; kt < NKT; ++kt) m = fmaxf(fmaxf(m, fmaxf(s[kt][0], s[kt][1])), fmaxf(s[kt][2], s[kt][3]));
@@ -357,7 +494,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_pipe2_kernel(const AttnPipePa
       for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float e = __builtin_amdgcn_exp2f(s[kt][r] - m);
+          const float e = (ABL & 1) ? (s[kt][r] - m) : __builtin_amdgcn_exp2f(s[kt][r] - m);
           s[kt][r] = e;
           l += e;
         }
@@ -367,9 +504,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_pipe2_kernel(const AttnPipePa
     }
     // V(b) (issued at T) has landed: at most the M group -- NDMA K instructions + 2 Q loads, all loads, all younger -- may still
     // be in flight (loads return in order among themselves; an outstanding store only makes the wait stricter)
-    if (b + 1 < b1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA + 2) : "memory");
+    if (b + 1 < b1 && !(ABL & 16)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA + 2) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();                                  // P
+    if (!(ABL & 32)) __builtin_amdgcn_s_barrier();                 // P
     if (wave_live) {
       f32x4 o[4];
 #pragma unroll
@@ -382,10 +519,14 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_pipe2_kernel(const AttnPipePa
         const char *vblk = vimg + (32 * mb + vrow) * 128 + 8 * vp;
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
-          const int slot = (dt ^ vf) << 5;
-          const u32x2 lo = dm_ds_read_tr16(vblk + slot);
-          const u32x2 hi = dm_ds_read_tr16(vblk + 16 * 128 + slot);
-          mma<bf16_t>(o[dt], pf, (u32x4){lo[0], lo[1], hi[0], hi[1]});
+          if constexpr (ABL & 4) {
+            mma<bf16_t>(o[dt], pf, pf);
+          } else {
+            const int slot = (dt ^ vf) << 5;
+            const u32x2 lo = dm_ds_read_tr16(vblk + slot);
+            const u32x2 hi = dm_ds_read_tr16(vblk + 16 * 128 + slot);
+            mma<bf16_t>(o[dt], pf, (u32x4){lo[0], lo[1], hi[0], hi[1]});
+          }
         }
       }
 #pragma unroll
@@ -397,6 +538,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_pipe2_kernel(const AttnPipePa
   }
   write_back(b1 - 1);
 }
+#endif  // DM_ATTN_ABLATIONS
 
 // (Round 2, tried and removed: a variant of the kernel above that software-pipelines ACROSS samples inside a wave -- raw scores of
 // sample b + 1 on the matrix pipe while the VALU exponentiates sample b, scale / bias / max of b + 1 under P(b).V(b), K one
@@ -454,7 +596,7 @@ __device__ __forceinline__ float dot8(const u32x4 &x, const u32x4 &y) {
 
 // ---- dQ (rows of the workgroup are queries) ---------------------------------------------------------------------------------
 template <int NKT, bool RAGGED>
-__global__ __launch_bounds__(512) void attn_bwd_dq_pipe_kernel(const AttnPipeBwdParams p, int bchunk) {
+__global__ __launch_bounds__(512) void attn_bwd_dq_pipe_kernel(const AttnPipeBwdParams p, int bchunk, int nblk, int chunks) {
   constexpr int NP = NKT * 16;
   const int N = RAGGED ? p.N : NP;
   constexpr int IMG = NP * 128;
@@ -462,7 +604,8 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_pipe_kernel(const AttnPipeBwd
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int g = lane >> 4, li = lane & 15;
-  const int h = blockIdx.x, rb = blockIdx.y, chunk = blockIdx.z;
+  int h, rb, chunk;
+  if (!pipe_coords(nblk, p.H, chunks, h, rb, chunk)) return;
   const int H = p.H;
   const int b0 = chunk * bchunk, b1 = min(p.B, b0 + bchunk);
   if (b0 >= b1) return;
@@ -597,7 +740,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_pipe_kernel(const AttnPipeBwd
 // ---- dK, dV (rows of the workgroup are keys; columns are queries), plus the chunk's summed dS for the bias gradient ----------
 // BIAS = false (vit_model.py attention: no bias table): no transposed-bias rows and no dS accumulator in registers
 template <int NKT, bool RAGGED, bool BIAS>
-__global__ __launch_bounds__(512) void attn_bwd_dkv_pipe_kernel(const AttnPipeBwdParams p, int bchunk) {
+__global__ __launch_bounds__(512) void attn_bwd_dkv_pipe_kernel(const AttnPipeBwdParams p, int bchunk, int nblk, int chunks) {
   constexpr int NP = NKT * 16;
   const int N = RAGGED ? p.N : NP;
   constexpr int IMG = NP * 128;
@@ -606,7 +749,8 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_pipe_kernel(const AttnPipeBw
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int g = lane >> 4, li = lane & 15;
-  const int h = blockIdx.x, rb = blockIdx.y, chunk = blockIdx.z;
+  int h, rb, chunk;
+  if (!pipe_coords(nblk, p.H, chunks, h, rb, chunk)) return;
   const int H = p.H;
   const int b0 = chunk * bchunk, b1 = min(p.B, b0 + bchunk);
   if (b0 >= b1) return;
@@ -785,13 +929,14 @@ template <int NKT, bool RAGGED> void launch_bwd(const AttnPipeBwdParams &p, hipS
   (void)ok;
   int nblk, chunks, bchunk;
   pipe_grid(p.B, p.N, p.H, nblk, chunks, bchunk);
-  hipLaunchKernelGGL((attn_bwd_dq_pipe_kernel<NKT, RAGGED>), dim3(p.H, nblk, chunks), dim3(512), LDS_DQ, s, p, bchunk);
+  hipLaunchKernelGGL((attn_bwd_dq_pipe_kernel<NKT, RAGGED>), dim3(pipe_grid_size(nblk, p.H, chunks)), dim3(512), LDS_DQ, s, p, bchunk, nblk, pipe_xcd_map() ? chunks : -chunks);
   if (p.bias || p.slab)
-    hipLaunchKernelGGL((attn_bwd_dkv_pipe_kernel<NKT, RAGGED, true>), dim3(p.H, nblk, chunks), dim3(512), LDS_DKV, s, p, bchunk);
+    hipLaunchKernelGGL((attn_bwd_dkv_pipe_kernel<NKT, RAGGED, true>), dim3(pipe_grid_size(nblk, p.H, chunks)), dim3(512), LDS_DKV, s, p, bchunk, nblk, pipe_xcd_map() ? chunks : -chunks);
   else
-    hipLaunchKernelGGL((attn_bwd_dkv_pipe_kernel<NKT, RAGGED, false>), dim3(p.H, nblk, chunks), dim3(512), LDS_DKV, s, p, bchunk);
+    hipLaunchKernelGGL((attn_bwd_dkv_pipe_kernel<NKT, RAGGED, false>), dim3(pipe_grid_size(nblk, p.H, chunks)), dim3(512), LDS_DKV, s, p, bchunk, nblk, pipe_xcd_map() ? chunks : -chunks);
 }
 
+#ifdef DM_ATTN_ABLATIONS
 inline void pipe2_grid(int B, int N, int H, int &nblk, int &chunks, int &bchunk) {
   nblk = (N + ROWS2 - 1) / ROWS2;
   chunks = 512 / (H * nblk);                     // two workgroups per CU
@@ -801,27 +946,34 @@ inline void pipe2_grid(int B, int N, int H, int &nblk, int &chunks, int &bchunk)
   chunks = (B + bchunk - 1) / bchunk;
 }
 
-template <int NKT, bool RAGGED> void launch2(const AttnPipeParams &p, hipStream_t s) {
+template <int NKT, bool RAGGED, int ABL = 0> void launch2(const AttnPipeParams &p, hipStream_t s) {
   constexpr int NP = NKT * 16;
   constexpr int LDS = 2 * NP * 128 + 4 * 16 * WB_PITCH;
-  static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void *>(attn_fwd_pipe2_kernel<NKT, RAGGED>),
+  static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void *>(attn_fwd_pipe2_kernel<NKT, RAGGED, ABL>),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS) == hipSuccess;
   (void)ok;
   int nblk, chunks, bchunk;
   pipe2_grid(p.B, p.N, p.H, nblk, chunks, bchunk);
-  hipLaunchKernelGGL((attn_fwd_pipe2_kernel<NKT, RAGGED>), dim3(p.H, nblk, chunks), dim3(256), LDS, s, p, bchunk);
+  hipLaunchKernelGGL((attn_fwd_pipe2_kernel<NKT, RAGGED, ABL>), dim3(pipe_grid_size(nblk, p.H, chunks)), dim3(256), LDS, s, p, bchunk, nblk, pipe_xcd_map() ? chunks : -chunks);
 }
+#endif
 
+template <int NKT, bool RAGGED, bool PF> void launch_pf(const AttnPipeParams &p, hipStream_t s);
 template <int NKT, bool RAGGED> void launch(const AttnPipeParams &p, hipStream_t s) {
+  static const bool pf = [] { const char *e = getenv("DM_ATTN_PF"); return !(e && atoi(e) == 0); }();
+  if (pf) launch_pf<NKT, RAGGED, true>(p, s);
+  else launch_pf<NKT, RAGGED, false>(p, s);
+}
+template <int NKT, bool RAGGED, bool PF> void launch_pf(const AttnPipeParams &p, hipStream_t s) {
   constexpr int NP = NKT * 16;
   constexpr int LDS = 4 * NP * 128 + WB_BYTES;
-  static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void *>(attn_fwd_pipe_kernel<NKT, RAGGED>),
+  static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void *>(attn_fwd_pipe_kernel<NKT, RAGGED, PF>),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS) == hipSuccess;
   (void)ok;
   // one workgroup per CU (two K/V buffers fill the LDS): as many chunks as fit one round of the 256 CUs
   int nblk, chunks, bchunk;
   pipe_grid(p.B, p.N, p.H, nblk, chunks, bchunk);
-  hipLaunchKernelGGL((attn_fwd_pipe_kernel<NKT, RAGGED>), dim3(p.H, nblk, chunks), dim3(512), LDS, s, p, bchunk);
+  hipLaunchKernelGGL((attn_fwd_pipe_kernel<NKT, RAGGED, PF>), dim3(pipe_grid_size(nblk, p.H, chunks)), dim3(512), LDS, s, p, bchunk, nblk, pipe_xcd_map() ? chunks : -chunks);
 }
 
 }  // namespace dmpipe
@@ -842,24 +994,31 @@ static int pipe_tiles(int N, bool &ragged) {
   return ragged ? (nkt + 1) / 2 * 2 : nkt;
 }
 
-static int pipe_fwd_variant() {
-  static const int v = [] { const char *e = getenv("DM_ATTN_FWD2"); return e ? atoi(e) : 0; }();
-  return v;
-}
-
 bool dm_attn_fwd_pipe(const AttnPipeParams &p, hipStream_t s) {
   if (!pipe_shape_ok(p.B, p.N, p.H)) return false;
   bool ragged;
-  if (pipe_fwd_variant() == 1) {
-    switch (pipe_tiles(p.N, ragged)) {
-      case 8: dmpipe::launch2<8, false>(p, s); return true;
-      case 10: dmpipe::launch2<10, true>(p, s); return true;
-      case 12: if (ragged) dmpipe::launch2<12, true>(p, s); else dmpipe::launch2<12, false>(p, s); return true;
-      case 14: dmpipe::launch2<14, true>(p, s); return true;
-      case 16: if (ragged) dmpipe::launch2<16, true>(p, s); else dmpipe::launch2<16, false>(p, s); return true;
-      default: return false;
+#ifdef DM_ATTN_ABLATIONS      // tools/mb_attn_abl.sh: DM_ATTN_FWD2=1 selects the two-workgroup variant, DM_ATTN_ABL its ablations
+  static const int fwd2 = [] { const char *e = getenv("DM_ATTN_FWD2"); return e ? atoi(e) : 0; }();
+  if (fwd2 == 1 && p.N == 256) {
+    static const int abl = [] { const char *e = getenv("DM_ATTN_ABL"); return e ? atoi(e) : 0; }();
+    switch (abl) {
+      case 1: dmpipe::launch2<16, false, 1>(p, s); return true;
+      case 2: dmpipe::launch2<16, false, 2>(p, s); return true;
+      case 4: dmpipe::launch2<16, false, 4>(p, s); return true;
+      case 6: dmpipe::launch2<16, false, 6>(p, s); return true;
+      case 8: dmpipe::launch2<16, false, 8>(p, s); return true;
+      case 14: dmpipe::launch2<16, false, 14>(p, s); return true;
+      case 16: dmpipe::launch2<16, false, 16>(p, s); return true;
+      case 32: dmpipe::launch2<16, false, 32>(p, s); return true;
+      case 48: dmpipe::launch2<16, false, 48>(p, s); return true;
+      case 62: dmpipe::launch2<16, false, 62>(p, s); return true;
+      case 64: dmpipe::launch2<16, false, 64>(p, s); return true;
+      case 128: dmpipe::launch2<16, false, 128>(p, s); return true;
+      case 192: dmpipe::launch2<16, false, 192>(p, s); return true;
+      default: dmpipe::launch2<16, false, 0>(p, s); return true;
     }
   }
+#endif
   switch (pipe_tiles(p.N, ragged)) {
     case 8: dmpipe::launch<8, false>(p, s); return true;
     case 10: dmpipe::launch<10, true>(p, s); return true;
