@@ -176,6 +176,10 @@ def extras(args, scales, in_c, depth, dev):
         c5 = BC.config5(steps=5, graph=True)
         out["config5_per_gpu_pairs_per_s"], out["config5"] = c5["pairs_per_s"], c5
         torch.cuda.empty_cache()
+        log("extras: config 5 per GPU, the reference's default 3-scale / 3-channel geometry")
+        c53 = BC.config5(steps=5, graph=True, three_scale=True)
+        out["config5_3scale_per_gpu_pairs_per_s"], out["config5_3scale"] = c53["pairs_per_s"], c53
+        torch.cuda.empty_cache()
         log("extras: config 4 (ExtractFeatures tile)")
         c4 = BC.config4(passes=1)
         out["config4_points_per_s"] = c4["encode(gather + v3[6,4,2] eval, batch 2000)"]["points_per_s"]

@@ -143,3 +143,9 @@ def rag_similarity_sweep(features: torch.Tensor, ptr: torch.Tensor, idx: torch.T
     pooled = ops.segment_mean(features.contiguous(), ptr.to(torch.int32).contiguous(), idx.to(torch.int32).contiguous())
     simi, merge = ops.edge_similarity(pooled, edges.to(torch.int32).contiguous(), margin)
     return pooled, simi, merge.bool()
+
+
+def near_margin_count(simi: torch.Tensor, margin: float = 1.0, band: float = 1e-4) -> int:
+    """Edges whose similarity lies within `band` of the margin: the only merge decisions that can differ between two encoders
+    whose features agree to ~1e-4 (reported next to the bit-exact `merge` comparison).  NaN (skipped edges) never counts."""
+    return int(((simi - margin).abs() < band).sum())

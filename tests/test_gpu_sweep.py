@@ -114,6 +114,11 @@ def test_sweep_matches_reference_fixture():
     assert (np.abs(simi[live] - 1.0) > tol).all()
     assert np.array_equal(got_merge[live], simi[live] < 1.0), "merge decisions must equal the reference's bit for bit"
     assert 0.1 < got_merge[live].mean() < 0.9
+    # the count of edges within 1e-4 of the margin is reported next to the bit-exact comparison
+    from deepmerge_amd.ExtractFeatures import near_margin_count
+    n_near = near_margin_count(torch.from_numpy(got_simi).to(DEV), 1.0)
+    assert n_near == int((np.abs(simi[live] - 1.0) < 1e-4).sum())
+    print(f"edges within 1e-4 of the margin: {n_near} of {int(live.sum())}")
 
 
 def test_edge_similarity_matches_reference_distance_cases():

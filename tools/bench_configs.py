@@ -64,9 +64,11 @@ def config3(steps=10):
             "ms_per_step": round(dt * 1e3, 2), "model_TFLOPs": round(B / dt * gf / 1e3, 1)}
 
 
-def config5(steps=8, graph=False):
+def config5(steps=8, graph=False, three_scale=False):
+    """SURVEY 8d config 5 on one GPU: the 4-scale / 4-channel 256x256 variant (headline) or, three_scale=True, the reference's
+    default 3-scale / 3-channel geometry (config.py: scales [32, 64, 128])."""
     from deepmerge_amd.nets.ShfitScaleFormer import ShfitScaleFormer_v3
-    scales, in_c, depth, B = [32, 64, 128, 256], 4, [6, 4, 2], 120
+    scales, in_c, depth, B = ([32, 64, 128], 3, [6, 4, 2], 120) if three_scale else ([32, 64, 128, 256], 4, [6, 4, 2], 120)
     net = ShfitScaleFormer_v3(cube_size=[8, 8], input_image_scales=list(scales), depth=list(depth), in_c=in_c, numerics="bf16").to(DEV)
     tr = PairTrainer(net, margin=1.0, lr=1e-4)
     if graph:
@@ -74,7 +76,7 @@ def config5(steps=8, graph=False):
     batch = synth_batch(B, scales, in_c, DEV, 7)
     dt = timed(lambda: tr.step(*batch), steps, warm=3 if graph else 2)
     gf = pair_step_flops(scales, in_c, depth) / 1e9
-    return {"config": "5 (1 GPU): v3 [6,4,2], 4 scales x 4 ch, 120 pairs/step, bf16, fwd+loss+bwd+Adam" + (", hipGraph replay" if graph else ""),
+    return {"config": f"5 (1 GPU): v3 [6,4,2], {len(scales)} scales x {in_c} ch, 120 pairs/step, bf16, fwd+loss+bwd+Adam" + (", hipGraph replay" if graph else ""),
             "pairs_per_s": round(B / dt, 1), "ms_per_step": round(dt * 1e3, 2), "gflop_per_pair": round(gf, 1), "model_TFLOPs": round(B / dt * gf / 1e3, 1)}
 
 
@@ -133,7 +135,9 @@ def config4(passes=2):
     E = edges.shape[0]
     out["edge_similarity"] = {"us": round(t_e * 1e6, 1), "edges_per_s": round(E / t_e), "GBps_algorithmic": round(E * 812 / t_e / 1e9, 1)}
     _, simi, merge = rag_similarity_sweep(F, ptr, idx, edges, 1.0)
+    from deepmerge_amd.ExtractFeatures import near_margin_count
     out["summary"] = {"points": P, "superpixels": S, "edges": E, "merge_fraction": round(float(merge.float().mean()), 3),
+                      "edges_within_1e-4_of_margin": near_margin_count(simi, 1.0),
                       "sweep_total_us(pool+edges)": round((t_p + t_e) * 1e6, 1)}
     return {"config": "4: ExtractFeatures pipeline, 4096x4096x4 tile", **out}
 
