@@ -67,6 +67,7 @@ def main():
     ap.add_argument("--pairs", type=int, default=120)
     ap.add_argument("--depth", type=str, default="6,4,2")
     ap.add_argument("--lr", type=float, default=1e-4)
+    ap.add_argument("--numerics", type=str, default="bf16", choices=["bf16", "fp32", "bf16x3"])
     ap.add_argument("--milestones", type=str, default="40,80")
     args = ap.parse_args()
     scales, bands = [32, 64, 128, 256], 4
@@ -75,7 +76,7 @@ def main():
     g = torch.Generator(device=DEV); g.manual_seed(0)
     torch.manual_seed(0)
     tiles = smooth_tiles(6, bands, 1024, g)
-    net = ShfitScaleFormer_v3(cube_size=[8, 8], input_image_scales=list(scales), depth=depth, in_c=bands, numerics="bf16").to(DEV)
+    net = ShfitScaleFormer_v3(cube_size=[8, 8], input_image_scales=list(scales), depth=depth, in_c=bands, numerics=args.numerics).to(DEV)
     tr = PairTrainer(net, margin=1.0, lr=args.lr)
     tr.enable_graph(warmup=1)
     curve = []
@@ -91,7 +92,7 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     n = args.epochs * args.steps_per_epoch
-    print(json.dumps({"tool": "train_synth", "depth": depth, "pairs_per_step": args.pairs, "steps": n, "loss_curve": curve,
+    print(json.dumps({"tool": "train_synth", "numerics": args.numerics, "depth": depth, "pairs_per_step": args.pairs, "steps": n, "loss_curve": curve,
                       "pairs_per_s_incl_data_generation": round(n * args.pairs / dt, 1)}))
 
 
