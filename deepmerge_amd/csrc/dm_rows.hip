@@ -20,7 +20,7 @@ namespace {
 constexpr int MAXCH = 4;          // float4 chunks per lane per row -> cols <= 1024 in the register-resident kernels
 constexpr int LN_WIDE_MAX = 8192; // widest row of the streamed kernels
 static int ln_max_wg() {           // workgroups of the LayerNorm backward (each writes one partial row pair)
-  static const int v = [] { const char *e = getenv("DM_LN_WG"); return e ? atoi(e) : 512; }();
+  static const int v = [] { const char *e = getenv("DM_LN_WG"); return e ? atoi(e) : 768; }();      // 3 workgroups (12 waves) per CU; 512 / 768 / 1024: 51 / 45 / 47 us at 16384 x 768 (tools/mb_ln.py)
   return v;
 }
 constexpr int CS_MAX_SLICES = 64;
@@ -81,18 +81,20 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float *__restr
 // LayerNorm backward: dx = dres + rstd*(g - mean(g) - xhat*mean(g*xhat)), g = dy*gamma.
 // Each workgroup keeps per-column partial sums of dy*xhat (dgamma) and dy (dbeta) in registers
 // over its grid-stride rows, combines its 4 waves through LDS and writes one partial row.
-template <typename TDY>
+// CH = float4 chunks per lane per row: 3 for rows of up to 768 columns (the encoder's width: 112 registers, 4 workgroups per CU),
+// 4 up to 1024.
+template <typename TDY, int CH>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const TDY *__restrict__ dy, const float *__restrict__ x,
                                                             const float *__restrict__ gamma, const float *__restrict__ mean,
                                                             const float *__restrict__ rstd, const float *__restrict__ dres,
                                                             float *__restrict__ dx, bf16_t *__restrict__ dx_lp,
                                                             float *__restrict__ partial, int rows, int cols) {
-  __shared__ float red[4][2][MAXCH * 256];
+  __shared__ float red[4][2][CH * 256];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nch = cols >> 2;
-  f32x4 dg[MAXCH], db[MAXCH], gam[MAXCH];
+  f32x4 dg[CH], db[CH], gam[CH];
 #pragma unroll
-  for (int i = 0; i < MAXCH; ++i) {
+  for (int i = 0; i < CH; ++i) {
     dg[i] = db[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int c = lane + 64 * i;
     gam[i] = (c < nch) ? dm_load4(gamma + 4 * c) : (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -100,10 +102,17 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const TDY *__restric
   for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
     const long long off = (long long)row * cols;
     const float mu = mean[row], rs = rstd[row];
-    f32x4 xh[MAXCH], g[MAXCH];
+    f32x4 xh[CH], g[CH], dr[CH];
     float s1 = 0.f, s2 = 0.f;
+    // every load of the row is issued before anything waits (the residual gradient used to be requested after the two wave
+    // reductions: a second full memory latency per row with only 8 waves per CU to hide it -- 3.4 TB/s at 16384 x 768)
 #pragma unroll
-    for (int i = 0; i < MAXCH; ++i) {
+    for (int i = 0; i < CH; ++i) {
+      const int c = lane + 64 * i;
+      dr[i] = (dres && c < nch) ? dm_load4(dres + off + 4 * c) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
       const int c = lane + 64 * i;
       if (c < nch) {
         const f32x4 xv = dm_load4(x + off + 4 * c);
@@ -123,20 +132,20 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const TDY *__restric
     }
     const float c1 = dm_wave_sum(s1) / (float)cols, c2 = dm_wave_sum(s2) / (float)cols;
 #pragma unroll
-    for (int i = 0; i < MAXCH; ++i) {
+    for (int i = 0; i < CH; ++i) {
       const int c = lane + 64 * i;
       if (c < nch) {
         f32x4 o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] = rs * (g[i][e] - c1 - xh[i][e] * c2);
-        if (dres) o += dm_load4(dres + off + 4 * c);
+        if (dres) o += dr[i];
         dm_store4(dx + off + 4 * c, o);
         if (dx_lp) dm_store4(dx_lp + off + 4 * c, o);
       }
     }
   }
 #pragma unroll
-  for (int i = 0; i < MAXCH; ++i) {
+  for (int i = 0; i < CH; ++i) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       red[wave][0][(lane + 64 * i) * 4 + e] = dg[i][e];
@@ -558,11 +567,16 @@ extern "C" int dm_layernorm_bwd(const void *dy, int32_t dy_dtype, const float *x
     return DM_OK;
   }
   const int grid = grid_for((long long)rows, 4, ln_max_wg());
-  if (dy_dtype == DM_F32)
-    hipLaunchKernelGGL(layernorm_bwd_kernel<float>, dim3(grid), dim3(256), 0, s, (const float *)dy, x, gamma, mean, rstd, dres, dx, (bf16_t *)dx_lp, partial, rows, cols);
-  else if (dy_dtype == DM_BF16)
-    hipLaunchKernelGGL(layernorm_bwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t *)dy, x, gamma, mean, rstd, dres, dx, (bf16_t *)dx_lp, partial, rows, cols);
-  else DM_REQUIRE(false, DM_ERR_BAD_DTYPE, "dm_layernorm_bwd: bad dy_dtype %d", dy_dtype);
+  DM_REQUIRE(dy_dtype == DM_F32 || dy_dtype == DM_BF16, DM_ERR_BAD_DTYPE, "dm_layernorm_bwd: bad dy_dtype %d", dy_dtype);
+  const bool narrow = cols <= 768;
+  if (dy_dtype == DM_F32 && narrow)
+    hipLaunchKernelGGL((layernorm_bwd_kernel<float, 3>), dim3(grid), dim3(256), 0, s, (const float *)dy, x, gamma, mean, rstd, dres, dx, (bf16_t *)dx_lp, partial, rows, cols);
+  else if (dy_dtype == DM_F32)
+    hipLaunchKernelGGL((layernorm_bwd_kernel<float, MAXCH>), dim3(grid), dim3(256), 0, s, (const float *)dy, x, gamma, mean, rstd, dres, dx, (bf16_t *)dx_lp, partial, rows, cols);
+  else if (narrow)
+    hipLaunchKernelGGL((layernorm_bwd_kernel<bf16_t, 3>), dim3(grid), dim3(256), 0, s, (const bf16_t *)dy, x, gamma, mean, rstd, dres, dx, (bf16_t *)dx_lp, partial, rows, cols);
+  else
+    hipLaunchKernelGGL((layernorm_bwd_kernel<bf16_t, MAXCH>), dim3(grid), dim3(256), 0, s, (const bf16_t *)dy, x, gamma, mean, rstd, dres, dx, (bf16_t *)dx_lp, partial, rows, cols);
   DM_LAUNCH_CHECK("dm_layernorm_bwd");
   hipLaunchKernelGGL(partial_reduce_kernel, dim3((2 * cols + 15) / 16), dim3(256), 0, s, partial, dgamma, dbeta, grid, 2 * cols, cols, accumulate_params);
   DM_LAUNCH_CHECK("dm_layernorm_bwd(reduce)");
