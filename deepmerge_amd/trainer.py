@@ -231,6 +231,21 @@ class PairTrainer:
         self._log("exchange complete")
         self._pending.clear()
 
+    def _finish_buckets(self, update):
+        """Per bucket, in launch order: wait for its all-reduce, then `update(bucket index)` (Adam on that range).  The optimizer
+        work of the early buckets (the last layers) thus runs while the later buckets -- the first layers, whose gradients are
+        ready last -- are still being exchanged: only the last bucket's update stays behind the exchange.  (A collective's
+        wait() orders the compute stream behind it; it does not block the host for RCCL.)"""
+        pending = dict(self._pending)
+        for bi in range(len(self.bucket_slices)):
+            work = pending.get(bi)
+            if work is not None:
+                self._log(f"wait bucket {bi}")
+                work.wait()
+            update(bi)
+        self._log("exchange complete")
+        self._pending.clear()
+
     def _segment_buckets(self, cuts: _Cuts):
         """One bucket per distinct cut owner + one for the tail.  A cut taken after module `owner` ends the segment that
         contains `owner`: in the flat buffer (reverse forward order) that segment starts at the lowest offset of owner's
@@ -338,10 +353,7 @@ class PairTrainer:
                 st["loss"] = loss.detach()
             st["pieces"] = [g]
             if self.dp:                              # no cut support: exchange the whole buffer after the one backward graph
-                ga = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(ga, pool=g.pool(), capture_error_mode="thread_local"):
-                    self._adam_slice(slice(0, self.fp.total), st["hyper"], 1.0 / self.world)
-                st["adam"] = ga
+                st["adam"] = self._capture_adam(st, g.pool())
             return
         cuts = _Cuts()
         self.net._dp_cut = cuts
@@ -359,15 +371,23 @@ class PairTrainer:
                 with torch.cuda.graph(gk, pool=g0.pool(), capture_error_mode="thread_local"):
                     x.backward(leaf.grad)
                 pieces.append(gk)
-            ga = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(ga, pool=g0.pool(), capture_error_mode="thread_local"):
-                self._adam_slice(slice(0, self.fp.total), st["hyper"], 1.0 / self.world)
         finally:
             self.net._dp_cut = None
         self.fp.finish_grads()      # (a tracked parameter no captured piece writes is cleared once here and stays clear: nothing replays a write to it)
-        st["pieces"], st["adam"], st["cuts"] = pieces, ga, cuts           # the cut tensors keep the autograd segments alive
+        st["pieces"], st["cuts"] = pieces, cuts                            # the cut tensors keep the autograd segments alive
         self.bucket_slices, self._ready_after = self._segment_buckets(cuts)
+        st["adam"] = self._capture_adam(st, g0.pool())
         # the retired-workspace list of ops.workspace keeps every scratch buffer these graphs point into alive
+
+    def _capture_adam(self, st, pool):
+        """One captured Adam launch per bucket (see _finish_buckets)."""
+        graphs = []
+        for sl in self.bucket_slices:
+            ga = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(ga, pool=pool, capture_error_mode="thread_local"):
+                self._adam_slice(sl, st["hyper"], 1.0 / self.world)
+            graphs.append(ga)
+        return graphs
 
     def _graph_step(self, left, left_designed, right, right_designed, flag, lr):
         st = self._graph
@@ -414,8 +434,7 @@ class PairTrainer:
             for piece, g in enumerate(st["pieces"]):
                 g.replay()
                 self._launch_ready(piece)                # the exchange runs next to the graphs replayed after it
-        self._wait_exchange()
-        st["adam"].replay()
+        self._finish_buckets(lambda bi: st["adam"][bi].replay())
         return st["loss"]
 
     def _adam_slice(self, sl: slice, hyper_dev, grad_scale: float):
@@ -457,10 +476,15 @@ class PairTrainer:
             if self.dp:
                 for bi in range(len(self.bucket_slices)):
                     self._launch_bucket(bi)
-        self._wait_exchange()
-        self.fp.finish_grads()
         self.step_count += 1
-        extra = {"param_lp": self.fp.flat_lp} if self.fp.flat_lp is not None else {}
-        self.adam_fn(self.fp.flat, self.fp.grad, self.m, self.v, self.step_count, lr=self.lr if lr is None else lr,
-                     beta1=self.betas[0], beta2=self.betas[1], eps=self.eps, grad_scale=1.0 / self.world, **extra)
+
+        def update(sl):
+            extra = {"param_lp": self.fp.flat_lp[sl]} if self.fp.flat_lp is not None else {}
+            self.adam_fn(self.fp.flat[sl], self.fp.grad[sl], self.m[sl], self.v[sl], self.step_count, lr=self.lr if lr is None else lr,
+                         beta1=self.betas[0], beta2=self.betas[1], eps=self.eps, grad_scale=1.0 / self.world, **extra)
+        if self.dp:
+            self._finish_buckets(lambda bi: update(self.bucket_slices[bi]))
+        else:
+            self.fp.finish_grads()
+            update(slice(0, self.fp.total))
         return loss.detach()
