@@ -279,10 +279,32 @@ __global__ __launch_bounds__(NTHREADS, (TM == 4 ? WG_PER_CU : 4)) void gemm_kern
     lstore(0);
   }
   __syncthreads();
+  // Epilogue read operands (the fp32 residual; the aux of the multiply / GELU' epilogues) are touched towards L2 a few K stages before
+  // the tile ends: the whole-line epilogue walks its 64 x 64 block 16 rows at a time and would otherwise pay a first-touch round
+  // trip per pass (proj forward reads 50 MB of residual stream, the dgrad of fc2 100 MB of GELU').  One row per lane, one dword
+  // per 128-byte line; the values are not read before the epilogue (the asm at its top is the use that keeps the loads alive).
+  float tv0 = 0.f, tv1 = 0.f;
+  const int touch_at = (TM == 4 && sizeof(T) == 2 && p.split_k <= 1 && !(p.debug & 0x200) && (p.residual || (p.aux && (p.epilogue == DM_EPI_DGELU || p.epilogue == DM_EPI_MUL))))
+                           ? max(0, nk - 4) : -1;
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
     const bool more = (kt + 1 < nk);
     if (more) gload(kbeg + (kt + 1) * BK);
+    if (kt == touch_at) {
+      const int m = m0 + wm * WT + lane, n = n0 + wn * WT;
+      if (m < p.M && n < p.N) {
+        const DmGemmRow rw = dm_gemm_row(p, m);
+        if (p.residual) {
+          tv0 = p.residual[rw.r + n];
+          if (n + 32 < p.N) tv1 = p.residual[rw.r + n + 32];
+        } else if (p.aux_dtype == DM_F32) {
+          tv0 = reinterpret_cast<const float *>(p.aux)[rw.x + n];
+          if (n + 32 < p.N) tv1 = reinterpret_cast<const float *>(p.aux)[rw.x + n + 32];
+        } else {
+          tv0 = __builtin_bit_cast(float, (unsigned)reinterpret_cast<const unsigned short *>(p.aux)[rw.x + n]);
+        }
+      }
+    }
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
       u32x4 fa[TM], fb[TM];
@@ -328,6 +350,7 @@ __global__ __launch_bounds__(NTHREADS, (TM == 4 ? WG_PER_CU : 4)) void gemm_kern
                          (p.rows_per_group == 0 || p.group_stride % 8 == 0) && (p.residual == nullptr || p.ldr % 8 == 0);
     if (rows_ok) {
       static_assert(2 * LDS_STAGES * G::STAGE >= 4 * 16 * DM_EPI_PITCH, "epilogue staging must fit the operand stage");
+      asm volatile("" ::"v"(tv0), "v"(tv1));
       dm_epilogue_rows<4, 16>(p, acc, smem + wave * (16 * DM_EPI_PITCH), m0 + wm * WT, n0 + wn * WT, lane);
       return;
     }
@@ -682,6 +705,8 @@ extern "C" int dm_gemm(const DmGemmArgs *a, void *stream) {
   {
     static const bool rows_off = [] { const char *e = getenv("DM_GEMM_T128_ROWS"); return e && e[0] == '0'; }();   // A/B aid: 4-column epilogue in the 128x128 kernel
     if (rows_off && !ring) p.debug |= 0x100;
+    static const bool touch_off = [] { const char *e = getenv("DM_GEMM_T128_TOUCH"); return e && e[0] == '0'; }();  // A/B aid: no early touch of the epilogue operands
+    if (touch_off) p.debug |= 0x200;
   }
   {
     static const int forced = [] { const char *e = getenv("DM_GEMM_GROUP_M"); return e ? atoi(e) : -1; }();
