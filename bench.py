@@ -27,7 +27,7 @@ KERNEL_SYMBOLS = {
                      "gemm_kernel<__bf16, 0, 4|2> (128x128 / 64x64 tiles)"],
     "gemm_bf16_NN": ["gemm_kernel<__bf16, 1, 4|2>", "dmw4::gemm_w4_kernel<1, 0, 0> (one round of tiles, K >= 1536)", "dm256::gemm256_kernel<1>"],
     "gemm_bf16_TN": ["dmw4::gemm_w4_kernel<2, 0, 0> (+ splitk_reduce_kernel)", "dm256::gemm256_kernel<2> (+ splitk_reduce_kernel)", "gemm_kernel<__bf16, 2, 4|2>"],
-    "attn_fwd_bf16": ["dmpipe::attn_fwd_pipe_kernel<NKT, RAGGED>", "attn_fwd_kernel<__bf16, ...> (N < 128)"],
+    "attn_fwd_bf16": ["dmpipe::attn_fwd_pipe_kernel<NKT, RAGGED, PF>", "attn_fwd_kernel<__bf16, ...> (N < 128)"],
     "attn_bwd_bf16": ["dmpipe::attn_bwd_dq_pipe_kernel", "dmpipe::attn_bwd_dkv_pipe_kernel", "attn_bwd_dq_kernel / attn_bwd_dkv_kernel (N < 128)"],
 }
 

@@ -18,6 +18,7 @@ python tools/pmc_traffic.py $(find $OUT/fetch -name "*.db" | head -1) $(find $OU
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum -d $OUT/mfma -- python3 $PARGS > /dev/null 2> $OUT/mfma.log
 python tools/pmc_dump.py $OUT/mfma gemm > $OUT/gemm_counters.txt
 python tools/pmc_dump.py $OUT/mfma attn >> $OUT/gemm_counters.txt
+cp $OUT/pmc_traffic.json profiles/pmc_traffic.json      # same sources: the bench line below quotes it (copy it back into the repo with the rest)
 python bench.py --steps 50 --warmup 3 > $OUT/bench.json 2> $OUT/bench.err
 rm -rf $OUT/trace $OUT/fetch $OUT/write $OUT/mfma
 ls -la $OUT
