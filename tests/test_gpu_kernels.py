@@ -405,6 +405,14 @@ def test_attention_pipelined_kernels(N, with_bias):
     test_attention_forward_backward("bf16", N, with_bias, B=8, H=12)
 
 
+@pytest.mark.parametrize("B,H,N,with_bias", [(9, 12, 256, True), (36, 3, 197, False), (11, 12, 128, True), (70, 12, 256, True), (13, 10, 192, True)])
+def test_attention_pipelined_workgroup_order(B, H, N, with_bias):
+    """The XCD-aware workgroup order of the pipelined kernels (pipe_coords: ids L, L + 8, ... are the row blocks of one
+    (head, sample chunk)) with group counts that are NOT multiples of 8 (the surplus workgroups of the rounded-up grid must
+    leave), uneven sample chunks, one and two row blocks."""
+    test_attention_forward_backward("bf16", N, with_bias, B=B, H=H)
+
+
 @pytest.mark.parametrize("mode", ["fp32", "bf16"])
 @pytest.mark.parametrize("N,with_bias", [(12, True), (16, True), (48, True), (64, True), (192, True), (256, True), (197, False), (198, False), (100, True), (37, True), (250, True)])
 def test_attention_forward_backward(mode, N, with_bias, B=3, H=4):
