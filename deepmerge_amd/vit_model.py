@@ -147,20 +147,18 @@ class VisionTransformer(nn.Module):
                  mlp_ratio=4.0, qkv_bias=True, qk_scale=None, representation_size=None, distilled=False, drop_ratio=0.,
                  attn_drop_ratio=0., drop_path_ratio=0., embed_layer=PatchEmbed, norm_layer=None, act_layer=None, numerics=None):
         super().__init__()
-        if distilled:
-            raise NotImplementedError("the distillation-token variant is not used by the reference's drivers")
         _check_dim(embed_dim)
         self.numerics = _mode(numerics)
         self.num_classes = num_classes
         self.num_features = self.embed_dim = embed_dim
-        self.num_tokens = 1
+        self.num_tokens = 2 if distilled else 1
         norm_layer = norm_layer or partial(nn.LayerNorm, eps=1e-6)
         act_layer = act_layer or nn.GELU
         kw = {"numerics": self.numerics} if embed_layer is PatchEmbed else {}
         self.patch_embed = embed_layer(img_size=img_size, patch_size=patch_size, in_c=in_c, embed_dim=embed_dim, **kw)
         num_patches = self.patch_embed.num_patches
         self.cls_token = nn.Parameter(torch.zeros(1, 1, embed_dim))
-        self.dist_token = None
+        self.dist_token = nn.Parameter(torch.zeros(1, 1, embed_dim)) if distilled else None      # DeiT token (:225)
         self.pos_embed = nn.Parameter(torch.zeros(1, num_patches + self.num_tokens, embed_dim))
         self.pos_drop = nn.Dropout(p=drop_ratio)
         self.blocks = nn.Sequential(*[
@@ -168,7 +166,7 @@ class VisionTransformer(nn.Module):
                   drop_ratio=drop_ratio, attn_drop_ratio=attn_drop_ratio, drop_path_ratio=0., norm_layer=norm_layer,
                   act_layer=act_layer, numerics=self.numerics) for _ in range(depth)])
         self.norm = norm_layer(embed_dim)
-        if representation_size:
+        if representation_size and not distilled:
             self.has_logits = True
             self.num_features = representation_size
             self.pre_logits = nn.Sequential(OrderedDict([("fc", nn.Linear(embed_dim, representation_size)), ("act", nn.Tanh())]))
@@ -177,32 +175,49 @@ class VisionTransformer(nn.Module):
             self.pre_logits = nn.Identity()
         self.head = nn.Linear(self.num_features, num_classes) if num_classes > 0 else nn.Identity()
         self.head_dist = None
+        if distilled:                                   # :250-253
+            self.head_dist = nn.Linear(self.embed_dim, self.num_classes) if num_classes > 0 else nn.Identity()
         nn.init.trunc_normal_(self.pos_embed, std=0.02)
+        if self.dist_token is not None:
+            nn.init.trunc_normal_(self.dist_token, std=0.02)
         nn.init.trunc_normal_(self.cls_token, std=0.02)
         self.apply(_init_vit_weights)
 
     def _encode(self, x):
-        """tokens -> blocks -> LayerNorm -> x[:, 0]"""
+        """tokens -> blocks -> LayerNorm (every row)"""
         x = self.blocks(self.pos_drop(x))
-        x = ops.LayerNormFn.apply(x, self.norm.weight, self.norm.bias, self.norm.eps, torch.float32)
-        return x[:, 0]
+        return ops.LayerNormFn.apply(x, self.norm.weight, self.norm.bias, self.norm.eps, torch.float32)
 
     def forward_features(self, x):
         x = self.patch_embed(x)
-        x = torch.cat((self.cls_token.expand(x.shape[0], -1, -1), x), dim=1) + self.pos_embed
+        cls = self.cls_token.expand(x.shape[0], -1, -1)
+        if self.dist_token is None:
+            x = torch.cat((cls, x), dim=1) + self.pos_embed
+        else:
+            x = torch.cat((cls, self.dist_token.expand(x.shape[0], -1, -1), x), dim=1) + self.pos_embed
         x = self._encode(x)
+        if self.dist_token is not None:                  # :277-280: (class-token row, distillation-token row)
+            return x[:, 0], x[:, 1]
+        x = x[:, 0]
         if self.has_logits:
             x = torch.tanh(_Head.linear(x, self.pre_logits.fc))
         return x
 
     def forward_once(self, x):
         x = self.forward_features(x)
+        if self.head_dist is not None:                   # :285-291: both heads in training, their average otherwise
+            a = _Head.linear(x[0], self.head) if isinstance(self.head, nn.Linear) else x[0]
+            b = _Head.linear(x[1], self.head_dist) if isinstance(self.head_dist, nn.Linear) else x[1]
+            return (a, b) if self.training else (a + b) / 2
         return _Head.linear(x, self.head) if isinstance(self.head, nn.Linear) else x
 
     def _many(self, xs):
         """Siamese passes share every weight and no op mixes samples -> one batch."""
         sizes = [t.shape[0] for t in xs]
         y = self.forward_once(torch.cat(list(xs), 0))
+        if isinstance(y, tuple):                         # distilled, training: one (x, x_dist) pair per input
+            parts = [torch.split(v, sizes, 0) for v in y]
+            return tuple(tuple(p[i] for p in parts) for i in range(len(sizes)))
         return tuple(torch.split(y, sizes, 0))
 
     def forward_twice(self, x1, x2):
@@ -234,14 +249,12 @@ class ScaleEmbedTransformer(nn.Module):
                  is_feature_embed=True, feature_embed=FeatureEmbed, is_label_embed=False, norm_layer=None, act_layer=None,
                  numerics=None):
         super().__init__()
-        if distilled:
-            raise NotImplementedError("the distillation-token variant is not used by the reference's drivers")
         _check_dim(embed_dim)
         self.numerics = _mode(numerics)
         self.num_classes = num_classes
         self.num_features = self.embed_dim = embed_dim
         self.scales = scales
-        self.num_tokens = 1
+        self.num_tokens = 2 if distilled else 1
         norm_layer = norm_layer or partial(nn.LayerNorm, eps=1e-6)
         act_layer = act_layer or nn.GELU
         self.is_multiscale_embed = is_multiscale_embed
@@ -256,7 +269,7 @@ class ScaleEmbedTransformer(nn.Module):
         self.is_label_embed = is_label_embed
         if is_label_embed:                       # vit_model.py:369-371
             self.label_token = nn.Parameter(torch.zeros(1, 1, embed_dim))
-        self.dist_token = None
+        self.dist_token = nn.Parameter(torch.zeros(1, 1, embed_dim)) if distilled else None
         self.is_feature_embed = is_feature_embed
         self.feature_embed = feature_embed(feature_size=19, embed_dim=768) if is_feature_embed else None
         self.pos_embed0 = nn.Parameter(torch.zeros(1, 49, embed_dim))
@@ -270,7 +283,7 @@ class ScaleEmbedTransformer(nn.Module):
                   drop_ratio=drop_ratio, attn_drop_ratio=attn_drop_ratio, drop_path_ratio=0., norm_layer=norm_layer,
                   act_layer=act_layer, numerics=self.numerics) for _ in range(depth)])
         self.norm = norm_layer(embed_dim)
-        if representation_size:
+        if representation_size and not distilled:
             self.has_logits = True
             self.num_features = representation_size
             self.pre_logits = nn.Sequential(OrderedDict([("fc", nn.Linear(embed_dim, representation_size)), ("act", nn.Tanh())]))
@@ -280,12 +293,16 @@ class ScaleEmbedTransformer(nn.Module):
         self.class_logits = nn.Linear(100, 11) if is_label_embed else nn.Identity()          # :408-412
         self.head = nn.Linear(self.num_features, num_classes) if num_classes > 0 else nn.Identity()
         self.head_dist = None
+        if distilled:                                    # :417-418
+            self.head_dist = nn.Linear(self.embed_dim, self.num_classes) if num_classes > 0 else nn.Identity()
         self.my_head = nn.Linear(768, 100)
         # :422-432 -- parameter containers; the arithmetic is in _class_head below
         self.my_class_head = nn.Sequential(nn.Linear(embed_dim, 100), nn.GELU(), nn.Dropout(0.3), nn.Linear(100, 100)) \
             if is_label_embed else nn.Identity()
         for pe in (self.pos_embed_non_multiscale, self.pos_embed0, self.pos_embed1, self.pos_embed2, self.pos_embed3, self.cls_token):
             nn.init.trunc_normal_(pe, std=0.02)
+        if self.dist_token is not None:
+            nn.init.trunc_normal_(self.dist_token, std=0.02)
         if is_label_embed:
             nn.init.trunc_normal_(self.label_token, std=0.02)
         self.apply(_init_vit_weights)
@@ -306,6 +323,14 @@ class ScaleEmbedTransformer(nn.Module):
         else:
             x = self.patch_embed(x) + self.pos_embed_non_multiscale
         cls_token = self.cls_token.expand(x.shape[0], -1, -1)
+        if self.dist_token is not None:
+            # :485-486, :509-510: cls, the designed-feature tensor AS GIVEN (upstream does not embed it on this branch, so it must
+            # already be [B, 1, embed_dim]; the usual [B, 1, 19] fails in torch.cat there and here), distillation token, patches;
+            # the result is rows 0 and 1 of the normalised sequence -- the class row and the DESIGNED-FEATURE row, as upstream
+            x = torch.cat((cls_token, designed_feature, self.dist_token.expand(x.shape[0], -1, -1), x), dim=1)
+            x = self.blocks(self.pos_drop(x))
+            x = ops.LayerNormFn.apply(x, self.norm.weight, self.norm.bias, self.norm.eps, torch.float32)
+            return x[:, 0], x[:, 1]
         if self.is_feature_embed:
             f = self.feature_embed(designed_feature)
             x = torch.cat((cls_token, f, x), dim=1)
@@ -340,7 +365,7 @@ class ScaleEmbedTransformer(nn.Module):
         else:
             xs = torch.cat((x1, x3), 0)
         y = self.forward_features(xs, torch.cat((x2, x4), 0))
-        if self.is_label_embed:
+        if isinstance(y, tuple):                         # label-token / distilled variants return tuples per side
             return tuple(v[:B] for v in y), tuple(v[B:] for v in y)
         return y[:B], y[B:]
 

@@ -47,12 +47,15 @@ def _block_spec(spec, pre, C, Hd):
     spec[pre + "mlp.fc2.weight"] = ((C, Hd), "float32"); spec[pre + "mlp.fc2.bias"] = ((C,), "float32")
 
 
-def vit_param_spec(cfg: VitConfig) -> "OrderedDict[str, Tuple[Tuple[int, ...], str]]":
-    """state_dict manifest of VisionTransformer (vit_model.py:214-262), registration order."""
+def vit_param_spec(cfg: VitConfig, distilled: bool = False) -> "OrderedDict[str, Tuple[Tuple[int, ...], str]]":
+    """state_dict manifest of VisionTransformer (vit_model.py:214-262), registration order; distilled: DeiT token + head_dist
+    (:225, :250-253; no pre_logits then, :239)."""
     C = cfg.dim
     spec: "OrderedDict[str, Tuple[Tuple[int, ...], str]]" = OrderedDict()
     spec["cls_token"] = ((1, 1, C), "float32")
-    spec["pos_embed"] = ((1, cfg.n_patches + 1, C), "float32")
+    if distilled:
+        spec["dist_token"] = ((1, 1, C), "float32")
+    spec["pos_embed"] = ((1, cfg.n_patches + (2 if distilled else 1), C), "float32")
     spec["patch_embed.proj.weight"] = ((C, cfg.in_c, cfg.patch, cfg.patch), "float32")
     spec["patch_embed.proj.bias"] = ((C,), "float32")
     for j in range(cfg.depth):
@@ -65,6 +68,8 @@ def vit_param_spec(cfg: VitConfig) -> "OrderedDict[str, Tuple[Tuple[int, ...], s
         feat = cfg.representation_size
     if cfg.num_classes > 0:
         spec["head.weight"] = ((cfg.num_classes, feat), "float32"); spec["head.bias"] = ((cfg.num_classes,), "float32")
+        if distilled:
+            spec["head_dist.weight"] = ((cfg.num_classes, C), "float32"); spec["head_dist.bias"] = ((cfg.num_classes,), "float32")
     return spec
 
 
@@ -102,6 +107,20 @@ def vit_forward_once(p: Params, x: torch.Tensor, cfg: VitConfig) -> torch.Tensor
     if cfg.num_classes > 0:
         t = F.linear(t, p["head.weight"], p["head.bias"])
     return t
+
+
+def vit_forward_once_distilled(p: Params, x: torch.Tensor, cfg: VitConfig, training: bool = True):
+    """VisionTransformer.forward_once with distilled=True (:264-291): (head(x[:,0]), head_dist(x[:,1])) in training mode, their
+    average otherwise."""
+    C = cfg.dim
+    t = _patch_tokens(p, "patch_embed.", x, cfg.patch)
+    t = torch.cat((p["cls_token"].expand(t.shape[0], -1, -1), p["dist_token"].expand(t.shape[0], -1, -1), t), dim=1) + p["pos_embed"]
+    for j in range(cfg.depth):
+        t = block(p, f"blocks.{j}.", t, cfg.heads)
+    t = F.layer_norm(t, (C,), p["norm.weight"], p["norm.bias"], EPS)
+    a = F.linear(t[:, 0], p["head.weight"], p["head.bias"])
+    b = F.linear(t[:, 1], p["head_dist.weight"], p["head_dist.bias"])
+    return (a, b) if training else (a + b) / 2
 
 
 def vit_forward_pair(p: Params, x1: torch.Tensor, x2: torch.Tensor, cfg: VitConfig):

@@ -474,6 +474,32 @@ def gen_vit(vit_model, Losses):
         two = net(xa, fa)
         fx[tag + "/two_args_equals_left"] = np.bool_(all(torch.equal(u, v) for u, v in zip(two, ra)))
         print(tag, "loss", fx[tag + "/loss"], "none", none, "params", int(fx[tag + "/n_params"]))
+    # ---- VisionTransformer with distilled=True (vit_model.py:217, :225, :250-253, :270, :277-291): DeiT distillation token and
+    #      head_dist; training mode returns (x, x_dist) per input, eval mode their average ---------------------------------------
+    tag = "vitb16_dist_d2"
+    if not have(tag):
+        net = vit_model.VisionTransformer(img_size=224, patch_size=16, embed_dim=768, depth=2, num_heads=12,
+                                          representation_size=None, num_classes=100, distilled=True)
+        load_det_weights(net, "")
+        sd = net.state_dict()
+        fx[tag + "/manifest_keys"] = np.array(list(sd.keys()))
+        fx[tag + "/manifest_shapes"] = np.array([",".join(map(str, v.shape)) for v in sd.values()])
+        fx[tag + "/n_params"] = np.int64(sum(p.numel() for p in net.parameters()))
+        x1 = t(tag + ".x1", (2, 3, 224, 224), "unit"); x2 = t(tag + ".x2", (2, 3, 224, 224), "unit")
+        x2[1] = x1[1] * 0.8 + 0.2 * x2[1]
+        net.train()
+        (ya, da), (yb, db) = net(x1, x2)
+        loss = crit(ya, yb, flag) + crit(da, db, flag)
+        loss.backward()
+        add(fx, tag + "/out_a", ya); add(fx, tag + "/out_b", yb); add(fx, tag + "/dist_a", da); add(fx, tag + "/dist_b", db)
+        fx[tag + "/loss"] = np.float64(loss.item())
+        for n, p in net.named_parameters():
+            assert p.grad is not None, n
+            add(fx, tag + "/grad/" + n, p.grad, k=512)
+        net.eval()
+        with torch.no_grad():
+            add(fx, tag + "/eval_a", net(x1))
+        print(tag, "loss", fx[tag + "/loss"], "params", int(fx[tag + "/n_params"]))
     if old is not None:
         fx.update({k: old[k] for k in old.files})
     np.savez_compressed(path, **fx)

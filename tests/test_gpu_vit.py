@@ -192,3 +192,52 @@ def test_scale_embed_transformer_label_token_parity_fp32():
     with torch.no_grad():
         r1 = net([t.to(DEV) for t in xa], fa.to(DEV))
     assert not torch.equal(r1[2], two[2]) and torch.equal(r1[0], two[0])
+
+
+def test_vision_transformer_distilled_parity_fp32():
+    """distilled=True (vit_model.py:217, :225, :250-253, :270, :277-291): distillation token, head_dist; training mode returns
+    (x, x_dist) per input, eval mode their average."""
+    from deepmerge_amd.Losses import Loss
+    tag = "vitb16_dist_d2"
+    fx = load_fx("model_vit.npz")
+    net = VM().VisionTransformer(img_size=224, patch_size=16, embed_dim=768, depth=2, num_heads=12, representation_size=None,
+                                 num_classes=100, distilled=True, numerics="fp32")
+    sd = net.state_dict()
+    assert list(sd.keys()) == [str(k) for k in fx[tag + "/manifest_keys"]]
+    assert [",".join(map(str, v.shape)) for v in sd.values()] == [str(s) for s in fx[tag + "/manifest_shapes"]]
+    assert net.num_tokens == 2 and net.has_logits is False
+    net = load_recipe_weights(net).to(DEV).train()
+    x1, x2, flag = vit_inputs(tag)
+    (ya, da), (yb, db) = net(x1.to(DEV), x2.to(DEV))
+    crit = Loss(1.0, 0.1, 0)
+    loss = crit(ya, yb, flag.to(DEV)) + crit(da, db, flag.to(DEV))
+    loss.backward()
+    for key, v in (("out_a", ya), ("out_b", yb), ("dist_a", da), ("dist_b", db)):
+        recipe.check_summary(f"{tag}/{key}", v.detach().cpu().numpy(), fx, GATE)
+    assert abs(loss.item() - float(fx[tag + "/loss"])) <= GATE * abs(float(fx[tag + "/loss"]))
+    for n, p in net.named_parameters():
+        assert p.grad is not None, n
+        recipe.check_summary(tag + "/grad/" + n, p.grad.cpu().numpy(), fx, GATE, k=512, atol=1e-7)
+    net.eval()
+    with torch.no_grad():
+        ev = net(x1.to(DEV))
+    recipe.check_summary(tag + "/eval_a", ev.cpu().numpy(), fx, GATE)
+
+
+def test_scale_embed_transformer_distilled_as_upstream():
+    """ScaleEmbedTransformer(distilled=True): dist_token / head_dist exist (vit_model.py:374, :417-418); its forward concatenates the
+    designed-feature tensor AS GIVEN (:485-486), so it only runs for [B, 1, embed_dim] inputs and returns rows 0 and 1 of the
+    normalised sequence; the usual [B, 1, 19] features fail in torch.cat upstream and here."""
+    net = VM().ScaleEmbedTransformer(img_size=224, patch_size=16, embed_dim=768, depth=1, num_heads=12, representation_size=None,
+                                     num_classes=16, distilled=True, numerics="fp32").to(DEV).train()
+    keys = list(net.state_dict().keys())
+    assert keys[:2] == ["cls_token", "dist_token"] and "head_dist.weight" in keys and net.num_tokens == 2
+    sizes = (28, 56, 112, 224)
+    xa = [torch.rand(2, 3, s, s, device=DEV) for s in sizes]
+    with pytest.raises(RuntimeError):
+        net(xa, torch.rand(2, 1, 19, device=DEV))
+    f = torch.randn(2, 1, 768, device=DEV)
+    r0, r1 = net(xa, f)
+    assert r0.shape == (2, 768) and r1.shape == (2, 768)
+    (a0, a1), (b0, b1) = net(xa, f, xa, f)
+    assert torch.allclose(a0, r0, atol=1e-5) and torch.allclose(b1, r1, atol=1e-5)

@@ -114,3 +114,27 @@ def test_scale_embed_transformer_label_token():
         if p[k].grad is not None:
             recipe.check_summary(tag + "/grad/" + k, p[k].grad.numpy(), fx, 1e-4, k=512, atol=1e-9)
     assert bool(fx[tag + "/two_args_equals_left"])
+
+
+def test_vision_transformer_distilled():
+    """distilled=True (vit_model.py:217, :225, :250-253, :270, :277-291): (x, x_dist) per input in training mode, the average in eval."""
+    tag = "vitb16_dist_d2"
+    fx = load_fx("model_vit.npz")
+    cfg = OV.VitConfig(depth=2, num_classes=100)
+    spec = OV.vit_param_spec(cfg, distilled=True)
+    assert list(spec.keys()) == [str(k) for k in fx[tag + "/manifest_keys"]]
+    assert [",".join(map(str, s)) for s, _ in spec.values()] == [str(s) for s in fx[tag + "/manifest_shapes"]]
+    p = det_params(spec.items())
+    x1, x2, flag = vit_inputs(tag)
+    ya, da = OV.vit_forward_once_distilled(p, x1, cfg)
+    yb, db = OV.vit_forward_once_distilled(p, x2, cfg)
+    loss = OL.contrastive_loss(ya, yb, flag, 1.0) + OL.contrastive_loss(da, db, flag, 1.0)
+    loss.backward()
+    for key, v in (("out_a", ya), ("out_b", yb), ("dist_a", da), ("dist_b", db)):
+        recipe.check_summary(f"{tag}/{key}", v.detach().numpy(), fx, RTOL)
+    assert abs(loss.item() - float(fx[tag + "/loss"])) <= 5e-5 * abs(float(fx[tag + "/loss"]))
+    for k in spec:
+        recipe.check_summary(tag + "/grad/" + k, p[k].grad.numpy(), fx, 1e-4, k=512, atol=1e-9)
+    with torch.no_grad():
+        ev = OV.vit_forward_once_distilled(p, x1, cfg, training=False)
+    recipe.check_summary(tag + "/eval_a", ev.numpy(), fx, RTOL)
