@@ -110,3 +110,24 @@ def test_drop_in_surface_names():
     net = S.ShfitScaleFormer_v3(depth=[1, 1, 1], cube_size=cube, input_image_scales=[32, 64, 128])
     assert cube == [3, 8, 8] and net.name == "S2Former_v3-3CH-3DP-SEF-111" and net.depth == [1, 1, 1]
     assert net.input_image_scales == [32, 64, 128]
+
+
+def test_numerics_mode_switches_need_no_gpu(built_lib):
+    """ops.check_numerics / set_fp32_products / fp32_products: validation and scoping of the numerics switches (pure host logic)."""
+    from deepmerge_amd import ops
+    assert ops.get_fp32_products() == "mfma_f32"
+    with pytest.raises(ValueError):
+        ops.check_numerics("fp16")
+    with pytest.raises(ValueError):
+        ops.set_fp32_products("tf32")
+    with ops.fp32_products("bf16x3"):
+        assert ops.get_fp32_products() == "bf16x3"
+        with ops.fp32_products("mfma_f32"):
+            assert ops.get_fp32_products() == "mfma_f32"
+        assert ops.get_fp32_products() == "bf16x3"
+    assert ops.get_fp32_products() == "mfma_f32"
+    try:
+        assert ops.check_numerics("bf16x3") == "bf16x3" and ops.get_fp32_products() == "bf16x3"      # building a bf16x3 module turns it on
+        assert ops.act_dtype("bf16x3") is __import__("torch").float32 and ops.act_dtype("bf16") is __import__("torch").bfloat16
+    finally:
+        ops.set_fp32_products("mfma_f32")

@@ -387,6 +387,17 @@ def test_graph_replayed_step_equals_eager_step(mode):
         graphed.step([t[:2] for t in batches[0][0]], batches[0][1][:2], [t[:2] for t in batches[0][2]], batches[0][3][:2], batches[0][4][:2])
 
 
+def test_graph_replayed_step_equals_eager_step_bf16x3():
+    """The same bitwise graph == eager contract with the fp32 products computed as split-bf16 triples (the split images live in
+    grow-only workspaces whose addresses the captured graph holds)."""
+    from deepmerge_amd import ops
+    try:
+        test_graph_replayed_step_equals_eager_step("bf16x3")
+        assert ops.get_fp32_products() == "bf16x3"
+    finally:
+        ops.set_fp32_products("mfma_f32")
+
+
 @pytest.mark.parametrize("graph", [False, True])
 def test_first_write_gradient_sinks(graph):
     """FlatParams(first_write=True): the fused blocks' gradients are not zeroed per step, their first write stores.  Three steps must
