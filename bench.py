@@ -205,6 +205,8 @@ def main():
                     "the default one-GPU run appends to the JSON line")
     ap.add_argument("--backend", type=str, default="nccl", choices=["nccl", "gloo"],
                     help="collective backend for --gpus > 1 (gloo only to rehearse the DP path with several ranks on ONE GPU)")
+    ap.add_argument("--compress-grads", type=str, default="none", choices=["none", "bf16"],
+                    help="--gpus > 1: exchange the gradient buckets as bf16 (opt-in, lossy: half the bytes on the links; default fp32)")
     ap.add_argument("--graph", type=str, default="auto", choices=["auto", "on", "off"],
                     help="replay the step's compute from captured hipGraphs (auto = on; with several ranks one graph per backward segment, "
                          "the bucket all-reduces are launched eagerly between them)")
@@ -251,7 +253,7 @@ def main():
     torch.manual_seed(0)
     net = ShfitScaleFormer_v3(cube_size=[8, 8], input_image_scales=list(scales), depth=list(depth), in_c=in_c,
                               numerics=args.numerics).to(dev)
-    trainer = PairTrainer(net, margin=1.0, lr=1e-4)
+    trainer = PairTrainer(net, margin=1.0, lr=1e-4, compress_grads=None if args.compress_grads == "none" else args.compress_grads)
     batch = synth_batch(args.pairs, scales, in_c, dev, 1000 + rank)
 
     def sync():
@@ -328,6 +330,7 @@ def main():
               "compute_only_ms_per_step": round(1e3 * float(tx[0]) / args.steps, 3),
               "exposed_exchange_ms_per_step": round(1e3 * (dt - float(tx[0])) / args.steps, 3),
               "segmented_backward": bool(trainer.segmented), "graph_capture_error": trainer.graph_error,
+              "bucket_dtype": "bf16" if trainer.compress_grads else "f32",
               "rehearsal_single_rank": bool(force_dp and world == 1)}
     rows = (_lib.DmProfRow * 256)()
     n = lib.dm_prof_collect(rows, 256)

@@ -177,8 +177,11 @@ class PairTrainer:
 
     def __init__(self, net: torch.nn.Module, margin: float = 1.0, lr: float = 1e-4, lamda: float = 0.1, belta: float = 0,
                  betas=(0.9, 0.999), eps: float = 1e-8, n_buckets: int = 4, process_group=None, criterion=None, adam_fn=None,
-                 segmented: Optional[bool] = None, first_write: Optional[bool] = None):
-        """`first_write`: see FlatParams.  `criterion` / `adam_fn` default to the HIP loss and fused Adam; tests of the exchange logic may
+                 segmented: Optional[bool] = None, first_write: Optional[bool] = None, compress_grads: Optional[str] = None):
+        """`compress_grads="bf16"` (opt-in, lossy; SURVEY 8e "optionally bf16-compressed buckets in throughput mode"): a bucket is
+        rounded to bf16, summed across ranks in bf16 and widened again before Adam -- half the bytes on the links for ~2^-9 relative
+        rounding per rank's contribution; the default exchanges fp32.
+        `first_write`: see FlatParams.  `criterion` / `adam_fn` default to the HIP loss and fused Adam; tests of the exchange logic may
         inject stand-ins with the same signatures.  `segmented`: run the backward pass in segments (default: world > 1 and
         the model supports cuts); `n_buckets` is the bucket count for models without cut support."""
         self.net = net
@@ -204,6 +207,10 @@ class PairTrainer:
         self._graph_warm = 0
         self.exchange = True        # False: skip the collectives (bench.py uses it to price the exposed exchange time)
         self.trace = os.environ.get("DM_DP_TRACE") == "1"
+        if compress_grads not in (None, "bf16"):
+            raise ValueError(f"compress_grads must be None or 'bf16', got {compress_grads!r}")
+        self.compress_grads = compress_grads
+        self._cbuf = torch.empty_like(self.fp.grad, dtype=torch.bfloat16) if (compress_grads and self.dp) else None
         self.stats = {"allreduce_calls": 0, "allreduce_bytes": 0}
         self.graph_error = None     # set when enable_graph() had to fall back to eager launches
 
@@ -220,14 +227,21 @@ class PairTrainer:
         self.fp.finish_grads(sl.start, sl.stop)
         if self.dp and self.exchange:
             self._log(f"launch bucket {bi} [{sl.start}:{sl.stop}] ({(sl.stop - sl.start) * 4 / 1e6:.1f} MB)")
-            self._pending.append((bi, dist.all_reduce(self.fp.grad[sl], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)))
+            if self._cbuf is not None:
+                self._cbuf[sl].copy_(self.fp.grad[sl])                   # fp32 -> bf16 (round to nearest even)
+                self._pending.append((bi, dist.all_reduce(self._cbuf[sl], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)))
+            else:
+                self._pending.append((bi, dist.all_reduce(self.fp.grad[sl], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)))
             self.stats["allreduce_calls"] += 1
-            self.stats["allreduce_bytes"] += (sl.stop - sl.start) * 4
+            self.stats["allreduce_bytes"] += (sl.stop - sl.start) * (2 if self._cbuf is not None else 4)
 
     def _wait_exchange(self):
         for bi, work in self._pending:
             self._log(f"wait bucket {bi}")
             work.wait()
+            if self._cbuf is not None:
+                sl = self.bucket_slices[bi]
+                self.fp.grad[sl].copy_(self._cbuf[sl])
         self._log("exchange complete")
         self._pending.clear()
 
@@ -242,6 +256,9 @@ class PairTrainer:
             if work is not None:
                 self._log(f"wait bucket {bi}")
                 work.wait()
+                if self._cbuf is not None:
+                    sl = self.bucket_slices[bi]
+                    self.fp.grad[sl].copy_(self._cbuf[sl])               # the bf16 sum, widened for the fp32 Adam
             update(bi)
         self._log("exchange complete")
         self._pending.clear()

@@ -70,7 +70,7 @@ def cpu_criterion(a, b, flag):
     return OL.contrastive_loss(a, b, flag, 50.0)    # large margin so the hinge branch is live
 
 
-def _worker(rank, world, port, out, steps=2):
+def _worker(rank, world, port, out, steps=2, compress=None):
     sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -78,7 +78,7 @@ def _worker(rank, world, port, out, steps=2):
     from deepmerge_amd.trainer import PairTrainer, shard_slice
     cfg = tiny_cfg()
     net = OracleNet(cfg)
-    tr = PairTrainer(net, lr=1e-3, n_buckets=3, criterion=cpu_criterion, adam_fn=cpu_adam)
+    tr = PairTrainer(net, lr=1e-3, n_buckets=3, criterion=cpu_criterion, adam_fn=cpu_adam, compress_grads=compress)
     assert tr.world == world and len(tr.bucket_slices) >= 2
     l, ld, r, rd, flag = make_batch(8, cfg, 99)
     sl = shard_slice(8, rank, world)
@@ -86,9 +86,26 @@ def _worker(rank, world, port, out, steps=2):
     for _ in range(steps):
         losses.append(float(tr.step([t[sl] for t in l], ld[sl], [t[sl] for t in r], rd[sl], flag[sl])))
     if rank == 0:
-        torch.save({"flat": tr.fp.flat.clone(), "grad": tr.fp.grad.clone() / world, "losses": losses}, out)
+        torch.save({"flat": tr.fp.flat.clone(), "grad": tr.fp.grad.clone() / world, "losses": losses, "bytes": tr.stats["allreduce_bytes"]}, out)
     dist.barrier()
     dist.destroy_process_group()
+
+
+def test_two_rank_bf16_compressed_buckets(tmp_path):
+    """compress_grads="bf16" (opt-in): buckets travel as bf16 -- half the bytes; the averaged gradient equals the exact
+    one to bf16 rounding of the ranks' contributions and of their sum."""
+    from deepmerge_amd.trainer import PairTrainer
+    out, out32 = str(tmp_path / "c.pt"), str(tmp_path / "f.pt")
+    mp.spawn(_worker, args=(2, _free_port(), out, 1, "bf16"), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, _free_port(), out32, 1, None), nprocs=2, join=True)
+    got, ref = torch.load(out), torch.load(out32)
+    assert got["bytes"] * 2 == ref["bytes"]
+    g, r = got["grad"], ref["grad"]
+    assert not torch.equal(g, r)
+    assert float((g - r).abs().max()) <= 2.0 ** -7 * float(r.abs().max())
+    assert float((g - r).norm() / r.norm()) < 2.0 ** -8         # (entry-wise relative error is unbounded: the two ranks' terms can cancel)
+    with pytest.raises(ValueError):
+        PairTrainer(OracleNet(tiny_cfg()), compress_grads="fp8", criterion=cpu_criterion, adam_fn=cpu_adam)
 
 
 def test_two_rank_step_equals_single_process_global_batch(tmp_path):
