@@ -9,6 +9,11 @@ Workload at every N (weak scaling): BASELINE.json configs[1] -- ShfitScaleFormer
     python bench.py [--gpus N] [--steps K] [--warmup W] [--pairs B] [--depth 3,2,1] [--no-cpu-baseline]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
 
+`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment launches itself: the parent (which never imports torch or
+touches a GPU) starts N children of this script, one rank per GPU, with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 /
+MASTER_PORT set, passes rank 0's single JSON line through and exits non-zero if any child fails (`launch_ranks`).  The reference has
+one device only (`net.cuda()`, /root/reference/Train_SMT.py:160-161); this is the multi-GPU path the build adds.
+
 Rank 0 prints ONE JSON line (see DESIGN.md "Measurement" for the roofline / cpu_baseline fields).
 """
 import argparse
@@ -190,6 +195,58 @@ def extras(args, scales, in_c, depth, dev):
     return out
 
 
+def free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def rank_env(base, rank, world, port):
+    """Environment of child `rank` of a self-launched run (the variables torch.distributed.run would set)."""
+    env = dict(base)
+    env.update({"RANK": str(rank), "LOCAL_RANK": str(rank), "WORLD_SIZE": str(world), "LOCAL_WORLD_SIZE": str(world),
+                "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "DM_BENCH_CHILD": "1"})
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL needs it on this host driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, usable_cores() // world)))
+    return env
+
+
+def launch_ranks(world, argv, script=None, poll_s=0.2):
+    """Parent of a self-launched multi-GPU run: one child process per rank, started BEFORE anything in this process imports
+    torch or initialises a GPU (no exec from a GPU process: plain children).  Children inherit stdout, and only rank 0 writes
+    there (its one JSON line); the first failing child ends the others and its code becomes ours."""
+    import signal
+    import subprocess
+    port = free_port()
+    cmd = [sys.executable, script or os.path.abspath(__file__)] + list(argv)
+    procs = [subprocess.Popen(cmd, env=rank_env(os.environ, r, world, port)) for r in range(world)]
+    rc = 0
+    try:
+        live = set(range(world))
+        while live and rc == 0:
+            for r in sorted(live):
+                code = procs[r].poll()
+                if code is None:
+                    continue
+                live.discard(r)
+                if code != 0:
+                    log(f"rank {r} exited with code {code}: ending the other ranks")
+                    rc = code if code > 0 else 1
+                    break
+            time.sleep(poll_s)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.send_signal(signal.SIGTERM)
+        for p in procs:
+            try:
+                p.wait(timeout=20)
+            except subprocess.TimeoutExpired:
+                p.kill()
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -211,6 +268,8 @@ def main():
                     help="replay the step's compute from captured hipGraphs (auto = on; with several ranks one graph per backward segment, "
                          "the bucket all-reduces are launched eagerly between them)")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
 
     # Exactly ONE line may reach stdout (the JSON result of rank 0), but native libraries write there too (RCCL prints a
     # five-line version banner at communicator creation): everything this process prints to file descriptor 1 goes to stderr,
@@ -225,8 +284,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run for --gpus > 1")
+        raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE={world} (launch with `python bench.py --gpus N` or "
+                         f"`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the measured path)")
     if args.backend == "gloo":
