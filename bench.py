@@ -153,22 +153,18 @@ def extras(args, scales, in_c, depth, dev):
         del net, tr
         torch.cuda.empty_cache()
         log("extras: bf16x3 mode (fp32 path, large products as split-bf16 triples on the bf16 matrix pipe), 5 steps")
-        from deepmerge_amd import ops
-        try:
-            torch.manual_seed(0)
-            net = ShfitScaleFormer_v3(cube_size=[8, 8], input_image_scales=list(scales), depth=list(depth), in_c=in_c, numerics="bf16x3").to(dev)
-            tr = PairTrainer(net, margin=1.0, lr=1e-4)
-            for _ in range(2):
-                tr.step(*batch)
-            torch.cuda.synchronize(); t0 = time.perf_counter()
-            for _ in range(5):
-                tr.step(*batch)
-            torch.cuda.synchronize(); d = (time.perf_counter() - t0) / 5
-            out["bf16x3_pairs_per_s"] = round(args.pairs / d, 1)
-            out["bf16x3_ms_per_step"] = round(1e3 * d, 2)
-            del net, tr
-        finally:
-            ops.set_fp32_products("mfma_f32")
+        torch.manual_seed(0)
+        net = ShfitScaleFormer_v3(cube_size=[8, 8], input_image_scales=list(scales), depth=list(depth), in_c=in_c, numerics="bf16x3").to(dev)
+        tr = PairTrainer(net, margin=1.0, lr=1e-4)
+        for _ in range(2):
+            tr.step(*batch)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(5):
+            tr.step(*batch)
+        torch.cuda.synchronize(); d = (time.perf_counter() - t0) / 5
+        out["bf16x3_pairs_per_s"] = round(args.pairs / d, 1)
+        out["bf16x3_ms_per_step"] = round(1e3 * d, 2)
+        del net, tr
         del batch
         torch.cuda.empty_cache()
         sys.path.insert(0, os.path.join(ROOT, "tools"))

@@ -25,8 +25,9 @@ __all__ = ["PatchEmbed", "Mlp", "FeatureEmbed", "CrossScaleAttention", "CrossSca
            "ShfitScaleFormer_v2", "ShfitScaleFormer_v3", "ShfitScaleFormer_v6"]
 
 
-def _mode(numerics: Optional[str]) -> str:
-    return ops.check_numerics(numerics or ops.get_numerics())
+def _mode(numerics: Optional[str], module=None) -> str:
+    """Validated numerics mode of a module; a "bf16x3" module gets its product scope bound to its calls (ops.bind_numerics)."""
+    return ops.bind_numerics(module, numerics or ops.get_numerics())
 
 
 def relative_position_index(cube: Sequence[int]) -> torch.Tensor:
@@ -52,7 +53,7 @@ class PatchEmbed(nn.Module):
         self.num_patches = self.grid_size[0] * self.grid_size[1]
         self.proj = nn.Conv2d(in_c, out_c, kernel_size=patch_size, stride=patch_size)
         self.norm = norm_layer(out_c) if norm_layer else nn.Identity()
-        self.numerics = _mode(numerics)
+        self.numerics = _mode(numerics, self)
 
     def operand_rows(self, x):
         """The patch-embed GEMM's A rows [B * num_patches, in_c * p * p] of an image batch (or of pre-gathered ops.PatchCols)."""
@@ -87,7 +88,7 @@ class Mlp(nn.Module):
         self.act = act_layer()
         self.fc2 = nn.Linear(hidden_features, out_features)
         self.drop = nn.Dropout(drop)
-        self.numerics = _mode(numerics)
+        self.numerics = _mode(numerics, self)
 
     def _run(self, x2d, residual2d, out_dtype):
         return ops.MlpFn.apply(x2d, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias, residual2d, out_dtype)
@@ -122,7 +123,7 @@ class FeatureEmbed(nn.Module):
         self.proj2 = nn.Conv1d(embed_dim, embed_dim, kernel_size=1, stride=1)
         self.norm = norm_layer(embed_dim) if norm_layer else nn.Identity()
         self.act = act_layer()
-        self.numerics = _mode(numerics)
+        self.numerics = _mode(numerics, self)
 
     def forward(self, x):
         B, T, F = x.shape                                    # [B, 1, 19]
@@ -152,7 +153,7 @@ class CrossScaleAttention(nn.Module):
         self.relative_position_bias_table = nn.Parameter(torch.zeros(self._table_rows(cube_size), num_heads))
         self.register_buffer("relative_position_index", self._make_index(cube_size))
         nn.init.trunc_normal_(self.relative_position_bias_table, std=.02)
-        self.numerics = _mode(numerics)
+        self.numerics = _mode(numerics, self)
         self._idx32 = None
 
     @staticmethod
@@ -185,9 +186,9 @@ class CrossScaleAttention(nn.Module):
 
 
 class CrossScaleBlock(nn.Module):
-    _dm_fused_block = True      # every parameter gets its gradient from ops.BlockFn.backward only (see trainer.FlatParams: first-write sinks)
     """Pre-norm block x += attn(LN(x)); x += mlp(LN(x)) (reference :158-184).  The residual stream stays
     fp32; both residual additions are fused into the proj / fc2 GEMM epilogues."""
+    _dm_fused_block = True      # every parameter gets its gradient from ops.BlockFn.backward only (see trainer.FlatParams: first-write sinks)
 
     _attention_cls = CrossScaleAttention
 
@@ -196,7 +197,7 @@ class CrossScaleBlock(nn.Module):
         super().__init__()
         if drop_path_ratio > 0.:
             raise ValueError("stochastic depth is not part of the accelerated path (reference passes 0)")
-        self.numerics = _mode(numerics)
+        self.numerics = _mode(numerics, self)
         self.norm1 = norm_layer(dim)
         self.attn = self._attention_cls(dim=dim, num_heads=num_heads, cube_size=cube_size, qkv_bias=qkv_bias,
                                         qk_scale=qk_scale, attn_drop_ratio=attn_drop_ratio, proj_drop_ratio=drop_ratio,
@@ -217,15 +218,15 @@ class CrossScaleBlock(nn.Module):
 
 
 class ShfitScaleFormer_v3(nn.Module):
-    _dm_first_write_blocks = True     # the blocks are only ever run through their fused forward: FlatParams need not zero their gradients
     """Multi-scale Siamese encoder, the variant the reference trains and serves (reference :772-1010)."""
+    _dm_first_write_blocks = True     # the blocks are only ever run through their fused forward: FlatParams need not zero their gradients
 
     def __init__(self, num_classes=11, is_designed_feature_embedding=True, FeatureEmbed=FeatureEmbed, PatchEmbed=PatchEmbed,
                  cube_size=[8, 8], input_image_scales=[32, 64, 128], embed_dim=768, depth=[6, 4, 2], num_heads=12,
                  mlp_ratio=4.0, drop_path_ratio=0., drop_ratio=0., attn_drop_ratio=0., norm_layer=nn.LayerNorm,
                  act_layer=nn.GELU, cuda=True, in_c=3, numerics=None):
         super().__init__()
-        self.numerics = _mode(numerics)
+        self.numerics = _mode(numerics, self)
         self.name = "S2Former_v3-3CH" + ("-3DP-SEF" if is_designed_feature_embedding else "")
         self.name = "{0}-{1}{2}{3}".format(self.name, depth[0], depth[1], depth[2])
         self.num_classes = num_classes
@@ -405,7 +406,7 @@ class AuxBolck(nn.Module):
         width = in_c * 2 if self._v5 else in_c
         self.norm = norm_layer(width)
         self.out_features = nn.Linear(width, out_c)
-        self.numerics = _mode(numerics)
+        self.numerics = _mode(numerics, self)
 
     def _scale_head(self, t):
         """t: [B, side*side, C] fp32 tokens of one scale -> [B, C/S]."""
@@ -449,12 +450,12 @@ class AuxBolck_v5(AuxBolck):
 
 
 class ShfitScaleFormer_v4(ShfitScaleFormer_v3):
-    _dm_first_write_blocks = False    # (not inherited: the auxiliary heads are separate autograd nodes; plain zero + accumulate)
     """v3 backbone + two auxiliary heads after blocks0 / blocks1 (reference :1013-1261).  Training returns
     ((x, aux0, aux1), (x, aux0, aux1)); eval returns x.  Three scales / 3 channels, as upstream.
 
     The two sides run as one batch of 2B through the backbone, but through the aux heads side by side:
     BatchNorm2d statistics (and their running updates) are per forward_once call upstream."""
+    _dm_first_write_blocks = False    # (not inherited: the auxiliary heads are separate autograd nodes; plain zero + accumulate)
 
     def __init__(self, num_classes=11, is_designed_feature_embedding=True, FeatureEmbed=FeatureEmbed, PatchEmbed=PatchEmbed,
                  cube_size=[8, 8], input_image_scales=[32, 64, 128], embed_dim=768, depth=[3, 2, 1], num_heads=12,
@@ -651,7 +652,7 @@ class ShfitScaleFormer(_SingleStage):
                  drop_path_ratio=0., drop_ratio=0., attn_drop_ratio=0., norm_layer=nn.LayerNorm, act_layer=nn.GELU, cuda=True,
                  numerics=None):
         super().__init__()
-        self.numerics = _mode(numerics)
+        self.numerics = _mode(numerics, self)
         self.num_classes = num_classes
         self.is_designed_feature_embedding = is_designed_feature_embedding
         self.patch_embed_layer, self.feature_embed_layer = PatchEmbed, FeatureEmbed
@@ -692,7 +693,7 @@ class ShfitScaleFormer_v2(_SingleStage):
                  drop_path_ratio=0., drop_ratio=0., attn_drop_ratio=0., norm_layer=nn.LayerNorm, act_layer=nn.GELU, cuda=True,
                  numerics=None):
         super().__init__()
-        self.numerics = _mode(numerics)
+        self.numerics = _mode(numerics, self)
         self.num_classes = num_classes
         self.is_designed_feature_embedding = is_designed_feature_embedding
         self.patch_embed_layer, self.feature_embed_layer = PatchEmbed, FeatureEmbed
@@ -729,7 +730,7 @@ class ShfitScaleFormer_v6(_SingleStage):
     def __init__(self, num_classes=11, FeatureEmbed=FeatureEmbed, embed_dim=768, mlp_ratio=4.0, drop_path_ratio=0., drop_ratio=0.,
                  norm_layer=nn.LayerNorm, act_layer=nn.GELU, cuda=True, numerics=None):
         super().__init__()
-        self.numerics = _mode(numerics)
+        self.numerics = _mode(numerics, self)
         self.num_classes = num_classes
         self.feature_embed_layer = FeatureEmbed
         self.feature_embed = FeatureEmbed(feature_size=19, embed_dim=768)

@@ -34,8 +34,7 @@ _SPLIT_MIN_WORK = 1 << 24       # products below this many multiply-adds stay on
 def set_numerics(mode: str) -> None:
     """Default numerics mode for modules constructed afterwards ("bf16", "fp32" or "bf16x3")."""
     global _NUMERICS
-    check_numerics(mode)
-    _NUMERICS = mode
+    _NUMERICS = check_numerics(mode)
 
 
 def get_numerics() -> str:
@@ -43,18 +42,40 @@ def get_numerics() -> str:
 
 
 def check_numerics(mode: str) -> str:
-    """Validate a module's numerics mode.  "bf16x3" = the fp32 mode (fp32 activations, gradients, attention, row kernels) with
-    its large products on the bf16 matrix pipe as split-bf16 triples (dm_split_bf16: ~2^-17 relative per product instead of
-    bf16's 2^-9).  How fp32 operands are multiplied is a process-wide switch (both the forward and the backward pass of every
-    fp32 module read it at call time): building a "bf16x3" module turns it on, `fp32_products(...)` scopes it."""
+    """Validate a module's numerics mode (no side effect).  "bf16x3" = the fp32 mode (fp32 activations, gradients, attention, row
+    kernels) with its large products on the bf16 matrix pipe as split-bf16 triples (dm_split_bf16: ~2^-17 relative per product
+    instead of bf16's 2^-9).  The product kind belongs to the MODULE: `bind_numerics` scopes every forward call of a "bf16x3"
+    module, and each autograd node replays the kind its forward ran under in its backward (`ctx.products`)."""
     if mode not in NUMERICS_MODES:
         raise ValueError(f"numerics must be one of {NUMERICS_MODES}, got {mode!r}")
-    if mode == "bf16x3":
-        set_fp32_products("bf16x3")
+    return mode
+
+
+def bind_numerics(module, mode: str) -> str:
+    """`self.numerics = ops.bind_numerics(self, mode)`: validates, and for "bf16x3" makes every call of this module run inside
+    `fp32_products("bf16x3")` (pre / post forward hooks; the post hook also runs when forward raises).  Modules of the other
+    modes leave the ambient kind alone, so `with ops.fp32_products("bf16x3"):` around an fp32 module still works as sugar."""
+    check_numerics(mode)
+    if mode == "bf16x3" and module is not None:
+        scopes = []
+
+        def _enter(mod, args):
+            sc = fp32_products("bf16x3")
+            sc.__enter__()
+            scopes.append(sc)
+
+        def _exit(mod, args, out):
+            if scopes:
+                scopes.pop().__exit__(None, None, None)
+
+        module.register_forward_pre_hook(_enter)
+        module.register_forward_hook(_exit, always_call=True)
     return mode
 
 
 def set_fp32_products(kind: str) -> None:
+    """Ambient product kind for fp32 operands OUTSIDE any module scope ("mfma_f32" by default).  Prefer the module's `numerics`
+    argument or the `fp32_products` context manager; nothing in this package calls this setter implicitly."""
     global _FP32_PRODUCTS
     if kind not in ("mfma_f32", "bf16x3"):
         raise ValueError(f"fp32 products are 'mfma_f32' or 'bf16x3', got {kind!r}")
@@ -66,19 +87,39 @@ def get_fp32_products() -> str:
 
 
 class fp32_products:
-    """with ops.fp32_products("bf16x3"): ...   (forward AND backward of the fp32-mode modules inside the block)"""
+    """with ops.fp32_products("bf16x3"): ...   scopes how gemm() multiplies fp32 operands.  Autograd nodes created inside the block
+    remember the kind (`_save_products`) and their backward runs under it wherever it is called from."""
 
     def __init__(self, kind: str):
+        if kind not in ("mfma_f32", "bf16x3"):
+            raise ValueError(f"fp32 products are 'mfma_f32' or 'bf16x3', got {kind!r}")
         self.kind = kind
 
     def __enter__(self):
+        global _FP32_PRODUCTS
         self.prev = _FP32_PRODUCTS
-        set_fp32_products(self.kind)
+        _FP32_PRODUCTS = self.kind
         return self
 
     def __exit__(self, *exc):
-        set_fp32_products(self.prev)
+        global _FP32_PRODUCTS
+        _FP32_PRODUCTS = self.prev
         return False
+
+
+def _save_products(ctx):
+    ctx.products = _FP32_PRODUCTS
+
+
+def _replay_products(backward):
+    """Decorator for an autograd Function's backward: run it under the product kind its forward recorded."""
+    import functools
+
+    @functools.wraps(backward)
+    def wrapped(ctx, *grads):
+        with fp32_products(getattr(ctx, "products", "mfma_f32")):
+            return backward(ctx, *grads)
+    return wrapped
 
 
 def act_dtype(mode: str) -> torch.dtype:
@@ -479,6 +520,7 @@ class LinearFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, residual, out_dtype):
+        _save_products(ctx)
         x = x.contiguous()
         M, K = x.shape
         N = weight.shape[0]
@@ -492,6 +534,7 @@ class LinearFn(torch.autograd.Function):
         return y
 
     @staticmethod
+    @_replay_products
     def backward(ctx, dy):
         x, w = ctx.saved_tensors
         dres = dy if ctx.needs_input_grad[3] else None
@@ -509,6 +552,7 @@ class PatchEmbedCatFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, S, T, *args):
+        _save_products(ctx)
         cols, weights, biases = args[:S], args[S:2 * S], args[2 * S:3 * S]
         B = cols[0].shape[0] // T
         Cc = weights[0].shape[0]
@@ -527,6 +571,7 @@ class PatchEmbedCatFn(torch.autograd.Function):
         return cube
 
     @staticmethod
+    @_replay_products
     def backward(ctx, dcube):
         S, T, B, Cc = ctx.cfg
         saved = ctx.saved_tensors
@@ -551,6 +596,7 @@ class MlpFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w1, b1, w2, b2, residual, out_dtype):
+        _save_products(ctx)
         x = x.contiguous()
         M, K = x.shape
         Hd, N = w1.shape[0], w2.shape[0]
@@ -567,6 +613,7 @@ class MlpFn(torch.autograd.Function):
         return y
 
     @staticmethod
+    @_replay_products
     def backward(ctx, dy):
         x, w1c, w2c, pre, h = ctx.saved_tensors
         M, K = x.shape
@@ -903,6 +950,7 @@ class BlockFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, n1w, n1b, table, index32, qkv_w, qkv_b, proj_w, proj_b, n2w, n2b, fc1_w, fc1_b, fc2_w, fc2_b,
                 heads, eps, scale, dtype):
+        _save_products(ctx)
         x = x.contiguous()
         B, N, Cc = x.shape
         M, Hd, D = B * N, fc1_w.shape[0], Cc // heads
@@ -936,6 +984,7 @@ class BlockFn(torch.autograd.Function):
         return x2.view(B, N, Cc)
 
     @staticmethod
+    @_replay_products
     def backward(ctx, dx2):
         (x, mean1, rstd1, y1, qkv, o, lse, bias, bias_t, index32, x1, mean2, rstd2, y2, pre, h,
          wq, wp, w1, w2, n1w, n2w) = ctx.saved_tensors

@@ -52,7 +52,7 @@ class PatchEmbed(nn.Module):
         self.num_patches = self.grid_size[0] * self.grid_size[1]
         self.proj = nn.Conv2d(in_c, embed_dim, kernel_size=patch_size, stride=patch_size)
         self.norm = norm_layer(embed_dim) if norm_layer else nn.Identity()
-        self.numerics = _mode(numerics)
+        self.numerics = _mode(numerics, self)
 
     def forward(self, x):
         B, C, H, W = x.shape
@@ -85,7 +85,7 @@ class Attention(nn.Module):
         self.attn_drop = nn.Dropout(attn_drop_ratio)
         self.proj = nn.Linear(dim, dim)
         self.proj_drop = nn.Dropout(proj_drop_ratio)
-        self.numerics = _mode(numerics)
+        self.numerics = _mode(numerics, self)
 
     def forward(self, x):
         B, N, Cc = x.shape
@@ -97,15 +97,15 @@ class Attention(nn.Module):
 
 
 class Block(nn.Module):
-    _dm_fused_block = True      # see nets/ShfitScaleFormer.py CrossScaleBlock
     """Pre-norm block (vit_model.py:160-185) as ONE fused autograd node."""
+    _dm_fused_block = True      # see nets/ShfitScaleFormer.py CrossScaleBlock
 
     def __init__(self, dim, num_heads, mlp_ratio=4., qkv_bias=False, qk_scale=None, drop_ratio=0., attn_drop_ratio=0.,
                  drop_path_ratio=0., act_layer=nn.GELU, norm_layer=nn.LayerNorm, numerics=None):
         super().__init__()
         if drop_path_ratio > 0.:
             raise ValueError("stochastic depth is not part of the accelerated path (reference passes 0)")
-        self.numerics = _mode(numerics)
+        self.numerics = _mode(numerics, self)
         self.norm1 = norm_layer(dim)
         self.attn = Attention(dim, num_heads=num_heads, qkv_bias=qkv_bias, qk_scale=qk_scale, attn_drop_ratio=attn_drop_ratio,
                               proj_drop_ratio=drop_ratio, numerics=self.numerics)
@@ -140,15 +140,15 @@ class _Head(nn.Module):
 
 
 class VisionTransformer(nn.Module):
-    _dm_first_write_blocks = True
     """vit_model.py:188-317.  forward(*args): 1 / 2 / 3 tensors -> once / twice / thrice, else ValueError."""
+    _dm_first_write_blocks = True
 
     def __init__(self, img_size=224, patch_size=16, in_c=3, num_classes=1000, embed_dim=768, depth=12, num_heads=12,
                  mlp_ratio=4.0, qkv_bias=True, qk_scale=None, representation_size=None, distilled=False, drop_ratio=0.,
                  attn_drop_ratio=0., drop_path_ratio=0., embed_layer=PatchEmbed, norm_layer=None, act_layer=None, numerics=None):
         super().__init__()
         _check_dim(embed_dim)
-        self.numerics = _mode(numerics)
+        self.numerics = _mode(numerics, self)
         self.num_classes = num_classes
         self.num_features = self.embed_dim = embed_dim
         self.num_tokens = 2 if distilled else 1
@@ -238,10 +238,10 @@ class VisionTransformer(nn.Module):
 
 
 class ScaleEmbedTransformer(nn.Module):
-    _dm_first_write_blocks = True
     """vit_model.py:321-549: four per-scale patch embeds (28/4, 56/8, 112/16, 224/32 -> 49 tokens each) with
     learned positional embeddings, a cls token and a designed-feature token, 12 blocks, `my_head` 768 -> 100.
     forward(*args): 1 -> forward_once, 2 -> (patches, designed) [NOT a pair], 4 -> pair, else ValueError."""
+    _dm_first_write_blocks = True
 
     def __init__(self, img_size=224, patch_size=16, in_c=3, num_classes=1000, embed_dim=768, depth=12, num_heads=12,
                  mlp_ratio=4.0, scales=[1, 1, 1, 1], qkv_bias=True, qk_scale=None, representation_size=None, distilled=False,
@@ -250,7 +250,7 @@ class ScaleEmbedTransformer(nn.Module):
                  numerics=None):
         super().__init__()
         _check_dim(embed_dim)
-        self.numerics = _mode(numerics)
+        self.numerics = _mode(numerics, self)
         self.num_classes = num_classes
         self.num_features = self.embed_dim = embed_dim
         self.scales = scales

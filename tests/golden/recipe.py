@@ -120,3 +120,20 @@ def summary_error(name: str, got: np.ndarray, fx, k: int = 2048):
     err = flat[idx] - want
     return (float(np.sqrt((err * err).sum()) / max(np.sqrt((want * want).sum()), 1e-300)),
             float(np.abs(err).max() / max(np.abs(want).max(), 1e-300)))
+
+
+def worst_gradient(prefix: str, named_grads, fx, k: int = 2048, floor: float = 1e-8):
+    """(name, rel-L2) of the gradient furthest from its pinned sample, over the tensors whose fixture sample has an l2 norm above
+    `floor` -- exactly-zero gradients (the k-bias of an attention block, say) have no relative error and are skipped."""
+    worst = ("(none)", 0.0)
+    for n, g in named_grads:
+        if g is None:
+            continue
+        want = fx[prefix + n + "/vals"].astype(np.float64)
+        if np.sqrt((want * want).sum()) < floor:
+            continue
+        e = summary_error(prefix + n, g, fx, k=k)[0]
+        if e > worst[1]:
+            worst = (n, e)
+    return worst
+

@@ -126,8 +126,56 @@ def test_numerics_mode_switches_need_no_gpu(built_lib):
             assert ops.get_fp32_products() == "mfma_f32"
         assert ops.get_fp32_products() == "bf16x3"
     assert ops.get_fp32_products() == "mfma_f32"
-    try:
-        assert ops.check_numerics("bf16x3") == "bf16x3" and ops.get_fp32_products() == "bf16x3"      # building a bf16x3 module turns it on
-        assert ops.act_dtype("bf16x3") is __import__("torch").float32 and ops.act_dtype("bf16") is __import__("torch").bfloat16
-    finally:
-        ops.set_fp32_products("mfma_f32")
+    # validation has no side effect: the product kind belongs to the module
+    assert ops.check_numerics("bf16x3") == "bf16x3" and ops.get_fp32_products() == "mfma_f32"
+    assert ops.act_dtype("bf16x3") is __import__("torch").float32 and ops.act_dtype("bf16") is __import__("torch").bfloat16
+
+
+def test_numerics_scope_belongs_to_the_module(built_lib):
+    """A "bf16x3" module runs ITS forward (and the backward of the autograd nodes it created) under split-bf16 products and
+    leaves the ambient kind alone -- two modules of different modes in one process do not share a setting."""
+    import torch
+    from deepmerge_amd import ops
+    from deepmerge_amd.nets import ShfitScaleFormer as S
+
+    seen = []
+
+    class Probe(torch.nn.Module):
+        def __init__(self, numerics):
+            super().__init__()
+            self.numerics = S._mode(numerics, self)
+
+        def forward(self, x, fail=False):
+            seen.append(ops.get_fp32_products())
+            if fail:
+                raise RuntimeError("boom")
+            return x
+
+    a, b = Probe("bf16x3"), Probe("fp32")
+    assert ops.get_fp32_products() == "mfma_f32"            # building a bf16x3 module flips nothing
+    a(1); b(2); a(3)
+    assert seen == ["bf16x3", "mfma_f32", "bf16x3"] and ops.get_fp32_products() == "mfma_f32"
+    with pytest.raises(RuntimeError):
+        a(1, fail=True)
+    assert ops.get_fp32_products() == "mfma_f32"            # the scope closes when forward raises
+    with ops.fp32_products("bf16x3"):                       # the context manager stays as sugar for fp32 modules
+        b(4)
+    assert seen[-1] == "bf16x3"
+
+    # backward replays the kind its forward recorded, whatever is ambient when autograd runs it
+    class Ctx:
+        pass
+
+    got = []
+
+    @ops._replay_products
+    def bwd(ctx, g):
+        got.append(ops.get_fp32_products())
+        return g
+
+    c = Ctx()
+    with ops.fp32_products("bf16x3"):
+        ops._save_products(c)
+    bwd(c, 0)
+    bwd(Ctx(), 0)
+    assert got == ["bf16x3", "mfma_f32"] and ops.get_fp32_products() == "mfma_f32"

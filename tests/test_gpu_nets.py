@@ -55,12 +55,11 @@ def test_rnn_matches_reference():
     (o * o).sum().backward()
     recipe.check_summary("rnn/out", o.detach().cpu().numpy(), fx, 2e-4)
     recipe.check_summary("rnn/dx", x.grad.cpu().numpy(), fx, 5e-4, atol=1e-7)
-    worst = 0.0
     for n, p in m.named_parameters():
         assert p.grad is not None, n
         recipe.check_summary("rnn/grad/" + n, p.grad.cpu().numpy(), fx, 5e-4, atol=1e-7)
-        worst = max(worst, recipe.summary_error("rnn/grad/" + n, p.grad.cpu().numpy(), fx)[0])
-    print(f"Nets.RNN: worst gradient rel-L2 error {worst:.2e}")
+    wn, we = recipe.worst_gradient("rnn/grad/", ((n, p.grad.cpu().numpy()) for n, p in m.named_parameters()), fx)
+    print(f"Nets.RNN: worst gradient rel-L2 error {we:.2e} ({wn})")
     m.train()
     torch.manual_seed(3)
     o2 = m(x.detach())

@@ -44,12 +44,11 @@ def test_vision_transformer_parity_fp32(tag, depth):
     recipe.check_summary(tag + "/out_a", ya.detach().cpu().numpy(), fx, GATE)
     recipe.check_summary(tag + "/out_b", yb.detach().cpu().numpy(), fx, GATE)
     assert abs(loss.item() - float(fx[tag + "/loss"])) <= GATE * abs(float(fx[tag + "/loss"]))
-    worst = 0.0
     for n, p in net.named_parameters():
         assert p.grad is not None, n
         recipe.check_summary(tag + "/grad/" + n, p.grad.cpu().numpy(), fx, GATE, k=512, atol=1e-7)
-        worst = max(worst, recipe.summary_error(tag + "/grad/" + n, p.grad.cpu().numpy(), fx, k=512)[0])
-    print(f"{tag}: worst gradient rel-L2 error {worst:.2e}")
+    wn, we = recipe.worst_gradient(tag + "/grad/", ((n, p.grad.cpu().numpy()) for n, p in net.named_parameters()), fx, k=512)
+    print(f"{tag}: worst gradient rel-L2 error {we:.2e} ({wn})")
     with torch.no_grad():
         one = net(x1.to(DEV))
     recipe.check_summary(tag + "/out_a", one.cpu().numpy(), fx, GATE)
@@ -176,13 +175,11 @@ def test_scale_embed_transformer_label_token_parity_fp32():
     assert abs(loss.item() - float(fx[tag + "/loss"])) <= GATE * abs(float(fx[tag + "/loss"]))
     none = sorted(n for n, p in net.named_parameters() if p.grad is None)
     assert none == sorted(str(s) for s in fx[tag + "/grad_none"])
-    worst = 0.0
     for n, p in net.named_parameters():
         if p.grad is not None:
             recipe.check_summary(tag + "/grad/" + n, p.grad.cpu().numpy(), fx, GATE, k=512, atol=1e-7)
-            if float(fx[tag + "/grad/" + n + "/l2"]) > 1e-4:
-                worst = max(worst, recipe.summary_error(tag + "/grad/" + n, p.grad.cpu().numpy(), fx, k=512)[0])
-    print(f"{tag}: worst gradient rel-L2 error {worst:.2e}")
+    wn, we = recipe.worst_gradient(tag + "/grad/", ((n, None if p.grad is None else p.grad.cpu().numpy()) for n, p in net.named_parameters()), fx, k=512)
+    print(f"{tag}: worst gradient rel-L2 error {we:.2e} ({wn})")
     with torch.no_grad():
         two = net([t.to(DEV) for t in xa], fa.to(DEV))
     for v, key in zip(two, ("out_a", "logits_a", "class_a")):

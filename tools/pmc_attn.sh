@@ -1,4 +1,8 @@
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+#!/bin/bash
+# MFMA / VALU / LDS counters of the attention kernels (tools/mb_attn.py), separate --pmc passes, program directly after `--`.
+set -euo pipefail
+ROOT="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
+cd /tmp && export TMPDIR=/tmp && cd "$ROOT"
 A="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE"
 Bc="SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU_TRANS_F32 SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_COEXEC_CYCLES"
 for cfg in "64 256 0" "256 197 1"; do set -- $cfg

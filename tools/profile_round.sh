@@ -4,7 +4,8 @@
 #   bash tools/profile_round.sh r02
 set -e
 TAG=${1:-r02}
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+ROOT="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
+cd /tmp && export TMPDIR=/tmp && cd "$ROOT"
 OUT=gpurun_out/${TAG}_prof
 rm -rf $OUT && mkdir -p $OUT
 ARGS="bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extras"
