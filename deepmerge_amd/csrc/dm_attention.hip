@@ -583,7 +583,7 @@ extern "C" int dm_attention_fwd(const void *qkv, const float *bias, void *out, f
     bool piped = false;
     if (dtype == DM_BF16) {      // persistent LDS-DMA pipeline for the big stage (dm_attention_pipe.hip)
       AttnPipeParams pp{qkv, bias, out, lse, B, N, H, scale};
-      piped = dm_attn_fwd_pipe(pp, s);
+      piped = dm_attn_fwd_q32(pp, s) || dm_attn_fwd_pipe(pp, s);     // 32 rows per wave (dm_attention_q32.hip), else 16 rows per wave
     }
     if (!piped) {
       if (dtype == DM_BF16) dispatch<bf16_t>(0, p, s); else dispatch<float>(0, p, s);

@@ -14,6 +14,10 @@ struct AttnPipeParams {
 // true if the pipelined forward kernel took the call (bf16, N a multiple of 16 in [128, 256]); false: nothing launched
 bool dm_attn_fwd_pipe(const AttnPipeParams &p, hipStream_t s);
 
+// Forward with 32 query rows per wave on the 32x32x16 MFMA, online softmax (dm_attention_q32.hip): bf16, 128 < N <= 256.
+// true if it took the call; DM_ATTN_Q32=0 disables it (A/B runs against the kernel above).
+bool dm_attn_fwd_q32(const AttnPipeParams &p, hipStream_t s);
+
 struct AttnPipeBwdParams {
   const void *qkv;      // [B, N, 3, H, 64] bf16
   const float *bias;    // [H, N, N] fp32 or NULL

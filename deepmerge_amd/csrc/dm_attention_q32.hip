@@ -1,0 +1,549 @@
+// Attention forward with 32 query rows per wave on the 32x32x16 bf16 MFMA (head dim 64, 128 < N <= 256), gfx950.
+//
+// Why (profiles/r02_attn_ablations.txt): in the 8-wave x 16-row kernel of dm_attention_pipe.hip every wave reads ALL of K and V from
+// LDS for 16 query rows -- 11 of its 42 us per stage-0 launch are fragment reads at the LDS peak, the softmax costs 7.8 VALU
+// instructions per score, and nothing overlaps.  Here a wave owns 32 query rows, so a K / V fragment feeds twice the MFMA work
+// (LDS fragment bytes per score halve), and the products are turned round so the QUERY sits on the MFMA lane:
+//   S^T[key][query] = K . Q^T     A = K rows from LDS (ds_read_b128), B = Q rows straight from global memory (lane = query)
+//   O^T[d][query]   = V^T . P^T   A = V^T by hardware-transposed LDS reads, B = P^T = the score registers themselves, packed
+// A lane then holds 16 keys per 32-key tile of ITS query row: row maximum and row sum are in-lane reductions plus one exchange with
+// lane ^ 32 (v_permlane32_swap), and the probabilities feed the second product without leaving the registers (MI355X guide, "an
+// accumulator tile as the next MFMA's operand": registers 8s .. 8s+7 of a 32x32 tile are the B fragment of k-step s, key order
+// 16 s + 8 (j >> 2) + 4 h + (j & 3) -- V^T is fetched in that order).
+// The relative-position bias costs NO instruction per score: the rows of the workgroup's queries (pre-divided by the scale) are
+// loaded once per workgroup and are the C operand of each tile's first MFMA (D != C).  Masked keys (ragged N) are a C operand of
+// -1e30 the same way.  Softmax per score: max3 (1/2), fma, exp2, add, cvt_pk (1/2) = 4 VALU issues.
+//
+// Register classes decide the structure.  C and D of an MFMA share one class (one acc_cd bit), and the VALU cannot read accumulator
+// registers, so scores AND bias must be architectural VGPRs (<= 256): 128 bias + 128 scores of an exact whole-row softmax do not fit.
+// Hence an ONLINE softmax over 32-key tiles with a deferred maximum: the reference maximum is the first tile's; a later tile only
+// forces a rescale when its maximum exceeds the reference by more than 2^16 (then l, and O after the pending P.V, are multiplied by
+// 2^(old - new): exact powers-of-two bookkeeping, so results do not depend on whether a rescale happened beyond fp32 rounding).
+// Live at any time: two score tiles (32 VGPRs), two packed P tiles (16), one K and one V fragment set (32), the bias (128).
+// O^T (32) and the Q^T fragments of this and the next sample (32) live in accumulator registers: the MFMAs are inline asm with
+// explicit register classes ("v" / "a"), so the wait states hipcc would pad are placed by hand:
+//   * VALU write -> MFMA operand: packed P is written at least four gaps before the MFMAs that read it (stage C of the pipeline
+//     below), fragments come from LDS behind hipcc's own waits; `s_nop 1` stands where an operand may be fresh (the Q copies at a
+//     sample's first MFMA, the last pairs before the epilogue's MFMAs, after a rescale); tools/isa_hazards.py checks the listing;
+//   * MFMA D -> VALU read: a tile's scores are first read after the NEXT tile's four MFMAs have been issued (>= 96 cycles), behind an
+//     opaque `asm volatile("" : "+v")` that the reads depend on; O is read behind `s_nop 15` twice.
+// Per tile the wave issues 4 QK^T MFMAs (tile j + 1) and 4 P.V MFMAs (tile j - 1) with the VALU work of tile j placed between them
+// piece by piece (sched_barrier fences): one wave per SIMD has no partner wave to fill its matrix pipe's gaps.
+//
+// One wave per SIMD (4 waves x 32 rows = 128-row block, one workgroup per CU); persistent over a chunk of samples like the pipelined
+// kernels: K / V of sample i + 1 arrive by LDS-DMA into the other buffer during the first tiles of sample i, Q fragments of sample
+// i + 1 are prefetched, one barrier per sample, results leave one sample late through a wave-private LDS block as whole 128-byte rows.
+// LDS images (bank model of MI355X_MICROARCH.md, both conflict-free for the access patterns used here):
+//   K [keys][128 B], 16-byte chunk index XOR ((key >> 1) & 7)   (ds_read_b128 of 32 consecutive rows, same chunk)
+//   V [keys][128 B], 64-byte half index XOR ((key >> 1) & 1)    (ds_read_b64_tr_b16 of 4 rows x 64 B per half-wave)
+#include <cstdlib>
+
+#include "dm_attention_pipe.h"
+#include "dm_common.h"
+#include "dm_mfma.h"
+
+// Timing ablations (tools/gpu_q32_abl.sh builds with EXTRA=-DDMQ_ABL=<bits>; results are then wrong by design):
+// 1 no bias loads, 2 no K / V DMA, 4 no exp pieces, 8 no P.V MFMAs, 16 no QK^T MFMAs, 32 no write-back, 64 no Q loads, 128 no fragment reads
+#ifndef DMQ_ABL
+#define DMQ_ABL 0
+#endif
+
+// -DDMQ_STAMP: wave 0 of every workgroup stamps s_memtime at six points of each of its first 8 samples into a __device__ array
+// (diagnostic build only: tools/q32_stamps.py reads it through dm_debug_q32_stamps)
+#ifdef DMQ_STAMP
+__device__ unsigned long long dmq_stamps[512 * 8 * 8];
+#define DMQ_T(i) do { if (wave == 0 && lane == 0 && (b - b0) < 8 && blockIdx.x < 512) dmq_stamps[(blockIdx.x * 8 + (b - b0)) * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+extern "C" int dm_debug_q32_stamps(unsigned long long *out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(dmq_stamps), sizeof(dmq_stamps)); }
+#else
+#define DMQ_T(i) do { } while (0)
+#endif
+
+namespace dmq32 {
+
+constexpr int HD = 64;
+constexpr int ROWS = 128;                       // query rows per workgroup: 4 waves x 32
+constexpr int WB_PITCH = 144;                   // write-back staging: 128-byte row + 16 bytes (keeps rows 16-byte aligned)
+constexpr int WB_WAVE = 32 * WB_PITCH;
+constexpr float NEG_BIG = -1.0e30f;
+
+// ---- MFMAs with explicit register classes (see the header: hipcc pads nothing inside or around these) ----------------------------
+#define DMQ_MFMA "v_mfma_f32_32x32x16_bf16"
+// scores: D, C in VGPRs; A = K fragment (VGPR), B = Q^T fragment: an accumulator register (QA, the bias instances: their 128 bias
+// registers leave no room in the architectural file) or a VGPR
+template <bool QA> __device__ __forceinline__ void qk_first(f32x16 &d, const u32x4 &k, const u32x4 &q, const f32x16 &c) {
+  if constexpr (QA) asm volatile(DMQ_MFMA " %0, %1, %2, %3" : "=&v"(d) : "v"(k), "a"(q), "v"(c));
+  else asm volatile(DMQ_MFMA " %0, %1, %2, %3" : "=&v"(d) : "v"(k), "v"(q), "v"(c));
+}
+template <bool QA> __device__ __forceinline__ void qk_first0(f32x16 &d, const u32x4 &k, const u32x4 &q) {
+  if constexpr (QA) asm volatile(DMQ_MFMA " %0, %1, %2, 0" : "=&v"(d) : "v"(k), "a"(q));
+  else asm volatile(DMQ_MFMA " %0, %1, %2, 0" : "=&v"(d) : "v"(k), "v"(q));
+}
+template <bool QA> __device__ __forceinline__ void qk_acc(f32x16 &d, const u32x4 &k, const u32x4 &q) {
+  if constexpr (QA) asm volatile(DMQ_MFMA " %0, %1, %2, %0" : "+v"(d) : "v"(k), "a"(q));
+  else asm volatile(DMQ_MFMA " %0, %1, %2, %0" : "+v"(d) : "v"(k), "v"(q));
+}
+// O^T: C = D in accumulator registers; A = V^T fragment, B = packed P^T (both VGPRs).  PAD: an operand may come fresh from the VALU.
+__device__ __forceinline__ void pv_acc(f32x16 &o, const u32x4 &v, const u32x4 &pb) {
+  asm volatile(DMQ_MFMA " %0, %1, %2, %0" : "+a"(o) : "v"(v), "v"(pb));
+}
+// row sums on the matrix pipe: A = ones, B = packed P^T -> every row of D holds, per query column, the sum over the k-step's 16 keys of
+// BOTH lane halves (what the P.V product sees, bf16-rounded); 2 MFMAs per tile replace 16 v_add_f32 per lane and the final exchange
+__device__ __forceinline__ void l_first(f32x16 &l, const u32x4 &ones, const u32x4 &pb) {
+  asm volatile(DMQ_MFMA " %0, %1, %2, 0" : "=&a"(l) : "v"(ones), "v"(pb));
+}
+__device__ __forceinline__ void l_acc(f32x16 &l, const u32x4 &ones, const u32x4 &pb) {
+  asm volatile(DMQ_MFMA " %0, %1, %2, %0" : "+a"(l) : "v"(ones), "v"(pb));
+}
+__device__ __forceinline__ void pv_first(f32x16 &o, const u32x4 &v, const u32x4 &pb) {
+  asm volatile(DMQ_MFMA " %0, %1, %2, 0" : "=&a"(o) : "v"(v), "v"(pb));
+}
+// A 128-bit value parked in accumulator registers: the "+a" operand makes hipcc copy it into ONE contiguous a[n:n+3] tuple here
+// (four v_accvgpr_write of its own, padded by itself), and from here on the value lives in that class -- the "a" operands of the
+// MFMAs below then need no copies.  (Four scalar "=a" outputs instead gave scattered registers that hipcc gathered with
+// v_accvgpr_mov directly in front of every MFMA: extra VALU work and, with no wait state before an asm MFMA, stale operands.)
+__device__ __forceinline__ void park_acc(u32x4 &v) { asm volatile("" : "+a"(v)); }
+// This file is built with -fno-slp-vectorize -ffinite-math-only (Makefile): adjacent f32 adds / fmas stay single instructions
+// (v_pk_*_f32 beside MFMAs cost more than two scalar ops) and fmaxf on MFMA results gets no NaN canonicalisation in front.
+__device__ __forceinline__ float max3(float a, float b, float c) { return __builtin_fmaxf(__builtin_fmaxf(a, b), c); }
+__device__ __forceinline__ unsigned pk_bf16(float lo, float hi) {
+  const bf16x2 r = {(bf16_t)lo, (bf16_t)hi};
+  return __builtin_bit_cast(unsigned, r);
+}
+// maximum / sum over the two half-waves (lane and lane ^ 32 hold the two key halves of one query row)
+__device__ __forceinline__ float half_max(float v) {
+  const unsigned u = __builtin_bit_cast(unsigned, v);
+  const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  return __builtin_fmaxf(__builtin_bit_cast(float, (unsigned)r[0]), __builtin_bit_cast(float, (unsigned)r[1]));
+}
+__device__ __forceinline__ float half_sum(float v) {
+  const unsigned u = __builtin_bit_cast(unsigned, v);
+  const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  return __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
+}
+// LDS-DMA as inline asm: hipcc orders a `buffer_load ... lds` builtin against every later ds_read with s_waitcnt vmcnt(0) (it sees an
+// LDS store), i.e. a wave that issues the next sample's K / V would wait for them at once.  In asm the transfer is invisible to that
+// bookkeeping; the kernel's own vmcnt(0) + barrier at the top of the next sample orders it (the destination is the OTHER buffer).
+// lds = wave-uniform LDS byte address of the 1 KiB piece, voff = per-lane byte offset, soff = wave-uniform byte offset.
+__device__ __forceinline__ void lds_dma(const i32x4 &rsrc, unsigned lds, unsigned voff, unsigned soff) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(lds), "s"(rsrc), "s"(soff) : "memory");
+}
+
+// Workgroup -> (head, row block, sample chunk): ids L, L + 8, ... share an XCD (round-robin dispatch) and are the row blocks of one
+// (head, chunk) group, so the second reader of a K / V row hits that XCD's L2 (same mapping as dm_attention_pipe.hip).
+__device__ __forceinline__ bool coords(int nblk, int H, int chunks, int &h, int &rb, int &chunk) {
+  const int L = blockIdx.x, xcd = L & 7, j = L >> 3;
+  rb = j % nblk;
+  const int group = xcd + 8 * (j / nblk);
+  if (group >= H * chunks) return false;
+  h = group % H;
+  chunk = group / H;
+  return true;
+}
+inline int grid_size(int nblk, int H, int chunks) { return (H * chunks + 7) / 8 * 8 * nblk; }
+
+// NKT: 32-key tiles; RAGGED: N < 32 NKT (keys >= N are zero-filled by the DMA descriptor and masked); BIAS: p.bias != NULL.
+template <int NKT, bool RAGGED, bool BIAS>
+__global__ __launch_bounds__(256, 1) void attn_fwd_q32_kernel(const AttnPipeParams p, int bchunk, int nblk, int chunks) {
+  constexpr int NP = NKT * 32;
+  const int N = RAGGED ? p.N : NP;
+  constexpr int IMG = NP * 128;
+  extern __shared__ __attribute__((aligned(16))) char smem[];      // [2 buffers][K image | V image] | 4 x write-back block
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int r = lane & 31, hh = lane >> 5;
+  int h, rb, chunk;
+  if (!coords(nblk, p.H, chunks, h, rb, chunk)) return;
+  const int H = p.H;
+  const int b0 = chunk * bchunk, b1 = min(p.B, b0 + bchunk);
+  if (b0 >= b1) return;
+  const int q_wave = rb * ROWS + wave * 32;
+  const int q = q_wave + r;                                         // this lane's query row
+  const bool wave_live = q_wave < N;                                // a wave without rows only takes part in the DMA / barriers
+  const bool row_ok = q < N;
+  const long long tok_stride = 3LL * H * HD;
+  const bf16_t *qkv = reinterpret_cast<const bf16_t *>(p.qkv);
+  constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
+  const float scale2 = p.scale * LOG2E;                             // scores are kept in raw q.k units; exp2(scale2 * (s - m))
+
+  // ---- C operands of each tile's first MFMA: bias / scale (per workgroup, all samples), or the key mask of the last tile ------------
+  constexpr int NC = BIAS ? NKT : (RAGGED ? 1 : 0);
+  f32x16 cinit[NC > 0 ? NC : 1];
+  if constexpr (BIAS) {
+    const float inv_scale = 1.f / p.scale;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int key = 32 * kt + 8 * c + 4 * hh;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (wave_live && row_ok && !(DMQ_ABL & 1)) {
+          const float *brow = p.bias + ((long long)h * N + q) * N + key;
+          if (!RAGGED || key + 4 <= N) {
+            if (!RAGGED) v = dm_load4(brow);                        // N % 32 == 0: 16-byte aligned rows
+            else { v[0] = brow[0]; v[1] = brow[1]; v[2] = brow[2]; v[3] = brow[3]; }
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (key + e < N) v[e] = brow[e];
+          }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) cinit[kt][4 * c + e] = (RAGGED && key + e >= N) ? NEG_BIG : v[e] * inv_scale;
+      }
+    }
+  } else if constexpr (RAGGED) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) cinit[0][i] = (32 * (NKT - 1) + 8 * (i >> 2) + 4 * hh + (i & 3) >= N) ? NEG_BIG : 0.f;
+  }
+  auto c_of = [&](int kt) -> f32x16 {
+    if constexpr (BIAS) return cinit[kt];
+    if constexpr (RAGGED) {
+      if (kt == NKT - 1) return cinit[0];
+    }
+    f32x16 z;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) z[i] = 0.f;
+    return z;
+  };
+
+  // ---- DMA: one wave-instruction = 8 keys x 128 B (1 KiB of an image); every wave stages NKT instructions of K and of V ------------
+  const int dkey = lane >> 3;                                       // key row of the instruction this lane fills
+  // the swizzles are applied on the SOURCE chunk (a wave-instruction's LDS destinations are lane-linear); instruction `inst` of a
+  // wave has inst & 1 == wave & 1, so (key >> 1) & 7 = ((wave & 1) << 2) | (dkey >> 1)
+  const unsigned rowoff0 = (unsigned)((8 * wave + dkey) * tok_stride * 2);
+  const unsigned voffK = rowoff0 + (unsigned)(1 * H * HD * 2) + (unsigned)(((lane & 7) ^ (((wave & 1) << 2) | (dkey >> 1))) * 16);
+  const unsigned voffV = rowoff0 + (unsigned)(2 * H * HD * 2) + (unsigned)(((lane & 7) ^ (((dkey >> 1) & 1) << 2)) * 16);
+  const unsigned lds0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(uintptr_t)(DM_LDS char *)smem);
+  unsigned step_bytes = (unsigned)__builtin_amdgcn_readfirstlane((int)(32 * tok_stride * 2));          // instruction j + 1 of a wave: 32 keys on
+  asm volatile("s_nop 4" : "+s"(step_bytes));
+  // buffer descriptor of sample b's rows of this head (out-of-range rows read zero): wave-uniform words in scalar registers
+  auto sample_rsrc = [&](int b) -> i32x4 {
+    const uintptr_t base = reinterpret_cast<uintptr_t>(qkv + (long long)b * N * tok_stride + (long long)h * HD);
+    i32x4 rs;
+    rs[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)(base & 0xffffffffu));
+    rs[1] = __builtin_amdgcn_readfirstlane((int)(unsigned)((base >> 32) & 0xffffu));
+    rs[2] = __builtin_amdgcn_readfirstlane((int)(N * tok_stride * 2));
+    rs[3] = 0x00020000;
+    asm volatile("s_nop 4" : "+s"(rs));                             // v_readfirstlane -> descriptor read by a buffer instruction: 5 wait states, paid here once
+    return rs;
+  };
+  // `part` (0..3): instructions j = part, part + 4, ... of this wave's NKT (the early tiles of the previous sample issue one part each)
+  auto stage_part = [&](const i32x4 &rs, int buf, int part) {
+    const unsigned kimg = lds0 + (unsigned)(buf * (2 * IMG)) + (unsigned)wave * 1024u, vimg = kimg + (unsigned)IMG;
+    if (DMQ_ABL & 2) return;
+#pragma unroll
+    for (int j = part; j < NKT; j += 4) {                           // instruction inst = wave + 4 j: keys 8 inst .. 8 inst + 7
+      lds_dma(rs, kimg + (unsigned)j * 4096u, voffK, (unsigned)j * step_bytes);
+      lds_dma(rs, vimg + (unsigned)j * 4096u, voffV, (unsigned)j * step_bytes);
+    }
+  };
+  auto stage_all = [&](int b, int buf) {
+    const i32x4 rs = sample_rsrc(b);
+#pragma unroll
+    for (int part = 0; part < 4; ++part) stage_part(rs, buf, part);
+  };
+  // Q^T fragments (B operand): lane (query r, half hh) holds d = 16 ks + 8 hh .. + 7 of its row for k-step ks
+  auto load_q = [&](int b, u32x4 (&f)[4]) {
+    const bf16_t *qrow = qkv + ((long long)b * N + q) * tok_stride + (long long)h * HD + 8 * hh;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+      f[ks] = (wave_live && row_ok && !(DMQ_ABL & 64)) ? *reinterpret_cast<const u32x4 *>(qrow + 16 * ks) : (u32x4){0u, 0u, 0u, 0u};
+  };
+  // ---- fragment offsets inside the images --------------------------------------------------------------------------------------
+  const int kx = (r >> 1) & 7;
+  int koff[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) koff[ks] = r * 128 + (((2 * ks + hh) ^ kx) << 4);                 // + 4096 kt
+  // V^T by transposed reads: lane 4 qd + pp of a 16-lane group addresses key row qd, d columns 4 pp .. 4 pp + 3 of the group's 16
+  const int ve = (lane >> 4) & 1, qd = (lane >> 2) & 3, pp = lane & 3;
+  int voff[2];
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt) voff[dt] = (4 * hh + qd) * 128 + ((dt ^ ((qd >> 1) & 1)) << 6) + ve * 32 + pp * 8;   // + (32 kt + 16 s + 8 j2) * 128
+
+  char *wb = smem + 4 * IMG + wave * WB_WAVE;
+  float lse_prev = 0.f;
+  // results of sample b sit in the wave's LDS block (bf16 rows) until the top of the next iteration: lane L stores the 16-byte
+  // chunk L & 7 of rows (L >> 3) + 8 k, i.e. every store instruction covers eight whole 128-byte rows
+  // part k (0..3): rows rr + 8 k of the wave's block (one LDS read + one store per lane); the parts are spread over the first tiles
+  // of the next sample: four stores issued together at its top queue behind the other waves' (the store path, not the bytes)
+  auto flush_part = [&](int b, int k) {
+    if (!wave_live || (DMQ_ABL & 32)) return;
+    bf16_t *orow0 = reinterpret_cast<bf16_t *>(p.out) + ((long long)b * N + q_wave) * H * HD + (long long)h * HD;
+    const int rr = lane >> 3, cc = lane & 7;
+    const u32x4 v = *reinterpret_cast<const u32x4 *>(wb + (rr + 8 * k) * WB_PITCH + cc * 16);
+    if (q_wave + rr + 8 * k < N) *reinterpret_cast<u32x4 *>(orow0 + (long long)(rr + 8 * k) * H * HD + cc * 8) = v;
+    if (k == 0 && hh == 0 && row_ok) p.lse[((long long)b * H + h) * N + q] = lse_prev;
+  };
+  auto flush = [&](int b) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) flush_part(b, k);
+  };
+
+  constexpr float RESCALE_LOG2 = 16.f;                              // a later tile may exceed the reference maximum by 2^16 before l / O are rescaled
+  constexpr bool QA = BIAS;                                         // Q^T fragments in accumulator registers
+  u32x4 qf[4], qld[4];                                              // qld: the next sample's rows, requested late in this sample
+  stage_all(b0, 0);
+  load_q(b0, qld);
+  for (int b = b0; b < b1; ++b) {
+    const int buf = (b - b0) & 1;
+    DMQ_T(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // this sample's K / V / Q have landed (issued during the previous sample)
+    DMQ_T(1);
+    __builtin_amdgcn_s_barrier();                                   // ... for every wave; and everyone is done with the other buffer
+    DMQ_T(2);
+    const bool more = b + 1 < b1;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      qf[ks] = qld[ks];
+      if constexpr (QA) park_acc(qf[ks]);
+    }
+    i32x4 rs_next = {0, 0, 0, 0};
+    if (more) rs_next = sample_rsrc(b + 1);
+    const char *kimg = smem + buf * (2 * IMG), *vimg = kimg + IMG;
+
+    if (wave_live) {
+      f32x16 s0, s1;                                                 // score tiles j (even) / j (odd): named, never indexed at run time
+      u32x4 pb0[2], pb1[2];                                          // packed P^T of tiles j even / odd, k-steps 0 / 1
+      u32x4 kf[4];
+      u32x2 vf[8];
+      f32x16 o0, o1, la;                                             // O^T (two 32-row d tiles) and the row sums: accumulator registers
+      u32x4 ones = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
+      asm volatile("" : "+v"(ones));
+      float m = 0.f, msc = 0.f, alpha = 1.f;
+      auto read_k = [&](int kt) {
+        if ((DMQ_ABL & 128) && kt > 0) return;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) kf[ks] = *reinterpret_cast<const u32x4 *>(kimg + kt * 4096 + koff[ks]);
+      };
+      auto read_v = [&](int kt) {
+        if ((DMQ_ABL & 128) && kt > 0) return;
+#pragma unroll
+        for (int sx = 0; sx < 2; ++sx)
+#pragma unroll
+          for (int dt = 0; dt < 2; ++dt) {
+            const char *a = vimg + (32 * kt + 16 * sx) * 128 + voff[dt];
+            vf[4 * sx + 2 * dt] = dm_ds_read_tr16(a);
+            vf[4 * sx + 2 * dt + 1] = dm_ds_read_tr16(a + 8 * 128);
+          }
+      };
+      auto vfrag = [&](int sx, int dt) { return (u32x4){vf[4 * sx + 2 * dt][0], vf[4 * sx + 2 * dt][1], vf[4 * sx + 2 * dt + 1][0], vf[4 * sx + 2 * dt + 1][1]}; };
+      // piece `ks` of tile kt's QK^T chain into `d`
+      auto qk_piece = [&](int kt, int ks, f32x16 &d) {
+        if ((DMQ_ABL & 16) && kt > 0) return;
+        if (ks == 0) {
+          if constexpr (BIAS) qk_first<QA>(d, kf[0], qf[0], cinit[kt]);
+          else if (RAGGED && kt == NKT - 1) qk_first<QA>(d, kf[0], qf[0], cinit[0]);
+          else qk_first0<QA>(d, kf[0], qf[0]);
+        } else {
+          qk_acc<QA>(d, kf[ks], qf[ks]);
+        }
+      };
+      // piece g (0..3) of tile kt's P.V: (k-step, d tile) = (g >> 1, g & 1); packed P of a k-step may come fresh from the VALU
+      auto pv_piece = [&](int kt, int g, const u32x4 (&pb)[2]) {
+        const int sx = g >> 1, dt = g & 1;
+        f32x16 &o = dt ? o1 : o0;
+        if ((DMQ_ABL & 8) && kt > 0) return;
+        if (kt == 0 && sx == 0) pv_first(o, vfrag(0, dt), pb[0]);
+        else pv_acc(o, vfrag(sx, dt), pb[sx]);
+      };
+      auto l_piece = [&](int kt, int sx, const u32x4 (&pb)[2]) {
+        if ((DMQ_ABL & 8) && kt > 0) return;
+        if (kt == 0 && sx == 0) l_first(la, ones, pb[0]);
+        else l_acc(la, ones, pb[sx]);
+      };
+      // ---- the VALU work of a tile as a three-stage pipeline over the MFMA gaps ---------------------------------------------------------
+      // One wave per SIMD has nobody to cover a dependent VALU result's latency (tools/hip/mb_coissue.hip: fma, fma, exp, exp, cvt on
+      // each other's results = 55 cycles instead of the 28 they take to issue; the MFMA itself hides completely beside them).  So a
+      // gap holds stage F of score pair k (s * scale2 - m * scale2), stage E of pair k - 1 (exp2) and stage C of pair k - 2 (pack to
+      // bf16): nothing in a gap depends on anything computed in the same or the previous instruction.
+      float fa[8][2], ex[8][2];
+      auto stage_f = [&](const f32x16 &sc, int k) {
+        if (DMQ_ABL & 4) return;
+        fa[k][0] = __builtin_fmaf(sc[2 * k], scale2, msc);
+        fa[k][1] = __builtin_fmaf(sc[2 * k + 1], scale2, msc);
+        asm volatile("" :: "v"(fa[k][0]), "v"(fa[k][1]));            // (stays in ITS gap: hipcc otherwise sinks it to the use)
+      };
+      auto stage_e = [&](int k) {
+        if (DMQ_ABL & 4) return;
+        ex[k][0] = __builtin_amdgcn_exp2f(fa[k][0]);
+        ex[k][1] = __builtin_amdgcn_exp2f(fa[k][1]);
+        asm volatile("" :: "v"(ex[k][0]), "v"(ex[k][1]));
+      };
+      auto stage_c = [&](int k, u32x4 (&pb)[2]) {
+        if (DMQ_ABL & 4) { pb[k >> 2][k & 3] = 0x3f803f80u; return; }
+        const unsigned w = pk_bf16(ex[k][0], ex[k][1]);
+        pb[k >> 2][k & 3] = w;
+        asm volatile("" :: "v"(w));
+      };
+      // running maximum of the NEXT tile's scores, two v_max3 per call (calls c = 0..3), started once its MFMAs are two gaps behind
+      float t0 = 0.f, t1 = 0.f;
+      auto stage_m = [&](f32x16 &sn, int c) {
+        if (c == 0) {
+          asm volatile("" : "+v"(sn));                               // the scores are read below this point only (MFMA D -> VALU distance)
+          t0 = max3(sn[0], sn[1], sn[2]); t1 = max3(sn[3], sn[4], sn[5]);
+        } else if (c == 1) {
+          t0 = max3(t0, sn[6], sn[7]); t1 = max3(t1, sn[8], sn[9]);
+        } else if (c == 2) {
+          t0 = max3(t0, sn[10], sn[11]); t1 = max3(t1, sn[12], sn[13]);
+        } else {
+          t0 = max3(t0, sn[14], sn[15]);
+        }
+        asm volatile("" :: "v"(t0), "v"(t1));
+      };
+      // reference maximum: tile 0 sets it (row maximum over both lane halves); a later tile only moves it when one of its scores is more
+      // than 2^RESCALE_LOG2 above (checked per half: no exchange on the common path).  t0 / t1 hold the tile's running maxima.
+      auto tile_max = [&](int kt) -> bool {
+        const float th = __builtin_fmaxf(t0, t1);
+        if (kt == 0) {
+          m = half_max(th);
+          msc = -m * scale2;
+          return false;
+        }
+        const bool grow = (th - m) * scale2 > RESCALE_LOG2;
+        if (__builtin_amdgcn_ballot_w64(grow) == 0) return false;    // wave-uniform: almost always
+        const float mn = __builtin_fmaxf(m, half_max(th));
+        alpha = __builtin_amdgcn_exp2f((m - mn) * scale2);           // 1 for the rows whose maximum did not grow
+        m = mn;
+        msc = -m * scale2;
+        return true;
+      };
+      auto rescale_o = [&]() {                                       // after the pending P.V / row-sum MFMAs of tile j - 1, before tile j's
+        asm volatile("s_nop 15\n\ts_nop 7" : "+a"(o0), "+a"(o1), "+a"(la));
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { o0[i] *= alpha; o1[i] *= alpha; la[i] *= alpha; }
+        asm volatile("s_nop 3" : "+a"(o0), "+a"(o1), "+a"(la));
+      };
+
+      // ---- prologue: tile 0's scores and their maximum ------------------------------------------------------------------------------------
+      read_k(0);
+      asm volatile("s_nop 1");                                       // Q^T copies into accumulator registers may be fresh (VALU write -> MFMA operand)
+      qk_piece(0, 0, s0); qk_piece(0, 1, s0); qk_piece(0, 2, s0); qk_piece(0, 3, s0);
+      if (NKT > 1) read_k(1);
+      asm volatile("s_nop 15\n\ts_nop 7" : "+v"(s0));
+      stage_m(s0, 0); stage_m(s0, 1); stage_m(s0, 2); stage_m(s0, 3);
+      DMQ_T(3);
+#pragma unroll
+      for (int j = 0; j < NKT; ++j) {
+        if (j == 4) DMQ_T(4);
+        // iteration j, ten MFMA gaps: QK^T(j + 1) x 4, row sums(j - 1) x 2, P.V(j - 1) x 4, with tile j's VALU pipeline between them
+        f32x16 &sc = (j & 1) ? s1 : s0;                              // tile j's scores; tile j + 1 accumulates into sn
+        f32x16 &sn = (j & 1) ? s0 : s1;
+        u32x4 (&pbc)[2] = (j & 1) ? pb1 : pb0;
+        u32x4 (&pbp)[2] = (j & 1) ? pb0 : pb1;
+        const bool resc = tile_max(j);
+        if (j > 0) read_v(j - 1);
+        __builtin_amdgcn_sched_barrier(0);
+        // The operands of an MFMA stay LIVE to the end of its gap (the empty asm statements): to hipcc an asm MFMA has read its
+        // operands when it is issued, so it would reuse a fragment's registers for the very next VALU results.
+#pragma unroll
+        for (int g = 0; g < 10; ++g) {
+          if (g < 4) {
+            if (j + 1 < NKT) qk_piece(j + 1, g, sn);
+          } else if (g < 6) {
+            if (j > 0) l_piece(j - 1, g - 4, pbp);
+          } else {
+            if (j > 0) pv_piece(j - 1, g - 6, pbp);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          if (g < 8) stage_f(sc, g);
+          if (g >= 1 && g < 9) stage_e(g - 1);
+          if (g >= 2) stage_c(g - 2, pbc);
+          if (g >= 6 && j + 1 < NKT) stage_m(sn, g - 6);
+          if (g == 4) {
+            if (j + 2 < NKT) read_k(j + 2);
+            if (QA && more && j == NKT - 2) load_q(b + 1, qld);      // bias instances: into the K fragment registers, free from here on
+            if (!QA && more && j == 1) load_q(b + 1, qld);           // next sample's Q rows (registers to spare without a bias)
+          }
+          if (g == 5) {
+            if (more && j < 4) stage_part(rs_next, buf ^ 1, j);      // next sample's K / V: a quarter of this wave's DMA per early tile
+            if (b > b0 && j < 4) flush_part(b - 1, j);               // previous sample's rows: a quarter per early tile
+          }
+          if (g < 4) {
+            if (j + 1 < NKT) asm volatile("" :: "v"(kf[g]));
+          } else if (g < 6) {
+            if (j > 0) asm volatile("" :: "v"(pbp[g - 4]), "v"(ones));
+          } else {
+            if (j > 0) asm volatile("" :: "v"(vf[2 * (g - 6)]), "v"(vf[2 * (g - 6) + 1]), "v"(pbp[(g - 6) >> 1]));
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if (resc) rescale_o();
+      }
+      DMQ_T(5);
+      // ---- epilogue: P.V and row sums of the last tile, normalise, park the rows in the wave's LDS block ---------------------------------
+      read_v(NKT - 1);
+      {
+        u32x4 (&pbl)[2] = ((NKT - 1) & 1) ? pb1 : pb0;
+        asm volatile("s_nop 1");                                     // the last packed pairs were written in the last gaps (VALU write -> MFMA operand)
+        l_piece(NKT - 1, 0, pbl);
+        l_piece(NKT - 1, 1, pbl);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) pv_piece(NKT - 1, g, pbl);
+        asm volatile("s_nop 15\n\ts_nop 7" : "+a"(o0), "+a"(o1), "+a"(la) : "v"(pbl[0]), "v"(pbl[1]), "v"(ones));
+      }
+      const float l = la[0];                                         // every row of `la` is the row sum of this lane's query
+      const float inv = 1.f / l;
+      lse_prev = (m * scale2 + __builtin_amdgcn_logf(l)) * LN2;      // natural-log units for the backward kernels
+      // lane (query r, half hh) holds d = 32 dt + 8 c + 4 hh + e in register 4 c + e of o<dt>
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const u32x2 w0 = {pk_bf16(o0[4 * c] * inv, o0[4 * c + 1] * inv), pk_bf16(o0[4 * c + 2] * inv, o0[4 * c + 3] * inv)};
+        const u32x2 w1 = {pk_bf16(o1[4 * c] * inv, o1[4 * c + 1] * inv), pk_bf16(o1[4 * c + 2] * inv, o1[4 * c + 3] * inv)};
+        *reinterpret_cast<u32x2 *>(wb + r * WB_PITCH + (8 * c + 4 * hh) * 2) = w0;
+        *reinterpret_cast<u32x2 *>(wb + r * WB_PITCH + (32 + 8 * c + 4 * hh) * 2) = w1;
+      }
+      DMQ_T(6);
+    } else if (more) {
+      stage_all(b + 1, buf ^ 1);                                     // a wave without rows still stages its share
+    }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  flush(b1 - 1);
+}
+
+inline void grid(int B, int N, int H, int &nblk, int &chunks, int &bchunk) {
+  nblk = (N + ROWS - 1) / ROWS;
+  chunks = 256 / (H * nblk);
+  if (chunks < 1) chunks = 1;
+  if (chunks > B) chunks = B;
+  bchunk = (B + chunks - 1) / chunks;
+  chunks = (B + bchunk - 1) / bchunk;
+}
+
+template <int NKT, bool RAGGED, bool BIAS> bool launch(const AttnPipeParams &p, hipStream_t s) {
+  constexpr int LDS = 4 * NKT * 32 * 128 + 4 * WB_WAVE;
+  static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void *>(attn_fwd_q32_kernel<NKT, RAGGED, BIAS>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, LDS) == hipSuccess;
+  if (!ok) return false;
+  int nblk, chunks, bchunk;
+  grid(p.B, p.N, p.H, nblk, chunks, bchunk);
+  hipLaunchKernelGGL((attn_fwd_q32_kernel<NKT, RAGGED, BIAS>), dim3(grid_size(nblk, p.H, chunks)), dim3(256), LDS, s, p, bchunk, nblk, chunks);
+  return true;
+}
+
+template <int NKT> bool launch_n(const AttnPipeParams &p, hipStream_t s) {
+  const bool ragged = p.N != NKT * 32;
+  if (p.bias) return ragged ? launch<NKT, true, true>(p, s) : launch<NKT, false, true>(p, s);
+  return ragged ? launch<NKT, true, false>(p, s) : launch<NKT, false, false>(p, s);
+}
+
+}  // namespace dmq32
+
+// bf16, head dim 64, 128 < N <= 256 (5 .. 8 key tiles of 32).  DM_ATTN_Q32=0 keeps the 16-row pipelined kernels (A/B runs).
+bool dm_attn_fwd_q32(const AttnPipeParams &p, hipStream_t s) {
+  static const int mode = [] { const char *e = getenv("DM_ATTN_Q32"); return e ? atoi(e) : 1; }();
+  if (mode == 0) return false;
+  if (p.N <= 128 || p.N > 256) return false;
+  if ((long long)p.N * 3 * p.H * 64 * 2 >= (1LL << 31)) return false;          // one sample's rows must fit a 32-bit DMA offset
+  if (mode != 2 && p.B * p.H < 96) return false;                              // too little work for persistent workgroups
+  if (p.bias && (reinterpret_cast<uintptr_t>(p.bias) & 15u)) return false;
+  switch ((p.N + 31) / 32) {
+    case 5: return dmq32::launch_n<5>(p, s);
+    case 6: return dmq32::launch_n<6>(p, s);
+    case 7: return dmq32::launch_n<7>(p, s);
+    case 8: return dmq32::launch_n<8>(p, s);
+    default: return false;
+  }
+}

@@ -107,6 +107,12 @@ class fp32_products:
         return False
 
 
+def module_products(module):
+    """The product scope of `module` as a context manager: for callers that enter a model through a method other than `__call__`
+    (PairTrainer's `forward_pair_batched`), where the forward hooks of `bind_numerics` do not fire."""
+    return fp32_products("bf16x3" if getattr(module, "numerics", None) == "bf16x3" else _FP32_PRODUCTS)
+
+
 def _save_products(ctx):
     ctx.products = _FP32_PRODUCTS
 

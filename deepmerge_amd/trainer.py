@@ -350,11 +350,12 @@ class PairTrainer:
         st["shapes"] = [tuple(t.shape) for t in st["left"] + st["right"]]
 
     def _forward_loss(self, st):
-        if st["both"] is not None:
-            fa, fb = self.net.forward_pair_batched(st["both"], st["dboth"])
-        else:
-            fa, fb = self.net(st["left"], st["ld"], st["right"], st["rd"])
-        return self.criterion(fa, fb, st["flag"])
+        with ops.module_products(self.net):          # forward_pair_batched is not `__call__`: the module's forward hooks do not fire
+            if st["both"] is not None:
+                fa, fb = self.net.forward_pair_batched(st["both"], st["dboth"])
+            else:
+                fa, fb = self.net(st["left"], st["ld"], st["right"], st["rd"])
+            return self.criterion(fa, fb, st["flag"])
 
     def _capture(self, st):
         torch.cuda.synchronize()

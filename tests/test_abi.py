@@ -162,6 +162,15 @@ def test_numerics_scope_belongs_to_the_module(built_lib):
         b(4)
     assert seen[-1] == "bf16x3"
 
+    # entry points other than __call__ (PairTrainer -> forward_pair_batched) take the module's scope explicitly
+    with ops.module_products(a):
+        assert ops.get_fp32_products() == "bf16x3"
+    with ops.module_products(b):
+        assert ops.get_fp32_products() == "mfma_f32"
+    with ops.fp32_products("bf16x3"), ops.module_products(b):      # an fp32 module leaves the ambient kind alone
+        assert ops.get_fp32_products() == "bf16x3"
+    assert ops.get_fp32_products() == "mfma_f32"
+
     # backward replays the kind its forward recorded, whatever is ambient when autograd runs it
     class Ctx:
         pass

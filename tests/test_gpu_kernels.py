@@ -413,6 +413,29 @@ def test_attention_pipelined_workgroup_order(B, H, N, with_bias):
     test_attention_forward_backward("bf16", N, with_bias, B=B, H=H)
 
 
+@pytest.mark.parametrize("N,with_bias", [(256, True), (197, False), (160, True), (224, False)])
+def test_attention_q32_deferred_maximum(N, with_bias):
+    """dm_attention_q32.hip keeps the FIRST 32-key tile's row maximum as the softmax reference and rescales l / O only when a later
+    tile exceeds it by more than 2^16.  Keys whose norm grows with their index force that path several times per row (scores of
+    later tiles are far above the first tile's); the result must still be the exact softmax (fp64 reference, bf16 tolerance).
+    Reference semantics: softmax over the whole row, nets/ShfitScaleFormer.py:127-131 / vit_model.py:125-127."""
+    ops = _ops()
+    rng = np.random.default_rng(N)
+    B, H, D = 8, 12, 64
+    qkv = rng.normal(size=(B, N, 3, H, D)).astype(np.float32)
+    qkv[:, :, 1] *= (1.0 + np.arange(N, dtype=np.float32) / 12.0)[None, :, None, None]      # |k| grows 20x from the first to the last key
+    qkv = torch.from_numpy(qkv).to(torch.bfloat16)
+    bias = torch.from_numpy(rng.normal(size=(H, N, N)).astype(np.float32)) if with_bias else None
+    o_ref, lse_ref = _attn_ref(qkv.double(), None if bias is None else bias.double(), 0.125)
+    spread = (qkv[:, :, 0].double().permute(0, 2, 1, 3) @ qkv[:, :, 1].double().permute(0, 2, 3, 1)) * 0.125 * 1.4427
+    assert ((spread[..., 32:].amax(-1) - spread[..., :32].amax(-1)) > 16).float().mean() > 0.5        # most rows do take the rescale path
+    out, lse = ops.attention_fwd(qkv.to(DEV), None if bias is None else bias.to(DEV), B, N, H, D, 0.125)
+    assert torch.isfinite(out.float()).all() and torch.isfinite(lse).all()
+    np.testing.assert_allclose(lse.cpu().numpy(), lse_ref.numpy(), rtol=2e-2, atol=2e-2)
+    err = (out.float().cpu().double() - o_ref).abs().max().item()
+    assert err < 3e-2, f"forward max err {err}"
+
+
 @pytest.mark.parametrize("mode", ["fp32", "bf16"])
 @pytest.mark.parametrize("N,with_bias", [(12, True), (16, True), (48, True), (64, True), (192, True), (256, True), (197, False), (198, False), (100, True), (37, True), (250, True)])
 def test_attention_forward_backward(mode, N, with_bias, B=3, H=4):
