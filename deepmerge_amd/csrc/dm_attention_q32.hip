@@ -61,7 +61,10 @@ extern "C" int dm_debug_q32_stamps(unsigned long long *out) { return (int)hipMem
 namespace dmq32 {
 
 constexpr int HD = 64;
-constexpr int ROWS = 128;                       // query rows per workgroup: 4 waves x 32
+// query rows per workgroup = 32 NW.  NW = 4: one wave per SIMD and up to 512 registers (what the bias instances need).  NW = 8 (no
+// bias, <= 7 key tiles: 8 waves x 240 registers, K / V for all rows of a (sample, head) staged once): two waves per SIMD -- a single
+// wave issues a VALU instruction every 4 cycles, two waves share the SIMD's full rate of one per 2, and one wave's MFMAs run under the
+// other's VALU work (the 4-wave form is ISSUE-bound: ~610 cycles of instruction issue per tile against 320 of the matrix pipe).
 constexpr int WB_PITCH = 144;                   // write-back staging: 128-byte row + 16 bytes (keeps rows 16-byte aligned)
 constexpr int WB_WAVE = 32 * WB_PITCH;
 constexpr float NEG_BIG = -1.0e30f;
@@ -70,32 +73,43 @@ constexpr float NEG_BIG = -1.0e30f;
 #define DMQ_MFMA "v_mfma_f32_32x32x16_bf16"
 // scores: D, C in VGPRs; A = K fragment (VGPR), B = Q^T fragment: an accumulator register (QA, the bias instances: their 128 bias
 // registers leave no room in the architectural file) or a VGPR
-template <bool QA> __device__ __forceinline__ void qk_first(f32x16 &d, const u32x4 &k, const u32x4 &q, const f32x16 &c) {
+// PAD (the 8-wave instances): under their 256-register budget hipcc parks values in accumulator registers and brings them back with
+// v_accvgpr_read directly in front of an asm MFMA that reads them (tools/isa_hazards.py found it) -- every MFMA there opens with
+// `s_nop 1`; with two waves per SIMD a wave's issue slots are not the limit.
+#define DMQ_PAD "s_nop 1\n\t"
+template <bool QA, bool PAD> __device__ __forceinline__ void qk_first(f32x16 &d, const u32x4 &k, const u32x4 &q, const f32x16 &c) {
   if constexpr (QA) asm volatile(DMQ_MFMA " %0, %1, %2, %3" : "=&v"(d) : "v"(k), "a"(q), "v"(c));
+  else if constexpr (PAD) asm volatile(DMQ_PAD DMQ_MFMA " %0, %1, %2, %3" : "=&v"(d) : "v"(k), "v"(q), "v"(c));
   else asm volatile(DMQ_MFMA " %0, %1, %2, %3" : "=&v"(d) : "v"(k), "v"(q), "v"(c));
 }
-template <bool QA> __device__ __forceinline__ void qk_first0(f32x16 &d, const u32x4 &k, const u32x4 &q) {
+template <bool QA, bool PAD> __device__ __forceinline__ void qk_first0(f32x16 &d, const u32x4 &k, const u32x4 &q) {
   if constexpr (QA) asm volatile(DMQ_MFMA " %0, %1, %2, 0" : "=&v"(d) : "v"(k), "a"(q));
+  else if constexpr (PAD) asm volatile(DMQ_PAD DMQ_MFMA " %0, %1, %2, 0" : "=&v"(d) : "v"(k), "v"(q));
   else asm volatile(DMQ_MFMA " %0, %1, %2, 0" : "=&v"(d) : "v"(k), "v"(q));
 }
-template <bool QA> __device__ __forceinline__ void qk_acc(f32x16 &d, const u32x4 &k, const u32x4 &q) {
+template <bool QA, bool PAD> __device__ __forceinline__ void qk_acc(f32x16 &d, const u32x4 &k, const u32x4 &q) {
   if constexpr (QA) asm volatile(DMQ_MFMA " %0, %1, %2, %0" : "+v"(d) : "v"(k), "a"(q));
+  else if constexpr (PAD) asm volatile(DMQ_PAD DMQ_MFMA " %0, %1, %2, %0" : "+v"(d) : "v"(k), "v"(q));
   else asm volatile(DMQ_MFMA " %0, %1, %2, %0" : "+v"(d) : "v"(k), "v"(q));
 }
 // O^T: C = D in accumulator registers; A = V^T fragment, B = packed P^T (both VGPRs).  PAD: an operand may come fresh from the VALU.
-__device__ __forceinline__ void pv_acc(f32x16 &o, const u32x4 &v, const u32x4 &pb) {
-  asm volatile(DMQ_MFMA " %0, %1, %2, %0" : "+a"(o) : "v"(v), "v"(pb));
+template <bool PAD> __device__ __forceinline__ void pv_acc(f32x16 &o, const u32x4 &v, const u32x4 &pb) {
+  if constexpr (PAD) asm volatile(DMQ_PAD DMQ_MFMA " %0, %1, %2, %0" : "+a"(o) : "v"(v), "v"(pb));
+  else asm volatile(DMQ_MFMA " %0, %1, %2, %0" : "+a"(o) : "v"(v), "v"(pb));
 }
 // row sums on the matrix pipe: A = ones, B = packed P^T -> every row of D holds, per query column, the sum over the k-step's 16 keys of
 // BOTH lane halves (what the P.V product sees, bf16-rounded); 2 MFMAs per tile replace 16 v_add_f32 per lane and the final exchange
-__device__ __forceinline__ void l_first(f32x16 &l, const u32x4 &ones, const u32x4 &pb) {
-  asm volatile(DMQ_MFMA " %0, %1, %2, 0" : "=&a"(l) : "v"(ones), "v"(pb));
+template <bool PAD> __device__ __forceinline__ void l_first(f32x16 &l, const u32x4 &ones, const u32x4 &pb) {
+  if constexpr (PAD) asm volatile(DMQ_PAD DMQ_MFMA " %0, %1, %2, 0" : "=&a"(l) : "v"(ones), "v"(pb));
+  else asm volatile(DMQ_MFMA " %0, %1, %2, 0" : "=&a"(l) : "v"(ones), "v"(pb));
 }
-__device__ __forceinline__ void l_acc(f32x16 &l, const u32x4 &ones, const u32x4 &pb) {
-  asm volatile(DMQ_MFMA " %0, %1, %2, %0" : "+a"(l) : "v"(ones), "v"(pb));
+template <bool PAD> __device__ __forceinline__ void l_acc(f32x16 &l, const u32x4 &ones, const u32x4 &pb) {
+  if constexpr (PAD) asm volatile(DMQ_PAD DMQ_MFMA " %0, %1, %2, %0" : "+a"(l) : "v"(ones), "v"(pb));
+  else asm volatile(DMQ_MFMA " %0, %1, %2, %0" : "+a"(l) : "v"(ones), "v"(pb));
 }
-__device__ __forceinline__ void pv_first(f32x16 &o, const u32x4 &v, const u32x4 &pb) {
-  asm volatile(DMQ_MFMA " %0, %1, %2, 0" : "=&a"(o) : "v"(v), "v"(pb));
+template <bool PAD> __device__ __forceinline__ void pv_first(f32x16 &o, const u32x4 &v, const u32x4 &pb) {
+  if constexpr (PAD) asm volatile(DMQ_PAD DMQ_MFMA " %0, %1, %2, 0" : "=&a"(o) : "v"(v), "v"(pb));
+  else asm volatile(DMQ_MFMA " %0, %1, %2, 0" : "=&a"(o) : "v"(v), "v"(pb));
 }
 // A 128-bit value parked in accumulator registers: the "+a" operand makes hipcc copy it into ONE contiguous a[n:n+3] tuple here
 // (four v_accvgpr_write of its own, padded by itself), and from here on the value lives in that class -- the "a" operands of the
@@ -144,8 +158,9 @@ __device__ __forceinline__ bool coords(int nblk, int H, int chunks, int &h, int 
 inline int grid_size(int nblk, int H, int chunks) { return (H * chunks + 7) / 8 * 8 * nblk; }
 
 // NKT: 32-key tiles; RAGGED: N < 32 NKT (keys >= N are zero-filled by the DMA descriptor and masked); BIAS: p.bias != NULL.
-template <int NKT, bool RAGGED, bool BIAS>
-__global__ __launch_bounds__(256, 1) void attn_fwd_q32_kernel(const AttnPipeParams p, int bchunk, int nblk, int chunks) {
+template <int NKT, bool RAGGED, bool BIAS, int NW>
+__global__ __launch_bounds__(64 * NW, NW / 4) void attn_fwd_q32_kernel(const AttnPipeParams p, int bchunk, int nblk, int chunks) {
+  constexpr int ROWS = 32 * NW;
   constexpr int NP = NKT * 32;
   const int N = RAGGED ? p.N : NP;
   constexpr int IMG = NP * 128;
@@ -229,20 +244,21 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_q32_kernel(const AttnPipePara
     asm volatile("s_nop 4" : "+s"(rs));                             // v_readfirstlane -> descriptor read by a buffer instruction: 5 wait states, paid here once
     return rs;
   };
-  // `part` (0..3): instructions j = part, part + 4, ... of this wave's NKT (the early tiles of the previous sample issue one part each)
-  auto stage_part = [&](const i32x4 &rs, int buf, int part) {
+  // The staging is done by waves 0..3 whatever NW is: instruction inst = wave + 4 j covers keys 8 inst .. 8 inst + 7, j < NKT.  In the
+  // 8-wave form the older wave of each SIMD wins the issue arbitration and otherwise waits ~1900 cycles per sample at the barrier for
+  // its partner (stamps): the DMA issue (~100 cycles a piece) goes where that slack is.
+  const bool dma_wave = wave < 4;
+  auto stage_piece = [&](const i32x4 &rs, int buf, int j) {
+    if ((DMQ_ABL & 2) || !dma_wave) return;
     const unsigned kimg = lds0 + (unsigned)(buf * (2 * IMG)) + (unsigned)wave * 1024u, vimg = kimg + (unsigned)IMG;
-    if (DMQ_ABL & 2) return;
-#pragma unroll
-    for (int j = part; j < NKT; j += 4) {                           // instruction inst = wave + 4 j: keys 8 inst .. 8 inst + 7
-      lds_dma(rs, kimg + (unsigned)j * 4096u, voffK, (unsigned)j * step_bytes);
-      lds_dma(rs, vimg + (unsigned)j * 4096u, voffV, (unsigned)j * step_bytes);
-    }
+    lds_dma(rs, kimg + (unsigned)j * 4096u, voffK, (unsigned)j * step_bytes);
+    lds_dma(rs, vimg + (unsigned)j * 4096u, voffV, (unsigned)j * step_bytes);
   };
   auto stage_all = [&](int b, int buf) {
+    if (!dma_wave) return;
     const i32x4 rs = sample_rsrc(b);
 #pragma unroll
-    for (int part = 0; part < 4; ++part) stage_part(rs, buf, part);
+    for (int j = 0; j < NKT; ++j) stage_piece(rs, buf, j);
   };
   // Q^T fragments (B operand): lane (query r, half hh) holds d = 16 ks + 8 hh .. + 7 of its row for k-step ks
   auto load_q = [&](int b, u32x4 (&f)[4]) {
@@ -262,27 +278,34 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_q32_kernel(const AttnPipePara
 #pragma unroll
   for (int dt = 0; dt < 2; ++dt) voff[dt] = (4 * hh + qd) * 128 + ((dt ^ ((qd >> 1) & 1)) << 6) + ve * 32 + pp * 8;   // + (32 kt + 16 s + 8 j2) * 128
 
-  char *wb = smem + 4 * IMG + wave * WB_WAVE;
+  char *wb = smem + 4 * IMG + wave * WB_WAVE;                       // (NW blocks behind the four images)
   float lse_prev = 0.f;
   // results of sample b sit in the wave's LDS block (bf16 rows) until the top of the next iteration: lane L stores the 16-byte
   // chunk L & 7 of rows (L >> 3) + 8 k, i.e. every store instruction covers eight whole 128-byte rows
   // part k (0..3): rows rr + 8 k of the wave's block (one LDS read + one store per lane); the parts are spread over the first tiles
   // of the next sample: four stores issued together at its top queue behind the other waves' (the store path, not the bytes)
-  auto flush_part = [&](int b, int k) {
+  // (read and store sit several MFMA gaps apart: the store then waits for ITS LDS read only, not for the fragment reads behind it)
+  u32x4 fl_v = {0u, 0u, 0u, 0u};
+  auto flush_read = [&](int k) {
+    if (!wave_live || (DMQ_ABL & 32)) return;
+    fl_v = *reinterpret_cast<const u32x4 *>(wb + ((lane >> 3) + 8 * k) * WB_PITCH + (lane & 7) * 16);
+  };
+  auto flush_store = [&](int b, int k) {
     if (!wave_live || (DMQ_ABL & 32)) return;
     bf16_t *orow0 = reinterpret_cast<bf16_t *>(p.out) + ((long long)b * N + q_wave) * H * HD + (long long)h * HD;
     const int rr = lane >> 3, cc = lane & 7;
-    const u32x4 v = *reinterpret_cast<const u32x4 *>(wb + (rr + 8 * k) * WB_PITCH + cc * 16);
-    if (q_wave + rr + 8 * k < N) *reinterpret_cast<u32x4 *>(orow0 + (long long)(rr + 8 * k) * H * HD + cc * 8) = v;
+    if (q_wave + rr + 8 * k < N) *reinterpret_cast<u32x4 *>(orow0 + (long long)(rr + 8 * k) * H * HD + cc * 8) = fl_v;
     if (k == 0 && hh == 0 && row_ok) p.lse[((long long)b * H + h) * N + q] = lse_prev;
   };
   auto flush = [&](int b) {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) flush_part(b, k);
+    for (int k = 0; k < 4; ++k) { flush_read(k); flush_store(b, k); }
   };
 
   constexpr float RESCALE_LOG2 = 16.f;                              // a later tile may exceed the reference maximum by 2^16 before l / O are rescaled
   constexpr bool QA = BIAS;                                         // Q^T fragments in accumulator registers
+  constexpr bool PAD = NW == 8;
+  static_assert(!(BIAS && NW == 8), "the bias rows need the 512-register budget of one wave per SIMD");
   u32x4 qf[4], qld[4];                                              // qld: the next sample's rows, requested late in this sample
   stage_all(b0, 0);
   load_q(b0, qld);
@@ -333,11 +356,11 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_q32_kernel(const AttnPipePara
       auto qk_piece = [&](int kt, int ks, f32x16 &d) {
         if ((DMQ_ABL & 16) && kt > 0) return;
         if (ks == 0) {
-          if constexpr (BIAS) qk_first<QA>(d, kf[0], qf[0], cinit[kt]);
-          else if (RAGGED && kt == NKT - 1) qk_first<QA>(d, kf[0], qf[0], cinit[0]);
-          else qk_first0<QA>(d, kf[0], qf[0]);
+          if constexpr (BIAS) qk_first<QA, PAD>(d, kf[0], qf[0], cinit[kt]);
+          else if (RAGGED && kt == NKT - 1) qk_first<QA, PAD>(d, kf[0], qf[0], cinit[0]);
+          else qk_first0<QA, PAD>(d, kf[0], qf[0]);
         } else {
-          qk_acc<QA>(d, kf[ks], qf[ks]);
+          qk_acc<QA, PAD>(d, kf[ks], qf[ks]);
         }
       };
       // piece g (0..3) of tile kt's P.V: (k-step, d tile) = (g >> 1, g & 1); packed P of a k-step may come fresh from the VALU
@@ -345,13 +368,13 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_q32_kernel(const AttnPipePara
         const int sx = g >> 1, dt = g & 1;
         f32x16 &o = dt ? o1 : o0;
         if ((DMQ_ABL & 8) && kt > 0) return;
-        if (kt == 0 && sx == 0) pv_first(o, vfrag(0, dt), pb[0]);
-        else pv_acc(o, vfrag(sx, dt), pb[sx]);
+        if (kt == 0 && sx == 0) pv_first<PAD>(o, vfrag(0, dt), pb[0]);
+        else pv_acc<PAD>(o, vfrag(sx, dt), pb[sx]);
       };
       auto l_piece = [&](int kt, int sx, const u32x4 (&pb)[2]) {
         if ((DMQ_ABL & 8) && kt > 0) return;
-        if (kt == 0 && sx == 0) l_first(la, ones, pb[0]);
-        else l_acc(la, ones, pb[sx]);
+        if (kt == 0 && sx == 0) l_first<PAD>(la, ones, pb[0]);
+        else l_acc<PAD>(la, ones, pb[sx]);
       };
       // ---- the VALU work of a tile as a three-stage pipeline over the MFMA gaps ---------------------------------------------------------
       // One wave per SIMD has nobody to cover a dependent VALU result's latency (tools/hip/mb_coissue.hip: fma, fma, exp, exp, cvt on
@@ -454,11 +477,16 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_q32_kernel(const AttnPipePara
           if (g == 4) {
             if (j + 2 < NKT) read_k(j + 2);
             if (QA && more && j == NKT - 2) load_q(b + 1, qld);      // bias instances: into the K fragment registers, free from here on
-            if (!QA && more && j == 1) load_q(b + 1, qld);           // next sample's Q rows (registers to spare without a bias)
+            if (!QA && more && j == 2) load_q(b + 1, qld);           // next sample's Q rows (registers to spare without a bias)
           }
-          if (g == 5) {
-            if (more && j < 4) stage_part(rs_next, buf ^ 1, j);      // next sample's K / V: a quarter of this wave's DMA per early tile
-            if (b > b0 && j < 4) flush_part(b - 1, j);               // previous sample's rows: a quarter per early tile
+          // previous sample's rows: a quarter per tile over the LAST four tiles, stored six gaps after its LDS read.  (The vector-memory
+          // instructions of a sample -- K / V pieces, Q rows, these stores -- are spread over its tiles: bunched into the first
+          // four they ran into the CU's ~11 B/clk memory path, +1200 cycles per sample in the 8-wave form.)
+          if (g == 1 && b > b0 && j >= NKT - 4) flush_read(j - (NKT - 4));
+          if (g == 7 && b > b0 && j >= NKT - 4) flush_store(b - 1, j - (NKT - 4));
+          if (g == 5 && more) {                                      // next sample's K / V: one (K, V) pair of pieces per tile, all before the last
+            if (j < NKT - 1) stage_piece(rs_next, buf ^ 1, j);
+            if (j == 0) stage_piece(rs_next, buf ^ 1, NKT - 1);
           }
           if (g < 4) {
             if (j + 1 < NKT) asm volatile("" :: "v"(kf[g]));
@@ -503,8 +531,8 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_q32_kernel(const AttnPipePara
   flush(b1 - 1);
 }
 
-inline void grid(int B, int N, int H, int &nblk, int &chunks, int &bchunk) {
-  nblk = (N + ROWS - 1) / ROWS;
+inline void grid(int B, int N, int H, int rows, int &nblk, int &chunks, int &bchunk) {
+  nblk = (N + rows - 1) / rows;
   chunks = 256 / (H * nblk);
   if (chunks < 1) chunks = 1;
   if (chunks > B) chunks = B;
@@ -512,21 +540,26 @@ inline void grid(int B, int N, int H, int &nblk, int &chunks, int &bchunk) {
   chunks = (B + bchunk - 1) / bchunk;
 }
 
-template <int NKT, bool RAGGED, bool BIAS> bool launch(const AttnPipeParams &p, hipStream_t s) {
-  constexpr int LDS = 4 * NKT * 32 * 128 + 4 * WB_WAVE;
-  static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void *>(attn_fwd_q32_kernel<NKT, RAGGED, BIAS>),
+template <int NKT, bool RAGGED, bool BIAS, int NW> bool launch(const AttnPipeParams &p, hipStream_t s) {
+  constexpr int LDS = 4 * NKT * 32 * 128 + NW * WB_WAVE;
+  static_assert(LDS <= 160 * 1024, "LDS budget");
+  static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void *>(attn_fwd_q32_kernel<NKT, RAGGED, BIAS, NW>),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS) == hipSuccess;
   if (!ok) return false;
   int nblk, chunks, bchunk;
-  grid(p.B, p.N, p.H, nblk, chunks, bchunk);
-  hipLaunchKernelGGL((attn_fwd_q32_kernel<NKT, RAGGED, BIAS>), dim3(grid_size(nblk, p.H, chunks)), dim3(256), LDS, s, p, bchunk, nblk, chunks);
+  grid(p.B, p.N, p.H, 32 * NW, nblk, chunks, bchunk);
+  hipLaunchKernelGGL((attn_fwd_q32_kernel<NKT, RAGGED, BIAS, NW>), dim3(grid_size(nblk, p.H, chunks)), dim3(64 * NW), LDS, s, p, bchunk, nblk, chunks);
   return true;
 }
 
 template <int NKT> bool launch_n(const AttnPipeParams &p, hipStream_t s) {
   const bool ragged = p.N != NKT * 32;
-  if (p.bias) return ragged ? launch<NKT, true, true>(p, s) : launch<NKT, false, true>(p, s);
-  return ragged ? launch<NKT, true, false>(p, s) : launch<NKT, false, false>(p, s);
+  if (p.bias) return ragged ? launch<NKT, true, true, 4>(p, s) : launch<NKT, false, true, 4>(p, s);
+  if constexpr (NKT <= 7) {                     // 8 waves: two per SIMD, K / V staged once per (sample, head); DM_ATTN_Q32_W8=0 for A/B runs
+    static const bool w8 = [] { const char *e = getenv("DM_ATTN_Q32_W8"); return !(e && atoi(e) == 0); }();
+    if (w8) return ragged ? launch<NKT, true, false, 8>(p, s) : launch<NKT, false, false, 8>(p, s);
+  }
+  return ragged ? launch<NKT, true, false, 4>(p, s) : launch<NKT, false, false, 4>(p, s);
 }
 
 }  // namespace dmq32
