@@ -56,7 +56,9 @@ class FeatureIO:
         sample point in FID order -- pixel position (or geo coordinates when `geotransform` is given: the reference's own
         conversion with its +1, MyUtils1.py:67-73), the `inner` / `object` window fields and the 15 designed attributes.  The
         per-point window arithmetic, crop, resize and patch-embed operand layout run on the device (patches.point_batch_cols);
-        returns / keeps F [P, 100] fp32, rows in point order, as the HDF5 `dataset` would hold them."""
+        returns / keeps F [P, 100] fp32, rows in point order, as the HDF5 `dataset` would hold them.
+        The band resize follows `self.resize` ("opencv" by default: cv2.resize(..., INTER_AREA) as MyUtils1.py:202-216 calls it, restated
+        branch by branch; set `FeatureIO.resize = "exact_area"` for the exact rational area average of earlier rounds)."""
         from .patches import geo_to_pixel, point_batch_cols
         import torch.distributed as dist
         if geotransform is not None:
@@ -91,7 +93,8 @@ class FeatureIO:
         feats = region_features.to(self.device)
         for s in range(0, P, batch_size):
             e = min(P, s + batch_size)
-            patches, designed = point_batch_cols(tile, xy[s:e], inner[s:e], obj[s:e], feats[s:e], scales=scales, grid=grid, dtype=dtype)
+            patches, designed = point_batch_cols(tile, xy[s:e], inner[s:e], obj[s:e], feats[s:e], scales=scales, grid=grid, dtype=dtype,
+                                                 resize=getattr(self, "resize", "opencv"))
             out[s:e] = self.net(patches, designed)
         self.features = out
         return out

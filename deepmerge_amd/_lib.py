@@ -85,8 +85,8 @@ SIGNATURES = {
     "dm_adam_step_dev": (_I, [_P, _P, _P, _P, _P, _L, _P, _D, _D, _D, _D, _P]),
     "dm_segment_mean": (_I, [_P, _P, _P, _P, _I, _I, _P]),
     "dm_edge_similarity": (_I, [_P, _P, _P, _P, _I, _I, _F, _P]),
-    "dm_patch_pyramid": (_I, [_P, _I, _I, _I, _P, _P, _I, _I, _I, _P, _P]),
-    "dm_patch_pyramid_cols": (_I, [_P, _I, _I, _I, _P, _P, _I, _I, _I, _I, _P, _I, _P]),
+    "dm_patch_pyramid": (_I, [_P, _I, _I, _I, _P, _P, _I, _I, _I, _I, _P, _P]),
+    "dm_patch_pyramid_cols": (_I, [_P, _I, _I, _I, _P, _P, _I, _I, _I, _I, _I, _P, _I, _P]),
     "dm_label_stats": (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
     "dm_label_features": (_I, [_P, _P, _P, _P, _P, _I, _I, _P, _P]),
     "dm_rag_edges": (_I, [_P, _I, _I, _I, _P, _P, _I, _P, _P, _I, _P, _P, _P]),
@@ -132,8 +132,8 @@ def lib() -> C.CDLL:
                 raise DeepMergeLibraryError(f"{LIB_PATH} does not export {name}") from e
             fn.restype = res
             fn.argtypes = args
-        if handle.dm_abi_version() != 1:
-            raise DeepMergeLibraryError(f"ABI version mismatch: library {handle.dm_abi_version()} != 1")
+        if handle.dm_abi_version() != 2:
+            raise DeepMergeLibraryError(f"ABI version mismatch: library {handle.dm_abi_version()} != 2")
         _lib = handle
         return _lib
 

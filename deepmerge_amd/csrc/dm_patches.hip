@@ -1,10 +1,12 @@
 // Multi-scale patch pyramid gather (gfx950): for every sample point, crop an L x L window of a uint8
-// multi-band tile (zero-padded outside the raster), resize it to t x t with an EXACT integer area average and
-// emit float32 in [0,1] -- the GPU counterpart of the per-item GDAL read + per-band cv2.resize that the
-// reference's data loaders run on one host thread (MyUtils1.py:116-223).  The resize rule is the build's own
-// spec (OpenCV parity is unpinned, see oracle/patches.py); it is integer arithmetic, so results are bit-exact
-// against the oracle.  HBM/L2-bound byte gather: the window is staged in LDS once, then each thread produces
-// output pixels from LDS.
+// multi-band tile (zero-padded outside the raster), resize it to t x t and emit float32 in [0,1] -- the GPU counterpart of
+// the per-item GDAL read + per-band cv2.resize(..., INTER_AREA) that the reference's data loaders run on one host thread
+// (MyUtils1.py:116-223).  Two resize rules (oracle/patches.py states both; the kernel is bit-exact against it for either):
+//   DM_RESIZE_OPENCV (default)  cv::resize's published INTER_AREA algorithm for uint8, branch by branch (integer-ratio fast path,
+//                               float area tables for other shrinks, 11-bit fixed-point bilinear with area coordinates when enlarging);
+//                               float32 operations in OpenCV's order with explicit roundings (this file is built with -ffp-contract=off)
+//   DM_RESIZE_EXACT_AREA        the exact rational area average (integer arithmetic), the rule of rounds 1-2
+// HBM/L2-bound byte gather: the window is staged in LDS once, then each thread produces output pixels from LDS.
 #include "dm_common.h"
 
 namespace {
@@ -18,10 +20,88 @@ constexpr int MAX_WINDOW = 384;   // L*L bytes of LDS (147 KB)
 // OUT = bf16_t / float with COLS: the patch-embed GEMM's operand rows directly -- row (p * G + py) * G + px, column
 // (c * ps + dy) * ps + dx with ps = T / G (the im2col order of Conv2d(k = ps, stride = ps), nets/ShfitScaleFormer.py:28-37) --
 // so the fp32 patch tensor and the separate im2col pass (dm_patchify) never exist.
+// ---- cv::resize(INTER_AREA), uint8, one output pixel (oy, ox) of a T x T image from the L x L window in LDS ---------------------------
+// computeResizeAreaTab's entries for destination index d: at most ceil(scale) + 2 (source index, float weight) pairs.
+struct AreaTab { int si0, n; float first, mid, last; bool has_first, has_last; int sx1, sx2; };
+__device__ __forceinline__ AreaTab area_tab(int d, int L, double scale) {
+  AreaTab t;
+  const double fsx1 = (double)d * scale, fsx2 = fsx1 + scale;
+  const double cell = fmin(scale, (double)L - fsx1);
+  int sx1 = (int)ceil(fsx1), sx2 = (int)floor(fsx2);
+  sx2 = min(sx2, L - 1);
+  sx1 = min(sx1, sx2);
+  t.sx1 = sx1; t.sx2 = sx2;
+  t.has_first = (double)sx1 - fsx1 > 1e-3;
+  t.first = (float)(((double)sx1 - fsx1) / cell);
+  t.mid = (float)(1.0 / cell);
+  t.has_last = fsx2 - (double)sx2 > 1e-3;
+  t.last = (float)(fmin(fmin(fsx2 - (double)sx2, 1.0), cell) / cell);
+  t.si0 = 0; t.n = 0;
+  return t;
+}
+__device__ __forceinline__ int cv_area_pixel(const unsigned char *win, int L, int T, int oy, int ox) {
+  if (L % T == 0) {                                             // is_area_fast: integer ratio k
+    const int k = L / T;
+    if (k == 1) return win[oy * L + ox];
+    int sum = 0;
+    for (int iy = 0; iy < k; ++iy)
+      for (int ix = 0; ix < k; ++ix) sum += win[(oy * k + iy) * L + ox * k + ix];
+    if (k == 2) return (sum + 2) >> 2;
+    const float scale = 1.f / (float)(k * k);
+    return min(255, max(0, __float2int_rn(__fmul_rn((float)sum, scale))));
+  }
+  const double inv_scale = (double)T / (double)L, scale = 1.0 / inv_scale;
+  if (L > T) {                                                  // area tables, float accumulation in table order
+    const AreaTab tx = area_tab(ox, L, scale), ty = area_tab(oy, L, scale);
+    auto fold_row = [&](int sy) {
+      const unsigned char *S = win + sy * L;
+      float buf = 0.f;
+      if (tx.has_first) buf = __fadd_rn(buf, __fmul_rn((float)S[tx.sx1 - 1], tx.first));
+      for (int sx = tx.sx1; sx < tx.sx2; ++sx) buf = __fadd_rn(buf, __fmul_rn((float)S[sx], tx.mid));
+      if (tx.has_last) buf = __fadd_rn(buf, __fmul_rn((float)S[tx.sx2], tx.last));
+      return buf;
+    };
+    float sum = 0.f;
+    bool first = true;
+    auto add_row = [&](int sy, float beta) {
+      const float term = __fmul_rn(beta, fold_row(sy));
+      sum = first ? term : __fadd_rn(sum, term);
+      first = false;
+    };
+    if (ty.has_first) add_row(ty.sx1 - 1, ty.first);
+    for (int sy = ty.sx1; sy < ty.sx2; ++sy) add_row(sy, ty.mid);
+    if (ty.has_last) add_row(ty.sx2, ty.last);
+    return min(255, max(0, __float2int_rn(sum)));
+  }
+  // enlarging: the bilinear code with area-style coordinates, INTER_RESIZE_COEF_BITS = 11
+  auto coeff = [&](int d, bool zero_at_border, int &s0, int &c0, int &c1, bool &inside) {
+    int sx = (int)floor((double)d * scale);
+    float fx = (float)((double)(d + 1) - (double)(sx + 1) * inv_scale);
+    fx = fx <= 0.f ? 0.f : __fsub_rn(fx, floorf(fx));
+    inside = sx + 1 < L;
+    if (!inside && zero_at_border && sx >= L - 1) { fx = 0.f; sx = L - 1; }
+    s0 = sx;
+    c0 = __float2int_rn(__fmul_rn(__fsub_rn(1.f, fx), 2048.f));
+    c1 = __float2int_rn(__fmul_rn(fx, 2048.f));
+  };
+  int sx, a0, a1, sy, b0, b1;
+  bool xin, yin;
+  coeff(ox, true, sx, a0, a1, xin);
+  coeff(oy, false, sy, b0, b1, yin);
+  const int r0 = min(sy, L - 1), r1 = min(sy + 1, L - 1);
+  auto hpass = [&](int row) {
+    const unsigned char *S = win + row * L;
+    return xin ? (int)S[sx] * a0 + (int)S[sx + 1] * a1 : (int)S[min(sx, L - 1)] * 2048;
+  };
+  const int h0 = hpass(r0), h1 = hpass(r1);
+  const int v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
+  return min(255, max(0, v));
+}
+
 template <int TLOG2, typename OUT, bool COLS>
 __global__ __launch_bounds__(256) void patch_pyramid_kernel(const unsigned char *__restrict__ tile, int bands, int H, int W,
                                                             const int *__restrict__ xy, const int *__restrict__ wins,
-                                                            int Trt, int G, OUT *__restrict__ out) {
+                                                            int Trt, int G, OUT *__restrict__ out, int rule) {
   extern __shared__ unsigned char win[];
   const int T = TLOG2 >= 0 ? (1 << TLOG2) : Trt;
   auto divT = [&](int v) { return TLOG2 >= 0 ? (v >> TLOG2) : v / T; };
@@ -48,6 +128,16 @@ __global__ __launch_bounds__(256) void patch_pyramid_kernel(const unsigned char 
   const long long Kc = (long long)bands * ps * ps;
   for (int o = t; o < T * T; o += 256) {
     const int oy = divT(o), ox = o - oy * T;
+    if (rule == DM_RESIZE_OPENCV) {
+      const float v = (float)cv_area_pixel(win, L, T, oy, ox) / 255.0f;
+      if constexpr (COLS) {
+        const int py = oy / ps, dy = oy - py * ps, px = ox / ps, dx = ox - px * ps;
+        dst[(((long long)p * G + py) * G + px) * Kc + ((long long)c * ps + dy) * ps + dx] = (OUT)v;
+      } else {
+        dst[o] = (OUT)v;
+      }
+      continue;
+    }
     const int ylo = oy * L, yhi = ylo + L, xlo = ox * L, xhi = xlo + L;       // footprints in 1/T input-pixel units
     const int iy0 = divT(ylo), iy1 = divT(yhi + T - 1), ix0 = divT(xlo), ix1 = divT(xhi + T - 1);
     int num = 0;
@@ -79,32 +169,35 @@ __global__ __launch_bounds__(256) void patch_pyramid_kernel(const unsigned char 
 namespace {
 template <typename OUT, bool COLS>
 void launch_pyramid(dim3 grid, size_t lds, hipStream_t s, const uint8_t *tile, int bands, int H, int W, const int32_t *xy, const int32_t *windows,
-                    int target, int G, OUT *out) {
+                    int target, int G, OUT *out, int rule) {
   switch (target) {
-    case 32: hipLaunchKernelGGL((patch_pyramid_kernel<5, OUT, COLS>), grid, dim3(256), lds, s, tile, bands, H, W, xy, windows, target, G, out); break;
-    case 64: hipLaunchKernelGGL((patch_pyramid_kernel<6, OUT, COLS>), grid, dim3(256), lds, s, tile, bands, H, W, xy, windows, target, G, out); break;
-    case 128: hipLaunchKernelGGL((patch_pyramid_kernel<7, OUT, COLS>), grid, dim3(256), lds, s, tile, bands, H, W, xy, windows, target, G, out); break;
-    case 256: hipLaunchKernelGGL((patch_pyramid_kernel<8, OUT, COLS>), grid, dim3(256), lds, s, tile, bands, H, W, xy, windows, target, G, out); break;
-    default: hipLaunchKernelGGL((patch_pyramid_kernel<-1, OUT, COLS>), grid, dim3(256), lds, s, tile, bands, H, W, xy, windows, target, G, out); break;
+    case 32: hipLaunchKernelGGL((patch_pyramid_kernel<5, OUT, COLS>), grid, dim3(256), lds, s, tile, bands, H, W, xy, windows, target, G, out, rule); break;
+    case 64: hipLaunchKernelGGL((patch_pyramid_kernel<6, OUT, COLS>), grid, dim3(256), lds, s, tile, bands, H, W, xy, windows, target, G, out, rule); break;
+    case 128: hipLaunchKernelGGL((patch_pyramid_kernel<7, OUT, COLS>), grid, dim3(256), lds, s, tile, bands, H, W, xy, windows, target, G, out, rule); break;
+    case 256: hipLaunchKernelGGL((patch_pyramid_kernel<8, OUT, COLS>), grid, dim3(256), lds, s, tile, bands, H, W, xy, windows, target, G, out, rule); break;
+    default: hipLaunchKernelGGL((patch_pyramid_kernel<-1, OUT, COLS>), grid, dim3(256), lds, s, tile, bands, H, W, xy, windows, target, G, out, rule); break;
   }
 }
 }  // namespace
 
 extern "C" int dm_patch_pyramid(const uint8_t *tile, int32_t bands, int32_t H, int32_t W, const int32_t *xy, const int32_t *windows,
-                                int32_t max_window, int32_t P, int32_t target, float *out, void *stream) {
+                                int32_t max_window, int32_t P, int32_t target, int32_t resize_rule, float *out, void *stream) {
+  DM_REQUIRE(resize_rule == DM_RESIZE_OPENCV || resize_rule == DM_RESIZE_EXACT_AREA, DM_ERR_UNSUPPORTED, "dm_patch_pyramid: unknown resize rule %d", resize_rule);
   DM_REQUIRE(tile && xy && windows && out && bands > 0 && H > 0 && W > 0 && P > 0 && target > 0, DM_ERR_BAD_SHAPE,
              "dm_patch_pyramid: bad arguments");
   DM_REQUIRE(max_window > 0 && max_window <= MAX_WINDOW, DM_ERR_UNSUPPORTED,
              "dm_patch_pyramid: window side %d outside 1..%d", max_window, MAX_WINDOW);
   DM_REQUIRE(bands <= 65535, DM_ERR_BAD_SHAPE, "dm_patch_pyramid: too many bands");
   launch_pyramid<float, false>(dim3(P, bands), (size_t)max_window * max_window, reinterpret_cast<hipStream_t>(stream), tile, bands, H, W, xy, windows,
-                               target, 1, out);
+                               target, 1, out, resize_rule);
   DM_LAUNCH_CHECK("dm_patch_pyramid");
   return DM_OK;
 }
 
 extern "C" int dm_patch_pyramid_cols(const uint8_t *tile, int32_t bands, int32_t H, int32_t W, const int32_t *xy, const int32_t *windows,
-                                     int32_t max_window, int32_t P, int32_t target, int32_t grid, void *cols, int32_t dtype, void *stream) {
+                                     int32_t max_window, int32_t P, int32_t target, int32_t grid, int32_t resize_rule, void *cols, int32_t dtype,
+                                     void *stream) {
+  DM_REQUIRE(resize_rule == DM_RESIZE_OPENCV || resize_rule == DM_RESIZE_EXACT_AREA, DM_ERR_UNSUPPORTED, "dm_patch_pyramid_cols: unknown resize rule %d", resize_rule);
   DM_REQUIRE(tile && xy && windows && cols && bands > 0 && H > 0 && W > 0 && P > 0 && target > 0, DM_ERR_BAD_SHAPE,
              "dm_patch_pyramid_cols: bad arguments");
   DM_REQUIRE(grid > 0 && target % grid == 0, DM_ERR_BAD_SHAPE, "dm_patch_pyramid_cols: target %d is not a multiple of the token grid %d", target, grid);
@@ -114,8 +207,8 @@ extern "C" int dm_patch_pyramid_cols(const uint8_t *tile, int32_t bands, int32_t
   const dim3 g(P, bands);
   const size_t lds = (size_t)max_window * max_window;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  if (dtype == DM_BF16) launch_pyramid<bf16_t, true>(g, lds, s, tile, bands, H, W, xy, windows, target, grid, reinterpret_cast<bf16_t *>(cols));
-  else if (dtype == DM_F32) launch_pyramid<float, true>(g, lds, s, tile, bands, H, W, xy, windows, target, grid, reinterpret_cast<float *>(cols));
+  if (dtype == DM_BF16) launch_pyramid<bf16_t, true>(g, lds, s, tile, bands, H, W, xy, windows, target, grid, reinterpret_cast<bf16_t *>(cols), resize_rule);
+  else if (dtype == DM_F32) launch_pyramid<float, true>(g, lds, s, tile, bands, H, W, xy, windows, target, grid, reinterpret_cast<float *>(cols), resize_rule);
   else DM_REQUIRE(false, DM_ERR_BAD_DTYPE, "dm_patch_pyramid_cols: bad dtype %d", dtype);
   DM_LAUNCH_CHECK("dm_patch_pyramid_cols");
   return DM_OK;

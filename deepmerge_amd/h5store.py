@@ -8,7 +8,11 @@ the "earliest" layout h5py / libhdf5 emit by default for such a file and the one
     H5FeatureReader(path)                 .shape, [i] -> row, .rows(a, b) -> [b-a, width]
 
 One 2-D little-endian IEEE float32 dataset named "dataset", dimension 0 unlimited (max dims (UNLIMITED, width)), chunked
-(chunk_rows x width), no filters, fill value undefined / incremental allocation.  The chunk index is a single leaf node for up
+(chunk_rows x width by default), no filters, fill value undefined / incremental allocation.  The READER takes any 2-D chunk grid
+(chunk_rows x chunk_cols with chunk_cols <= width -- what h5py's `chunks=True` guess produces for [P, 100] float32: both dimensions
+halved until the chunk is small, e.g. (128, 25)), every chunk stored whole as the format requires, follows object-header continuation
+blocks (message 0x0010) and skips NIL / unknown messages; the writer can produce such files too (`chunk_cols=`, `split_header=True`),
+which is what the reader's tests are built from (no h5py-written fixture can be produced here).  The chunk index is a single leaf node for up
 to 64 chunks and a two-level tree above (default indexed-storage K = 32).  The file is rewritten index-last on close(), so an
 interrupted run leaves no half-valid index.
 
@@ -43,10 +47,19 @@ def _object_header(messages: List[bytes]) -> bytes:
 
 
 class H5FeatureWriter:
-    def __init__(self, path: str, width: int = 100, chunk_rows: int = 1024, name: str = "dataset"):
+    def __init__(self, path: str, width: int = 100, chunk_rows: int = 1024, name: str = "dataset", chunk_cols: int = 0,
+                 split_header: bool = False):
+        """chunk_cols: columns per chunk (0 = the full width, one chunk per row band).  split_header: put the layout message into an
+        object-header continuation block behind the data (with a NIL message in front of the continuation message and a
+        modification-time message beside the layout), the way libhdf5 lays a header out once it has outgrown its first block."""
         if width <= 0 or chunk_rows <= 0:
             raise ValueError("width and chunk_rows must be positive")
         self.path, self.width, self.chunk_rows, self.name = path, int(width), int(chunk_rows), name
+        self.chunk_cols = int(chunk_cols) if chunk_cols else int(width)
+        if not 0 < self.chunk_cols <= self.width:
+            raise ValueError("chunk_cols must be in 1..width")
+        self.col_chunks = (self.width + self.chunk_cols - 1) // self.chunk_cols
+        self.split_header = bool(split_header)
         self.f = open(path, "wb")
         self.rows = 0
         self._tail = np.zeros((0, self.width), np.float32)      # rows of the last, partially filled chunk
@@ -65,21 +78,35 @@ class H5FeatureWriter:
         self.dset_header_size = len(self._dataset_header(0, 0))
         self.addr_data = (self.addr_dset + self.dset_header_size + 7) // 8 * 8
         self.f.write(b"\0" * self.addr_data)
-        self.chunk_bytes = self.chunk_rows * self.width * 4
+        self.chunk_bytes = self.chunk_rows * self.chunk_cols * 4
 
     # ---- metadata pieces -----------------------------------------------------------------------------------------------
-    def _dataset_header(self, rows: int, index_addr: int) -> bytes:
+    def _layout_message(self, index_addr: int) -> bytes:
+        layout = struct.pack("<BBB", 3, 2, 3) + struct.pack("<Q", index_addr) + struct.pack("<III", self.chunk_rows, self.chunk_cols, 4)
+        return _message(0x0008, layout)
+
+    def _continuation_block(self, index_addr: int) -> bytes:
+        mtime = _message(0x0012, struct.pack("<B3xI", 1, 0))        # modification time, version 1, seconds since the epoch
+        return self._layout_message(index_addr) + mtime
+
+    def _dataset_header(self, rows: int, index_addr: int, cont_addr: int = 0) -> bytes:
         dataspace = struct.pack("<BBB5x", 1, 2, 1) + struct.pack("<QQ", rows, self.width) + struct.pack("<QQ", UNDEF, self.width)
         # IEEE binary32, little-endian: class 1 (floating point), version 1; bit field: LE, no padding, mantissa normalisation 2
         # (implied leading one), sign at bit 31; properties: bit offset 0, precision 32, exponent at 23 (8 bits), mantissa at 0
         # (23 bits), bias 127
         datatype = struct.pack("<BBBBI", 0x11, 0x20, 0x1F, 0x00, 4) + struct.pack("<HHBBBBI", 0, 32, 23, 8, 0, 23, 127)
         fill = struct.pack("<BBBB", 2, 3, 0, 0)                 # version 2, incremental allocation, fill written on allocation, undefined value
-        layout = struct.pack("<BBB", 3, 2, 3) + struct.pack("<Q", index_addr) + struct.pack("<III", self.chunk_rows, self.width, 4)
-        return _object_header([_message(0x0001, dataspace), _message(0x0003, datatype, 1), _message(0x0005, fill), _message(0x0008, layout)])
+        head = [_message(0x0001, dataspace), _message(0x0003, datatype, 1), _message(0x0005, fill)]
+        if not self.split_header:
+            return _object_header(head + [self._layout_message(index_addr)])
+        cont = _message(0x0010, struct.pack("<QQ", cont_addr, len(self._continuation_block(0))))
+        body = b"".join(head + [_message(0x0000, b"\0" * 8), cont])
+        # the message count of a version-1 header covers the continuation blocks too (+ layout, + modification time)
+        return struct.pack("<BBHII4x", 1, 0, len(head) + 2 + 2, 1, len(body)) + body
 
     def _chunk_key(self, i: int, size: int) -> bytes:
-        return struct.pack("<II", size, 0) + struct.pack("<QQQ", i * self.chunk_rows, 0, 0)
+        """Key of chunk number i in row-major order of the chunk grid: byte size, filter mask, element offsets (row, column, 0)."""
+        return struct.pack("<II", size, 0) + struct.pack("<QQQ", (i // self.col_chunks) * self.chunk_rows, (i % self.col_chunks) * self.chunk_cols, 0)
 
     def _chunk_node(self, level: int, entries: List[Tuple[int, int]], last_row_chunk: int) -> bytes:
         """entries: (first chunk index, child address).  A node is allocated at full size (2K entries) as libhdf5 does."""
@@ -99,20 +126,30 @@ class H5FeatureWriter:
         buf = np.concatenate([self._tail, a]) if self._tail.shape[0] else a
         n_full = buf.shape[0] // self.chunk_rows
         for c in range(n_full):
-            self._chunks.append(self.f.tell())
-            self.f.write(buf[c * self.chunk_rows:(c + 1) * self.chunk_rows].astype("<f4").tobytes())
+            self._write_band(buf[c * self.chunk_rows:(c + 1) * self.chunk_rows])
         self._tail = buf[n_full * self.chunk_rows:].copy()
+
+    def _write_band(self, band: np.ndarray) -> None:
+        """One band of chunk_rows rows as its column chunks, each stored whole (edge chunks padded, as the format requires)."""
+        for cc in range(self.col_chunks):
+            piece = np.zeros((self.chunk_rows, self.chunk_cols), "<f4")
+            cols = band[:, cc * self.chunk_cols:(cc + 1) * self.chunk_cols]
+            piece[:cols.shape[0], :cols.shape[1]] = cols
+            self._chunks.append(self.f.tell())
+            self.f.write(piece.tobytes())
 
     def close(self) -> None:
         if self.f is None:
             return
         f = self.f
         chunks = list(self._chunks)
-        if self._tail.shape[0]:                                   # the last chunk is stored whole; rows past `rows` are never read
-            chunks.append(f.tell())
-            pad = np.zeros((self.chunk_rows, self.width), "<f4")
-            pad[:self._tail.shape[0]] = self._tail
-            f.write(pad.tobytes())
+        if self._tail.shape[0]:                                   # the last band is stored whole; rows past `rows` are never read
+            self._write_band(self._tail)
+            chunks = list(self._chunks)
+        cont_addr = 0
+        if self.split_header:
+            cont_addr = f.tell()
+            f.write(b"\0" * len(self._continuation_block(0)))      # patched once the index address is known
         n = len(chunks)
         index_addr = UNDEF
         if n:
@@ -152,9 +189,12 @@ class H5FeatureWriter:
         f.seek(self.addr_snod)
         snod = b"SNOD" + struct.pack("<BBH", 1, 0, 1) + struct.pack("<QQII16x", name_off, self.addr_dset, 0, 0)
         f.write(snod + b"\0" * (self.snod_size - len(snod)))
-        hdr = self._dataset_header(self.rows, index_addr)
+        hdr = self._dataset_header(self.rows, index_addr, cont_addr)
         assert len(hdr) == self.dset_header_size
         f.write(hdr)
+        if self.split_header:
+            f.seek(cont_addr)
+            f.write(self._continuation_block(index_addr))
         f.close()
         self.f = None
 
@@ -254,18 +294,19 @@ class H5FeatureReader:
         ndim = lay[2]
         index = struct.unpack("<Q", lay[3:11])[0]
         cdims = struct.unpack("<" + "I" * ndim, lay[11:11 + 4 * ndim])
-        if ndim != 3 or cdims[2] != 4 or cdims[1] != dims[1]:
+        if ndim != 3 or cdims[2] != 4 or not (0 < cdims[1] <= dims[1]) or cdims[0] == 0:
             raise ValueError(f"unsupported chunk shape {cdims}")
         self.shape = (int(dims[0]), int(dims[1]))
         self.maxshape = (None if maxdims[0] == UNDEF else int(maxdims[0]), int(maxdims[1]))
-        self.chunk_rows = int(cdims[0])
+        self.chunk_rows, self.chunk_cols = int(cdims[0]), int(cdims[1])
         self.info.update(datatype_version=ver_dt, fill=tuple(msgs[0x0005][:4]) if 0x0005 in msgs else None, chunk_dims=cdims, index=index)
         # chunk index
         self.chunks = {}
         if index != UNDEF:
             self._walk_chunks(index)
         need = (self.shape[0] + self.chunk_rows - 1) // self.chunk_rows
-        missing = [c for c in range(need) if c * self.chunk_rows not in self.chunks]
+        ncol = (self.shape[1] + self.chunk_cols - 1) // self.chunk_cols
+        missing = [(r, c) for r in range(need) for c in range(ncol) if (r * self.chunk_rows, c * self.chunk_cols) not in self.chunks]
         if missing:
             raise ValueError(f"chunks missing from the index: {missing[:5]}")
 
@@ -274,15 +315,30 @@ class H5FeatureReader:
         return struct.unpack("<QQ", m[0x0011][:16])
 
     def _messages(self, addr: int) -> dict:
+        """Messages of a version-1 object header by type, continuation blocks (0x0010: address, length) included; the header's message
+        count covers all blocks.  NIL messages (0x0000) are padding."""
         ver, _r, nmsg, _ref, size = struct.unpack("<BBHII", self._at(addr, 12))
         if ver != 1:
             raise ValueError("expected a version-1 object header")
-        body = self._at(addr + 16, size)
-        out, off = {}, 0
-        for _ in range(nmsg):
-            mtype, msize, _flags = struct.unpack("<HHB", body[off:off + 5])
-            out[mtype] = body[off + 8:off + 8 + msize]
-            off += 8 + msize
+        blocks = [(addr + 16, size)]
+        out, seen = {}, 0
+        while blocks and seen < nmsg:
+            baddr, bsize = blocks.pop(0)
+            body = self._at(baddr, bsize)
+            off = 0
+            while off + 8 <= len(body) and seen < nmsg:
+                mtype, msize, _flags = struct.unpack("<HHB", body[off:off + 5])
+                data = body[off + 8:off + 8 + msize]
+                if len(data) != msize:
+                    raise ValueError("object header message runs past its block")
+                if mtype == 0x0010:
+                    blocks.append(struct.unpack("<QQ", data[:16]))
+                elif mtype != 0x0000:
+                    out[mtype] = data
+                seen += 1
+                off += 8 + msize
+        if seen != nmsg:
+            raise ValueError(f"object header announces {nmsg} messages, found {seen}")
         return out
 
     def _walk_chunks(self, node: int) -> None:
@@ -299,9 +355,9 @@ class H5FeatureReader:
             if level > 0:
                 self._walk_chunks(child)
             else:
-                if mask != 0 or c0 != 0 or size != self.chunk_rows * self.shape[1] * 4:
-                    raise ValueError("filtered / partial chunks are not supported")
-                self.chunks[int(r0)] = child
+                if mask != 0 or size != self.chunk_rows * self.chunk_cols * 4 or r0 % self.chunk_rows or c0 % self.chunk_cols:
+                    raise ValueError("filtered / partial / misaligned chunks are not supported")
+                self.chunks[(int(r0), int(c0))] = child
 
     def rows(self, a: int, b: int) -> np.ndarray:
         if not (0 <= a <= b <= self.shape[0]):
@@ -309,10 +365,12 @@ class H5FeatureReader:
         out = np.empty((b - a, self.shape[1]), np.float32)
         r = a
         while r < b:
-            c0 = r // self.chunk_rows * self.chunk_rows
-            n = min(b, c0 + self.chunk_rows) - r
-            raw = self._at(self.chunks[c0] + (r - c0) * self.shape[1] * 4, n * self.shape[1] * 4)
-            out[r - a:r - a + n] = np.frombuffer(raw, "<f4").reshape(n, self.shape[1])
+            r0 = r // self.chunk_rows * self.chunk_rows
+            n = min(b, r0 + self.chunk_rows) - r
+            for c0 in range(0, self.shape[1], self.chunk_cols):      # the band's column chunks; the last one may hang over the width
+                w = min(self.chunk_cols, self.shape[1] - c0)
+                raw = self._at(self.chunks[(r0, c0)] + (r - r0) * self.chunk_cols * 4, n * self.chunk_cols * 4)
+                out[r - a:r - a + n, c0:c0 + w] = np.frombuffer(raw, "<f4").reshape(n, self.chunk_cols)[:, :w]
             r += n
         return out
 

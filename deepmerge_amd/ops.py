@@ -371,8 +371,20 @@ def patchify(x: torch.Tensor, patch: int, dtype: torch.dtype) -> torch.Tensor:
     return cols
 
 
-def patch_pyramid(tile: torch.Tensor, xy: torch.Tensor, windows: torch.Tensor, target: int, max_window: Optional[int] = None) -> torch.Tensor:
-    """One scale of the patch pyramid: tile uint8 [bands,H,W], xy int32 [P,2], windows int32 [P] -> float32 [P,bands,t,t]."""
+RESIZE_RULES = {"opencv": 0, "exact_area": 1}      # DM_RESIZE_OPENCV / DM_RESIZE_EXACT_AREA (include/deepmerge_hip.h)
+
+
+def _resize_rule(resize: str) -> int:
+    if resize not in RESIZE_RULES:
+        raise ValueError(f"resize must be one of {tuple(RESIZE_RULES)}, got {resize!r}")
+    return RESIZE_RULES[resize]
+
+
+def patch_pyramid(tile: torch.Tensor, xy: torch.Tensor, windows: torch.Tensor, target: int, max_window: Optional[int] = None,
+                  resize: str = "opencv") -> torch.Tensor:
+    """One scale of the patch pyramid: tile uint8 [bands,H,W], xy int32 [P,2], windows int32 [P] -> float32 [P,bands,t,t].
+    resize: "opencv" = cv2.resize(..., INTER_AREA) as the reference calls it (MyUtils1.py:202-216), restated branch by branch;
+    "exact_area" = the exact rational area average (oracle/patches.py states both)."""
     _need_cuda(tile, xy, windows)
     if tile.dtype != torch.uint8:
         raise ValueError("tile must be uint8")
@@ -382,8 +394,8 @@ def patch_pyramid(tile: torch.Tensor, xy: torch.Tensor, windows: torch.Tensor, t
         max_window = int(windows.max().item())
     out = torch.empty((P, bands, target, target), dtype=torch.float32, device=tile.device)
     check(_lib.lib().dm_patch_pyramid(tile.contiguous().data_ptr(), bands, H, W, xy.to(torch.int32).contiguous().data_ptr(),
-                                      windows.to(torch.int32).contiguous().data_ptr(), max_window, P, target, out.data_ptr(), _stream()),
-          "dm_patch_pyramid")
+                                      windows.to(torch.int32).contiguous().data_ptr(), max_window, P, target, _resize_rule(resize),
+                                      out.data_ptr(), _stream()), "dm_patch_pyramid")
     return out
 
 
@@ -411,8 +423,8 @@ class PatchCols:
 
 
 def patch_pyramid_cols(tile: torch.Tensor, xy: torch.Tensor, windows: torch.Tensor, target: int, grid: int = 8,
-                       dtype: torch.dtype = torch.bfloat16, max_window: Optional[int] = None) -> PatchCols:
-    """One scale of the patch pyramid as patch-embed GEMM rows (dm_patch_pyramid_cols)."""
+                       dtype: torch.dtype = torch.bfloat16, max_window: Optional[int] = None, resize: str = "opencv") -> PatchCols:
+    """One scale of the patch pyramid as patch-embed GEMM rows (dm_patch_pyramid_cols); `resize` as in `patch_pyramid`."""
     _need_cuda(tile, xy, windows)
     if tile.dtype != torch.uint8:
         raise ValueError("tile must be uint8")
@@ -425,8 +437,8 @@ def patch_pyramid_cols(tile: torch.Tensor, xy: torch.Tensor, windows: torch.Tens
         max_window = int(windows.max().item())
     cols = torch.empty((P * grid * grid, bands * ps * ps), dtype=dtype, device=tile.device)
     check(_lib.lib().dm_patch_pyramid_cols(tile.contiguous().data_ptr(), bands, H, W, xy.to(torch.int32).contiguous().data_ptr(),
-                                           windows.to(torch.int32).contiguous().data_ptr(), max_window, P, target, grid, cols.data_ptr(),
-                                           _dt(cols), _stream()), "dm_patch_pyramid_cols")
+                                           windows.to(torch.int32).contiguous().data_ptr(), max_window, P, target, grid, _resize_rule(resize),
+                                           cols.data_ptr(), _dt(cols), _stream()), "dm_patch_pyramid_cols")
     return PatchCols(cols, P, target, ps, bands)
 
 

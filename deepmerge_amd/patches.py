@@ -32,25 +32,25 @@ def geo_to_pixel(gt: Sequence[float], x_geo: torch.Tensor, y_geo: torch.Tensor) 
 
 
 def point_batch(tile: torch.Tensor, xy: torch.Tensor, inner: torch.Tensor, obj: torch.Tensor, region_features: torch.Tensor,
-                scales: Sequence[int] = (32, 64, 128)) -> Tuple[List[torch.Tensor], torch.Tensor]:
+                scales: Sequence[int] = (32, 64, 128), resize: str = "opencv") -> Tuple[List[torch.Tensor], torch.Tensor]:
     """The model inputs for P sample points: per-scale patches float32 [P, bands, s, s] (device) and designed
     features [P, 1, 19] = 15 region features || 4 scale factors (MyUtils1.py:60-77).
     tile: uint8 [bands,H,W] on the GPU; xy int [P,2] pixel coordinates; inner/obj int [P]; region_features [P,15]."""
     windows, factors = get_scales(inner, obj)
     windows = windows.to(tile.device)
-    patches = [ops.patch_pyramid(tile, xy, windows[:, i].contiguous(), int(t)) for i, t in enumerate(scales)]
+    patches = [ops.patch_pyramid(tile, xy, windows[:, i].contiguous(), int(t), resize=resize) for i, t in enumerate(scales)]
     designed = torch.cat((region_features.to(torch.float32), factors.to(region_features.device)), dim=1).unsqueeze(1)
     return patches, designed
 
 
 def point_batch_cols(tile: torch.Tensor, xy: torch.Tensor, inner: torch.Tensor, obj: torch.Tensor, region_features: torch.Tensor,
-                     scales: Sequence[int] = (32, 64, 128), grid: int = 8, dtype: torch.dtype = torch.bfloat16):
+                     scales: Sequence[int] = (32, 64, 128), grid: int = 8, dtype: torch.dtype = torch.bfloat16, resize: str = "opencv"):
     """point_batch with the gather FUSED into the patch-embed operand load: per scale an ops.PatchCols
     (bf16 im2col rows written by the gather kernel itself) instead of the fp32 [P, bands, s, s] tensor + dm_patchify.
     Bytes per point and scale: window in (L^2 * bands, uint8) + s^2 * bands * 2 out -- against + s^2 * bands * (4 + 4 + 2) for the
     unfused chain.  The model consumes the list exactly like image tensors; results are bit-identical."""
     windows, factors = get_scales(inner, obj)
     windows = windows.to(tile.device)
-    patches = [ops.patch_pyramid_cols(tile, xy, windows[:, i].contiguous(), int(t), grid, dtype) for i, t in enumerate(scales)]
+    patches = [ops.patch_pyramid_cols(tile, xy, windows[:, i].contiguous(), int(t), grid, dtype, resize=resize) for i, t in enumerate(scales)]
     designed = torch.cat((region_features.to(torch.float32), factors.to(region_features.device)), dim=1).unsqueeze(1)
     return patches, designed

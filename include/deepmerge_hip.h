@@ -40,7 +40,7 @@ typedef enum {
 } DmStatus;
 
 /* ---- library ------------------------------------------------------------------------- */
-int dm_abi_version(void);
+int dm_abi_version(void);   /* 2: dm_patch_pyramid / dm_patch_pyramid_cols take a resize rule (round 3) */
 const char *dm_last_error(void);
 /* Name of the code object architecture the library was built for ("gfx950"). */
 const char *dm_arch(void);
@@ -232,17 +232,23 @@ int dm_edge_similarity(const float *pooled, const int32_t *edges, float *simi, u
  * Replaces, for one scale, the per-point loader work of MyUtils1.py:116-223 / MyUtils2.py:286-437:
  * calculate_left_top_point_and_size (top-left = int(mid - L/2), truncation toward zero), cut_image (window
  * clipped to the raster, zero padded) and resize_data (per band resize to target x target on uint8, /255).
- * The resize is the build's exact integer area average (OpenCV parity unpinned; oracle/patches.py).
+ * resize_rule: DM_RESIZE_OPENCV = cv::resize(..., INTER_AREA) on uint8 restated branch by branch (integer-ratio fast path incl. the
+ * half-up 2x case, float area tables, 11-bit fixed-point bilinear with area coordinates when the window is smaller than the target);
+ * DM_RESIZE_EXACT_AREA = the exact rational area average of rounds 1-2.  Both are specified in oracle/patches.py (no cv2 fixture
+ * exists: the OpenCV rule is faithful to the published algorithm, unpinned against a build).
  *   tile [bands,H,W] uint8; xy int32 [P,2] = (XPixel, YLine); windows int32 [P] = window side L for this scale,
  *   every L <= max_window <= 384; out float32 [P, bands, target, target]. */
+#define DM_RESIZE_OPENCV 0
+#define DM_RESIZE_EXACT_AREA 1
 int dm_patch_pyramid(const uint8_t *tile, int32_t bands, int32_t H, int32_t W, const int32_t *xy, const int32_t *windows,
-                     int32_t max_window, int32_t P, int32_t target, float *out, void *stream);
+                     int32_t max_window, int32_t P, int32_t target, int32_t resize_rule, float *out, void *stream);
 /* The same gather emitting the patch-embed GEMM's operand rows directly ("patch pyramid gather fused into
  * patch-embed"): cols [P * grid * grid, bands * ps * ps] with ps = target / grid, row (p * grid + py) * grid + px, column
  * (c * ps + dy) * ps + dx -- the im2col order of Conv2d(k = ps, stride = ps) (nets/ShfitScaleFormer.py:28-37) -- in bf16 or
  * fp32.  Equal, bit for bit, to dm_patch_pyramid followed by dm_patchify. */
 int dm_patch_pyramid_cols(const uint8_t *tile, int32_t bands, int32_t H, int32_t W, const int32_t *xy, const int32_t *windows,
-                          int32_t max_window, int32_t P, int32_t target, int32_t grid, void *cols, int32_t dtype, void *stream);
+                          int32_t max_window, int32_t P, int32_t target, int32_t grid, int32_t resize_rule, void *cols, int32_t dtype,
+                          void *stream);
 
 /* ---- region-adjacency graph + superpixel statistics from a label raster ---------------------------
  * Replaces, on the device, the inputs the reference reads from files written by external GIS software: the RAG edge

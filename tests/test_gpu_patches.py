@@ -1,4 +1,5 @@
-"""GPU: dm_patch_pyramid against the oracle (bit-exact: the spec is integer arithmetic) + host window helpers."""
+"""GPU: dm_patch_pyramid against the oracle, bit for bit under both resize rules ("opencv": cv::resize INTER_AREA restated, float32 in a
+fixed order; "exact_area": integer arithmetic) + host window helpers."""
 import numpy as np
 import pytest
 import torch
@@ -9,8 +10,10 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
-def test_patch_pyramid_bit_exact_vs_oracle():
+@pytest.mark.parametrize("rule", ["opencv", "exact_area"])
+def test_patch_pyramid_bit_exact_vs_oracle(rule):
     from deepmerge_amd import ops
+    resize = OP.RESIZE_RULES[rule]
     rng = np.random.default_rng(1)
     bands, H, W = 4, 300, 340
     img = rng.integers(0, 256, size=(bands, H, W), dtype=np.uint8)
@@ -21,12 +24,14 @@ def test_patch_pyramid_bit_exact_vs_oracle():
     for t, lo, hi in ((32, 7, 90), (64, 20, 130), (128, 40, 200), (16, 1, 40)):
         wins = rng.integers(lo, hi, P).astype(np.int32)
         wins[0], wins[1] = t, 2 * t                                                   # identity and exact 2x box
-        got = ops.patch_pyramid(tile, torch.from_numpy(xy).to(DEV), torch.from_numpy(wins).to(DEV), t).cpu().numpy()
+        wins[2], wins[3], wins[4], wins[5] = 3 * t, (4 * t + 2) // 3, (8 * t) // 5, max(1, (3 * t) // 4)    # 1/3, ~3/4, 5/8 shrinks; 4/3 enlarging
+        wins[6], wins[7] = max(1, t // 2), 4 * t                                      # exact 2x enlarging (replication under "opencv"), 1/4
+        got = ops.patch_pyramid(tile, torch.from_numpy(xy).to(DEV), torch.from_numpy(wins).to(DEV), t, resize=rule).cpu().numpy()
         for p in range(P):
             x0, y0 = OP.top_left(int(xy[p, 0]), int(xy[p, 1]), int(wins[p]))
             win = OP.cut_image(img, x0, y0, int(wins[p]))
-            want = np.stack([OP.area_resize_u8(win[b], t) for b in range(bands)]).astype(np.float32) / 255.0
-            assert np.array_equal(got[p].view(np.uint32), want.view(np.uint32)), (t, p, wins[p])
+            want = np.stack([resize(win[b], t) for b in range(bands)]).astype(np.float32) / 255.0
+            assert np.array_equal(got[p].view(np.uint32), want.view(np.uint32)), (rule, t, p, wins[p])
 
 
 def test_point_batch_matches_reference_contract():
@@ -71,12 +76,14 @@ def test_patch_pyramid_full_tile_properties():
     for p in rng.integers(0, P, 12):
         x0, y0 = OP.top_left(int(xy[p, 0]), int(xy[p, 1]), int(wins[p]))
         win = OP.cut_image(img, x0, y0, int(wins[p]))
-        want = np.stack([OP.area_resize_u8(win[c], 64) for c in range(bands)]).astype(np.float32) / 255.0
+        want = np.stack([OP.cv_resize_area_u8(win[c], 64) for c in range(bands)]).astype(np.float32) / 255.0
         assert np.array_equal(a[p].cpu().numpy(), want)
     const = torch.full((bands, 512, 512), 200, dtype=torch.uint8, device=DEV)
     inside = torch.tensor([[256, 256]], dtype=torch.int32, device=DEV)
-    out = ops.patch_pyramid(const, inside, torch.tensor([77], dtype=torch.int32, device=DEV), 32)
-    assert torch.equal(out, torch.full_like(out, 200.0 / 255.0))
+    for rule in ("opencv", "exact_area"):                # a constant tile stays constant through every branch: shrink, integer ratio, enlarge
+        for L in (77, 96, 64, 32, 20, 16):
+            out = ops.patch_pyramid(const, inside, torch.tensor([L], dtype=torch.int32, device=DEV), 32, resize=rule)
+            assert torch.equal(out, torch.full_like(out, 200.0 / 255.0)), (rule, L)
     far = torch.tensor([[5000, -4000]], dtype=torch.int32, device=DEV)
     assert float(ops.patch_pyramid(const, far, torch.tensor([50], dtype=torch.int32, device=DEV), 32).abs().max()) == 0.0
     with pytest.raises(ValueError):
@@ -116,8 +123,9 @@ def test_point_chain_matches_reference_fixture():
             assert np.array_equal(OP.cut_image(img, x0, y0, L), fx[f"point/{k}/crop{i}"])
 
 
+@pytest.mark.parametrize("rule", ["opencv", "exact_area"])
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
-def test_fused_gather_rows_equal_pyramid_then_patchify(dtype):
+def test_fused_gather_rows_equal_pyramid_then_patchify(dtype, rule):
     """dm_patch_pyramid_cols == dm_patch_pyramid -> dm_patchify, bit for bit (windows over every border, 4 bands, all four targets)."""
     from deepmerge_amd import ops
     rng = np.random.default_rng(9)
@@ -127,9 +135,9 @@ def test_fused_gather_rows_equal_pyramid_then_patchify(dtype):
     for t, lo, hi in ((32, 7, 90), (64, 20, 130), (128, 40, 200), (256, 60, 300)):
         wins = torch.from_numpy(rng.integers(lo, hi, P).astype(np.int32)).to(DEV)
         wins[0] = t
-        planar = ops.patch_pyramid(tile, xy, wins, t)
+        planar = ops.patch_pyramid(tile, xy, wins, t, resize=rule)
         want = ops.patchify(planar, t // 8, dtype)
-        got = ops.patch_pyramid_cols(tile, xy, wins, t, 8, dtype)
+        got = ops.patch_pyramid_cols(tile, xy, wins, t, 8, dtype, resize=rule)
         assert got.cols.shape == want.shape == (P * 64, bands * (t // 8) ** 2) and got.shape == (P, bands, t, t)
         assert torch.equal(got.cols.view(torch.int16 if dtype == torch.bfloat16 else torch.int32), want.view(torch.int16 if dtype == torch.bfloat16 else torch.int32)), t
 

@@ -57,13 +57,13 @@ def test_superblock_and_headers_follow_the_specification(tmp_path):
         types.append(t); off += 8 + size
     assert types == [0x0001, 0x0003, 0x0005, 0x0008]          # dataspace, datatype, fill value, layout
     assert r.info["chunk_dims"] == (128, 100, 4) and r.chunk_rows == 128
-    assert sorted(r.chunks) == [0, 128, 256]                 # 300 rows -> 3 chunks, the last stored whole
+    assert sorted(r.chunks) == [(0, 0), (128, 0), (256, 0)]  # 300 rows -> 3 chunks, the last stored whole
     idx = r.info["index"]
     assert raw[idx:idx + 4] == b"TREE" and raw[idx + 4] == 1 and raw[idx + 5] == 0 and struct.unpack("<H", raw[idx + 6:idx + 8])[0] == 3
     assert struct.unpack("<QQ", raw[idx + 8:idx + 24]) == (UNDEF, UNDEF)
     last_key = raw[idx + 24 + 3 * 40:idx + 24 + 3 * 40 + 32]
     assert struct.unpack("<QQQ", last_key[8:]) == (384, 0, 0)
-    for row0, addr in r.chunks.items():
+    for (row0, _col0), addr in r.chunks.items():
         got = np.frombuffer(raw[addr:addr + 128 * 400], "<f4").reshape(128, 100)
         n = min(128, 300 - row0)
         assert np.array_equal(got[:n], np.arange(300 * 100, dtype=np.float32).reshape(300, 100)[row0:row0 + n])
@@ -115,3 +115,46 @@ def test_featureio_store_round_trip_without_a_gpu(tmp_path):
     with pytest.raises(IndexError):
         fio.GetFeaturesByID(4100)
     fio.Close(); r.close()
+
+
+def test_reader_takes_h5py_style_layouts(tmp_path):
+    """What h5py's `chunks=True` / libhdf5 produce for the reference's `create_dataset("dataset", ..., maxshape=(None, 100), chunks=True)`
+    (ExtractFeatures.py:88-101) and this writer's default does not: a 2-D chunk GRID (both dimensions split, e.g. (128, 25); edge
+    chunks hang over the width and are stored whole), an object header whose layout message sits in a continuation block, NIL padding
+    and a message type the reader does not need.  No h5py here: the vectors come from the writer's own options, the
+    reader takes every size and address from the file."""
+    rng = np.random.default_rng(5)
+    data = rng.normal(size=(300, 100)).astype(np.float32)
+    for kw in ({"chunk_cols": 25}, {"chunk_cols": 32}, {"chunk_cols": 25, "split_header": True}, {"split_header": True}):
+        path = str(tmp_path / "grid.h5")
+        with H5FeatureWriter(path, width=100, chunk_rows=128, **kw) as w:
+            w.append(data[:70]); w.append(data[70:])
+        r = H5FeatureReader(path)
+        cc = kw.get("chunk_cols", 100)
+        assert r.shape == (300, 100) and r.info["chunk_dims"] == (128, cc, 4) and (r.chunk_rows, r.chunk_cols) == (128, cc)
+        assert len(r.chunks) == 3 * -(-100 // cc)
+        assert np.array_equal(r.rows(0, 300), data) and np.array_equal(r[299], data[299]) and np.array_equal(r.rows(120, 140), data[120:140])
+        raw = open(path, "rb").read()
+        assert os.path.getsize(path) == r.info["eof"]
+        hdr = r.info["dataset_header"]
+        nmsg, first = struct.unpack("<H", raw[hdr + 2:hdr + 4])[0], struct.unpack("<I", raw[hdr + 8:hdr + 12])[0]
+        types, off = [], hdr + 16
+        while off < hdr + 16 + first:
+            t, size = struct.unpack("<HH", raw[off:off + 4])
+            types.append(t); off += 8 + size
+        if kw.get("split_header"):
+            assert types == [0x0001, 0x0003, 0x0005, 0x0000, 0x0010] and nmsg == 7            # + layout and modification time in the block
+            caddr, clen = struct.unpack("<QQ", raw[off - 16:off])
+            assert struct.unpack("<H", raw[caddr:caddr + 2])[0] == 0x0008 and struct.unpack("<H", raw[caddr + clen - 16:caddr + clen - 14])[0] == 0x0012
+        else:
+            assert types == [0x0001, 0x0003, 0x0005, 0x0008] and nmsg == 4
+        # chunk keys are in row-major grid order and every chunk is stored whole
+        keys = sorted(r.chunks)
+        assert keys == [(r0, c0) for r0 in (0, 128, 256) for c0 in range(0, 100, cc)]
+        (r0, c0), addr = keys[-1], r.chunks[keys[-1]]
+        got = np.frombuffer(raw[addr:addr + 128 * cc * 4], "<f4").reshape(128, cc)
+        assert np.array_equal(got[:300 - r0, :100 - c0], data[r0:, c0:]) and not got[300 - r0:].any()
+        r.close()
+    with pytest.raises(ValueError):
+        H5FeatureWriter(str(tmp_path / "bad.h5"), width=100, chunk_cols=101)
+

@@ -102,3 +102,49 @@ def test_point_chain_matches_reference():
         for i, L in enumerate(w):
             x0, y0 = OP.top_left(px, py, L)
             assert np.array_equal(OP.cut_image(img, x0, y0, L), fx[f"point/{k}/crop{i}"]), (k, i)
+
+
+def test_cv_inter_area_branches_known_answers():
+    """`cv_resize_area_u8` = cv::resize(..., INTER_AREA) on uint8 restated (reference call site MyUtils1.py:202-216; no cv2 here, so the
+    anchors are values worked out by hand from the published algorithm, one per branch)."""
+    a = np.arange(16, dtype=np.uint8).reshape(4, 4)
+    assert np.array_equal(OP.cv_resize_area_u8(a, 4), a)                                # scale 1: copy
+    q = np.array([[1, 2], [3, 4]], np.uint8)
+    assert OP.cv_resize_area_u8(q, 1)[0, 0] == 3 and OP.area_resize_u8(q, 1)[0, 0] == 2   # 2x: (10 + 2) >> 2 rounds the tie UP; exact area: half to even
+    n = np.zeros((3, 3), np.uint8); n[1, 1] = 13
+    assert OP.cv_resize_area_u8(n, 1)[0, 0] == 1                                         # 3x: 13 * float(1/9) = 1.44 -> 1
+    n[1, 1] = 14
+    assert OP.cv_resize_area_u8(n, 1)[0, 0] == 2                                         # 14 / 9 = 1.56 -> 2
+    e = np.array([[10, 20], [30, 40]], np.uint8)
+    assert np.array_equal(OP.cv_resize_area_u8(e, 4), np.kron(e, np.ones((2, 2), np.uint8)))   # exact 2x enlarging: every fx is 0 -> replication
+    # 3 -> 2 (scale 1.5): tables [(0, 2/3), (1, 1/3)] and [(1, 1/3), (2, 2/3)]
+    tab = OP.cv_area_tab(3, 2)
+    assert [[si for si, _ in ent] for ent in tab] == [[0, 1], [1, 2]]
+    np.testing.assert_allclose([[float(al) for _, al in ent] for ent in tab], [[2 / 3, 1 / 3], [1 / 3, 2 / 3]], rtol=1e-6)
+    b = np.zeros((3, 3), np.uint8); b[1, 1] = 90
+    assert OP.cv_resize_area_u8(b, 2).tolist() == [[10, 10], [10, 10]]                   # 90 * (1/3)^2
+    # 3 -> 4 (enlarging, scale 0.75): sx = [0, 0, 1, 2], fx = [0, 2/3, 1/3, 0] -> coefficients of 2048
+    ofs, a0, a1, dmax = OP.cv_linear_coeffs(3, 4)
+    assert ofs.tolist() == [0, 0, 1, 2] and a1.tolist() == [0, 1365, 683, 0] and a0.tolist() == [2048, 683, 1365, 2048] and dmax == 3
+    row = np.array([[0, 90, 30]] * 3, np.uint8)
+    assert OP.cv_resize_area_u8(row, 4)[0].tolist() == [0, 60, 70, 30]                   # (0*683 + 90*1365)/2048 = 59.99 -> 60; (90*1365 + 30*683)/2048 = 69.99 -> 70
+
+
+def test_cv_inter_area_properties():
+    """Size-independent properties over all three branches: a constant image stays constant; shrinking stays within one grey level
+    of the exact rational area average (they differ in ties and float rounding only); enlarging is a convex combination."""
+    rng = np.random.default_rng(11)
+    for L, t in ((64, 32), (96, 32), (43, 32), (51, 32), (24, 32), (16, 32), (200, 128), (77, 64), (31, 32), (33, 32)):
+        c = np.full((L, L), 137, np.uint8)
+        assert np.array_equal(OP.cv_resize_area_u8(c, t), np.full((t, t), 137, np.uint8)), (L, t)
+        img = rng.integers(0, 256, (L, L), dtype=np.uint8)
+        got = OP.cv_resize_area_u8(img, t)
+        if L >= t:
+            assert np.abs(got.astype(int) - OP.area_resize_u8(img, t).astype(int)).max() <= 1, (L, t)
+        else:
+            assert got.min() >= img.min() and got.max() <= img.max()
+    img = rng.integers(0, 256, (3, 40, 40), dtype=np.uint8)
+    for rule in ("opencv", "exact_area"):
+        out = OP.patch_pyramid(img, 20, 20, [20, 40, 56], (32, 32, 32), resize=rule)
+        assert [o.shape for o in out] == [(3, 32, 32)] * 3 and all(o.dtype == np.float32 for o in out)
+
