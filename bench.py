@@ -137,7 +137,8 @@ def extras(args, scales, in_c, depth, dev):
     try:
         from deepmerge_amd.nets.ShfitScaleFormer import ShfitScaleFormer_v3
         from deepmerge_amd.trainer import PairTrainer
-        log("extras: fp32 parity mode, 5 steps")
+        NS = 10                                            # timed steps of every secondary measurement (>= 10)
+        log(f"extras: fp32 parity mode, {NS} steps")
         torch.manual_seed(0)
         net = ShfitScaleFormer_v3(cube_size=[8, 8], input_image_scales=list(scales), depth=list(depth), in_c=in_c, numerics="fp32").to(dev)
         tr = PairTrainer(net, margin=1.0, lr=1e-4)
@@ -145,23 +146,23 @@ def extras(args, scales, in_c, depth, dev):
         for _ in range(2):
             tr.step(*batch)
         torch.cuda.synchronize(); t0 = time.perf_counter()
-        for _ in range(5):
+        for _ in range(NS):
             tr.step(*batch)
-        torch.cuda.synchronize(); d = (time.perf_counter() - t0) / 5
+        torch.cuda.synchronize(); d = (time.perf_counter() - t0) / NS
         out["fp32_parity_pairs_per_s"] = round(args.pairs / d, 1)
         out["fp32_parity_ms_per_step"] = round(1e3 * d, 2)
         del net, tr
         torch.cuda.empty_cache()
-        log("extras: bf16x3 mode (fp32 path, large products as split-bf16 triples on the bf16 matrix pipe), 5 steps")
+        log(f"extras: bf16x3 mode (fp32 path, large products as split-bf16 triples on the bf16 matrix pipe), {NS} steps")
         torch.manual_seed(0)
         net = ShfitScaleFormer_v3(cube_size=[8, 8], input_image_scales=list(scales), depth=list(depth), in_c=in_c, numerics="bf16x3").to(dev)
         tr = PairTrainer(net, margin=1.0, lr=1e-4)
         for _ in range(2):
             tr.step(*batch)
         torch.cuda.synchronize(); t0 = time.perf_counter()
-        for _ in range(5):
+        for _ in range(NS):
             tr.step(*batch)
-        torch.cuda.synchronize(); d = (time.perf_counter() - t0) / 5
+        torch.cuda.synchronize(); d = (time.perf_counter() - t0) / NS
         out["bf16x3_pairs_per_s"] = round(args.pairs / d, 1)
         out["bf16x3_ms_per_step"] = round(1e3 * d, 2)
         del net, tr
@@ -170,16 +171,27 @@ def extras(args, scales, in_c, depth, dev):
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         import bench_configs as BC
         log("extras: config 3 (ViT-B/16 pairs)")
-        c3 = BC.config3(steps=5)
+        c3 = BC.config3(steps=NS)
         out["config3_vit_pairs_per_s"], out["config3"] = c3["pairs_per_s"], c3
         torch.cuda.empty_cache()
         log("extras: config 5 per GPU (v3 [6,4,2], 120 pairs)")
-        c5 = BC.config5(steps=5, graph=True)
+        c5 = BC.config5(steps=NS, graph=True)
         out["config5_per_gpu_pairs_per_s"], out["config5"] = c5["pairs_per_s"], c5
         torch.cuda.empty_cache()
         log("extras: config 5 per GPU, the reference's default 3-scale / 3-channel geometry")
-        c53 = BC.config5(steps=5, graph=True, three_scale=True)
+        c53 = BC.config5(steps=NS, graph=True, three_scale=True)
         out["config5_3scale_per_gpu_pairs_per_s"], out["config5_3scale"] = c53["pairs_per_s"], c53
+        torch.cuda.empty_cache()
+        # the mode that meets north_star's 1e-3 tolerance (bf16x3), on the model the >= 10 k pairs/s target is defined on and on config 3
+        log("extras: config 5 per GPU in bf16x3 (4 scales x 4 ch), then 3 scales x 3 ch, then config 3 in bf16x3")
+        c5x = BC.config5(steps=NS, graph=True, numerics="bf16x3")
+        out["config5_bf16x3_per_gpu_pairs_per_s"], out["config5_bf16x3"] = c5x["pairs_per_s"], c5x
+        torch.cuda.empty_cache()
+        c53x = BC.config5(steps=NS, graph=True, three_scale=True, numerics="bf16x3")
+        out["config5_3scale_bf16x3_per_gpu_pairs_per_s"], out["config5_3scale_bf16x3"] = c53x["pairs_per_s"], c53x
+        torch.cuda.empty_cache()
+        c3x = BC.config3(steps=NS, numerics="bf16x3")
+        out["config3_bf16x3_pairs_per_s"], out["config3_bf16x3"] = c3x["pairs_per_s"], c3x
         torch.cuda.empty_cache()
         log("extras: config 4 (ExtractFeatures tile)")
         c4 = BC.config4(passes=1)

@@ -345,200 +345,9 @@ __global__ __launch_bounds__(512) void attn_fwd_pipe_kernel(const AttnPipeParams
   write_back(b1 - 1);
 }
 
-// ---- forward, two independent workgroups per CU (experiment + timing-ablation vehicle; built only with EXTRA=-DDM_ATTN_ABLATIONS) ----
-// Measured (profiles/r02_attn_ablations.txt): correct, and no faster than the 8-wave kernel (42.0 vs 40.9 us at B = 64, tie at
-// B = 240) -- decoupling the two waves of a SIMD was not the limiter.  Its compile-time ablations are what showed where the time
-// goes: a 20 us floor (MFMAs, bias / scale, write-back, prologue) + 11 us of K / V fragment reads (= the LDS's 128 B/clk for the
-// 3.6 MB a CU reads per launch: every wave reads all of K and V) + 9.5 us of softmax arithmetic + 5 us of DMA, and the parts add.
-#ifdef DM_ATTN_ABLATIONS
-// The kernel above keeps one 8-wave workgroup per CU (two K / V buffers fill the LDS) and its two waves per SIMD meet at the one
-// barrier per sample, so they run their MFMA phases together and their softmax phases together (profiles/r02_attn_mfma_util.md: the
-// matrix pipe is busy 10 % of the time, the waves are parked or issue-stalled 75 %).  Here a workgroup is 4 waves x 16 query rows
-// with ONE K and ONE V image (64 KiB + write-back staging): two workgroups share a CU, one wave of each per SIMD, and nothing ties
-// their phases together -- one's softmax runs under the other's QK^T / P.V.  The images are refilled in place as soon as their last
-// reader is done: K(b+1) right after the QK^T of sample b (lands under softmax + P.V), V(b) at the top of sample b (lands under QK^T +
-// softmax).  Three 4-wave barriers per sample:
-//   T: K(b) has landed for every wave; every wave has finished P.V(b-1)  -> issue V(b) DMA, write back O(b-1)
-//   M: every wave has finished QK^T(b)                                   -> issue K(b+1) DMA, Q(b+1) loads
-//   P: V(b) has landed for every wave (counted wait: only the M group, all loads, is younger)
-constexpr int ROWS2 = 64;
-template <int NKT, bool RAGGED, int ABL = 0>
-__global__ __launch_bounds__(256, 2) void attn_fwd_pipe2_kernel(const AttnPipeParams p, int bchunk, int nblk, int chunks) {
-  constexpr int NP = NKT * 16;
-  const int N = RAGGED ? p.N : NP;
-  constexpr int IMG = NP * 128;
-  constexpr int NDMA = (2 * NKT + 3) / 4;          // K (or V) DMA instructions per wave: 2 NKT instructions of 8 keys over 4 waves
-  extern __shared__ __attribute__((aligned(16))) char smem[];   // [K image | V image | write-back staging]
-  const int t = threadIdx.x, lane = t & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int g = lane >> 4, li = lane & 15;
-  int h, rb, chunk;
-  if (!pipe_coords(nblk, p.H, chunks, h, rb, chunk)) return;
-  const int H = p.H;
-  const int b0 = chunk * bchunk, b1 = min(p.B, b0 + bchunk);
-  if (b0 >= b1) return;
-  const int q_wave = rb * ROWS2 + wave * 16;
-  const int q = q_wave + li;
-  const bool wave_live = q_wave < N;
-  const bool row_ok = q < N;
-  const long long tok_stride = 3LL * H * HD;
-  const bf16_t *qkv = reinterpret_cast<const bf16_t *>(p.qkv);
-
-  f32x4 bias[NKT];
-#pragma unroll
-  for (int kt = 0; kt < NKT; ++kt) bias[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
-  if (p.bias && wave_live && row_ok) {
-    const float *brow = p.bias + ((long long)h * N + q) * N + 4 * g;
-#pragma unroll
-    for (int kt = 0; kt < NKT; ++kt) {
-      if constexpr (!RAGGED) {
-        bias[kt] = dm_load4(brow + 16 * kt) * LOG2E;
-      } else {
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (16 * kt + 4 * g + r < N) bias[kt][r] = brow[16 * kt + r] * LOG2E;
-      }
-    }
-  }
-  const float scale2 = p.scale * LOG2E;
-
-  char *kimg = smem, *vimg = smem + IMG;
-  const int dkey = lane >> 3;
-  const unsigned srcK = (unsigned)(((lane & 7) ^ dkey) * 16);
-  const unsigned srcV = (unsigned)(((lane & 7) ^ (((dkey >> 1) & 3) << 1)) * 16);
-  // which: 1 = K, 2 = V (the slot of the packed qkv row)
-  auto stage = [&](int b, int which) {
-    const bf16_t *base = qkv + (long long)b * N * tok_stride + (long long)h * HD;
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t *>(base), 0, (int)(N * tok_stride * 2), 0x00020000);
-    char *img = which == 1 ? kimg : vimg;
-    const unsigned colo = (unsigned)(which * H * HD * 2) + (which == 1 ? srcK : srcV);
-#pragma unroll
-    for (int j = 0; j < NDMA; ++j) {
-      // every wave issues exactly NDMA instructions (the counted wait at P relies on it): a wave whose last instruction falls
-      // past the image repeats the image's last one (same bytes to the same place)
-      const int inst = min(wave + 4 * j, NP / 8 - 1);
-      DM_LDS_DMA(rs, img + inst * 1024, (unsigned)((8 * inst + dkey) * tok_stride * 2) + colo, 0);
-    }
-  };
-  auto load_q = [&](int b, u32x4 (&fq)[2]) {
-    // unconditional loads (clamped row): the counted wait at P needs the same number of vector-memory instructions in every wave
-    const int qr = min(q, N - 1);
-    const bf16_t *qrow = qkv + ((long long)b * N + qr) * tok_stride + (long long)h * HD;
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) fq[ks] = *reinterpret_cast<const u32x4 *>(qrow + (4 * ks + g) * 8);
-  };
-
-  const int kswz0 = ((g) ^ (li & 7)) << 4, kswz1 = ((4 + g) ^ (li & 7)) << 4;
-  const int vq = li >> 2, vp = li & 3;
-  const int vrow = 4 * g + vq;
-  const int vf = ((vrow >> 1) & 3);
-
-  u32x4 fq[2], fq_next[2];
-  f32x4 o_prev[4];
-  float lse_prev = 0.f;
-  char *wb_stage = smem + 2 * IMG + wave * (16 * WB_PITCH);
-  auto write_back = [&](int b) {
-    if (!wave_live) return;
-    bf16_t *orow0 = reinterpret_cast<bf16_t *>(p.out) + ((long long)b * N + q_wave) * H * HD + (long long)h * HD;
-    wb_rows16(wb_stage, o_prev, orow0, (long long)H * HD, lane, N - q_wave);
-    if (g == 0 && row_ok) p.lse[((long long)b * H + h) * N + q] = lse_prev;
-  };
-  stage(b0, 1);
-  load_q(b0, fq);
-  fq_next[0] = fq[0];
-  fq_next[1] = fq[1];
-  for (int b = b0; b < b1; ++b) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // K(b), Q(b): issued at M of the previous sample
-    __builtin_amdgcn_s_barrier();                                  // T
-    if (!(ABL & 16) || b == b0) stage((ABL & 64) ? b0 : b, 2);
-    if (b > b0 && !(ABL & 128)) write_back(b - 1);
-
-    f32x4 s[NKT];
-    if (wave_live) {
-#pragma unroll
-      for (int kt = 0; kt < NKT; ++kt) {
-        const char *krow = kimg + (16 * kt + li) * 128;
-        f32x4 a = {0.f, 0.f, 0.f, 0.f};
-        if constexpr (ABL & 2) {
-          mma<bf16_t>(a, fq[0], fq[1]);
-          mma<bf16_t>(a, fq[1], fq[0]);
-        } else {
-          mma<bf16_t>(a, fq[0], *reinterpret_cast<const u32x4 *>(krow + kswz0));
-          mma<bf16_t>(a, fq[1], *reinterpret_cast<const u32x4 *>(krow + kswz1));
-        }
-        s[kt] = a * scale2 + bias[kt];
-        if constexpr (RAGGED) {
-          if (16 * kt + 16 > N) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-              if (16 * kt + 4 * g + r >= N) s[kt][r] = -INFINITY;
-          }
-        }
-      }
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");             // this wave's K fragment reads have returned
-    if (!(ABL & 32)) __builtin_amdgcn_s_barrier();                 // M
-    if (b + 1 < b1) {
-      if (!(ABL & 16)) stage((ABL & 64) ? b0 : b + 1, 1);
-      load_q((ABL & 64) ? b0 : b + 1, fq_next);
-    }
-    float inv = 0.f;
-    if (wave_live && !(ABL & 8)) {
-      float m = -INFINITY;
-#pragma unroll
-      for (int kt = 0; kt < NKT; ++kt) m = fmaxf(fmaxf(m, fmaxf(s[kt][0], s[kt][1])), fmaxf(s[kt][2], s[kt][3]));
-      m = row_max4(m);
-      float l = 0.f;
-#pragma unroll
-      for (int kt = 0; kt < NKT; ++kt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float e = (ABL & 1) ? (s[kt][r] - m) : __builtin_amdgcn_exp2f(s[kt][r] - m);
-          s[kt][r] = e;
-          l += e;
-        }
-      l = row_sum4(l);
-      inv = 1.f / l;
-      lse_prev = (m + __builtin_amdgcn_logf(l)) * LN2;
-    }
-    // V(b) (issued at T) has landed: at most the M group -- NDMA K instructions + 2 Q loads, all loads, all younger -- may still
-    // be in flight (loads return in order among themselves; an outstanding store only makes the wait stricter)
-    if (b + 1 < b1 && !(ABL & 16)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA + 2) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (!(ABL & 32)) __builtin_amdgcn_s_barrier();                 // P
-    if (wave_live) {
-      f32x4 o[4];
-#pragma unroll
-      for (int dt = 0; dt < 4; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int mb = 0; mb < NKT / 2; ++mb) {
-        const f32x4 pa = s[2 * mb], pb = s[2 * mb + 1];
-        const bf16x8 pk = {(bf16_t)pa[0], (bf16_t)pa[1], (bf16_t)pa[2], (bf16_t)pa[3], (bf16_t)pb[0], (bf16_t)pb[1], (bf16_t)pb[2], (bf16_t)pb[3]};
-        const u32x4 pf = __builtin_bit_cast(u32x4, pk);
-        const char *vblk = vimg + (32 * mb + vrow) * 128 + 8 * vp;
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
-          if constexpr (ABL & 4) {
-            mma<bf16_t>(o[dt], pf, pf);
-          } else {
-            const int slot = (dt ^ vf) << 5;
-            const u32x2 lo = dm_ds_read_tr16(vblk + slot);
-            const u32x2 hi = dm_ds_read_tr16(vblk + 16 * 128 + slot);
-            mma<bf16_t>(o[dt], pf, (u32x4){lo[0], lo[1], hi[0], hi[1]});
-          }
-        }
-      }
-#pragma unroll
-      for (int dt = 0; dt < 4; ++dt) o_prev[dt] = o[dt] * inv;
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");             // this wave's V fragment reads have returned (V is refilled after T)
-    fq[0] = fq_next[0];
-    fq[1] = fq_next[1];
-  }
-  write_back(b1 - 1);
-}
-#endif  // DM_ATTN_ABLATIONS
+// (Round 2: a two-workgroups-per-CU variant of the kernel above -- 4 waves x 16 rows, ONE K and ONE V image refilled in place -- was
+// built to stop the two waves of a SIMD running in lockstep, measured no faster (42.0 vs 40.9 us) and served as the vehicle of the
+// compile-time timing ablations in profiles/r02_attn_ablations.txt; removed from the product library in round 3, see git history.)
 
 // (Round 2, tried and removed: a variant of the kernel above that software-pipelines ACROSS samples inside a wave -- raw scores of
 // sample b + 1 on the matrix pipe while the VALU exponentiates sample b, scale / bias / max of b + 1 under P(b).V(b), K one
@@ -936,27 +745,6 @@ template <int NKT, bool RAGGED> void launch_bwd(const AttnPipeBwdParams &p, hipS
     hipLaunchKernelGGL((attn_bwd_dkv_pipe_kernel<NKT, RAGGED, false>), dim3(pipe_grid_size(nblk, p.H, chunks)), dim3(512), LDS_DKV, s, p, bchunk, nblk, pipe_xcd_map() ? chunks : -chunks);
 }
 
-#ifdef DM_ATTN_ABLATIONS
-inline void pipe2_grid(int B, int N, int H, int &nblk, int &chunks, int &bchunk) {
-  nblk = (N + ROWS2 - 1) / ROWS2;
-  chunks = 512 / (H * nblk);                     // two workgroups per CU
-  if (chunks < 1) chunks = 1;
-  if (chunks > B) chunks = B;
-  bchunk = (B + chunks - 1) / chunks;
-  chunks = (B + bchunk - 1) / bchunk;
-}
-
-template <int NKT, bool RAGGED, int ABL = 0> void launch2(const AttnPipeParams &p, hipStream_t s) {
-  constexpr int NP = NKT * 16;
-  constexpr int LDS = 2 * NP * 128 + 4 * 16 * WB_PITCH;
-  static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void *>(attn_fwd_pipe2_kernel<NKT, RAGGED, ABL>),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, LDS) == hipSuccess;
-  (void)ok;
-  int nblk, chunks, bchunk;
-  pipe2_grid(p.B, p.N, p.H, nblk, chunks, bchunk);
-  hipLaunchKernelGGL((attn_fwd_pipe2_kernel<NKT, RAGGED, ABL>), dim3(pipe_grid_size(nblk, p.H, chunks)), dim3(256), LDS, s, p, bchunk, nblk, pipe_xcd_map() ? chunks : -chunks);
-}
-#endif
 
 template <int NKT, bool RAGGED, bool PF> void launch_pf(const AttnPipeParams &p, hipStream_t s);
 template <int NKT, bool RAGGED> void launch(const AttnPipeParams &p, hipStream_t s) {
@@ -997,28 +785,6 @@ static int pipe_tiles(int N, bool &ragged) {
 bool dm_attn_fwd_pipe(const AttnPipeParams &p, hipStream_t s) {
   if (!pipe_shape_ok(p.B, p.N, p.H)) return false;
   bool ragged;
-#ifdef DM_ATTN_ABLATIONS      // tools/mb_attn_abl.sh: DM_ATTN_FWD2=1 selects the two-workgroup variant, DM_ATTN_ABL its ablations
-  static const int fwd2 = [] { const char *e = getenv("DM_ATTN_FWD2"); return e ? atoi(e) : 0; }();
-  if (fwd2 == 1 && p.N == 256) {
-    static const int abl = [] { const char *e = getenv("DM_ATTN_ABL"); return e ? atoi(e) : 0; }();
-    switch (abl) {
-      case 1: dmpipe::launch2<16, false, 1>(p, s); return true;
-      case 2: dmpipe::launch2<16, false, 2>(p, s); return true;
-      case 4: dmpipe::launch2<16, false, 4>(p, s); return true;
-      case 6: dmpipe::launch2<16, false, 6>(p, s); return true;
-      case 8: dmpipe::launch2<16, false, 8>(p, s); return true;
-      case 14: dmpipe::launch2<16, false, 14>(p, s); return true;
-      case 16: dmpipe::launch2<16, false, 16>(p, s); return true;
-      case 32: dmpipe::launch2<16, false, 32>(p, s); return true;
-      case 48: dmpipe::launch2<16, false, 48>(p, s); return true;
-      case 62: dmpipe::launch2<16, false, 62>(p, s); return true;
-      case 64: dmpipe::launch2<16, false, 64>(p, s); return true;
-      case 128: dmpipe::launch2<16, false, 128>(p, s); return true;
-      case 192: dmpipe::launch2<16, false, 192>(p, s); return true;
-      default: dmpipe::launch2<16, false, 0>(p, s); return true;
-    }
-  }
-#endif
   switch (pipe_tiles(p.N, ragged)) {
     case 8: dmpipe::launch<8, false>(p, s); return true;
     case 10: dmpipe::launch<10, true>(p, s); return true;

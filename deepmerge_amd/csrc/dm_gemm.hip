@@ -40,8 +40,6 @@ bool dm_gemm256_plan(GemmParams &p, int layout, int ab_dtype, bool can_split, lo
 void dm_gemm256_launch(const GemmParams &p, int layout, hipStream_t s);
 int dm_gemm_ring_plan(GemmParams &p, int layout, int ab_dtype, bool aligned8);      // dm_gemm_ring.hip
 void dm_gemm_ring_launch(const GemmParams &p, int wm, hipStream_t s);
-int dm_gemm_p192_plan(GemmParams &p, int layout, int ab_dtype, bool aligned8);      // dm_gemm_p192.hip (returns the grid size, 0 = not taken)
-void dm_gemm_p192_launch(const GemmParams &p, int layout, int grid, hipStream_t s);
 int dm_gemm_w4_plan(GemmParams &p, int layout, int ab_dtype, bool aligned8, bool can_split, long long workspace_bytes);   // dm_gemm_w4.hip (grid size, 0 = not taken)
 void dm_gemm_w4_launch(const GemmParams &p, int layout, int grid, hipStream_t s);
 
@@ -401,37 +399,6 @@ __global__ void splitk_reduce_kernel(const float *__restrict__ slab, float *__re
   }
 }
 
-// Forward / dgrad split-K (bf16, M = 4096 / 1024 stages with K >= 2048: the 128x128 grid has fewer tiles than the chip has CUs and each
-// workgroup would walk 36-48 K stages alone): the slices' fp32 partial tiles are summed in slice order HERE and sent through the fused
-// epilogue (bias, GELU variants, residual, bf16 / fp32 store) 8 columns per thread -- same arithmetic order for every launch.
-__global__ __launch_bounds__(256) void splitk_epilogue_kernel(const GemmParams p, int S) {
-  const long long items = (long long)p.M * (p.N / 8);
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < items; i += (long long)gridDim.x * blockDim.x) {
-    const int m = (int)(i / (p.N / 8)), n = (int)(i % (p.N / 8)) * 8;
-    const float *src = p.workspace + (long long)m * p.N + n;
-    f32x4 lo = dm_load4(src), hi = dm_load4(src + 4);
-    for (int sidx = 1; sidx < S; ++sidx) {
-      const float *q = src + (long long)sidx * p.M * p.N;
-      lo += dm_load4(q);
-      hi += dm_load4(q + 4);
-    }
-    dm_gemm_emit8(p, lo, hi, dm_gemm_row(p, m), n);
-  }
-}
-
-// slices for a forward / dgrad product on the 128x128 kernel (1 = do not split)
-static int fwd_split(int M, int N, int K) {
-  // Off by default: inside the training step it is a wash (the main kernels of the seven products it takes get 78 us per step shorter,
-  // the seven reduce launches give it back: 6.21 vs 6.20 ms).  DM_GEMM_FWD_SPLIT=1 enables it (read per call: the test flips it).
-  const char *e = getenv("DM_GEMM_FWD_SPLIT");
-  if (!e || atoi(e) == 0 || K < 2048) return 1;
-  const long long t128 = (long long)((M + 127) / 128) * ((N + 127) / 128);
-  if (t128 >= 256) return 1;
-  int s = (int)((448 + t128 / 2) / t128);
-  if (s > 4) s = 4;
-  while (s > 1 && K / s < 512) --s;
-  return s < 1 ? 1 : s;
-}
 
 // out[m] (+)= sum_r rows[r][m], rows in index order (the pipeline's partial column sums of A)
 __global__ void colsum_rows_reduce_kernel(const float *__restrict__ rows, float *__restrict__ out, int M, int R, int accumulate) {
@@ -576,10 +543,7 @@ static int64_t colsum_region_floats(int M) {
 }
 
 extern "C" int64_t dm_gemm_workspace_bytes(int32_t layout, int32_t M, int32_t N, int32_t K) {
-  if (layout != DM_TN) {
-    const int s = fwd_split(M, N, K);
-    return s > 1 ? (int64_t)s * M * N * 4 : 0;
-  }
+  if (layout != DM_TN) return 0;
   const int tile = pick_tile(layout, M, N, K);
   const int tiles = ((M + tile - 1) / tile) * ((N + tile - 1) / tile);
   const int s = choose_split(tiles, K, 32);
@@ -663,32 +627,16 @@ extern "C" int dm_gemm(const DmGemmArgs *a, void *stream) {
   // two-workgroups-per-CU ring kernel (k-contiguous operands, 16-byte row pieces in the epilogue)
   const bool ring_aligned = (a->ldc % 8 == 0) && (a->aux == nullptr || a->ldaux % 8 == 0) &&
                             (a->rows_per_group == 0 || a->group_stride % 8 == 0) && a->split_k <= 1 && !a->colsum_a;
-  // persistent 256x192 pipeline (whole rounds of tiles on the 16384-token stage), then the ring kernel, then the 256x256 pipeline
+  // the 4-wave register-staged persistent kernel, then the ring kernel, then the 256x256 pipeline
   p.workspace = reinterpret_cast<float *>(a->workspace);
   const bool w4_ok = (a->layout == DM_TN) ? (a->split_k == 0 && a->ldc % 4 == 0) : ring_aligned;     // wgrad: automatic slice count only
   const int w4 = w4_ok ? dm_gemm_w4_plan(p, a->layout, a->ab_dtype, true, can_split, slab_bytes) : 0;
-  const int p192 = w4 ? 0 : dm_gemm_p192_plan(p, a->layout, a->ab_dtype, ring_aligned);
-  const bool persistent = w4 || p192;
+  const bool persistent = w4 != 0;
   const int ring = persistent ? 0 : dm_gemm_ring_plan(p, a->layout, a->ab_dtype, ring_aligned);
   const bool big = !persistent && !ring && dm_gemm256_plan(p, a->layout, a->ab_dtype, can_split, slab_bytes, a->split_k);
-  int tile = w4 ? 1924 : p192 ? 192 : ring ? (ring == 8 ? 2568 : 1288) : big ? 256 : pick_tile(a->layout, a->M, a->N, a->K);
+  int tile = w4 ? 1924 : ring ? (ring == 8 ? 2568 : 1288) : big ? 256 : pick_tile(a->layout, a->M, a->N, a->K);
   int split = w4 ? p.split_k : (ring || persistent) ? 1 : p.split_k;
-  // forward / dgrad split-K on the 128x128 kernel (see splitk_epilogue_kernel)
-  int fsplit = 1;
-  if (!big && !ring && !persistent && a->layout != DM_TN && a->ab_dtype == DM_BF16 && ring_aligned && a->N % 8 == 0 &&
-      (a->residual == nullptr || a->ldr % 8 == 0) && a->workspace != nullptr) {
-    fsplit = fwd_split(a->M, a->N, a->K);
-    if ((int64_t)fsplit * a->M * a->N * 4 > slab_bytes) fsplit = 1;
-  }
-  if (fsplit > 1) {
-    p.tiles_m = (a->M + 127) / 128;
-    p.tiles_n = (a->N + 127) / 128;
-    int kps = ((a->K + fsplit - 1) / fsplit + 63) / 64 * 64;
-    split = (a->K + kps - 1) / kps;
-    p.split_k = split;
-    p.k_per_split = kps;
-    tile = 128;
-  } else if (!big && !ring && !persistent) {
+  if (!big && !ring && !persistent) {
     p.tiles_m = (a->M + tile - 1) / tile;
     p.tiles_n = (a->N + tile - 1) / tile;
     const int bk = (a->ab_dtype == DM_BF16) ? 64 : 32;
@@ -733,8 +681,6 @@ extern "C" int dm_gemm(const DmGemmArgs *a, void *stream) {
     p.colsum_slab = ((big || (w4 && a->layout == DM_TN)) && cs_region) ? cs_region : nullptr;
     if (w4) {
       dm_gemm_w4_launch(p, a->layout, w4, s);
-    } else if (p192) {
-      dm_gemm_p192_launch(p, a->layout, p192, s);
     } else if (ring) {
       dm_gemm_ring_launch(p, ring, s);
     } else if (big) {
@@ -748,13 +694,6 @@ extern "C" int dm_gemm(const DmGemmArgs *a, void *stream) {
   DM_LAUNCH_CHECK("dm_gemm");
   const bool cs_fused = big || (w4 && a->layout == DM_TN);      // these kernels produce the partial column sums of A themselves
   const int cs_rows_per_slice = big ? 4 : 2;
-  if (split > 1 && a->layout != DM_TN) {      // forward / dgrad slices: ordered sum + fused epilogue
-    const long long items = (long long)a->M * (a->N / 8);
-    const long long want = (items + 255) / 256;
-    hipLaunchKernelGGL(splitk_epilogue_kernel, dim3((unsigned)(want < 4096 ? want : 4096)), dim3(256), 0, s, p, split);
-    DM_LAUNCH_CHECK("dm_gemm(split-k epilogue)");
-    return DM_OK;
-  }
   if (split > 1) {
     const long long n4 = (long long)a->M * a->N / 4;
     const long long want = (n4 + 255) / 256;

@@ -69,19 +69,6 @@ def ring_env():
 
 
 @pytest.fixture
-def p192_env():
-    """Route every legal bf16 NT / NN product to the persistent 256x192 pipeline (dm_gemm_p192.hip) for one test."""
-    import os
-    old = os.environ.get("DM_GEMM_P192")
-    os.environ["DM_GEMM_P192"] = "2"
-    yield
-    if old is None:
-        os.environ.pop("DM_GEMM_P192", None)
-    else:
-        os.environ["DM_GEMM_P192"] = old
-
-
-@pytest.fixture
 def w4_env():
     """Route every legal bf16 NT / NN product to the 4-wave persistent kernel (dm_gemm_w4.hip) for one test."""
     import os
@@ -100,7 +87,7 @@ def w4_env():
 def test_gemm_w4_exact_integers(w4_env, layout, M, N, K):
     """Exact small-integer products through the 4-wave persistent kernel (register-staged operands, tiles chained into one K-step
     sequence): one to several tiles per workgroup, ragged M, 2 .. 48 K steps, both layouts of B."""
-    test_gemm_p192_exact_integers(None, layout, M, N, K)
+    _persistent_exact_integers(layout, M, N, K)
 
 
 @pytest.mark.parametrize("Mrows,N,K,acc", [(16384, 768, 768, True), (4096, 2304, 768, False), (16384, 3072, 768, True), (256, 256, 192, True),
@@ -142,11 +129,8 @@ def test_gemm_w4_epilogues(w4_env):
     test_gemm_epilogues("bf16", M=512, N=384)
 
 
-@pytest.mark.parametrize("layout", ["NT", "NN"])
-@pytest.mark.parametrize("M,N,K", [(256, 192, 128), (512, 384, 192), (1000, 192, 768), (16, 768, 3072), (4096, 2304, 768),
-                                   (66000, 192, 128), (33000, 384, 256), (16384, 768, 128)])
-def test_gemm_p192_exact_integers(p192_env, layout, M, N, K):
-    """Exact small-integer products through the persistent kernel: one to several tiles per workgroup (the flattened K-step
+def _persistent_exact_integers(layout, M, N, K):
+    """Exact small-integer products through a persistent kernel: one to several tiles per workgroup (the flattened K-step
     sequence crosses tile boundaries), ragged M, 2 .. 48 K steps, both operand layouts of B; fp32 and bf16 outputs."""
     ops = _ops()
     from deepmerge_amd._lib import DM_NN, DM_NT
@@ -163,10 +147,6 @@ def test_gemm_p192_exact_integers(p192_env, layout, M, N, K):
     Ch = torch.zeros((M, N), device=DEV, dtype=torch.bfloat16)
     ops.gemm(lay, A, B_, Ch, M, N, K, lda=K, ldb=ldb, ldc=N)
     assert torch.equal(Ch.cpu().double(), want.to(torch.bfloat16).double())
-
-
-def test_gemm_p192_epilogues(p192_env):
-    test_gemm_epilogues("bf16", M=512, N=384)
 
 
 @pytest.mark.parametrize("wm", [8, 4])
@@ -250,53 +230,6 @@ def test_gemm_epilogues(mode, M=192, N=256):
     ops.gemm(DM_NT, A, B_, cube[:, 36:], M, N, K, lda=K, ldb=K, ldc=N, rows_per_group=64, group_stride=100 * N)
     np.testing.assert_allclose(cube[:, 36:].cpu().double().numpy().reshape(M, N), base.numpy(), rtol=0, atol=2e-6)
     assert float(cube[:, :36].abs().max()) == 0.0
-
-
-@pytest.mark.parametrize("layout", ["NT", "NN"])
-@pytest.mark.parametrize("M,N,K", [(4096, 768, 3072), (1024, 768, 2304), (1000, 776, 2048)])
-def test_gemm_forward_split_k(layout, M, N, K):
-    """Forward / dgrad products whose 128x128 grid under-fills the chip and whose K is long are cut into K slices; the slices are summed in
-    order and sent through the fused epilogue by splitk_epilogue_kernel.  Exact in small integers (plain, fp32 and bf16 outputs), and the
-    bias + residual / GELU epilogues agree with float64."""
-    import os
-    ops = _ops()
-    from deepmerge_amd._lib import DM_EPI_GELU, DM_NN, DM_NT
-    old = os.environ.get("DM_GEMM_FWD_SPLIT")
-    os.environ["DM_GEMM_FWD_SPLIT"] = "1"
-    try:
-        _forward_split_body(ops, layout, M, N, K, DM_EPI_GELU, DM_NN, DM_NT)
-    finally:
-        if old is None:
-            os.environ.pop("DM_GEMM_FWD_SPLIT", None)
-        else:
-            os.environ["DM_GEMM_FWD_SPLIT"] = old
-
-
-def _forward_split_body(ops, layout, M, N, K, DM_EPI_GELU, DM_NN, DM_NT):
-    rng = np.random.default_rng(M + N + K)
-    a = _ints(rng, (M, K), -2, 3)
-    b = _ints(rng, (N, K) if layout == "NT" else (K, N), -2, 3)
-    want = a.double() @ (b.double().T if layout == "NT" else b.double())
-    A, B_ = a.to(DEV).to(torch.bfloat16), b.to(DEV).to(torch.bfloat16)
-    lay, ldb = (DM_NT, K) if layout == "NT" else (DM_NN, N)
-    C32 = torch.full((M + 2, N), float("nan"), device=DEV)
-    ops.gemm(lay, A, B_, C32, M, N, K, lda=K, ldb=ldb, ldc=N)
-    assert torch.equal(C32[:M].cpu().double(), want) and torch.isnan(C32[M:]).all()
-    C16 = torch.empty((M, N), device=DEV, dtype=torch.bfloat16)
-    ops.gemm(lay, A, B_, C16, M, N, K, lda=K, ldb=ldb, ldc=N)
-    assert torch.equal(C16.cpu().double(), want.to(torch.bfloat16).double())
-    bias = torch.from_numpy(rng.normal(size=N).astype(np.float32))
-    res = torch.from_numpy(rng.normal(size=(M, N)).astype(np.float32))
-    out = torch.empty((M, N), device=DEV)
-    As = (a * 0.0078125).to(DEV).to(torch.bfloat16)          # exact in bf16
-    ops.gemm(lay, As, B_, out, M, N, K, lda=K, ldb=ldb, ldc=N, bias=bias.to(DEV), residual=res.to(DEV))
-    np.testing.assert_allclose(out.cpu().double().numpy(), (want * 0.0078125 + bias.double() + res.double()).numpy(), rtol=0, atol=3e-5)
-    pre = torch.empty((M, N), device=DEV, dtype=torch.bfloat16)
-    h = torch.empty((M, N), device=DEV, dtype=torch.bfloat16)
-    ops.gemm(lay, As, B_, h, M, N, K, lda=K, ldb=ldb, ldc=N, bias=bias.to(DEV), epilogue=DM_EPI_GELU, aux=pre, ldaux=N)
-    u = want * 0.0078125 + bias.double()
-    np.testing.assert_allclose(h.float().cpu().double().numpy(), torch.nn.functional.gelu(u).numpy(), rtol=1.6e-2, atol=1.6e-2)
-    np.testing.assert_allclose(pre.float().cpu().double().numpy(), u.numpy(), rtol=1.6e-2, atol=1.6e-2)
 
 
 @pytest.mark.parametrize("mode", ["fp32", "bf16"])

@@ -24,8 +24,8 @@ def test_patch_pyramid_bit_exact_vs_oracle(rule):
     for t, lo, hi in ((32, 7, 90), (64, 20, 130), (128, 40, 200), (16, 1, 40)):
         wins = rng.integers(lo, hi, P).astype(np.int32)
         wins[0], wins[1] = t, 2 * t                                                   # identity and exact 2x box
-        wins[2], wins[3], wins[4], wins[5] = 3 * t, (4 * t + 2) // 3, (8 * t) // 5, max(1, (3 * t) // 4)    # 1/3, ~3/4, 5/8 shrinks; 4/3 enlarging
-        wins[6], wins[7] = max(1, t // 2), 4 * t                                      # exact 2x enlarging (replication under "opencv"), 1/4
+        wins[2], wins[3], wins[4], wins[5] = min(3 * t, 384), (4 * t + 2) // 3, (8 * t) // 5, max(1, (3 * t) // 4)    # 1/3, ~3/4, 5/8 shrinks; 4/3 enlarging
+        wins[6], wins[7] = max(1, t // 2), min(4 * t, 384)                                      # exact 2x enlarging (replication under "opencv"), 1/4
         got = ops.patch_pyramid(tile, torch.from_numpy(xy).to(DEV), torch.from_numpy(wins).to(DEV), t, resize=rule).cpu().numpy()
         for p in range(P):
             x0, y0 = OP.top_left(int(xy[p, 0]), int(xy[p, 1]), int(wins[p]))

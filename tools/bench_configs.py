@@ -43,15 +43,15 @@ def ev(fn, iters=10):
     return a.elapsed_time(b) / iters * 1e-3
 
 
-def config3(steps=10):
+def config3(steps=10, numerics="bf16"):
     from deepmerge_amd.Losses import Loss
     from deepmerge_amd.vit_model import vit_base_patch16_224_in21k
     B = 128
-    net = vit_base_patch16_224_in21k(num_classes=100, has_logits=False, numerics="bf16").to(DEV)
+    net = vit_base_patch16_224_in21k(num_classes=100, has_logits=False, numerics=numerics).to(DEV)
 
     class Pair(torch.nn.Module):      # adapt the 2-tensor pair signature to PairTrainer's 4-argument step
         def __init__(self, n):
-            super().__init__(); self.n = n; self.numerics = "bf16"
+            super().__init__(); self.n = n; self.numerics = numerics
         def forward(self, a, _1, b, _2):
             return self.n(a, b)
     tr = PairTrainer(Pair(net), margin=1.0, lr=1e-4)
@@ -60,23 +60,23 @@ def config3(steps=10):
     flag = (torch.arange(B) % 2).to(DEV)
     dt = timed(lambda: tr.step(x1, None, x2, None, flag), steps)
     gf = 210.6
-    return {"config": "3: ViT-B/16 pair encoder 224x224x3, 128 pairs/step, bf16, fwd+loss+bwd+Adam", "pairs_per_s": round(B / dt, 1),
+    return {"config": f"3: ViT-B/16 pair encoder 224x224x3, 128 pairs/step, {numerics}, fwd+loss+bwd+Adam, {steps} timed steps", "pairs_per_s": round(B / dt, 1),
             "ms_per_step": round(dt * 1e3, 2), "model_TFLOPs": round(B / dt * gf / 1e3, 1)}
 
 
-def config5(steps=8, graph=False, three_scale=False):
+def config5(steps=10, graph=False, three_scale=False, numerics="bf16"):
     """SURVEY 8d config 5 on one GPU: the 4-scale / 4-channel 256x256 variant (headline) or, three_scale=True, the reference's
     default 3-scale / 3-channel geometry (config.py: scales [32, 64, 128])."""
     from deepmerge_amd.nets.ShfitScaleFormer import ShfitScaleFormer_v3
     scales, in_c, depth, B = ([32, 64, 128], 3, [6, 4, 2], 120) if three_scale else ([32, 64, 128, 256], 4, [6, 4, 2], 120)
-    net = ShfitScaleFormer_v3(cube_size=[8, 8], input_image_scales=list(scales), depth=list(depth), in_c=in_c, numerics="bf16").to(DEV)
+    net = ShfitScaleFormer_v3(cube_size=[8, 8], input_image_scales=list(scales), depth=list(depth), in_c=in_c, numerics=numerics).to(DEV)
     tr = PairTrainer(net, margin=1.0, lr=1e-4)
     if graph:
         tr.enable_graph(warmup=1)
     batch = synth_batch(B, scales, in_c, DEV, 7)
     dt = timed(lambda: tr.step(*batch), steps, warm=3 if graph else 2)
     gf = pair_step_flops(scales, in_c, depth) / 1e9
-    return {"config": f"5 (1 GPU): v3 [6,4,2], {len(scales)} scales x {in_c} ch, 120 pairs/step, bf16, fwd+loss+bwd+Adam" + (", hipGraph replay" if graph else ""),
+    return {"config": f"5 (1 GPU): v3 [6,4,2], {len(scales)} scales x {in_c} ch, 120 pairs/step, {numerics}, fwd+loss+bwd+Adam, {steps} timed steps" + (", hipGraph replay" if graph else ""),
             "pairs_per_s": round(B / dt, 1), "ms_per_step": round(dt * 1e3, 2), "gflop_per_pair": round(gf, 1), "model_TFLOPs": round(B / dt * gf / 1e3, 1)}
 
 
@@ -85,21 +85,22 @@ def config4(passes=2):
     from deepmerge_amd.nets.ShfitScaleFormer import ShfitScaleFormer_v3
     from deepmerge_amd.patches import point_batch
     torch.manual_seed(0)
-    bands, H, W, side, k = 4, 4096, 4096, 141, 3
-    S = side * side
+    # SURVEY 8d geometry: a jittered-Voronoi superpixel raster (cell 29 px -> 142 x 142 = 20 164 superpixels on the 4096^2 tile), 3 sample
+    # points per superpixel around its seed, and the region-adjacency edges FROM the raster (deepmerge_amd.rag.rag_edges: ~59 k unique
+    # 4-neighbour label pairs) -- not a regular grid with its 2 S edges
+    from deepmerge_amd import rag
+    bands, H, W, k = 4, 4096, 4096, 3
+    lab, cy, cx, S = voronoi_raster(H, W, 29)
     tile = torch.randint(0, 256, (bands, H, W), dtype=torch.uint8, device=DEV)
     P = S * k
-    cell = H / side
-    sp = torch.arange(S)
-    cx = ((sp % side).float() + 0.5) * cell; cy = ((sp // side).float() + 0.5) * cell
-    xy = torch.stack([(cx[:, None] + torch.randint(-8, 9, (S, k))).reshape(-1), (cy[:, None] + torch.randint(-8, 9, (S, k))).reshape(-1)], 1)
+    xy = torch.stack([(cx.reshape(-1, 1).cpu() + torch.randint(-6, 7, (S, k))).reshape(-1), (cy.reshape(-1, 1).cpu() + torch.randint(-6, 7, (S, k))).reshape(-1)], 1)
     xy = xy.clamp(0, H - 1).to(torch.int32).to(DEV)
     inner = torch.randint(20, 29, (P,)); obj = inner + torch.randint(20, 29, (P,))
     feats = torch.rand(P, 15, device=DEV)
     ptr = (torch.arange(S + 1) * k).to(torch.int32).to(DEV); idx = torch.arange(P, dtype=torch.int32, device=DEV)
-    grid = torch.arange(S).reshape(side, side)
-    edges = torch.cat([torch.stack([grid[:, :-1].reshape(-1), grid[:, 1:].reshape(-1)], 1),
-                       torch.stack([grid[:-1].reshape(-1), grid[1:].reshape(-1)], 1)]).to(torch.int32).to(DEV)
+    edges, _w = rag.rag_edges(lab, S)
+    edges = edges.to(torch.int32).contiguous()
+    del lab
     net = ShfitScaleFormer_v3(cube_size=[8, 8], input_image_scales=[32, 64, 128], depth=[6, 4, 2], in_c=bands, numerics="bf16")
     fio = FeatureIO(net, None, DEV)
     bs = 2000
@@ -142,12 +143,10 @@ def config4(passes=2):
     return {"config": "4: ExtractFeatures pipeline, 4096x4096x4 tile", **out}
 
 
-def config4r():
-    """RAG + designed attributes from a 4096x4096 label raster (SURVEY 8f rank 2): HBM-bound integer passes."""
-    from deepmerge_amd import rag
-    torch.manual_seed(0)
-    bands, H, W, cell = 4, 4096, 4096, 29
-    gy = gx = (H + cell - 1) // cell
+def voronoi_raster(H, W, cell):
+    """Jittered-Voronoi label raster: one seed per cell x cell square (jittered inside its middle 60 %), every pixel takes the nearest of the
+    nine seeds around its square.  Returns (labels int32 [H, W], seed rows [gy, gx], seed columns [gy, gx], number of superpixels)."""
+    gy, gx = (H + cell - 1) // cell, (W + cell - 1) // cell
     cy = (torch.arange(gy, device=DEV)[:, None] + torch.rand(gy, gx, device=DEV) * 0.6 + 0.2) * cell
     cx = (torch.arange(gx, device=DEV)[None, :] + torch.rand(gy, gx, device=DEV) * 0.6 + 0.2) * cell
     yy, xx = torch.meshgrid(torch.arange(H, device=DEV), torch.arange(W, device=DEV), indexing="ij")
@@ -159,7 +158,15 @@ def config4r():
             d = (yy - cy[ny, nx]) ** 2 + (xx - cx[ny, nx]) ** 2
             upd = d < best
             best = torch.where(upd, d, best); lab = torch.where(upd, (ny * gx + nx).to(torch.int32), lab)
-    S = gy * gx
+    return lab, cy.clamp(0, H - 1), cx.clamp(0, W - 1), gy * gx
+
+
+def config4r():
+    """RAG + designed attributes from a 4096x4096 label raster (SURVEY 8f rank 2): HBM-bound integer passes."""
+    from deepmerge_amd import rag
+    torch.manual_seed(0)
+    bands, H, W, cell = 4, 4096, 4096, 29
+    lab, _cy, _cx, S = voronoi_raster(H, W, cell)
     tile = torch.randint(0, 256, (bands, H, W), dtype=torch.uint8, device=DEV)
     t_s = ev(lambda: rag.label_stats(lab, tile, S), 10)
     st = rag.label_stats(lab, tile, S)
