@@ -622,7 +622,10 @@ extern "C" int dm_attention_bwd(const void *qkv, const float *bias, const float 
     bool piped = false;
     if (dtype == DM_BF16) {
       AttnPipeBwdParams pp{qkv, bias, out, dout, lse, delta, dqkv, dbias_slab, B, N, H, scale};
-      piped = dm_attn_bwd_pipe(pp, s);
+      if (dm_attn_bwd_pipe_ok(pp)) {      // 32 rows per wave where those kernels take the pass (dm_attention_q32_bwd.hip), else 16
+        const bool dq = dm_attn_bwd_dq_q32(pp, s);
+        piped = (dq && dm_attn_bwd_dkv_q32(pp, s)) || dm_attn_bwd_pipe(pp, s, dq);
+      }
     }
     if (!piped) {
       if (dtype == DM_BF16) { dispatch<bf16_t>(1, p, s); dispatch<bf16_t>(2, p, s); }

@@ -33,5 +33,12 @@ struct AttnPipeBwdParams {
 
 // Number of batch chunks the pipelined backward uses (first dimension of `slab`); 0 if it does not take this shape.
 int dm_attn_bwd_pipe_chunks(int B, int N, int H, int dtype_is_bf16);
-// true if the pipelined dQ and dK/dV kernels took the call
-bool dm_attn_bwd_pipe(const AttnPipeBwdParams &p, hipStream_t s);
+// true if the pipelined dQ and dK/dV kernels take this shape (`dm_attn_bwd_pipe` would return true)
+bool dm_attn_bwd_pipe_ok(const AttnPipeBwdParams &p);
+// true if the pipelined kernels took the call; dq_done: dQ and delta are already written (dm_attn_bwd_dq_q32), only dK / dV (+ slab) run
+bool dm_attn_bwd_pipe(const AttnPipeBwdParams &p, hipStream_t s, bool dq_done = false);
+// dQ + delta with 32 query rows per wave (dm_attention_q32_bwd.hip): bf16, 128 < N <= 256; true if it took the call.  Call it only
+// where `dm_attn_bwd_pipe_ok` holds (the generic dQ kernel also produces the bias-gradient slab, this one does not).
+bool dm_attn_bwd_dq_q32(const AttnPipeBwdParams &p, hipStream_t s);
+// dK / dV with 32 keys per wave, bias-free shapes only (reads p.delta: run a dQ pass first); true if it took the call
+bool dm_attn_bwd_dkv_q32(const AttnPipeBwdParams &p, hipStream_t s);

@@ -726,7 +726,7 @@ inline void pipe_grid(int B, int N, int H, int &nblk, int &chunks, int &bchunk) 
   chunks = (B + bchunk - 1) / bchunk;
 }
 
-template <int NKT, bool RAGGED> void launch_bwd(const AttnPipeBwdParams &p, hipStream_t s) {
+template <int NKT, bool RAGGED> void launch_bwd(const AttnPipeBwdParams &p, hipStream_t s, bool dq_done) {
   constexpr int NP = NKT * 16;
   constexpr int LDS_DQ = 4 * NP * 128 + WB_BYTES, LDS_DKV = 2 * (2 * NP * 128 + 2048) + WB_BYTES;
   static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void *>(attn_bwd_dq_pipe_kernel<NKT, RAGGED>),
@@ -738,7 +738,8 @@ template <int NKT, bool RAGGED> void launch_bwd(const AttnPipeBwdParams &p, hipS
   (void)ok;
   int nblk, chunks, bchunk;
   pipe_grid(p.B, p.N, p.H, nblk, chunks, bchunk);
-  hipLaunchKernelGGL((attn_bwd_dq_pipe_kernel<NKT, RAGGED>), dim3(pipe_grid_size(nblk, p.H, chunks)), dim3(512), LDS_DQ, s, p, bchunk, nblk, pipe_xcd_map() ? chunks : -chunks);
+  if (!dq_done)       // (dQ and delta may already have been written by the 32-row kernel of dm_attention_q32_bwd.hip)
+    hipLaunchKernelGGL((attn_bwd_dq_pipe_kernel<NKT, RAGGED>), dim3(pipe_grid_size(nblk, p.H, chunks)), dim3(512), LDS_DQ, s, p, bchunk, nblk, pipe_xcd_map() ? chunks : -chunks);
   if (p.bias || p.slab)
     hipLaunchKernelGGL((attn_bwd_dkv_pipe_kernel<NKT, RAGGED, true>), dim3(pipe_grid_size(nblk, p.H, chunks)), dim3(512), LDS_DKV, s, p, bchunk, nblk, pipe_xcd_map() ? chunks : -chunks);
   else
@@ -805,18 +806,25 @@ int dm_attn_bwd_pipe_chunks(int B, int N, int H, int dtype_is_bf16) {
   return chunks;
 }
 
-bool dm_attn_bwd_pipe(const AttnPipeBwdParams &p, hipStream_t s) {
+bool dm_attn_bwd_pipe_ok(const AttnPipeBwdParams &p) {
   if (!pipe_shape_ok(p.B, p.N, p.H)) return false;
   bool ragged;
   const int nkt = pipe_tiles(p.N, ragged);
   // masked + bias (v5's N = 193): the dK/dV kernel would need > 256 registers (it spills); the generic kernels take it
   if (ragged && (p.bias || p.slab)) return false;
+  return nkt >= 8 && nkt <= 16 && nkt % 2 == 0;
+}
+
+bool dm_attn_bwd_pipe(const AttnPipeBwdParams &p, hipStream_t s, bool dq_done) {
+  if (!dm_attn_bwd_pipe_ok(p)) return false;
+  bool ragged;
+  const int nkt = pipe_tiles(p.N, ragged);
   switch (nkt) {
-    case 8: dmpipe::launch_bwd<8, false>(p, s); return true;
-    case 10: dmpipe::launch_bwd<10, true>(p, s); return true;
-    case 12: if (ragged) dmpipe::launch_bwd<12, true>(p, s); else dmpipe::launch_bwd<12, false>(p, s); return true;
-    case 14: dmpipe::launch_bwd<14, true>(p, s); return true;
-    case 16: if (ragged) dmpipe::launch_bwd<16, true>(p, s); else dmpipe::launch_bwd<16, false>(p, s); return true;
+    case 8: dmpipe::launch_bwd<8, false>(p, s, dq_done); return true;
+    case 10: dmpipe::launch_bwd<10, true>(p, s, dq_done); return true;
+    case 12: if (ragged) dmpipe::launch_bwd<12, true>(p, s, dq_done); else dmpipe::launch_bwd<12, false>(p, s, dq_done); return true;
+    case 14: dmpipe::launch_bwd<14, true>(p, s, dq_done); return true;
+    case 16: if (ragged) dmpipe::launch_bwd<16, true>(p, s, dq_done); else dmpipe::launch_bwd<16, false>(p, s, dq_done); return true;
     default: return false;
   }
 }

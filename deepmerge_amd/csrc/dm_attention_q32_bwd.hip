@@ -1,0 +1,662 @@
+// Attention backward, dQ pass, with 32 query rows per wave on the 32x32x16 bf16 MFMA (head dim 64, 128 < N <= 256), gfx950.
+// Same structure as the forward kernel of dm_attention_q32.hip (read its header first): the query sits on the MFMA lane, so the
+// per-row constants of the backward pass -- the forward's log-sum-exp and delta = rowsum(dO . O) -- are per-LANE scalars:
+//   S^T[key][query]   = K . Q^T  (+ bias / scale as the C operand)      A = K rows (LDS), B = Q rows from global memory
+//   dP^T[key][query]  = V . dO^T                                        A = V rows (LDS), B = dO rows from global memory
+//   P^T = exp2(scale2 S^T - lse log2e),  dS^T = P^T (dP^T - delta)      4 VALU instructions per score, no maximum, no row sum
+//   dQ^T[d][query]   += K^T . dS^T                                      A = K^T by transposed LDS reads, B = dS^T packed from registers
+// 12 MFMAs per 32-key tile.  K is read by rows AND transposed from ONE image: 16-byte chunk index XOR
+// x(key) = (((key >> 1) & 1) << 2) | ((key >> 2) & 3), conflict-free for both access patterns in the bank model of
+// MI355X_MICROARCH.md (checked by script); V uses the same layout (rows only).
+// Register classes: with a bias its 128 per-lane values AND the S^T tiles live in accumulator registers (the MFMA chain runs C = bias,
+// D = scores there; 16 v_accvgpr_read per tile bring a finished tile to the VALU), dP^T tiles are VGPRs; Q^T / dO^T fragments and dQ^T are
+// accumulator registers.  Without a bias (8-wave instances, 256 registers) everything the VALU touches is a VGPR.
+// delta is computed here from the O / dO rows (v_dot2c_f32_bf16 + one lane exchange) and stored for the dK / dV pass.
+#include "dm_attention_q32.h"
+
+#ifndef DMQ_ABL
+#define DMQ_ABL 0
+#endif
+
+namespace dmq32 {
+
+// scores in accumulator registers (the bias instances): C = bias (a), D (a); A = K fragment (v), B = Q^T fragment (a)
+__device__ __forceinline__ void qk_first_acc(f32x16 &d, const u32x4 &k, const u32x4 &q, const f32x16 &c) {
+  asm volatile(DMQ_MFMA " %0, %1, %2, %3" : "=&a"(d) : "v"(k), "a"(q), "a"(c));
+}
+__device__ __forceinline__ void qk_acc_acc(f32x16 &d, const u32x4 &k, const u32x4 &q) {
+  asm volatile(DMQ_MFMA " %0, %1, %2, %0" : "+a"(d) : "v"(k), "a"(q));
+}
+__device__ __forceinline__ void park_acc16(f32x16 &v) { asm volatile("" : "+a"(v)); }
+__device__ __forceinline__ float dot2(unsigned a, unsigned b, float c) {
+  return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, a), __builtin_bit_cast(bf16x2, b), c, false);
+}
+
+template <int NKT, bool RAGGED, bool BIAS, int NW>
+__global__ __launch_bounds__(64 * NW, NW / 4) void attn_bwd_dq_q32_kernel(const AttnPipeBwdParams p, int bchunk, int nblk, int chunks) {
+  constexpr int ROWS = 32 * NW;
+  constexpr int NP = NKT * 32;
+  const int N = RAGGED ? p.N : NP;
+  constexpr int IMG = NP * 128;
+  extern __shared__ __attribute__((aligned(16))) char smem[];      // [2 buffers][K image | V image] | NW x write-back block
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int r = lane & 31, hh = lane >> 5;
+  int h, rb, chunk;
+  if (!coords(nblk, p.H, chunks, h, rb, chunk)) return;
+  const int H = p.H;
+  const int b0 = chunk * bchunk, b1 = min(p.B, b0 + bchunk);
+  if (b0 >= b1) return;
+  const int q_wave = rb * ROWS + wave * 32;
+  const int q = q_wave + r;
+  const bool wave_live = q_wave < N;
+  const bool row_ok = q < N;
+  const long long tok_stride = 3LL * H * HD;
+  const bf16_t *qkv = reinterpret_cast<const bf16_t *>(p.qkv);
+  const bf16_t *outp = reinterpret_cast<const bf16_t *>(p.out);
+  const bf16_t *dout = reinterpret_cast<const bf16_t *>(p.dout);
+  constexpr float LOG2E = 1.4426950408889634f;
+  const float scale2 = p.scale * LOG2E;
+  constexpr bool QA = BIAS;                                         // Q^T / dO^T fragments in accumulator registers
+  constexpr bool PAD = NW == 8;
+  static_assert(!(BIAS && NW == 8), "the bias rows need the 512-register budget of one wave per SIMD");
+
+  // ---- C operands of each tile's first S^T MFMA: bias / scale (accumulator registers), or the key mask of the last tile ------------
+  constexpr int NC = BIAS ? NKT : (RAGGED ? 1 : 0);
+  f32x16 cinit[NC > 0 ? NC : 1];
+  if constexpr (BIAS) {
+    const float inv_scale = 1.f / p.scale;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int key = 32 * kt + 8 * c + 4 * hh;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (wave_live && row_ok && !(DMQ_ABL & 1)) {
+          const float *brow = p.bias + ((long long)h * N + q) * N + key;
+          if (!RAGGED) {
+            v = dm_load4(brow);
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (key + e < N) v[e] = brow[e];
+          }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) cinit[kt][4 * c + e] = (RAGGED && key + e >= N) ? NEG_BIG : v[e] * inv_scale;
+      }
+      park_acc16(cinit[kt]);
+    }
+  } else if constexpr (RAGGED) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) cinit[0][i] = (32 * (NKT - 1) + 8 * (i >> 2) + 4 * hh + (i & 3) >= N) ? NEG_BIG : 0.f;
+  }
+
+  // ---- DMA (waves 0..3; see the forward kernel): both images with the dual-use swizzle x(key), applied on the source chunk --------------
+  const int dkey = lane >> 3;
+  const unsigned rowoff0 = (unsigned)((8 * wave + dkey) * tok_stride * 2);
+  const unsigned src_swz = (unsigned)(((lane & 7) ^ ((((dkey >> 1) & 1) << 2) | ((((wave & 1) << 1) | (dkey >> 2)) & 3))) * 16);
+  const unsigned voffK = rowoff0 + (unsigned)(1 * H * HD * 2) + src_swz;
+  const unsigned voffV = rowoff0 + (unsigned)(2 * H * HD * 2) + src_swz;
+  const unsigned lds0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(uintptr_t)(DM_LDS char *)smem);
+  unsigned step_bytes = (unsigned)__builtin_amdgcn_readfirstlane((int)(32 * tok_stride * 2));
+  asm volatile("s_nop 4" : "+s"(step_bytes));
+  auto sample_rsrc = [&](int b) -> i32x4 {
+    const uintptr_t base = reinterpret_cast<uintptr_t>(qkv + (long long)b * N * tok_stride + (long long)h * HD);
+    i32x4 rs;
+    rs[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)(base & 0xffffffffu));
+    rs[1] = __builtin_amdgcn_readfirstlane((int)(unsigned)((base >> 32) & 0xffffu));
+    rs[2] = __builtin_amdgcn_readfirstlane((int)(N * tok_stride * 2));
+    rs[3] = 0x00020000;
+    asm volatile("s_nop 4" : "+s"(rs));
+    return rs;
+  };
+  const bool dma_wave = wave < 4;
+  auto stage_piece = [&](const i32x4 &rs, int buf, int j) {
+    if ((DMQ_ABL & 2) || !dma_wave) return;
+    const unsigned kimg = lds0 + (unsigned)(buf * (2 * IMG)) + (unsigned)wave * 1024u, vimg = kimg + (unsigned)IMG;
+    lds_dma(rs, kimg + (unsigned)j * 4096u, voffK, (unsigned)j * step_bytes);
+    lds_dma(rs, vimg + (unsigned)j * 4096u, voffV, (unsigned)j * step_bytes);
+  };
+  auto stage_all = [&](int b, int buf) {
+    if (!dma_wave) return;
+    const i32x4 rs = sample_rsrc(b);
+#pragma unroll
+    for (int j = 0; j < NKT; ++j) stage_piece(rs, buf, j);
+  };
+  // this lane's rows of the next sample: Q and dO fragments (B operands: d = 16 ks + 8 hh .. + 7), the O fragment for delta, lse
+  auto load_rows = [&](int b, u32x4 (&fq)[4], u32x4 (&fdo)[4], u32x4 (&fo)[4], float &lse) {
+    const bool ok = wave_live && row_ok && !(DMQ_ABL & 64);
+    const bf16_t *qrow = qkv + ((long long)b * N + q) * tok_stride + (long long)h * HD + 8 * hh;
+    const long long orow = ((long long)b * N + q) * H * HD + (long long)h * HD + 8 * hh;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      fq[ks] = ok ? *reinterpret_cast<const u32x4 *>(qrow + 16 * ks) : (u32x4){0u, 0u, 0u, 0u};
+      fdo[ks] = ok ? *reinterpret_cast<const u32x4 *>(dout + orow + 16 * ks) : (u32x4){0u, 0u, 0u, 0u};
+      fo[ks] = ok ? *reinterpret_cast<const u32x4 *>(outp + orow + 16 * ks) : (u32x4){0u, 0u, 0u, 0u};
+    }
+    lse = ok ? p.lse[((long long)b * H + h) * N + q] : 0.f;
+  };
+
+  // ---- fragment offsets ---------------------------------------------------------------------------------------------------------
+  const int xr = (((r >> 1) & 1) << 2) | ((r >> 2) & 3);            // x(key) of row r of a 32-key tile (32 kt does not change it)
+  int roff[4];                                                      // K / V rows: + 4096 kt
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) roff[ks] = r * 128 + (((2 * ks + hh) ^ xr) << 4);
+  // K^T by transposed reads: lane 4 qd + pp of a 16-lane group addresses key row 4 hh + qd (+ 8 j2 + 16 s + 32 kt), d columns
+  // 32 dt + 16 e + 4 pp .. + 3; x(key) = ((qd >> 1) << 2) | ((2 j2 + hh) & 3)
+  const int ve = (lane >> 4) & 1, qd = (lane >> 2) & 3, pp = lane & 3;
+  int toff[2][2];                                                   // [dt][j2]: + (32 kt + 16 s) * 128
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int j2 = 0; j2 < 2; ++j2) {
+      const int x = ((qd >> 1) << 2) | ((2 * j2 + hh) & 3);
+      toff[dt][j2] = (8 * j2 + 4 * hh + qd) * 128 + (((4 * dt + 2 * ve + (pp >> 1)) ^ x) << 4) + 8 * (pp & 1);
+    }
+
+  char *wb = smem + 4 * IMG + wave * WB_WAVE;
+  u32x4 fl_v = {0u, 0u, 0u, 0u};
+  auto flush_read = [&](int k) {
+    if (!wave_live || (DMQ_ABL & 32)) return;
+    fl_v = *reinterpret_cast<const u32x4 *>(wb + ((lane >> 3) + 8 * k) * WB_PITCH + (lane & 7) * 16);
+  };
+  auto flush_store = [&](int b, int k) {                            // dQ rows of sample b: dqkv[b][q][0][h][:]
+    if (!wave_live || (DMQ_ABL & 32)) return;
+    bf16_t *drow0 = reinterpret_cast<bf16_t *>(p.dqkv) + ((long long)b * N + q_wave) * tok_stride + (long long)h * HD;
+    const int rr = lane >> 3, cc = lane & 7;
+    if (q_wave + rr + 8 * k < N) *reinterpret_cast<u32x4 *>(drow0 + (long long)(rr + 8 * k) * tok_stride + cc * 8) = fl_v;
+  };
+
+  u32x4 qf[4], dof[4], qld[4], dold[4], old[4];
+  float lse_ld = 0.f;
+  stage_all(b0, 0);
+  load_rows(b0, qld, dold, old, lse_ld);
+  for (int b = b0; b < b1; ++b) {
+    const int buf = (b - b0) & 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    const bool more = b + 1 < b1;
+    // ---- per-row constants of this sample: delta = rowsum(dO . O) over both lane halves, -lse in log2 units ---------------------------
+    float dl = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+      for (int w = 0; w < 4; ++w) dl = dot2(dold[ks][w], old[ks][w], dl);
+    const float delta = half_sum(dl);
+    const float nl = -lse_ld * LOG2E;
+    if (wave_live && row_ok && hh == 0) p.delta[((long long)b * H + h) * N + q] = delta;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      qf[ks] = qld[ks];
+      dof[ks] = dold[ks];
+      if constexpr (QA) { park_acc(qf[ks]); park_acc(dof[ks]); }
+    }
+    i32x4 rs_next = {0, 0, 0, 0};
+    if (more) rs_next = sample_rsrc(b + 1);
+    const char *kimg = smem + buf * (2 * IMG), *vimg = kimg + IMG;
+
+    if (wave_live) {
+      f32x16 s0, s1, dp0, dp1;                                       // S^T and dP^T tiles of even / odd key tiles
+      u32x4 dsb0[2], dsb1[2];                                        // packed dS^T of even / odd tiles, k-steps 0 / 1
+      u32x4 kf[4], vf[4];
+      u32x2 tf[8];
+      f32x16 dq0, dq1;
+      auto read_k = [&](int kt) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) kf[ks] = *reinterpret_cast<const u32x4 *>(kimg + kt * 4096 + roff[ks]);
+      };
+      auto read_v = [&](int kt) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) vf[ks] = *reinterpret_cast<const u32x4 *>(vimg + kt * 4096 + roff[ks]);
+      };
+      auto read_t = [&](int kt) {
+#pragma unroll
+        for (int sx = 0; sx < 2; ++sx)
+#pragma unroll
+          for (int dt = 0; dt < 2; ++dt) {
+            const char *a = kimg + (32 * kt + 16 * sx) * 128;
+            tf[4 * sx + 2 * dt] = dm_ds_read_tr16(a + toff[dt][0]);
+            tf[4 * sx + 2 * dt + 1] = dm_ds_read_tr16(a + toff[dt][1]);
+          }
+      };
+      auto tfrag = [&](int sx, int dt) { return (u32x4){tf[4 * sx + 2 * dt][0], tf[4 * sx + 2 * dt][1], tf[4 * sx + 2 * dt + 1][0], tf[4 * sx + 2 * dt + 1][1]}; };
+      auto s_piece = [&](int kt, int ks, f32x16 &d) {
+        if ((DMQ_ABL & 16) && kt > 0) return;
+        if constexpr (BIAS) {
+          if (ks == 0) qk_first_acc(d, kf[0], qf[0], cinit[kt]); else qk_acc_acc(d, kf[ks], qf[ks]);
+        } else {
+          if (ks == 0) {
+            if (RAGGED && kt == NKT - 1) qk_first<QA, PAD>(d, kf[0], qf[0], cinit[0]); else qk_first0<QA, PAD>(d, kf[0], qf[0]);
+          } else {
+            qk_acc<QA, PAD>(d, kf[ks], qf[ks]);
+          }
+        }
+      };
+      auto dp_piece = [&](int kt, int ks, f32x16 &d) {
+        if ((DMQ_ABL & 16) && kt > 0) return;
+        if (ks == 0) qk_first0<QA, PAD>(d, vf[0], dof[0]); else qk_acc<QA, PAD>(d, vf[ks], dof[ks]);
+      };
+      auto dq_piece = [&](int kt, int g, const u32x4 (&dsb)[2]) {
+        const int sx = g >> 1, dt = g & 1;
+        f32x16 &o = dt ? dq1 : dq0;
+        if ((DMQ_ABL & 8) && kt > 0) return;
+        if (kt == 0 && sx == 0) pv_first<PAD>(o, tfrag(0, dt), dsb[0]); else pv_acc<PAD>(o, tfrag(sx, dt), dsb[sx]);
+      };
+      // VALU piece k (0..7) of a tile: scores 2k, 2k + 1 -> P, dS = P (dP - delta), one packed pair
+      auto ds_piece = [&](const f32x16 &sc, const f32x16 &dp, int k, u32x4 (&dsb)[2]) {
+        if (DMQ_ABL & 4) { dsb[k >> 2][k & 3] = 0x3f803f80u; return; }
+        const float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[2 * k], scale2, nl));
+        const float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[2 * k + 1], scale2, nl));
+        const unsigned w = pk_bf16(p0 * (dp[2 * k] - delta), p1 * (dp[2 * k + 1] - delta));
+        dsb[k >> 2][k & 3] = w;
+        asm volatile("" :: "v"(w));                                  // this piece's arithmetic stays in ITS gap
+      };
+
+      if constexpr (NW == 4) {
+        // ---- prologue: S^T and dP^T of tile 0 -------------------------------------------------------------------------------------------
+        read_k(0);
+        read_v(0);
+        asm volatile("s_nop 1");                                       // the fragment copies into accumulator registers may be fresh
+        s_piece(0, 0, s0); s_piece(0, 1, s0); s_piece(0, 2, s0); s_piece(0, 3, s0);
+        dp_piece(0, 0, dp0); dp_piece(0, 1, dp0); dp_piece(0, 2, dp0); dp_piece(0, 3, dp0);
+        if (NKT > 1) { read_k(1); read_v(1); }
+        if constexpr (BIAS) asm volatile("s_nop 15\n\ts_nop 7" : "+a"(s0), "+v"(dp0)); else asm volatile("s_nop 15\n\ts_nop 7" : "+v"(s0), "+v"(dp0));
+  #pragma unroll
+        for (int j = 0; j < NKT; ++j) {
+          // iteration j, twelve MFMA gaps: S^T(j + 1) x 4, dP^T(j + 1) x 4, dQ^T(j - 1) x 4, with tile j's VALU pieces in the first eight
+          f32x16 &sc = (j & 1) ? s1 : s0;
+          f32x16 &sn = (j & 1) ? s0 : s1;
+          f32x16 &dpc = (j & 1) ? dp1 : dp0;
+          f32x16 &dpn = (j & 1) ? dp0 : dp1;
+          u32x4 (&dsc)[2] = (j & 1) ? dsb1 : dsb0;
+          u32x4 (&dsp)[2] = (j & 1) ? dsb0 : dsb1;
+          // tile j's tiles are read below this point only: their last MFMA was issued at least four MFMAs ago (MFMA D -> VALU distance)
+          if constexpr (BIAS) asm volatile("" : "+a"(sc), "+v"(dpc)); else asm volatile("" : "+v"(sc), "+v"(dpc));
+          if (j > 0) read_t(j - 1);
+          __builtin_amdgcn_sched_barrier(0);
+  #pragma unroll
+          for (int g = 0; g < 12; ++g) {
+            if (g < 4) {
+              if (j + 1 < NKT) s_piece(j + 1, g, sn);
+            } else if (g < 8) {
+              if (j + 1 < NKT) dp_piece(j + 1, g - 4, dpn);
+            } else {
+              if (j > 0) dq_piece(j - 1, g - 8, dsp);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (g < 8) ds_piece(sc, dpc, g, dsc);
+            if (g == 3 && j + 2 < NKT) read_k(j + 2);
+            if (g == 7 && j + 2 < NKT) read_v(j + 2);
+            if (g == 8 && more && j == NKT - 2) load_rows(b + 1, qld, dold, old, lse_ld);       // (all S^T / dP^T MFMAs of this sample are issued)
+            if (g == 1 && b > b0 && j >= NKT - 4) flush_read(j - (NKT - 4));
+            if (g == 9 && b > b0 && j >= NKT - 4) flush_store(b - 1, j - (NKT - 4));
+            if (g == 5 && more) {
+              if (j < NKT - 1) stage_piece(rs_next, buf ^ 1, j);
+              if (j == 0) stage_piece(rs_next, buf ^ 1, NKT - 1);
+            }
+            if (g < 4) {
+              if (j + 1 < NKT) asm volatile("" :: "v"(kf[g]));
+            } else if (g < 8) {
+              if (j + 1 < NKT) asm volatile("" :: "v"(vf[g - 4]));
+            } else {
+              if (j > 0) asm volatile("" :: "v"(tf[2 * (g - 8)]), "v"(tf[2 * (g - 8) + 1]), "v"(dsp[(g - 8) >> 1]));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+        // ---- epilogue: dQ^T of the last tile --------------------------------------------------------------------------------------------
+        read_t(NKT - 1);
+        u32x4 (&dsl)[2] = ((NKT - 1) & 1) ? dsb1 : dsb0;
+        asm volatile("s_nop 1");
+#pragma unroll
+        for (int g = 0; g < 4; ++g) dq_piece(NKT - 1, g, dsl);
+        asm volatile("s_nop 15\n\ts_nop 7" : "+a"(dq0), "+a"(dq1) : "v"(dsl[0]), "v"(dsl[1]));
+      } else {
+        // Two waves per SIMD: the partner wave fills this wave's gaps, so a tile runs start to end (S^T, dP^T, the VALU pieces, dQ^T)
+        // with ONE score / dP / dS tile live -- the software-pipelined form above needs 276-300 registers, this one fits 256.
+#pragma unroll
+        for (int j = 0; j < NKT; ++j) {
+          read_k(j);
+          read_v(j);
+          read_t(j);
+          if (j == 0) asm volatile("s_nop 1");
+          s_piece(j, 0, s0); s_piece(j, 1, s0); s_piece(j, 2, s0); s_piece(j, 3, s0);
+          dp_piece(j, 0, dp0); dp_piece(j, 1, dp0); dp_piece(j, 2, dp0); dp_piece(j, 3, dp0);
+          if (b > b0 && j >= NKT - 4) flush_read(j - (NKT - 4));
+          if (more) {
+            if (j < NKT - 1) stage_piece(rs_next, buf ^ 1, j);
+            if (j == 0) stage_piece(rs_next, buf ^ 1, NKT - 1);
+          }
+          if (more && j == NKT - 1) load_rows(b + 1, qld, dold, old, lse_ld);
+          asm volatile("s_nop 15\n\ts_nop 7" : "+v"(s0), "+v"(dp0) : "v"(kf[3]), "v"(vf[0]), "v"(vf[1]), "v"(vf[2]), "v"(vf[3]));
+#pragma unroll
+          for (int k = 0; k < 8; ++k) ds_piece(s0, dp0, k, dsb0);
+          if (b > b0 && j >= NKT - 4) flush_store(b - 1, j - (NKT - 4));
+#pragma unroll
+          for (int g = 0; g < 4; ++g) dq_piece(j, g, dsb0);
+          asm volatile("" :: "v"(tf[0]), "v"(tf[1]), "v"(tf[2]), "v"(tf[3]), "v"(tf[4]), "v"(tf[5]), "v"(tf[6]), "v"(tf[7]), "v"(dsb0[0]), "v"(dsb0[1]));
+        }
+        asm volatile("s_nop 15\n\ts_nop 7" : "+a"(dq0), "+a"(dq1));
+      }
+      // ---- scale, park the rows in the wave's LDS block ---------------------------------------------------------------------------------
+      const float sc_out = p.scale;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const u32x2 w0 = {pk_bf16(dq0[4 * c] * sc_out, dq0[4 * c + 1] * sc_out), pk_bf16(dq0[4 * c + 2] * sc_out, dq0[4 * c + 3] * sc_out)};
+        const u32x2 w1 = {pk_bf16(dq1[4 * c] * sc_out, dq1[4 * c + 1] * sc_out), pk_bf16(dq1[4 * c + 2] * sc_out, dq1[4 * c + 3] * sc_out)};
+        *reinterpret_cast<u32x2 *>(wb + r * WB_PITCH + (8 * c + 4 * hh) * 2) = w0;
+        *reinterpret_cast<u32x2 *>(wb + r * WB_PITCH + (32 + 8 * c + 4 * hh) * 2) = w1;
+      }
+    } else if (more) {
+      stage_all(b + 1, buf ^ 1);
+      load_rows(b + 1, qld, dold, old, lse_ld);
+    }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { flush_read(k); flush_store(b1 - 1, k); }
+}
+
+// ---- dK / dV pass without a bias (ViT: vit_model.py:125-131), 32 KEYS per wave: the key sits on the MFMA lane -------------------------
+//   S[query][key]  = Q . K^T - lse / scale        A = Q rows (LDS), B = K rows from global memory (lane = key), C = per-query constants
+//   dP[query][key] = dO . V^T - delta             A = dO rows (LDS), B = V rows from global memory,            C = per-query constants
+//   P = exp2(scale2 S),  dS = P dP                 3 VALU instructions per score + two packs
+//   dV^T[d][key] += dO^T . P,  dK^T[d][key] += Q^T . dS      A by transposed reads of the SAME two images, B = P / dS packed from registers
+// The per-query constants (-lse / scale, -delta; -1e30 / 0 for queries >= N) are staged per sample in a small LDS table and reach the
+// accumulators as the C operand: 4 + 4 broadcast ds_read_b128 per tile, no VALU.  16 MFMAs per 32-query tile.  Two waves per SIMD
+// (8 waves, 256 keys per workgroup) wherever the images fit; a tile runs start to end, the partner wave fills the gaps.
+// With a bias the 16-row kernels of dm_attention_pipe.hip keep the pass: the transposed bias rows AND the dS accumulator of the
+// bias-table gradient are 128 registers each per 32 keys.
+template <int NKT, bool RAGGED, int NW>
+__global__ __launch_bounds__(64 * NW, NW / 4) void attn_bwd_dkv_q32_kernel(const AttnPipeBwdParams p, int bchunk, int nblk, int chunks) {
+  constexpr int ROWS = 32 * NW;
+  constexpr int NP = NKT * 32;
+  const int N = RAGGED ? p.N : NP;
+  constexpr int IMG = NP * 128;
+  constexpr int STAT = 2 * NP * 4;                                  // [-lse / scale | -delta] per buffer
+  extern __shared__ __attribute__((aligned(16))) char smem[];      // [2 buffers][Q image | dO image] | [2 buffers] stat | NW x write-back block
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int r = lane & 31, hh = lane >> 5;
+  int h, rb, chunk;
+  if (!coords(nblk, p.H, chunks, h, rb, chunk)) return;
+  const int H = p.H;
+  const int b0 = chunk * bchunk, b1 = min(p.B, b0 + bchunk);
+  if (b0 >= b1) return;
+  const int k_wave = rb * ROWS + wave * 32;
+  const int key = k_wave + r;                                       // this lane's key row
+  const bool wave_live = k_wave < N;
+  const bool row_ok = key < N;
+  const long long tok_stride = 3LL * H * HD, out_stride = (long long)H * HD;
+  const bf16_t *qkv = reinterpret_cast<const bf16_t *>(p.qkv);
+  const bf16_t *dout = reinterpret_cast<const bf16_t *>(p.dout);
+  constexpr float LOG2E = 1.4426950408889634f;
+  const float scale2 = p.scale * LOG2E;
+  const float inv_scale = 1.f / p.scale;
+  constexpr bool PAD = NW == 8;
+
+  // ---- DMA (waves 0..3): Q rows of qkv and dO rows, both with the dual-use swizzle ---------------------------------------------------------
+  const int dkey = lane >> 3;
+  const unsigned src_swz = (unsigned)(((lane & 7) ^ ((((dkey >> 1) & 1) << 2) | ((((wave & 1) << 1) | (dkey >> 2)) & 3))) * 16);
+  const unsigned voffQ = (unsigned)((8 * wave + dkey) * tok_stride * 2) + src_swz;
+  const unsigned voffD = (unsigned)((8 * wave + dkey) * out_stride * 2) + src_swz;
+  const unsigned lds0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(uintptr_t)(DM_LDS char *)smem);
+  unsigned stepQ = (unsigned)__builtin_amdgcn_readfirstlane((int)(32 * tok_stride * 2));
+  unsigned stepD = (unsigned)__builtin_amdgcn_readfirstlane((int)(32 * out_stride * 2));
+  asm volatile("s_nop 4" : "+s"(stepQ), "+s"(stepD));
+  auto make_rsrc = [&](const bf16_t *base, long long bytes) -> i32x4 {
+    const uintptr_t a = reinterpret_cast<uintptr_t>(base);
+    i32x4 rs;
+    rs[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)(a & 0xffffffffu));
+    rs[1] = __builtin_amdgcn_readfirstlane((int)(unsigned)((a >> 32) & 0xffffu));
+    rs[2] = __builtin_amdgcn_readfirstlane((int)bytes);
+    rs[3] = 0x00020000;
+    asm volatile("s_nop 4" : "+s"(rs));
+    return rs;
+  };
+  const bool dma_wave = wave < 4;
+  auto stage_piece = [&](const i32x4 &rsq, const i32x4 &rsd, int buf, int j) {
+    if (!dma_wave) return;
+    const unsigned qimg = lds0 + (unsigned)(buf * (2 * IMG)) + (unsigned)wave * 1024u, dimg = qimg + (unsigned)IMG;
+    lds_dma(rsq, qimg + (unsigned)j * 4096u, voffQ, (unsigned)j * stepQ);
+    lds_dma(rsd, dimg + (unsigned)j * 4096u, voffD, (unsigned)j * stepD);
+  };
+  auto rsrc_q = [&](int b) { return make_rsrc(qkv + (long long)b * N * tok_stride + (long long)h * HD, N * tok_stride * 2); };
+  auto rsrc_d = [&](int b) { return make_rsrc(dout + (long long)b * N * out_stride + (long long)h * HD, N * out_stride * 2); };
+  // this lane's K / V rows of a sample (B operands: d = 16 ks + 8 hh .. + 7) and, for the first 64 * 4 lanes of the workgroup, one
+  // query's lse / delta for the stat table
+  const int sq = (wave & 3) * 64 + lane;                            // the query whose constants this lane stages (waves 0..3)
+  auto load_rows = [&](int b, u32x4 (&fk)[4], u32x4 (&fv)[4], float &lse, float &dl) {
+    const bool ok = wave_live && row_ok;
+    const bf16_t *krow = qkv + ((long long)b * N + key) * tok_stride + (long long)(H + h) * HD + 8 * hh;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      fk[ks] = ok ? *reinterpret_cast<const u32x4 *>(krow + 16 * ks) : (u32x4){0u, 0u, 0u, 0u};
+      fv[ks] = ok ? *reinterpret_cast<const u32x4 *>(krow + (long long)H * HD + 16 * ks) : (u32x4){0u, 0u, 0u, 0u};
+    }
+    const bool sok = dma_wave && sq < N;
+    lse = sok ? p.lse[((long long)b * H + h) * N + sq] : 0.f;
+    dl = sok ? p.delta[((long long)b * H + h) * N + sq] : 0.f;
+  };
+
+  // ---- fragment offsets (the dual-use image of the dQ kernel, rows = queries here) -------------------------------------------------------
+  const int xr = (((r >> 1) & 1) << 2) | ((r >> 2) & 3);
+  int roff[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) roff[ks] = r * 128 + (((2 * ks + hh) ^ xr) << 4);
+  const int ve = (lane >> 4) & 1, qd = (lane >> 2) & 3, pp = lane & 3;
+  int toff[2][2];
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int j2 = 0; j2 < 2; ++j2) {
+      const int x = ((qd >> 1) << 2) | ((2 * j2 + hh) & 3);
+      toff[dt][j2] = (8 * j2 + 4 * hh + qd) * 128 + (((4 * dt + 2 * ve + (pp >> 1)) ^ x) << 4) + 8 * (pp & 1);
+    }
+  char *stat0 = smem + 4 * IMG;
+  char *wb = smem + 4 * IMG + 2 * STAT + wave * WB_WAVE;
+
+  u32x4 kfr[4], vfr[4], kld[4], vld[4];
+  float lse_ld = 0.f, dl_ld = 0.f;
+  if (dma_wave) {
+    const i32x4 rq = rsrc_q(b0), rd = rsrc_d(b0);
+#pragma unroll
+    for (int j = 0; j < NKT; ++j) stage_piece(rq, rd, 0, j);
+  }
+  load_rows(b0, kld, vld, lse_ld, dl_ld);
+  for (int b = b0; b < b1; ++b) {
+    const int buf = (b - b0) & 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // this sample's per-query constants into its stat buffer (queries >= N: no probability, no gradient)
+    if (dma_wave && sq < NP) {
+      float *st = reinterpret_cast<float *>(stat0 + buf * STAT);
+      st[sq] = sq < N ? -lse_ld * inv_scale : NEG_BIG;
+      st[NP + sq] = sq < N ? -dl_ld : 0.f;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              // the table entries are in LDS before the barrier releases their readers
+    __builtin_amdgcn_s_barrier();
+    const bool more = b + 1 < b1;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) { kfr[ks] = kld[ks]; vfr[ks] = vld[ks]; }
+    i32x4 rq_next = {0, 0, 0, 0}, rd_next = {0, 0, 0, 0};
+    if (more && dma_wave) { rq_next = rsrc_q(b + 1); rd_next = rsrc_d(b + 1); }
+    const char *qimg = smem + buf * (2 * IMG), *dimg = qimg + IMG;
+    const char *stat = stat0 + buf * STAT;
+
+    if (wave_live) {
+      f32x16 sc, dp;
+      u32x4 pb[2], dsb[2];
+      u32x4 qf[4], df[4];
+      u32x2 qt[8], dtf[8];
+      f32x16 dk0, dk1, dv0, dv1;
+#pragma unroll
+      for (int j = 0; j < NKT; ++j) {
+        // C operands: -lse / scale and -delta of this lane half's 16 queries of the tile, straight into the accumulators
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const f32x4 a = *reinterpret_cast<const f32x4 *>(stat + (32 * j + 8 * c + 4 * hh) * 4);
+          const f32x4 d = *reinterpret_cast<const f32x4 *>(stat + (NP + 32 * j + 8 * c + 4 * hh) * 4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { sc[4 * c + e] = a[e]; dp[4 * c + e] = d[e]; }
+        }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          qf[ks] = *reinterpret_cast<const u32x4 *>(qimg + j * 4096 + roff[ks]);
+          df[ks] = *reinterpret_cast<const u32x4 *>(dimg + j * 4096 + roff[ks]);
+        }
+#pragma unroll
+        for (int sx = 0; sx < 2; ++sx)
+#pragma unroll
+          for (int dt = 0; dt < 2; ++dt) {
+            const int o = (32 * j + 16 * sx) * 128;
+            qt[4 * sx + 2 * dt] = dm_ds_read_tr16(qimg + o + toff[dt][0]);
+            qt[4 * sx + 2 * dt + 1] = dm_ds_read_tr16(qimg + o + toff[dt][1]);
+            dtf[4 * sx + 2 * dt] = dm_ds_read_tr16(dimg + o + toff[dt][0]);
+            dtf[4 * sx + 2 * dt + 1] = dm_ds_read_tr16(dimg + o + toff[dt][1]);
+          }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) qk_acc<false, true>(sc, qf[ks], kfr[ks]);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) qk_acc<false, true>(dp, df[ks], vfr[ks]);
+        if (more && j < NKT - 1) stage_piece(rq_next, rd_next, buf ^ 1, j);
+        if (more && j == 0) stage_piece(rq_next, rd_next, buf ^ 1, NKT - 1);
+        if (more && j == NKT - 1) load_rows(b + 1, kld, vld, lse_ld, dl_ld);
+        asm volatile("s_nop 15\n\ts_nop 7" : "+v"(sc), "+v"(dp) : "v"(qf[3]), "v"(df[0]), "v"(df[1]), "v"(df[2]), "v"(df[3]));
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const float p0 = __builtin_amdgcn_exp2f(sc[2 * k] * scale2), p1 = __builtin_amdgcn_exp2f(sc[2 * k + 1] * scale2);
+          pb[k >> 2][k & 3] = pk_bf16(p0, p1);
+          dsb[k >> 2][k & 3] = pk_bf16(p0 * dp[2 * k], p1 * dp[2 * k + 1]);
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int sx = g >> 1, dt = g & 1;
+          const u32x4 fa = {dtf[4 * sx + 2 * dt][0], dtf[4 * sx + 2 * dt][1], dtf[4 * sx + 2 * dt + 1][0], dtf[4 * sx + 2 * dt + 1][1]};
+          const u32x4 fb = {qt[4 * sx + 2 * dt][0], qt[4 * sx + 2 * dt][1], qt[4 * sx + 2 * dt + 1][0], qt[4 * sx + 2 * dt + 1][1]};
+          f32x16 &dv = dt ? dv1 : dv0;
+          f32x16 &dk = dt ? dk1 : dk0;
+          if (j == 0 && sx == 0) { pv_first<true>(dv, fa, pb[0]); pv_first<true>(dk, fb, dsb[0]); }
+          else { pv_acc<true>(dv, fa, pb[sx]); pv_acc<true>(dk, fb, dsb[sx]); }
+        }
+        asm volatile("" :: "v"(qt[0]), "v"(qt[1]), "v"(qt[2]), "v"(qt[3]), "v"(qt[4]), "v"(qt[5]), "v"(qt[6]), "v"(qt[7]),
+                     "v"(dtf[0]), "v"(dtf[1]), "v"(dtf[2]), "v"(dtf[3]), "v"(dtf[4]), "v"(dtf[5]), "v"(dtf[6]), "v"(dtf[7]),
+                     "v"(pb[0]), "v"(pb[1]), "v"(dsb[0]), "v"(dsb[1]));
+      }
+      asm volatile("s_nop 15\n\ts_nop 7" : "+a"(dk0), "+a"(dk1), "+a"(dv0), "+a"(dv1));
+      // ---- rows of this wave's keys: dK (scaled) then dV through the wave's LDS block, eight whole 128-byte rows per store instruction ----
+      const int rr = lane >> 3, cc = lane & 7;
+#pragma unroll
+      for (int which = 0; which < 2; ++which) {
+        const f32x16 &a0 = which ? dv0 : dk0;
+        const f32x16 &a1 = which ? dv1 : dk1;
+        const float f = which ? 1.f : p.scale;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const u32x2 w0 = {pk_bf16(a0[4 * c] * f, a0[4 * c + 1] * f), pk_bf16(a0[4 * c + 2] * f, a0[4 * c + 3] * f)};
+          const u32x2 w1 = {pk_bf16(a1[4 * c] * f, a1[4 * c + 1] * f), pk_bf16(a1[4 * c + 2] * f, a1[4 * c + 3] * f)};
+          *reinterpret_cast<u32x2 *>(wb + r * WB_PITCH + (8 * c + 4 * hh) * 2) = w0;
+          *reinterpret_cast<u32x2 *>(wb + r * WB_PITCH + (32 + 8 * c + 4 * hh) * 2) = w1;
+        }
+        bf16_t *drow0 = reinterpret_cast<bf16_t *>(p.dqkv) + ((long long)b * N + k_wave) * tok_stride + (long long)((1 + which) * H + h) * HD;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const u32x4 v = *reinterpret_cast<const u32x4 *>(wb + (rr + 8 * k) * WB_PITCH + cc * 16);
+          if (k_wave + rr + 8 * k < N) *reinterpret_cast<u32x4 *>(drow0 + (long long)(rr + 8 * k) * tok_stride + cc * 8) = v;
+        }
+      }
+    } else if (more) {
+      if (dma_wave) {
+#pragma unroll
+        for (int j = 0; j < NKT; ++j) stage_piece(rq_next, rd_next, buf ^ 1, j);
+      }
+      load_rows(b + 1, kld, vld, lse_ld, dl_ld);
+    }
+  }
+}
+
+inline void grid_bwd(int B, int N, int H, int rows, int &nblk, int &chunks, int &bchunk) {
+  nblk = (N + rows - 1) / rows;
+  chunks = 256 / (H * nblk);
+  if (chunks < 1) chunks = 1;
+  if (chunks > B) chunks = B;
+  bchunk = (B + chunks - 1) / chunks;
+  chunks = (B + bchunk - 1) / bchunk;
+}
+
+template <int NKT, bool RAGGED, bool BIAS, int NW> bool launch_dq(const AttnPipeBwdParams &p, hipStream_t s) {
+  constexpr int LDS = 4 * NKT * 32 * 128 + NW * WB_WAVE;
+  static_assert(LDS <= 160 * 1024, "LDS budget");
+  static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void *>(attn_bwd_dq_q32_kernel<NKT, RAGGED, BIAS, NW>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, LDS) == hipSuccess;
+  if (!ok) return false;
+  int nblk, chunks, bchunk;
+  grid_bwd(p.B, p.N, p.H, 32 * NW, nblk, chunks, bchunk);
+  hipLaunchKernelGGL((attn_bwd_dq_q32_kernel<NKT, RAGGED, BIAS, NW>), dim3(grid_size(nblk, p.H, chunks)), dim3(64 * NW), LDS, s, p, bchunk, nblk, chunks);
+  return true;
+}
+
+template <int NKT> bool launch_dq_n(const AttnPipeBwdParams &p, hipStream_t s) {
+  const bool ragged = p.N != NKT * 32;
+  if (p.bias) return ragged ? launch_dq<NKT, true, true, 4>(p, s) : launch_dq<NKT, false, true, 4>(p, s);
+  if constexpr (NKT <= 7) {
+    static const bool w8 = [] { const char *e = getenv("DM_ATTN_Q32_W8"); return !(e && atoi(e) == 0); }();
+    if (w8) return ragged ? launch_dq<NKT, true, false, 8>(p, s) : launch_dq<NKT, false, false, 8>(p, s);
+  }
+  return ragged ? launch_dq<NKT, true, false, 4>(p, s) : launch_dq<NKT, false, false, 4>(p, s);
+}
+
+template <int NKT, bool RAGGED, int NW> bool launch_dkv(const AttnPipeBwdParams &p, hipStream_t s) {
+  constexpr int LDS = 4 * NKT * 32 * 128 + 2 * (2 * NKT * 32 * 4) + NW * WB_WAVE;
+  static_assert(LDS <= 160 * 1024, "LDS budget");
+  static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void *>(attn_bwd_dkv_q32_kernel<NKT, RAGGED, NW>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, LDS) == hipSuccess;
+  if (!ok) return false;
+  int nblk, chunks, bchunk;
+  grid_bwd(p.B, p.N, p.H, 32 * NW, nblk, chunks, bchunk);
+  hipLaunchKernelGGL((attn_bwd_dkv_q32_kernel<NKT, RAGGED, NW>), dim3(grid_size(nblk, p.H, chunks)), dim3(64 * NW), LDS, s, p, bchunk, nblk, chunks);
+  return true;
+}
+
+template <int NKT> bool launch_dkv_n(const AttnPipeBwdParams &p, hipStream_t s) {
+  const bool ragged = p.N != NKT * 32;
+  if constexpr (NKT <= 7) return ragged ? launch_dkv<NKT, true, 8>(p, s) : launch_dkv<NKT, false, 8>(p, s);
+  else return ragged ? launch_dkv<NKT, true, 4>(p, s) : launch_dkv<NKT, false, 4>(p, s);
+}
+
+}  // namespace dmq32
+
+// dK / dV pass without a bias (reads p.delta, written by a dQ pass): bf16, head dim 64, 128 < N <= 256; true if it took the call.
+bool dm_attn_bwd_dkv_q32(const AttnPipeBwdParams &p, hipStream_t s) {
+  static const int mode = [] { const char *e = getenv("DM_ATTN_Q32_BWD"); return e ? atoi(e) : 1; }();
+  if (mode == 0 || mode == 3) return false;                       // 3: new dQ only (A/B runs)
+  if (p.bias || p.slab) return false;
+  if (p.N <= 128 || p.N > 256) return false;
+  if ((long long)p.N * 3 * p.H * 64 * 2 >= (1LL << 31)) return false;
+  if (mode != 2 && p.B * p.H < 96) return false;
+  switch ((p.N + 31) / 32) {
+    case 5: return dmq32::launch_dkv_n<5>(p, s);
+    case 6: return dmq32::launch_dkv_n<6>(p, s);
+    case 7: return dmq32::launch_dkv_n<7>(p, s);
+    case 8: return dmq32::launch_dkv_n<8>(p, s);
+    default: return false;
+  }
+}
+
+// dQ pass (+ delta) of the backward: bf16, head dim 64, 128 < N <= 256.  The dK / dV pass that follows reads p.delta.
+// true if it took the call; DM_ATTN_Q32_BWD=0 keeps the 16-row pipelined dQ kernel (A/B runs).
+bool dm_attn_bwd_dq_q32(const AttnPipeBwdParams &p, hipStream_t s) {
+  static const int mode = [] { const char *e = getenv("DM_ATTN_Q32_BWD"); return e ? atoi(e) : 1; }();
+  if (mode == 0) return false;
+  if (p.N <= 128 || p.N > 256) return false;
+  if ((long long)p.N * 3 * p.H * 64 * 2 >= (1LL << 31)) return false;
+  if (mode != 2 && p.B * p.H < 96) return false;
+  if (p.bias && (reinterpret_cast<uintptr_t>(p.bias) & 15u)) return false;
+  switch ((p.N + 31) / 32) {
+    case 5: return dmq32::launch_dq_n<5>(p, s);
+    case 6: return dmq32::launch_dq_n<6>(p, s);
+    case 7: return dmq32::launch_dq_n<7>(p, s);
+    case 8: return dmq32::launch_dq_n<8>(p, s);
+    default: return false;
+  }
+}
