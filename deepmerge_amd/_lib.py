@@ -44,6 +44,11 @@ class DmGemmArgs(C.Structure):
     ]
 
 
+class DmReduceItem(C.Structure):
+    _fields_ = [("partial", C.c_void_p), ("out0", C.c_void_p), ("out1", C.c_void_p),
+                ("nrows", C.c_int32), ("width", C.c_int32), ("split", C.c_int32), ("accumulate", C.c_int32)]
+
+
 class DmProfRow(C.Structure):
     _fields_ = [("name", C.c_char * 64), ("launches", C.c_int64), ("total_ms", C.c_double),
                 ("total_flops", C.c_double), ("total_bytes", C.c_double)]
@@ -65,6 +70,8 @@ SIGNATURES = {
     "dm_relpos_bias_reduce": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "dm_layernorm_fwd": (_I, [_P, _P, _P, _P, _I, _P, _P, _I, _I, _F, _P]),
     "dm_layernorm_bwd": (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _I, _I, _P]),
+    "dm_layernorm_bwd_partials": (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, C.POINTER(C.c_int32), _P]),
+    "dm_partial_reduce_batch": (_I, [C.POINTER(DmReduceItem), _I, _P]),
     "dm_layernorm_bwd_partial_floats": (_L, [_I]),
     "dm_token_pool_fwd": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "dm_token_pool_bwd": (_I, [_P, _P, _I, _I, _I, _I, _P]),

@@ -200,6 +200,52 @@ __global__ __launch_bounds__(256) void partial_reduce_kernel(const float *__rest
   }
 }
 
+// The same reduction for up to 32 independent (partial rows -> out0 | out1) jobs in ONE launch (dm_partial_reduce_batch): the
+// LayerNorm / bias-gradient reductions of a backward pass are 96-column-block launches of ~5 us each (29 per step of the headline
+// model); queued and reduced together they fill the chip once.  Same arithmetic per job as partial_reduce_kernel (bit-identical results).
+struct ReduceBatch {
+  DmReduceItem it[32];
+  int start[33];            // first workgroup of job i; start[n] = grid size
+  int n;
+};
+__global__ __launch_bounds__(256) void partial_reduce_batch_kernel(const ReduceBatch rb) {
+  __shared__ float red[16][17];
+  int job = 0;
+  while (job + 1 < rb.n && (int)blockIdx.x >= rb.start[job + 1]) ++job;
+  const DmReduceItem &it = rb.it[job];
+  const float *__restrict__ partial = it.partial;
+  const int nrows = it.nrows, width = it.width;
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const int j = ((int)blockIdx.x - rb.start[job]) * 16 + tx;
+  float s = 0.f;
+  if (j < width) {
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int r = ty;
+    for (; r + 48 < nrows; r += 64) {
+      s0 += partial[(long long)r * width + j];
+      s1 += partial[(long long)(r + 16) * width + j];
+      s2 += partial[(long long)(r + 32) * width + j];
+      s3 += partial[(long long)(r + 48) * width + j];
+    }
+    for (; r < nrows; r += 16) s0 += partial[(long long)r * width + j];
+    s = (s0 + s1) + (s2 + s3);
+  }
+  red[ty][tx] = s;
+  __syncthreads();
+  if (ty == 0 && j < width) {
+    float t[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t[k] = red[k][tx];
+#pragma unroll
+    for (int w = 8; w > 0; w >>= 1)
+#pragma unroll
+      for (int k = 0; k < w; ++k) t[k] = t[2 * k] + t[2 * k + 1];
+    s = t[0];
+    float *o = (j < it.split) ? it.out0 + j : it.out1 + (j - it.split);
+    *o = it.accumulate ? *o + s : s;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // token pooling
 // ---------------------------------------------------------------------------------------------
@@ -550,24 +596,22 @@ extern "C" int dm_layernorm_fwd(const float *x, const float *gamma, const float 
 
 extern "C" int64_t dm_layernorm_bwd_partial_floats(int32_t cols) { return (int64_t)ln_max_wg() * 2 * cols; }
 
-extern "C" int dm_layernorm_bwd(const void *dy, int32_t dy_dtype, const float *x, const float *gamma, const float *mean,
-                                const float *rstd, const float *dres, float *dx, void *dx_lp, float *dgamma, float *dbeta,
-                                int32_t accumulate_params, float *partial, int32_t rows, int32_t cols, void *stream) {
-  DM_REQUIRE(rows > 0 && cols > 0 && cols % 4 == 0 && cols <= LN_WIDE_MAX, DM_ERR_BAD_SHAPE,
-             "dm_layernorm_bwd: rows=%d cols=%d", rows, cols);
-  DM_REQUIRE(dy && x && gamma && mean && rstd && dx && dgamma && dbeta && partial, DM_ERR_BAD_SHAPE, "dm_layernorm_bwd: null pointer");
-  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+// main kernel of the LayerNorm backward: dx (+ dres), optional bf16 copy, one [dgamma | dbeta] partial row per workgroup; *n_partial rows
+static int ln_bwd_main(const void *dy, int32_t dy_dtype, const float *x, const float *gamma, const float *mean, const float *rstd,
+                       const float *dres, float *dx, void *dx_lp, float *partial, int32_t rows, int32_t cols, int32_t *n_partial, hipStream_t s,
+                       const char *who) {
+  DM_REQUIRE(rows > 0 && cols > 0 && cols % 4 == 0 && cols <= LN_WIDE_MAX, DM_ERR_BAD_SHAPE, "%s: rows=%d cols=%d", who, rows, cols);
+  DM_REQUIRE(dy && x && gamma && mean && rstd && dx && partial && n_partial, DM_ERR_BAD_SHAPE, "%s: null pointer", who);
   if (cols > MAXCH * 256) {
     int slices = 0;
     const int rc = dm_layernorm_wide_bwd(dy, dy_dtype, x, gamma, mean, rstd, dres, dx, dx_lp, partial, ln_max_wg(), &slices, rows, cols, s);
-    DM_REQUIRE(rc == DM_OK, rc, "dm_layernorm_bwd: bad dy_dtype %d", dy_dtype);
+    DM_REQUIRE(rc == DM_OK, rc, "%s: bad dy_dtype %d", who, dy_dtype);
     DM_LAUNCH_CHECK("dm_layernorm_bwd(wide)");
-    hipLaunchKernelGGL(partial_reduce_kernel, dim3((2 * cols + 15) / 16), dim3(256), 0, s, partial, dgamma, dbeta, slices, 2 * cols, cols, accumulate_params);
-    DM_LAUNCH_CHECK("dm_layernorm_bwd(reduce)");
+    *n_partial = slices;
     return DM_OK;
   }
   const int grid = grid_for((long long)rows, 4, ln_max_wg());
-  DM_REQUIRE(dy_dtype == DM_F32 || dy_dtype == DM_BF16, DM_ERR_BAD_DTYPE, "dm_layernorm_bwd: bad dy_dtype %d", dy_dtype);
+  DM_REQUIRE(dy_dtype == DM_F32 || dy_dtype == DM_BF16, DM_ERR_BAD_DTYPE, "%s: bad dy_dtype %d", who, dy_dtype);
   const bool narrow = cols <= 768;
   if (dy_dtype == DM_F32 && narrow)
     hipLaunchKernelGGL((layernorm_bwd_kernel<float, 3>), dim3(grid), dim3(256), 0, s, (const float *)dy, x, gamma, mean, rstd, dres, dx, (bf16_t *)dx_lp, partial, rows, cols);
@@ -578,8 +622,48 @@ extern "C" int dm_layernorm_bwd(const void *dy, int32_t dy_dtype, const float *x
   else
     hipLaunchKernelGGL((layernorm_bwd_kernel<bf16_t, MAXCH>), dim3(grid), dim3(256), 0, s, (const bf16_t *)dy, x, gamma, mean, rstd, dres, dx, (bf16_t *)dx_lp, partial, rows, cols);
   DM_LAUNCH_CHECK("dm_layernorm_bwd");
-  hipLaunchKernelGGL(partial_reduce_kernel, dim3((2 * cols + 15) / 16), dim3(256), 0, s, partial, dgamma, dbeta, grid, 2 * cols, cols, accumulate_params);
+  *n_partial = grid;
+  return DM_OK;
+}
+
+extern "C" int dm_layernorm_bwd(const void *dy, int32_t dy_dtype, const float *x, const float *gamma, const float *mean,
+                                const float *rstd, const float *dres, float *dx, void *dx_lp, float *dgamma, float *dbeta,
+                                int32_t accumulate_params, float *partial, int32_t rows, int32_t cols, void *stream) {
+  DM_REQUIRE(dgamma && dbeta, DM_ERR_BAD_SHAPE, "dm_layernorm_bwd: null pointer");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  int32_t slices = 0;
+  if (const int rc = ln_bwd_main(dy, dy_dtype, x, gamma, mean, rstd, dres, dx, dx_lp, partial, rows, cols, &slices, s, "dm_layernorm_bwd")) return rc;
+  hipLaunchKernelGGL(partial_reduce_kernel, dim3((2 * cols + 15) / 16), dim3(256), 0, s, partial, dgamma, dbeta, slices, 2 * cols, cols, accumulate_params);
   DM_LAUNCH_CHECK("dm_layernorm_bwd(reduce)");
+  return DM_OK;
+}
+
+extern "C" int dm_layernorm_bwd_partials(const void *dy, int32_t dy_dtype, const float *x, const float *gamma, const float *mean,
+                                         const float *rstd, const float *dres, float *dx, void *dx_lp, float *partial, int32_t rows,
+                                         int32_t cols, int32_t *n_partial, void *stream) {
+  return ln_bwd_main(dy, dy_dtype, x, gamma, mean, rstd, dres, dx, dx_lp, partial, rows, cols, n_partial, reinterpret_cast<hipStream_t>(stream),
+                     "dm_layernorm_bwd_partials");
+}
+
+extern "C" int dm_partial_reduce_batch(const DmReduceItem *items, int32_t n, void *stream) {
+  DM_REQUIRE(items && n > 0, DM_ERR_BAD_SHAPE, "dm_partial_reduce_batch: no items");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  for (int32_t base = 0; base < n; base += 32) {
+    ReduceBatch rb;
+    rb.n = (n - base < 32) ? n - base : 32;
+    int total = 0;
+    for (int i = 0; i < rb.n; ++i) {
+      const DmReduceItem &it = items[base + i];
+      DM_REQUIRE(it.partial && it.out0 && it.out1 && it.nrows > 0 && it.width > 0 && it.split >= 0 && it.split <= it.width, DM_ERR_BAD_SHAPE,
+                 "dm_partial_reduce_batch: item %d: nrows=%d width=%d split=%d", base + i, it.nrows, it.width, it.split);
+      rb.it[i] = it;
+      rb.start[i] = total;
+      total += (it.width + 15) / 16;
+    }
+    for (int i = rb.n; i <= 32; ++i) rb.start[i] = total;
+    hipLaunchKernelGGL(partial_reduce_batch_kernel, dim3(total), dim3(256), 0, s, rb);
+    DM_LAUNCH_CHECK("dm_partial_reduce_batch");
+  }
   return DM_OK;
 }
 

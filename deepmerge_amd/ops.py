@@ -271,9 +271,57 @@ def layernorm_fwd(x: torch.Tensor, gamma, beta, eps: float, out_dtype: torch.dty
     return y, mean, rstd
 
 
-def layernorm_bwd(dy, x, gamma, mean, rstd, dres=None, dgamma=None, dbeta=None, accumulate=False, want_lp=False):
-    """Returns (dx, dgamma, dbeta) or, with want_lp, (dx, dx_bf16, dgamma, dbeta)."""
+# ---- deferred partial-row reductions ------------------------------------------------------------------------------------------------
+# The LayerNorm backward leaves one [dgamma | dbeta] partial row per workgroup; reducing them is a ~5 us launch of 96 workgroups per
+# LayerNorm application (16 per step of the headline model).  When the results go straight into gradient sinks (nothing reads them
+# before the backward pass ends), the reductions are queued and done by ONE dm_partial_reduce_batch launch from an end-of-backward
+# callback of the autograd engine -- inside a captured step that launch is captured like any other.  Same arithmetic, same bits.
+_pending_reduce = []        # (DmReduceItem field tuple, tensors kept alive until the launch)
+_pending_out = set()
+_flush_queued = False
+
+
+def _in_backward() -> bool:
+    return torch._C._current_graph_task_id() != -1
+
+
+def flush_reductions() -> None:
+    """Launch the queued reductions (no-op when nothing is pending).  Called by the autograd engine at the end of a backward pass;
+    call it yourself before reading a deferred result outside one."""
+    global _flush_queued
+    _flush_queued = False
+    if not _pending_reduce:
+        return
+    items = (_lib.DmReduceItem * len(_pending_reduce))()
+    for i, (f, _keep) in enumerate(_pending_reduce):
+        items[i].partial, items[i].out0, items[i].out1, items[i].nrows, items[i].width, items[i].split, items[i].accumulate = f
+    n = len(_pending_reduce)
+    keep = list(_pending_reduce)
+    _pending_reduce.clear()
+    _pending_out.clear()
+    check(_lib.lib().dm_partial_reduce_batch(items, n, _stream()), "dm_partial_reduce_batch")
+    del keep
+
+
+def _queue_reduce(part, out0, out1, nrows, width, split, accumulate) -> None:
+    global _flush_queued
+    keys = (out0.data_ptr(), out1.data_ptr())
+    if keys[0] in _pending_out or keys[1] in _pending_out:      # a second contribution to the same parameter (a shared norm): keep the order
+        flush_reductions()
+    _pending_reduce.append(((part.data_ptr(), keys[0], keys[1], int(nrows), int(width), int(split), int(bool(accumulate))), (part, out0, out1)))
+    _pending_out.update(keys)
+    if not _flush_queued:
+        torch.autograd.Variable._execution_engine.queue_callback(flush_reductions)
+        _flush_queued = True
+
+
+def layernorm_bwd(dy, x, gamma, mean, rstd, dres=None, dgamma=None, dbeta=None, accumulate=False, want_lp=False, defer=False):
+    """Returns (dx, dgamma, dbeta) or, with want_lp, (dx, dx_bf16, dgamma, dbeta).
+    defer=True (only with caller-provided dgamma / dbeta, inside a backward pass): their reduction is queued for the end of the pass
+    (`flush_reductions`); dx is complete on return."""
     _need_cuda(dy, x)
+    if not (dy.is_contiguous() and x.is_contiguous()) or dy.numel() != x.numel():
+        raise ValueError("layernorm_bwd: dy and x must be contiguous and of the same size (an expanded gradient has no rows to read)")
     rows, cols = x.numel() // x.shape[-1], x.shape[-1]
     dx = torch.empty(x.shape, dtype=torch.float32, device=x.device)
     dx_lp = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device) if want_lp else None
@@ -281,11 +329,23 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dres=None, dgamma=None, dbeta=None, 
         dgamma = torch.empty(cols, dtype=torch.float32, device=x.device)
         dbeta = torch.empty(cols, dtype=torch.float32, device=x.device)
         accumulate = False
+        defer = False
+    if defer and _DEFER_REDUCTIONS and _in_backward():
+        part = torch.empty(_lib.lib().dm_layernorm_bwd_partial_floats(cols), dtype=torch.float32, device=x.device)
+        n_part = C.c_int32(0)
+        check(_lib.lib().dm_layernorm_bwd_partials(dy.data_ptr(), _dt(dy), x.data_ptr(), gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                                   _ptr(dres), dx.data_ptr(), _ptr(dx_lp), part.data_ptr(), rows, cols, C.byref(n_part),
+                                                   _stream()), "dm_layernorm_bwd_partials")
+        _queue_reduce(part, dgamma, dbeta, n_part.value, 2 * cols, cols, accumulate)
+        return (dx, dx_lp, dgamma, dbeta) if want_lp else (dx, dgamma, dbeta)
     part = workspace(_lib.lib().dm_layernorm_bwd_partial_floats(cols) * 4, x.device, "partial")
     check(_lib.lib().dm_layernorm_bwd(dy.data_ptr(), _dt(dy), x.data_ptr(), gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
                                       _ptr(dres), dx.data_ptr(), _ptr(dx_lp), dgamma.data_ptr(), dbeta.data_ptr(), int(accumulate),
                                       part.data_ptr(), rows, cols, _stream()), "dm_layernorm_bwd")
     return (dx, dx_lp, dgamma, dbeta) if want_lp else (dx, dgamma, dbeta)
+
+
+_DEFER_REDUCTIONS = os.environ.get("DM_DEFER_REDUCTIONS", "1") != "0"      # A/B switch
 
 
 def relpos_bias_gather(table: torch.Tensor, index32: torch.Tensor, N: int, transposed: bool = False):
@@ -1041,7 +1101,7 @@ class BlockFn(torch.autograd.Function):
             dg2, dbt2, k_n2, k_n2b = torch.empty(Cc, device=dev), torch.empty(Cc, device=dev), False, False
         a_n2 = _acc(P_n2w, k_n2)
         _acc(P_n2b, k_n2b)                              # (gamma and beta are written by the same launch)
-        r = layernorm_bwd(dy2, x1, n2w, mean2, rstd2, dres=dx2, dgamma=dg2, dbeta=dbt2, accumulate=a_n2, want_lp=lp)
+        r = layernorm_bwd(dy2, x1, n2w, mean2, rstd2, dres=dx2, dgamma=dg2, dbeta=dbt2, accumulate=a_n2, want_lp=lp, defer=bool(k_n2 and k_n2b))
         dx1, dx1_lp = (r[0], r[1]) if lp else (r[0], r[0])
         # ---- attention -----------------------------------------------------------------------
         dwp, k_wp = _grad_out(P_proj_w, (Cc, Cc), dev)
@@ -1068,7 +1128,7 @@ class BlockFn(torch.autograd.Function):
             dg1, dbt1, k_n1, k_n1b = torch.empty(Cc, device=dev), torch.empty(Cc, device=dev), False, False
         a_n1 = _acc(P_n1w, k_n1)
         _acc(P_n1b, k_n1b)
-        r = layernorm_bwd(dy1, x, n1w, mean1, rstd1, dres=dx1, dgamma=dg1, dbeta=dbt1, accumulate=a_n1, want_lp=lp)
+        r = layernorm_bwd(dy1, x, n1w, mean1, rstd1, dres=dx1, dgamma=dg1, dbeta=dbt1, accumulate=a_n1, want_lp=lp, defer=bool(k_n1 and k_n1b))
         if side is not None:
             torch.cuda.current_stream().wait_stream(side)          # join: every weight gradient of this block is complete
         dx = r[0].view(B, N, Cc)

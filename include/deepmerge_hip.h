@@ -155,6 +155,22 @@ int dm_layernorm_bwd(const void *dy, int32_t dy_dtype, const float *x, const flo
                      float *dgamma, float *dbeta, int32_t accumulate_params, float *partial,
                      int32_t rows, int32_t cols, void *stream);
 int64_t dm_layernorm_bwd_partial_floats(int32_t cols);
+/* The same backward WITHOUT the final reduction of the per-workgroup [dgamma | dbeta] partial rows: `*n_partial` rows of 2 * cols floats
+ * are left in `partial` (keep it until they are reduced).  The reductions of a whole backward pass -- one per LayerNorm application,
+ * nets/ShfitScaleFormer.py:170-183 runs two per block -- are then done by ONE dm_partial_reduce_batch launch instead of one small
+ * launch each (out0 = dgamma, out1 = dbeta, width = 2 * cols, split = cols).  Results are bit-identical to dm_layernorm_bwd. */
+int dm_layernorm_bwd_partials(const void *dy, int32_t dy_dtype, const float *x, const float *gamma,
+                              const float *mean, const float *rstd, const float *dres, float *dx, void *dx_lp,
+                              float *partial, int32_t rows, int32_t cols, int32_t *n_partial, void *stream);
+/* One job of dm_partial_reduce_batch: out0[j] (+)= sum_r partial[r][j] for j < split, out1[j - split] (+)= ... for split <= j < width;
+ * rows are summed in a fixed order (deterministic).  Jobs of one batch must not share output elements. */
+typedef struct DmReduceItem {
+  const float *partial;
+  float *out0, *out1;
+  int32_t nrows, width, split, accumulate;
+} DmReduceItem;
+/* items: HOST array of n jobs (passed to the kernel by value, 32 per launch). */
+int dm_partial_reduce_batch(const DmReduceItem *items, int32_t n, void *stream);
 
 /* Per-scale 2x2 average pooling of the token grid (AvgPool2d(2,2) on [B,C,side,side] views,
  * nets/ShfitScaleFormer.py:892-901, :905-914): x [B, S*side*side, C] -> y [B, S*(side/2)^2, C], fp32. */

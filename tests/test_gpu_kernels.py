@@ -418,6 +418,74 @@ def test_attention_forward_backward(mode, N, with_bias, B=3, H=4):
         assert err < (1e-4 if mode == "fp32" else 6e-2) * max(1.0, gt.abs().max().item()), f"dtable max err {err}"
 
 
+def test_partial_reduce_batch_equals_separate_reductions():
+    """dm_layernorm_bwd_partials + ONE dm_partial_reduce_batch launch for many LayerNorm backward passes == dm_layernorm_bwd's own
+    reduction, bit for bit (store and accumulate jobs, more than 32 jobs = two launches, different widths); then the deferred path of
+    ops.layernorm_bwd inside a real backward pass (queued, flushed by the engine's end-of-backward callback)."""
+    import ctypes as C
+    ops = _ops()
+    from deepmerge_amd import _lib
+    lib = _lib.lib()
+    rng = np.random.default_rng(21)
+    jobs, keep = [], []
+    want = []
+    for i in range(35):
+        rows, cols = int(rng.integers(1, 5000)), [768, 128, 1024, 64][i % 4]
+        x = torch.from_numpy(rng.normal(size=(rows, cols)).astype(np.float32)).to(DEV)
+        dy = torch.from_numpy(rng.normal(size=(rows, cols)).astype(np.float32)).to(DEV)
+        if i % 3 == 0:
+            dy = dy.to(torch.bfloat16)
+        g = torch.from_numpy(rng.normal(size=cols).astype(np.float32)).to(DEV)
+        _y, mean, rstd = ops.layernorm_fwd(x, g, torch.zeros_like(g), 1e-6, torch.float32)
+        acc = bool(i % 2)
+        dg0 = torch.from_numpy(rng.normal(size=cols).astype(np.float32)).to(DEV)
+        db0 = torch.from_numpy(rng.normal(size=cols).astype(np.float32)).to(DEV)
+        dg_ref, db_ref = dg0.clone(), db0.clone()
+        dx_ref, _, _ = ops.layernorm_bwd(dy, x, g, mean, rstd, dgamma=dg_ref, dbeta=db_ref, accumulate=acc)
+        dx = torch.empty_like(x)
+        part = torch.empty(lib.dm_layernorm_bwd_partial_floats(cols), dtype=torch.float32, device=DEV)
+        n_part = C.c_int32(0)
+        _lib.check(lib.dm_layernorm_bwd_partials(dy.data_ptr(), ops._dt(dy), x.data_ptr(), g.data_ptr(), mean.data_ptr(), rstd.data_ptr(), None,
+                                                 dx.data_ptr(), None, part.data_ptr(), rows, cols, C.byref(n_part), ops._stream()), "partials")
+        assert torch.equal(dx, dx_ref) and n_part.value > 0
+        dg, db = dg0.clone(), db0.clone()
+        jobs.append((part.data_ptr(), dg.data_ptr(), db.data_ptr(), n_part.value, 2 * cols, cols, int(acc)))
+        keep.append((part, dg, db))
+        want.append((dg_ref, db_ref))
+    items = (_lib.DmReduceItem * len(jobs))()
+    for i, f in enumerate(jobs):
+        items[i].partial, items[i].out0, items[i].out1, items[i].nrows, items[i].width, items[i].split, items[i].accumulate = f
+    _lib.check(lib.dm_partial_reduce_batch(items, len(jobs), ops._stream()), "batch")
+    for (part, dg, db), (dg_ref, db_ref) in zip(keep, want):
+        assert torch.equal(dg, dg_ref) and torch.equal(db, db_ref)
+    with pytest.raises(ValueError):
+        _lib.check(lib.dm_partial_reduce_batch(items, 0, ops._stream()), "batch")
+
+    # the deferred path inside a backward pass
+    class Probe(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x):
+            return x.clone()
+
+        @staticmethod
+        def backward(ctx, gy):
+            assert ops._in_backward()
+            Probe.out = ops.layernorm_bwd(gy.contiguous(), Probe.x, Probe.g, Probe.mean, Probe.rstd, dgamma=Probe.dg, dbeta=Probe.db, accumulate=False, defer=True)
+            Probe.pending = len(ops._pending_reduce)
+            return gy
+    rows, cols = 777, 768
+    Probe.x = torch.from_numpy(rng.normal(size=(rows, cols)).astype(np.float32)).to(DEV)
+    Probe.g = torch.ones(cols, device=DEV)
+    _y, Probe.mean, Probe.rstd = ops.layernorm_fwd(Probe.x, Probe.g, torch.zeros_like(Probe.g), 1e-6, torch.float32)
+    Probe.dg, Probe.db = torch.full((cols,), float("nan"), device=DEV), torch.full((cols,), float("nan"), device=DEV)
+    inp = torch.from_numpy(rng.normal(size=(rows, cols)).astype(np.float32)).to(DEV).requires_grad_(True)
+    Probe.apply(inp).sum().backward()
+    assert Probe.pending == 1 and not ops._pending_reduce          # queued inside the pass, flushed at its end
+    dg_ref, db_ref = torch.empty(cols, device=DEV), torch.empty(cols, device=DEV)
+    ops.layernorm_bwd(torch.ones_like(Probe.x), Probe.x, Probe.g, Probe.mean, Probe.rstd, dgamma=dg_ref, dbeta=db_ref)
+    assert torch.equal(Probe.dg, dg_ref) and torch.equal(Probe.db, db_ref)
+
+
 @pytest.mark.parametrize("out_dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("rows,cols", [(1, 768), (37, 768), (4096, 768), (50, 128), (9, 1024),
                                        (1, 1280), (514, 1280), (5000, 1028), (33, 8192)])      # > 1024 columns: dm_rows_wide.hip
