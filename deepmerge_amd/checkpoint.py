@@ -30,17 +30,26 @@ def optimizer_state_dict(trainer) -> Dict[str, Any]:
     params = _ordered_params(trainer.net)
     state = {}
     if trainer.step_count > 0:
+        # torch.optim.Adam creates a parameter's state lazily, at its first step WITH a gradient: parameters that never receive one
+        # (final_features.*, head.* on the designed-feature path) have no entry upstream.  Here their moments are exactly zero forever
+        # (zero gradient in, zero out), which is how they are recognised -- a parameter whose gradients were all EXACTLY zero so far (a
+        # dead unit) is indistinguishable and gets no entry either; reloading it is harmless (zero moments are what it has).  One pass over
+        # the flat buffers and one host copy decide all parameters (it used to be two host syncs per parameter).
+        nz = ((trainer.m != 0) | (trainer.v != 0)).to(torch.int32).cumsum(0, dtype=torch.int64)
+        lo = torch.tensor([where[id(p)] for p in params], dtype=torch.int64, device=nz.device)
+        hi = lo + torch.tensor([p.numel() for p in params], dtype=torch.int64, device=nz.device)
+        before = torch.where(lo > 0, nz[(lo - 1).clamp(min=0)], torch.zeros_like(lo))
+        touched = (nz[hi - 1] - before).cpu().tolist()
         for i, p in enumerate(params):
             o, n = where[id(p)], p.numel()
-            # torch.optim.Adam creates a parameter's state lazily, at its first step WITH a gradient: parameters that never
-            # receive one (final_features.*, head.* on the designed-feature path) have no entry upstream.  Here their moments are
-            # exactly zero forever (zero gradient in, zero out), which is how they are recognised.
-            if not bool(trainer.v[o:o + n].any()) and not bool(trainer.m[o:o + n].any()):
+            if touched[i] == 0:
                 continue
             state[i] = {"step": torch.tensor(float(trainer.step_count)),
                         "exp_avg": trainer.m[o:o + n].view_as(p).detach().clone().cpu(),
                         "exp_avg_sq": trainer.v[o:o + n].view_as(p).detach().clone().cpu()}
-    group = dict(_GROUP_DEFAULTS, lr=trainer.lr, betas=tuple(trainer.betas), eps=trainer.eps, params=list(range(len(params))))
+    # `dm_step_count`: the fused Adam's one step count, kept even when no parameter has an entry (torch ignores unknown group keys)
+    group = dict(_GROUP_DEFAULTS, lr=trainer.lr, betas=tuple(trainer.betas), eps=trainer.eps, params=list(range(len(params))),
+                 dm_step_count=int(trainer.step_count))
     return {"state": state, "param_groups": [group]}
 
 
@@ -72,7 +81,7 @@ def load_optimizer_state_dict(trainer, sd: Dict[str, Any]) -> None:
         steps.add(int(float(st["step"])))
     if len(steps) > 1:
         raise ValueError(f"per-parameter step counts differ ({sorted(steps)}); the fused Adam keeps one step count")
-    trainer.step_count = steps.pop() if steps else 0
+    trainer.step_count = steps.pop() if steps else int(g.get("dm_step_count", 0))
 
 
 def save_checkpoint(path: str, trainer, epoch: int, elapsed: float) -> Dict[str, Any]:

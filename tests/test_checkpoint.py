@@ -58,6 +58,16 @@ def test_optimizer_state_round_trips_through_torch_adam(tmp_path):
     for i in (0, 1):
         assert torch.equal(again["state"][i]["exp_avg"], opt.state_dict()["state"][i]["exp_avg"])
         assert float(again["state"][i]["step"]) == float(opt.state_dict()["state"][i]["step"]) == 2.0
+    # a trainer whose moments are all zero (every gradient so far exactly zero) still keeps its step count across a save / load
+    net3 = Tiny()
+    tr3 = _trainer(net3)
+    tr3.step_count = 5
+    sd3 = ck.optimizer_state_dict(tr3)
+    assert sd3["state"] == {} and sd3["param_groups"][0]["dm_step_count"] == 5
+    torch.optim.Adam(filter(lambda p: p.requires_grad, net3.parameters())).load_state_dict(sd3)      # torch ignores the extra group key
+    tr4 = _trainer(Tiny())
+    ck.load_optimizer_state_dict(tr4, sd3)
+    assert tr4.step_count == 5
 
 
 def test_checkpoint_dict_keys_and_reload(tmp_path):
