@@ -25,6 +25,38 @@ __all__ = ["PatchEmbed", "Mlp", "FeatureEmbed", "CrossScaleAttention", "CrossSca
            "ShfitScaleFormer_v2", "ShfitScaleFormer_v3", "ShfitScaleFormer_v6"]
 
 
+def drop_path(x, drop_prob: float = 0., training: bool = False):
+    """Stochastic depth per sample, as the reference draws it (vit_model.py:12-28, used by nets/ShfitScaleFormer.py:170-183):
+    mask = floor(keep + U[0, 1)) per sample, output = x / keep * mask.  Identity for ratio 0 or in eval mode."""
+    if drop_prob == 0. or not training:
+        return x
+    keep = 1 - drop_prob
+    mask = keep + torch.rand((x.shape[0],) + (1,) * (x.ndim - 1), dtype=x.dtype, device=x.device)
+    mask.floor_()
+    return x.div(keep) * mask
+
+
+class DropPath(nn.Module):
+    def __init__(self, drop_prob=None):
+        super().__init__()
+        self.drop_prob = drop_prob
+
+    def forward(self, x):
+        return drop_path(x, self.drop_prob, self.training)
+
+
+def stochastic_block_forward(block, x, table_args):
+    """The pre-norm block with stochastic depth (training mode, ratio > 0): the two residual branches are separate autograd nodes so a
+    per-sample mask can sit between a branch and its residual add; LayerNorm, the attention module and the Mlp are the same kernels
+    the fused node uses.  x: [B, N, C] fp32."""
+    x = x.float()
+    dt = ops.act_dtype(block.numerics)
+    y = ops.LayerNormFn.apply(x, block.norm1.weight, block.norm1.bias, block.norm1.eps, dt)
+    x = x + block.drop_path(block.attn(y))
+    y = ops.LayerNormFn.apply(x, block.norm2.weight, block.norm2.bias, block.norm2.eps, dt)
+    return x + block.drop_path(block.mlp(y).float())
+
+
 def _mode(numerics: Optional[str], module=None) -> str:
     """Validated numerics mode of a module; a "bf16x3" module gets its product scope bound to its calls (ops.bind_numerics)."""
     return ops.bind_numerics(module, numerics or ops.get_numerics())
@@ -195,20 +227,24 @@ class CrossScaleBlock(nn.Module):
     def __init__(self, dim, num_heads, cube_size, mlp_ratio=4., qkv_bias=True, qk_scale=None, drop_ratio=0.,
                  attn_drop_ratio=0., drop_path_ratio=0., act_layer=nn.GELU, norm_layer=nn.LayerNorm, numerics=None):
         super().__init__()
-        if drop_path_ratio > 0.:
-            raise ValueError("stochastic depth is not part of the accelerated path (reference passes 0)")
         self.numerics = _mode(numerics, self)
         self.norm1 = norm_layer(dim)
         self.attn = self._attention_cls(dim=dim, num_heads=num_heads, cube_size=cube_size, qkv_bias=qkv_bias,
                                         qk_scale=qk_scale, attn_drop_ratio=attn_drop_ratio, proj_drop_ratio=drop_ratio,
                                         numerics=self.numerics)
-        self.drop_path = nn.Identity()
+        # stochastic depth (reference :171): ratio 0 everywhere upstream -> the fused node; a ratio > 0 runs the block as separate
+        # nodes in training mode (stochastic_block_forward), and its parameters then take gradients from several writers
+        self.drop_path = DropPath(drop_path_ratio) if drop_path_ratio > 0. else nn.Identity()
+        if drop_path_ratio > 0.:
+            self._dm_fused_block = False
         self.norm2 = norm_layer(dim)
         self.mlp = Mlp(in_features=dim, hidden_features=int(dim * mlp_ratio), act_layer=act_layer, drop=drop_ratio,
                        numerics=self.numerics)
 
     def forward(self, x):
         a, m = self.attn, self.mlp
+        if self.training and isinstance(self.drop_path, DropPath):
+            return stochastic_block_forward(self, x, None)
         if a.qkv.bias is None:
             raise ValueError("the fused block kernel path expects qkv_bias=True (the reference default, :165)")
         return ops.BlockFn.apply(x.float(), self.norm1.weight, self.norm1.bias, a.relative_position_bias_table, a._index32(),
@@ -665,10 +701,11 @@ class ShfitScaleFormer(_SingleStage):
         for i, ps in enumerate((4, 8, 16, 32)):           # hard-coded upstream (:454-457)
             setattr(self, f"patch_embed_scale{i}", PatchEmbed(img_size=input_image_scales[i], patch_size=ps, in_c=3, out_c=768, **kw))
         self.feature_embed = FeatureEmbed(feature_size=19, embed_dim=768) if is_designed_feature_embedding else None
+        dpr = [x.item() for x in torch.linspace(0, drop_path_ratio, depth)]      # stochastic depth decay rule (reference :463)
         self.blocks = nn.Sequential(*[
             CrossScaleBlock(dim=embed_dim, num_heads=num_heads, cube_size=self.cube_size, mlp_ratio=mlp_ratio, drop_ratio=drop_ratio,
-                            attn_drop_ratio=attn_drop_ratio, drop_path_ratio=0., norm_layer=norm_layer, act_layer=act_layer,
-                            numerics=self.numerics) for _ in range(depth)])
+                            attn_drop_ratio=attn_drop_ratio, drop_path_ratio=dpr[i], norm_layer=norm_layer, act_layer=act_layer,
+                            numerics=self.numerics) for i in range(depth)])
         self._build_tail(embed_dim, norm_layer, drop_ratio, num_classes)
         self.apply(self._init_weights)
 

@@ -22,23 +22,7 @@ import torch.nn as nn
 from . import ops
 from .nets.ShfitScaleFormer import FeatureEmbed as _S2FeatureEmbed
 from .nets.ShfitScaleFormer import Mlp as _S2Mlp
-from .nets.ShfitScaleFormer import _CastFn, _mode
-
-
-def drop_path(x, drop_prob: float = 0., training: bool = False):
-    """Stochastic depth (vit_model.py:12-28).  Every reference configuration uses ratio 0 -> identity."""
-    if drop_prob == 0. or not training:
-        return x
-    raise NotImplementedError("stochastic depth > 0 is not part of the accelerated path")
-
-
-class DropPath(nn.Module):
-    def __init__(self, drop_prob=None):
-        super().__init__()
-        self.drop_prob = drop_prob
-
-    def forward(self, x):
-        return drop_path(x, self.drop_prob, self.training)
+from .nets.ShfitScaleFormer import DropPath, _CastFn, _mode, drop_path, stochastic_block_forward  # noqa: F401
 
 
 class PatchEmbed(nn.Module):
@@ -103,19 +87,22 @@ class Block(nn.Module):
     def __init__(self, dim, num_heads, mlp_ratio=4., qkv_bias=False, qk_scale=None, drop_ratio=0., attn_drop_ratio=0.,
                  drop_path_ratio=0., act_layer=nn.GELU, norm_layer=nn.LayerNorm, numerics=None):
         super().__init__()
-        if drop_path_ratio > 0.:
-            raise ValueError("stochastic depth is not part of the accelerated path (reference passes 0)")
         self.numerics = _mode(numerics, self)
         self.norm1 = norm_layer(dim)
         self.attn = Attention(dim, num_heads=num_heads, qkv_bias=qkv_bias, qk_scale=qk_scale, attn_drop_ratio=attn_drop_ratio,
                               proj_drop_ratio=drop_ratio, numerics=self.numerics)
-        self.drop_path = nn.Identity()
+        # stochastic depth (vit_model.py:12-40, :171): see nets/ShfitScaleFormer.py CrossScaleBlock
+        self.drop_path = DropPath(drop_path_ratio) if drop_path_ratio > 0. else nn.Identity()
+        if drop_path_ratio > 0.:
+            self._dm_fused_block = False
         self.norm2 = norm_layer(dim)
         self.mlp = Mlp(in_features=dim, hidden_features=int(dim * mlp_ratio), act_layer=act_layer, drop=drop_ratio,
                        numerics=self.numerics)
 
     def forward(self, x):
         a, m = self.attn, self.mlp
+        if self.training and isinstance(self.drop_path, DropPath):
+            return stochastic_block_forward(self, x, None)
         if a.qkv.bias is None:
             zero = torch.zeros(a.qkv.out_features, device=x.device)      # qkv_bias=False: bias-free GEMM epilogue
             qb = zero
@@ -161,10 +148,11 @@ class VisionTransformer(nn.Module):
         self.dist_token = nn.Parameter(torch.zeros(1, 1, embed_dim)) if distilled else None      # DeiT token (:225)
         self.pos_embed = nn.Parameter(torch.zeros(1, num_patches + self.num_tokens, embed_dim))
         self.pos_drop = nn.Dropout(p=drop_ratio)
+        dpr = [x.item() for x in torch.linspace(0, drop_path_ratio, depth)]      # stochastic depth decay rule (vit_model.py:229 / :387)
         self.blocks = nn.Sequential(*[
             Block(dim=embed_dim, num_heads=num_heads, mlp_ratio=mlp_ratio, qkv_bias=qkv_bias, qk_scale=qk_scale,
-                  drop_ratio=drop_ratio, attn_drop_ratio=attn_drop_ratio, drop_path_ratio=0., norm_layer=norm_layer,
-                  act_layer=act_layer, numerics=self.numerics) for _ in range(depth)])
+                  drop_ratio=drop_ratio, attn_drop_ratio=attn_drop_ratio, drop_path_ratio=dpr[i], norm_layer=norm_layer,
+                  act_layer=act_layer, numerics=self.numerics) for i in range(depth)])
         self.norm = norm_layer(embed_dim)
         if representation_size and not distilled:
             self.has_logits = True
@@ -278,10 +266,11 @@ class ScaleEmbedTransformer(nn.Module):
         self.pos_embed3 = nn.Parameter(torch.zeros(1, 49, embed_dim))
         self.pos_embed_non_multiscale = nn.Parameter(torch.zeros(1, 196, embed_dim))
         self.pos_drop = nn.Dropout(p=drop_ratio)
+        dpr = [x.item() for x in torch.linspace(0, drop_path_ratio, depth)]      # stochastic depth decay rule (vit_model.py:229 / :387)
         self.blocks = nn.Sequential(*[
             Block(dim=embed_dim, num_heads=num_heads, mlp_ratio=mlp_ratio, qkv_bias=qkv_bias, qk_scale=qk_scale,
-                  drop_ratio=drop_ratio, attn_drop_ratio=attn_drop_ratio, drop_path_ratio=0., norm_layer=norm_layer,
-                  act_layer=act_layer, numerics=self.numerics) for _ in range(depth)])
+                  drop_ratio=drop_ratio, attn_drop_ratio=attn_drop_ratio, drop_path_ratio=dpr[i], norm_layer=norm_layer,
+                  act_layer=act_layer, numerics=self.numerics) for i in range(depth)])
         self.norm = norm_layer(embed_dim)
         if representation_size and not distilled:
             self.has_logits = True

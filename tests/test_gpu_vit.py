@@ -238,3 +238,72 @@ def test_scale_embed_transformer_distilled_as_upstream():
     assert r0.shape == (2, 768) and r1.shape == (2, 768)
     (a0, a1), (b0, b1) = net(xa, f, xa, f)
     assert torch.allclose(a0, r0, atol=1e-5) and torch.allclose(b1, r1, atol=1e-5)
+
+
+def test_stochastic_depth_blocks(monkeypatch):
+    """drop_path_ratio > 0 (vit_model.py:12-40, :171-185; nets/ShfitScaleFormer.py:170-183): per-sample mask floor(keep + U) / keep on
+    both residual branches in training mode, identity in eval mode.  The mask's uniform numbers are fixed by patching torch.rand, the
+    expected values come from a plain torch fp32 restatement of the block with the same mask (forward, input gradient and a weight
+    gradient); eval mode must equal the fused block bit for bit; the decay rule gives block i ratio i / (depth - 1) * rate."""
+    import torch.nn.functional as F
+    vm = VM()
+    from deepmerge_amd.nets import ShfitScaleFormer as S
+    torch.manual_seed(3)
+    B, N, C, H = 4, 64, 768, 12
+    for kind in ("vit", "s2"):
+        if kind == "vit":
+            blk = vm.Block(dim=C, num_heads=H, qkv_bias=True, drop_path_ratio=0.25, numerics="fp32").to(DEV)
+            fused = vm.Block(dim=C, num_heads=H, qkv_bias=True, drop_path_ratio=0., numerics="fp32").to(DEV)
+        else:
+            blk = S.CrossScaleBlock(dim=C, num_heads=H, cube_size=[1, 8, 8], drop_path_ratio=0.25, numerics="fp32").to(DEV)
+            fused = S.CrossScaleBlock(dim=C, num_heads=H, cube_size=[1, 8, 8], drop_path_ratio=0., numerics="fp32").to(DEV)
+        with torch.no_grad():
+            for p_ in blk.parameters():
+                p_.copy_(torch.randn_like(p_) * 0.05)
+        fused.load_state_dict(blk.state_dict())
+        assert blk._dm_fused_block is False and fused._dm_fused_block is True and isinstance(blk.drop_path, S.DropPath)
+        x = torch.randn(B, N, C, device=DEV)
+        blk.eval(); fused.eval()
+        with torch.no_grad():
+            assert torch.equal(blk(x), fused(x))                       # eval mode: the fused node, no mask
+        # training mode with known uniforms: samples 0 and 2 are dropped on the first branch, sample 3 on the second
+        draws = [torch.tensor([0.1, 0.9, 0.2, 0.8]), torch.tensor([0.9, 0.8, 0.7, 0.1])]
+        calls = []
+
+        def fake_rand(shape, dtype=None, device=None):
+            calls.append(tuple(shape))
+            return draws[len(calls) - 1].to(device=device, dtype=dtype).reshape(shape)
+        monkeypatch.setattr(torch, "rand", fake_rand)
+        blk.train()
+        xin = x.clone().requires_grad_(True)
+        y = blk(xin)
+        (y * y).sum().backward()
+        monkeypatch.undo()
+        assert calls == [(B, 1, 1), (B, 1, 1)]
+        keep = 0.75
+        masks = [torch.floor(keep + d).to(DEV).view(B, 1, 1) / keep for d in draws]
+        # torch restatement
+        sd = {k: v.detach().clone().requires_grad_(v.dtype.is_floating_point) for k, v in blk.state_dict().items()}
+        xr = x.clone().requires_grad_(True)
+        h1 = F.layer_norm(xr, (C,), sd["norm1.weight"], sd["norm1.bias"], blk.norm1.eps)
+        qkv = F.linear(h1, sd["attn.qkv.weight"], sd["attn.qkv.bias"]).reshape(B, N, 3, H, C // H).permute(2, 0, 3, 1, 4)
+        att = (qkv[0] * (C // H) ** -0.5) @ qkv[1].transpose(-2, -1)
+        if kind == "s2":
+            idx = blk.attn.relative_position_index.view(-1).long()
+            att = att + sd["attn.relative_position_bias_table"][idx].view(N, N, H).permute(2, 0, 1).unsqueeze(0)
+        a = F.linear((att.softmax(-1) @ qkv[2]).transpose(1, 2).reshape(B, N, C), sd["attn.proj.weight"], sd["attn.proj.bias"])
+        x1 = xr + a * masks[0]
+        h2 = F.layer_norm(x1, (C,), sd["norm2.weight"], sd["norm2.bias"], blk.norm2.eps)
+        m = F.linear(F.gelu(F.linear(h2, sd["mlp.fc1.weight"], sd["mlp.fc1.bias"])), sd["mlp.fc2.weight"], sd["mlp.fc2.bias"])
+        yr = x1 + m * masks[1]
+        (yr * yr).sum().backward()
+        rel = lambda got, want: float((got - want).norm() / want.norm())
+        assert rel(y.detach(), yr.detach()) < 1e-4 and rel(xin.grad, xr.grad) < 1e-3
+        assert rel(blk.mlp.fc1.weight.grad, sd["mlp.fc1.weight"].grad) < 1e-3 and rel(blk.attn.qkv.weight.grad, sd["attn.qkv.weight"].grad) < 1e-3
+        # sample 3's second branch is dropped: y = x1 there
+        assert rel(y[3].detach(), x1[3].detach()) < 1e-4
+    # the decay rule (vit_model.py:229): block i of a depth-4 encoder at rate 0.3 drops with probability 0.1 i
+    net = vm.VisionTransformer(img_size=32, patch_size=16, embed_dim=768, depth=4, num_heads=12, num_classes=10, drop_path_ratio=0.3, numerics="fp32")
+    got = [getattr(b.drop_path, "drop_prob", 0.0) for b in net.blocks]
+    assert np.allclose(got, [0.0, 0.1, 0.2, 0.3]) and isinstance(net.blocks[0].drop_path, torch.nn.Identity)
+
