@@ -64,6 +64,9 @@ SIGNATURES = {
     "dm_gemm": (_I, [C.POINTER(DmGemmArgs), _P]),
     "dm_gemm_workspace_bytes": (_L, [_I, _I, _I, _I]),
     "dm_attention_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _P]),
+    "dm_attention_relpos_inkernel": (_I, [_I, _I, _I, _I, _I, _I, _I, _I]),
+    "dm_attention_fwd_relpos": (_I, [_P, _P, _I, _I, _I, _P, _P, _I, _I, _I, _I, _F, _I, _P]),
+    "dm_attention_bwd_relpos": (_I, [_P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _P]),
     "dm_attention_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _P]),
     "dm_attention_bwd_batch_chunks": (_I, [_I, _I, _I, _I]),
     "dm_relpos_bias_gather": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),

@@ -593,9 +593,43 @@ extern "C" int dm_attention_fwd(const void *qkv, const float *bias, void *out, f
   return DM_OK;
 }
 
-extern "C" int dm_attention_bwd(const void *qkv, const float *bias, const float *bias_t, const void *out, const void *dout,
-                                const float *lse, void *dqkv, float *delta, float *dbias_slab, int32_t B, int32_t N, int32_t H, int32_t D, float scale, int32_t dtype,
-                                void *stream) {
+// Forward with the relative-position bias formed inside the kernel from the table (no dense [H, N, N] rows): the 32-rows-per-wave
+// kernel with the head's table in LDS (dm_attention_q32.hip).  Token cube (cube_s, 8, 8), scale-major then row-major.
+static bool relpos_inkernel(int32_t B, int32_t N, int32_t H, int32_t D, int32_t cube_s, int32_t cube_h, int32_t cube_w, int32_t dtype) {
+  if (dtype != DM_BF16 || D != HD || cube_h != 8 || cube_w != 8 || B <= 0 || H <= 0) return false;
+  AttnPipeParams pp{nullptr, nullptr, nullptr, nullptr, B, N, H, 1.f};
+  pp.table = reinterpret_cast<const float *>(16);      // (shape decision only)
+  pp.cube_s = cube_s;
+  return dm_attn_fwd_q32_takes(pp);
+}
+
+extern "C" int32_t dm_attention_relpos_inkernel(int32_t B, int32_t N, int32_t H, int32_t D, int32_t cube_s, int32_t cube_h, int32_t cube_w,
+                                                int32_t dtype) {
+  return relpos_inkernel(B, N, H, D, cube_s, cube_h, cube_w, dtype) ? 1 : 0;
+}
+
+extern "C" int dm_attention_fwd_relpos(const void *qkv, const float *table, int32_t cube_s, int32_t cube_h, int32_t cube_w, void *out,
+                                       float *lse, int32_t B, int32_t N, int32_t H, int32_t D, float scale, int32_t dtype, void *stream) {
+  DM_REQUIRE(relpos_inkernel(B, N, H, D, cube_s, cube_h, cube_w, dtype), DM_ERR_UNSUPPORTED,
+             "dm_attention_fwd_relpos: shape not taken (B=%d N=%d H=%d D=%d cube=%dx%dx%d dtype=%d); gather the bias and call dm_attention_fwd",
+             B, N, H, D, cube_s, cube_h, cube_w, dtype);
+  DM_REQUIRE(qkv && table && out && lse, DM_ERR_BAD_SHAPE, "dm_attention_fwd_relpos: null pointer");
+  DM_REQUIRE(dm_aligned16(qkv) && dm_aligned16(out), DM_ERR_BAD_ALIGN, "dm_attention_fwd_relpos: qkv/out must be 16-byte aligned");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  {
+    DmProfScope prof("attn_fwd_bf16", s, 4.0 * B * H * (double)N * N * HD, 2.0 * 4.0 * B * H * (double)N * HD);
+    AttnPipeParams pp{qkv, nullptr, out, lse, B, N, H, scale};
+    pp.table = table;
+    pp.cube_s = cube_s;
+    DM_REQUIRE(dm_attn_fwd_q32(pp, s), DM_ERR_UNSUPPORTED, "dm_attention_fwd_relpos: kernel could not be configured");
+  }
+  DM_LAUNCH_CHECK("dm_attention_fwd_relpos");
+  return DM_OK;
+}
+
+static int attention_bwd(const void *qkv, const float *bias, const float *bias_t, const float *table, int32_t cube_s, const void *out,
+                         const void *dout, const float *lse, void *dqkv, float *delta, float *dbias_slab, int32_t B, int32_t N, int32_t H,
+                         int32_t D, float scale, int32_t dtype, void *stream) {
   if (dm_attn_generic_shape(N, D)) {
     DM_REQUIRE(B > 0 && H > 0 && H <= 65535 && B <= 65535 && (dtype == DM_F32 || dtype == DM_BF16) && qkv && out && dout && lse && dqkv && delta,
                DM_ERR_BAD_SHAPE, "dm_attention_bwd: bad arguments (B=%d H=%d dtype=%d)", B, H, dtype);
@@ -622,6 +656,8 @@ extern "C" int dm_attention_bwd(const void *qkv, const float *bias, const float 
     bool piped = false;
     if (dtype == DM_BF16) {
       AttnPipeBwdParams pp{qkv, bias, out, dout, lse, delta, dqkv, dbias_slab, B, N, H, scale};
+      pp.table = table;
+      pp.cube_s = cube_s;
       if (dm_attn_bwd_pipe_ok(pp)) {      // 32 rows per wave where those kernels take the pass (dm_attention_q32_bwd.hip), else 16
         const bool dq = dm_attn_bwd_dq_q32(pp, s);
         piped = (dq && dm_attn_bwd_dkv_q32(pp, s)) || dm_attn_bwd_pipe(pp, s, dq);
@@ -634,4 +670,22 @@ extern "C" int dm_attention_bwd(const void *qkv, const float *bias, const float 
   }
   DM_LAUNCH_CHECK("dm_attention_bwd");
   return DM_OK;
+}
+
+extern "C" int dm_attention_bwd(const void *qkv, const float *bias, const float *bias_t, const void *out, const void *dout,
+                                const float *lse, void *dqkv, float *delta, float *dbias_slab, int32_t B, int32_t N, int32_t H, int32_t D, float scale, int32_t dtype,
+                                void *stream) {
+  return attention_bwd(qkv, bias, bias_t, nullptr, 0, out, dout, lse, dqkv, delta, dbias_slab, B, N, H, D, scale, dtype, stream);
+}
+
+// The backward of dm_attention_fwd_relpos: the passes that can form the bias from the table inside the kernel do (the dQ pass, 8 waves
+// with the head's table in LDS); the others read the dense rows, which the caller still supplies.
+extern "C" int dm_attention_bwd_relpos(const void *qkv, const float *table, int32_t cube_s, int32_t cube_h, int32_t cube_w, const float *bias,
+                                       const float *bias_t, const void *out, const void *dout, const float *lse, void *dqkv, float *delta,
+                                       float *dbias_slab, int32_t B, int32_t N, int32_t H, int32_t D, float scale, int32_t dtype, void *stream) {
+  DM_REQUIRE(table && bias, DM_ERR_BAD_SHAPE, "dm_attention_bwd_relpos: table and dense bias are both required");
+  DM_REQUIRE(relpos_inkernel(B, N, H, D, cube_s, cube_h, cube_w, dtype), DM_ERR_UNSUPPORTED,
+             "dm_attention_bwd_relpos: shape not taken (B=%d N=%d H=%d D=%d cube=%dx%dx%d dtype=%d); call dm_attention_bwd", B, N, H, D, cube_s,
+             cube_h, cube_w, dtype);
+  return attention_bwd(qkv, bias, bias_t, table, cube_s, out, dout, lse, dqkv, delta, dbias_slab, B, N, H, D, scale, dtype, stream);
 }

@@ -9,6 +9,8 @@ struct AttnPipeParams {
   float *lse;           // [B, H, N]
   int B, N, H;
   float scale;
+  const float *table = nullptr;   // [bins, H] fp32 relative-position table of a (cube_s, 8, 8) token cube, instead of `bias` (q32 kernels only)
+  int cube_s = 0;
 };
 
 // true if the pipelined forward kernel took the call (bf16, N a multiple of 16 in [128, 256]); false: nothing launched
@@ -17,6 +19,7 @@ bool dm_attn_fwd_pipe(const AttnPipeParams &p, hipStream_t s);
 // Forward with 32 query rows per wave on the 32x32x16 MFMA, online softmax (dm_attention_q32.hip): bf16, 128 < N <= 256.
 // true if it took the call; DM_ATTN_Q32=0 disables it (A/B runs against the kernel above).
 bool dm_attn_fwd_q32(const AttnPipeParams &p, hipStream_t s);
+bool dm_attn_fwd_q32_takes(const AttnPipeParams &p);      // the same decision without launching
 
 struct AttnPipeBwdParams {
   const void *qkv;      // [B, N, 3, H, 64] bf16
@@ -29,6 +32,8 @@ struct AttnPipeBwdParams {
   float *slab;          // [chunks, H, N, N] fp32 or NULL: sum over the chunk's samples of dS
   int B, N, H;
   float scale;
+  const float *table = nullptr;   // [bins, H] relative-position table of a (cube_s, 8, 8) token cube: the q32 dQ kernel reads it instead of `bias`
+  int cube_s = 0;
 };
 
 // Number of batch chunks the pipelined backward uses (first dimension of `slab`); 0 if it does not take this shape.

@@ -56,9 +56,16 @@ extern "C" int dm_debug_q32_stamps(unsigned long long *out) { return (int)hipMem
 
 namespace dmq32 {
 
-// NKT: 32-key tiles; RAGGED: N < 32 NKT (keys >= N are zero-filled by the DMA descriptor and masked); BIAS: p.bias != NULL.
-template <int NKT, bool RAGGED, bool BIAS, int NW>
+// NKT: 32-key tiles; RAGGED: N < 32 NKT (keys >= N are zero-filled by the DMA descriptor and masked).
+// BM: 0 no bias; 1 dense bias rows p.bias in registers; 2 the head's relative-position TABLE in LDS (p.table; tokens are a
+// (NKT / 2, 8, 8) cube, scale-major then row-major): a lane's 16 keys of a tile are 4 key rows x 4 consecutive key columns, i.e. four
+// runs of 4 consecutive table entries once the table is stored with its x axis reversed -- eight ds_read2_b32 per tile straight into
+// the score registers, which the tile's MFMAs then accumulate onto (C = D).  No bias registers: the 8-wave form applies.
+template <int NKT, bool RAGGED, int BM, int NW>
 __global__ __launch_bounds__(64 * NW, NW / 4) void attn_fwd_q32_kernel(const AttnPipeParams p, int bchunk, int nblk, int chunks) {
+  constexpr bool BIAS = BM == 1, TAB = BM == 2;
+  constexpr bool DIRECT = TAB && NW == 8;                           // no LDS left for the write-back blocks: rows leave from registers
+  static_assert(!TAB || (!RAGGED && NKT % 2 == 0), "table form: N = 64 x scales");
   constexpr int ROWS = 32 * NW;
   constexpr int NP = NKT * 32;
   const int N = RAGGED ? p.N : NP;
@@ -67,11 +74,25 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void attn_fwd_q32_kernel(const Att
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int r = lane & 31, hh = lane >> 5;
-  int h, rb, chunk;
-  if (!coords(nblk, p.H, chunks, h, rb, chunk)) return;
+  // Work units are (head, sample) pairs, u = head * B + sample.  4 waves: a workgroup owns one row block of one head for a chunk of
+  // samples (`coords`).  8 waves (RUNS: the workgroup covers all rows of a unit, nothing is shared between workgroups): the units are
+  // dealt out as gridDim.x contiguous runs of equal length +- 1, which may cross a head boundary -- 64 samples x 12 heads on 256 CUs
+  // are 3 units each, where whole-sample chunks per head would be 192 workgroups of 4.
+  constexpr bool RUNS = NW == 8;
   const int H = p.H;
-  const int b0 = chunk * bchunk, b1 = min(p.B, b0 + bchunk);
-  if (b0 >= b1) return;
+  int rb = 0, u0, u1;
+  if constexpr (RUNS) {
+    const int units = p.B * H, G = gridDim.x, base = units / G, rem = units - base * G, w = blockIdx.x;
+    u0 = w * base + min(w, rem);
+    u1 = u0 + base + (w < rem ? 1 : 0);
+  } else {
+    int h0, chunk;
+    if (!coords(nblk, H, chunks, h0, rb, chunk)) return;
+    u0 = h0 * p.B + chunk * bchunk;
+    u1 = h0 * p.B + min(p.B, chunk * bchunk + bchunk);
+  }
+  if (u0 >= u1) return;
+  int h = u0 / p.B;                                                 // head of the current unit
   const int q_wave = rb * ROWS + wave * 32;
   const int q = q_wave + r;                                         // this lane's query row
   const bool wave_live = q_wave < N;                                // a wave without rows only takes part in the DMA / barriers
@@ -111,15 +132,30 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void attn_fwd_q32_kernel(const Att
 #pragma unroll
     for (int i = 0; i < 16; ++i) cinit[0][i] = (32 * (NKT - 1) + 8 * (i >> 2) + 4 * hh + (i & 3) >= N) ? NEG_BIG : 0.f;
   }
-  auto c_of = [&](int kt) -> f32x16 {
-    if constexpr (BIAS) return cinit[kt];
-    if constexpr (RAGGED) {
-      if (kt == NKT - 1) return cinit[0];
+  // table form: rows p = (dz + S - 1) * 15 + (dy + 7) of 16 floats, entry j = 7 - dx (x reversed), pre-divided by the scale
+  constexpr int TAB_ROWS = (NKT - 1) * 15;
+  constexpr int TAB_MAXC = 15 * ((NKT - 1) >> 1) + 7;               // largest (15 kz + ky) of a key
+  float *tab = reinterpret_cast<float *>(smem + 4 * IMG + (DIRECT ? 0 : NW * WB_WAVE));
+  const float *tabl = tab;
+  auto fill_table = [&](int hd) {                                   // every thread; a barrier must follow before the table is read
+    const float inv_scale = 1.f / p.scale;
+    for (int i = t; i < (NKT - 1) * 225; i += 64 * NW) {
+      const int pz = i / 225, rem = i - pz * 225, py = rem / 15, px = rem - py * 15;
+      tab[(pz * 15 + py) * 16 + (14 - px)] = p.table[(long long)i * H + hd] * inv_scale;
     }
-    f32x16 z;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  };
+  if constexpr (TAB) {
+    fill_table(h);                                                  // (visible to the other waves behind the first unit's barrier)
+    const int qz = q >> 6, qy = (q >> 3) & 7, qx = q & 7;
+    tabl = tab + ((qz + NKT / 2 - 1) * 15 + qy + 7 - TAB_MAXC) * 16 + 7 - qx + 4 * hh;
+  }
+  // bias / scale of tile kt into its score registers: key (kz, ky, kx) = (kt >> 1, 4 (kt & 1) + c, 4 hh + e) for register 4 c + e
+  auto read_bias = [&](int kt, f32x16 &d) {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) z[i] = 0.f;
-    return z;
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) d[4 * c + e] = tabl[16 * (TAB_MAXC - (15 * (kt >> 1) + 4 * (kt & 1) + c)) + e];
   };
 
   // ---- DMA: one wave-instruction = 8 keys x 128 B (1 KiB of an image); every wave stages NKT instructions of K and of V ------------
@@ -133,8 +169,9 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void attn_fwd_q32_kernel(const Att
   unsigned step_bytes = (unsigned)__builtin_amdgcn_readfirstlane((int)(32 * tok_stride * 2));          // instruction j + 1 of a wave: 32 keys on
   asm volatile("s_nop 4" : "+s"(step_bytes));
   // buffer descriptor of sample b's rows of this head (out-of-range rows read zero): wave-uniform words in scalar registers
-  auto sample_rsrc = [&](int b) -> i32x4 {
-    const uintptr_t base = reinterpret_cast<uintptr_t>(qkv + (long long)b * N * tok_stride + (long long)h * HD);
+  auto sample_rsrc = [&](int u) -> i32x4 {
+    const int hd = u / p.B, b = u - hd * p.B;
+    const uintptr_t base = reinterpret_cast<uintptr_t>(qkv + (long long)b * N * tok_stride + (long long)hd * HD);
     i32x4 rs;
     rs[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)(base & 0xffffffffu));
     rs[1] = __builtin_amdgcn_readfirstlane((int)(unsigned)((base >> 32) & 0xffffu));
@@ -153,15 +190,16 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void attn_fwd_q32_kernel(const Att
     lds_dma(rs, kimg + (unsigned)j * 4096u, voffK, (unsigned)j * step_bytes);
     lds_dma(rs, vimg + (unsigned)j * 4096u, voffV, (unsigned)j * step_bytes);
   };
-  auto stage_all = [&](int b, int buf) {
+  auto stage_all = [&](int u, int buf) {
     if (!dma_wave) return;
-    const i32x4 rs = sample_rsrc(b);
+    const i32x4 rs = sample_rsrc(u);
 #pragma unroll
     for (int j = 0; j < NKT; ++j) stage_piece(rs, buf, j);
   };
   // Q^T fragments (B operand): lane (query r, half hh) holds d = 16 ks + 8 hh .. + 7 of its row for k-step ks
-  auto load_q = [&](int b, u32x4 (&f)[4]) {
-    const bf16_t *qrow = qkv + ((long long)b * N + q) * tok_stride + (long long)h * HD + 8 * hh;
+  auto load_q = [&](int u, u32x4 (&f)[4]) {
+    const int hd = u / p.B, b = u - hd * p.B;
+    const bf16_t *qrow = qkv + ((long long)b * N + q) * tok_stride + (long long)hd * HD + 8 * hh;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks)
       f[ks] = (wave_live && row_ok && !(DMQ_ABL & 64)) ? *reinterpret_cast<const u32x4 *>(qrow + 16 * ks) : (u32x4){0u, 0u, 0u, 0u};
@@ -189,16 +227,17 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void attn_fwd_q32_kernel(const Att
     if (!wave_live || (DMQ_ABL & 32)) return;
     fl_v = *reinterpret_cast<const u32x4 *>(wb + ((lane >> 3) + 8 * k) * WB_PITCH + (lane & 7) * 16);
   };
-  auto flush_store = [&](int b, int k) {
+  auto flush_store = [&](int u, int k) {
     if (!wave_live || (DMQ_ABL & 32)) return;
-    bf16_t *orow0 = reinterpret_cast<bf16_t *>(p.out) + ((long long)b * N + q_wave) * H * HD + (long long)h * HD;
+    const int hd = u / p.B, b = u - hd * p.B;
+    bf16_t *orow0 = reinterpret_cast<bf16_t *>(p.out) + ((long long)b * N + q_wave) * H * HD + (long long)hd * HD;
     const int rr = lane >> 3, cc = lane & 7;
     if (q_wave + rr + 8 * k < N) *reinterpret_cast<u32x4 *>(orow0 + (long long)(rr + 8 * k) * H * HD + cc * 8) = fl_v;
-    if (k == 0 && hh == 0 && row_ok) p.lse[((long long)b * H + h) * N + q] = lse_prev;
+    if (k == 0 && hh == 0 && row_ok) p.lse[((long long)b * H + hd) * N + q] = lse_prev;
   };
-  auto flush = [&](int b) {
+  auto flush = [&](int u) {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { flush_read(k); flush_store(b, k); }
+    for (int k = 0; k < 4; ++k) { flush_read(k); flush_store(u, k); }
   };
 
   constexpr float RESCALE_LOG2 = 16.f;                              // a later tile may exceed the reference maximum by 2^16 before l / O are rescaled
@@ -206,15 +245,24 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void attn_fwd_q32_kernel(const Att
   constexpr bool PAD = NW == 8;
   static_assert(!(BIAS && NW == 8), "the bias rows need the 512-register budget of one wave per SIMD");
   u32x4 qf[4], qld[4];                                              // qld: the next sample's rows, requested late in this sample
-  stage_all(b0, 0);
-  load_q(b0, qld);
-  for (int b = b0; b < b1; ++b) {
+  stage_all(u0, 0);
+  load_q(u0, qld);
+  for (int b = u0; b < u1; ++b) {                                   // b: the unit (head * B + sample)
+    const int b0 = u0, b1 = u1;
     const int buf = (b - b0) & 1;
     DMQ_T(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // this sample's K / V / Q have landed (issued during the previous sample)
     DMQ_T(1);
     __builtin_amdgcn_s_barrier();                                   // ... for every wave; and everyone is done with the other buffer
     DMQ_T(2);
+    if constexpr (RUNS) {
+      const int hn = b / p.B;
+      if (TAB && hn != h) {                                         // the run crossed into the next head: everyone is past the old table's last read
+        fill_table(hn);
+        __builtin_amdgcn_s_barrier();
+      }
+      h = hn;
+    }
     const bool more = b + 1 < b1;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
@@ -255,7 +303,8 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void attn_fwd_q32_kernel(const Att
       auto qk_piece = [&](int kt, int ks, f32x16 &d) {
         if ((DMQ_ABL & 16) && kt > 0) return;
         if (ks == 0) {
-          if constexpr (BIAS) qk_first<QA, PAD>(d, kf[0], qf[0], cinit[kt]);
+          if constexpr (TAB) qk_acc<QA, PAD>(d, kf[0], qf[0]);       // d holds bias / scale (read_bias)
+          else if constexpr (BIAS) qk_first<QA, PAD>(d, kf[0], qf[0], cinit[kt]);
           else if (RAGGED && kt == NKT - 1) qk_first<QA, PAD>(d, kf[0], qf[0], cinit[0]);
           else qk_first0<QA, PAD>(d, kf[0], qf[0]);
         } else {
@@ -339,6 +388,10 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void attn_fwd_q32_kernel(const Att
       };
 
       // ---- prologue: tile 0's scores and their maximum ------------------------------------------------------------------------------------
+      if constexpr (TAB) {
+        read_bias(0, s0);
+        if (NKT > 1) read_bias(1, s1);
+      }
       read_k(0);
       asm volatile("s_nop 1");                                       // Q^T copies into accumulator registers may be fresh (VALU write -> MFMA operand)
       qk_piece(0, 0, s0); qk_piece(0, 1, s0); qk_piece(0, 2, s0); qk_piece(0, 3, s0);
@@ -381,8 +434,11 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void attn_fwd_q32_kernel(const Att
           // previous sample's rows: a quarter per tile over the LAST four tiles, stored six gaps after its LDS read.  (The vector-memory
           // instructions of a sample -- K / V pieces, Q rows, these stores -- are spread over its tiles: bunched into the first
           // four they ran into the CU's ~11 B/clk memory path, +1200 cycles per sample in the 8-wave form.)
-          if (g == 1 && b > b0 && j >= NKT - 4) flush_read(j - (NKT - 4));
-          if (g == 7 && b > b0 && j >= NKT - 4) flush_store(b - 1, j - (NKT - 4));
+          if constexpr (!DIRECT) {
+            if (g == 1 && b > b0 && j >= NKT - 4) flush_read(j - (NKT - 4));
+            if (g == 7 && b > b0 && j >= NKT - 4) flush_store(b - 1, j - (NKT - 4));
+          }
+          if (TAB && g == 8 && j + 2 < NKT) read_bias(j + 2, sc);     // tile j's scores were last read in gap 7; tile j + 2 accumulates onto these
           if (g == 5 && more) {                                      // next sample's K / V: one (K, V) pair of pieces per tile, all before the last
             if (j < NKT - 1) stage_piece(rs_next, buf ^ 1, j);
             if (j == 0) stage_piece(rs_next, buf ^ 1, NKT - 1);
@@ -414,6 +470,30 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void attn_fwd_q32_kernel(const Att
       const float inv = 1.f / l;
       lse_prev = (m * scale2 + __builtin_amdgcn_logf(l)) * LN2;      // natural-log units for the backward kernels
       // lane (query r, half hh) holds d = 32 dt + 8 c + 4 hh + e in register 4 c + e of o<dt>
+      if constexpr (DIRECT) {
+        // the two halves of a row trade 8-byte pieces so that each lane owns 16 contiguous bytes: half 0 keeps the even c, half 1 the odd
+        const int smp = b - h * p.B;
+        bf16_t *orow = reinterpret_cast<bf16_t *>(p.out) + ((long long)smp * N + q) * H * HD + (long long)h * HD + 8 * hh;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          const f32x16 &o = dt ? o1 : o0;
+#pragma unroll
+          for (int cp = 0; cp < 2; ++cp) {
+            const int c0 = 2 * cp, c1 = c0 + 1;
+            u32x4 w;
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+              const unsigned a = pk_bf16(o[4 * c0 + 2 * k] * inv, o[4 * c0 + 2 * k + 1] * inv);
+              const unsigned bb = pk_bf16(o[4 * c1 + 2 * k] * inv, o[4 * c1 + 2 * k + 1] * inv);
+              const auto sw = __builtin_amdgcn_permlane32_swap(a, bb, false, false);
+              w[k] = (unsigned)sw[0];
+              w[2 + k] = (unsigned)sw[1];
+            }
+            *reinterpret_cast<u32x4 *>(orow + 32 * dt + 16 * cp) = w;
+          }
+        }
+        if (hh == 0) p.lse[((long long)smp * H + h) * N + q] = lse_prev;
+      } else
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         const u32x2 w0 = {pk_bf16(o0[4 * c] * inv, o0[4 * c + 1] * inv), pk_bf16(o0[4 * c + 2] * inv, o0[4 * c + 3] * inv)};
@@ -427,7 +507,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void attn_fwd_q32_kernel(const Att
     }
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  flush(b1 - 1);
+  if constexpr (!DIRECT) flush(u1 - 1);
 }
 
 inline void grid(int B, int N, int H, int rows, int &nblk, int &chunks, int &bchunk) {
@@ -439,38 +519,51 @@ inline void grid(int B, int N, int H, int rows, int &nblk, int &chunks, int &bch
   chunks = (B + bchunk - 1) / bchunk;
 }
 
-template <int NKT, bool RAGGED, bool BIAS, int NW> bool launch(const AttnPipeParams &p, hipStream_t s) {
-  constexpr int LDS = 4 * NKT * 32 * 128 + NW * WB_WAVE;
+template <int NKT, bool RAGGED, int BM, int NW> bool launch(const AttnPipeParams &p, hipStream_t s) {
+  constexpr int LDS = 4 * NKT * 32 * 128 + (BM == 2 && NW == 8 ? 0 : NW * WB_WAVE) + (BM == 2 ? (NKT - 1) * 15 * 64 : 0);
   static_assert(LDS <= 160 * 1024, "LDS budget");
-  static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void *>(attn_fwd_q32_kernel<NKT, RAGGED, BIAS, NW>),
+  static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void *>(attn_fwd_q32_kernel<NKT, RAGGED, BM, NW>),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS) == hipSuccess;
   if (!ok) return false;
   int nblk, chunks, bchunk;
   grid(p.B, p.N, p.H, 32 * NW, nblk, chunks, bchunk);
-  hipLaunchKernelGGL((attn_fwd_q32_kernel<NKT, RAGGED, BIAS, NW>), dim3(grid_size(nblk, p.H, chunks)), dim3(64 * NW), LDS, s, p, bchunk, nblk, chunks);
+  const int wgs = NW == 8 ? (p.B * p.H < 256 ? p.B * p.H : 256) : grid_size(nblk, p.H, chunks);      // 8 waves: one run of units per CU
+  hipLaunchKernelGGL((attn_fwd_q32_kernel<NKT, RAGGED, BM, NW>), dim3(wgs), dim3(64 * NW), LDS, s, p, bchunk, nblk, chunks);
   return true;
 }
 
 template <int NKT> bool launch_n(const AttnPipeParams &p, hipStream_t s) {
   const bool ragged = p.N != NKT * 32;
-  if (p.bias) return ragged ? launch<NKT, true, true, 4>(p, s) : launch<NKT, false, true, 4>(p, s);
+  if constexpr (NKT % 2 == 0) {
+    if (p.table) {                               // DM_ATTN_Q32_TABW=4: the table form with one wave per SIMD (A/B runs)
+      static const int tabw = [] { const char *e = getenv("DM_ATTN_Q32_TABW"); return e ? atoi(e) : 8; }();
+      return tabw == 4 ? launch<NKT, false, 2, 4>(p, s) : launch<NKT, false, 2, 8>(p, s);
+    }
+  }
+  if (p.bias) return ragged ? launch<NKT, true, 1, 4>(p, s) : launch<NKT, false, 1, 4>(p, s);
   if constexpr (NKT <= 7) {                     // 8 waves: two per SIMD, K / V staged once per (sample, head); DM_ATTN_Q32_W8=0 for A/B runs
     static const bool w8 = [] { const char *e = getenv("DM_ATTN_Q32_W8"); return !(e && atoi(e) == 0); }();
-    if (w8) return ragged ? launch<NKT, true, false, 8>(p, s) : launch<NKT, false, false, 8>(p, s);
+    if (w8) return ragged ? launch<NKT, true, 0, 8>(p, s) : launch<NKT, false, 0, 8>(p, s);
   }
-  return ragged ? launch<NKT, true, false, 4>(p, s) : launch<NKT, false, false, 4>(p, s);
+  return ragged ? launch<NKT, true, 0, 4>(p, s) : launch<NKT, false, 0, 4>(p, s);
 }
 
 }  // namespace dmq32
 
 // bf16, head dim 64, 128 < N <= 256 (5 .. 8 key tiles of 32).  DM_ATTN_Q32=0 keeps the 16-row pipelined kernels (A/B runs).
-bool dm_attn_fwd_q32(const AttnPipeParams &p, hipStream_t s) {
+bool dm_attn_fwd_q32_takes(const AttnPipeParams &p) {
   static const int mode = [] { const char *e = getenv("DM_ATTN_Q32"); return e ? atoi(e) : 1; }();
   if (mode == 0) return false;
   if (p.N <= 128 || p.N > 256) return false;
   if ((long long)p.N * 3 * p.H * 64 * 2 >= (1LL << 31)) return false;          // one sample's rows must fit a 32-bit DMA offset
   if (mode != 2 && p.B * p.H < 96) return false;                              // too little work for persistent workgroups
   if (p.bias && (reinterpret_cast<uintptr_t>(p.bias) & 15u)) return false;
+  if (p.table && (p.bias || p.N != 64 * p.cube_s || (p.cube_s != 3 && p.cube_s != 4))) return false;
+  return true;
+}
+
+bool dm_attn_fwd_q32(const AttnPipeParams &p, hipStream_t s) {
+  if (!dm_attn_fwd_q32_takes(p)) return false;
   switch ((p.N + 31) / 32) {
     case 5: return dmq32::launch_n<5>(p, s);
     case 6: return dmq32::launch_n<6>(p, s);

@@ -32,8 +32,14 @@ __device__ __forceinline__ float dot2(unsigned a, unsigned b, float c) {
   return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, a), __builtin_bit_cast(bf16x2, b), c, false);
 }
 
-template <int NKT, bool RAGGED, bool BIAS, int NW>
+// BM: 0 no bias, 1 dense bias rows in accumulator registers (4 waves), 2 the head's relative-position table in LDS (8 waves; see the
+// forward kernel: eight ds_read2_b32 per tile put bias / scale into the score registers, the S^T chain accumulates onto them).
+template <int NKT, bool RAGGED, int BM, int NW>
 __global__ __launch_bounds__(64 * NW, NW / 4) void attn_bwd_dq_q32_kernel(const AttnPipeBwdParams p, int bchunk, int nblk, int chunks) {
+  constexpr bool BIAS = BM == 1, TAB = BM == 2;
+  constexpr bool DIRECT = TAB && NW == 8;                           // no LDS left for the write-back blocks: rows leave from registers
+  constexpr bool RUNS = NW == 8;                                    // (head, sample) units dealt out as contiguous runs (forward kernel)
+  static_assert(!TAB || (!RAGGED && NKT % 2 == 0 && NW == 8), "table form: N = 64 x scales, 8 waves");
   constexpr int ROWS = 32 * NW;
   constexpr int NP = NKT * 32;
   const int N = RAGGED ? p.N : NP;
@@ -42,11 +48,20 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void attn_bwd_dq_q32_kernel(const 
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int r = lane & 31, hh = lane >> 5;
-  int h, rb, chunk;
-  if (!coords(nblk, p.H, chunks, h, rb, chunk)) return;
   const int H = p.H;
-  const int b0 = chunk * bchunk, b1 = min(p.B, b0 + bchunk);
-  if (b0 >= b1) return;
+  int rb = 0, u0, u1;
+  if constexpr (RUNS) {
+    const int units = p.B * H, G = gridDim.x, base = units / G, rem = units - base * G, w = blockIdx.x;
+    u0 = w * base + min(w, rem);
+    u1 = u0 + base + (w < rem ? 1 : 0);
+  } else {
+    int h0, chunk;
+    if (!coords(nblk, H, chunks, h0, rb, chunk)) return;
+    u0 = h0 * p.B + chunk * bchunk;
+    u1 = h0 * p.B + min(p.B, chunk * bchunk + bchunk);
+  }
+  if (u0 >= u1) return;
+  int h = u0 / p.B;                                                 // head of the current unit
   const int q_wave = rb * ROWS + wave * 32;
   const int q = q_wave + r;
   const bool wave_live = q_wave < N;
@@ -101,8 +116,9 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void attn_bwd_dq_q32_kernel(const 
   const unsigned lds0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(uintptr_t)(DM_LDS char *)smem);
   unsigned step_bytes = (unsigned)__builtin_amdgcn_readfirstlane((int)(32 * tok_stride * 2));
   asm volatile("s_nop 4" : "+s"(step_bytes));
-  auto sample_rsrc = [&](int b) -> i32x4 {
-    const uintptr_t base = reinterpret_cast<uintptr_t>(qkv + (long long)b * N * tok_stride + (long long)h * HD);
+  auto sample_rsrc = [&](int u) -> i32x4 {
+    const int hd = u / p.B, b = u - hd * p.B;
+    const uintptr_t base = reinterpret_cast<uintptr_t>(qkv + (long long)b * N * tok_stride + (long long)hd * HD);
     i32x4 rs;
     rs[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)(base & 0xffffffffu));
     rs[1] = __builtin_amdgcn_readfirstlane((int)(unsigned)((base >> 32) & 0xffffu));
@@ -118,24 +134,48 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void attn_bwd_dq_q32_kernel(const 
     lds_dma(rs, kimg + (unsigned)j * 4096u, voffK, (unsigned)j * step_bytes);
     lds_dma(rs, vimg + (unsigned)j * 4096u, voffV, (unsigned)j * step_bytes);
   };
-  auto stage_all = [&](int b, int buf) {
+  auto stage_all = [&](int u, int buf) {
     if (!dma_wave) return;
-    const i32x4 rs = sample_rsrc(b);
+    const i32x4 rs = sample_rsrc(u);
 #pragma unroll
     for (int j = 0; j < NKT; ++j) stage_piece(rs, buf, j);
   };
   // this lane's rows of the next sample: Q and dO fragments (B operands: d = 16 ks + 8 hh .. + 7), the O fragment for delta, lse
-  auto load_rows = [&](int b, u32x4 (&fq)[4], u32x4 (&fdo)[4], u32x4 (&fo)[4], float &lse) {
+  auto load_rows = [&](int u, u32x4 (&fq)[4], u32x4 (&fdo)[4], u32x4 (&fo)[4], float &lse) {
+    const int hd = u / p.B, b = u - hd * p.B;
     const bool ok = wave_live && row_ok && !(DMQ_ABL & 64);
-    const bf16_t *qrow = qkv + ((long long)b * N + q) * tok_stride + (long long)h * HD + 8 * hh;
-    const long long orow = ((long long)b * N + q) * H * HD + (long long)h * HD + 8 * hh;
+    const bf16_t *qrow = qkv + ((long long)b * N + q) * tok_stride + (long long)hd * HD + 8 * hh;
+    const long long orow = ((long long)b * N + q) * H * HD + (long long)hd * HD + 8 * hh;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       fq[ks] = ok ? *reinterpret_cast<const u32x4 *>(qrow + 16 * ks) : (u32x4){0u, 0u, 0u, 0u};
       fdo[ks] = ok ? *reinterpret_cast<const u32x4 *>(dout + orow + 16 * ks) : (u32x4){0u, 0u, 0u, 0u};
       fo[ks] = ok ? *reinterpret_cast<const u32x4 *>(outp + orow + 16 * ks) : (u32x4){0u, 0u, 0u, 0u};
     }
-    lse = ok ? p.lse[((long long)b * H + h) * N + q] : 0.f;
+    lse = ok ? p.lse[((long long)b * H + hd) * N + q] : 0.f;
+  };
+  // table form (see the forward kernel): rows p = (dz + S - 1) * 15 + (dy + 7) of 16 floats, entry 7 - dx, pre-divided by the scale
+  constexpr int TAB_MAXC = 15 * ((NKT - 1) >> 1) + 7;
+  float *tab = reinterpret_cast<float *>(smem + 4 * IMG + (DIRECT ? 0 : NW * WB_WAVE));
+  const float *tabl = tab;
+  auto fill_table = [&](int hd) {                                   // every thread; a barrier must follow before the table is read
+    const float inv_scale = 1.f / p.scale;
+    for (int i = t; i < (NKT - 1) * 225; i += 64 * NW) {
+      const int pz = i / 225, rem = i - pz * 225, py = rem / 15, px = rem - py * 15;
+      tab[(pz * 15 + py) * 16 + (14 - px)] = p.table[(long long)i * H + hd] * inv_scale;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  };
+  if constexpr (TAB) {
+    fill_table(h);
+    const int qz = q >> 6, qy = (q >> 3) & 7, qx = q & 7;
+    tabl = tab + ((qz + NKT / 2 - 1) * 15 + qy + 7 - TAB_MAXC) * 16 + 7 - qx + 4 * hh;
+  }
+  auto read_bias = [&](int kt, f32x16 &d) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) d[4 * c + e] = tabl[16 * (TAB_MAXC - (15 * (kt >> 1) + 4 * (kt & 1) + c)) + e];
   };
 
   // ---- fragment offsets ---------------------------------------------------------------------------------------------------------
@@ -161,21 +201,32 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void attn_bwd_dq_q32_kernel(const 
     if (!wave_live || (DMQ_ABL & 32)) return;
     fl_v = *reinterpret_cast<const u32x4 *>(wb + ((lane >> 3) + 8 * k) * WB_PITCH + (lane & 7) * 16);
   };
-  auto flush_store = [&](int b, int k) {                            // dQ rows of sample b: dqkv[b][q][0][h][:]
+  auto flush_store = [&](int u, int k) {                            // dQ rows of unit u: dqkv[b][q][0][h][:]
     if (!wave_live || (DMQ_ABL & 32)) return;
-    bf16_t *drow0 = reinterpret_cast<bf16_t *>(p.dqkv) + ((long long)b * N + q_wave) * tok_stride + (long long)h * HD;
+    const int hd = u / p.B, b = u - hd * p.B;
+    bf16_t *drow0 = reinterpret_cast<bf16_t *>(p.dqkv) + ((long long)b * N + q_wave) * tok_stride + (long long)hd * HD;
     const int rr = lane >> 3, cc = lane & 7;
     if (q_wave + rr + 8 * k < N) *reinterpret_cast<u32x4 *>(drow0 + (long long)(rr + 8 * k) * tok_stride + cc * 8) = fl_v;
   };
 
   u32x4 qf[4], dof[4], qld[4], dold[4], old[4];
   float lse_ld = 0.f;
-  stage_all(b0, 0);
-  load_rows(b0, qld, dold, old, lse_ld);
-  for (int b = b0; b < b1; ++b) {
+  stage_all(u0, 0);
+  load_rows(u0, qld, dold, old, lse_ld);
+  for (int b = u0; b < u1; ++b) {                                   // b: the unit (head * B + sample)
+    const int b0 = u0, b1 = u1;
     const int buf = (b - b0) & 1;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    if constexpr (RUNS) {
+      const int hn = b / p.B;
+      if (TAB && hn != h) {                                         // the run crossed into the next head
+        fill_table(hn);
+        __builtin_amdgcn_s_barrier();
+      }
+      h = hn;
+    }
+    const int smp = b - h * p.B;
     const bool more = b + 1 < b1;
     // ---- per-row constants of this sample: delta = rowsum(dO . O) over both lane halves, -lse in log2 units ---------------------------
     float dl = 0.f;
@@ -185,7 +236,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void attn_bwd_dq_q32_kernel(const 
       for (int w = 0; w < 4; ++w) dl = dot2(dold[ks][w], old[ks][w], dl);
     const float delta = half_sum(dl);
     const float nl = -lse_ld * LOG2E;
-    if (wave_live && row_ok && hh == 0) p.delta[((long long)b * H + h) * N + q] = delta;
+    if (wave_live && row_ok && hh == 0) p.delta[((long long)smp * H + h) * N + q] = delta;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       qf[ks] = qld[ks];
@@ -225,6 +276,8 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void attn_bwd_dq_q32_kernel(const 
         if ((DMQ_ABL & 16) && kt > 0) return;
         if constexpr (BIAS) {
           if (ks == 0) qk_first_acc(d, kf[0], qf[0], cinit[kt]); else qk_acc_acc(d, kf[ks], qf[ks]);
+        } else if constexpr (TAB) {
+          qk_acc<QA, PAD>(d, kf[ks], qf[ks]);                        // d holds bias / scale (read_bias)
         } else {
           if (ks == 0) {
             if (RAGGED && kt == NKT - 1) qk_first<QA, PAD>(d, kf[0], qf[0], cinit[0]); else qk_first0<QA, PAD>(d, kf[0], qf[0]);
@@ -317,13 +370,14 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void attn_bwd_dq_q32_kernel(const 
         // with ONE score / dP / dS tile live -- the software-pipelined form above needs 276-300 registers, this one fits 256.
 #pragma unroll
         for (int j = 0; j < NKT; ++j) {
+          if constexpr (TAB) read_bias(j, s0);
           read_k(j);
           read_v(j);
           read_t(j);
           if (j == 0) asm volatile("s_nop 1");
           s_piece(j, 0, s0); s_piece(j, 1, s0); s_piece(j, 2, s0); s_piece(j, 3, s0);
           dp_piece(j, 0, dp0); dp_piece(j, 1, dp0); dp_piece(j, 2, dp0); dp_piece(j, 3, dp0);
-          if (b > b0 && j >= NKT - 4) flush_read(j - (NKT - 4));
+          if (!DIRECT && b > b0 && j >= NKT - 4) flush_read(j - (NKT - 4));
           if (more) {
             if (j < NKT - 1) stage_piece(rs_next, buf ^ 1, j);
             if (j == 0) stage_piece(rs_next, buf ^ 1, NKT - 1);
@@ -332,7 +386,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void attn_bwd_dq_q32_kernel(const 
           asm volatile("s_nop 15\n\ts_nop 7" : "+v"(s0), "+v"(dp0) : "v"(kf[3]), "v"(vf[0]), "v"(vf[1]), "v"(vf[2]), "v"(vf[3]));
 #pragma unroll
           for (int k = 0; k < 8; ++k) ds_piece(s0, dp0, k, dsb0);
-          if (b > b0 && j >= NKT - 4) flush_store(b - 1, j - (NKT - 4));
+          if (!DIRECT && b > b0 && j >= NKT - 4) flush_store(b - 1, j - (NKT - 4));
 #pragma unroll
           for (int g = 0; g < 4; ++g) dq_piece(j, g, dsb0);
           asm volatile("" :: "v"(tf[0]), "v"(tf[1]), "v"(tf[2]), "v"(tf[3]), "v"(tf[4]), "v"(tf[5]), "v"(tf[6]), "v"(tf[7]), "v"(dsb0[0]), "v"(dsb0[1]));
@@ -341,6 +395,28 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void attn_bwd_dq_q32_kernel(const 
       }
       // ---- scale, park the rows in the wave's LDS block ---------------------------------------------------------------------------------
       const float sc_out = p.scale;
+      if constexpr (DIRECT) {
+        // the two halves of a row trade 8-byte pieces so that each lane owns 16 contiguous bytes (forward kernel)
+        bf16_t *drow = reinterpret_cast<bf16_t *>(p.dqkv) + ((long long)smp * N + q) * tok_stride + (long long)h * HD + 8 * hh;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          const f32x16 &o = dt ? dq1 : dq0;
+#pragma unroll
+          for (int cp = 0; cp < 2; ++cp) {
+            const int c0 = 2 * cp, c1 = c0 + 1;
+            u32x4 w;
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+              const unsigned a = pk_bf16(o[4 * c0 + 2 * k] * sc_out, o[4 * c0 + 2 * k + 1] * sc_out);
+              const unsigned bb = pk_bf16(o[4 * c1 + 2 * k] * sc_out, o[4 * c1 + 2 * k + 1] * sc_out);
+              const auto sw = __builtin_amdgcn_permlane32_swap(a, bb, false, false);
+              w[k] = (unsigned)sw[0];
+              w[2 + k] = (unsigned)sw[1];
+            }
+            *reinterpret_cast<u32x4 *>(drow + 32 * dt + 16 * cp) = w;
+          }
+        }
+      } else
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         const u32x2 w0 = {pk_bf16(dq0[4 * c] * sc_out, dq0[4 * c + 1] * sc_out), pk_bf16(dq0[4 * c + 2] * sc_out, dq0[4 * c + 3] * sc_out)};
@@ -354,8 +430,10 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void attn_bwd_dq_q32_kernel(const 
     }
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  if constexpr (!DIRECT) {
 #pragma unroll
-  for (int k = 0; k < 4; ++k) { flush_read(k); flush_store(b1 - 1, k); }
+    for (int k = 0; k < 4; ++k) { flush_read(k); flush_store(u1 - 1, k); }
+  }
 }
 
 // ---- dK / dV pass without a bias (ViT: vit_model.py:125-131), 32 KEYS per wave: the key sits on the MFMA lane -------------------------
@@ -584,26 +662,30 @@ inline void grid_bwd(int B, int N, int H, int rows, int &nblk, int &chunks, int 
   chunks = (B + bchunk - 1) / bchunk;
 }
 
-template <int NKT, bool RAGGED, bool BIAS, int NW> bool launch_dq(const AttnPipeBwdParams &p, hipStream_t s) {
-  constexpr int LDS = 4 * NKT * 32 * 128 + NW * WB_WAVE;
+template <int NKT, bool RAGGED, int BM, int NW> bool launch_dq(const AttnPipeBwdParams &p, hipStream_t s) {
+  constexpr int LDS = 4 * NKT * 32 * 128 + (BM == 2 ? 0 : NW * WB_WAVE) + (BM == 2 ? (NKT - 1) * 15 * 64 : 0);
   static_assert(LDS <= 160 * 1024, "LDS budget");
-  static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void *>(attn_bwd_dq_q32_kernel<NKT, RAGGED, BIAS, NW>),
+  static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void *>(attn_bwd_dq_q32_kernel<NKT, RAGGED, BM, NW>),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS) == hipSuccess;
   if (!ok) return false;
   int nblk, chunks, bchunk;
   grid_bwd(p.B, p.N, p.H, 32 * NW, nblk, chunks, bchunk);
-  hipLaunchKernelGGL((attn_bwd_dq_q32_kernel<NKT, RAGGED, BIAS, NW>), dim3(grid_size(nblk, p.H, chunks)), dim3(64 * NW), LDS, s, p, bchunk, nblk, chunks);
+  const int wgs = NW == 8 ? (p.B * p.H < 256 ? p.B * p.H : 256) : grid_size(nblk, p.H, chunks);      // 8 waves: one run of units per CU
+  hipLaunchKernelGGL((attn_bwd_dq_q32_kernel<NKT, RAGGED, BM, NW>), dim3(wgs), dim3(64 * NW), LDS, s, p, bchunk, nblk, chunks);
   return true;
 }
 
 template <int NKT> bool launch_dq_n(const AttnPipeBwdParams &p, hipStream_t s) {
   const bool ragged = p.N != NKT * 32;
-  if (p.bias) return ragged ? launch_dq<NKT, true, true, 4>(p, s) : launch_dq<NKT, false, true, 4>(p, s);
+  if constexpr (NKT % 2 == 0) {
+    if (p.table && !ragged) return launch_dq<NKT, false, 2, 8>(p, s);
+  }
+  if (p.bias) return ragged ? launch_dq<NKT, true, 1, 4>(p, s) : launch_dq<NKT, false, 1, 4>(p, s);
   if constexpr (NKT <= 7) {
     static const bool w8 = [] { const char *e = getenv("DM_ATTN_Q32_W8"); return !(e && atoi(e) == 0); }();
-    if (w8) return ragged ? launch_dq<NKT, true, false, 8>(p, s) : launch_dq<NKT, false, false, 8>(p, s);
+    if (w8) return ragged ? launch_dq<NKT, true, 0, 8>(p, s) : launch_dq<NKT, false, 0, 8>(p, s);
   }
-  return ragged ? launch_dq<NKT, true, false, 4>(p, s) : launch_dq<NKT, false, false, 4>(p, s);
+  return ragged ? launch_dq<NKT, true, 0, 4>(p, s) : launch_dq<NKT, false, 0, 4>(p, s);
 }
 
 template <int NKT, bool RAGGED, int NW> bool launch_dkv(const AttnPipeBwdParams &p, hipStream_t s) {
@@ -652,6 +734,7 @@ bool dm_attn_bwd_dq_q32(const AttnPipeBwdParams &p, hipStream_t s) {
   if ((long long)p.N * 3 * p.H * 64 * 2 >= (1LL << 31)) return false;
   if (mode != 2 && p.B * p.H < 96) return false;
   if (p.bias && (reinterpret_cast<uintptr_t>(p.bias) & 15u)) return false;
+  if (p.table && (p.N != 64 * p.cube_s || (p.cube_s != 3 && p.cube_s != 4))) return false;      // (the dense rows take the pass if given)
   switch ((p.N + 31) / 32) {
     case 5: return dmq32::launch_dq_n<5>(p, s);
     case 6: return dmq32::launch_dq_n<6>(p, s);

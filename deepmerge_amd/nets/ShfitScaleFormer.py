@@ -200,7 +200,14 @@ class CrossScaleAttention(nn.Module):
         src = self.relative_position_index
         tag = (src.data_ptr(), src._version, src.device)
         if self._idx32 is None or self._idx32[0] != tag:
-            self._idx32 = (tag, src.to(torch.int32).contiguous())
+            idx = src.to(torch.int32).contiguous()
+            # The attention kernels can form the bias from the table themselves when the index is the closed form of a token cube
+            # (reference :139-156); vouch for that only after comparing (a loaded checkpoint could carry any buffer).
+            cube = tuple(int(c) for c in self.cube_size)
+            if len(cube) == 3 and tuple(src.shape) == (cube[0] * cube[1] * cube[2],) * 2 and \
+                    bool((src == relative_position_index(cube).to(src.device)).all()):
+                idx._dm_cube = cube
+            self._idx32 = (tag, idx)
         return self._idx32[1]
 
     def _run(self, y, residual2d, out_dtype):

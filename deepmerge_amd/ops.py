@@ -368,6 +368,38 @@ def attention_fwd(qkv: torch.Tensor, bias: Optional[torch.Tensor], B: int, N: in
     return out, lse
 
 
+def _inkernel_cube(table, index32, B, N, H, D, dtype):
+    """The token cube if the forward kernel can form the bias from `table` itself (the module vouches for the index: `_dm_cube` on the
+    int32 index tensor is set only after comparing it with the closed form), else None."""
+    cube = None if table is None else getattr(index32, "_dm_cube", None)
+    if cube is None or _INKERNEL_TABLE is False or not relpos_inkernel(B, N, H, D, cube, dtype):
+        return None
+    return cube
+
+
+_INKERNEL_TABLE = os.environ.get("DM_ATTN_TABLE_IN_KERNEL", "1") != "0"      # A/B switch
+
+
+def relpos_inkernel(B: int, N: int, H: int, D: int, cube, dtype: torch.dtype) -> bool:
+    """True where dm_attention_fwd_relpos takes the table itself (no dense bias rows) for a (scales, rows, cols) token cube."""
+    if cube is None or len(cube) != 3:
+        return False
+    return bool(_lib.lib().dm_attention_relpos_inkernel(B, N, H, D, int(cube[0]), int(cube[1]), int(cube[2]),
+                                                        DM_BF16 if dtype == torch.bfloat16 else DM_F32))
+
+
+def attention_fwd_relpos(qkv: torch.Tensor, table: torch.Tensor, cube, B: int, N: int, H: int, D: int, scale: float):
+    """attention_fwd with bias = table[relative_position_index(cube)], formed inside the kernel (table [n_bins, H] fp32)."""
+    _need_cuda(qkv, table)
+    if table.dtype != torch.float32 or not table.is_contiguous() or tuple(table.shape) != ((2 * cube[0] - 1) * (2 * cube[1] - 1) * (2 * cube[2] - 1), H):
+        raise ValueError(f"attention_fwd_relpos: table must be contiguous fp32 [(2s-1)(2h-1)(2w-1), H], got {tuple(table.shape)} {table.dtype}")
+    out = torch.empty((B, N, H * D), dtype=qkv.dtype, device=qkv.device)
+    lse = torch.empty((B, H, N), dtype=torch.float32, device=qkv.device)
+    check(_lib.lib().dm_attention_fwd_relpos(qkv.data_ptr(), table.data_ptr(), int(cube[0]), int(cube[1]), int(cube[2]), out.data_ptr(),
+                                             lse.data_ptr(), B, N, H, D, scale, _dt(qkv), _stream()), "dm_attention_fwd_relpos")
+    return out, lse
+
+
 _CSR_CACHE = {}
 
 
@@ -392,9 +424,10 @@ def relpos_index_csr(index32: torch.Tensor, n_bins: int):
     return hit[0], hit[1]
 
 
-def attention_bwd(qkv, bias, out, dout, lse, B, N, H, D, scale, index32=None, n_bins=0, bias_t=None):
-    """Returns (dqkv, dbias_slab or None, info); `info` goes to relpos_bias_scatter with the slab."""
-    _need_cuda(qkv, bias, out, dout, lse, index32, bias_t)
+def attention_bwd(qkv, bias, out, dout, lse, B, N, H, D, scale, index32=None, n_bins=0, bias_t=None, table=None, cube=None):
+    """Returns (dqkv, dbias_slab or None, info); `info` goes to relpos_bias_scatter with the slab.  table + cube (the forward ran
+    attention_fwd_relpos): the passes that can read the table themselves do, the dense `bias` rows serve the rest."""
+    _need_cuda(qkv, bias, out, dout, lse, index32, bias_t, table)
     dqkv = torch.empty_like(qkv)
     delta = torch.empty((B, H, N), dtype=torch.float32, device=qkv.device)
     slab, info = None, None
@@ -404,6 +437,12 @@ def attention_bwd(qkv, bias, out, dout, lse, B, N, H, D, scale, index32=None, n_
         chunks = _lib.lib().dm_attention_bwd_batch_chunks(B, N, H, _dt(qkv))
         slab = torch.empty((chunks, H, N, N), dtype=torch.float32, device=qkv.device)
         info = (chunks, N, relpos_index_csr(index32, n_bins))
+    if table is not None and cube is not None:
+        check(_lib.lib().dm_attention_bwd_relpos(qkv.data_ptr(), table.data_ptr(), int(cube[0]), int(cube[1]), int(cube[2]), _ptr(bias),
+                                                 _ptr(bias_t), out.data_ptr(), dout.data_ptr(), lse.data_ptr(), dqkv.data_ptr(),
+                                                 delta.data_ptr(), _ptr(slab), B, N, H, D, scale, _dt(qkv), _stream()),
+              "dm_attention_bwd_relpos")
+        return dqkv, slab, info
     check(_lib.lib().dm_attention_bwd(qkv.data_ptr(), _ptr(bias), _ptr(bias_t), out.data_ptr(), dout.data_ptr(), lse.data_ptr(), dqkv.data_ptr(),
                                       delta.data_ptr(), _ptr(slab), B, N, H, D, scale, _dt(qkv), _stream()),
           "dm_attention_bwd")
@@ -740,20 +779,28 @@ class AttentionFn(torch.autograd.Function):
     def forward(ctx, qkv, table, index32, B, N, H, D, scale):
         qkv = qkv.contiguous()
         bias = bias_t = None
-        if table is not None:
-            bias, bias_t = relpos_bias_gather(table.contiguous(), index32, N, transposed=True)
-        out, lse = attention_fwd(qkv, bias, B, N, H, D, scale)
-        ctx.save_for_backward(qkv, out, lse, bias, bias_t, index32)
+        cube = _inkernel_cube(table, index32, B, N, H, D, qkv.dtype)
+        if cube is not None:                                 # the kernel reads the table itself: no dense rows in the forward pass
+            out, lse = attention_fwd_relpos(qkv, table.contiguous(), cube, B, N, H, D, scale)
+        else:
+            if table is not None:
+                bias, bias_t = relpos_bias_gather(table.contiguous(), index32, N, transposed=True)
+            out, lse = attention_fwd(qkv, bias, B, N, H, D, scale)
+        ctx.save_for_backward(qkv, out, lse, bias, bias_t, index32, table if cube is not None else None)
         ctx.dims = (B, N, H, D, scale, None if table is None else table.shape[0])
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        qkv, out, lse, bias, bias_t, index32 = ctx.saved_tensors
+        qkv, out, lse, bias, bias_t, index32, table = ctx.saved_tensors
         B, N, H, D, scale, n_bins = ctx.dims
+        cube = None
+        if table is not None:
+            table, cube = table.contiguous(), index32._dm_cube
+            bias, bias_t = relpos_bias_gather(table, index32, N, transposed=True)
         want_table = bias is not None and ctx.needs_input_grad[1]
         dqkv, slab, rows = attention_bwd(qkv, bias, out, _as_operand(dout, qkv.dtype), lse, B, N, H, D, scale,
-                                         index32 if want_table else None, n_bins or 0, bias_t=bias_t)
+                                         index32 if want_table else None, n_bins or 0, bias_t=bias_t, table=table, cube=cube)
         dtable = None
         if want_table:
             dtable = torch.empty((n_bins, H), dtype=torch.float32, device=qkv.device)
@@ -1040,9 +1087,13 @@ class BlockFn(torch.autograd.Function):
         qkv = torch.empty((M, 3 * Cc), dtype=dtype, device=dev)
         gemm(DM_NT, y1, wq, qkv, M, 3 * Cc, Cc, lda=Cc, ldb=Cc, ldc=3 * Cc, bias=qkv_b)
         bias = bias_t = None
-        if table is not None:
-            bias, bias_t = relpos_bias_gather(table.contiguous(), index32, N, transposed=True)
-        o, lse = attention_fwd(qkv, bias, B, N, heads, D, scale)
+        cube = _inkernel_cube(table, index32, B, N, heads, D, dtype)
+        if cube is not None:
+            o, lse = attention_fwd_relpos(qkv, table.contiguous(), cube, B, N, heads, D, scale)
+        else:
+            if table is not None:
+                bias, bias_t = relpos_bias_gather(table.contiguous(), index32, N, transposed=True)
+            o, lse = attention_fwd(qkv, bias, B, N, heads, D, scale)
         x1 = torch.empty((M, Cc), dtype=torch.float32, device=dev)
         gemm(DM_NT, o.view(M, Cc), wp, x1, M, Cc, Cc, lda=Cc, ldb=Cc, ldc=Cc, bias=proj_b, residual=x2d)
         y2, mean2, rstd2 = layernorm_fwd(x1, n2w, n2b, eps, dtype)
@@ -1058,6 +1109,7 @@ class BlockFn(torch.autograd.Function):
         ctx.save_for_backward(x2d, mean1, rstd1, y1, qkv, o, lse, bias, bias_t, index32, x1, mean2, rstd2, y2, pre, h,
                               wq, wp, w1, w2, n1w, n2w)
         ctx.dims = (B, N, Cc, heads, D, Hd, scale, None if table is None else table.shape[0])
+        ctx.table_in_kernel = cube is not None
         ctx.params = (n1w, n1b, table, qkv_w, qkv_b, proj_w, proj_b, n2w, n2b, fc1_w, fc1_b, fc2_w, fc2_b)
         return x2.view(B, N, Cc)
 
@@ -1109,9 +1161,13 @@ class BlockFn(torch.autograd.Function):
         wgrad(DM_TN, dx1_lp, o.view(M, Cc), dwp, Cc, Cc, M, lda=Cc, ldb=Cc, ldc=Cc, accumulate=_acc(P_proj_w, k_wp), colsum_out=dbp, colsum_accumulate=_acc(P_proj_b, k_bp))
         do = torch.empty((M, Cc), dtype=dtype, device=dev)
         gemm(DM_NN, dx1_lp, wp, do, M, Cc, Cc, lda=Cc, ldb=Cc, ldc=Cc)
+        tab, cube = None, None
+        if ctx.table_in_kernel:                              # the forward kernel read the table itself; so does the dQ pass, dK / dV takes dense rows
+            tab, cube = P_table.detach().contiguous(), index32._dm_cube
+            bias, bias_t = relpos_bias_gather(tab, index32, N, transposed=True)
         want_table = bias is not None
         dqkv, slab, rows = attention_bwd(qkv, bias, o, do, lse, B, N, heads, D, scale,
-                                         index32 if want_table else None, n_bins or 0, bias_t=bias_t)
+                                         index32 if want_table else None, n_bins or 0, bias_t=bias_t, table=tab, cube=cube)
         dtable, k_t = None, False
         if want_table:
             dtable, k_t = _grad_out(P_table, (n_bins, heads), dev)

@@ -117,6 +117,17 @@ int64_t dm_gemm_workspace_bytes(int32_t layout, int32_t M, int32_t N, int32_t K)
  */
 int dm_attention_fwd(const void *qkv, const float *bias, void *out, float *lse,
                      int32_t B, int32_t N, int32_t H, int32_t D, float scale, int32_t dtype, void *stream);
+/* The same forward with the bias taken inside the kernel from relative_position_bias_table [n_bins, H] fp32 of a
+ * (cube_s, cube_h, cube_w) token cube (tokens scale-major then row-major, index rule of nets/ShfitScaleFormer.py:139-156):
+ * the dense [H,N,N] rows of dm_relpos_bias_gather are never formed.  dm_attention_relpos_inkernel returns 1 for the
+ * shapes this takes (bf16, D = 64, cube (3|4, 8, 8), N = 64 cube_s, B*H >= 96) and 0 otherwise: for those, gather and
+ * call dm_attention_fwd (dm_attention_fwd_relpos returns DM_ERR_UNSUPPORTED without launching anything).  Results equal dm_attention_fwd's
+ * on the gathered bias up to fp32 rounding of bias / scale. */
+int32_t dm_attention_relpos_inkernel(int32_t B, int32_t N, int32_t H, int32_t D, int32_t cube_s, int32_t cube_h,
+                                     int32_t cube_w, int32_t dtype);
+int dm_attention_fwd_relpos(const void *qkv, const float *table, int32_t cube_s, int32_t cube_h, int32_t cube_w,
+                            void *out, float *lse, int32_t B, int32_t N, int32_t H, int32_t D, float scale,
+                            int32_t dtype, void *stream);
 /* Backward: dqkv [B,N,3,H,D] T (fully written).  If dbias_slab != NULL the gradient of the dense bias is written
  * too: dbias_slab[c][h][i][j] = sum over the samples of batch chunk c of dS[b,h,i,j], fp32, fully written,
  * dm_attention_bwd_batch_chunks(B,N,H) * H * N * N floats; fold it into the table's gradient with
@@ -126,6 +137,13 @@ int dm_attention_fwd(const void *qkv, const float *bias, void *out, float *lse,
 int dm_attention_bwd(const void *qkv, const float *bias, const float *bias_t, const void *out, const void *dout,
                      const float *lse, void *dqkv, float *delta, float *dbias_slab, int32_t B, int32_t N, int32_t H,
                      int32_t D, float scale, int32_t dtype, void *stream);
+/* dm_attention_bwd for the shapes dm_attention_relpos_inkernel takes: the passes that can form the bias from the table
+ * inside the kernel do so (the dQ pass); the dK / dV pass still reads the dense rows, so bias (and optionally bias_t)
+ * are passed as for dm_attention_bwd.  Same outputs, same determinism. */
+int dm_attention_bwd_relpos(const void *qkv, const float *table, int32_t cube_s, int32_t cube_h, int32_t cube_w,
+                            const float *bias, const float *bias_t, const void *out, const void *dout, const float *lse,
+                            void *dqkv, float *delta, float *dbias_slab, int32_t B, int32_t N, int32_t H, int32_t D,
+                            float scale, int32_t dtype, void *stream);
 /* Number of batch chunks dm_attention_bwd uses for this problem size and dtype (first dimension of dbias_slab). */
 int32_t dm_attention_bwd_batch_chunks(int32_t B, int32_t N, int32_t H, int32_t dtype);
 

@@ -338,11 +338,13 @@ def test_attention_pipelined_kernels(N, with_bias):
     test_attention_forward_backward("bf16", N, with_bias, B=8, H=12)
 
 
-@pytest.mark.parametrize("B,H,N,with_bias", [(9, 12, 256, True), (36, 3, 197, False), (11, 12, 128, True), (70, 12, 256, True), (13, 10, 192, True)])
+@pytest.mark.parametrize("B,H,N,with_bias", [(9, 12, 256, True), (36, 3, 197, False), (11, 12, 128, True), (70, 12, 256, True), (13, 10, 192, True), (50, 12, 197, False),
+                                             (29, 11, 224, False)])
 def test_attention_pipelined_workgroup_order(B, H, N, with_bias):
     """The XCD-aware workgroup order of the pipelined kernels (pipe_coords: ids L, L + 8, ... are the row blocks of one
     (head, sample chunk)) with group counts that are NOT multiples of 8 (the surplus workgroups of the rounded-up grid must
-    leave), uneven sample chunks, one and two row blocks."""
+    leave), uneven sample chunks, one and two row blocks.  The 8-wave kernels deal (head, sample) units out as 256 contiguous runs:
+    the last two cases give runs of 2-3 / 1-2 units that cross head boundaries."""
     test_attention_forward_backward("bf16", N, with_bias, B=B, H=H)
 
 
@@ -367,6 +369,48 @@ def test_attention_q32_deferred_maximum(N, with_bias):
     np.testing.assert_allclose(lse.cpu().numpy(), lse_ref.numpy(), rtol=2e-2, atol=2e-2)
     err = (out.float().cpu().double() - o_ref).abs().max().item()
     assert err < 3e-2, f"forward max err {err}"
+
+
+@pytest.mark.parametrize("scales,B,H", [(4, 8, 12), (3, 10, 12), (4, 33, 3), (4, 50, 12), (3, 43, 7)])
+def test_attention_relpos_table_in_kernel(scales, B, H):
+    """dm_attention_fwd_relpos forms the bias of a (scales, 8, 8) token cube from the table inside the kernel (table in LDS, x axis
+    reversed, two floats per read; the last cases make a workgroup's run of (head, sample) units cross into the next head, where
+    the table is reloaded); it must equal dm_attention_fwd on the gathered dense bias (same kernel family, same summation
+    order: differences only from where bias / scale is rounded) and the fp64 reference.  Index rule: nets/ShfitScaleFormer.py:139-156."""
+    from oracle import s2former as O
+    ops = _ops()
+    cube = (scales, 8, 8)
+    N, D = 64 * scales, 64
+    rng = np.random.default_rng(100 + scales)
+    qkv = torch.from_numpy(rng.normal(size=(B, N, 3, H, D)).astype(np.float32)).to(torch.bfloat16)
+    n_bins = (2 * scales - 1) * 225
+    table = torch.from_numpy(rng.normal(size=(n_bins, H)).astype(np.float32))
+    index = torch.from_numpy(O.relpos_index(cube).astype(np.int32))
+    assert ops.relpos_inkernel(B, N, H, D, cube, torch.bfloat16)
+    assert not ops.relpos_inkernel(B, N, H, D, (scales, 4, 16), torch.bfloat16) and not ops.relpos_inkernel(B, N, H, D, cube, torch.float32)
+    bias = ops.relpos_bias_gather(table.to(DEV), index.to(DEV), N)
+    o_dense, lse_dense = ops.attention_fwd(qkv.to(DEV), bias, B, N, H, D, 0.125)
+    out, lse = ops.attention_fwd_relpos(qkv.to(DEV), table.to(DEV), cube, B, N, H, D, 0.125)
+    o_ref, lse_ref = _attn_ref(qkv.double(), bias.cpu().double(), 0.125)
+    np.testing.assert_allclose(lse.cpu().numpy(), lse_ref.numpy(), rtol=2e-2, atol=2e-2)
+    assert (out.float().cpu().double() - o_ref).abs().max().item() < 3e-2
+    assert (out.float() - o_dense.float()).abs().max().item() <= 2 ** -6          # one bf16 step of an O(1) output at most
+    np.testing.assert_allclose(lse.cpu().numpy(), lse_dense.cpu().numpy(), rtol=0, atol=1e-4)
+    with pytest.raises(ValueError):
+        ops.attention_fwd_relpos(qkv.to(DEV), table[:-1].to(DEV), cube, B, N, H, D, 0.125)
+    # backward: the dQ pass reads the table in LDS too (8 waves), dK / dV and the table gradient keep the dense rows
+    dout = torch.from_numpy(rng.normal(size=(B, N, H * D)).astype(np.float32)).to(torch.bfloat16).to(DEV)
+    bias, bias_t = ops.relpos_bias_gather(table.to(DEV), index.to(DEV), N, transposed=True)
+    d_dense, slab_d, info_d = ops.attention_bwd(qkv.to(DEV), bias, o_dense, dout, lse_dense, B, N, H, D, 0.125, index.to(DEV), n_bins, bias_t=bias_t)
+    d_tab, slab_t, info_t = ops.attention_bwd(qkv.to(DEV), bias, o_dense, dout, lse_dense, B, N, H, D, 0.125, index.to(DEV), n_bins, bias_t=bias_t,
+                                              table=table.to(DEV), cube=cube)
+    q64 = qkv.double().requires_grad_(True)
+    o64, _ = _attn_ref(q64, bias.cpu().double(), 0.125)
+    o64.backward(dout.cpu().double())
+    scale_g = q64.grad.abs().max().item()
+    assert (d_tab.float().cpu().double() - q64.grad).abs().max().item() < 2e-2 * scale_g
+    assert (d_tab.float() - d_dense.float()).abs().max().item() < 1e-2 * scale_g
+    assert torch.equal(d_tab[:, :, 1:], d_dense[:, :, 1:])        # dK / dV: the same kernels on the same delta up to dQ-pass rounding
 
 
 @pytest.mark.parametrize("mode", ["fp32", "bf16"])
