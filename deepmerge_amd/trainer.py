@@ -177,7 +177,8 @@ class PairTrainer:
 
     def __init__(self, net: torch.nn.Module, margin: float = 1.0, lr: float = 1e-4, lamda: float = 0.1, belta: float = 0,
                  betas=(0.9, 0.999), eps: float = 1e-8, n_buckets: int = 4, process_group=None, criterion=None, adam_fn=None,
-                 segmented: Optional[bool] = None, first_write: Optional[bool] = None, compress_grads: Optional[str] = None):
+                 segmented: Optional[bool] = None, first_write: Optional[bool] = None, compress_grads: Optional[str] = None,
+                 overlap_adam: bool = False):
         """`compress_grads="bf16"` (opt-in, lossy; SURVEY 8e "optionally bf16-compressed buckets in throughput mode"): a bucket is
         rounded to bf16, summed across ranks in bf16 and widened again before Adam -- half the bytes on the links for ~2^-9 relative
         rounding per rank's contribution; the default exchanges fp32.
@@ -199,7 +200,13 @@ class PairTrainer:
         self.step_count = 0
         self.can_cut = hasattr(net, "_dp_cut")
         self.dp = self.world > 1 or self.force_dp
-        self.segmented = (self.dp and self.can_cut) if segmented is None else (bool(segmented) and self.can_cut)
+        # one GPU, graph replay: `overlap_adam=True` (or DM_ADAM_OVERLAP=1) runs the backward in segments inside ONE graph with each
+        # bucket's Adam update as a side branch (_capture_overlapped).  Off by default: measured 5.88 -> 6.15 ms per step on the headline
+        # model -- the streaming update takes more from the GEMMs it runs beside (L2 / fabric) than its own 0.23 ms.
+        self.overlap_adam = (bool(overlap_adam) or os.environ.get("DM_ADAM_OVERLAP", "0") == "1") and not self.dp and self.can_cut
+        if segmented is None:
+            segmented = self.dp or self.overlap_adam
+        self.segmented = (bool(segmented) or self.overlap_adam) and self.can_cut
         self.n_buckets = max(1, n_buckets)
         self.bucket_slices = self.fp.buckets(self.n_buckets if self.dp else 1)     # re-derived from the cuts when segmented
         self._pending = []
@@ -373,6 +380,8 @@ class PairTrainer:
             if self.dp:                              # no cut support: exchange the whole buffer after the one backward graph
                 st["adam"] = self._capture_adam(st, g.pool())
             return
+        if self.overlap_adam:
+            return self._capture_overlapped(st)
         cuts = _Cuts()
         self.net._dp_cut = cuts
         pieces = []
@@ -396,6 +405,41 @@ class PairTrainer:
         self.bucket_slices, self._ready_after = self._segment_buckets(cuts)
         st["adam"] = self._capture_adam(st, g0.pool())
         # the retired-workspace list of ops.workspace keeps every scratch buffer these graphs point into alive
+
+    def _capture_overlapped(self, st):
+        """One GPU, segmented backward (`PairTrainer(segmented=True)`): ONE graph in which the Adam update of a bucket is a side
+        branch that starts as soon as the backward piece that completes the bucket's gradients has been enqueued.  Adam is a
+        pure streaming kernel (7 fp32 passes + the bf16 mirror over the bucket, HBM-bound) and the backward pieces that follow
+        are matrix-pipe work on other layers' weights, so the two share the chip; only the last bucket's update (the first
+        layers, whose gradients complete last) runs alone at the end of the step.  Same arithmetic as the unsegmented step."""
+        cuts = _Cuts()
+        self.net._dp_cut = cuts
+        side = torch.cuda.Stream(device=self.fp.flat.device)
+        g = torch.cuda.CUDAGraph()
+        try:
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                main = torch.cuda.current_stream()
+                self.fp.zero_grad()
+                loss = self._forward_loss(st)
+                self.bucket_slices, self._ready_after = self._segment_buckets(cuts)
+                forked = False
+                for piece in self._backward_segments(loss, cuts):
+                    ready = [bi for bi, r in enumerate(self._ready_after) if r == piece]
+                    if not ready:
+                        continue
+                    side.wait_stream(main)               # the piece's kernels (incl. its batched reductions) are enqueued on `main`
+                    forked = True
+                    with torch.cuda.stream(side):
+                        for bi in ready:
+                            sl = self.bucket_slices[bi]
+                            self.fp.finish_grads(sl.start, sl.stop)
+                            self._adam_slice(sl, st["hyper"], 1.0)
+                if forked:
+                    main.wait_stream(side)
+                st["loss"] = loss.detach()
+        finally:
+            self.net._dp_cut = None
+        st["pieces"], st["cuts"] = [g], cuts
 
     def _capture_adam(self, st, pool):
         """One captured Adam launch per bucket (see _finish_buckets)."""
@@ -441,8 +485,8 @@ class PairTrainer:
         put(st["flag"], flag)
         self.step_count += 1
         st["hyper"].copy_(ops.adam_hyper(self.step_count, self.lr if lr is None else lr, self.betas[0], self.betas[1]), non_blocking=True)
-        if not self.dp and not self.segmented:
-            st["pieces"][0].replay()                     # Adam is inside the one graph
+        if not self.dp and (not self.segmented or self.overlap_adam):
+            st["pieces"][0].replay()                     # Adam is inside the one graph (a side branch per bucket with overlap_adam)
             return st["loss"]
         if not self.segmented:                       # one backward graph, then the bucketed exchange of the whole buffer
             st["pieces"][0].replay()

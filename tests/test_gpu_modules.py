@@ -475,15 +475,19 @@ def test_segmented_graphs_equal_plain_step():
     cfg = MODEL_CASES[tag]
     left, ld, right, rd, flag = model_inputs(tag, cfg.scales, cfg.in_c, 4)
     b = ([t.to(DEV) for t in left], ld.to(DEV), [t.to(DEV) for t in right], rd.to(DEV), flag.to(DEV))
-    nets = [build_model(tag, "bf16")[1].train() for _ in range(3)]
+    nets = [build_model(tag, "bf16")[1].train() for _ in range(4)]
     eager = PairTrainer(nets[0], lr=1e-4)
     seg_eager = PairTrainer(nets[1], lr=1e-4, segmented=True)
     seg_graph = PairTrainer(nets[2], lr=1e-4, segmented=True)
     seg_graph.enable_graph(warmup=1)
+    ov_graph = PairTrainer(nets[3], lr=1e-4, overlap_adam=True)      # one graph, each bucket's Adam a side branch behind its backward piece
+    ov_graph.enable_graph(warmup=1)
     for _ in range(4):
-        l0 = eager.step(*b); l1 = seg_eager.step(*b); l2 = seg_graph.step(*b)
-        assert float(l0) == float(l1) == float(l2)
+        l0 = eager.step(*b); l1 = seg_eager.step(*b); l2 = seg_graph.step(*b); l3 = ov_graph.step(*b)
+        assert float(l0) == float(l1) == float(l2) == float(l3)
     assert torch.equal(eager.fp.flat, seg_eager.fp.flat) and torch.equal(eager.fp.flat, seg_graph.fp.flat)
+    assert torch.equal(eager.fp.flat, ov_graph.fp.flat) and torch.equal(eager.m, ov_graph.m) and torch.equal(eager.v, ov_graph.v)
+    assert len(ov_graph._graph["pieces"]) == 1 and len(ov_graph.bucket_slices) == 7
     assert len(seg_graph._graph["pieces"]) == 1 + 6 and len(seg_graph.bucket_slices) == 7       # tail + the six stage-0 blocks
     sl = seg_graph.bucket_slices
     assert sl[0].start == 0 and sl[-1].stop == seg_graph.fp.total and all(x.stop == y.start for x, y in zip(sl[:-1], sl[1:]))
