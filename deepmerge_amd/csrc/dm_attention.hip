@@ -678,12 +678,17 @@ extern "C" int dm_attention_bwd(const void *qkv, const float *bias, const float 
   return attention_bwd(qkv, bias, bias_t, nullptr, 0, out, dout, lse, dqkv, delta, dbias_slab, B, N, H, D, scale, dtype, stream);
 }
 
-// The backward of dm_attention_fwd_relpos: the passes that can form the bias from the table inside the kernel do (the dQ pass, 8 waves
-// with the head's table in LDS); the others read the dense rows, which the caller still supplies.
+// The backward of dm_attention_fwd_relpos: both passes form the bias from the table inside the kernel (dQ: 8 waves, dK / dV + the
+// table-gradient slab: 4 waves; dm_attention_q32_bwd.hip); bias / bias_t may be NULL.
 extern "C" int dm_attention_bwd_relpos(const void *qkv, const float *table, int32_t cube_s, int32_t cube_h, int32_t cube_w, const float *bias,
                                        const float *bias_t, const void *out, const void *dout, const float *lse, void *dqkv, float *delta,
                                        float *dbias_slab, int32_t B, int32_t N, int32_t H, int32_t D, float scale, int32_t dtype, void *stream) {
-  DM_REQUIRE(table && bias, DM_ERR_BAD_SHAPE, "dm_attention_bwd_relpos: table and dense bias are both required");
+  DM_REQUIRE(table, DM_ERR_BAD_SHAPE, "dm_attention_bwd_relpos: null table");
+  {      // the dense rows are only needed where the table-reading dK / dV kernel is switched off (A/B runs)
+    const char *e = getenv("DM_ATTN_Q32_TABKV"), *m = getenv("DM_ATTN_Q32_BWD");
+    const bool dense_needed = (e && atoi(e) == 0) || (m && (atoi(m) == 0 || atoi(m) == 3));
+    DM_REQUIRE(bias || !dense_needed, DM_ERR_BAD_SHAPE, "dm_attention_bwd_relpos: the dense bias rows are required with DM_ATTN_Q32_TABKV=0 / DM_ATTN_Q32_BWD=0|3");
+  }
   DM_REQUIRE(relpos_inkernel(B, N, H, D, cube_s, cube_h, cube_w, dtype), DM_ERR_UNSUPPORTED,
              "dm_attention_bwd_relpos: shape not taken (B=%d N=%d H=%d D=%d cube=%dx%dx%d dtype=%d); call dm_attention_bwd", B, N, H, D, cube_s,
              cube_h, cube_w, dtype);

@@ -653,6 +653,353 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void attn_bwd_dkv_q32_kernel(const
   }
 }
 
+// ---- dK / dV pass WITH the relative-position bias, 32 keys per wave, head's table in LDS, one wave per SIMD ---------------------------------
+// Same products as the kernel above with the key on the lane; what the bias adds, and how it is paid for:
+//   * bias / scale reaches the scores as the C operand: a lane's 16 queries of a 32-query tile are 4 query rows x 4 consecutive query
+//     columns of the token cube, i.e. four runs of 4 consecutive table entries in the table's natural order -- eight ds_read2_b32 per
+//     tile into the score registers (the forward / dQ kernels read the x-reversed table for the same reason with the roles swapped);
+//     -lse then enters as the addend of the exponent's fma (a per-query value: 16 registers per tile from the stat table), so the
+//     VALU count per score is the same as without a bias;
+//   * the gradient of the table needs sum_samples dS[query][key]: 128 fp32 values per lane for 256 queries.  They live in ACCUMULATOR
+//     registers and are added to by the matrix pipe: H_j += E_s . dS_s (two MFMAs per tile), where dS_s is the packed bf16 dS^T operand
+//     the dK product uses anyway and E_s is the 32 x 16 selection matrix that puts k-step s's 16 queries back on their rows.  (The sum
+//     therefore sees dS rounded to bf16, like dK does.)  One slab [chunk][head][query][key] per workgroup chunk as before; the
+//     deterministic bin reduction (dm_relpos_bias_reduce) is unchanged.
+// 18 MFMAs per tile, software-pipelined like the dQ kernel's 4-wave form: iteration j issues S / dP of tile j + 1 and dV / dK / H of
+// tile j - 1 with tile j's VALU work (three stages: fma, exp2, products + packs) in the gaps.
+template <int NKT>
+__global__ __launch_bounds__(256, 1) void attn_bwd_dkv_tab_kernel(const AttnPipeBwdParams p, int bchunk, int nblk, int chunks) {
+  constexpr int NW = 4, ROWS = 128;
+  constexpr int NP = NKT * 32, N = NP;
+  constexpr int IMG = NP * 128;
+  constexpr int STAT = 2 * NP * 4;                                  // [-lse log2e | -delta] per buffer
+  constexpr int TAB_ROWS = (NKT - 1) * 15;
+  extern __shared__ __attribute__((aligned(16))) char smem[];      // [2][Q image | dO image] | [2] stat | 4 x write-back block | table
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int r = lane & 31, hh = lane >> 5;
+  int h, rb, chunk;
+  if (!coords(nblk, p.H, chunks, h, rb, chunk)) return;
+  const int H = p.H;
+  const int b0 = chunk * bchunk, b1 = min(p.B, b0 + bchunk);
+  if (b0 >= b1) return;
+  const int k_wave = rb * ROWS + wave * 32;
+  const int key = k_wave + r;
+  const bool wave_live = k_wave < N;                                // (N = 192: the second workgroup's upper two waves own no keys)
+  const long long tok_stride = 3LL * H * HD, out_stride = (long long)H * HD;
+  const bf16_t *qkv = reinterpret_cast<const bf16_t *>(p.qkv);
+  const bf16_t *dout = reinterpret_cast<const bf16_t *>(p.dout);
+  constexpr float LOG2E = 1.4426950408889634f;
+  const float scale2 = p.scale * LOG2E;
+
+  // ---- DMA: Q rows of qkv and dO rows, both with the dual-use swizzle (kernel above) ------------------------------------------------------
+  const int dkey = lane >> 3;
+  const unsigned src_swz = (unsigned)(((lane & 7) ^ ((((dkey >> 1) & 1) << 2) | ((((wave & 1) << 1) | (dkey >> 2)) & 3))) * 16);
+  const unsigned voffQ = (unsigned)((8 * wave + dkey) * tok_stride * 2) + src_swz;
+  const unsigned voffD = (unsigned)((8 * wave + dkey) * out_stride * 2) + src_swz;
+  const unsigned lds0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(uintptr_t)(DM_LDS char *)smem);
+  unsigned stepQ = (unsigned)__builtin_amdgcn_readfirstlane((int)(32 * tok_stride * 2));
+  unsigned stepD = (unsigned)__builtin_amdgcn_readfirstlane((int)(32 * out_stride * 2));
+  asm volatile("s_nop 4" : "+s"(stepQ), "+s"(stepD));
+  auto make_rsrc = [&](const bf16_t *base, long long bytes) -> i32x4 {
+    const uintptr_t a = reinterpret_cast<uintptr_t>(base);
+    i32x4 rs;
+    rs[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)(a & 0xffffffffu));
+    rs[1] = __builtin_amdgcn_readfirstlane((int)(unsigned)((a >> 32) & 0xffffu));
+    rs[2] = __builtin_amdgcn_readfirstlane((int)bytes);
+    rs[3] = 0x00020000;
+    asm volatile("s_nop 4" : "+s"(rs));
+    return rs;
+  };
+  auto stage_piece = [&](const i32x4 &rsq, const i32x4 &rsd, int buf, int j) {
+    const unsigned qimg = lds0 + (unsigned)(buf * (2 * IMG)) + (unsigned)wave * 1024u, dimg = qimg + (unsigned)IMG;
+    lds_dma(rsq, qimg + (unsigned)j * 4096u, voffQ, (unsigned)j * stepQ);
+    lds_dma(rsd, dimg + (unsigned)j * 4096u, voffD, (unsigned)j * stepD);
+  };
+  auto rsrc_q = [&](int b) { return make_rsrc(qkv + (long long)b * N * tok_stride + (long long)h * HD, (long long)N * tok_stride * 2); };
+  auto rsrc_d = [&](int b) { return make_rsrc(dout + (long long)b * N * out_stride + (long long)h * HD, (long long)N * out_stride * 2); };
+  const int sq = wave * 64 + lane;                                  // the query whose constants this lane stages
+  auto load_rows = [&](int b, u32x4 (&fk)[4], u32x4 (&fv)[4], float &lse, float &dl) {
+    const bf16_t *krow = qkv + ((long long)b * N + key) * tok_stride + (long long)(H + h) * HD + 8 * hh;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      fk[ks] = wave_live ? *reinterpret_cast<const u32x4 *>(krow + 16 * ks) : (u32x4){0u, 0u, 0u, 0u};
+      fv[ks] = wave_live ? *reinterpret_cast<const u32x4 *>(krow + (long long)H * HD + 16 * ks) : (u32x4){0u, 0u, 0u, 0u};
+    }
+    const bool sok = sq < N;
+    lse = sok ? p.lse[((long long)b * H + h) * N + sq] : 0.f;
+    dl = sok ? p.delta[((long long)b * H + h) * N + sq] : 0.f;
+  };
+
+  // ---- fragment offsets (dual-use images, rows = queries) ------------------------------------------------------------------------------------
+  const int xr = (((r >> 1) & 1) << 2) | ((r >> 2) & 3);
+  int roff[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) roff[ks] = r * 128 + (((2 * ks + hh) ^ xr) << 4);
+  const int ve = (lane >> 4) & 1, qd = (lane >> 2) & 3, pp = lane & 3;
+  int toff[2][2];
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int j2 = 0; j2 < 2; ++j2) {
+      const int x = ((qd >> 1) << 2) | ((2 * j2 + hh) & 3);
+      toff[dt][j2] = (8 * j2 + 4 * hh + qd) * 128 + (((4 * dt + 2 * ve + (pp >> 1)) ^ x) << 4) + 8 * (pp & 1);
+    }
+  char *stat0 = smem + 4 * IMG;
+  char *wb = smem + 4 * IMG + 2 * STAT + wave * WB_WAVE;
+  float *tab = reinterpret_cast<float *>(smem + 4 * IMG + 2 * STAT + NW * WB_WAVE);
+  {                                                                 // the head's table, natural order: row (dz + S - 1) * 15 + dy + 7, entry dx + 7
+    const float inv_scale = 1.f / p.scale;
+    for (int i = t; i < (NKT - 1) * 225; i += 256) {
+      const int prow = i / 15, px = i - prow * 15;
+      tab[prow * 16 + px] = p.table[(long long)i * H + h] * inv_scale;
+    }
+  }
+  const int kz = key >> 6, ky = (key >> 3) & 7, kx = key & 7;
+  const float *tabl = tab + (wave_live ? ((NKT / 2 - 1 - kz) * 15 + 7 - ky) * 16 + 4 * hh - kx + 7 : 0);
+  // selection matrices of the table-gradient accumulation: E_s[row][k] = 1 where row = 16 s + 8 (i >> 2) + 4 hh + (i & 3), k = 8 hh + i
+  u32x4 esel[2];
+#pragma unroll
+  for (int sx = 0; sx < 2; ++sx)
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const int i0 = 2 * w, i1 = 2 * w + 1;
+      const unsigned lo = (r == 16 * sx + 8 * (i0 >> 2) + 4 * hh + (i0 & 3)) ? 0x3f80u : 0u;
+      const unsigned hi = (r == 16 * sx + 8 * (i1 >> 2) + 4 * hh + (i1 & 3)) ? 0x3f80u : 0u;
+      esel[sx][w] = lo | (hi << 16);
+    }
+  f32x16 hacc[NKT];                                                 // sum over this workgroup's samples of dS[query tile j][key]: accumulator registers
+#pragma unroll
+  for (int j = 0; j < NKT; ++j) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) hacc[j][i] = 0.f;
+    asm volatile("" : "+a"(hacc[j]));
+  }
+
+  u32x4 kfr[4], vfr[4], kld[4], vld[4];
+  float lse_ld = 0.f, dl_ld = 0.f;
+  {
+    const i32x4 rq = rsrc_q(b0), rd = rsrc_d(b0);
+#pragma unroll
+    for (int j = 0; j < NKT; ++j) stage_piece(rq, rd, 0, j);
+  }
+  load_rows(b0, kld, vld, lse_ld, dl_ld);
+  for (int b = b0; b < b1; ++b) {
+    const int buf = (b - b0) & 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (sq < NP) {
+      float *st = reinterpret_cast<float *>(stat0 + buf * STAT);
+      st[sq] = -lse_ld * LOG2E;
+      st[NP + sq] = -dl_ld;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              // the stat entries (and, first sample, the table) are in LDS before the barrier
+    __builtin_amdgcn_s_barrier();
+    const bool more = b + 1 < b1;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      kfr[ks] = kld[ks]; vfr[ks] = vld[ks];
+      park_acc(kfr[ks]); park_acc(vfr[ks]);                         // B operands of S / dP: accumulator registers
+    }
+    i32x4 rq_next = {0, 0, 0, 0}, rd_next = {0, 0, 0, 0};
+    if (more) { rq_next = rsrc_q(b + 1); rd_next = rsrc_d(b + 1); }
+    const char *qimg = smem + buf * (2 * IMG), *dimg = qimg + IMG;
+    const char *stat = stat0 + buf * STAT;
+
+    if (wave_live) {
+      f32x16 s0, s1, dp0, dp1;
+      f32x16 nl;
+      u32x4 pb0[2], pb1[2], dsb0[2], dsb1[2];
+      u32x4 qf[4], df[4];
+      u32x2 qt[8], dtf[8];
+      f32x16 dk0, dk1, dv0, dv1;
+      auto read_a = [&](int jt) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          qf[ks] = *reinterpret_cast<const u32x4 *>(qimg + jt * 4096 + roff[ks]);
+          df[ks] = *reinterpret_cast<const u32x4 *>(dimg + jt * 4096 + roff[ks]);
+        }
+      };
+      auto read_t = [&](int jt) {
+#pragma unroll
+        for (int sx = 0; sx < 2; ++sx)
+#pragma unroll
+          for (int dt = 0; dt < 2; ++dt) {
+            const int o = (32 * jt + 16 * sx) * 128;
+            qt[4 * sx + 2 * dt] = dm_ds_read_tr16(qimg + o + toff[dt][0]);
+            qt[4 * sx + 2 * dt + 1] = dm_ds_read_tr16(qimg + o + toff[dt][1]);
+            dtf[4 * sx + 2 * dt] = dm_ds_read_tr16(dimg + o + toff[dt][0]);
+            dtf[4 * sx + 2 * dt + 1] = dm_ds_read_tr16(dimg + o + toff[dt][1]);
+          }
+      };
+      // query (qz, qy, qx) = (jt >> 1, 4 (jt & 1) + c, 4 hh + e) for register 4 c + e
+      auto read_bias = [&](int jt, f32x16 &d) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) d[4 * c + e] = tabl[16 * (15 * (jt >> 1) + 4 * (jt & 1) + c) + e];
+      };
+      auto read_stat = [&](int jt, int which, f32x16 &d) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const f32x4 a = *reinterpret_cast<const f32x4 *>(stat + (which * NP + 32 * jt + 8 * c + 4 * hh) * 4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) d[4 * c + e] = a[e];
+        }
+      };
+      auto s_piece = [&](int ks, f32x16 &d) { qk_acc<true, false>(d, qf[ks], kfr[ks]); };
+      auto dp_piece = [&](int ks, f32x16 &d) { qk_acc<true, false>(d, df[ks], vfr[ks]); };
+      auto tfrag = [&](const u32x2 (&f)[8], int sx, int dt) { return (u32x4){f[4 * sx + 2 * dt][0], f[4 * sx + 2 * dt][1], f[4 * sx + 2 * dt + 1][0], f[4 * sx + 2 * dt + 1][1]}; };
+      auto dv_piece = [&](int jt, int g, const u32x4 (&pb)[2]) {
+        const int sx = g >> 1, dt = g & 1;
+        f32x16 &o = dt ? dv1 : dv0;
+        if (jt == 0 && sx == 0) pv_first<false>(o, tfrag(dtf, 0, dt), pb[0]); else pv_acc<false>(o, tfrag(dtf, sx, dt), pb[sx]);
+      };
+      auto dk_piece = [&](int jt, int g, const u32x4 (&dsb)[2]) {
+        const int sx = g >> 1, dt = g & 1;
+        f32x16 &o = dt ? dk1 : dk0;
+        if (jt == 0 && sx == 0) pv_first<false>(o, tfrag(qt, 0, dt), dsb[0]); else pv_acc<false>(o, tfrag(qt, sx, dt), dsb[sx]);
+      };
+      // VALU pipeline of a tile: A (exponent), B (exp2), C (dS = P dP, the two packs)
+      float fa[8][2], ex[8][2];
+      auto stage_a = [&](const f32x16 &sc, int k) {
+        fa[k][0] = __builtin_fmaf(sc[2 * k], scale2, nl[2 * k]);
+        fa[k][1] = __builtin_fmaf(sc[2 * k + 1], scale2, nl[2 * k + 1]);
+        asm volatile("" :: "v"(fa[k][0]), "v"(fa[k][1]));
+      };
+      auto stage_b = [&](int k) {
+        ex[k][0] = __builtin_amdgcn_exp2f(fa[k][0]);
+        ex[k][1] = __builtin_amdgcn_exp2f(fa[k][1]);
+        asm volatile("" :: "v"(ex[k][0]), "v"(ex[k][1]));
+      };
+      auto stage_c = [&](const f32x16 &dp, int k, u32x4 (&pb)[2], u32x4 (&dsb)[2]) {
+        const unsigned wp = pk_bf16(ex[k][0], ex[k][1]);
+        const unsigned wd = pk_bf16(ex[k][0] * dp[2 * k], ex[k][1] * dp[2 * k + 1]);
+        pb[k >> 2][k & 3] = wp;
+        dsb[k >> 2][k & 3] = wd;
+        asm volatile("" :: "v"(wp), "v"(wd));
+      };
+
+      // ---- prologue: S and dP of tile 0 on top of bias / scale and -delta ------------------------------------------------------------------
+      read_a(0);
+      read_bias(0, s0);
+      read_stat(0, 1, dp0);
+      read_stat(0, 0, nl);
+      asm volatile("s_nop 1");                                       // the K / V fragment copies into accumulator registers may be fresh
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) s_piece(ks, s0);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) dp_piece(ks, dp0);
+      asm volatile("" :: "v"(qf[0]), "v"(qf[1]), "v"(qf[2]), "v"(qf[3]), "v"(df[0]), "v"(df[1]), "v"(df[2]), "v"(df[3]));
+      if (NKT > 1) { read_a(1); read_bias(1, s1); read_stat(1, 1, dp1); }
+      asm volatile("s_nop 15\n\ts_nop 7" : "+v"(s0), "+v"(dp0));
+#pragma unroll
+      for (int j = 0; j < NKT; ++j) {
+        f32x16 &sc = (j & 1) ? s1 : s0;
+        f32x16 &sn = (j & 1) ? s0 : s1;
+        f32x16 &dpc = (j & 1) ? dp1 : dp0;
+        f32x16 &dpn = (j & 1) ? dp0 : dp1;
+        u32x4 (&pbc)[2] = (j & 1) ? pb1 : pb0;
+        u32x4 (&pbp)[2] = (j & 1) ? pb0 : pb1;
+        u32x4 (&dsc)[2] = (j & 1) ? dsb1 : dsb0;
+        u32x4 (&dsp)[2] = (j & 1) ? dsb0 : dsb1;
+        asm volatile("" : "+v"(sc), "+v"(dpc));                      // tile j's tiles are read below this point only (MFMA D -> VALU distance)
+        if (j > 0) read_t(j - 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int g = 0; g < 18; ++g) {
+          if (g < 4) {
+            if (j + 1 < NKT) s_piece(g, sn);
+          } else if (g < 8) {
+            if (j + 1 < NKT) dp_piece(g - 4, dpn);
+          } else if (g < 12) {
+            if (j > 0) dv_piece(j - 1, g - 8, pbp);
+          } else if (g < 16) {
+            if (j > 0) dk_piece(j - 1, g - 12, dsp);
+          } else {
+            if (j > 0) pv_acc<false>(hacc[j > 0 ? j - 1 : 0], esel[g - 16], dsp[g - 16]);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          if (g < 8) stage_a(sc, g);
+          if (g >= 1 && g < 9) stage_b(g - 1);
+          if (g >= 2 && g < 10) stage_c(dpc, g - 2, pbc, dsc);
+          if (g == 8 && j + 2 < NKT) { read_a(j + 2); read_bias(j + 2, sc); }       // (tile j's scores were last read in gap 7)
+          if (g == 10 && j + 2 < NKT) read_stat(j + 2, 1, dpc);                      // (tile j's dP was last read in gap 9)
+          if (g == 10 && j + 1 < NKT) read_stat(j + 1, 0, nl);
+          if (g == 13 && more) {
+            if (j < NKT - 1) stage_piece(rq_next, rd_next, buf ^ 1, j);
+            if (j == 0) stage_piece(rq_next, rd_next, buf ^ 1, NKT - 1);
+          }
+          if (g == 14 && more && j == NKT - 1) load_rows(b + 1, kld, vld, lse_ld, dl_ld);
+          if (g < 4) {
+            if (j + 1 < NKT) asm volatile("" :: "v"(qf[g]));
+          } else if (g < 8) {
+            if (j + 1 < NKT) asm volatile("" :: "v"(df[g - 4]));
+          } else if (g < 12) {
+            if (j > 0) asm volatile("" :: "v"(dtf[2 * (g - 8)]), "v"(dtf[2 * (g - 8) + 1]), "v"(pbp[(g - 8) >> 1]));
+          } else if (g < 16) {
+            if (j > 0) asm volatile("" :: "v"(qt[2 * (g - 12)]), "v"(qt[2 * (g - 12) + 1]), "v"(dsp[(g - 12) >> 1]));
+          } else {
+            if (j > 0) asm volatile("" :: "v"(esel[g - 16]), "v"(dsp[g - 16]));
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      // ---- epilogue: dV, dK and the table-gradient rows of the last tile -------------------------------------------------------------------
+      read_t(NKT - 1);
+      {
+        u32x4 (&pbl)[2] = ((NKT - 1) & 1) ? pb1 : pb0;
+        u32x4 (&dsl)[2] = ((NKT - 1) & 1) ? dsb1 : dsb0;
+        asm volatile("s_nop 1");
+#pragma unroll
+        for (int g = 0; g < 4; ++g) dv_piece(NKT - 1, g, pbl);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) dk_piece(NKT - 1, g, dsl);
+        pv_acc<false>(hacc[NKT - 1], esel[0], dsl[0]);
+        pv_acc<false>(hacc[NKT - 1], esel[1], dsl[1]);
+        asm volatile("s_nop 15\n\ts_nop 7" : "+a"(dk0), "+a"(dk1), "+a"(dv0), "+a"(dv1)
+                     : "v"(pbl[0]), "v"(pbl[1]), "v"(dsl[0]), "v"(dsl[1]), "v"(esel[0]), "v"(esel[1]),
+                       "v"(qt[0]), "v"(qt[1]), "v"(qt[2]), "v"(qt[3]), "v"(qt[4]), "v"(qt[5]), "v"(qt[6]), "v"(qt[7]),
+                       "v"(dtf[0]), "v"(dtf[1]), "v"(dtf[2]), "v"(dtf[3]), "v"(dtf[4]), "v"(dtf[5]), "v"(dtf[6]), "v"(dtf[7]));
+      }
+      // ---- rows of this wave's keys: dK (scaled) then dV through the wave's LDS block ------------------------------------------------------
+      const int rr = lane >> 3, cc = lane & 7;
+#pragma unroll
+      for (int which = 0; which < 2; ++which) {
+        const f32x16 &a0 = which ? dv0 : dk0;
+        const f32x16 &a1 = which ? dv1 : dk1;
+        const float f = which ? 1.f : p.scale;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const u32x2 w0 = {pk_bf16(a0[4 * c] * f, a0[4 * c + 1] * f), pk_bf16(a0[4 * c + 2] * f, a0[4 * c + 3] * f)};
+          const u32x2 w1 = {pk_bf16(a1[4 * c] * f, a1[4 * c + 1] * f), pk_bf16(a1[4 * c + 2] * f, a1[4 * c + 3] * f)};
+          *reinterpret_cast<u32x2 *>(wb + r * WB_PITCH + (8 * c + 4 * hh) * 2) = w0;
+          *reinterpret_cast<u32x2 *>(wb + r * WB_PITCH + (32 + 8 * c + 4 * hh) * 2) = w1;
+        }
+        bf16_t *drow0 = reinterpret_cast<bf16_t *>(p.dqkv) + ((long long)b * N + k_wave) * tok_stride + (long long)((1 + which) * H + h) * HD;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const u32x4 v = *reinterpret_cast<const u32x4 *>(wb + (rr + 8 * k) * WB_PITCH + cc * 16);
+          *reinterpret_cast<u32x4 *>(drow0 + (long long)(rr + 8 * k) * tok_stride + cc * 8) = v;
+        }
+      }
+    } else if (more) {
+#pragma unroll
+      for (int j = 0; j < NKT; ++j) stage_piece(rq_next, rd_next, buf ^ 1, j);
+      load_rows(b + 1, kld, vld, lse_ld, dl_ld);
+    }
+  }
+  // ---- the workgroup's slab rows: slab[chunk][h][query][key], 32 consecutive keys per store instruction ---------------------------------------
+  if (wave_live && p.slab) {
+    float *sl = p.slab + ((long long)(chunk * H + h) * N) * N + key;
+#pragma unroll
+    for (int j = 0; j < NKT; ++j) {
+      asm volatile("s_nop 15\n\ts_nop 7" : "+a"(hacc[j]));
+#pragma unroll
+      for (int i = 0; i < 16; ++i) sl[(long long)(32 * j + 8 * (i >> 2) + 4 * hh + (i & 3)) * N] = hacc[j][i];
+    }
+  }
+}
+
 inline void grid_bwd(int B, int N, int H, int rows, int &nblk, int &chunks, int &bchunk) {
   nblk = (N + rows - 1) / rows;
   chunks = 256 / (H * nblk);
@@ -700,6 +1047,18 @@ template <int NKT, bool RAGGED, int NW> bool launch_dkv(const AttnPipeBwdParams 
   return true;
 }
 
+template <int NKT> bool launch_dkv_tab(const AttnPipeBwdParams &p, hipStream_t s) {
+  constexpr int LDS = 4 * NKT * 32 * 128 + 2 * (2 * NKT * 32 * 4) + 4 * WB_WAVE + (NKT - 1) * 15 * 64;
+  static_assert(LDS <= 160 * 1024, "LDS budget");
+  static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void *>(attn_bwd_dkv_tab_kernel<NKT>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, LDS) == hipSuccess;
+  if (!ok) return false;
+  int nblk, chunks, bchunk;
+  grid_bwd(p.B, p.N, p.H, 128, nblk, chunks, bchunk);            // the same chunks as dm_attn_bwd_pipe_chunks: one slab per chunk
+  hipLaunchKernelGGL((attn_bwd_dkv_tab_kernel<NKT>), dim3(grid_size(nblk, p.H, chunks)), dim3(256), LDS, s, p, bchunk, nblk, chunks);
+  return true;
+}
+
 template <int NKT> bool launch_dkv_n(const AttnPipeBwdParams &p, hipStream_t s) {
   const bool ragged = p.N != NKT * 32;
   if constexpr (NKT <= 7) return ragged ? launch_dkv<NKT, true, 8>(p, s) : launch_dkv<NKT, false, 8>(p, s);
@@ -712,6 +1071,11 @@ template <int NKT> bool launch_dkv_n(const AttnPipeBwdParams &p, hipStream_t s) 
 bool dm_attn_bwd_dkv_q32(const AttnPipeBwdParams &p, hipStream_t s) {
   static const int mode = [] { const char *e = getenv("DM_ATTN_Q32_BWD"); return e ? atoi(e) : 1; }();
   if (mode == 0 || mode == 3) return false;                       // 3: new dQ only (A/B runs)
+  if (p.table && p.N == 64 * p.cube_s && (p.cube_s == 3 || p.cube_s == 4) && (mode == 2 || p.B * p.H >= 96) &&
+      (long long)p.N * 3 * p.H * 64 * 2 < (1LL << 31)) {
+    static const bool tabkv = [] { const char *e = getenv("DM_ATTN_Q32_TABKV"); return !(e && atoi(e) == 0); }();      // A/B switch
+    if (tabkv) return p.cube_s == 3 ? dmq32::launch_dkv_tab<6>(p, s) : dmq32::launch_dkv_tab<8>(p, s);
+  }
   if (p.bias || p.slab) return false;
   if (p.N <= 128 || p.N > 256) return false;
   if ((long long)p.N * 3 * p.H * 64 * 2 >= (1LL << 31)) return false;

@@ -378,6 +378,8 @@ def _inkernel_cube(table, index32, B, N, H, D, dtype):
 
 
 _INKERNEL_TABLE = os.environ.get("DM_ATTN_TABLE_IN_KERNEL", "1") != "0"      # A/B switch
+# the backward kernels read the table themselves too; the dense rows are gathered only when those kernels are switched off (A/B runs)
+_DENSE_BWD_ROWS = os.environ.get("DM_ATTN_Q32_TABKV", "1") == "0" or os.environ.get("DM_ATTN_Q32_BWD", "1") in ("0", "3")
 
 
 def relpos_inkernel(B: int, N: int, H: int, D: int, cube, dtype: torch.dtype) -> bool:
@@ -797,8 +799,9 @@ class AttentionFn(torch.autograd.Function):
         cube = None
         if table is not None:
             table, cube = table.contiguous(), index32._dm_cube
-            bias, bias_t = relpos_bias_gather(table, index32, N, transposed=True)
-        want_table = bias is not None and ctx.needs_input_grad[1]
+            if _DENSE_BWD_ROWS:
+                bias, bias_t = relpos_bias_gather(table, index32, N, transposed=True)
+        want_table = (bias is not None or table is not None) and ctx.needs_input_grad[1]
         dqkv, slab, rows = attention_bwd(qkv, bias, out, _as_operand(dout, qkv.dtype), lse, B, N, H, D, scale,
                                          index32 if want_table else None, n_bins or 0, bias_t=bias_t, table=table, cube=cube)
         dtable = None
@@ -1164,8 +1167,9 @@ class BlockFn(torch.autograd.Function):
         tab, cube = None, None
         if ctx.table_in_kernel:                              # the forward kernel read the table itself; so does the dQ pass, dK / dV takes dense rows
             tab, cube = P_table.detach().contiguous(), index32._dm_cube
-            bias, bias_t = relpos_bias_gather(tab, index32, N, transposed=True)
-        want_table = bias is not None
+            if _DENSE_BWD_ROWS:
+                bias, bias_t = relpos_bias_gather(tab, index32, N, transposed=True)
+        want_table = bias is not None or tab is not None
         dqkv, slab, rows = attention_bwd(qkv, bias, o, do, lse, B, N, heads, D, scale,
                                          index32 if want_table else None, n_bins or 0, bias_t=bias_t, table=tab, cube=cube)
         dtable, k_t = None, False

@@ -137,9 +137,10 @@ int dm_attention_fwd_relpos(const void *qkv, const float *table, int32_t cube_s,
 int dm_attention_bwd(const void *qkv, const float *bias, const float *bias_t, const void *out, const void *dout,
                      const float *lse, void *dqkv, float *delta, float *dbias_slab, int32_t B, int32_t N, int32_t H,
                      int32_t D, float scale, int32_t dtype, void *stream);
-/* dm_attention_bwd for the shapes dm_attention_relpos_inkernel takes: the passes that can form the bias from the table
- * inside the kernel do so (the dQ pass); the dK / dV pass still reads the dense rows, so bias (and optionally bias_t)
- * are passed as for dm_attention_bwd.  Same outputs, same determinism. */
+/* dm_attention_bwd for the shapes dm_attention_relpos_inkernel takes: both passes form the bias from the table inside
+ * the kernel, so bias / bias_t may be NULL (they are only read when the table kernels are switched off for A/B runs).
+ * dbias_slab as for dm_attention_bwd (same chunk count, same layout, deterministic); its entries are sums of dS values
+ * rounded to bf16 (the operand the dK product consumes), accumulated in fp32. */
 int dm_attention_bwd_relpos(const void *qkv, const float *table, int32_t cube_s, int32_t cube_h, int32_t cube_w,
                             const float *bias, const float *bias_t, const void *out, const void *dout, const float *lse,
                             void *dqkv, float *delta, float *dbias_slab, int32_t B, int32_t N, int32_t H, int32_t D,

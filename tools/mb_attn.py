@@ -36,9 +36,10 @@ if os.environ.get("FWD_ONLY") == "1":
     sys.exit(0)
 out, lse = ops.attention_fwd(qkv, bias, B, N, H, D, 0.125)
 dout = torch.randn_like(out)
-idx = None if bias is None else torch.randint(0, 1575, (N, N), device=dev, dtype=torch.int32)
-t = timeit(lambda: ops.attention_bwd(qkv, bias, out, dout, lse, B, N, H, D, 0.125, idx, 1575 if bias is not None else 0))
+NB = (2 * (N // 64) - 1) * 225 if N % 64 == 0 else 1575
+idx = None if bias is None else torch.randint(0, NB, (N, N), device=dev, dtype=torch.int32)
+t = timeit(lambda: ops.attention_bwd(qkv, bias, out, dout, lse, B, N, H, D, 0.125, idx, NB if bias is not None else 0))
 print(f"bwd B={B} N={N}: {t*1e6:7.1f} us  {10.0*B*H*N*N*D/t/1e12:6.1f} TFLOP/s (incl. slab alloc)")
 if bias is not None and N % 64 == 0 and ops.relpos_inkernel(B, N, H, D, (N // 64, 8, 8), torch.bfloat16):
-    t = timeit(lambda: ops.attention_bwd(qkv, bias, out, dout, lse, B, N, H, D, 0.125, idx, 1575, table=table, cube=cube))
-    print(f"bwd (dQ: table in LDS) B={B} N={N}: {t*1e6:7.1f} us  {10.0*B*H*N*N*D/t/1e12:6.1f} TFLOP/s (incl. slab alloc)")
+    t = timeit(lambda: ops.attention_bwd(qkv, None, out, dout, lse, B, N, H, D, 0.125, idx, table.shape[0], table=table, cube=cube))
+    print(f"bwd (table in LDS) B={B} N={N}: {t*1e6:7.1f} us  {10.0*B*H*N*N*D/t/1e12:6.1f} TFLOP/s (incl. slab alloc)")
