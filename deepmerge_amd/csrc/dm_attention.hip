@@ -28,6 +28,7 @@
 #include "dm_common.h"
 #include "dm_mfma.h"
 #include "dm_attention_pipe.h"
+#include "dm_attention_x3.h"
 #include "dm_prof.h"
 
 namespace {
@@ -693,4 +694,35 @@ extern "C" int dm_attention_bwd_relpos(const void *qkv, const float *table, int3
              "dm_attention_bwd_relpos: shape not taken (B=%d N=%d H=%d D=%d cube=%dx%dx%d dtype=%d); call dm_attention_bwd", B, N, H, D, cube_s,
              cube_h, cube_w, dtype);
   return attention_bwd(qkv, bias, bias_t, table, cube_s, out, dout, lse, dqkv, delta, dbias_slab, B, N, H, D, scale, dtype, stream);
+}
+
+// ---- "bf16x3" numerics mode: fp32 tensors, split-bf16 products (dm_attention_x3.hip) ------------------------------------------------------------
+static bool split_shape(int32_t B, int32_t N, int32_t H, int32_t D, int32_t has_table, int32_t cube_s, int32_t cube_h, int32_t cube_w) {
+  if (D != HD) return false;
+  if (has_table && (cube_h != 8 || cube_w != 8)) return false;
+  return dm_attn_x3_shape(B, N, H, has_table != 0, cube_s);
+}
+
+extern "C" int32_t dm_attention_split_ok(int32_t B, int32_t N, int32_t H, int32_t D, int32_t has_table, int32_t cube_s, int32_t cube_h,
+                                         int32_t cube_w) {
+  return split_shape(B, N, H, D, has_table, cube_s, cube_h, cube_w) ? 1 : 0;
+}
+
+extern "C" int dm_attention_split_fwd(const float *qkv, void *qkv_hi, void *qkv_lo, const float *table, int32_t cube_s, int32_t cube_h,
+                                      int32_t cube_w, float *out, float *lse, int32_t B, int32_t N, int32_t H, int32_t D, float scale,
+                                      void *stream) {
+  DM_REQUIRE(split_shape(B, N, H, D, table != nullptr, cube_s, cube_h, cube_w), DM_ERR_UNSUPPORTED,
+             "dm_attention_split_fwd: shape not taken (B=%d N=%d H=%d D=%d cube=%dx%dx%d); use dm_attention_fwd", B, N, H, D, cube_s, cube_h, cube_w);
+  DM_REQUIRE(qkv && qkv_hi && qkv_lo && out && lse, DM_ERR_BAD_SHAPE, "dm_attention_split_fwd: null pointer");
+  DM_REQUIRE(dm_aligned16(qkv) && dm_aligned16(qkv_hi) && dm_aligned16(qkv_lo) && dm_aligned16(out), DM_ERR_BAD_ALIGN,
+             "dm_attention_split_fwd: tensors must be 16-byte aligned");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  {
+    DmProfScope prof("attn_fwd_x3", s, 3.0 * 4.0 * B * H * (double)N * N * HD, 4.0 * 4.0 * B * H * (double)N * HD);
+    dm_attn_x3_split(qkv, qkv_hi, qkv_lo, (long long)B * N * 3 * H * HD, s);
+    AttnX3Params p{reinterpret_cast<const bf16_t *>(qkv_hi), reinterpret_cast<const bf16_t *>(qkv_lo), table, cube_s, out, lse, B, N, H, scale};
+    DM_REQUIRE(dm_attn_fwd_x3(p, s), DM_ERR_UNSUPPORTED, "dm_attention_split_fwd: kernel could not be configured");
+  }
+  DM_LAUNCH_CHECK("dm_attention_split_fwd");
+  return DM_OK;
 }

@@ -1,0 +1,21 @@
+// Attention kernels of the "bf16x3" numerics mode (dm_attention_x3.hip): fp32 tensors, split-bf16 products on the matrix pipe.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "dm_common.h"
+
+struct AttnX3Params {
+  const bf16_t *hi, *lo;   // the split images of qkv [B, N, 3, H, 64] (dm_attn_x3_split)
+  const float *table;      // [bins, H] relative-position table of a (cube_s, 8, 8) token cube, or NULL (no bias)
+  int cube_s;
+  float *out;              // [B, N, H*64] fp32
+  float *lse;              // [B, H, N]
+  int B, N, H;
+  float scale;
+};
+
+// shapes the kernels take: head dim 64, 128 < N <= 256, bias absent or a (3 | 4, 8, 8) cube's table; DM_ATTN_X3=0 switches them off
+bool dm_attn_x3_shape(int B, int N, int H, bool has_table, int cube_s);
+// x [n] fp32 -> hi = bf16(x), lo = bf16(x - hi); n % 4 == 0
+void dm_attn_x3_split(const float *x, void *hi, void *lo, long long n, hipStream_t s);
+bool dm_attn_fwd_x3(const AttnX3Params &p, hipStream_t s);

@@ -368,6 +368,20 @@ def attention_fwd(qkv: torch.Tensor, bias: Optional[torch.Tensor], B: int, N: in
     return out, lse
 
 
+def _split_attention(table, index32, qkv, B, N, H, D):
+    """(use, cube): whether the forward runs on the split-bf16 attention kernels -- fp32 tensors inside a "bf16x3" scope, a shape they
+    take, and a bias that is either absent or the table of a token cube the module vouches for."""
+    if qkv.dtype != torch.float32 or _FP32_PRODUCTS != "bf16x3" or not _SPLIT_ATTENTION:
+        return False, None
+    cube = None if table is None else getattr(index32, "_dm_cube", None)
+    if table is not None and cube is None:
+        return False, None
+    return attention_split_ok(B, N, H, D, cube), cube
+
+
+_SPLIT_ATTENTION = os.environ.get("DM_ATTN_X3", "1") != "0"
+
+
 def _inkernel_cube(table, index32, B, N, H, D, dtype):
     """The token cube if the forward kernel can form the bias from `table` itself (the module vouches for the index: `_dm_cube` on the
     int32 index tensor is set only after comparing it with the closed form), else None."""
@@ -400,6 +414,29 @@ def attention_fwd_relpos(qkv: torch.Tensor, table: torch.Tensor, cube, B: int, N
     check(_lib.lib().dm_attention_fwd_relpos(qkv.data_ptr(), table.data_ptr(), int(cube[0]), int(cube[1]), int(cube[2]), out.data_ptr(),
                                              lse.data_ptr(), B, N, H, D, scale, _dt(qkv), _stream()), "dm_attention_fwd_relpos")
     return out, lse
+
+
+def attention_split_ok(B: int, N: int, H: int, D: int, cube=None) -> bool:
+    """True where the split-bf16 attention kernels (the "bf16x3" mode's) take the shape; cube = token cube of the bias table or None."""
+    c = (0, 0, 0) if cube is None else tuple(int(v) for v in cube)
+    return bool(_lib.lib().dm_attention_split_ok(B, N, H, D, int(cube is not None), c[0], c[1], c[2]))
+
+
+def attention_fwd_split(qkv: torch.Tensor, table: Optional[torch.Tensor], cube, B: int, N: int, H: int, D: int, scale: float):
+    """fp32 attention with split-bf16 products.  Returns (out, lse, qkv_hi, qkv_lo); the two bf16 images go to the backward pass."""
+    _need_cuda(qkv, table)
+    if qkv.dtype != torch.float32 or not qkv.is_contiguous():
+        raise ValueError("attention_fwd_split: qkv must be a contiguous fp32 tensor")
+    if table is not None and (table.dtype != torch.float32 or not table.is_contiguous()):
+        raise ValueError("attention_fwd_split: table must be contiguous fp32")
+    out = torch.empty((B, N, H * D), dtype=torch.float32, device=qkv.device)
+    lse = torch.empty((B, H, N), dtype=torch.float32, device=qkv.device)
+    hi = torch.empty(qkv.shape, dtype=torch.bfloat16, device=qkv.device)
+    lo = torch.empty(qkv.shape, dtype=torch.bfloat16, device=qkv.device)
+    c = (0, 0, 0) if cube is None else tuple(int(v) for v in cube)
+    check(_lib.lib().dm_attention_split_fwd(qkv.data_ptr(), hi.data_ptr(), lo.data_ptr(), _ptr(table), c[0], c[1], c[2], out.data_ptr(),
+                                            lse.data_ptr(), B, N, H, D, scale, _stream()), "dm_attention_split_fwd")
+    return out, lse, hi, lo
 
 
 _CSR_CACHE = {}
@@ -782,7 +819,12 @@ class AttentionFn(torch.autograd.Function):
         qkv = qkv.contiguous()
         bias = bias_t = None
         cube = _inkernel_cube(table, index32, B, N, H, D, qkv.dtype)
-        if cube is not None:                                 # the kernel reads the table itself: no dense rows in the forward pass
+        split, scube = _split_attention(table, index32, qkv, B, N, H, D)
+        if split:                                            # "bf16x3": split-bf16 products on the matrix pipe, the table read in the kernel
+            out, lse, _hi, _lo = attention_fwd_split(qkv, None if table is None else table.contiguous(), scube, B, N, H, D, scale)
+            if table is not None:
+                bias, bias_t = relpos_bias_gather(table.contiguous(), index32, N, transposed=True)     # (the fp32 backward kernels read dense rows)
+        elif cube is not None:                               # the kernel reads the table itself: no dense rows in the forward pass
             out, lse = attention_fwd_relpos(qkv, table.contiguous(), cube, B, N, H, D, scale)
         else:
             if table is not None:
@@ -1091,7 +1133,12 @@ class BlockFn(torch.autograd.Function):
         gemm(DM_NT, y1, wq, qkv, M, 3 * Cc, Cc, lda=Cc, ldb=Cc, ldc=3 * Cc, bias=qkv_b)
         bias = bias_t = None
         cube = _inkernel_cube(table, index32, B, N, heads, D, dtype)
-        if cube is not None:
+        split, scube = _split_attention(table, index32, qkv, B, N, heads, D)
+        if split:
+            o, lse, _hi, _lo = attention_fwd_split(qkv, None if table is None else table.contiguous(), scube, B, N, heads, D, scale)
+            if table is not None:
+                bias, bias_t = relpos_bias_gather(table.contiguous(), index32, N, transposed=True)     # (the fp32 backward kernels read dense rows)
+        elif cube is not None:
             o, lse = attention_fwd_relpos(qkv, table.contiguous(), cube, B, N, heads, D, scale)
         else:
             if table is not None:

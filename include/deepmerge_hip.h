@@ -145,6 +145,18 @@ int dm_attention_bwd_relpos(const void *qkv, const float *table, int32_t cube_s,
                             const float *bias, const float *bias_t, const void *out, const void *dout, const float *lse,
                             void *dqkv, float *delta, float *dbias_slab, int32_t B, int32_t N, int32_t H, int32_t D,
                             float scale, int32_t dtype, void *stream);
+/* Attention of the "bf16x3" numerics mode: fp32 tensors, every product as a split-bf16 triple on the matrix pipe (hi.hi +
+ * lo.hi + hi.lo into fp32: ~2^-17 relative per product, where the plain fp32 entry points above use fp32 FMA / fp32 MFMA
+ * arithmetic at a fraction of the rate).  Replaces the same reference statements as dm_attention_fwd.  qkv_hi / qkv_lo:
+ * caller-allocated bf16 tensors of qkv's shape, WRITTEN here (hi = bf16(x), lo = bf16(x - hi)) and kept by the caller for
+ * the backward pass.  table: NULL (no bias) or the relative-position table of a (cube_s, 8, 8) token cube as for
+ * dm_attention_fwd_relpos.  dm_attention_split_ok returns 1 for the shapes taken (D = 64, 128 < N <= 256, cube (3|4, 8, 8)
+ * when a table is given). */
+int32_t dm_attention_split_ok(int32_t B, int32_t N, int32_t H, int32_t D, int32_t has_table, int32_t cube_s, int32_t cube_h,
+                              int32_t cube_w);
+int dm_attention_split_fwd(const float *qkv, void *qkv_hi, void *qkv_lo, const float *table, int32_t cube_s, int32_t cube_h,
+                           int32_t cube_w, float *out, float *lse, int32_t B, int32_t N, int32_t H, int32_t D, float scale,
+                           void *stream);
 /* Number of batch chunks dm_attention_bwd uses for this problem size and dtype (first dimension of dbias_slab). */
 int32_t dm_attention_bwd_batch_chunks(int32_t B, int32_t N, int32_t H, int32_t dtype);
 

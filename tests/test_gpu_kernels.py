@@ -428,6 +428,37 @@ def test_attention_relpos_table_in_kernel(scales, B, H):
     assert torch.equal(d_tab, d_tab2) and torch.equal(dt_tab, dt_tab2)          # run-to-run deterministic (no atomics anywhere)
 
 
+@pytest.mark.parametrize("N,scales,B,H", [(256, 4, 8, 12), (192, 3, 9, 12), (197, 0, 10, 12), (160, 0, 7, 5), (224, 0, 3, 4), (256, 0, 5, 3)])
+def test_attention_split_forward(N, scales, B, H):
+    """dm_attention_split_fwd (the bf16x3 mode's attention): fp32 tensors, every product a split-bf16 triple on the matrix pipe, the
+    bias from the table in LDS (scales > 0) or none (ragged N allowed).  Against fp64: the error must be at the fp32 kernels' level
+    (1e-5-ish), nowhere near bf16's 1e-2.  Reference: nets/ShfitScaleFormer.py:119-133 / vit_model.py:119-133 in fp32."""
+    from oracle import s2former as O
+    ops = _ops()
+    D = 64
+    rng = np.random.default_rng(7 * N + scales)
+    qkv = torch.from_numpy(rng.normal(size=(B, N, 3, H, D)).astype(np.float32))
+    cube = (scales, 8, 8) if scales else None
+    table = bias64 = None
+    if scales:
+        n_bins = (2 * scales - 1) * 225
+        table = torch.from_numpy(rng.normal(size=(n_bins, H)).astype(np.float32))
+        index = torch.from_numpy(O.relpos_index(cube).astype(np.int64))
+        bias64 = table.double()[index.reshape(-1)].reshape(N, N, H).permute(2, 0, 1)
+    assert ops.attention_split_ok(B, N, H, D, cube)
+    o_ref, lse_ref = _attn_ref(qkv.double(), bias64, 0.125)
+    out, lse, hi, lo = ops.attention_fwd_split(qkv.to(DEV), None if table is None else table.to(DEV), cube, B, N, H, D, 0.125)
+    # the images: hi is the bf16 rounding, hi + lo recovers x to 2^-17 relative
+    assert torch.equal(hi.cpu(), qkv.to(torch.bfloat16))
+    assert ((hi.float() + lo.float()).cpu() - qkv).abs().max().item() <= 2.0 ** -16 * qkv.abs().max().item()
+    err_o = (out.cpu().double() - o_ref).abs().max().item()
+    err_l = (lse.cpu().double() - lse_ref).abs().max().item()
+    print(f"split-bf16 attention N={N}: max |out - fp64| {err_o:.2e}, max |lse - fp64| {err_l:.2e}")
+    assert err_o < 5e-5 and err_l < 5e-5
+    o32, lse32 = ops.attention_fwd(qkv.to(DEV), None if bias64 is None else bias64.float().contiguous().to(DEV), B, N, H, D, 0.125)
+    assert (out - o32).abs().max().item() < 5e-5
+
+
 @pytest.mark.parametrize("mode", ["fp32", "bf16"])
 @pytest.mark.parametrize("N,with_bias", [(12, True), (16, True), (48, True), (64, True), (192, True), (256, True), (197, False), (198, False), (100, True), (37, True), (250, True)])
 def test_attention_forward_backward(mode, N, with_bias, B=3, H=4):

@@ -32,6 +32,15 @@ if bias is not None and N % 64 == 0 and ops.relpos_inkernel(B, N, H, D, (N // 64
     table = torch.randn(((2 * cube[0] - 1) * 225, H), device=dev, generator=g) * 0.3
     t = timeit(lambda: ops.attention_fwd_relpos(qkv, table, cube, B, N, H, D, 0.125))
     print(f"fwd (table in LDS) B={B} N={N}: {t*1e6:7.1f} us  {4.0*B*H*N*N*D/t/1e12:6.1f} TFLOP/s")
+if os.environ.get("X3") == "1":
+    q32 = qkv.float()
+    t = timeit(lambda: ops.attention_fwd(q32, bias, B, N, H, D, 0.125))
+    print(f"fwd fp32 kernels B={B} N={N}: {t*1e6:7.1f} us")
+    cube3 = (N // 64, 8, 8) if (bias is not None and N % 64 == 0) else None
+    tab3 = None if cube3 is None else torch.randn(((2 * cube3[0] - 1) * 225, H), device=dev, generator=g) * 0.3
+    if ops.attention_split_ok(B, N, H, D, cube3) and (bias is None or cube3 is not None):
+        t = timeit(lambda: ops.attention_fwd_split(q32, tab3, cube3, B, N, H, D, 0.125))
+        print(f"fwd split-bf16 kernels B={B} N={N}: {t*1e6:7.1f} us  {3*4.0*B*H*N*N*D/t/1e12:6.1f} TFLOP/s (3 MFMAs per product, incl. the split pass)")
 if os.environ.get("FWD_ONLY") == "1":
     sys.exit(0)
 out, lse = ops.attention_fwd(qkv, bias, B, N, H, D, 0.125)
