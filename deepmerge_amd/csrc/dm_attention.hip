@@ -726,3 +726,26 @@ extern "C" int dm_attention_split_fwd(const float *qkv, void *qkv_hi, void *qkv_
   DM_LAUNCH_CHECK("dm_attention_split_fwd");
   return DM_OK;
 }
+
+extern "C" int32_t dm_attention_split_bwd_chunks(int32_t B, int32_t N, int32_t H) { return dm_attn_x3_chunks(B, N, H); }
+
+extern "C" int dm_attention_split_bwd(const void *qkv_hi, const void *qkv_lo, const float *table, int32_t cube_s, int32_t cube_h, int32_t cube_w,
+                                      const float *out, const float *dout, void *dout_hi, void *dout_lo, const float *lse, float *dqkv,
+                                      float *delta, float *dbias_slab, int32_t B, int32_t N, int32_t H, int32_t D, float scale, void *stream) {
+  DM_REQUIRE(split_shape(B, N, H, D, table != nullptr, cube_s, cube_h, cube_w), DM_ERR_UNSUPPORTED,
+             "dm_attention_split_bwd: shape not taken (B=%d N=%d H=%d D=%d cube=%dx%dx%d); use dm_attention_bwd", B, N, H, D, cube_s, cube_h, cube_w);
+  DM_REQUIRE(qkv_hi && qkv_lo && out && dout && dout_hi && dout_lo && lse && dqkv && delta, DM_ERR_BAD_SHAPE, "dm_attention_split_bwd: null pointer");
+  DM_REQUIRE(table || !dbias_slab, DM_ERR_BAD_SHAPE, "dm_attention_split_bwd: a bias-gradient slab needs the table");
+  DM_REQUIRE(dm_aligned16(qkv_hi) && dm_aligned16(qkv_lo) && dm_aligned16(out) && dm_aligned16(dout) && dm_aligned16(dout_hi) &&
+             dm_aligned16(dout_lo) && dm_aligned16(dqkv) && dm_aligned16(dbias_slab), DM_ERR_BAD_ALIGN, "dm_attention_split_bwd: tensors must be 16-byte aligned");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  {
+    DmProfScope prof("attn_bwd_x3", s, 3.0 * 10.0 * B * H * (double)N * N * HD, 4.0 * 8.0 * B * H * (double)N * HD);
+    dm_attn_x3_split(dout, dout_hi, dout_lo, (long long)B * N * H * HD, s);
+    AttnX3BwdParams p{reinterpret_cast<const bf16_t *>(qkv_hi), reinterpret_cast<const bf16_t *>(qkv_lo), reinterpret_cast<const bf16_t *>(dout_hi),
+                      reinterpret_cast<const bf16_t *>(dout_lo), out, dout, lse, delta, dqkv, dbias_slab, table, cube_s, B, N, H, scale};
+    DM_REQUIRE(dm_attn_bwd_dq_x3(p, s) && dm_attn_bwd_dkv_x3(p, s), DM_ERR_UNSUPPORTED, "dm_attention_split_bwd: kernels could not be configured");
+  }
+  DM_LAUNCH_CHECK("dm_attention_split_bwd");
+  return DM_OK;
+}

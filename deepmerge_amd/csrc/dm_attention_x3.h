@@ -19,3 +19,20 @@ bool dm_attn_x3_shape(int B, int N, int H, bool has_table, int cube_s);
 // x [n] fp32 -> hi = bf16(x), lo = bf16(x - hi); n % 4 == 0
 void dm_attn_x3_split(const float *x, void *hi, void *lo, long long n, hipStream_t s);
 bool dm_attn_fwd_x3(const AttnX3Params &p, hipStream_t s);
+
+struct AttnX3BwdParams {
+  const bf16_t *hi, *lo;       // split images of qkv (from the forward pass)
+  const bf16_t *dohi, *dolo;   // split images of dout [B, N, H*64]
+  const float *out, *dout;     // [B, N, H*64] fp32 (delta = rowsum(dO . O))
+  const float *lse;            // [B, H, N]
+  float *delta;                // [B, H, N]: written by the dQ pass, read by the dK / dV pass
+  float *dqkv;                 // [B, N, 3, H, 64] fp32, fully written by the two passes
+  float *slab;                 // [chunks, H, N, N] or NULL
+  const float *table;
+  int cube_s;
+  int B, N, H;
+  float scale;
+};
+bool dm_attn_bwd_dq_x3(const AttnX3BwdParams &p, hipStream_t s);
+bool dm_attn_bwd_dkv_x3(const AttnX3BwdParams &p, hipStream_t s);
+int dm_attn_x3_chunks(int B, int N, int H);

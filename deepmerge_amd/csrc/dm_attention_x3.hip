@@ -336,6 +336,490 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_x3_kernel(const AttnX3Params 
   }
 }
 
+// ---- backward, dQ pass (+ delta): the dQ kernel of dm_attention_q32_bwd.hip with every product a triple --------------------------------------
+//   S^T = K . Q^T (+ bias / scale),  dP^T = V . dO^T,  P^T = exp2(scale2 S^T - lse log2e),  dS^T = P^T (dP^T - delta),  dQ^T += K^T . dS^T
+// Images [K hi | K lo | V hi | V lo] with the dual-use swizzle (K is read by rows and transposed); Q / dO fragments of the lane's row
+// come from the split tensors in global memory, dS^T is split in registers.  36 MFMAs per 32-key tile; a tile runs start to end
+// (score chains, wait, VALU, dQ chain): the simple form already is several times the fp32-MFMA kernels' rate.
+template <int NKT, bool RAGGED, bool TAB>
+__global__ __launch_bounds__(256, 1) void attn_bwd_dq_x3_kernel(const AttnX3BwdParams p, int bchunk, int nblk, int chunks) {
+  static_assert(!(TAB && (RAGGED || NKT % 2)), "table form: N = 64 x scales");
+  constexpr int NP = NKT * 32;
+  const int N = RAGGED ? p.N : NP;
+  constexpr int IMG = NP * 128;
+  extern __shared__ __attribute__((aligned(16))) char smem[];      // K hi | K lo | V hi | V lo | table
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int r = lane & 31, hh = lane >> 5;
+  int h, rb, chunk;
+  if (!coords(nblk, p.H, chunks, h, rb, chunk)) return;
+  const int H = p.H;
+  const int b0 = chunk * bchunk, b1 = min(p.B, b0 + bchunk);
+  if (b0 >= b1) return;
+  const int q_wave = rb * 128 + wave * 32;
+  const int q = q_wave + r;
+  const bool wave_live = q_wave < N;
+  const bool row_ok = q < N;
+  const long long tok_stride = 3LL * H * HD, out_stride = (long long)H * HD;
+  constexpr float LOG2E = 1.4426950408889634f;
+  const float scale2 = p.scale * LOG2E;
+
+  constexpr int TAB_MAXC = 15 * ((NKT - 1) >> 1) + 7;
+  float *tab = reinterpret_cast<float *>(smem + 4 * IMG);
+  const float *tabl = tab;
+  if constexpr (TAB) {
+    const float inv_scale = 1.f / p.scale;
+    for (int i = t; i < (NKT - 1) * 225; i += 256) {
+      const int prow = i / 15, px = i - prow * 15;
+      tab[prow * 16 + (14 - px)] = p.table[(long long)i * H + h] * inv_scale;
+    }
+    const int qz = q >> 6, qy = (q >> 3) & 7, qx = q & 7;
+    tabl = tab + ((qz + NKT / 2 - 1) * 15 + qy + 7 - TAB_MAXC) * 16 + 7 - qx + 4 * hh;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+  auto init_c = [&](int kt, f32x16 &d) {
+    if constexpr (TAB) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) d[4 * c + e] = tabl[16 * (TAB_MAXC - (15 * (kt >> 1) + 4 * (kt & 1) + c)) + e];
+    } else {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) d[i] = (RAGGED && kt == NKT - 1 && 32 * kt + 8 * (i >> 2) + 4 * hh + (i & 3) >= N) ? NEG_BIG : 0.f;
+      asm volatile("" : "+v"(d));
+    }
+  };
+
+  const int dkey = lane >> 3;
+  const unsigned rowoff0 = (unsigned)((8 * wave + dkey) * tok_stride * 2);
+  const unsigned src_swz = (unsigned)(((lane & 7) ^ ((((dkey >> 1) & 1) << 2) | ((((wave & 1) << 1) | (dkey >> 2)) & 3))) * 16);
+  const unsigned voffK = rowoff0 + (unsigned)(1 * H * HD * 2) + src_swz;
+  const unsigned voffV = rowoff0 + (unsigned)(2 * H * HD * 2) + src_swz;
+  const unsigned lds0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(uintptr_t)(DM_LDS char *)smem);
+  unsigned step_bytes = (unsigned)__builtin_amdgcn_readfirstlane((int)(32 * tok_stride * 2));
+  asm volatile("s_nop 4" : "+s"(step_bytes));
+  auto sample_rsrc = [&](const bf16_t *src, int b) -> i32x4 {
+    const uintptr_t base = reinterpret_cast<uintptr_t>(src + (long long)b * N * tok_stride + (long long)h * HD);
+    i32x4 rs;
+    rs[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)(base & 0xffffffffu));
+    rs[1] = __builtin_amdgcn_readfirstlane((int)(unsigned)((base >> 32) & 0xffffu));
+    rs[2] = __builtin_amdgcn_readfirstlane((int)(N * tok_stride * 2));
+    rs[3] = 0x00020000;
+    asm volatile("s_nop 4" : "+s"(rs));
+    return rs;
+  };
+  auto stage_all = [&](int b) {
+    const i32x4 rh = sample_rsrc(p.hi, b), rl = sample_rsrc(p.lo, b);
+    const unsigned base = lds0 + (unsigned)wave * 1024u;
+#pragma unroll
+    for (int j = 0; j < NKT; ++j) {
+      lds_dma(rh, base + 0 * IMG + (unsigned)j * 4096u, voffK, (unsigned)j * step_bytes);
+      lds_dma(rl, base + 1 * IMG + (unsigned)j * 4096u, voffK, (unsigned)j * step_bytes);
+      lds_dma(rh, base + 2 * IMG + (unsigned)j * 4096u, voffV, (unsigned)j * step_bytes);
+      lds_dma(rl, base + 3 * IMG + (unsigned)j * 4096u, voffV, (unsigned)j * step_bytes);
+    }
+  };
+  const int xr = (((r >> 1) & 1) << 2) | ((r >> 2) & 3);
+  int roff[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) roff[ks] = r * 128 + (((2 * ks + hh) ^ xr) << 4);
+  const int ve = (lane >> 4) & 1, qd = (lane >> 2) & 3, pp = lane & 3;
+  int toff[2][2];
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int j2 = 0; j2 < 2; ++j2) {
+      const int x = ((qd >> 1) << 2) | ((2 * j2 + hh) & 3);
+      toff[dt][j2] = (8 * j2 + 4 * hh + qd) * 128 + (((4 * dt + 2 * ve + (pp >> 1)) ^ x) << 4) + 8 * (pp & 1);
+    }
+
+  for (int b = b0; b < b1; ++b) {
+    __builtin_amdgcn_s_barrier();
+    stage_all(b);
+    // this lane's row: Q and dO fragments (hi / lo), delta = rowsum(dO . O) in fp32, -lse in log2 units
+    u32x4 qh[4], ql[4], dh[4], dl[4];
+    float dsum = 0.f, lse = 0.f;
+    {
+      const bool ok = wave_live && row_ok;
+      const long long qoff = ((long long)b * N + q) * tok_stride + (long long)h * HD + 8 * hh;
+      const long long ooff = ((long long)b * N + q) * out_stride + (long long)h * HD + 8 * hh;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        qh[ks] = ok ? *reinterpret_cast<const u32x4 *>(p.hi + qoff + 16 * ks) : (u32x4){0u, 0u, 0u, 0u};
+        ql[ks] = ok ? *reinterpret_cast<const u32x4 *>(p.lo + qoff + 16 * ks) : (u32x4){0u, 0u, 0u, 0u};
+        dh[ks] = ok ? *reinterpret_cast<const u32x4 *>(p.dohi + ooff + 16 * ks) : (u32x4){0u, 0u, 0u, 0u};
+        dl[ks] = ok ? *reinterpret_cast<const u32x4 *>(p.dolo + ooff + 16 * ks) : (u32x4){0u, 0u, 0u, 0u};
+        if (ok) {
+#pragma unroll
+          for (int w = 0; w < 2; ++w) {
+            const f32x4 ov = dm_load4(p.out + ooff + 16 * ks + 4 * w), gv = dm_load4(p.dout + ooff + 16 * ks + 4 * w);
+            dsum += ov[0] * gv[0] + ov[1] * gv[1] + ov[2] * gv[2] + ov[3] * gv[3];
+          }
+        }
+      }
+      lse = ok ? p.lse[((long long)b * H + h) * N + q] : 0.f;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    const float delta = half_sum(dsum);
+    const float nl = -lse * LOG2E;
+    if (wave_live && row_ok && hh == 0) p.delta[((long long)b * H + h) * N + q] = delta;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) { park_acc(qh[ks]); park_acc(ql[ks]); park_acc(dh[ks]); park_acc(dl[ks]); }
+    if (!wave_live) continue;
+    const char *kh = smem, *kl = smem + IMG, *vh = smem + 2 * IMG, *vl = smem + 3 * IMG;
+
+    f32x16 sc, dp;
+    u32x4 dsh[2], dsl[2];
+    u32x4 kfh[4], kfl[4], vfh[4], vfl[4];
+    u32x2 tfh[8], tfl[8];
+    f32x16 dq0, dq1;
+    auto tfrag = [&](const u32x2 (&f)[8], int sx, int dt) { return (u32x4){f[4 * sx + 2 * dt][0], f[4 * sx + 2 * dt][1], f[4 * sx + 2 * dt + 1][0], f[4 * sx + 2 * dt + 1][1]}; };
+    asm volatile("s_nop 1");
+#pragma unroll
+    for (int j = 0; j < NKT; ++j) {
+      init_c(j, sc);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        kfh[ks] = *reinterpret_cast<const u32x4 *>(kh + j * 4096 + roff[ks]);
+        kfl[ks] = *reinterpret_cast<const u32x4 *>(kl + j * 4096 + roff[ks]);
+        vfh[ks] = *reinterpret_cast<const u32x4 *>(vh + j * 4096 + roff[ks]);
+        vfl[ks] = *reinterpret_cast<const u32x4 *>(vl + j * 4096 + roff[ks]);
+      }
+#pragma unroll
+      for (int sx = 0; sx < 2; ++sx)
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          const int o = (32 * j + 16 * sx) * 128;
+          tfh[4 * sx + 2 * dt] = dm_ds_read_tr16(kh + o + toff[dt][0]);
+          tfh[4 * sx + 2 * dt + 1] = dm_ds_read_tr16(kh + o + toff[dt][1]);
+          tfl[4 * sx + 2 * dt] = dm_ds_read_tr16(kl + o + toff[dt][0]);
+          tfl[4 * sx + 2 * dt + 1] = dm_ds_read_tr16(kl + o + toff[dt][1]);
+        }
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        qk_acc<true, false>(sc, kfh[ks], qh[ks]);
+        qk_acc<true, false>(sc, kfl[ks], qh[ks]);
+        qk_acc<true, false>(sc, kfh[ks], ql[ks]);
+      }
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        if (ks == 0) qk_first0<true, false>(dp, vfh[0], dh[0]); else qk_acc<true, false>(dp, vfh[ks], dh[ks]);
+        qk_acc<true, false>(dp, vfl[ks], dh[ks]);
+        qk_acc<true, false>(dp, vfh[ks], dl[ks]);
+      }
+      asm volatile("s_nop 15\n\ts_nop 7" : "+v"(sc), "+v"(dp)
+                   : "v"(kfh[0]), "v"(kfh[1]), "v"(kfh[2]), "v"(kfh[3]), "v"(kfl[0]), "v"(kfl[1]), "v"(kfl[2]), "v"(kfl[3]),
+                     "v"(vfh[0]), "v"(vfh[1]), "v"(vfh[2]), "v"(vfh[3]), "v"(vfl[0]), "v"(vfl[1]), "v"(vfl[2]), "v"(vfl[3]));
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[2 * k], scale2, nl));
+        const float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[2 * k + 1], scale2, nl));
+        const float d0 = p0 * (dp[2 * k] - delta), d1 = p1 * (dp[2 * k + 1] - delta);
+        const unsigned w = pk_bf16(d0, d1);
+        dsh[k >> 2][k & 3] = w;
+        dsl[k >> 2][k & 3] = split_lo(d0, d1, w);
+      }
+      asm volatile("s_nop 1" : "+v"(dsh[0]), "+v"(dsh[1]), "+v"(dsl[0]), "+v"(dsl[1]));      // VALU write -> MFMA operand
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int sx = g >> 1, dt = g & 1;
+        f32x16 &o = dt ? dq1 : dq0;
+        if (j == 0 && sx == 0) pv_first<false>(o, tfrag(tfh, 0, dt), dsh[0]); else pv_acc<false>(o, tfrag(tfh, sx, dt), dsh[sx]);
+        pv_acc<false>(o, tfrag(tfl, sx, dt), dsh[sx]);
+        pv_acc<false>(o, tfrag(tfh, sx, dt), dsl[sx]);
+      }
+      asm volatile("" :: "v"(tfh[0]), "v"(tfh[1]), "v"(tfh[2]), "v"(tfh[3]), "v"(tfh[4]), "v"(tfh[5]), "v"(tfh[6]), "v"(tfh[7]),
+                   "v"(tfl[0]), "v"(tfl[1]), "v"(tfl[2]), "v"(tfl[3]), "v"(tfl[4]), "v"(tfl[5]), "v"(tfl[6]), "v"(tfl[7]),
+                   "v"(dsh[0]), "v"(dsh[1]), "v"(dsl[0]), "v"(dsl[1]));
+    }
+    asm volatile("s_nop 15\n\ts_nop 7" : "+a"(dq0), "+a"(dq1));
+    if (row_ok) {
+      float *drow = p.dqkv + ((long long)b * N + q) * tok_stride + (long long)h * HD + 4 * hh;
+      const float f = p.scale;
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        const f32x16 &o = dt ? dq1 : dq0;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) dm_store4(drow + 32 * dt + 8 * c, (f32x4){o[4 * c] * f, o[4 * c + 1] * f, o[4 * c + 2] * f, o[4 * c + 3] * f});
+      }
+    }
+  }
+}
+
+// ---- backward, dK / dV pass (+ the table-gradient slab): the key on the lane (dm_attention_q32_bwd.hip), every product a triple -------------
+//   S = Q . K^T (+ bias / scale from the table, natural order),  dP = dO . V^T - delta (C operand from the stat table)
+//   P = exp2(scale2 S - lse log2e) (-lse: the fma's addend, one value per query register),  dS = P dP
+//   dV^T += dO^T . P,  dK^T += Q^T . dS,  H_j += E_s . dS_s (hi and lo: the slab sums dS to ~2^-17 relative)
+// Images [Q hi | Q lo | dO hi | dO lo] (dual-use swizzle); K / V fragments of the lane's key from the split tensors.  52 MFMAs per tile.
+template <int NKT, bool RAGGED, bool TAB>
+__global__ __launch_bounds__(256, 1) void attn_bwd_dkv_x3_kernel(const AttnX3BwdParams p, int bchunk, int nblk, int chunks) {
+  static_assert(!(TAB && (RAGGED || NKT % 2)), "table form: N = 64 x scales");
+  constexpr int NP = NKT * 32;
+  const int N = RAGGED ? p.N : NP;
+  constexpr int IMG = NP * 128;
+  constexpr int STAT = 2 * NP * 4;
+  extern __shared__ __attribute__((aligned(16))) char smem[];      // Q hi | Q lo | dO hi | dO lo | stat | table
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int r = lane & 31, hh = lane >> 5;
+  int h, rb, chunk;
+  if (!coords(nblk, p.H, chunks, h, rb, chunk)) return;
+  const int H = p.H;
+  const int b0 = chunk * bchunk, b1 = min(p.B, b0 + bchunk);
+  if (b0 >= b1) return;
+  const int k_wave = rb * 128 + wave * 32;
+  const int key = k_wave + r;
+  const bool wave_live = k_wave < N;
+  const bool row_ok = key < N;
+  const long long tok_stride = 3LL * H * HD, out_stride = (long long)H * HD;
+  constexpr float LOG2E = 1.4426950408889634f;
+  const float scale2 = p.scale * LOG2E;
+
+  const int dkey = lane >> 3;
+  const unsigned src_swz = (unsigned)(((lane & 7) ^ ((((dkey >> 1) & 1) << 2) | ((((wave & 1) << 1) | (dkey >> 2)) & 3))) * 16);
+  const unsigned voffQ = (unsigned)((8 * wave + dkey) * tok_stride * 2) + src_swz;
+  const unsigned voffD = (unsigned)((8 * wave + dkey) * out_stride * 2) + src_swz;
+  const unsigned lds0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(uintptr_t)(DM_LDS char *)smem);
+  unsigned stepQ = (unsigned)__builtin_amdgcn_readfirstlane((int)(32 * tok_stride * 2));
+  unsigned stepD = (unsigned)__builtin_amdgcn_readfirstlane((int)(32 * out_stride * 2));
+  asm volatile("s_nop 4" : "+s"(stepQ), "+s"(stepD));
+  auto make_rsrc = [&](const bf16_t *base, long long bytes) -> i32x4 {
+    const uintptr_t a = reinterpret_cast<uintptr_t>(base);
+    i32x4 rs;
+    rs[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)(a & 0xffffffffu));
+    rs[1] = __builtin_amdgcn_readfirstlane((int)(unsigned)((a >> 32) & 0xffffu));
+    rs[2] = __builtin_amdgcn_readfirstlane((int)bytes);
+    rs[3] = 0x00020000;
+    asm volatile("s_nop 4" : "+s"(rs));
+    return rs;
+  };
+  auto stage_all = [&](int b) {
+    const long long qb = (long long)b * N * tok_stride + (long long)h * HD, db = (long long)b * N * out_stride + (long long)h * HD;
+    const i32x4 rqh = make_rsrc(p.hi + qb, (long long)N * tok_stride * 2), rql = make_rsrc(p.lo + qb, (long long)N * tok_stride * 2);
+    const i32x4 rdh = make_rsrc(p.dohi + db, (long long)N * out_stride * 2), rdl = make_rsrc(p.dolo + db, (long long)N * out_stride * 2);
+    const unsigned base = lds0 + (unsigned)wave * 1024u;
+#pragma unroll
+    for (int j = 0; j < NKT; ++j) {
+      lds_dma(rqh, base + 0 * IMG + (unsigned)j * 4096u, voffQ, (unsigned)j * stepQ);
+      lds_dma(rql, base + 1 * IMG + (unsigned)j * 4096u, voffQ, (unsigned)j * stepQ);
+      lds_dma(rdh, base + 2 * IMG + (unsigned)j * 4096u, voffD, (unsigned)j * stepD);
+      lds_dma(rdl, base + 3 * IMG + (unsigned)j * 4096u, voffD, (unsigned)j * stepD);
+    }
+  };
+  const int xr = (((r >> 1) & 1) << 2) | ((r >> 2) & 3);
+  int roff[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) roff[ks] = r * 128 + (((2 * ks + hh) ^ xr) << 4);
+  const int ve = (lane >> 4) & 1, qd = (lane >> 2) & 3, pp = lane & 3;
+  int toff[2][2];
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int j2 = 0; j2 < 2; ++j2) {
+      const int x = ((qd >> 1) << 2) | ((2 * j2 + hh) & 3);
+      toff[dt][j2] = (8 * j2 + 4 * hh + qd) * 128 + (((4 * dt + 2 * ve + (pp >> 1)) ^ x) << 4) + 8 * (pp & 1);
+    }
+  float *st = reinterpret_cast<float *>(smem + 4 * IMG);
+  float *tab = reinterpret_cast<float *>(smem + 4 * IMG + STAT);
+  const float *tabl = tab;
+  if constexpr (TAB) {                                              // natural order: row (dz + S - 1) * 15 + dy + 7, entry dx + 7
+    const float inv_scale = 1.f / p.scale;
+    for (int i = t; i < (NKT - 1) * 225; i += 256) {
+      const int prow = i / 15, px = i - prow * 15;
+      tab[prow * 16 + px] = p.table[(long long)i * H + h] * inv_scale;
+    }
+    const int kz = key >> 6, ky = (key >> 3) & 7, kx = key & 7;
+    tabl = tab + (wave_live ? ((NKT / 2 - 1 - kz) * 15 + 7 - ky) * 16 + 4 * hh - kx + 7 : 0);
+  }
+  u32x4 esel[2];
+#pragma unroll
+  for (int sx = 0; sx < 2; ++sx)
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const int i0 = 2 * w, i1 = 2 * w + 1;
+      const unsigned lo = (r == 16 * sx + 8 * (i0 >> 2) + 4 * hh + (i0 & 3)) ? 0x3f80u : 0u;
+      const unsigned hi = (r == 16 * sx + 8 * (i1 >> 2) + 4 * hh + (i1 & 3)) ? 0x3f80u : 0u;
+      esel[sx][w] = lo | (hi << 16);
+    }
+  constexpr int NH = TAB ? NKT : 1;
+  f32x16 hacc[NH];
+  if constexpr (TAB) {
+#pragma unroll
+    for (int j = 0; j < NKT; ++j) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) hacc[j][i] = 0.f;
+      asm volatile("" : "+a"(hacc[j]));
+    }
+  }
+  const bool want_slab = TAB && p.slab != nullptr;
+
+  const int sq = wave * 64 + lane;
+  for (int b = b0; b < b1; ++b) {
+    __builtin_amdgcn_s_barrier();
+    stage_all(b);
+    u32x4 kh[4], kl[4], vh[4], vl[4];
+    {
+      const bool ok = wave_live && row_ok;
+      const long long koff = ((long long)b * N + key) * tok_stride + (long long)(H + h) * HD + 8 * hh;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        kh[ks] = ok ? *reinterpret_cast<const u32x4 *>(p.hi + koff + 16 * ks) : (u32x4){0u, 0u, 0u, 0u};
+        kl[ks] = ok ? *reinterpret_cast<const u32x4 *>(p.lo + koff + 16 * ks) : (u32x4){0u, 0u, 0u, 0u};
+        vh[ks] = ok ? *reinterpret_cast<const u32x4 *>(p.hi + koff + (long long)H * HD + 16 * ks) : (u32x4){0u, 0u, 0u, 0u};
+        vl[ks] = ok ? *reinterpret_cast<const u32x4 *>(p.lo + koff + (long long)H * HD + 16 * ks) : (u32x4){0u, 0u, 0u, 0u};
+      }
+      if (sq < NP) {                                                // per-query constants (queries >= N: no probability, no gradient)
+        const bool sok = sq < N;
+        st[sq] = sok ? -p.lse[((long long)b * H + h) * N + sq] * LOG2E : NEG_BIG;
+        st[NP + sq] = sok ? -p.delta[((long long)b * H + h) * N + sq] : 0.f;
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) { park_acc(kh[ks]); park_acc(kl[ks]); park_acc(vh[ks]); park_acc(vl[ks]); }
+    if (!wave_live) continue;
+    const char *qih = smem, *qil = smem + IMG, *dih = smem + 2 * IMG, *dil = smem + 3 * IMG;
+
+    f32x16 sc, dp, nl;
+    u32x4 pbh[2], pbl[2], dsh[2], dsl[2];
+    u32x4 afh[4], afl[4];
+    u32x2 th[8], tl[8];
+    f32x16 dk0, dk1, dv0, dv1;
+    auto tfrag = [&](const u32x2 (&f)[8], int sx, int dt) { return (u32x4){f[4 * sx + 2 * dt][0], f[4 * sx + 2 * dt][1], f[4 * sx + 2 * dt + 1][0], f[4 * sx + 2 * dt + 1][1]}; };
+    auto read_rows = [&](const char *ih, const char *il, int j) {
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        afh[ks] = *reinterpret_cast<const u32x4 *>(ih + j * 4096 + roff[ks]);
+        afl[ks] = *reinterpret_cast<const u32x4 *>(il + j * 4096 + roff[ks]);
+      }
+    };
+    auto read_tr = [&](const char *ih, const char *il, int j) {
+#pragma unroll
+      for (int sx = 0; sx < 2; ++sx)
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          const int o = (32 * j + 16 * sx) * 128;
+          th[4 * sx + 2 * dt] = dm_ds_read_tr16(ih + o + toff[dt][0]);
+          th[4 * sx + 2 * dt + 1] = dm_ds_read_tr16(ih + o + toff[dt][1]);
+          tl[4 * sx + 2 * dt] = dm_ds_read_tr16(il + o + toff[dt][0]);
+          tl[4 * sx + 2 * dt + 1] = dm_ds_read_tr16(il + o + toff[dt][1]);
+        }
+    };
+    auto pin_rows = [&]() {
+      asm volatile("" :: "v"(afh[0]), "v"(afh[1]), "v"(afh[2]), "v"(afh[3]), "v"(afl[0]), "v"(afl[1]), "v"(afl[2]), "v"(afl[3]));
+    };
+    auto pin_tr = [&]() {
+      asm volatile("" :: "v"(th[0]), "v"(th[1]), "v"(th[2]), "v"(th[3]), "v"(th[4]), "v"(th[5]), "v"(th[6]), "v"(th[7]),
+                   "v"(tl[0]), "v"(tl[1]), "v"(tl[2]), "v"(tl[3]), "v"(tl[4]), "v"(tl[5]), "v"(tl[6]), "v"(tl[7]));
+    };
+    asm volatile("s_nop 1");
+#pragma unroll
+    for (int j = 0; j < NKT; ++j) {
+      // C operands: bias / scale (or 0) for the scores, -delta for dP; -lse log2e as the exponent's addend
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const f32x4 a = *reinterpret_cast<const f32x4 *>(st + 32 * j + 8 * c + 4 * hh);
+        const f32x4 d = *reinterpret_cast<const f32x4 *>(st + NP + 32 * j + 8 * c + 4 * hh);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          nl[4 * c + e] = a[e];
+          dp[4 * c + e] = d[e];
+          if constexpr (TAB) sc[4 * c + e] = tabl[16 * (15 * (j >> 1) + 4 * (j & 1) + c) + e];
+          else sc[4 * c + e] = 0.f;
+        }
+      }
+      if constexpr (!TAB) asm volatile("" : "+v"(sc));
+      read_rows(qih, qil, j);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        qk_acc<true, false>(sc, afh[ks], kh[ks]);
+        qk_acc<true, false>(sc, afl[ks], kh[ks]);
+        qk_acc<true, false>(sc, afh[ks], kl[ks]);
+      }
+      pin_rows();
+      read_rows(dih, dil, j);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        qk_acc<true, false>(dp, afh[ks], vh[ks]);
+        qk_acc<true, false>(dp, afl[ks], vh[ks]);
+        qk_acc<true, false>(dp, afh[ks], vl[ks]);
+      }
+      pin_rows();
+      read_tr(dih, dil, j);                                          // dO^T for dV (lands during the wait below)
+      asm volatile("s_nop 15\n\ts_nop 7" : "+v"(sc), "+v"(dp));
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[2 * k], scale2, nl[2 * k]));
+        const float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[2 * k + 1], scale2, nl[2 * k + 1]));
+        const float d0 = p0 * dp[2 * k], d1 = p1 * dp[2 * k + 1];
+        const unsigned wp = pk_bf16(p0, p1), wd = pk_bf16(d0, d1);
+        pbh[k >> 2][k & 3] = wp;
+        pbl[k >> 2][k & 3] = split_lo(p0, p1, wp);
+        dsh[k >> 2][k & 3] = wd;
+        dsl[k >> 2][k & 3] = split_lo(d0, d1, wd);
+      }
+      asm volatile("s_nop 1" : "+v"(pbh[0]), "+v"(pbh[1]), "+v"(pbl[0]), "+v"(pbl[1]), "+v"(dsh[0]), "+v"(dsh[1]), "+v"(dsl[0]), "+v"(dsl[1]));
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int sx = g >> 1, dt = g & 1;
+        f32x16 &o = dt ? dv1 : dv0;
+        if (j == 0 && sx == 0) pv_first<false>(o, tfrag(th, 0, dt), pbh[0]); else pv_acc<false>(o, tfrag(th, sx, dt), pbh[sx]);
+        pv_acc<false>(o, tfrag(tl, sx, dt), pbh[sx]);
+        pv_acc<false>(o, tfrag(th, sx, dt), pbl[sx]);
+      }
+      pin_tr();
+      read_tr(qih, qil, j);                                          // Q^T for dK
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int sx = g >> 1, dt = g & 1;
+        f32x16 &o = dt ? dk1 : dk0;
+        if (j == 0 && sx == 0) pv_first<false>(o, tfrag(th, 0, dt), dsh[0]); else pv_acc<false>(o, tfrag(th, sx, dt), dsh[sx]);
+        pv_acc<false>(o, tfrag(tl, sx, dt), dsh[sx]);
+        pv_acc<false>(o, tfrag(th, sx, dt), dsl[sx]);
+      }
+      pin_tr();
+      if constexpr (TAB) {
+        if (want_slab) {
+          pv_acc<false>(hacc[j], esel[0], dsh[0]);
+          pv_acc<false>(hacc[j], esel[1], dsh[1]);
+          pv_acc<false>(hacc[j], esel[0], dsl[0]);
+          pv_acc<false>(hacc[j], esel[1], dsl[1]);
+        }
+      }
+      asm volatile("" :: "v"(pbh[0]), "v"(pbh[1]), "v"(pbl[0]), "v"(pbl[1]), "v"(dsh[0]), "v"(dsh[1]), "v"(dsl[0]), "v"(dsl[1]), "v"(esel[0]), "v"(esel[1]));
+    }
+    asm volatile("s_nop 15\n\ts_nop 7" : "+a"(dk0), "+a"(dk1), "+a"(dv0), "+a"(dv1));
+    if (row_ok) {
+      float *krow = p.dqkv + ((long long)b * N + key) * tok_stride + (long long)(H + h) * HD + 4 * hh;
+      float *vrow = krow + (long long)H * HD;
+      const float f = p.scale;
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        const f32x16 &a = dt ? dk1 : dk0;
+        const f32x16 &v = dt ? dv1 : dv0;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          dm_store4(krow + 32 * dt + 8 * c, (f32x4){a[4 * c] * f, a[4 * c + 1] * f, a[4 * c + 2] * f, a[4 * c + 3] * f});
+          dm_store4(vrow + 32 * dt + 8 * c, (f32x4){v[4 * c], v[4 * c + 1], v[4 * c + 2], v[4 * c + 3]});
+        }
+      }
+    }
+  }
+  if constexpr (TAB) {
+    if (wave_live && want_slab) {
+      float *sl = p.slab + ((long long)(chunk * H + h) * N) * N + key;
+#pragma unroll
+      for (int j = 0; j < NKT; ++j) {
+        asm volatile("s_nop 15\n\ts_nop 7" : "+a"(hacc[j]));
+#pragma unroll
+        for (int i = 0; i < 16; ++i) sl[(long long)(32 * j + 8 * (i >> 2) + 4 * hh + (i & 3)) * N] = hacc[j][i];
+      }
+    }
+  }
+}
+
 inline void grid(int B, int N, int H, int &nblk, int &chunks, int &bchunk) {
   nblk = (N + 127) / 128;
   chunks = 256 / (H * nblk);
@@ -366,6 +850,47 @@ template <int NKT> bool launch_fwd_n(const AttnX3Params &p, hipStream_t s) {
   return ragged ? launch_fwd<NKT, true, false>(p, s) : launch_fwd<NKT, false, false>(p, s);
 }
 
+template <int NKT, bool RAGGED, bool TAB> bool launch_dq(const AttnX3BwdParams &p, hipStream_t s) {
+  constexpr int LDS = 4 * NKT * 32 * 128 + (TAB ? (NKT - 1) * 15 * 64 : 0);
+  static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void *>(attn_bwd_dq_x3_kernel<NKT, RAGGED, TAB>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, LDS) == hipSuccess;
+  if (!ok) return false;
+  int nblk, chunks, bchunk;
+  grid(p.B, p.N, p.H, nblk, chunks, bchunk);
+  hipLaunchKernelGGL((attn_bwd_dq_x3_kernel<NKT, RAGGED, TAB>), dim3(grid_size(nblk, p.H, chunks)), dim3(256), LDS, s, p, bchunk, nblk, chunks);
+  return true;
+}
+
+template <int NKT> bool launch_dq_n(const AttnX3BwdParams &p, hipStream_t s) {
+  const bool ragged = p.N != NKT * 32;
+  if constexpr (NKT % 2 == 0) {
+    if (p.table) return !ragged && launch_dq<NKT, false, true>(p, s);
+  }
+  if (p.table) return false;
+  return ragged ? launch_dq<NKT, true, false>(p, s) : launch_dq<NKT, false, false>(p, s);
+}
+
+template <int NKT, bool RAGGED, bool TAB> bool launch_dkv(const AttnX3BwdParams &p, hipStream_t s) {
+  constexpr int LDS = 4 * NKT * 32 * 128 + 2 * NKT * 32 * 4 + (TAB ? (NKT - 1) * 15 * 64 : 0);
+  static_assert(LDS <= 160 * 1024, "LDS budget");
+  static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void *>(attn_bwd_dkv_x3_kernel<NKT, RAGGED, TAB>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, LDS) == hipSuccess;
+  if (!ok) return false;
+  int nblk, chunks, bchunk;
+  grid(p.B, p.N, p.H, nblk, chunks, bchunk);
+  hipLaunchKernelGGL((attn_bwd_dkv_x3_kernel<NKT, RAGGED, TAB>), dim3(grid_size(nblk, p.H, chunks)), dim3(256), LDS, s, p, bchunk, nblk, chunks);
+  return true;
+}
+
+template <int NKT> bool launch_dkv_n(const AttnX3BwdParams &p, hipStream_t s) {
+  const bool ragged = p.N != NKT * 32;
+  if constexpr (NKT % 2 == 0) {
+    if (p.table) return !ragged && launch_dkv<NKT, false, true>(p, s);
+  }
+  if (p.table) return false;
+  return ragged ? launch_dkv<NKT, true, false>(p, s) : launch_dkv<NKT, false, false>(p, s);
+}
+
 }  // namespace dmx3
 
 bool dm_attn_x3_shape(int B, int N, int H, bool has_table, int cube_s) {
@@ -392,4 +917,33 @@ bool dm_attn_fwd_x3(const AttnX3Params &p, hipStream_t s) {
     case 8: return dmx3::launch_fwd_n<8>(p, s);
     default: return false;
   }
+}
+
+bool dm_attn_bwd_dq_x3(const AttnX3BwdParams &p, hipStream_t s) {
+  if (!dm_attn_x3_shape(p.B, p.N, p.H, p.table != nullptr, p.cube_s)) return false;
+  switch ((p.N + 31) / 32) {
+    case 5: return dmx3::launch_dq_n<5>(p, s);
+    case 6: return dmx3::launch_dq_n<6>(p, s);
+    case 7: return dmx3::launch_dq_n<7>(p, s);
+    case 8: return dmx3::launch_dq_n<8>(p, s);
+    default: return false;
+  }
+}
+
+bool dm_attn_bwd_dkv_x3(const AttnX3BwdParams &p, hipStream_t s) {
+  if (!dm_attn_x3_shape(p.B, p.N, p.H, p.table != nullptr, p.cube_s)) return false;
+  switch ((p.N + 31) / 32) {
+    case 5: return dmx3::launch_dkv_n<5>(p, s);
+    case 6: return dmx3::launch_dkv_n<6>(p, s);
+    case 7: return dmx3::launch_dkv_n<7>(p, s);
+    case 8: return dmx3::launch_dkv_n<8>(p, s);
+    default: return false;
+  }
+}
+
+// slab chunks of the dK / dV pass (first dimension of AttnX3BwdParams::slab)
+int dm_attn_x3_chunks(int B, int N, int H) {
+  int nblk, chunks, bchunk;
+  dmx3::grid(B, N, H, nblk, chunks, bchunk);
+  return chunks;
 }

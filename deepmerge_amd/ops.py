@@ -439,6 +439,27 @@ def attention_fwd_split(qkv: torch.Tensor, table: Optional[torch.Tensor], cube, 
     return out, lse, hi, lo
 
 
+def attention_bwd_split(hi, lo, table, cube, out, dout, lse, B, N, H, D, scale, index32=None, n_bins=0):
+    """Backward of attention_fwd_split.  Returns (dqkv fp32, dbias_slab or None, info) like attention_bwd."""
+    _need_cuda(hi, lo, table, out, dout, lse, index32)
+    if out.dtype != torch.float32 or dout.dtype != torch.float32 or not (out.is_contiguous() and dout.is_contiguous()):
+        raise ValueError("attention_bwd_split: out / dout must be contiguous fp32")
+    dqkv = torch.empty(hi.shape, dtype=torch.float32, device=hi.device)
+    delta = torch.empty((B, H, N), dtype=torch.float32, device=hi.device)
+    dhi = torch.empty(dout.shape, dtype=torch.bfloat16, device=hi.device)
+    dlo = torch.empty(dout.shape, dtype=torch.bfloat16, device=hi.device)
+    slab, info = None, None
+    if index32 is not None and table is not None:
+        chunks = _lib.lib().dm_attention_split_bwd_chunks(B, N, H)
+        slab = torch.empty((chunks, H, N, N), dtype=torch.float32, device=hi.device)
+        info = (chunks, N, relpos_index_csr(index32, n_bins))
+    c = (0, 0, 0) if cube is None else tuple(int(v) for v in cube)
+    check(_lib.lib().dm_attention_split_bwd(hi.data_ptr(), lo.data_ptr(), _ptr(table), c[0], c[1], c[2], out.data_ptr(), dout.data_ptr(),
+                                            dhi.data_ptr(), dlo.data_ptr(), lse.data_ptr(), dqkv.data_ptr(), delta.data_ptr(), _ptr(slab),
+                                            B, N, H, D, scale, _stream()), "dm_attention_split_bwd")
+    return dqkv, slab, info
+
+
 _CSR_CACHE = {}
 
 
@@ -821,9 +842,11 @@ class AttentionFn(torch.autograd.Function):
         cube = _inkernel_cube(table, index32, B, N, H, D, qkv.dtype)
         split, scube = _split_attention(table, index32, qkv, B, N, H, D)
         if split:                                            # "bf16x3": split-bf16 products on the matrix pipe, the table read in the kernel
-            out, lse, _hi, _lo = attention_fwd_split(qkv, None if table is None else table.contiguous(), scube, B, N, H, D, scale)
-            if table is not None:
-                bias, bias_t = relpos_bias_gather(table.contiguous(), index32, N, transposed=True)     # (the fp32 backward kernels read dense rows)
+            out, lse, hi, lo = attention_fwd_split(qkv, None if table is None else table.contiguous(), scube, B, N, H, D, scale)
+            ctx.save_for_backward(hi, lo, out, lse, index32, table)
+            ctx.dims = (B, N, H, D, scale, None if table is None else table.shape[0])
+            ctx.split_cube = (scube,)
+            return out
         elif cube is not None:                               # the kernel reads the table itself: no dense rows in the forward pass
             out, lse = attention_fwd_relpos(qkv, table.contiguous(), cube, B, N, H, D, scale)
         else:
@@ -836,8 +859,18 @@ class AttentionFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dout):
-        qkv, out, lse, bias, bias_t, index32, table = ctx.saved_tensors
         B, N, H, D, scale, n_bins = ctx.dims
+        if getattr(ctx, "split_cube", None) is not None:
+            hi, lo, out, lse, index32, table = ctx.saved_tensors
+            want_table = table is not None and ctx.needs_input_grad[1]
+            dqkv, slab, rows = attention_bwd_split(hi, lo, None if table is None else table.contiguous(), ctx.split_cube[0], out,
+                                                   dout.contiguous().float(), lse, B, N, H, D, scale, index32 if want_table else None, n_bins or 0)
+            dtable = None
+            if want_table:
+                dtable = torch.empty((n_bins, H), dtype=torch.float32, device=hi.device)
+                relpos_bias_scatter(slab, dtable, B, H, rows, n_bins)
+            return dqkv, dtable, None, None, None, None, None, None
+        qkv, out, lse, bias, bias_t, index32, table = ctx.saved_tensors
         cube = None
         if table is not None:
             table, cube = table.contiguous(), index32._dm_cube
@@ -1134,10 +1167,10 @@ class BlockFn(torch.autograd.Function):
         bias = bias_t = None
         cube = _inkernel_cube(table, index32, B, N, heads, D, dtype)
         split, scube = _split_attention(table, index32, qkv, B, N, heads, D)
+        split_imgs = None
         if split:
-            o, lse, _hi, _lo = attention_fwd_split(qkv, None if table is None else table.contiguous(), scube, B, N, heads, D, scale)
-            if table is not None:
-                bias, bias_t = relpos_bias_gather(table.contiguous(), index32, N, transposed=True)     # (the fp32 backward kernels read dense rows)
+            o, lse, hi, lo = attention_fwd_split(qkv, None if table is None else table.contiguous(), scube, B, N, heads, D, scale)
+            split_imgs = (hi, lo, scube)
         elif cube is not None:
             o, lse = attention_fwd_relpos(qkv, table.contiguous(), cube, B, N, heads, D, scale)
         else:
@@ -1160,6 +1193,7 @@ class BlockFn(torch.autograd.Function):
                               wq, wp, w1, w2, n1w, n2w)
         ctx.dims = (B, N, Cc, heads, D, Hd, scale, None if table is None else table.shape[0])
         ctx.table_in_kernel = cube is not None
+        ctx.split_imgs = split_imgs         # (two bf16 tensors of qkv's size, alive until this node's backward has run)
         ctx.params = (n1w, n1b, table, qkv_w, qkv_b, proj_w, proj_b, n2w, n2b, fc1_w, fc1_b, fc2_w, fc2_b)
         return x2.view(B, N, Cc)
 
@@ -1212,13 +1246,20 @@ class BlockFn(torch.autograd.Function):
         do = torch.empty((M, Cc), dtype=dtype, device=dev)
         gemm(DM_NN, dx1_lp, wp, do, M, Cc, Cc, lda=Cc, ldb=Cc, ldc=Cc)
         tab, cube = None, None
-        if ctx.table_in_kernel:                              # the forward kernel read the table itself; so does the dQ pass, dK / dV takes dense rows
-            tab, cube = P_table.detach().contiguous(), index32._dm_cube
-            if _DENSE_BWD_ROWS:
-                bias, bias_t = relpos_bias_gather(tab, index32, N, transposed=True)
-        want_table = bias is not None or tab is not None
-        dqkv, slab, rows = attention_bwd(qkv, bias, o, do, lse, B, N, heads, D, scale,
-                                         index32 if want_table else None, n_bins or 0, bias_t=bias_t, table=tab, cube=cube)
+        if ctx.split_imgs is not None:                       # "bf16x3": the split-bf16 backward kernels (table read in the kernel, slab included)
+            hi, lo, scube = ctx.split_imgs
+            ctx.split_imgs = None
+            want_table = P_table is not None
+            dqkv, slab, rows = attention_bwd_split(hi, lo, None if P_table is None else P_table.detach().contiguous(), scube, o.view(B, N, Cc),
+                                                   do.view(B, N, Cc), lse, B, N, heads, D, scale, index32 if want_table else None, n_bins or 0)
+        else:
+            if ctx.table_in_kernel:                          # the forward kernel read the table itself; so do both backward passes
+                tab, cube = P_table.detach().contiguous(), index32._dm_cube
+                if _DENSE_BWD_ROWS:
+                    bias, bias_t = relpos_bias_gather(tab, index32, N, transposed=True)
+            want_table = bias is not None or tab is not None
+            dqkv, slab, rows = attention_bwd(qkv, bias, o, do, lse, B, N, heads, D, scale,
+                                             index32 if want_table else None, n_bins or 0, bias_t=bias_t, table=tab, cube=cube)
         dtable, k_t = None, False
         if want_table:
             dtable, k_t = _grad_out(P_table, (n_bins, heads), dev)

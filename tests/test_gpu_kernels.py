@@ -429,7 +429,7 @@ def test_attention_relpos_table_in_kernel(scales, B, H):
 
 
 @pytest.mark.parametrize("N,scales,B,H", [(256, 4, 8, 12), (192, 3, 9, 12), (197, 0, 10, 12), (160, 0, 7, 5), (224, 0, 3, 4), (256, 0, 5, 3)])
-def test_attention_split_forward(N, scales, B, H):
+def test_attention_split_forward_backward(N, scales, B, H):
     """dm_attention_split_fwd (the bf16x3 mode's attention): fp32 tensors, every product a split-bf16 triple on the matrix pipe, the
     bias from the table in LDS (scales > 0) or none (ragged N allowed).  Against fp64: the error must be at the fp32 kernels' level
     (1e-5-ish), nowhere near bf16's 1e-2.  Reference: nets/ShfitScaleFormer.py:119-133 / vit_model.py:119-133 in fp32."""
@@ -457,6 +457,26 @@ def test_attention_split_forward(N, scales, B, H):
     assert err_o < 5e-5 and err_l < 5e-5
     o32, lse32 = ops.attention_fwd(qkv.to(DEV), None if bias64 is None else bias64.float().contiguous().to(DEV), B, N, H, D, 0.125)
     assert (out - o32).abs().max().item() < 5e-5
+    # backward: dqkv (and the table gradient through the slab) against fp64 autograd
+    dout = torch.from_numpy(rng.normal(size=(B, N, H * D)).astype(np.float32))
+    q64 = qkv.double().requires_grad_(True)
+    t64 = None if table is None else table.double().requires_grad_(True)
+    b64 = None if table is None else t64[index.reshape(-1)].reshape(N, N, H).permute(2, 0, 1)
+    o64, _ = _attn_ref(q64, b64, 0.125)
+    o64.backward(dout.double())
+    idx32 = None if table is None else index.to(torch.int32).to(DEV)
+    dqkv, slab, info = ops.attention_bwd_split(hi, lo, None if table is None else table.to(DEV), cube, out, dout.to(DEV), lse, B, N, H, D, 0.125,
+                                               idx32, 0 if table is None else n_bins)
+    g = q64.grad
+    err_g = (dqkv.cpu().double() - g).abs().max().item() / g.abs().max().item()
+    print(f"split-bf16 attention backward N={N}: max |dqkv - fp64| / max |dqkv| = {err_g:.2e}")
+    assert err_g < 2e-5
+    if table is not None:
+        dt = torch.empty((n_bins, H), device=DEV)
+        ops.relpos_bias_scatter(slab, dt, B, H, info, n_bins)
+        err_t = (dt.cpu().double() - t64.grad).abs().max().item() / t64.grad.abs().max().item()
+        print(f"   table gradient: max error / max = {err_t:.2e}")
+        assert err_t < 2e-5
 
 
 @pytest.mark.parametrize("mode", ["fp32", "bf16"])

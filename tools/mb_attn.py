@@ -41,6 +41,14 @@ if os.environ.get("X3") == "1":
     if ops.attention_split_ok(B, N, H, D, cube3) and (bias is None or cube3 is not None):
         t = timeit(lambda: ops.attention_fwd_split(q32, tab3, cube3, B, N, H, D, 0.125))
         print(f"fwd split-bf16 kernels B={B} N={N}: {t*1e6:7.1f} us  {3*4.0*B*H*N*N*D/t/1e12:6.1f} TFLOP/s (3 MFMAs per product, incl. the split pass)")
+        o3, l3, hi3, lo3 = ops.attention_fwd_split(q32, tab3, cube3, B, N, H, D, 0.125)
+        do3 = torch.randn_like(o3)
+        idx3 = None if cube3 is None else torch.randint(0, tab3.shape[0], (N, N), device=dev, dtype=torch.int32)
+        b32 = None if bias is None else bias
+        t = timeit(lambda: ops.attention_bwd(q32, b32, o3, do3, l3, B, N, H, D, 0.125, idx3, 0 if tab3 is None else tab3.shape[0]), n=10)
+        print(f"bwd fp32 kernels B={B} N={N}: {t*1e6:7.1f} us")
+        t = timeit(lambda: ops.attention_bwd_split(hi3, lo3, tab3, cube3, o3, do3, l3, B, N, H, D, 0.125, idx3, 0 if tab3 is None else tab3.shape[0]), n=10)
+        print(f"bwd split-bf16 kernels B={B} N={N}: {t*1e6:7.1f} us  {3*10.0*B*H*N*N*D/t/1e12:6.1f} TFLOP/s (incl. the dout split pass)")
 if os.environ.get("FWD_ONLY") == "1":
     sys.exit(0)
 out, lse = ops.attention_fwd(qkv, bias, B, N, H, D, 0.125)
