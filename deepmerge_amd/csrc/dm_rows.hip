@@ -363,6 +363,30 @@ __global__ void split_bf16_kernel(const float *__restrict__ src, long long ld, l
     for (int j = 0; j < 3; ++j) *reinterpret_cast<bf16x4 *>(d + j * piece) = ((pattern >> j) & 1) ? lo : hi;
   }
 }
+// The same for cols % 8 == 0 (every operand of the model): 8 columns per thread (two 16-byte loads, three 16-byte stores), threads
+// (32 x 8) = 256 columns x 8 rows per block, rows walked by blockIdx.y -- no 64-bit division per element, whole 128-byte lines.
+__global__ __launch_bounds__(256) void split_bf16_rows_kernel(const float *__restrict__ src, long long ld, int rows, int cols,
+                                                              bf16_t *__restrict__ dst, int stack, int pattern) {
+  const int c = (blockIdx.x * 32 + threadIdx.x) * 8;
+  if (c >= cols) return;
+  const long long piece = stack ? (long long)rows * cols : cols, ldd = stack ? cols : 3LL * cols;
+  for (int r = blockIdx.y * 8 + threadIdx.y; r < rows; r += gridDim.y * 8) {
+    const float *sp = src + (long long)r * ld + c;
+    const f32x4 x0 = dm_load4(sp), x1 = dm_load4(sp + 4);
+    u32x4 hi, lo;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float a = j < 2 ? x0[2 * j] : x1[2 * j - 4], b = j < 2 ? x0[2 * j + 1] : x1[2 * j - 3];
+      const bf16x2 h2 = {(bf16_t)a, (bf16_t)b};
+      const bf16x2 l2 = {(bf16_t)(a - (float)h2[0]), (bf16_t)(b - (float)h2[1])};
+      hi[j] = __builtin_bit_cast(unsigned, h2);
+      lo[j] = __builtin_bit_cast(unsigned, l2);
+    }
+    bf16_t *d = dst + (long long)r * ldd + c;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) *reinterpret_cast<u32x4 *>(d + j * piece) = ((pattern >> j) & 1) ? lo : hi;
+  }
+}
 __global__ void copy_f32_kernel(const float *__restrict__ src, float *__restrict__ dst, long long n) {
   const long long n4 = n >> 2;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x)
@@ -736,8 +760,18 @@ extern "C" int dm_split_bf16(const float *src, int64_t ld, int64_t rows, int64_t
              "dm_split_bf16: rows=%lld cols=%lld ld=%lld (cols and ld must be multiples of 4)", (long long)rows, (long long)cols, (long long)ld);
   DM_REQUIRE(pattern >= 0 && pattern < 8, DM_ERR_BAD_SHAPE, "dm_split_bf16: pattern %d", pattern);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  hipLaunchKernelGGL(split_bf16_kernel, dim3(grid_for(rows * (cols / 4))), dim3(256), 0, s, src, (long long)ld, (long long)rows,
-                     (long long)cols, (bf16_t *)dst, stack ? 1 : 0, pattern);
+  if (cols % 8 == 0 && rows < (1LL << 31) && cols < (1LL << 31) && dm_aligned16(src) && dm_aligned16(dst) && ld % 4 == 0 &&
+      (stack ? (rows * cols) % 8 == 0 : true)) {
+    const int gx = (int)((cols / 8 + 31) / 32);
+    long long gy = (rows + 7) / 8;
+    const long long cap = 8192 / gx > 0 ? 8192 / gx : 1;       // ~32 blocks per CU in flight at most; rows beyond are walked
+    if (gy > cap) gy = cap;
+    hipLaunchKernelGGL(split_bf16_rows_kernel, dim3(gx, (unsigned)gy), dim3(32, 8), 0, s, src, (long long)ld, (int)rows, (int)cols, (bf16_t *)dst,
+                       stack ? 1 : 0, pattern);
+  } else {
+    hipLaunchKernelGGL(split_bf16_kernel, dim3(grid_for(rows * (cols / 4))), dim3(256), 0, s, src, (long long)ld, (long long)rows,
+                       (long long)cols, (bf16_t *)dst, stack ? 1 : 0, pattern);
+  }
   DM_LAUNCH_CHECK("dm_split_bf16");
   return DM_OK;
 }

@@ -861,12 +861,13 @@ def test_attention_generic_shapes(mode, B, N, H, D, with_bias):
 
 
 # ---- split-bf16 ("bf16x3") products ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("rows,cols,ld", [(37, 24, 32), (37, 20, 32), (300, 768, 772), (9, 264, 264), (70000, 64, 64)])
 @pytest.mark.parametrize("stack,pattern", [(0, 0b100), (0, 0b010), (1, 0b100), (1, 0b010)])
-def test_split_bf16_images(stack, pattern):
-    """dm_split_bf16: hi = bf16(x), lo = bf16(x - hi), three pieces side by side (stack 0) or one under the other (stack 1)."""
+def test_split_bf16_images(stack, pattern, rows, cols, ld):
+    """dm_split_bf16: hi = bf16(x), lo = bf16(x - hi), three pieces side by side (stack 0) or one under the other (stack 1).  Shapes
+    with cols % 8 == 0 take the 8-columns-per-thread kernel (rows walked by the grid's second dimension), the others the generic one."""
     from deepmerge_amd import _lib
     torch.manual_seed(3)
-    rows, cols, ld = 37, 24, 32
     src = (torch.randn(rows, ld, device=DEV) * torch.logspace(-3, 3, ld, device=DEV)).contiguous()
     dst = torch.full((3 * rows * cols,), float("nan"), dtype=torch.bfloat16, device=DEV)
     rc = _lib.lib().dm_split_bf16(src.data_ptr(), ld, rows, cols, dst.data_ptr(), stack, pattern, torch.cuda.current_stream().cuda_stream)
