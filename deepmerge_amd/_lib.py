@@ -88,6 +88,8 @@ SIGNATURES = {
     "dm_colsum_partial_floats": (_L, [_I]),
     "dm_cast": (_I, [_P, _P, _I, _L, _P]),
     "dm_split_bf16": (_I, [_P, _L, _L, _L, _P, _I, _I, _P]),
+    "dm_split_colsum_partial_floats": (_L, [_L, _L]),
+    "dm_split_bf16_colsum": (_I, [_P, _L, _L, _L, _P, _I, _I, _P, _P, _P]),
     "dm_patchify": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "dm_contrastive_loss": (_I, [_P, _P, _P, _F, _F, _P, _P, _P, _I, _I, _P]),
     "dm_cross_entropy": (_I, [_P, _P, _P, _F, _P, _P, _I, _I, _P]),

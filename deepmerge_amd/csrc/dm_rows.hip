@@ -365,14 +365,24 @@ __global__ void split_bf16_kernel(const float *__restrict__ src, long long ld, l
 }
 // The same for cols % 8 == 0 (every operand of the model): 8 columns per thread (two 16-byte loads, three 16-byte stores), threads
 // (32 x 8) = 256 columns x 8 rows per block, rows walked by blockIdx.y -- no 64-bit division per element, whole 128-byte lines.
+// CS: also leave this block's column sums of the fp32 source in partial[blockIdx.y][cols] (the bias gradient that goes with a
+// weight gradient: the operand is read once for both); rows in a fixed order per thread, the block's 8 row-threads in a fixed tree.
+template <bool CS>
 __global__ __launch_bounds__(256) void split_bf16_rows_kernel(const float *__restrict__ src, long long ld, int rows, int cols,
-                                                              bf16_t *__restrict__ dst, int stack, int pattern) {
+                                                              bf16_t *__restrict__ dst, int stack, int pattern, float *__restrict__ partial) {
+  __shared__ float red[CS ? 8 : 1][CS ? 264 : 1];
   const int c = (blockIdx.x * 32 + threadIdx.x) * 8;
-  if (c >= cols) return;
+  const bool live = c < cols;
+  if (!CS && !live) return;
   const long long piece = stack ? (long long)rows * cols : cols, ldd = stack ? cols : 3LL * cols;
-  for (int r = blockIdx.y * 8 + threadIdx.y; r < rows; r += gridDim.y * 8) {
+  float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int r = blockIdx.y * 8 + threadIdx.y; live && r < rows; r += gridDim.y * 8) {
     const float *sp = src + (long long)r * ld + c;
     const f32x4 x0 = dm_load4(sp), x1 = dm_load4(sp + 4);
+    if constexpr (CS) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { cs[j] += x0[j]; cs[4 + j] += x1[j]; }
+    }
     u32x4 hi, lo;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -385,6 +395,18 @@ __global__ __launch_bounds__(256) void split_bf16_rows_kernel(const float *__res
     bf16_t *d = dst + (long long)r * ldd + c;
 #pragma unroll
     for (int j = 0; j < 3; ++j) *reinterpret_cast<u32x4 *>(d + j * piece) = ((pattern >> j) & 1) ? lo : hi;
+  }
+  if constexpr (CS) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) red[threadIdx.y][threadIdx.x * 8 + j] = cs[j];
+    __syncthreads();
+    if (threadIdx.y == 0 && live) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int x = threadIdx.x * 8 + j;
+        partial[(long long)blockIdx.y * cols + c + j] = ((red[0][x] + red[1][x]) + (red[2][x] + red[3][x])) + ((red[4][x] + red[5][x]) + (red[6][x] + red[7][x]));
+      }
+    }
   }
 }
 __global__ void copy_f32_kernel(const float *__restrict__ src, float *__restrict__ dst, long long n) {
@@ -754,20 +776,50 @@ extern "C" int dm_cast(const float *src, void *dst, int32_t dst_dtype, int64_t n
   return DM_OK;
 }
 
+static bool split_rows_ok(const float *src, int64_t ld, int64_t rows, int64_t cols, const void *dst, int32_t stack) {
+  return cols % 8 == 0 && rows < (1LL << 31) && cols < (1LL << 31) && dm_aligned16(src) && dm_aligned16(dst) && ld % 4 == 0 &&
+         (stack ? (rows * cols) % 8 == 0 : true);
+}
+static void split_rows_grid(int64_t rows, int64_t cols, int &gx, int &gy) {
+  gx = (int)((cols / 8 + 31) / 32);
+  long long y = (rows + 7) / 8;
+  const long long cap = 8192 / gx > 0 ? 8192 / gx : 1;       // ~32 blocks per CU in flight at most; rows beyond are walked
+  gy = (int)(y > cap ? cap : y);
+}
+
+extern "C" int64_t dm_split_colsum_partial_floats(int64_t rows, int64_t cols) {
+  if (rows <= 0 || cols <= 0 || cols % 8) return 0;
+  int gx, gy;
+  split_rows_grid(rows, cols, gx, gy);
+  return (int64_t)gy * cols;
+}
+
+extern "C" int dm_split_bf16_colsum(const float *src, int64_t ld, int64_t rows, int64_t cols, void *dst, int32_t stack, int32_t pattern,
+                                    float *partial, int32_t *n_partial, void *stream) {
+  DM_REQUIRE(src && dst && partial && n_partial && rows > 0 && cols > 0 && ld >= cols && pattern >= 0 && pattern < 8, DM_ERR_BAD_SHAPE,
+             "dm_split_bf16_colsum: bad arguments (rows=%lld cols=%lld ld=%lld)", (long long)rows, (long long)cols, (long long)ld);
+  DM_REQUIRE(split_rows_ok(src, ld, rows, cols, dst, stack), DM_ERR_UNSUPPORTED,
+             "dm_split_bf16_colsum: needs cols %% 8 == 0, ld %% 4 == 0 and 16-byte aligned tensors (cols=%lld ld=%lld)", (long long)cols, (long long)ld);
+  int gx, gy;
+  split_rows_grid(rows, cols, gx, gy);
+  hipLaunchKernelGGL(split_bf16_rows_kernel<true>, dim3(gx, (unsigned)gy), dim3(32, 8), 0, reinterpret_cast<hipStream_t>(stream), src, (long long)ld,
+                     (int)rows, (int)cols, (bf16_t *)dst, stack ? 1 : 0, pattern, partial);
+  DM_LAUNCH_CHECK("dm_split_bf16_colsum");
+  *n_partial = gy;
+  return DM_OK;
+}
+
 extern "C" int dm_split_bf16(const float *src, int64_t ld, int64_t rows, int64_t cols, void *dst, int32_t stack, int32_t pattern,
                              void *stream) {
   DM_REQUIRE(src && dst && rows > 0 && cols > 0 && cols % 4 == 0 && ld >= cols && ld % 4 == 0, DM_ERR_BAD_SHAPE,
              "dm_split_bf16: rows=%lld cols=%lld ld=%lld (cols and ld must be multiples of 4)", (long long)rows, (long long)cols, (long long)ld);
   DM_REQUIRE(pattern >= 0 && pattern < 8, DM_ERR_BAD_SHAPE, "dm_split_bf16: pattern %d", pattern);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  if (cols % 8 == 0 && rows < (1LL << 31) && cols < (1LL << 31) && dm_aligned16(src) && dm_aligned16(dst) && ld % 4 == 0 &&
-      (stack ? (rows * cols) % 8 == 0 : true)) {
-    const int gx = (int)((cols / 8 + 31) / 32);
-    long long gy = (rows + 7) / 8;
-    const long long cap = 8192 / gx > 0 ? 8192 / gx : 1;       // ~32 blocks per CU in flight at most; rows beyond are walked
-    if (gy > cap) gy = cap;
-    hipLaunchKernelGGL(split_bf16_rows_kernel, dim3(gx, (unsigned)gy), dim3(32, 8), 0, s, src, (long long)ld, (int)rows, (int)cols, (bf16_t *)dst,
-                       stack ? 1 : 0, pattern);
+  if (split_rows_ok(src, ld, rows, cols, dst, stack)) {
+    int gx, gy;
+    split_rows_grid(rows, cols, gx, gy);
+    hipLaunchKernelGGL(split_bf16_rows_kernel<false>, dim3(gx, (unsigned)gy), dim3(32, 8), 0, s, src, (long long)ld, (int)rows, (int)cols,
+                       (bf16_t *)dst, stack ? 1 : 0, pattern, (float *)nullptr);
   } else {
     hipLaunchKernelGGL(split_bf16_kernel, dim3(grid_for(rows * (cols / 4))), dim3(256), 0, s, src, (long long)ld, (long long)rows,
                        (long long)cols, (bf16_t *)dst, stack ? 1 : 0, pattern);

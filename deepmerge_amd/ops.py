@@ -202,10 +202,21 @@ def gemm(layout: int, A: torch.Tensor, B: torch.Tensor, C_out: torch.Tensor, M: 
         a_stack, b_stack = int(layout == DM_TN), int(layout != DM_NT)
         A3 = workspace(6 * a_rows * a_cols, A.device, ws_slot + ".split_a").view(torch.bfloat16)    # per slot: the side stream
         B3 = workspace(6 * b_rows * b_cols, A.device, ws_slot + ".split_b").view(torch.bfloat16)    # has its own images
-        check(_lib.lib().dm_split_bf16(A.data_ptr(), lda, a_rows, a_cols, A3.data_ptr(), a_stack, 0b100, _stream()), "dm_split_bf16")
+        n_part = _lib.lib().dm_split_colsum_partial_floats(a_rows, a_cols) if (colsum_out is not None and a_cols % 8 == 0) else 0
+        if n_part > 0:                       # the bias gradient rides on the operand's split pass: A is read once for both
+            part = workspace(4 * n_part, A.device, ws_slot + ".partial").view(torch.float32)
+            rows_out = C.c_int32(0)
+            check(_lib.lib().dm_split_bf16_colsum(A.data_ptr(), lda, a_rows, a_cols, A3.data_ptr(), a_stack, 0b100, part.data_ptr(),
+                                                  C.byref(rows_out), _stream()), "dm_split_bf16_colsum")
+            item = (_lib.DmReduceItem * 1)()
+            item[0].partial, item[0].out0, item[0].out1 = part.data_ptr(), colsum_out.data_ptr(), colsum_out.data_ptr()
+            item[0].nrows, item[0].width, item[0].split, item[0].accumulate = rows_out.value, a_cols, a_cols, int(bool(colsum_accumulate))
+            check(_lib.lib().dm_partial_reduce_batch(item, 1, _stream()), "dm_partial_reduce_batch")
+        else:
+            check(_lib.lib().dm_split_bf16(A.data_ptr(), lda, a_rows, a_cols, A3.data_ptr(), a_stack, 0b100, _stream()), "dm_split_bf16")
+            if colsum_out is not None:       # column sums of the fp32 operand itself (the stacked image would count hi twice)
+                colsum(torch.as_strided(A, (a_rows, a_cols), (lda, 1)), colsum_out, accumulate=colsum_accumulate, ws_slot=ws_slot + ".partial")
         check(_lib.lib().dm_split_bf16(B.data_ptr(), ldb, b_rows, b_cols, B3.data_ptr(), b_stack, 0b010, _stream()), "dm_split_bf16")
-        if colsum_out is not None:           # column sums of the fp32 operand itself (the stacked image would count hi twice)
-            colsum(torch.as_strided(A, (a_rows, a_cols), (lda, 1)), colsum_out, accumulate=colsum_accumulate, ws_slot=ws_slot + ".partial")
         return gemm(layout, A3, B3, C_out, M, N, 3 * K, lda=(a_cols if a_stack else 3 * a_cols), ldb=(b_cols if b_stack else 3 * b_cols),
                     ldc=ldc, bias=bias, residual=residual, ldr=ldr, epilogue=epilogue, aux=aux, ldaux=ldaux, accumulate=accumulate,
                     split_k=split_k, rows_per_group=rows_per_group, group_stride=group_stride, ws_slot=ws_slot)

@@ -237,6 +237,13 @@ int dm_cast(const float *src, void *dst, int32_t dst_dtype, int64_t n, void *str
  * pattern bit j set = piece j is the lo part: 0b100 for the left operand (hi, hi, lo), 0b010 for the right (hi, lo, hi).
  * cols % 4 == 0. */
 int dm_split_bf16(const float *src, int64_t ld, int64_t rows, int64_t cols, void *dst, int32_t stack, int32_t pattern, void *stream);
+/* The same with the column sums of src on the side (the bias gradient db = colsum(dy) that goes with dW = dy^T x,
+ * nets/ShfitScaleFormer.py:58-66 under autograd: dy is read once for its split image and its sums): partial receives
+ * *n_partial rows of `cols` floats (dm_split_colsum_partial_floats(rows, cols) floats at most), to be summed in row order --
+ * e.g. by dm_partial_reduce_batch.  cols % 8 == 0, ld % 4 == 0, 16-byte aligned tensors (DM_ERR_UNSUPPORTED otherwise). */
+int64_t dm_split_colsum_partial_floats(int64_t rows, int64_t cols);
+int dm_split_bf16_colsum(const float *src, int64_t ld, int64_t rows, int64_t cols, void *dst, int32_t stack, int32_t pattern,
+                         float *partial, int32_t *n_partial, void *stream);
 
 /* Patch extraction for the k=stride Conv2d of PatchEmbed (nets/ShfitScaleFormer.py:25, :35):
  * x [B, C, side, side] fp32 -> cols [B*(side/p)^2, C*p*p] T, column order (c, dy, dx) = the

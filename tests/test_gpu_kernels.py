@@ -885,6 +885,37 @@ def test_split_bf16_images(stack, pattern, rows, cols, ld):
     assert _lib.lib().dm_split_bf16(src.data_ptr(), ld, rows, 22, dst.data_ptr(), stack, pattern, None) != 0     # cols % 4
 
 
+@pytest.mark.parametrize("rows,cols,ld,stack", [(300, 768, 772, 1), (16384, 3072, 3072, 1), (37, 24, 32, 0), (70000, 64, 64, 1)])
+def test_split_bf16_with_column_sums(rows, cols, ld, stack):
+    """dm_split_bf16_colsum: the split image of dm_split_bf16, bit for bit, plus partial column sums of the fp32 source whose
+    row-ordered reduction (dm_partial_reduce_batch) equals the float64 column sums to fp32 accuracy -- run-to-run identical."""
+    import ctypes as C
+    from deepmerge_amd import _lib
+    lib = _lib.lib()
+    torch.manual_seed(5)
+    src = torch.randn(rows, ld, device=DEV)
+    st = torch.cuda.current_stream().cuda_stream
+    want = torch.empty(3 * rows * cols, dtype=torch.bfloat16, device=DEV)
+    assert lib.dm_split_bf16(src.data_ptr(), ld, rows, cols, want.data_ptr(), stack, 0b100, st) == 0
+    outs = []
+    for _ in range(2):
+        dst = torch.empty_like(want)
+        part = torch.empty(lib.dm_split_colsum_partial_floats(rows, cols), device=DEV)
+        n = C.c_int32(0)
+        assert lib.dm_split_bf16_colsum(src.data_ptr(), ld, rows, cols, dst.data_ptr(), stack, 0b100, part.data_ptr(), C.byref(n), st) == 0
+        assert 0 < n.value * cols <= part.numel() and torch.equal(dst, want)
+        out = torch.full((cols,), 3.0, device=DEV)
+        item = (_lib.DmReduceItem * 1)()
+        item[0].partial, item[0].out0, item[0].out1 = part.data_ptr(), out.data_ptr(), out.data_ptr()
+        item[0].nrows, item[0].width, item[0].split, item[0].accumulate = n.value, cols, cols, 1
+        assert lib.dm_partial_reduce_batch(item, 1, st) == 0
+        outs.append(out)
+    ref = src[:, :cols].double().sum(0) + 3.0
+    assert (outs[0].double() - ref).abs().max().item() < 1e-4 * max(1.0, rows ** 0.5)
+    assert torch.equal(outs[0], outs[1])
+    assert lib.dm_split_bf16_colsum(src.data_ptr(), ld, rows, 20, want.data_ptr(), stack, 0b100, outs[0].data_ptr(), C.byref(n), st) != 0     # cols % 8
+
+
 @pytest.mark.parametrize("layout", ["NT", "NN", "TN"])
 def test_split_bf16_gemm_against_float64(layout):
     """ops.gemm under fp32_products("bf16x3"): every layout, with bias / GELU / residual epilogues and the fused column sums,
