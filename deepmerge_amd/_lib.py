@@ -148,8 +148,8 @@ def lib() -> C.CDLL:
                 raise DeepMergeLibraryError(f"{LIB_PATH} does not export {name}") from e
             fn.restype = res
             fn.argtypes = args
-        if handle.dm_abi_version() != 2:
-            raise DeepMergeLibraryError(f"ABI version mismatch: library {handle.dm_abi_version()} != 2")
+        if handle.dm_abi_version() != 3:
+            raise DeepMergeLibraryError(f"ABI version mismatch: library {handle.dm_abi_version()} != 3")
         _lib = handle
         return _lib
 

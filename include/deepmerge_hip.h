@@ -40,7 +40,7 @@ typedef enum {
 } DmStatus;
 
 /* ---- library ------------------------------------------------------------------------- */
-int dm_abi_version(void);   /* 2: dm_patch_pyramid / dm_patch_pyramid_cols take a resize rule (round 3) */
+int dm_abi_version(void);   /* 2: dm_patch_pyramid / dm_patch_pyramid_cols take a resize rule; 3: table-reading and split-bf16 attention entry points, dm_split_bf16_colsum (round 3) */
 const char *dm_last_error(void);
 /* Name of the code object architecture the library was built for ("gfx950"). */
 const char *dm_arch(void);
