@@ -43,6 +43,20 @@ def shard_slice(global_batch: int, rank: int, world: int) -> slice:
     return slice(rank * per, (rank + 1) * per)
 
 
+_SINK_VIOLATION = ("first-write gradient sink violated: a parameter of a fused block received a gradient outside the block kernels (its "
+                   ".grad was replaced, or autograd accumulated into it); build the trainer with first_write=False for models that use "
+                   "these parameters elsewhere")
+
+
+def _sink_guard(param):
+    """Gradient hook of a tracked parameter: the fused blocks return None for it (they wrote the sink themselves), and autograd then
+    calls the hook with None; a real tensor here is a gradient from somewhere else on its way into the un-zeroed buffer."""
+    def hook(g):
+        if g is not None:
+            raise RuntimeError(f"{_SINK_VIOLATION} [parameter {getattr(param, '_dm_name', '?')} {tuple(param.shape)}]")
+    return hook
+
+
 class FlatParams:
     """Re-homes a module's parameters and gradients into flat fp32 buffers (views keep autograd working)."""
 
@@ -89,6 +103,11 @@ class FlatParams:
                 if id(p) in ids:
                     p._dm_gw = [False]
                     self.tracked.append((p, o, p.numel()))
+                    if getattr(p, "_dm_sink_guard", None) is None:      # the fused blocks never hand these gradients to autograd
+                        p._dm_sink_guard = p.register_hook(_sink_guard(p))
+            names = {id(q): n for n, q in module.named_parameters()}
+            for p, _, _ in self.tracked:
+                p._dm_name = names.get(id(p), "?")
         # what zero_grad() still has to clear: the maximal runs of untracked parameters (alignment gaps included)
         self._zero_ranges, tr = [], {o for _, o, _ in self.tracked}
         run = None
@@ -126,7 +145,16 @@ class FlatParams:
         hi = self.total if hi is None else hi
         n = 0
         for p, o, cnt in self.tracked:
-            if lo <= o < hi and not p._dm_gw[0]:
+            if not lo <= o < hi:
+                continue
+            # The first-write contract: a tracked parameter's gradient is written by the fused-block kernels only, through the raw
+            # pointer of its sink view (they store on the first write of a step).  A gradient that arrives through autograd's own
+            # accumulation instead would be added to last step's values: the gradient hook registered in __init__ refuses
+            # that; here the other way out of the contract is caught, a .grad that is no longer the sink view.
+            g = p.grad
+            if g is None or g.data_ptr() != self.grad.data_ptr() + 4 * o:
+                raise RuntimeError(_SINK_VIOLATION)
+            if not p._dm_gw[0]:
                 self.grad[o:o + cnt].zero_()
                 p._dm_gw[0] = True
                 n += 1

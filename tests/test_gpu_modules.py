@@ -467,6 +467,36 @@ def test_graph_survives_workspace_growth():
     del junk
 
 
+def test_first_write_sink_contract_is_enforced():
+    """A parameter of a fused block that receives a gradient through plain autograd (used outside its block) would be added to last
+    step's values under the first-write sinks: the trainer refuses instead; first_write=False accepts the same model."""
+    from deepmerge_amd.trainer import PairTrainer
+    tag = "v3_3s3c_642"
+    cfg = MODEL_CASES[tag]
+    left, ld, right, rd, flag = model_inputs(tag, cfg.scales, cfg.in_c, 4)
+    b = ([t.to(DEV) for t in left], ld.to(DEV), [t.to(DEV) for t in right], rd.to(DEV), flag.to(DEV))
+
+    class Leaky(torch.nn.Module):
+        numerics = "bf16"
+
+        def __init__(self, net):
+            super().__init__(); self.net = net
+        def forward(self, *a):
+            fa, fb = self.net(*a)
+            extra = self.net.blocks0[0].norm1.weight.sum() * 1e-3          # a fused block's parameter used outside the block
+            return fa + extra, fb
+    for first_write in (True, False):
+        net = build_model(tag, "bf16")[1].train()
+        tr = PairTrainer(Leaky(net), lr=1e-4, first_write=first_write)
+        if first_write:
+            assert tr.fp.tracked
+            with pytest.raises(RuntimeError, match="first-write gradient sink violated"):
+                tr.step(*b)
+        else:
+            assert not tr.fp.tracked
+            assert torch.isfinite(tr.step(*b))
+
+
 def test_segmented_graphs_equal_plain_step():
     """The data-parallel schedule on one process: backward in segments, one hipGraph per segment + one for Adam, buckets derived
     from the cuts -- weights after 4 steps are bit-identical to the single-graph and to the eager step."""
