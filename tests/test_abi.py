@@ -188,3 +188,43 @@ def test_numerics_scope_belongs_to_the_module(built_lib):
     bwd(c, 0)
     bwd(Ctx(), 0)
     assert got == ["bf16x3", "mfma_f32"] and ops.get_fp32_products() == "mfma_f32"
+
+
+def test_attention_routing_decisions_need_no_gpu(built_lib):
+    """Which shapes the table-reading (bf16) and split-bf16 (bf16x3) attention entry points take is host logic; the refusals are
+    reported before any launch (reference shapes: nets/ShfitScaleFormer.py:84-156 cubes (S, 8, 8), vit_model.py N = 197)."""
+    lib = built_lib.lib()
+    BF16, F32 = built_lib.DM_BF16, built_lib.DM_F32
+    assert lib.dm_attention_relpos_inkernel(64, 256, 12, 64, 4, 8, 8, BF16) == 1
+    assert lib.dm_attention_relpos_inkernel(64, 192, 12, 64, 3, 8, 8, BF16) == 1
+    assert lib.dm_attention_relpos_inkernel(64, 256, 12, 64, 4, 8, 8, F32) == 0          # fp32 tensors: the split entry points
+    assert lib.dm_attention_relpos_inkernel(64, 256, 12, 64, 4, 4, 16, BF16) == 0        # not an (S, 8, 8) cube
+    assert lib.dm_attention_relpos_inkernel(64, 192, 12, 64, 4, 8, 8, BF16) == 0         # N != 64 S
+    assert lib.dm_attention_relpos_inkernel(64, 128, 12, 64, 2, 8, 8, BF16) == 0         # two scales: N = 128 stays on the 16-row kernels
+    assert lib.dm_attention_relpos_inkernel(2, 256, 12, 64, 4, 8, 8, BF16) == 0          # too little work for persistent workgroups
+    assert lib.dm_attention_relpos_inkernel(64, 256, 12, 80, 4, 8, 8, BF16) == 0         # head dim
+    assert lib.dm_attention_fwd_relpos(None, None, 4, 4, 16, None, None, 64, 256, 12, 64, 0.125, BF16, None) == -6
+    assert b"shape not taken" in lib.dm_last_error()
+    assert lib.dm_attention_fwd_relpos(None, None, 4, 8, 8, None, None, 64, 256, 12, 64, 0.125, BF16, None) == -1
+    assert b"null pointer" in lib.dm_last_error()
+    assert lib.dm_attention_split_ok(64, 256, 12, 64, 1, 4, 8, 8) == 1 and lib.dm_attention_split_ok(256, 197, 12, 64, 0, 0, 0, 0) == 1
+    assert lib.dm_attention_split_ok(2, 256, 12, 64, 1, 4, 8, 8) == 1                    # (no persistent chunks: any batch)
+    assert lib.dm_attention_split_ok(64, 193, 12, 64, 1, 3, 8, 8) == 0                   # v5's extra token: N != 64 S
+    assert lib.dm_attention_split_ok(64, 64, 12, 64, 0, 0, 0, 0) == 0 and lib.dm_attention_split_ok(64, 257, 12, 64, 0, 0, 0, 0) == 0
+    assert lib.dm_attention_split_bwd_chunks(64, 256, 12) == 10 and lib.dm_attention_split_bwd_chunks(3, 197, 12) == 3
+    assert lib.dm_attention_split_fwd(None, None, None, None, 0, 0, 0, None, None, 64, 64, 12, 64, 0.125, None) == -6
+    assert lib.dm_split_colsum_partial_floats(16384, 3072) > 0 and lib.dm_split_colsum_partial_floats(16384, 20) == 0
+
+
+def test_relative_position_index_is_vouched_for_only_when_it_is_the_closed_form():
+    """`CrossScaleAttention._index32()` tags the int32 index with its cube -- the licence for the kernels to form the bias from the table
+    themselves -- only when the buffer equals the closed form of reference :139-156; a tampered buffer and v5's extended index get none."""
+    import torch
+    from deepmerge_amd.nets import ShfitScaleFormer as S
+    a = S.CrossScaleAttention(dim=768, num_heads=12, cube_size=[4, 8, 8], qkv_bias=True)
+    assert getattr(a._index32(), "_dm_cube", None) == (4, 8, 8)
+    with torch.no_grad():
+        a.relative_position_index[3, 5] += 1
+    assert getattr(a._index32(), "_dm_cube", None) is None
+    b = S.CrossScaleAttention_v5(dim=768, num_heads=12, cube_size=[3, 8, 8], qkv_bias=True)
+    assert b._index32().shape == (193, 193) and getattr(b._index32(), "_dm_cube", None) is None
