@@ -290,6 +290,7 @@ def layernorm_fwd(x: torch.Tensor, gamma, beta, eps: float, out_dtype: torch.dty
 _pending_reduce = []        # (DmReduceItem field tuple, tensors kept alive until the launch)
 _pending_out = set()
 _flush_queued = False
+_flush_task = -1            # autograd graph task the queue belongs to (a backward pass that raised leaves its queue behind: dropped on sight)
 
 
 def _in_backward() -> bool:
@@ -315,7 +316,13 @@ def flush_reductions() -> None:
 
 
 def _queue_reduce(part, out0, out1, nrows, width, split, accumulate) -> None:
-    global _flush_queued
+    global _flush_queued, _flush_task
+    task = torch._C._current_graph_task_id()
+    if task != _flush_task:                                   # leftovers of a backward pass that never reached its callback
+        _pending_reduce.clear()
+        _pending_out.clear()
+        _flush_queued = False
+        _flush_task = task
     keys = (out0.data_ptr(), out1.data_ptr())
     if keys[0] in _pending_out or keys[1] in _pending_out:      # a second contribution to the same parameter (a shared norm): keep the order
         flush_reductions()
@@ -471,16 +478,15 @@ def attention_bwd_split(hi, lo, table, cube, out, dout, lse, B, N, H, D, scale, 
     return dqkv, slab, info
 
 
-_CSR_CACHE = {}
-
-
 def relpos_index_csr(index32: torch.Tensor, n_bins: int):
     """CSR inverse of a relative_position_index: (positions int32 [<= N*N], offsets int32 [n_bins+1]) with
     positions[offsets[b]:offsets[b+1]] = the flat entries i*N+j whose index is b, ascending.  Entries outside
-    [0, n_bins) are dropped.  Cached per index tensor (the index is a fixed buffer of the module)."""
-    key = (index32.data_ptr(), index32._version, n_bins, index32.device)
-    hit = _CSR_CACHE.get(key)
-    if hit is None:
+    [0, n_bins) are dropped.  Cached ON the index tensor (the int32 copy of the module's buffer lives as long as the module; a
+    process-wide cache with eviction could drop an entry between a trainer's warm-up steps and its graph capture, and the
+    rebuild below synchronises -- illegal while a stream is capturing)."""
+    key = (index32._version, n_bins)
+    hit = getattr(index32, "_dm_csr", None)
+    if hit is None or hit[0] != key:
         flat = index32.reshape(-1).to(torch.int64)
         ok = (flat >= 0) & (flat < n_bins)
         where = torch.nonzero(ok).reshape(-1)
@@ -489,10 +495,8 @@ def relpos_index_csr(index32: torch.Tensor, n_bins: int):
         counts = torch.bincount(flat[where], minlength=n_bins)
         offsets = torch.zeros(n_bins + 1, dtype=torch.int64, device=index32.device)
         offsets[1:] = torch.cumsum(counts, 0)
-        if len(_CSR_CACHE) > 256:
-            _CSR_CACHE.clear()
-        hit = _CSR_CACHE[key] = (positions, offsets.to(torch.int32).contiguous(), index32)   # keep the index alive: its address is the key
-    return hit[0], hit[1]
+        hit = index32._dm_csr = (key, positions, offsets.to(torch.int32).contiguous())
+    return hit[1], hit[2]
 
 
 def attention_bwd(qkv, bias, out, dout, lse, B, N, H, D, scale, index32=None, n_bins=0, bias_t=None, table=None, cube=None):

@@ -48,15 +48,6 @@ _SINK_VIOLATION = ("first-write gradient sink violated: a parameter of a fused b
                    "these parameters elsewhere")
 
 
-def _sink_guard(param):
-    """Gradient hook of a tracked parameter: the fused blocks return None for it (they wrote the sink themselves), and autograd then
-    calls the hook with None; a real tensor here is a gradient from somewhere else on its way into the un-zeroed buffer."""
-    def hook(g):
-        if g is not None:
-            raise RuntimeError(f"{_SINK_VIOLATION} [parameter {getattr(param, '_dm_name', '?')} {tuple(param.shape)}]")
-    return hook
-
-
 class FlatParams:
     """Re-homes a module's parameters and gradients into flat fp32 buffers (views keep autograd working)."""
 
@@ -103,8 +94,6 @@ class FlatParams:
                 if id(p) in ids:
                     p._dm_gw = [False]
                     self.tracked.append((p, o, p.numel()))
-                    if getattr(p, "_dm_sink_guard", None) is None:      # the fused blocks never hand these gradients to autograd
-                        p._dm_sink_guard = p.register_hook(_sink_guard(p))
             names = {id(q): n for n, q in module.named_parameters()}
             for p, _, _ in self.tracked:
                 p._dm_name = names.get(id(p), "?")
@@ -138,6 +127,11 @@ class FlatParams:
         for p, o in zip(self.params, self.offsets):      # re-attach views if something replaced them
             if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + 4 * o:
                 p.grad = self.grad[o:o + p.numel()].view_as(p)
+        # Tracked parameters go through the backward pass WITHOUT a .grad: the fused blocks write their sinks through
+        # `_dm_grad_sink` and hand autograd nothing, so a .grad that exists afterwards was produced by autograd -- by some other
+        # use of the parameter -- and finish_grads() refuses it (it would otherwise have been added to last step's values).
+        for p, _, _ in self.tracked:
+            p.grad = None
 
     def finish_grads(self, lo: int = 0, hi: Optional[int] = None) -> int:
         """Call after the backward pass (of the range [lo, hi) of the flat buffer) and before its gradients are used: a tracked
@@ -148,12 +142,12 @@ class FlatParams:
             if not lo <= o < hi:
                 continue
             # The first-write contract: a tracked parameter's gradient is written by the fused-block kernels only, through the raw
-            # pointer of its sink view (they store on the first write of a step).  A gradient that arrives through autograd's own
-            # accumulation instead would be added to last step's values: the gradient hook registered in __init__ refuses
-            # that; here the other way out of the contract is caught, a .grad that is no longer the sink view.
-            g = p.grad
-            if g is None or g.data_ptr() != self.grad.data_ptr() + 4 * o:
-                raise RuntimeError(_SINK_VIOLATION)
+            # pointer of its sink view (they store on the first write of a step).  zero_grad() detached the parameter's .grad, so
+            # one that exists now came from autograd -- another use of the parameter.  (No hook on the parameter: a hook keeps its
+            # AccumulateGrad node alive across steps, on the stream it was created on, which breaks stream capture.)
+            if p.grad is not None and p.grad.data_ptr() != self.grad.data_ptr() + 4 * o:
+                raise RuntimeError(f"{_SINK_VIOLATION} [parameter {getattr(p, '_dm_name', '?')} {tuple(p.shape)}]")
+            p.grad = self.grad[o:o + cnt].view_as(p)         # what optimizers / callers read after the step
             if not p._dm_gw[0]:
                 self.grad[o:o + cnt].zero_()
                 p._dm_gw[0] = True
@@ -491,6 +485,8 @@ class PairTrainer:
                 self._capture(st)
             except Exception as e:                        # e.g. a collective backend whose helper threads break stream capture
                 import sys
+                if os.environ.get("DM_GRAPH_DEBUG") == "1":
+                    raise
                 print(f"[deepmerge_amd] hipGraph capture failed ({type(e).__name__}: {e}); the step stays eager", file=sys.stderr, flush=True)
                 torch.cuda.synchronize()
                 if getattr(self.net, "_dp_cut", None) is not None:
