@@ -204,8 +204,11 @@ def extras(args, scales, in_c, depth, dev):
 
 
 def free_port():
+    """A port nobody listens on right now.  The probe socket is closed before rank 0 binds the port (a short window in which
+    another process could take it; rank 0 then fails at rendezvous, every rank exits non-zero and the launcher reports it)."""
     import socket
     with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
         sk.bind(("127.0.0.1", 0))
         return sk.getsockname()[1]
 
@@ -220,17 +223,44 @@ def rank_env(base, rank, world, port):
     return env
 
 
+class _LauncherSignal(Exception):
+    def __init__(self, signum):
+        super().__init__(signum)
+        self.signum = signum
+
+
+def _child_setup():
+    """Runs in each child between fork and exec: its own session (so the whole rank, helpers included, can be ended as a
+    group) and a parent-death signal (a SIGKILLed launcher cannot run its cleanup: the kernel ends the ranks instead)."""
+    import ctypes
+    import signal
+    os.setsid()
+    try:
+        ctypes.CDLL(None, use_errno=True).prctl(1, signal.SIGTERM, 0, 0, 0)      # PR_SET_PDEATHSIG
+    except Exception:
+        pass
+
+
 def launch_ranks(world, argv, script=None, poll_s=0.2):
     """Parent of a self-launched multi-GPU run: one child process per rank, started BEFORE anything in this process imports
     torch or initialises a GPU (no exec from a GPU process: plain children).  Children inherit stdout, and only rank 0 writes
-    there (its one JSON line); the first failing child ends the others and its code becomes ours."""
+    there (its one JSON line); the first failing child ends the others and its code becomes ours.  SIGTERM / SIGINT / SIGHUP
+    sent to the launcher (a `timeout`, a scheduler) end every rank's process group before the launcher exits with 128 + signal:
+    ranks stuck in a collective never outlive it."""
     import signal
     import subprocess
-    port = free_port()
-    cmd = [sys.executable, script or os.path.abspath(__file__)] + list(argv)
-    procs = [subprocess.Popen(cmd, env=rank_env(os.environ, r, world, port)) for r in range(world)]
+
+    def on_signal(signum, _frame):
+        raise _LauncherSignal(signum)
+    caught = (signal.SIGTERM, signal.SIGINT, signal.SIGHUP)
+    previous = {sg: signal.signal(sg, on_signal) for sg in caught}
+    procs = []
     rc = 0
     try:
+        port = free_port()
+        cmd = [sys.executable, script or os.path.abspath(__file__)] + list(argv)
+        for r in range(world):
+            procs.append(subprocess.Popen(cmd, env=rank_env(os.environ, r, world, port), preexec_fn=_child_setup))
         live = set(range(world))
         while live and rc == 0:
             for r in sorted(live):
@@ -243,15 +273,29 @@ def launch_ranks(world, argv, script=None, poll_s=0.2):
                     rc = code if code > 0 else 1
                     break
             time.sleep(poll_s)
+    except _LauncherSignal as e:
+        log(f"launcher received signal {e.signum}: ending all ranks")
+        rc = 128 + e.signum
     finally:
+        for sg in caught:                       # a second signal during the cleanup must not abandon it half-way
+            signal.signal(sg, signal.SIG_IGN)
+
+        def end(p, sig):
+            try:
+                os.killpg(p.pid, sig)           # the child is its own session / group leader (_child_setup)
+            except (ProcessLookupError, PermissionError):
+                pass
         for p in procs:
             if p.poll() is None:
-                p.send_signal(signal.SIGTERM)
+                end(p, signal.SIGTERM)
         for p in procs:
             try:
                 p.wait(timeout=20)
             except subprocess.TimeoutExpired:
-                p.kill()
+                end(p, signal.SIGKILL)
+                p.wait()
+        for sg, h in previous.items():
+            signal.signal(sg, h)
     return rc
 
 
@@ -294,6 +338,9 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE={world} (launch with `python bench.py --gpus N` or "
                          f"`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`)")
+    if args.backend == "nccl" and world > 1 and torch.cuda.device_count() < world:       # (counting devices initialises nothing)
+        raise SystemExit(f"bench.py --gpus {world} over RCCL needs {world} GPUs on this node, found {torch.cuda.device_count()} "
+                         f"(one rank per GPU; `--backend gloo` rehearses several ranks on one GPU)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the measured path)")
     if args.backend == "gloo":

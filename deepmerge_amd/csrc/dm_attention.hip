@@ -601,7 +601,13 @@ static bool relpos_inkernel(int32_t B, int32_t N, int32_t H, int32_t D, int32_t 
   AttnPipeParams pp{nullptr, nullptr, nullptr, nullptr, B, N, H, 1.f};
   pp.table = reinterpret_cast<const float *>(16);      // (shape decision only)
   pp.cube_s = cube_s;
-  return dm_attn_fwd_q32_takes(pp);
+  if (!dm_attn_fwd_q32_takes(pp)) return false;
+  // the backward pass must take the table too: a caller told "in kernel" holds no dense rows, and the 16-row / generic
+  // backward kernels would then run WITHOUT the bias (the forward and backward switches and B * H rules differ)
+  AttnPipeBwdParams bp{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, B, N, H, 1.f};
+  bp.table = pp.table;
+  bp.cube_s = cube_s;
+  return dm_attn_bwd_tab_takes(bp);
 }
 
 extern "C" int32_t dm_attention_relpos_inkernel(int32_t B, int32_t N, int32_t H, int32_t D, int32_t cube_s, int32_t cube_h, int32_t cube_w,
@@ -655,13 +661,21 @@ static int attention_bwd(const void *qkv, const float *bias, const float *bias_t
     DmProfScope prof(dtype == DM_BF16 ? "attn_bwd_bf16" : "attn_bwd_f32", s, 10.0 * B * H * (double)N * N * HD,
                      esz * 8.0 * B * H * (double)N * HD);
     bool piped = false;
+    DM_REQUIRE(!(table && !bias) || dtype == DM_BF16, DM_ERR_UNSUPPORTED, "dm_attention_bwd_relpos: the table-reading kernels are bf16 only");
     if (dtype == DM_BF16) {
       AttnPipeBwdParams pp{qkv, bias, out, dout, lse, delta, dqkv, dbias_slab, B, N, H, scale};
       pp.table = table;
       pp.cube_s = cube_s;
+      // a table without dense rows: only the two table-reading kernels may run -- every other kernel would drop the bias
+      const bool table_only = table && !bias;
+      DM_REQUIRE(!table_only || dm_attn_bwd_tab_takes(pp), DM_ERR_UNSUPPORTED,
+                 "dm_attention_bwd_relpos: the table-reading backward kernels do not take this call (B=%d N=%d H=%d, switches "
+                 "DM_ATTN_PIPE / DM_ATTN_Q32_BWD / DM_ATTN_Q32_TABKV) and no dense bias rows were given", B, N, H);
       if (dm_attn_bwd_pipe_ok(pp)) {      // 32 rows per wave where those kernels take the pass (dm_attention_q32_bwd.hip), else 16
         const bool dq = dm_attn_bwd_dq_q32(pp, s);
-        piped = (dq && dm_attn_bwd_dkv_q32(pp, s)) || dm_attn_bwd_pipe(pp, s, dq);
+        const bool dkv = dq && dm_attn_bwd_dkv_q32(pp, s);
+        DM_REQUIRE(!table_only || dkv, DM_ERR_HIP, "dm_attention_bwd_relpos: a table-reading backward kernel could not be configured");
+        piped = dkv || dm_attn_bwd_pipe(pp, s, dq);
       }
     }
     if (!piped) {
@@ -685,12 +699,8 @@ extern "C" int dm_attention_bwd_relpos(const void *qkv, const float *table, int3
                                        const float *bias_t, const void *out, const void *dout, const float *lse, void *dqkv, float *delta,
                                        float *dbias_slab, int32_t B, int32_t N, int32_t H, int32_t D, float scale, int32_t dtype, void *stream) {
   DM_REQUIRE(table, DM_ERR_BAD_SHAPE, "dm_attention_bwd_relpos: null table");
-  {      // the dense rows are only needed where the table-reading dK / dV kernel is switched off (A/B runs)
-    const char *e = getenv("DM_ATTN_Q32_TABKV"), *m = getenv("DM_ATTN_Q32_BWD");
-    const bool dense_needed = (e && atoi(e) == 0) || (m && (atoi(m) == 0 || atoi(m) == 3));
-    DM_REQUIRE(bias || !dense_needed, DM_ERR_BAD_SHAPE, "dm_attention_bwd_relpos: the dense bias rows are required with DM_ATTN_Q32_TABKV=0 / DM_ATTN_Q32_BWD=0|3");
-  }
-  DM_REQUIRE(relpos_inkernel(B, N, H, D, cube_s, cube_h, cube_w, dtype), DM_ERR_UNSUPPORTED,
+  // (with dense rows given, the A/B switches may route either pass to the kernels that read them; without, attention_bwd refuses)
+  DM_REQUIRE(bias || relpos_inkernel(B, N, H, D, cube_s, cube_h, cube_w, dtype), DM_ERR_UNSUPPORTED,
              "dm_attention_bwd_relpos: shape not taken (B=%d N=%d H=%d D=%d cube=%dx%dx%d dtype=%d); call dm_attention_bwd", B, N, H, D, cube_s,
              cube_h, cube_w, dtype);
   return attention_bwd(qkv, bias, bias_t, table, cube_s, out, dout, lse, dqkv, delta, dbias_slab, B, N, H, D, scale, dtype, stream);

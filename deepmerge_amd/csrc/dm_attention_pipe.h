@@ -47,3 +47,6 @@ bool dm_attn_bwd_pipe(const AttnPipeBwdParams &p, hipStream_t s, bool dq_done = 
 bool dm_attn_bwd_dq_q32(const AttnPipeBwdParams &p, hipStream_t s);
 // dK / dV with 32 keys per wave, bias-free shapes only (reads p.delta: run a dQ pass first); true if it took the call
 bool dm_attn_bwd_dkv_q32(const AttnPipeBwdParams &p, hipStream_t s);
+// true if BOTH table-reading backward kernels (dQ and dK / dV with the head's table in LDS) take this shape under the current
+// switches -- the only case in which a backward pass may run without the dense bias rows (the decision, without launching)
+bool dm_attn_bwd_tab_takes(const AttnPipeBwdParams &p);

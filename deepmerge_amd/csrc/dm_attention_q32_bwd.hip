@@ -1089,6 +1089,16 @@ bool dm_attn_bwd_dkv_q32(const AttnPipeBwdParams &p, hipStream_t s) {
   }
 }
 
+bool dm_attn_bwd_tab_takes(const AttnPipeBwdParams &p) {
+  static const int mode = [] { const char *e = getenv("DM_ATTN_Q32_BWD"); return e ? atoi(e) : 1; }();
+  static const bool tabkv = [] { const char *e = getenv("DM_ATTN_Q32_TABKV"); return !(e && atoi(e) == 0); }();
+  if (mode == 0 || mode == 3 || !tabkv || !p.table) return false;
+  if (p.N != 64 * p.cube_s || (p.cube_s != 3 && p.cube_s != 4)) return false;
+  if ((long long)p.N * 3 * p.H * 64 * 2 >= (1LL << 31)) return false;
+  if (mode != 2 && p.B * p.H < 96) return false;
+  return dm_attn_bwd_pipe_ok(p);      // attention_bwd only reaches the 32-row kernels behind this gate (DM_ATTN_PIPE, B * H)
+}
+
 // dQ pass (+ delta) of the backward: bf16, head dim 64, 128 < N <= 256.  The dK / dV pass that follows reads p.delta.
 // true if it took the call; DM_ATTN_Q32_BWD=0 keeps the 16-row pipelined dQ kernel (A/B runs).
 bool dm_attn_bwd_dq_q32(const AttnPipeBwdParams &p, hipStream_t s) {

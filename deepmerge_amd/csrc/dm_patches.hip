@@ -40,7 +40,10 @@ __device__ __forceinline__ AreaTab area_tab(int d, int L, double scale) {
   return t;
 }
 __device__ __forceinline__ int cv_area_pixel(const unsigned char *win, int L, int T, int oy, int ox) {
-  if (L % T == 0) {                                             // is_area_fast: integer ratio k
+  const double inv_scale = (double)T / (double)L, scale = 1.0 / inv_scale;
+  // cv::resize's is_area_fast: |scale - cvRound(scale)| < DBL_EPSILON on the DOUBLE quotient -- for some integer ratios
+  // (k = 49, 93, 98, ...: 1 / (1 / k) != k in binary64) it fails and the float table path below runs (oracle/patches.py cv_is_area_fast)
+  if (L % T == 0 && fabs(scale - rint(scale)) < 2.220446049250313e-16) {
     const int k = L / T;
     if (k == 1) return win[oy * L + ox];
     int sum = 0;
@@ -50,7 +53,6 @@ __device__ __forceinline__ int cv_area_pixel(const unsigned char *win, int L, in
     const float scale = 1.f / (float)(k * k);
     return min(255, max(0, __float2int_rn(__fmul_rn((float)sum, scale))));
   }
-  const double inv_scale = (double)T / (double)L, scale = 1.0 / inv_scale;
   if (L > T) {                                                  // area tables, float accumulation in table order
     const AreaTab tx = area_tab(ox, L, scale), ty = area_tab(oy, L, scale);
     auto fold_row = [&](int sy) {

@@ -16,9 +16,12 @@ which is what the reader's tests are built from (no h5py-written fixture can be 
 to 64 chunks and a two-level tree above (default indexed-storage K = 32).  The file is rewritten index-last on close(), so an
 interrupted run leaves no half-valid index.
 
-Parity status: h5py is not available here or on the GPU box, so libhdf5 has never read these bytes: tests/test_h5store.py checks
-the structure field by field with an independent walk of the specification (H5FeatureReader shares no layout constants with
-the writer: it takes every size and address from the file) -- "structurally validated", not library-validated.
+Parity status (round 4): h5py is absent, but the image carries libhdf5 1.10.6 with its tools (/opt/conda/bin/h5dump, h5repack,
+/opt/conda/lib/libhdf5.so.103), and tests/test_h5store.py uses them in both directions: h5dump reads both writer layouts and dumps
+the payload byte for byte; files re-written by h5repack (as is, and re-chunked to 128 x 25) and a file produced by the upstream call
+sequence through libhdf5's C API (H5Dcreate2 with maxshape (UNLIMITED, 100) + H5Dset_extent + hyperslab writes = what h5py does)
+read back bit-equal through H5FeatureReader.  The field-by-field walk of the specification stays (H5FeatureReader shares no layout
+constants with the writer: it takes every size and address from the file).
 """
 from __future__ import annotations
 
@@ -95,7 +98,11 @@ class H5FeatureWriter:
         # (implied leading one), sign at bit 31; properties: bit offset 0, precision 32, exponent at 23 (8 bits), mantissa at 0
         # (23 bits), bias 127
         datatype = struct.pack("<BBBBI", 0x11, 0x20, 0x1F, 0x00, 4) + struct.pack("<HHBBBBI", 0, 32, 23, 8, 0, 23, 127)
-        fill = struct.pack("<BBBB", 2, 3, 0, 0)                 # version 2, incremental allocation, fill written on allocation, undefined value
+        # version 2, incremental allocation, fill written "if set", DEFAULT fill value (defined, size 0): the bytes libhdf5 1.10 /
+        # h5py write for `create_dataset(..., chunks=True)` (checked against a libhdf5-written file, tests/test_h5store.py).  Rounds
+        # 2-3 wrote "on allocation + undefined value", which libhdf5 READS but refuses to re-create (h5repack -l failed with
+        # "fill value writing on allocation set, but no fill value defined")
+        fill = struct.pack("<BBBBI", 2, 3, 2, 1, 0)
         head = [_message(0x0001, dataspace), _message(0x0003, datatype, 1), _message(0x0005, fill)]
         if not self.split_header:
             return _object_header(head + [self._layout_message(index_addr)])
@@ -385,3 +392,9 @@ class H5FeatureReader:
 
     def close(self):
         self.f.close()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()

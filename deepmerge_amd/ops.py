@@ -202,7 +202,10 @@ def gemm(layout: int, A: torch.Tensor, B: torch.Tensor, C_out: torch.Tensor, M: 
         a_stack, b_stack = int(layout == DM_TN), int(layout != DM_NT)
         A3 = workspace(6 * a_rows * a_cols, A.device, ws_slot + ".split_a").view(torch.bfloat16)    # per slot: the side stream
         B3 = workspace(6 * b_rows * b_cols, A.device, ws_slot + ".split_b").view(torch.bfloat16)    # has its own images
-        n_part = _lib.lib().dm_split_colsum_partial_floats(a_rows, a_cols) if (colsum_out is not None and a_cols % 8 == 0) else 0
+        # the fused split + column-sum pass has the vector kernel's preconditions (dm_rows.hip split_rows_ok: 16-byte aligned
+        # source, ld % 4 == 0 -- required above -- and whole 8-column groups); an offset view of dy takes the two-pass route below
+        fused_ok = colsum_out is not None and a_cols % 8 == 0 and A.data_ptr() % 16 == 0 and (a_rows * a_cols) % 8 == 0
+        n_part = _lib.lib().dm_split_colsum_partial_floats(a_rows, a_cols) if fused_ok else 0
         if n_part > 0:                       # the bias gradient rides on the operand's split pass: A is read once for both
             part = workspace(4 * n_part, A.device, ws_slot + ".partial").view(torch.float32)
             rows_out = C.c_int32(0)

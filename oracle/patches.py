@@ -152,13 +152,24 @@ def cv_linear_coeffs(ssize: int, dsize: int):
     return ofs, a0, a1, dmax
 
 
+def cv_is_area_fast(L: int, t: int) -> bool:
+    """cv::resize's `is_area_fast` for a square L -> t shrink: scale = 1. / ((double)t / L) is compared with its rounded value
+    against DBL_EPSILON.  For most integer ratios k = L / t the double quotient is exactly k; for some (k = 49, 93, 98, 99, 103, ...:
+    1 / (1 / k) != k in binary64) it is k +- 1e-14, the test fails and OpenCV takes the float area-table path instead of the integer
+    block mean -- e.g. L = 1568, t = 32."""
+    if L % t != 0:
+        return False
+    scale = np.float64(1.0) / (np.float64(t) / np.float64(L))
+    return bool(abs(scale - np.rint(scale)) < np.finfo(np.float64).eps)
+
+
 def cv_resize_area_u8(band: np.ndarray, t: int) -> np.ndarray:
     """uint8 [L, L] -> uint8 [t, t] as cv2.resize(band, (t, t), interpolation=cv2.INTER_AREA) computes it (module docstring;
     reference call site MyUtils1.py:202-216)."""
     L = band.shape[0]
     assert band.shape == (L, L) and band.dtype == np.uint8
     src = band.astype(np.int64)
-    if L % t == 0:                                                  # is_area_fast
+    if cv_is_area_fast(L, t):
         k = L // t
         if k == 1:
             return band.copy()

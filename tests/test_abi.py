@@ -4,6 +4,7 @@ import ctypes
 import os
 import re
 import subprocess
+import sys
 
 import pytest
 
@@ -214,6 +215,28 @@ def test_attention_routing_decisions_need_no_gpu(built_lib):
     assert lib.dm_attention_split_bwd_chunks(64, 256, 12) == 10 and lib.dm_attention_split_bwd_chunks(3, 197, 12) == 3
     assert lib.dm_attention_split_fwd(None, None, None, None, 0, 0, 0, None, None, 64, 64, 12, 64, 0.125, None) == -6
     assert lib.dm_split_colsum_partial_floats(16384, 3072) > 0 and lib.dm_split_colsum_partial_floats(16384, 20) == 0
+
+
+@pytest.mark.parametrize("env,B,expect", [
+    ({}, 64, 1),
+    ({"DM_ATTN_PIPE": "0"}, 64, 0),            # the 32-row backward kernels sit behind the pipelined family's gate
+    ({"DM_ATTN_Q32": "2"}, 2, 0),              # forward forced for a small batch; the backward's B * H rule still refuses
+    ({"DM_ATTN_Q32": "2", "DM_ATTN_Q32_BWD": "2", "DM_ATTN_PIPE": "2"}, 2, 1),
+    ({"DM_ATTN_Q32_BWD": "3"}, 64, 0),         # new dQ only: dK / dV would need the dense rows
+    ({"DM_ATTN_Q32_TABKV": "0"}, 64, 0),
+])
+def test_table_in_kernel_answer_covers_the_backward_pass(built_lib, env, B, expect):
+    """`dm_attention_relpos_inkernel` licenses the caller to hold NO dense bias rows, so it must be the conjunction
+    of the forward and the backward gates (their switches and B * H rules differ); a backward call without dense rows that the
+    table-reading kernels do not take is refused instead of running bias-free kernels (nets/ShfitScaleFormer.py:123-128)."""
+    code = ("import sys; sys.path.insert(0, %r); from deepmerge_amd import _lib; l = _lib.lib();"
+            "ok = l.dm_attention_relpos_inkernel(%d, 256, 12, 64, 4, 8, 8, _lib.DM_BF16);"
+            "print(ok, 0 if ok else l.dm_attention_bwd_relpos(16, 16, 4, 8, 8, None, None, 16, 16, 16, 16, 16, None, %d, 256, 12, 64,"
+            " 0.125, _lib.DM_BF16, None))" % (ROOT, B, B))
+    out = subprocess.run([sys.executable, "-c", code], env={**os.environ, **env}, capture_output=True, text=True, check=True).stdout.split()
+    assert int(out[0]) == expect
+    if not expect:
+        assert int(out[1]) == -6          # DM_ERR_UNSUPPORTED before any launch (no GPU here)
 
 
 def test_relative_position_index_is_vouched_for_only_when_it_is_the_closed_form():

@@ -73,3 +73,56 @@ def test_bench_refuses_mismatched_world():
     env = dict(os.environ, WORLD_SIZE="4", RANK="0")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode != 0 and "does not match WORLD_SIZE" in r.stderr
+
+
+def test_bench_fails_fast_without_enough_gpus_for_rccl():
+    """One rank per GPU over RCCL: a node with fewer devices than ranks is refused with a clear message before any process group
+    exists (no device at all in this container)."""
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode != 0 and "needs 2 GPUs on this node, found 0" in r.stderr
+
+
+def test_sigterm_to_the_launcher_ends_every_rank(tmp_path):
+    """a `timeout` / scheduler SIGTERM on `python bench.py --gpus N` must not orphan ranks that sit in a collective
+    holding GPUs: the launcher ends each rank's process group (grandchildren included) and exits 128 + SIGTERM."""
+    import signal
+    import time
+    child = tmp_path / "child.py"
+    child.write_text(textwrap.dedent(f"""
+        import os, subprocess, sys, time
+        helper = subprocess.Popen([sys.executable, "-c", "import time; time.sleep(300)"])      # a rank's own helper process
+        open(os.path.join({str(tmp_path)!r}, "pids.%s" % os.environ["RANK"]), "w").write("%d %d" % (os.getpid(), helper.pid))
+        time.sleep(300)
+    """))
+    driver = tmp_path / "driver.py"
+    driver.write_text(textwrap.dedent(f"""
+        import sys
+        sys.path.insert(0, {ROOT!r})
+        import bench
+        raise SystemExit(bench.launch_ranks(2, [], script={str(child)!r}, poll_s=0.05))
+    """))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    p = subprocess.Popen([sys.executable, str(driver)], env=env, stderr=subprocess.PIPE, text=True)
+    deadline = time.time() + 60
+    while time.time() < deadline and not all((tmp_path / f"pids.{r}").exists() and (tmp_path / f"pids.{r}").read_text().count(" ") for r in (0, 1)):
+        time.sleep(0.05)
+    pids = [int(x) for r in (0, 1) for x in (tmp_path / f"pids.{r}").read_text().split()]
+    assert len(pids) == 4
+    p.send_signal(signal.SIGTERM)
+    assert p.wait(timeout=60) == 128 + signal.SIGTERM
+    assert "ending all ranks" in p.stderr.read()
+
+    def alive(pid):
+        try:
+            os.kill(pid, 0)
+        except ProcessLookupError:
+            return False
+        try:                                   # a zombie reparented to init still answers kill(0)
+            return open(f"/proc/{pid}/stat").read().split(")")[-1].split()[0] != "Z"
+        except FileNotFoundError:
+            return False
+    deadline = time.time() + 10
+    while time.time() < deadline and any(alive(x) for x in pids):
+        time.sleep(0.1)
+    assert not any(alive(x) for x in pids)

@@ -916,6 +916,30 @@ def test_split_bf16_with_column_sums(rows, cols, ld, stack):
     assert lib.dm_split_bf16_colsum(src.data_ptr(), ld, rows, 20, want.data_ptr(), stack, 0b100, outs[0].data_ptr(), C.byref(n), st) != 0     # cols % 8
 
 
+def test_split_bf16_wgrad_with_an_offset_operand():
+    """the bf16x3 weight-gradient path fuses the bias gradient's column sums into the operand split only where the
+    vector kernel's preconditions hold; a dy view that starts 4 bytes into its storage (not 16-byte aligned) takes the two-pass
+    route and gives the same product and column sums (reference use: Linear backward, nets/ShfitScaleFormer.py:53-56)."""
+    from deepmerge_amd import ops
+    from deepmerge_amd._lib import DM_TN
+    torch.manual_seed(17)
+    K, M, N = 1024, 384, 512
+    store = torch.randn(K * M + 4, device=DEV)
+    x = torch.randn(K, N, device=DEV)
+    outs = []
+    for off in (0, 1):                     # aligned (fused pass) and offset by one float (two passes)
+        dy = store[off:off + K * M].view(K, M)
+        assert (dy.data_ptr() % 16 == 0) == (off == 0)
+        dw = torch.empty(M, N, device=DEV)
+        db = torch.zeros(M, device=DEV)
+        with ops.fp32_products("bf16x3"):
+            ops.gemm(DM_TN, dy, x, dw, M, N, K, colsum_out=db)
+        ref = dy.double().t() @ x.double()
+        assert ((dw.double() - ref).abs().max() / ref.abs().max()).item() < 3e-5
+        assert (db.double() - dy.double().sum(0)).abs().max().item() < 1e-3
+        outs.append((dw, db))
+
+
 @pytest.mark.parametrize("layout", ["NT", "NN", "TN"])
 def test_split_bf16_gemm_against_float64(layout):
     """ops.gemm under fp32_products("bf16x3"): every layout, with bias / GELU / residual epilogues and the fused column sums,

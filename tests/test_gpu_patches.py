@@ -21,8 +21,10 @@ def test_patch_pyramid_bit_exact_vs_oracle(rule):
     xy = np.stack([rng.integers(-5, W + 5, P), rng.integers(-5, H + 5, P)], 1).astype(np.int32)
     xy[:4] = [[0, 0], [W - 1, H - 1], [1, H - 1], [W // 2, 0]]                       # corners / edges
     tile = torch.from_numpy(img).to(DEV)
-    for t, lo, hi in ((32, 7, 90), (64, 20, 130), (128, 40, 200), (16, 1, 40)):
+    for t, lo, hi in ((32, 7, 90), (64, 20, 130), (128, 40, 200), (16, 1, 40), (4, 150, 250), (2, 150, 250)):
         wins = rng.integers(lo, hi, P).astype(np.int32)
+        if t <= 4:                                # integer ratios whose DOUBLE quotient is not the integer (cv_is_area_fast): table path
+            wins[8:12] = [49 * t, 93 * t if 93 * t <= 384 else 98 * t // 2, 98 * t if 98 * t <= 384 else 50 * t, 48 * t]
         wins[0], wins[1] = t, 2 * t                                                   # identity and exact 2x box
         wins[2], wins[3], wins[4], wins[5] = min(3 * t, 384), (4 * t + 2) // 3, (8 * t) // 5, max(1, (3 * t) // 4)    # 1/3, ~3/4, 5/8 shrinks; 4/3 enlarging
         wins[6], wins[7] = max(1, t // 2), min(4 * t, 384)                                      # exact 2x enlarging (replication under "opencv"), 1/4

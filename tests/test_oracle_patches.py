@@ -148,3 +148,21 @@ def test_cv_inter_area_properties():
         out = OP.patch_pyramid(img, 20, 20, [20, 40, 56], (32, 32, 32), resize=rule)
         assert [o.shape for o in out] == [(3, 32, 32)] * 3 and all(o.dtype == np.float32 for o in out)
 
+
+
+def test_cv_is_area_fast_follows_the_double_quotient():
+    """cv::resize decides its integer fast path on scale = 1. / ((double)t / L) against DBL_EPSILON, not on L % t (ADVICE round 3):
+    for k = 49, 93, 98, ... the double quotient is k +- 1e-14 and the float table path runs (reference call site MyUtils1.py:202-216)."""
+    assert all(OP.cv_is_area_fast(k * 32, 32) for k in (1, 2, 3, 4, 5, 7, 8, 12, 48, 50))
+    slow = [k for k in range(1, 130) if not OP.cv_is_area_fast(k * 4, 4)]
+    assert slow == [49, 93, 98, 99, 103, 105, 107, 117, 123]
+    assert not OP.cv_is_area_fast(100, 32) and not OP.cv_is_area_fast(16, 32)
+    # on such a window both paths are area means; the table path rounds float sums (no integer block mean): a constant stays constant,
+    # a random image stays within one grey level of the exact rational mean, and a 196 x 196 delta image gives the table weights' product
+    rng = np.random.default_rng(3)
+    img = rng.integers(0, 256, (196, 196), dtype=np.uint8)
+    got = OP.cv_resize_area_u8(img, 4)
+    assert np.abs(got.astype(int) - OP.area_resize_u8(img, 4).astype(int)).max() <= 1
+    assert np.array_equal(OP.cv_resize_area_u8(np.full((196, 196), 201, np.uint8), 4), np.full((4, 4), 201, np.uint8))
+    tab = OP.cv_area_tab(196, 4)
+    assert [len(e) for e in tab] == [50, 50, 50, 49] or all(49 <= len(e) <= 51 for e in tab)      # k = 49 cells + the 1e-14 slivers
