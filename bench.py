@@ -203,6 +203,36 @@ def extras(args, scales, in_c, depth, dev):
     return out
 
 
+def at_tolerance(args, scales, in_c, depth, dev, steps=20):
+    """The headline config in the numerics mode that MEETS north_star's tolerance (logits / grads within 1e-3 rel of the fp32
+    reference): `bf16x3` (fp32 tensors, every large product a split-bf16 triple on the bf16 matrix pipe; whole-model parity
+    7e-6 / 4e-5, tests/test_gpu_modules.py::test_whole_model_parity_bf16x3).  Same model, batch, step (fwd + loss + bwd + Adam) and
+    hipGraph replay as the headline `value`, >= 20 timed steps; outside the headline's timed region."""
+    import torch
+    from deepmerge_amd.nets.ShfitScaleFormer import ShfitScaleFormer_v3
+    from deepmerge_amd.trainer import PairTrainer
+    torch.manual_seed(0)
+    net = ShfitScaleFormer_v3(cube_size=[8, 8], input_image_scales=list(scales), depth=list(depth), in_c=in_c, numerics="bf16x3").to(dev)
+    tr = PairTrainer(net, margin=1.0, lr=1e-4)
+    batch = synth_batch(args.pairs, scales, in_c, dev, 1000)
+    graph = args.graph in ("on", "auto")
+    if graph:
+        tr.enable_graph(warmup=2)
+    for _ in range(3):
+        tr.step(*batch)
+    if graph and tr.graph_inputs() is not None:
+        batch = tr.graph_inputs()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(steps):
+        tr.step(*batch)
+    torch.cuda.synchronize(); d = (time.perf_counter() - t0) / steps
+    ok = bool(graph and tr.graph_error is None)
+    del net, tr, batch
+    torch.cuda.empty_cache()
+    return {"value": round(args.pairs / d, 2), "ms_per_step": round(1e3 * d, 3), "dtype": "bf16x3", "steps": steps, "hip_graph": ok,
+            "tolerance": "1e-3 rel vs fp32 reference (observed 7e-6 outputs / 4e-5 gradients); the bf16 headline drifts 4.3e-3 / 2.2e-2"}
+
+
 def free_port():
     """A port nobody listens on right now.  The probe socket is closed before rank 0 binds the port (a short window in which
     another process could take it; rank 0 then fails at rendezvous, every rank exits non-zero and the launcher reports it)."""
@@ -503,7 +533,18 @@ def main():
         else:
             out["cpu_baseline"] = None
         if world == 1 and not args.no_extras:
-            out["extras"] = extras(args, scales, in_c, depth, dev)
+            ex = extras(args, scales, in_c, depth, dev)
+            # the line stays short enough for a record that keeps only its tail: scalars here, the nested per-config dicts on stderr
+            log("extras (details): " + json.dumps({k: v for k, v in ex.items() if isinstance(v, dict)}))
+            out["extras"] = {k: v for k, v in ex.items() if not isinstance(v, dict)}
+            # LAST keys of the line: the throughput at north_star's tolerance, same config and step as `value`
+            try:
+                log("at tolerance: the headline config in bf16x3, 20 timed steps")
+                tol = at_tolerance(args, scales, in_c, depth, dev)
+                out["value_at_tolerance"], out["ms_per_step_at_tolerance"], out["dtype_at_tolerance"] = tol["value"], tol["ms_per_step"], tol["dtype"]
+                out["at_tolerance"] = tol
+            except Exception as e:
+                out["value_at_tolerance"], out["at_tolerance"] = None, {"error": f"{type(e).__name__}: {e}"}
         sys.stdout.flush()
         os.write(result_fd, (json.dumps(out) + "\n").encode())
     if world > 1 or force_dp:

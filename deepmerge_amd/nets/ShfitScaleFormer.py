@@ -336,7 +336,10 @@ class ShfitScaleFormer_v3(nn.Module):
 
     def _pooled_tokens(self, x):
         B = x[0].shape[0]
-        x = self._ln(self.backbone(self.pos_drop(self.patch_embed(x))))
+        x = self.pos_drop(self.patch_embed(x))
+        if self._dp_cut is not None:             # the patch embeds' gradients (17 MB at 4 scales x 4 ch) get a bucket of their own: the
+            x = self._dp_cut(x, self.patch_embed_blocks)   # exchange of stage-0 block 0 then starts before their backward, not after it
+        x = self._ln(self.backbone(x))
         g = x.shape[1] // self.input_scales_num
         return ops.GroupMeanFn.apply(x, g).view(B, -1)
 
