@@ -353,6 +353,30 @@ __global__ __launch_bounds__(NTHREADS, (TM == 4 ? WG_PER_CU : 4)) void gemm_kern
       return;
     }
   }
+  if (TM == 2 && !(p.debug & 0x400)) {
+    // 64 x 64 tiles (the 4096- / 1024-token stages, the patch embeds): all loads of the wave's four strips first, then the stores
+    // (dm_gemm_common.h: a load behind a store waits for the store's acknowledgement)
+    DmGemmRow rbs[TM];
+    DmStripPre pre[TM][TM];
+    bool ok[TM][TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int m = m0 + wm * WT + i * 16 + li;
+      rbs[i] = dm_gemm_row(p, m < p.M ? m : p.M - 1);
+#pragma unroll
+      for (int j = 0; j < TM; ++j) {
+        const int n = n0 + wn * WT + j * 16 + 4 * g;
+        ok[i][j] = m < p.M && n < p.N;      // N % 4 == 0 is enforced by the launcher
+        if (ok[i][j]) dm_gemm_strip_load(p, rbs[i], n, pre[i][j]);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TM; ++j)
+        if (ok[i][j]) dm_gemm_strip_store<sizeof(T) == 2>(p, acc[i][j], rbs[i], n0 + wn * WT + j * 16 + 4 * g, pre[i][j]);
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
     const int m = m0 + wm * WT + i * 16 + li;
@@ -558,6 +582,8 @@ extern "C" int dm_gemm(const DmGemmArgs *a, void *stream) {
   DM_REQUIRE(a->c_dtype == DM_F32 || a->c_dtype == DM_BF16, DM_ERR_BAD_DTYPE, "dm_gemm: bad c_dtype %d", a->c_dtype);
   DM_REQUIRE(a->A && a->B && a->C, DM_ERR_BAD_SHAPE, "dm_gemm: null operand");
   DM_REQUIRE(!(a->accumulate && a->c_dtype != DM_F32), DM_ERR_BAD_DTYPE, "dm_gemm: accumulate needs an fp32 C");
+  DM_REQUIRE(!(a->accumulate && (a->epilogue == DM_EPI_DGELU || a->epilogue == DM_EPI_MUL)), DM_ERR_UNSUPPORTED,
+             "dm_gemm: accumulate cannot be combined with an aux-reading epilogue (DM_EPI_DGELU / DM_EPI_MUL)");
   DM_REQUIRE(a->epilogue == DM_EPI_NONE || a->epilogue == DM_EPI_GELU || a->aux != nullptr, DM_ERR_BAD_SHAPE,
              "dm_gemm: this epilogue needs aux (only DM_EPI_GELU may run without one: inference)");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
@@ -655,6 +681,8 @@ extern "C" int dm_gemm(const DmGemmArgs *a, void *stream) {
     if (rows_off && !ring) p.debug |= 0x100;
     static const bool touch_off = [] { const char *e = getenv("DM_GEMM_T128_TOUCH"); return e && e[0] == '0'; }();  // A/B aid: no early touch of the epilogue operands
     if (touch_off) p.debug |= 0x200;
+    static const bool lean_off = [] { const char *e = getenv("DM_GEMM_EPI_LEAN"); return e && e[0] == '0'; }();     // A/B aid: the generic whole-line epilogue (dm_gemm_common.h)
+    if (lean_off) p.debug |= 0x400;
   }
   {
     static const int forced = [] { const char *e = getenv("DM_GEMM_GROUP_M"); return e ? atoi(e) : -1; }();

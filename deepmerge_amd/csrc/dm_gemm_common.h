@@ -86,6 +86,62 @@ __device__ __forceinline__ void dm_gemm_emit(const GemmParams &p, f32x4 v, const
   }
 }
 
+// The same strip in two steps, for kernels that keep the MFMA layout in their epilogue (64 x 64 tiles): dm_gemm_emit loads its read
+// operands (bias, residual, aux, old C) right before it stores, so in a sequence of strips every load sits behind the previous
+// strip's store and waits for that store's acknowledgement (vmcnt retires in order): a memory round trip per strip.  The caller
+// issues the loads of ALL its strips first (dm_gemm_strip_load), then computes and stores (dm_gemm_strip_store).
+struct DmStripPre { f32x4 bias, res, y; };
+__device__ __forceinline__ void dm_gemm_strip_load(const GemmParams &p, const DmGemmRow &rb, int n, DmStripPre &pre) {
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  pre.bias = p.bias ? dm_load4(p.bias + n) : zero;
+  pre.res = p.residual ? dm_load4(p.residual + rb.r + n) : zero;
+  pre.y = zero;
+  if (p.epilogue == DM_EPI_DGELU || p.epilogue == DM_EPI_MUL)
+    pre.y = (p.aux_dtype == DM_F32) ? dm_load4(reinterpret_cast<const float *>(p.aux) + rb.x + n) : dm_load4(reinterpret_cast<const bf16_t *>(p.aux) + rb.x + n);
+  else if (p.c_dtype == DM_F32 && p.accumulate)
+    pre.y = dm_load4(reinterpret_cast<const float *>(p.C) + rb.c + n);
+}
+template <bool FAST>
+__device__ __forceinline__ void dm_gemm_strip_store(const GemmParams &p, f32x4 v, const DmGemmRow &rb, int n, const DmStripPre &pre) {
+  v += pre.bias;
+  if (p.epilogue == DM_EPI_GELU) {
+    if (p.aux) {
+      if (p.aux_dtype == DM_F32) dm_store4(reinterpret_cast<float *>(p.aux) + rb.x + n, v);
+      else dm_store4(reinterpret_cast<bf16_t *>(p.aux) + rb.x + n, v);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = FAST ? dm_gelu_fast(v[e]) : dm_gelu(v[e]);
+  } else if (p.epilogue == DM_EPI_GELU_GRAD) {
+    f32x4 d;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if constexpr (FAST) {
+        float cdf, pdf;
+        dm_gelu_parts_fast(v[e], cdf, pdf);
+        d[e] = fmaf(v[e], pdf, cdf);
+        v[e] = v[e] * cdf;
+      } else {
+        d[e] = dm_dgelu(v[e]);
+        v[e] = dm_gelu(v[e]);
+      }
+    }
+    if (p.aux_dtype == DM_F32) dm_store4(reinterpret_cast<float *>(p.aux) + rb.x + n, d);
+    else dm_store4(reinterpret_cast<bf16_t *>(p.aux) + rb.x + n, d);
+  } else if (p.epilogue == DM_EPI_MUL) {
+    v *= pre.y;
+  } else if (p.epilogue == DM_EPI_DGELU) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] *= FAST ? dm_dgelu_fast(pre.y[e]) : dm_dgelu(pre.y[e]);
+  }
+  v += pre.res;
+  if (p.c_dtype == DM_F32) {
+    if (p.accumulate) v += pre.y;      // (accumulate never goes with an aux-reading epilogue: dm_gemm refuses the combination)
+    dm_store4(reinterpret_cast<float *>(p.C) + rb.c + n, v);
+  } else {
+    dm_store4(reinterpret_cast<bf16_t *>(p.C) + rb.c + n, v);
+  }
+}
+
 // ---- whole-line epilogue shared by the LDS-DMA kernels (dm_gemm_ring.hip, dm_gemm256.hip) ----------------------------------
 // A wave owns a (WM * 16) x 64 block of outputs as acc[WM][4] (row i * 16 + (lane & 15), columns j * 16 + 4 * (lane >> 4) ..+3).
 // Stored from that layout an instruction touches 16 rows x 32..64 B.  Instead the wave transposes ROWS rows at a time through a
@@ -152,7 +208,7 @@ __device__ __forceinline__ void dm_gemm_emit8(const GemmParams &p, f32x4 lo, f32
 
 
 template <int WM, int ROWS, bool SKIP_STORES = false>
-__device__ __forceinline__ void dm_epilogue_rows(const GemmParams &p, f32x4 (&acc)[WM][4], char *mine, int m_wave, int n_wave, int lane) {
+__device__ __forceinline__ void dm_epilogue_rows_generic(const GemmParams &p, f32x4 (&acc)[WM][4], char *mine, int m_wave, int n_wave, int lane) {
   const int g = lane >> 4, li = lane & 15;
   constexpr int PASS_TILES = ROWS / 16;
 #pragma unroll
@@ -177,4 +233,204 @@ __device__ __forceinline__ void dm_epilogue_rows(const GemmParams &p, f32x4 (&ac
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the next pass overwrites the region
     __builtin_amdgcn_sched_barrier(0);
   }
+}
+
+
+// ---- lean whole-line epilogue (round 4) ------------------------------------------------------------------------------------------
+// Same arithmetic as dm_gemm_emit8 row by row, restructured after reading the ISA of the form above (tools/isa_hazards.py listings):
+//   * the generic form pays ~25 quarter-rate integer multiplies per 8-column item (64-bit row offsets, the grouped-row division)
+//     and, worse, every item's bias / residual / aux LOADS sit behind the previous item's STORES in program order: vmcnt retires in
+//     order, so each item waits for a store acknowledgement (a memory round trip per 8 rows: 8-24 of them per tile);
+//   * here a wave builds three buffer descriptors per tile (C, residual, aux: base = the wave's first row / column, extent = the
+//     valid rows below it, so rows past M are dropped / read zero in hardware and the code has no branches), per-lane byte offsets
+//     are computed ONCE (row lane >> 3, columns 8 (lane & 7)), an item only advances a SCALAR offset (8 rows), the bias is loaded
+//     once per tile, and the loads of item q + 1 are issued BEFORE the stores of item q (software pipeline over the tile's items):
+//     no load ever waits for a store.
+// Preconditions (the caller falls back to the generic form otherwise): plain rows (rows_per_group == 0) and 32-bit offsets inside a
+// wave's block (16 WM rows x leading dimension x 4 B < 2^31).
+// A 16-byte buffer store followed closely by a VALU write of its data registers: observed on gfx950 (exact-integer GELU + aux test,
+// ~1 wave-instruction in 3000) that the LAST FOUR LANES of each 16-lane group stored the new value of a data register that a VALU
+// instruction three slots behind the store overwrote -- beyond the one wait state the ISA manual asks for and the compiler
+// provides.  The data registers are therefore kept alive (and idle) for 16 more cycles behind every store (8 made the test pass; the margin is cheap: < 1 % of an item).
+#ifndef DM_EPI_STORE_NOP
+#define DM_EPI_STORE_NOP "s_nop 7\n\ts_nop 7"
+#endif
+#define DM_EPI_BSTORE(data, rsrc, vo, so, aux)                                  \
+  do {                                                                          \
+    const u32x4 dm_bs_ = (data);                                                \
+    __builtin_amdgcn_raw_buffer_store_b128(dm_bs_, rsrc, vo, so, aux);          \
+    asm volatile(DM_EPI_STORE_NOP ::"v"(dm_bs_) : "memory");                    \
+  } while (0)
+struct DmEpiPre { f32x4 r0, r1; u32x4 y0, y1; };      // residual; the old C (accumulate) OR the aux operand (never both: see dm_epilogue_rows)
+
+__device__ __forceinline__ int dm_epi_records(long long bytes) { return (int)(bytes < 0 ? 0 : (bytes > 0x7fffffffLL ? 0x7fffffffLL : bytes)); }
+
+// RT = true: which operands exist is read from `p` at run time (any combination; the wave-uniform branches around the memory
+// instructions make the compiler's waitcnt bookkeeping conservative: vmcnt(0) at the merge points).  RT = false: the STRUCTURE of an
+// item -- RES: fp32 residual read; YL: 0 none / 1 old C (accumulate) / 2 aux read, bf16 / 3 aux read, fp32; C32: fp32 C; XS: 0 no aux
+// store / 1 bf16 / 2 fp32 -- is a template argument, so every memory instruction is straight-line code with counted waits; only the
+// arithmetic kind (GELU / GELU' / multiply) stays a run-time branch.  dm_epilogue_rows dispatches the combinations the encoder uses.
+template <int WM, int ROWS, bool SKIP_STORES = false, bool RT = true, bool RES = false, int YL = 0, bool C32 = false, int XS = 0>
+__device__ __forceinline__ void dm_epilogue_rows_lean(const GemmParams &p, f32x4 (&acc)[WM][4], char *mine, int m_wave_in, int n_wave_in, int lane) {
+  // wave-uniform by construction, but derived from threadIdx in some callers: without the readfirstlane the descriptors below live
+  // in VGPRs and every buffer access becomes a waterfall loop
+  const int m_wave = __builtin_amdgcn_readfirstlane(m_wave_in), n_wave = __builtin_amdgcn_readfirstlane(n_wave_in);
+  constexpr int PASS_TILES = ROWS / 16, NPASS = WM / PASS_TILES, R = ROWS / 8, Q = NPASS * R;
+  const int g = lane >> 4, li = lane & 15, c8 = lane & 7, rl = lane >> 3;
+  const int n = n_wave + c8 * 8;
+  const unsigned kill = (n < p.N) ? 0u : 0x80000000u;              // columns past N (N % 8 == 0: whole groups)
+  const bool c32 = RT ? (p.c_dtype == DM_F32) : C32;
+  const bool x32 = RT ? (p.aux_dtype == DM_F32) : (YL == 3 || XS == 2);
+  const int csz = c32 ? 4 : 2, xsz = x32 ? 4 : 2;
+  const bool live = m_wave < p.M;
+  const long long rows_below = (long long)(p.M - 1 - m_wave), cols_right = (long long)(p.N - n_wave);
+  const bool has_res = RT ? (p.residual != nullptr) : RES;
+  const bool has_acc = RT ? (c32 && p.accumulate) : (YL == 1);
+  const bool aux_load = RT ? (p.aux && (p.epilogue == DM_EPI_DGELU || p.epilogue == DM_EPI_MUL)) : (YL >= 2);
+  const bool aux_store = RT ? (p.aux && (p.epilogue == DM_EPI_GELU || p.epilogue == DM_EPI_GELU_GRAD)) : (XS != 0);
+  const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc(
+      reinterpret_cast<char *>(p.C) + ((long long)m_wave * p.ldc + n_wave) * csz, 0, live ? dm_epi_records((rows_below * p.ldc + cols_right) * csz) : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float *>(p.residual) + (has_res ? (long long)m_wave * p.ldr + n_wave : 0), 0,
+      (live && has_res) ? dm_epi_records((rows_below * p.ldr + cols_right) * 4) : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(
+      reinterpret_cast<char *>(p.aux) + (p.aux ? ((long long)m_wave * p.ldaux + n_wave) * xsz : 0), 0,
+      (live && p.aux) ? dm_epi_records((rows_below * p.ldaux + cols_right) * xsz) : 0, 0x00020000);
+  const unsigned voC = (unsigned)((rl * (int)p.ldc + c8 * 8) * csz) | kill;
+  const unsigned voR = (unsigned)((rl * (int)p.ldr + c8 * 8) * 4) | kill;
+  const unsigned voX = (unsigned)((rl * (int)p.ldaux + c8 * 8) * xsz) | kill;
+  const int stepC = 8 * (int)p.ldc * csz, stepR = 8 * (int)p.ldr * 4, stepX = 8 * (int)p.ldaux * xsz;      // 8 rows
+  f32x4 b_lo = {0.f, 0.f, 0.f, 0.f}, b_hi = {0.f, 0.f, 0.f, 0.f};
+  if (p.bias && !kill) { b_lo = dm_load4(p.bias + n); b_hi = dm_load4(p.bias + n + 4); }
+
+  auto prefetch = [&](DmEpiPre &pre, int q) __attribute__((always_inline)) {
+    if (has_res) {
+      pre.r0 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsR, voR, q * stepR, 0));
+      pre.r1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsR, voR + 16, q * stepR, 0));
+    }
+    if (has_acc) {
+      pre.y0 = __builtin_amdgcn_raw_buffer_load_b128(rsC, voC, q * stepC, 0);
+      pre.y1 = __builtin_amdgcn_raw_buffer_load_b128(rsC, voC + 16, q * stepC, 0);
+    }
+    if (aux_load) {
+      pre.y0 = __builtin_amdgcn_raw_buffer_load_b128(rsX, voX, q * stepX, 0);
+      if (x32) pre.y1 = __builtin_amdgcn_raw_buffer_load_b128(rsX, voX + 16, q * stepX, 0);
+    }
+  };
+  auto pack8 = [](const f32x4 &a, const f32x4 &b) __attribute__((always_inline)) {
+    const bf16x8 o = {(bf16_t)a[0], (bf16_t)a[1], (bf16_t)a[2], (bf16_t)a[3], (bf16_t)b[0], (bf16_t)b[1], (bf16_t)b[2], (bf16_t)b[3]};
+    return __builtin_bit_cast(u32x4, o);
+  };
+  auto emit = [&](f32x4 lo, f32x4 hi, const DmEpiPre &pre, int q) __attribute__((always_inline)) {
+    lo += b_lo; hi += b_hi;
+    if (p.epilogue == DM_EPI_GELU) {
+      if (aux_store) {
+        if (x32) {
+          DM_EPI_BSTORE(__builtin_bit_cast(u32x4, lo), rsX, voX, q * stepX, 0);
+          DM_EPI_BSTORE(__builtin_bit_cast(u32x4, hi), rsX, voX + 16, q * stepX, 0);
+        } else {
+          DM_EPI_BSTORE(pack8(lo, hi), rsX, voX, q * stepX, 0);
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { lo[e] = dm_gelu_fast(lo[e]); hi[e] = dm_gelu_fast(hi[e]); }
+    } else if (p.epilogue == DM_EPI_GELU_GRAD) {
+      f32x4 dl, dh;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float cdf, pdf;
+        dm_gelu_parts_fast(lo[e], cdf, pdf);
+        dl[e] = fmaf(lo[e], pdf, cdf);
+        lo[e] = lo[e] * cdf;
+        dm_gelu_parts_fast(hi[e], cdf, pdf);
+        dh[e] = fmaf(hi[e], pdf, cdf);
+        hi[e] = hi[e] * cdf;
+      }
+      if (aux_store) {
+        if (x32) {
+          DM_EPI_BSTORE(__builtin_bit_cast(u32x4, dl), rsX, voX, q * stepX, 0);
+          DM_EPI_BSTORE(__builtin_bit_cast(u32x4, dh), rsX, voX + 16, q * stepX, 0);
+        } else {
+          DM_EPI_BSTORE(pack8(dl, dh), rsX, voX, q * stepX, 0);
+        }
+      }
+    } else if (aux_load) {
+      f32x4 ul, uh;
+      if (x32) { ul = __builtin_bit_cast(f32x4, pre.y0); uh = __builtin_bit_cast(f32x4, pre.y1); }
+      else {
+        const bf16x8 u = __builtin_bit_cast(bf16x8, pre.y0);
+        ul = (f32x4){(float)u[0], (float)u[1], (float)u[2], (float)u[3]};
+        uh = (f32x4){(float)u[4], (float)u[5], (float)u[6], (float)u[7]};
+      }
+      if (p.epilogue == DM_EPI_MUL) { lo *= ul; hi *= uh; }
+      else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { lo[e] *= dm_dgelu_fast(ul[e]); hi[e] *= dm_dgelu_fast(uh[e]); }
+      }
+    }
+    if (has_res) { lo += pre.r0; hi += pre.r1; }
+    if (c32) {
+      if (has_acc) { lo += __builtin_bit_cast(f32x4, pre.y0); hi += __builtin_bit_cast(f32x4, pre.y1); }
+      DM_EPI_BSTORE(__builtin_bit_cast(u32x4, lo), rsC, voC, q * stepC, 0);
+      DM_EPI_BSTORE(__builtin_bit_cast(u32x4, hi), rsC, voC + 16, q * stepC, 0);
+    } else {
+      DM_EPI_BSTORE(pack8(lo, hi), rsC, voC, q * stepC, 0);
+    }
+  };
+
+  DmEpiPre pre[2];
+  prefetch(pre[0], 0);
+#pragma unroll
+  for (int ps = 0; ps < NPASS; ++ps) {
+#pragma unroll
+    for (int ii = 0; ii < PASS_TILES; ++ii)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        *reinterpret_cast<f32x4 *>(mine + (ii * 16 + li) * DM_EPI_PITCH + (j * 16 + 4 * g) * 4) = acc[ps * PASS_TILES + ii][j];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int q = ps * R + r;
+      if (q + 1 < Q) prefetch(pre[(q + 1) & 1], q + 1);          // (issued before this item's stores: see the header)
+      __builtin_amdgcn_sched_barrier(0);
+      const int row = r * 8 + rl;
+      const f32x4 lo = *reinterpret_cast<const f32x4 *>(mine + row * DM_EPI_PITCH + c8 * 32);
+      const f32x4 hi = *reinterpret_cast<const f32x4 *>(mine + row * DM_EPI_PITCH + c8 * 32 + 16);
+      if constexpr (SKIP_STORES) { if (lo[0] == 12345.678f) emit(lo, hi, pre[q & 1], q); }
+      else emit(lo, hi, pre[q & 1], q);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the next pass overwrites the region
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// DM_GEMM_EPI_LEAN=0 in the environment selects the generic form everywhere (p.debug bit 0x400: A/B runs).
+template <int WM, int ROWS, bool SKIP_STORES = false>
+__device__ __forceinline__ void dm_epilogue_rows(const GemmParams &p, f32x4 (&acc)[WM][4], char *mine, int m_wave, int n_wave, int lane) {
+  constexpr long long LIM = (1LL << 31) / (16LL * WM * 4);
+  const bool aux_read = p.aux && (p.epilogue == DM_EPI_DGELU || p.epilogue == DM_EPI_MUL);
+  const bool aux_write = p.aux && (p.epilogue == DM_EPI_GELU || p.epilogue == DM_EPI_GELU_GRAD);
+  const bool lean = p.rows_per_group == 0 && !(p.debug & 0x400) && p.ldc < LIM && p.ldr < LIM && p.ldaux < LIM &&
+                    !(aux_read && p.accumulate);          // (one prefetch slot serves the old C or the aux operand)
+  if (!lean) { dm_epilogue_rows_generic<WM, ROWS, SKIP_STORES>(p, acc, mine, m_wave, n_wave, lane); return; }
+  // structure key of an item: residual | old C | aux read (bf16 / fp32) | fp32 C | aux store (bf16 / fp32)
+  const bool c32 = p.c_dtype == DM_F32, x32 = p.aux_dtype == DM_F32;
+  const int yl = (c32 && p.accumulate) ? 1 : aux_read ? (x32 ? 3 : 2) : 0;
+  const int xs = aux_write ? (x32 ? 2 : 1) : 0;
+  const int key = (p.residual ? 1 : 0) | (yl << 1) | ((c32 ? 1 : 0) << 3) | (xs << 4);
+#define DM_EPI_CASE(RES, YL, C32, XS) \
+  case ((RES) | ((YL) << 1) | ((C32) << 3) | ((XS) << 4)): \
+    dm_epilogue_rows_lean<WM, ROWS, SKIP_STORES, false, (RES) != 0, (YL), (C32) != 0, (XS)>(p, acc, mine, m_wave, n_wave, lane); break;
+  switch (key) {
+    DM_EPI_CASE(0, 0, 0, 0)      // bf16 C (+ bias / GELU without a saved derivative): qkv forward, the dgrads, inference fc1
+    DM_EPI_CASE(1, 0, 1, 0)      // fp32 C + fp32 residual: proj / fc2 forward
+    DM_EPI_CASE(0, 0, 1, 0)      // fp32 C: split-K slabs, unsplit weight gradients, fp32 activations
+    DM_EPI_CASE(0, 1, 1, 0)      // fp32 C accumulated in place
+    DM_EPI_CASE(0, 0, 0, 1)      // bf16 C + bf16 aux written: fc1 forward (GELU + saved GELU')
+    DM_EPI_CASE(0, 2, 0, 0)      // bf16 C, bf16 aux read: dgrad of fc2 (multiply by the saved GELU')
+    default: dm_epilogue_rows_lean<WM, ROWS, SKIP_STORES, true>(p, acc, mine, m_wave, n_wave, lane); break;
+  }
+#undef DM_EPI_CASE
 }

@@ -64,7 +64,7 @@ const char *dm_arch(void);
  *                                       pre-activation: same bytes, and the backward epilogue becomes one multiply)
  *   v *= aux[m,n]                    if epilogue == DM_EPI_MUL      (backward through GELU with the saved derivative)
  *   v += residual[m,n]               if residual != NULL (fp32)
- *   v += C_old[m,n]                  if accumulate (C must be fp32)
+ *   v += C_old[m,n]                  if accumulate (C must be fp32; not with DM_EPI_DGELU / DM_EPI_MUL: DM_ERR_UNSUPPORTED)
  *   C[m,n] = v (as c_dtype)
  * split_k > 1 (DM_TN only): the contraction is cut into split_k slices whose fp32 partial tiles
  * go to `workspace` ([split_k, M, N] floats) and are summed deterministically by a second
