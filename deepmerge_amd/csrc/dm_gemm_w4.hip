@@ -48,8 +48,12 @@ __device__ __forceinline__ void mma_pinned(f32x4 &acc, const u32x4 &a, const u32
 }
 
 // DBG (ablation builds only, -DDM_W4_ABLATE): 1 no epilogue, 4 no global loads, 8 no LDS writes, 16 no fragment reads, 32 no MFMAs
-template <int LAYOUT, int DBG = 0, int EPIU = 0>
+// EK: 0 = the generic fused epilogue (any operand combination, grouped rows); k > 0 = the lean epilogue with item structure key
+// k - 1 = RES | YL << 1 | C32 << 3 | XS << 4 (dm_gemm_common.h).  ONE epilogue per kernel instance: with two in one kernel the
+// accumulators meet in phi nodes behind them and the register allocator spills all 48 tiles around every tile end (tried).
+template <int LAYOUT, int DBG = 0, int EK = 0>
 __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmParams p) {
+  constexpr int EPIU = 0;
   constexpr bool AMM = (LAYOUT == DM_TN);      // A m-contiguous [K][M] (wgrad) or k-contiguous [M][K]
   constexpr bool BMM = (LAYOUT != DM_NT);      // B m-contiguous [K][N] (dgrad, wgrad) or k-contiguous [N][K] (forward)
   constexpr int NB = BMM ? 8 : 6;              // global loads of B per thread and K step
@@ -360,7 +364,174 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmParams p) {
   // common LDS slab and then each walks 8 of the rows whole: a row is 24 lanes x 8 columns, so bias / residual / aux reads and the C
   // stores are complete 128-byte lines (a wave's own 96 columns = 192 B of bf16 would end in half lines, which the memory system
   // pays for with read-modify-writes: measured 2.6 TB/s of stores).  K-step buffers untouched: the staging of the next tile goes on.
-  auto epilogue = [&]() __attribute__((always_inline)) {
+  // Round 4: the same epilogue in the lean form of dm_gemm_common.h (dm_epilogue_rows_lean): three buffer descriptors per tile, per-lane
+  // offsets of the three passes computed once per tile, a row tile only advances a scalar offset, bias loaded once per tile, and the
+  // read operands of item (i, q + 1) are requested BEFORE the stores of item (i, q) -- in the generic form below every pass pays
+  // ~25 quarter-rate integer multiplies (64-bit row offsets, item / 24) and its loads wait for the previous pass's stores (vmcnt
+  // retires in order): a memory round trip per pass, 24 per tile.  RT / RES / YL / C32 / XS: the structure of an item, as there.
+  auto epilogue_lean = [&](auto rt_tag, auto res_tag, auto yl_tag, auto c32_tag, auto xs_tag) __attribute__((always_inline)) {
+    constexpr bool RT = decltype(rt_tag)::value != 0, RES = decltype(res_tag)::value != 0, C32 = decltype(c32_tag)::value != 0;
+    constexpr int YL = decltype(yl_tag)::value, XS = decltype(xs_tag)::value;
+    char *slab = smem + 2 * BUF_BYTES + wm * (2 * EPI_WAVE);
+    int lane = lane_outer;
+    asm volatile("" : "+v"(lane) : "v"(tv[0]), "v"(tv[1]), "v"(tv[2]), "v"(tv[3]), "v"(tv[4]), "v"(tv[5]));
+    const int g = lane >> 4, li = lane & 15;
+    const bool split = AMM && p.split_k > 1;
+    const bool c32 = AMM ? true : (RT ? (p.c_dtype == DM_F32) : C32);
+    const bool x32 = RT ? (p.aux_dtype == DM_F32) : (YL == 3 || XS == 2);
+    const bool has_res = !AMM && (RT ? (p.residual != nullptr) : RES);
+    const bool has_acc = RT ? (c32 && p.accumulate && !split) : (YL == 1);
+    const bool aux_load = !AMM && (RT ? (p.aux && (p.epilogue == DM_EPI_DGELU || p.epilogue == DM_EPI_MUL)) : (YL >= 2));
+    const bool aux_store = !AMM && (RT ? (p.aux && (p.epilogue == DM_EPI_GELU || p.epilogue == DM_EPI_GELU_GRAD)) : (XS != 0));
+    const int csz = c32 ? 4 : 2, xsz = x32 ? 4 : 2;
+    const int m_base = m_cur + wm * 128, n_base = n_cur;            // wave-uniform (wave id through readfirstlane)
+    const bool live = m_base < p.M;
+    const long long rows_below = (long long)(p.M - 1 - m_base), cols_right = (long long)(p.N - n_base);
+    const long long ldc_eff = split ? (long long)p.N : p.ldc;
+    char *cptr = split ? reinterpret_cast<char *>(p.workspace + ((long long)zslice * p.M + m_base) * p.N + n_base)
+                       : reinterpret_cast<char *>(p.C) + ((long long)m_base * p.ldc + n_base) * csz;
+    const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc(cptr, 0, live ? dm_epi_records((rows_below * ldc_eff + cols_right) * csz) : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(p.residual) + (has_res ? (long long)m_base * p.ldr + n_base : 0), 0,
+        (live && has_res) ? dm_epi_records((rows_below * p.ldr + cols_right) * 4) : 0, 0x00020000);
+    const bool has_aux = aux_load || aux_store;
+    const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(
+        reinterpret_cast<char *>(p.aux) + (has_aux ? ((long long)m_base * p.ldaux + n_base) * xsz : 0), 0,
+        (live && has_aux) ? dm_epi_records((rows_below * p.ldaux + cols_right) * xsz) : 0, 0x00020000);
+    const int stepC = 16 * (int)ldc_eff * csz, stepR = 16 * (int)p.ldr * 4, stepX = 16 * (int)p.ldaux * xsz;      // one row tile
+    unsigned oC[3], oR[3], oX[3];
+    int sl0[3], sl1[3];
+    f32x4 b_lo[3], b_hi[3];
+#pragma unroll
+    for (int q3 = 0; q3 < 3; ++q3) {
+      const int item = q3 * 64 + lane;             // 8 rows x 24 groups of 8 columns
+      const int rr = item / 24, cg = item - rr * 24;
+      const int row = wn * 8 + rr;
+      const unsigned kill = (n_base + cg * 8 < p.N) ? 0u : 0x80000000u;
+      oC[q3] = (unsigned)((row * (int)ldc_eff + cg * 8) * csz) | kill;
+      oR[q3] = (unsigned)((row * (int)p.ldr + cg * 8) * 4) | kill;
+      oX[q3] = (unsigned)((row * (int)p.ldaux + cg * 8) * xsz) | kill;
+      sl0[q3] = row * 768 + (((2 * cg) ^ (row & 7)) << 4);
+      sl1[q3] = row * 768 + (((2 * cg + 1) ^ (row & 7)) << 4);
+      b_lo[q3] = b_hi[q3] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (!AMM && p.bias && !kill) { b_lo[q3] = dm_load4(p.bias + n_base + cg * 8); b_hi[q3] = dm_load4(p.bias + n_base + cg * 8 + 4); }
+    }
+    auto prefetch = [&](DmEpiPre &pre, int i, int q3) __attribute__((always_inline)) {
+      if (has_res) {
+        pre.r0 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsR, oR[q3], i * stepR, 0));
+        pre.r1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsR, oR[q3] + 16, i * stepR, 0));
+      }
+      if (has_acc) {
+        pre.y0 = __builtin_amdgcn_raw_buffer_load_b128(rsC, oC[q3], i * stepC, 0);
+        pre.y1 = __builtin_amdgcn_raw_buffer_load_b128(rsC, oC[q3] + 16, i * stepC, 0);
+      }
+      if (aux_load) {
+        pre.y0 = __builtin_amdgcn_raw_buffer_load_b128(rsX, oX[q3], i * stepX, 0);
+        if (x32) pre.y1 = __builtin_amdgcn_raw_buffer_load_b128(rsX, oX[q3] + 16, i * stepX, 0);
+      }
+    };
+    auto pack8 = [](const f32x4 &a, const f32x4 &b) __attribute__((always_inline)) {
+      const bf16x8 o = {(bf16_t)a[0], (bf16_t)a[1], (bf16_t)a[2], (bf16_t)a[3], (bf16_t)b[0], (bf16_t)b[1], (bf16_t)b[2], (bf16_t)b[3]};
+      return __builtin_bit_cast(u32x4, o);
+    };
+    auto emit = [&](f32x4 lo, f32x4 hi, const DmEpiPre &pre, int i, int q3) __attribute__((always_inline)) {
+      lo += b_lo[q3]; hi += b_hi[q3];
+      if (!AMM && p.epilogue == DM_EPI_GELU) {
+        if (aux_store) {
+          if (x32) {
+            DM_EPI_BSTORE(__builtin_bit_cast(u32x4, lo), rsX, oX[q3], i * stepX, 0);
+            DM_EPI_BSTORE(__builtin_bit_cast(u32x4, hi), rsX, oX[q3] + 16, i * stepX, 0);
+          } else {
+            DM_EPI_BSTORE(pack8(lo, hi), rsX, oX[q3], i * stepX, 0);
+          }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { lo[e] = dm_gelu_fast(lo[e]); hi[e] = dm_gelu_fast(hi[e]); }
+      } else if (!AMM && p.epilogue == DM_EPI_GELU_GRAD) {
+        f32x4 dl, dh;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float cdf, pdf;
+          dm_gelu_parts_fast(lo[e], cdf, pdf);
+          dl[e] = fmaf(lo[e], pdf, cdf);
+          lo[e] = lo[e] * cdf;
+          dm_gelu_parts_fast(hi[e], cdf, pdf);
+          dh[e] = fmaf(hi[e], pdf, cdf);
+          hi[e] = hi[e] * cdf;
+        }
+        if (aux_store) {
+          if (x32) {
+            DM_EPI_BSTORE(__builtin_bit_cast(u32x4, dl), rsX, oX[q3], i * stepX, 0);
+            DM_EPI_BSTORE(__builtin_bit_cast(u32x4, dh), rsX, oX[q3] + 16, i * stepX, 0);
+          } else {
+            DM_EPI_BSTORE(pack8(dl, dh), rsX, oX[q3], i * stepX, 0);
+          }
+        }
+      } else if (aux_load) {
+        f32x4 ul, uh;
+        if (x32) { ul = __builtin_bit_cast(f32x4, pre.y0); uh = __builtin_bit_cast(f32x4, pre.y1); }
+        else {
+          const bf16x8 u = __builtin_bit_cast(bf16x8, pre.y0);
+          ul = (f32x4){(float)u[0], (float)u[1], (float)u[2], (float)u[3]};
+          uh = (f32x4){(float)u[4], (float)u[5], (float)u[6], (float)u[7]};
+        }
+        if (p.epilogue == DM_EPI_MUL) { lo *= ul; hi *= uh; }
+        else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { lo[e] *= dm_dgelu_fast(ul[e]); hi[e] *= dm_dgelu_fast(uh[e]); }
+        }
+      }
+      if (has_res) { lo += pre.r0; hi += pre.r1; }
+      if (c32) {
+        if (has_acc) { lo += __builtin_bit_cast(f32x4, pre.y0); hi += __builtin_bit_cast(f32x4, pre.y1); }
+        DM_EPI_BSTORE(__builtin_bit_cast(u32x4, lo), rsC, oC[q3], i * stepC, 0);
+        DM_EPI_BSTORE(__builtin_bit_cast(u32x4, hi), rsC, oC[q3] + 16, i * stepC, 0);
+      } else {
+        DM_EPI_BSTORE(pack8(lo, hi), rsC, oC[q3], i * stepC, 0);
+      }
+    };
+    DmEpiPre pre[2];
+    prefetch(pre[0], 0, 0);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+        asm volatile("" : "+a"(acc[i][j]));
+        *reinterpret_cast<f32x4 *>(slab + li * 768 + (((wn * 24 + j * 4 + g) ^ (li & 7)) << 4)) = acc[i][j];
+        zero_pinned(acc[i][j], vzero);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int q3 = 0; q3 < 3; ++q3) {
+        const int idx = i * 3 + q3;
+        if (idx + 1 < 24) prefetch(pre[(idx + 1) & 1], (idx + 1) / 3, (idx + 1) % 3);
+        __builtin_amdgcn_sched_barrier(0);
+        const f32x4 lo = *reinterpret_cast<const f32x4 *>(slab + sl0[q3]);
+        const f32x4 hi = *reinterpret_cast<const f32x4 *>(slab + sl1[q3]);
+        emit(lo, hi, pre[idx & 1], i, q3);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the next row tile overwrites the slab
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if constexpr (AMM) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) asm volatile("" : "+a"(accb[i]));
+      if (colsum && g == 0) {
+        float *row = p.colsum_slab + (long long)(zslice * 2 + wn) * p.M;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) row[m_cur + wm * 128 + i * 16 + li] = accb[i][0];
+      }
+    }
+    kt = 0;
+    ++r;
+    if (r < n_my) tile_mn(r, m_cur, n_cur);
+  };
+
+  auto epilogue_generic = [&]() __attribute__((always_inline)) {
     char *slab = smem + 2 * BUF_BYTES + wm * (2 * EPI_WAVE);           // 16 rows x 768 B, XOR-swizzled 16-byte chunks
     const int m_pair = m_cur + wm * 128;
     // the lane-dependent addresses of the epilogue are recomputed here from an opaque copy of the lane id: hoisted out of the K
@@ -483,7 +654,8 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmParams p) {
     kt += 2;
     if (kt == ntile) {
       if constexpr (DBG & 1) { kt = 0; ++r; if (r < n_my) tile_mn(r, m_cur, n_cur); } else
-      epilogue();
+      if constexpr (EK == 0) epilogue_generic();
+      else epilogue_lean(IC<0>{}, IC<(EK - 1) & 1>{}, IC<((EK - 1) >> 1) & 3>{}, IC<((EK - 1) >> 3) & 1>{}, IC<((EK - 1) >> 4) & 3>{});
       // The next step's k-step-0 fragments were prefetched during the last MFMAs; holding their 56 registers across the epilogue
       // (on top of the 88 staging registers in flight) overflows the register file, so they are read again here instead.
 #pragma unroll
@@ -497,8 +669,8 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmParams p) {
 }  // namespace dmw4
 
 namespace {
-template <int LAYOUT, int DBG = 0, int EPIU = 0> bool w4_set_lds_limit() {
-  return hipFuncSetAttribute(reinterpret_cast<const void *>(dmw4::gemm_w4_kernel<LAYOUT, DBG, EPIU>), hipFuncAttributeMaxDynamicSharedMemorySize,
+template <int LAYOUT, int DBG = 0, int EK = 0> bool w4_set_lds_limit() {
+  return hipFuncSetAttribute(reinterpret_cast<const void *>(dmw4::gemm_w4_kernel<LAYOUT, DBG, EK>), hipFuncAttributeMaxDynamicSharedMemorySize,
                              dmw4::LDS_BYTES) == hipSuccess;
 }
 int w4_cu_count() {
@@ -549,7 +721,7 @@ int dm_gemm_w4_plan(GemmParams &p, int layout, int ab_dtype, bool aligned8, bool
     // in-step per launch (tools/prof_shapes.py): K = 16384: 100 -> 84, 92 -> 83, 80 -> 67, 41 -> 38 us; K = 4096 with 48 tiles x 4 slices:
     // 26 -> 24 us; fewer workgroups than 0.7 of the CUs, or the 1024-token stage, lose
     if (tmode == 1 && ((double)(tiles * split) / cus < 0.7 || tiles < 12 || (tiles < 24 && p.K < 8192))) return 0;
-    static const bool attr_tn = w4_set_lds_limit<DM_TN>();
+    static const bool attr_tn = w4_set_lds_limit<DM_TN>() && w4_set_lds_limit<DM_TN, 0, 9>() && w4_set_lds_limit<DM_TN, 0, 11>();
     if (!attr_tn) return 0;
     p.tiles_m = p.M / TM;
     p.tiles_n = p.N / TN;
@@ -581,7 +753,8 @@ int dm_gemm_w4_plan(GemmParams &p, int layout, int ab_dtype, bool aligned8, bool
     const long long rounds = (tiles + cus - 1) / cus;
     if ((double)tiles / (double)(rounds * cus) < 0.85) return 0;
   }
-  static const bool attr_ok = w4_set_lds_limit<DM_NT>() && w4_set_lds_limit<DM_NN>() && w4_set_lds_limit<DM_NT, 0, 1>() && w4_set_lds_limit<DM_NN, 0, 1>();
+  static const bool attr_ok = w4_set_lds_limit<DM_NT>() && w4_set_lds_limit<DM_NN>() && w4_set_lds_limit<DM_NT, 0, 1>() && w4_set_lds_limit<DM_NT, 0, 10>() &&
+                              w4_set_lds_limit<DM_NT, 0, 17>() && w4_set_lds_limit<DM_NN, 0, 1>() && w4_set_lds_limit<DM_NN, 0, 5>();
   if (!attr_ok) return 0;
   p.tiles_m = tiles_m;
   p.tiles_n = tiles_n;
@@ -601,17 +774,30 @@ void dm_gemm_w4_launch(const GemmParams &p, int layout, int grid, hipStream_t s)
 #undef W4_CASE
   }
 #endif
-  // EPIU = 1 unrolls the epilogue's three row passes (their residual / aux loads in flight together).  Measured inside the training
-  // step it LOSES 12-15 % on every shape, with or without epilogue reads (tools/prof_shapes.py, same box): experiment knob only.
-  const char *uenv = getenv("DM_W4_EPI_UNROLL");
-  const bool unroll = uenv && atoi(uenv) != 0;
+  // Which epilogue: the lean form (dm_gemm_common.h) where its preconditions hold -- plain rows, 32-bit offsets inside a wave pair's
+  // 128 rows -- and the item structure is one of the instantiated ones; the generic form otherwise (and with DM_GEMM_EPI_LEAN=0).
+  constexpr long long LIM = (1LL << 31) / (128LL * 4);
+  const bool lean_ok = !(p.debug & 0x400) && p.rows_per_group == 0 && p.ldc < LIM && p.ldr < LIM && p.ldaux < LIM && p.N < LIM;
+  const bool c32 = p.c_dtype == DM_F32, x32 = p.aux_dtype == DM_F32;
+  const bool aux_read = p.aux && (p.epilogue == DM_EPI_DGELU || p.epilogue == DM_EPI_MUL);
+  const bool aux_write = p.aux && (p.epilogue == DM_EPI_GELU || p.epilogue == DM_EPI_GELU_GRAD);
+  const int yl = (c32 && p.accumulate && p.split_k <= 1) ? 1 : aux_read ? (x32 ? 3 : 2) : 0;
+  const int xs = aux_write ? (x32 ? 2 : 1) : 0;
+  const int key = (p.residual ? 1 : 0) | (yl << 1) | ((c32 ? 1 : 0) << 3) | (xs << 4);
+#define W4_GO(LAY, EKV) hipLaunchKernelGGL((dmw4::gemm_w4_kernel<LAY, 0, EKV>), dim3(grid), dim3(256), dmw4::LDS_BYTES, s, p)
   if (layout == DM_TN) {
-    hipLaunchKernelGGL((dmw4::gemm_w4_kernel<DM_TN, 0, 0>), dim3(grid), dim3(256), dmw4::LDS_BYTES, s, p);
+    if (lean_ok && key == 8) W4_GO(DM_TN, 9);             // fp32 slab / gradient written
+    else if (lean_ok && key == 10) W4_GO(DM_TN, 11);      // fp32 gradient accumulated in place
+    else W4_GO(DM_TN, 0);
   } else if (layout == DM_NT) {
-    if (unroll) hipLaunchKernelGGL((dmw4::gemm_w4_kernel<DM_NT, 0, 1>), dim3(grid), dim3(256), dmw4::LDS_BYTES, s, p);
-    else hipLaunchKernelGGL((dmw4::gemm_w4_kernel<DM_NT, 0, 0>), dim3(grid), dim3(256), dmw4::LDS_BYTES, s, p);
+    if (lean_ok && key == 0) W4_GO(DM_NT, 1);             // bf16 C
+    else if (lean_ok && key == 9) W4_GO(DM_NT, 10);       // fp32 C + fp32 residual: fc2 / proj forward
+    else if (lean_ok && key == 16) W4_GO(DM_NT, 17);      // bf16 C + bf16 aux written: fc1 forward
+    else W4_GO(DM_NT, 0);
   } else {
-    if (unroll) hipLaunchKernelGGL((dmw4::gemm_w4_kernel<DM_NN, 0, 1>), dim3(grid), dim3(256), dmw4::LDS_BYTES, s, p);
-    else hipLaunchKernelGGL((dmw4::gemm_w4_kernel<DM_NN, 0, 0>), dim3(grid), dim3(256), dmw4::LDS_BYTES, s, p);
+    if (lean_ok && key == 0) W4_GO(DM_NN, 1);             // bf16 C: dgrads
+    else if (lean_ok && key == 4) W4_GO(DM_NN, 5);        // bf16 C x saved GELU' (bf16 aux read): dgrad of fc2
+    else W4_GO(DM_NN, 0);
   }
+#undef W4_GO
 }
