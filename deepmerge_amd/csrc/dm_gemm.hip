@@ -424,6 +424,23 @@ __global__ void splitk_reduce_kernel(const float *__restrict__ slab, float *__re
 }
 
 
+// Forward / dgrad K slices: 8 consecutive outputs of a row = sum of the S partial tiles (slice order) through the fused epilogue
+// (bias, GELU / GELU' with the saved operand, residual, bf16 / fp32 store, grouped rows): same arithmetic as an unsplit launch except
+// for the order of the fp32 additions over K.
+__global__ __launch_bounds__(256) void splitk_epilogue_kernel(const GemmParams p, const float *__restrict__ slab, int S) {
+  const long long n8 = (long long)p.M * p.N / 8;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long long)gridDim.x * blockDim.x) {
+    const long long e = i * 8;
+    const int m = (int)(e / p.N), n = (int)(e % p.N);
+    f32x4 lo = {0.f, 0.f, 0.f, 0.f}, hi = {0.f, 0.f, 0.f, 0.f};
+    for (int sl = 0; sl < S; ++sl) {
+      lo += dm_load4(slab + (long long)sl * p.M * p.N + e);
+      hi += dm_load4(slab + (long long)sl * p.M * p.N + e + 4);
+    }
+    dm_gemm_emit8(p, lo, hi, dm_gemm_row(p, m), n);
+  }
+}
+
 // out[m] (+)= sum_r rows[r][m], rows in index order (the pipeline's partial column sums of A)
 __global__ void colsum_rows_reduce_kernel(const float *__restrict__ rows, float *__restrict__ out, int M, int R, int accumulate) {
   const int m = blockIdx.x * blockDim.x + threadIdx.x;
@@ -557,6 +574,27 @@ int choose_split(int tiles, int K, int bk) {
   return s;
 }
 
+// Forward / dgrad products with a long contraction and a small output (the 4096- and 1024-token stages' fc2 forward, fc1 / qkv
+// dgrad, the 256-pixel patch embed: M x N = 4096 x 768 or 1024 x 768 with K = 2304 .. 4096) have too few 128 x 128 tiles for the
+// chip and, as 64 x 64 tiles, move twice the operand bytes through L2 -> LDS (measured 403-440 TFLOP/s, 120-150 at M = 1024, where
+// 192 workgroups walk 48 K stages each).  Round 4: K slices for them too -- fp32 partial tiles into the workspace, summed in slice
+// order and passed through the fused epilogue by splitk_epilogue_kernel.  Returns the slice count (1 = no split) and the tile.
+inline int plan_fwd_split(int layout, int M, int N, int K, int &tile) {
+  tile = 0;
+  static const int mode = [] { const char *e = getenv("DM_GEMM_FWD_SPLIT"); return e ? atoi(e) : 1; }();      // 0 = off (A/B runs)
+  if (mode == 0 || layout == DM_TN || N % 8 != 0 || K < 1536) return 1;
+  const long long t128 = (long long)((M + 127) / 128) * ((N + 127) / 128);
+  if (t128 >= 256) return 1;                       // enough tiles without slices
+  int split = 4;
+  while (split > 1 && K / split < 8 * 64) split >>= 1;      // >= 8 K stages per slice
+  if (split <= 1) return 1;
+  // (128 x 128 tiles x 4 slices for the M = 4096 products measured no faster than unsplit 64 x 64 tiles -- the slab round trip eats the
+  // gain; those go to the 4-wave kernel's slices, dm_gemm_w4_plan -- so this path serves what is left: M <= 1024)
+  if (t128 * split >= 512) return 1;
+  tile = 64;
+  return split;
+}
+
 }  // namespace
 
 // floats at the end of the workspace reserved for the column sums of A (colsum_a): the pipeline's [32 slices * 4][M] partial
@@ -567,7 +605,11 @@ static int64_t colsum_region_floats(int M) {
 }
 
 extern "C" int64_t dm_gemm_workspace_bytes(int32_t layout, int32_t M, int32_t N, int32_t K) {
-  if (layout != DM_TN) return 0;
+  if (layout != DM_TN) {
+    // forward / dgrad K slices (plan_fwd_split, dm_gemm_w4_plan): at most 4 partial tiles
+    const long long t128 = (long long)((M + 127) / 128) * ((N + 127) / 128);
+    return (N % 8 == 0 && K >= 1536 && t128 < 256) ? (int64_t)4 * M * N * 4 : 0;
+  }
   const int tile = pick_tile(layout, M, N, K);
   const int tiles = ((M + tile - 1) / tile) * ((N + tile - 1) / tile);
   const int s = choose_split(tiles, K, 32);
@@ -656,18 +698,33 @@ extern "C" int dm_gemm(const DmGemmArgs *a, void *stream) {
   // the 4-wave register-staged persistent kernel, then the ring kernel, then the 256x256 pipeline
   p.workspace = reinterpret_cast<float *>(a->workspace);
   const bool w4_ok = (a->layout == DM_TN) ? (a->split_k == 0 && a->ldc % 4 == 0) : ring_aligned;     // wgrad: automatic slice count only
-  const int w4 = w4_ok ? dm_gemm_w4_plan(p, a->layout, a->ab_dtype, true, can_split, slab_bytes) : 0;
+  // forward / dgrad K slices (w4: (tile, slice) per workgroup; 128 x 128 / 64 x 64: plan_fwd_split): automatic slice count only, the
+  // 8-column epilogue of splitk_epilogue_kernel must be legal, and the caller's workspace holds the slab
+  const bool fwd_slices_ok = a->layout != DM_TN && a->ab_dtype == DM_BF16 && a->split_k == 0 && ring_aligned && a->N % 8 == 0 &&
+                             (a->residual == nullptr || a->ldr % 8 == 0) && a->workspace != nullptr && slab_bytes > 0;
+  const int w4 = w4_ok ? dm_gemm_w4_plan(p, a->layout, a->ab_dtype, true, a->layout == DM_TN ? can_split : fwd_slices_ok, slab_bytes) : 0;
   const bool persistent = w4 != 0;
   const int ring = persistent ? 0 : dm_gemm_ring_plan(p, a->layout, a->ab_dtype, ring_aligned);
   const bool big = !persistent && !ring && dm_gemm256_plan(p, a->layout, a->ab_dtype, can_split, slab_bytes, a->split_k);
   int tile = w4 ? 1924 : ring ? (ring == 8 ? 2568 : 1288) : big ? 256 : pick_tile(a->layout, a->M, a->N, a->K);
   int split = w4 ? p.split_k : (ring || persistent) ? 1 : p.split_k;
+  // forward / dgrad K slices (plan_fwd_split): bf16, automatic slice count, 8-column epilogue legal, slab inside the workspace
+  bool fwd_split = persistent && a->layout != DM_TN && p.split_k > 1;      // the 4-wave kernel planned slices
+  if (!big && !ring && !persistent && fwd_slices_ok) {
+    int ft;
+    const int fs = plan_fwd_split(a->layout, a->M, a->N, a->K, ft);
+    if (fs > 1 && (int64_t)fs * a->M * a->N * 4 <= slab_bytes && !getenv("DM_GEMM_FORCE_TILE")) {
+      fwd_split = true;
+      tile = ft;
+    }
+  }
   if (!big && !ring && !persistent) {
     p.tiles_m = (a->M + tile - 1) / tile;
     p.tiles_n = (a->N + tile - 1) / tile;
     const int bk = (a->ab_dtype == DM_BF16) ? 64 : 32;
     split = a->split_k;
-    if (split == 0) split = can_split ? choose_split(p.tiles_m * p.tiles_n, a->K, bk) : 1;
+    if (fwd_split) { int ft; split = plan_fwd_split(a->layout, a->M, a->N, a->K, ft); }
+    else if (split == 0) split = can_split ? choose_split(p.tiles_m * p.tiles_n, a->K, bk) : 1;
     if (split > 1)
       while (split > 1 && (int64_t)split * a->M * a->N * 4 > slab_bytes) split >>= 1;
     int kps = ((a->K + split - 1) / split + bk - 1) / bk * bk;
@@ -718,8 +775,16 @@ extern "C" int dm_gemm(const DmGemmArgs *a, void *stream) {
     } else {
       if (tile == 128) launch_mfma<float, 4>(p, a->layout, grid, s); else launch_mfma<float, 2>(p, a->layout, grid, s);
     }
+    if (fwd_split && split > 1) {      // (inside the profiler scope: the class time of these products includes their reduction)
+      const long long n8 = (long long)a->M * a->N / 8;
+      const long long want = (n8 + 255) / 256;
+      GemmParams q = p;
+      q.split_k = 1;
+      hipLaunchKernelGGL(splitk_epilogue_kernel, dim3((unsigned)(want < 4096 ? want : 4096)), dim3(256), 0, s, q, p.workspace, split);
+    }
   }
   DM_LAUNCH_CHECK("dm_gemm");
+  if (fwd_split) return DM_OK;
   const bool cs_fused = big || (w4 && a->layout == DM_TN);      // these kernels produce the partial column sums of A themselves
   const int cs_rows_per_slice = big ? 4 : 2;
   if (split > 1) {

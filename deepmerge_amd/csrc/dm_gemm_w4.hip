@@ -66,13 +66,26 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmParams p) {
   const int G = gridDim.x;
   const int L = dm_xcd_remap(blockIdx.x, G);
   const int tiles = p.tiles_m * p.tiles_n;
+  {
+    // Experiment (DM_W4_STAGGER = n, off by default): the workgroups of every other XCD start n x 1024 cycles late, so that half of the
+    // chip stores its tiles while the other half is in its K loop (all 256 workgroups otherwise reach every epilogue together and
+    // the stores run at the memory system's burst rate with the matrix pipes idle).
+    const int stag = (p.debug >> 16) & 0x7fff;
+    if (stag && (blockIdx.x & 1)) {
+      const long long t0 = __builtin_amdgcn_s_memtime();
+      while (__builtin_amdgcn_s_memtime() - t0 < (long long)stag * 1024) __builtin_amdgcn_s_sleep(32);
+    }
+  }
   // wgrad (TN): one (tile, K slice) per workgroup, slices of k_per_split (the last one may be shorter); the partial tile goes to
   // slab z of the split-K workspace.  Forward / dgrad: whole K, tiles L, L + G, ...
-  const int zslice = AMM ? L / tiles : 0;
-  const int kbeg = AMM ? zslice * p.k_per_split : 0;
-  const int kend = AMM ? min(p.K, kbeg + p.k_per_split) : p.K;
+  // (round 4: forward / dgrad products with few tiles and a long contraction are sliced the same way -- p.split_k > 1, partial
+  // tiles to the slab, dm_gemm's splitk_epilogue_kernel applies the fused epilogue)
+  const bool sliced = AMM || p.split_k > 1;
+  const int zslice = sliced ? L / tiles : 0;
+  const int kbeg = sliced ? zslice * p.k_per_split : 0;
+  const int kend = sliced ? min(p.K, kbeg + p.k_per_split) : p.K;
   const int ntile = (kend - kbeg) / BK;
-  const int n_my = AMM ? 1 : (tiles - L + G - 1) / G;
+  const int n_my = sliced ? 1 : (tiles - L + G - 1) / G;
   const int total = n_my * ntile;
 
   // ---- global -> register mapping -----------------------------------------------------------------------------------------------
@@ -150,15 +163,15 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmParams p) {
   // ---- tile cursors (uniform) -------------------------------------------------------------------------------------------------------
   const bf16_t *Ab = reinterpret_cast<const bf16_t *>(p.A), *Bb = reinterpret_cast<const bf16_t *>(p.B);
   auto tile_mn = [&](int r, int &m0, int &n0) __attribute__((always_inline)) {
-    const int tid = (DBG & 64) ? (L & 7) : AMM ? L - zslice * tiles : L + r * G;        // (ablation 64: every workgroup reads the same few L2-resident tiles)
+    const int tid = (DBG & 64) ? (L & 7) : sliced ? L - zslice * tiles : L + r * G;        // (ablation 64: every workgroup reads the same few L2-resident tiles)
     const int tm = tid / p.tiles_n;
     m0 = tm * TM;
     n0 = (tid - tm * p.tiles_n) * TN;
   };
   auto make_a = [&](int m0, bool live) __attribute__((always_inline)) {
     if constexpr (!AMM) {
-      const long long bytes = ((long long)(min(TM, p.M - m0) - 1) * p.lda + p.K) * 2;
-      return __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t *>(Ab + (long long)m0 * p.lda), 0, live ? (int)min(bytes, 0x7fffffffLL) : 0, 0x00020000);
+      const long long bytes = ((long long)(min(TM, p.M - m0) - 1) * p.lda + (kend - kbeg)) * 2;
+      return __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t *>(Ab + (long long)m0 * p.lda + kbeg), 0, live ? (int)min(bytes, 0x7fffffffLL) : 0, 0x00020000);
     } else {
       const long long bytes = ((long long)(kend - kbeg - 1) * p.lda + (p.M - m0)) * 2;
       return __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t *>(Ab + (long long)kbeg * p.lda + m0), 0, live ? (int)min(bytes, 0x7fffffffLL) : 0, 0x00020000);
@@ -166,8 +179,8 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmParams p) {
   };
   auto make_b = [&](int n0, bool live) __attribute__((always_inline)) {
     if constexpr (!BMM) {
-      const long long bytes = ((long long)(min(TN, p.N - n0) - 1) * p.ldb + p.K) * 2;
-      return __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t *>(Bb + (long long)n0 * p.ldb), 0, live ? (int)min(bytes, 0x7fffffffLL) : 0, 0x00020000);
+      const long long bytes = ((long long)(min(TN, p.N - n0) - 1) * p.ldb + (kend - kbeg)) * 2;
+      return __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t *>(Bb + (long long)n0 * p.ldb + kbeg), 0, live ? (int)min(bytes, 0x7fffffffLL) : 0, 0x00020000);
     } else {
       const long long bytes = ((long long)(kend - kbeg - 1) * p.ldb + (p.N - n0)) * 2;
       return __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t *>(Bb + (long long)kbeg * p.ldb + n0), 0, live ? (int)min(bytes, 0x7fffffffLL) : 0, 0x00020000);
@@ -376,13 +389,14 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmParams p) {
     int lane = lane_outer;
     asm volatile("" : "+v"(lane) : "v"(tv[0]), "v"(tv[1]), "v"(tv[2]), "v"(tv[3]), "v"(tv[4]), "v"(tv[5]));
     const int g = lane >> 4, li = lane & 15;
-    const bool split = AMM && p.split_k > 1;
-    const bool c32 = AMM ? true : (RT ? (p.c_dtype == DM_F32) : C32);
+    const bool split = p.split_k > 1;
+    const bool c32 = (AMM || split) ? true : (RT ? (p.c_dtype == DM_F32) : C32);
     const bool x32 = RT ? (p.aux_dtype == DM_F32) : (YL == 3 || XS == 2);
-    const bool has_res = !AMM && (RT ? (p.residual != nullptr) : RES);
-    const bool has_acc = RT ? (c32 && p.accumulate && !split) : (YL == 1);
-    const bool aux_load = !AMM && (RT ? (p.aux && (p.epilogue == DM_EPI_DGELU || p.epilogue == DM_EPI_MUL)) : (YL >= 2));
-    const bool aux_store = !AMM && (RT ? (p.aux && (p.epilogue == DM_EPI_GELU || p.epilogue == DM_EPI_GELU_GRAD)) : (XS != 0));
+    const bool plain = AMM || split;                       // no fused epilogue: partial tile / weight gradient
+    const bool has_res = !plain && (RT ? (p.residual != nullptr) : RES);
+    const bool has_acc = !split && (RT ? (c32 && p.accumulate) : (YL == 1));
+    const bool aux_load = !plain && (RT ? (p.aux && (p.epilogue == DM_EPI_DGELU || p.epilogue == DM_EPI_MUL)) : (YL >= 2));
+    const bool aux_store = !plain && (RT ? (p.aux && (p.epilogue == DM_EPI_GELU || p.epilogue == DM_EPI_GELU_GRAD)) : (XS != 0));
     const int csz = c32 ? 4 : 2, xsz = x32 ? 4 : 2;
     const int m_base = m_cur + wm * 128, n_base = n_cur;            // wave-uniform (wave id through readfirstlane)
     const bool live = m_base < p.M;
@@ -414,7 +428,7 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmParams p) {
       sl0[q3] = row * 768 + (((2 * cg) ^ (row & 7)) << 4);
       sl1[q3] = row * 768 + (((2 * cg + 1) ^ (row & 7)) << 4);
       b_lo[q3] = b_hi[q3] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      if (!AMM && p.bias && !kill) { b_lo[q3] = dm_load4(p.bias + n_base + cg * 8); b_hi[q3] = dm_load4(p.bias + n_base + cg * 8 + 4); }
+      if (!plain && p.bias && !kill) { b_lo[q3] = dm_load4(p.bias + n_base + cg * 8); b_hi[q3] = dm_load4(p.bias + n_base + cg * 8 + 4); }
     }
     auto prefetch = [&](DmEpiPre &pre, int i, int q3) __attribute__((always_inline)) {
       if (has_res) {
@@ -436,7 +450,7 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmParams p) {
     };
     auto emit = [&](f32x4 lo, f32x4 hi, const DmEpiPre &pre, int i, int q3) __attribute__((always_inline)) {
       lo += b_lo[q3]; hi += b_hi[q3];
-      if (!AMM && p.epilogue == DM_EPI_GELU) {
+      if (!plain && p.epilogue == DM_EPI_GELU) {
         if (aux_store) {
           if (x32) {
             DM_EPI_BSTORE(__builtin_bit_cast(u32x4, lo), rsX, oX[q3], i * stepX, 0);
@@ -447,7 +461,7 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmParams p) {
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e) { lo[e] = dm_gelu_fast(lo[e]); hi[e] = dm_gelu_fast(hi[e]); }
-      } else if (!AMM && p.epilogue == DM_EPI_GELU_GRAD) {
+      } else if (!plain && p.epilogue == DM_EPI_GELU_GRAD) {
         f32x4 dl, dh;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -557,9 +571,9 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmParams p) {
         const f32x4 lo = *reinterpret_cast<const f32x4 *>(slab + row * 768 + (((2 * cg) ^ (row & 7)) << 4));
         const f32x4 hi = *reinterpret_cast<const f32x4 *>(slab + row * 768 + (((2 * cg + 1) ^ (row & 7)) << 4));
         int m = m_pair + i * 16 + row;
-        if constexpr (AMM) {
+        if (AMM || p.split_k > 1) {
           // wgrad: fp32 partial tile into slab z of the split-K workspace (summed in slice order by splitk_reduce_kernel), or,
-          // unsplit, straight into the gradient
+          // unsplit, straight into the gradient (a sliced forward / dgrad product always writes the slab)
           if (m < p.M) {
             const int n = n_cur + cg * 8;
             if (p.split_k > 1) {
@@ -648,7 +662,7 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmParams p) {
 
   // K % 128 == 0 (plan): a tile is an even number of K steps, so tiles end after an odd step only
   for (int step = 0; step < total; step += 2) {
-    if constexpr (!AMM) { if (kt + 2 == ntile) touch_epilogue_operands(); }
+    if constexpr (!AMM) { if (kt + 2 == ntile && p.split_k <= 1) touch_epilogue_operands(); }
     body(IC<0>{});
     body(IC<1>{});
     kt += 2;
@@ -738,6 +752,36 @@ int dm_gemm_w4_plan(GemmParams &p, int layout, int ab_dtype, bool aligned8, bool
   const long long tiles = (long long)tiles_m * tiles_n;
   const int cus = w4_cu_count();
   if (cus <= 0) return 0;
+  {
+    // Round 4: few tiles and a long contraction (the 4096-token stage's fc2 forward, fc1 / qkv dgrad: 64 tiles, K = 2304 .. 4096):
+    // one (tile, K slice) per workgroup as for the weight gradients, <= 4 slices of an even number (>= 8) of K steps; dm_gemm sums
+    // the slab and applies the fused epilogue (splitk_epilogue_kernel).  `can_split`: the caller allows it (automatic slice count,
+    // 8-column epilogue legal, workspace present).
+    // Measured in the step (tools/prof_shapes.py, same box): 4096 x 768 x 3072 54 us sliced against 47 us on unsplit 64 x 64 tiles (fc1
+    // dgrad 51 / 44, qkv dgrad 42 / 35): 256 workgroups x 12 K steps pay the kernel's fill and a 192 KiB fp32 slab each, then the 63 MB
+    // reduction -- OFF by default (DM_GEMM_W4_SLICES=1 for A/B runs); the M <= 1024 products gain from slices on 64 x 64 tiles instead.
+    static const bool slices_on = [] { const char *e = getenv("DM_GEMM_W4_SLICES"); return e && atoi(e) == 1; }();
+    constexpr long long LIM = (1LL << 31) / (128LL * 4);
+    if (slices_on && can_split && mode != 0 && tiles * 2 <= cus && p.K >= 1536 && p.N < LIM && !(p.debug & 0x400)) {
+      const int steps = p.K / BK;
+      int split = (int)(cus / tiles);
+      if (split > 4) split = 4;
+      int per = (steps + split - 1) / split;
+      per += per & 1;
+      if (per < 8) per = 8;
+      split = (steps + per - 1) / per;
+      if (split > 1 && (long long)split * p.M * p.N * 4 <= workspace_bytes && (double)(tiles * split) / cus >= 0.7) {
+        static const bool attr_sl = w4_set_lds_limit<DM_NT, 0, 9>() && w4_set_lds_limit<DM_NN, 0, 9>();
+        if (attr_sl) {
+          p.tiles_m = tiles_m;
+          p.tiles_n = tiles_n;
+          p.split_k = split;
+          p.k_per_split = per * BK;
+          return (int)(tiles * split);
+        }
+      }
+    }
+  }
   if (mode == 1 || mode == 4 || mode == 5) {
     // One workgroup per CU, all of them in lockstep: a tile's stores (25 MB per round of the chip) are not hidden by anybody's MFMAs,
     // ~10 us per round (tools/mb_w4_loop.py).  With ONE tile per workgroup that is paid once and the deep operand pipeline wins
@@ -784,11 +828,19 @@ void dm_gemm_w4_launch(const GemmParams &p, int layout, int grid, hipStream_t s)
   const int yl = (c32 && p.accumulate && p.split_k <= 1) ? 1 : aux_read ? (x32 ? 3 : 2) : 0;
   const int xs = aux_write ? (x32 ? 2 : 1) : 0;
   const int key = (p.residual ? 1 : 0) | (yl << 1) | ((c32 ? 1 : 0) << 3) | (xs << 4);
-#define W4_GO(LAY, EKV) hipLaunchKernelGGL((dmw4::gemm_w4_kernel<LAY, 0, EKV>), dim3(grid), dim3(256), dmw4::LDS_BYTES, s, p)
+  GemmParams q = p;
+  {
+    const char *senv = getenv("DM_W4_STAGGER");
+    const int stag = senv ? atoi(senv) : 0;
+    if (stag > 0 && layout != DM_TN && q.tiles_m * q.tiles_n > grid) q.debug |= (stag & 0x7fff) << 16;      // multi-tile forward / dgrad launches only
+  }
+#define W4_GO(LAY, EKV) hipLaunchKernelGGL((dmw4::gemm_w4_kernel<LAY, 0, EKV>), dim3(grid), dim3(256), dmw4::LDS_BYTES, s, q)
   if (layout == DM_TN) {
     if (lean_ok && key == 8) W4_GO(DM_TN, 9);             // fp32 slab / gradient written
     else if (lean_ok && key == 10) W4_GO(DM_TN, 11);      // fp32 gradient accumulated in place
     else W4_GO(DM_TN, 0);
+  } else if (p.split_k > 1) {                             // sliced forward / dgrad: fp32 partial tile into the slab
+    if (layout == DM_NT) W4_GO(DM_NT, 9); else W4_GO(DM_NN, 9);
   } else if (layout == DM_NT) {
     if (lean_ok && key == 0) W4_GO(DM_NT, 1);             // bf16 C
     else if (lean_ok && key == 9) W4_GO(DM_NT, 10);       // fp32 C + fp32 residual: fc2 / proj forward

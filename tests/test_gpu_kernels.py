@@ -753,6 +753,56 @@ def test_gemm256_pipeline_exact_and_epilogues(M, N, K):
     assert float((h.float() - want_h).abs().max()) <= 2.0 ** -7 * float(want_h.abs().max())
 
 
+@pytest.mark.parametrize("layout", ["NT", "NN"])
+@pytest.mark.parametrize("M,N,K", [(4096, 768, 3072), (1024, 768, 3072), (4096, 768, 2304), (1000, 776, 1600), (4096, 768, 4096)])
+def test_gemm_forward_k_slices_exact_and_epilogues(layout, M, N, K):
+    """Round 4: forward / dgrad products with a long contraction and a small output (the 4096- / 1024-token stages' fc2 forward
+    nets/ShfitScaleFormer.py:55, fc1 / qkv dgrad, the patch embed :28-37) run as K slices: fp32 partial tiles + splitk_epilogue_kernel.
+    Exact on integer data for every fused epilogue, ragged M / N, grouped rows; run-to-run identical; the plan reports its workspace."""
+    ops = _ops()
+    from deepmerge_amd import _lib
+    from deepmerge_amd._lib import DM_EPI_GELU_GRAD, DM_EPI_MUL, DM_NN, DM_NT
+    lay = DM_NT if layout == "NT" else DM_NN
+    assert _lib.lib().dm_gemm_workspace_bytes(lay, M, N, K) >= 2 * M * N * 4          # a slab of >= 2 slices: the split is planned
+    g = torch.Generator(device=DEV); g.manual_seed(M + N + K)
+    a = torch.randint(-2, 3, (M, K), device=DEV, generator=g).to(torch.bfloat16)
+    if layout == "NT":
+        b = torch.randint(-2, 3, (N, K), device=DEV, generator=g).to(torch.bfloat16)
+        ref, ldb = a.float() @ b.float().T, K
+    else:
+        b = torch.randint(-2, 3, (K, N), device=DEV, generator=g).to(torch.bfloat16)
+        ref, ldb = a.float() @ b.float(), N
+    outs = []
+    for _ in range(2):
+        out = torch.empty((M, N), device=DEV, dtype=torch.bfloat16)
+        ops.gemm(lay, a, b, out, M, N, K, lda=K, ldb=ldb, ldc=N)
+        outs.append(out)
+    assert torch.equal(outs[0], ref.to(torch.bfloat16)) and torch.equal(outs[0], outs[1])
+    bias = torch.randint(-3, 4, (N,), device=DEV, generator=g).float()
+    res = torch.randint(-5, 6, (M, N), device=DEV, generator=g).float()
+    out32 = torch.empty((M, N), device=DEV)
+    ops.gemm(lay, a, b, out32, M, N, K, lda=K, ldb=ldb, ldc=N, bias=bias, residual=res)      # fc2 forward form
+    assert torch.equal(out32, ref + bias + res)
+    aux = torch.randint(-2, 3, (M, N), device=DEV, generator=g).to(torch.bfloat16)
+    outm = torch.empty((M, N), device=DEV, dtype=torch.bfloat16)
+    ops.gemm(lay, a, b, outm, M, N, K, lda=K, ldb=ldb, ldc=N, epilogue=DM_EPI_MUL, aux=aux, ldaux=N)      # dgrad x saved GELU' form
+    assert torch.equal(outm, (ref * aux.float()).to(torch.bfloat16))
+    a2 = (a.float() * 0.125).to(torch.bfloat16)
+    d = torch.empty((M, N), device=DEV, dtype=torch.bfloat16)
+    h = torch.empty((M, N), device=DEV, dtype=torch.bfloat16)
+    ops.gemm(lay, a2, b, h, M, N, K, lda=K, ldb=ldb, ldc=N, bias=bias, epilogue=DM_EPI_GELU_GRAD, aux=d, ldaux=N)
+    pre = (ref * 0.125 + bias).double()
+    want_h = torch.nn.functional.gelu(pre).float()
+    want_d = (0.5 * (1 + torch.erf(pre / 2 ** 0.5)) + pre * torch.exp(-0.5 * pre * pre) / (2 * torch.pi) ** 0.5).float()
+    assert float((h.float() - want_h).abs().max()) <= 2.0 ** -7 * float(want_h.abs().max())
+    assert float((d.float() - want_d).abs().max()) <= 2.0 ** -7
+    if M % 64 == 0 and layout == "NT":          # grouped rows: tokens written at their offset of a wider cube (patch-embed form, :869-882)
+        T, S = 64, 3
+        cube = torch.zeros((M // T, S * T, N), device=DEV)
+        ops.gemm(lay, a, b, cube.view(-1)[T * N:], M, N, K, lda=K, ldb=ldb, ldc=N, bias=bias, rows_per_group=T, group_stride=S * T * N)
+        assert torch.equal(cube[:, T:2 * T, :].reshape(M, N), ref + bias) and float(cube[:, :T].abs().max()) == 0 and float(cube[:, 2 * T:].abs().max()) == 0
+
+
 def test_gemm256_pipeline_wgrad_and_dgrad_layouts():
     """The m-contiguous images of the 256x256 pipeline (hardware-transposed LDS reads): TN with split-K + accumulate
     (wgrad of a 16384-token stage) and NN with many tiles, exact on integer data and run-to-run identical."""

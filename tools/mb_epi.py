@@ -43,7 +43,12 @@ def bench(name, lay, M, N, K, variant, tile=None):
     print(f"{name:10s} {['NT','NN','TN'][lay]} {M}x{N}x{K} {variant:9s} tile={tile or 'auto':>4}: {dt*1e6:7.1f} us  {2.0*M*N*K/dt/1e12:7.1f} TF/s", flush=True)
 
 which = sys.argv[1] if len(sys.argv) > 1 else "epi"
-if which == "epi":
+if which == "w4set":          # the multi-tile K = 768 products (w4 under DM_GEMM_W4=3) with their step epilogues
+    bench("fc1", DM_NT, 16384, 3072, 768, "gelu_grad")
+    bench("fc1", DM_NT, 16384, 3072, 768, "none")
+    bench("dfc2", DM_NN, 16384, 3072, 768, "mul")
+    bench("qkv", DM_NT, 16384, 2304, 768, "bias")
+elif which == "epi":
     for v in ("none", "bias", "gelu", "gelu_grad"):
         for tile in (None, 128):
             bench("fc1", DM_NT, 16384, 3072, 768, v, tile)
