@@ -107,6 +107,17 @@ template <bool MM, bool IS_B> struct Operand {
       }
     }
   }
+  // persistent kernel: panel start / extent of another tile (whole K; the per-lane offsets above do not depend on the tile as long as
+  // no column of an m-contiguous panel lies past the operand: the plan requires N % 256 == 0 for that kernel)
+  __device__ __forceinline__ void retile(const bf16_t *base, long long ld, int o0, int extent, int K) {
+    if constexpr (!MM) {
+      pnl = base + (long long)o0 * ld;
+      nbytes = (int)min(((long long)(min(T256, extent - o0) - 1) * ld + K) * 2, 0x7fffffffLL);
+    } else {
+      pnl = base + o0;
+      nbytes = (int)min(((long long)(K - 1) * ld + (extent - o0)) * 2, 0x7fffffffLL);
+    }
+  }
   // LDS byte offset (inside an operand image) of DMA piece u for this wave
   __device__ __forceinline__ static int piece_offset(int u, int wave) { return MM ? u * 8192 + wave * 1024 : (64 * u + 8 * wave) * 128; }
 
@@ -330,9 +341,189 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
   }
 }
 
+// ---- persistent form (round 4): forward (NT) and dgrad (NN) products with several tiles per CU ------------------------------------
+// One workgroup per CU walks its tiles (L, L + G, ...) as ONE flattened sequence of K tiles: the LDS-DMA of the next tile's first two K
+// tiles is issued during the current tile's last two (same phases, same hazard table as above -- the buffer is the flattened index & 1),
+// so only the first tile of a launch pays a cold fill; the epilogue runs between two K tiles through a wave-PRIVATE 4 KiB staging block
+// outside the K-tile buffers (2 x 64 KiB + 8 x 4 KiB = exactly 160 KiB; 16 rows x 256 B, XOR-swizzled: dm_epi_slot) in the lean form
+// of dm_gemm_common.h, without barriers, while those DMA pieces land.  Measured per tile before (one workgroup per tile): ~20 us of
+// fill + drain + epilogue around 12 x 1.2 us of K loop at K = 768.
+constexpr int EPI_P = 16 * 256;                          // one wave's staging block
+constexpr int LDS256P = 2 * BUF_BYTES + 8 * EPI_P;       // 163840
+
+template <int LAYOUT>
+__global__ __launch_bounds__(512) void gemm256p_kernel(const GemmParams p) {
+  static_assert(LAYOUT != DM_TN, "weight gradients keep the one-tile form (split-K)");
+  constexpr bool BMM = (LAYOUT != DM_NT);
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+
+  const int G = gridDim.x;
+  const int L = dm_xcd_remap(blockIdx.x, G);
+  const int tiles = p.tiles_m * p.tiles_n;
+  const int ntile = p.K / BK256;
+  const int n_my = (tiles - L + G - 1) / G;
+  const int total = n_my * ntile;
+  auto tile_mn = [&](int r, int &m0, int &n0) {
+    const int id = L + r * G;
+    int tm, tn;
+    if (p.group_m > 0) {
+      const int band = id / (p.group_m * p.tiles_n);
+      const int within = id - band * (p.group_m * p.tiles_n);
+      const int gsz = min(p.group_m, p.tiles_m - band * p.group_m);
+      tn = within / gsz;
+      tm = band * p.group_m + (within - tn * gsz);
+    } else {
+      tn = id % p.tiles_n;
+      tm = id / p.tiles_n;
+    }
+    m0 = tm * T256;
+    n0 = tn * T256;
+  };
+  int m_cur, n_cur;
+  tile_mn(0, m_cur, n_cur);
+  const bf16_t *Ab = reinterpret_cast<const bf16_t *>(p.A), *Bb = reinterpret_cast<const bf16_t *>(p.B);
+  Operand<false, false> opA;
+  Operand<BMM, true> opB;
+  opA.setup(Ab, p.lda, m_cur, p.M, 0, p.K, wave, lane, wr);
+  opB.setup(Bb, p.ldb, n_cur, p.N, 0, p.K, wave, lane, wc);
+  // descriptors of the tile being computed (c) and of the next one (n): staging looks at most two K tiles ahead
+  __amdgpu_buffer_rsrc_t rsAc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t *>(opA.pnl), 0, opA.nbytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t rsBc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t *>(opB.pnl), 0, opB.nbytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t rsAn = rsAc, rsBn = rsBc;
+  auto make_next = [&](int r) {
+    if (r < n_my) {
+      int m0, n0;
+      tile_mn(r, m0, n0);
+      opA.retile(Ab, p.lda, m0, p.M, p.K);
+      opB.retile(Bb, p.ldb, n0, p.N, p.K);
+      rsAn = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t *>(opA.pnl), 0, opA.nbytes, 0x00020000);
+      rsBn = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t *>(opB.pnl), 0, opB.nbytes, 0x00020000);
+    }
+  };
+  make_next(1);
+  int kt = 0, r = 0, flat = 0;
+  // piece u of the A (which = 0) / B (which = 1) image of the K tile d steps ahead of the current one (d = 0 only in the prologue)
+  auto stage = [&](int d, int which, int u) {
+    int kk = kt + d;
+    const bool nx = kk >= ntile;
+    if (nx) kk -= ntile;
+    char *buf = smem + ((flat + d) & 1) * BUF_BYTES;
+    if (which == 0) {
+      if (nx) DM_LDS_DMA(rsAn, buf + opA.piece_offset(u, wave), (int)opA.vo[u], (int)(kk * opA.tile_step));
+      else DM_LDS_DMA(rsAc, buf + opA.piece_offset(u, wave), (int)opA.vo[u], (int)(kk * opA.tile_step));
+    } else {
+      if (nx) DM_LDS_DMA(rsBn, buf + OPER_BYTES + opB.piece_offset(u, wave), (int)opB.vo[u], (int)(kk * opB.tile_step));
+      else DM_LDS_DMA(rsBc, buf + OPER_BYTES + opB.piece_offset(u, wave), (int)opB.vo[u], (int)(kk * opB.tile_step));
+    }
+  };
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  u32x4 fa[8], fb0[4], fb1[4];
+  constexpr bool AM = false;       // (the macros below were written for the one-tile kernel)
+  const bool colsum = false;
+  f32x4 accb[1];
+  const u32x4 ones = {0, 0, 0, 0};
+  (void)accb; (void)ones; (void)colsum;
+
+  // ---- prologue: all of K tile 0, and of K tile 1 everything except the A-sub1 pieces (staged in phase 0) ------------------------
+#pragma unroll
+  for (int u = 0; u < 4; ++u) { stage(0, 0, u); stage(0, 1, u); }
+  if (total > 1) {
+    stage(1, 0, 0); stage(1, 0, 2);
+    stage(1, 1, 0); stage(1, 1, 1);
+    stage(1, 1, 2); stage(1, 1, 3);
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __builtin_amdgcn_s_barrier();
+  if (wr == 1) __builtin_amdgcn_s_barrier();   // the second wave row runs one barrier behind the first
+
+  // (two nested loops on purpose: with the epilogue inside ONE flattened loop the compiler's waitcnt bookkeeping puts a vmcnt(2) for the
+  // epilogue's load destinations at the loop head -- every K tile then waits for the DMA pieces issued one phase earlier)
+  for (; r < n_my;) {
+  for (kt = 0; kt < ntile; ++kt, ++flat) {
+    const char *imgA = smem + (flat & 1) * BUF_BYTES;
+    const char *imgB = imgA + OPER_BYTES;
+    // phase 0: quadrant (0,0)
+    opB.template load<2>(fb0, imgB, 0, wc);
+    __builtin_amdgcn_sched_barrier(0);
+    opA.template load<4>(fa, imgA, 0, wr);
+    if (flat + 1 < total) { stage(1, 0, 1); stage(1, 0, 3); }
+    DM_PHASE_SYNC();
+    DM_QUAD(0, 0, fb0);
+    DM_PHASE_END();
+    // phase 1: quadrant (0,1)
+    opB.template load<2>(fb1, imgB, 1, wc);
+    DM_PHASE_SYNC();
+    DM_QUAD(0, 1, fb1);
+    DM_PHASE_END();
+    // phase 2: quadrant (1,1)
+    opA.template load<4>(fa, imgA, 1, wr);
+    if (flat + 2 < total) { stage(2, 0, 0); stage(2, 0, 2); stage(2, 1, 0); stage(2, 1, 1); }
+    DM_PHASE_SYNC();
+    DM_QUAD(1, 1, fb1);
+    DM_PHASE_END();
+    // phase 3: quadrant (1,0); retire the next K tile's DMA
+    if (flat + 2 < total) {
+      stage(2, 1, 2); stage(2, 1, 3);
+      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    DM_PHASE_SYNC();
+    DM_QUAD(1, 0, fb0);
+    DM_PHASE_END();
+
+  }
+    {
+      // tile finished: epilogue through this wave's private block (no barrier: the K-tile buffers are not touched and the next
+      // tile's first two K tiles keep landing); the stores are waited for by the counted vmcnt of the next K tile's phase 3
+      kt = ntile;         // (stage() is not called here; keeps the cursor meaningful for readers)
+      dm_epilogue_rows<8, 16, false, 256, true, true>(p, acc, smem + 2 * BUF_BYTES + wave * EPI_P, m_cur + wr * 128, n_cur + wc * 64, lane);
+      // A wait the COMPILER sees (the builtin, not asm): every specialised item structure issues at least two stores behind its last
+      // load, so vmcnt(2) proves all VGPR-destination loads of the epilogue complete on every path.  Without it the waitcnt pass
+      // assumes they may be pending at the K loop's head and puts a vmcnt(2) THERE -- executed every K tile, against the DMA queue.
+      __builtin_amdgcn_s_waitcnt(0x0F72);      // vmcnt(2) expcnt(7) lgkmcnt(15)
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      ++r;
+      if (r < n_my) tile_mn(r, m_cur, n_cur);
+      rsAc = rsAn;
+      rsBc = rsBn;
+      make_next(r + 1);
+    }
+  }
+  if (wr == 0) __builtin_amdgcn_s_barrier();   // balance the stagger
+}
+
 }  // namespace dm256
 
 namespace {
+template <int LAYOUT> bool set_lds_limit_p() {
+  return hipFuncSetAttribute(reinterpret_cast<const void *>(dm256::gemm256p_kernel<LAYOUT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                             dm256::LDS256P) == hipSuccess;
+}
+int p256_cu_count() {
+  static const int n = [] {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+    const char *e = getenv("DM_GEMM_CUS_RESERVED");
+    const int rsv = e ? atoi(e) : 0;
+    return (rsv > 0 && rsv < cus) ? cus - rsv : cus;
+  }();
+  return n;
+}
 template <int LAYOUT> bool set_lds_limit() {
   return hipFuncSetAttribute(reinterpret_cast<const void *>(dm256::gemm256_kernel<LAYOUT>), hipFuncAttributeMaxDynamicSharedMemorySize,
                              dm256::LDS256) == hipSuccess;
@@ -343,7 +534,8 @@ using namespace dm256;
 // Decides whether the 256x256 pipeline runs this product and, if so, fills p.tiles_m / tiles_n / split_k / k_per_split.
 // Called by dm_gemm after argument validation (alignment, N % 4, ...).
 bool dm_gemm256_plan(GemmParams &p, int layout, int ab_dtype, bool can_split, long long workspace_bytes, int user_split) {
-  static const int mode = [] { const char *e = getenv("DM_GEMM_256"); return e ? atoi(e) : 1; }();   // 0 = off, 2 = always (A/B runs)
+  const char *menv = getenv("DM_GEMM_256");              // 0 = off, 2 = always (A/B runs); read per call: tests flip it
+  const int mode = menv ? atoi(menv) : 1;
   if (mode == 0 || ab_dtype != DM_BF16) return false;
   if (p.K < BK256) return false;
   const bool am = layout == DM_TN, bm = layout != DM_NT;
@@ -404,6 +596,30 @@ void dm_gemm256_launch(const GemmParams &p_in, int layout, hipStream_t s) {
   GemmParams p = p_in;
   static const int gm = [] { const char *e = getenv("DM_GEMM_256_GROUP_M"); return e ? atoi(e) : -1; }();
   if (gm >= 0) p.group_m = gm;
+  {
+    // persistent form: forward / dgrad, more tiles than CUs, the whole-line 8-column epilogue legal, no ragged N.  OFF by default
+    // (DM_GEMM_256P=1: where tiles > CUs; 2: every legal launch; read per call so tests can flip it).  Measured (tools/mb_epi.py w4set,
+    // cold operands, same box, persistent / one tile per workgroup): 16384 x 3072 x 768 plain 88-90 / 88-90 us, + GELU' 136-138 / 115-116,
+    // dgrad x GELU' 132 / 117, qkv + bias 78-80 / 73-76.  Staging the next tile's K tiles under the current tile's tail does NOT
+    // recover the ~15 us a tile spends outside its K loop: that time is the stores (128 KiB per tile at ~3.5 B/clk per CU), which only
+    // overlap with matrix work when accumulators are double-buffered; and the 16-row staging block makes the epilogue itself slower.
+    const char *penv = getenv("DM_GEMM_256P");
+    const int pmode = penv ? atoi(penv) : 0;
+    const int cus = p256_cu_count();
+    const long long tiles = (long long)p.tiles_m * p.tiles_n;
+    const bool rows_ok = (p.N % 8 == 0) && (p.ldc % 8 == 0) && (p.aux == nullptr || p.ldaux % 8 == 0) && (p.rows_per_group == 0 || p.group_stride % 8 == 0) &&
+                         (p.residual == nullptr || p.ldr % 8 == 0);
+    if (pmode != 0 && layout != DM_TN && p.split_k <= 1 && cus > 0 && (tiles > cus || pmode == 2) && p.N % 256 == 0 && p.K % BK256 == 0 && rows_ok &&
+        dm_epi_key_specialised(dm_epi_lean_key(p, 128))) {
+      static const bool attr_ok = set_lds_limit_p<DM_NT>() && set_lds_limit_p<DM_NN>();
+      if (attr_ok) {
+        const dim3 pg((unsigned)(tiles < cus ? tiles : cus));
+        if (layout == DM_NT) hipLaunchKernelGGL(dm256::gemm256p_kernel<DM_NT>, pg, dim3(512), LDS256P, s, p);
+        else hipLaunchKernelGGL(dm256::gemm256p_kernel<DM_NN>, pg, dim3(512), LDS256P, s, p);
+        return;
+      }
+    }
+  }
   const dim3 grid((unsigned)(p.tiles_m * p.tiles_n * p.split_k));
   switch (layout) {
     case DM_NT: hipLaunchKernelGGL(dm256::gemm256_kernel<DM_NT>, grid, dim3(512), LDS256, s, p); break;

@@ -207,7 +207,15 @@ __device__ __forceinline__ void dm_gemm_emit8(const GemmParams &p, f32x4 lo, f32
 }
 
 
-template <int WM, int ROWS, bool SKIP_STORES = false>
+// Staging layout of one wave: rows of PITCH bytes holding 64 fp32 columns.  SWZ = false: padded rows (PITCH = DM_EPI_PITCH = 272),
+// chunk c of a row at c * 16; SWZ = true: exact rows (PITCH = 256, for kernels whose LDS is full), the 16-byte chunk c of row r at
+// slot c ^ (r & 15) -- both patterns (ds_write_b128 of an accumulator tile: 16 rows x 4 chunks; ds_read_b128 of a row's chunk pair by 8
+// lanes x 8 rows) are conflict-free in the bank model of the guide.
+template <int PITCH, bool SWZ> __device__ __forceinline__ int dm_epi_slot(int row, int chunk) {
+  return row * PITCH + ((SWZ ? (chunk ^ (row & 15)) : chunk) << 4);
+}
+
+template <int WM, int ROWS, bool SKIP_STORES = false, int PITCH = DM_EPI_PITCH, bool SWZ = false>
 __device__ __forceinline__ void dm_epilogue_rows_generic(const GemmParams &p, f32x4 (&acc)[WM][4], char *mine, int m_wave, int n_wave, int lane) {
   const int g = lane >> 4, li = lane & 15;
   constexpr int PASS_TILES = ROWS / 16;
@@ -217,7 +225,7 @@ __device__ __forceinline__ void dm_epilogue_rows_generic(const GemmParams &p, f3
     for (int ii = 0; ii < PASS_TILES; ++ii)
 #pragma unroll
       for (int j = 0; j < 4; ++j)
-        *reinterpret_cast<f32x4 *>(mine + (ii * 16 + li) * DM_EPI_PITCH + (j * 16 + 4 * g) * 4) = acc[ps * PASS_TILES + ii][j];
+        *reinterpret_cast<f32x4 *>(mine + dm_epi_slot<PITCH, SWZ>(ii * 16 + li, j * 4 + g)) = acc[ps * PASS_TILES + ii][j];
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
     const int n = n_wave + (lane & 7) * 8;
@@ -225,8 +233,8 @@ __device__ __forceinline__ void dm_epilogue_rows_generic(const GemmParams &p, f3
     for (int r = 0; r < ROWS / 8; ++r) {
       const int row = r * 8 + (lane >> 3);
       const int m = m_wave + ps * ROWS + row;
-      const f32x4 lo = *reinterpret_cast<const f32x4 *>(mine + row * DM_EPI_PITCH + (lane & 7) * 32);
-      const f32x4 hi = *reinterpret_cast<const f32x4 *>(mine + row * DM_EPI_PITCH + (lane & 7) * 32 + 16);
+      const f32x4 lo = *reinterpret_cast<const f32x4 *>(mine + dm_epi_slot<PITCH, SWZ>(row, (lane & 7) * 2));
+      const f32x4 hi = *reinterpret_cast<const f32x4 *>(mine + dm_epi_slot<PITCH, SWZ>(row, (lane & 7) * 2 + 1));
       if constexpr (SKIP_STORES) { if (lo[0] == 12345.678f && m < p.M) dm_gemm_emit8(p, lo, hi, dm_gemm_row(p, m), n); }
       else if (m < p.M && n < p.N) dm_gemm_emit8(p, lo, hi, dm_gemm_row(p, m), n);
     }
@@ -270,7 +278,8 @@ __device__ __forceinline__ int dm_epi_records(long long bytes) { return (int)(by
 // item -- RES: fp32 residual read; YL: 0 none / 1 old C (accumulate) / 2 aux read, bf16 / 3 aux read, fp32; C32: fp32 C; XS: 0 no aux
 // store / 1 bf16 / 2 fp32 -- is a template argument, so every memory instruction is straight-line code with counted waits; only the
 // arithmetic kind (GELU / GELU' / multiply) stays a run-time branch.  dm_epilogue_rows dispatches the combinations the encoder uses.
-template <int WM, int ROWS, bool SKIP_STORES = false, bool RT = true, bool RES = false, int YL = 0, bool C32 = false, int XS = 0>
+template <int WM, int ROWS, bool SKIP_STORES = false, bool RT = true, bool RES = false, int YL = 0, bool C32 = false, int XS = 0,
+          int PITCH = DM_EPI_PITCH, bool SWZ = false>
 __device__ __forceinline__ void dm_epilogue_rows_lean(const GemmParams &p, f32x4 (&acc)[WM][4], char *mine, int m_wave_in, int n_wave_in, int lane) {
   // wave-uniform by construction, but derived from threadIdx in some callers: without the readfirstlane the descriptors below live
   // in VGPRs and every buffer access becomes a waterfall loop
@@ -300,8 +309,10 @@ __device__ __forceinline__ void dm_epilogue_rows_lean(const GemmParams &p, f32x4
   const unsigned voR = (unsigned)((rl * (int)p.ldr + c8 * 8) * 4) | kill;
   const unsigned voX = (unsigned)((rl * (int)p.ldaux + c8 * 8) * xsz) | kill;
   const int stepC = 8 * (int)p.ldc * csz, stepR = 8 * (int)p.ldr * 4, stepX = 8 * (int)p.ldaux * xsz;      // 8 rows
-  f32x4 b_lo = {0.f, 0.f, 0.f, 0.f}, b_hi = {0.f, 0.f, 0.f, 0.f};
-  if (p.bias && !kill) { b_lo = dm_load4(p.bias + n); b_hi = dm_load4(p.bias + n + 4); }
+  // bias of the lane's 8 columns, once per tile; through a descriptor too (a null one reads zeros: no branch in front of the items)
+  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.bias), 0, p.bias ? dm_epi_records((long long)p.N * 4) : 0, 0x00020000);
+  const f32x4 b_lo = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, (unsigned)(n * 4) | kill, 0, 0));
+  const f32x4 b_hi = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, ((unsigned)(n * 4) | kill) + 16, 0, 0));
 
   auto prefetch = [&](DmEpiPre &pre, int q) __attribute__((always_inline)) {
     if (has_res) {
@@ -386,7 +397,7 @@ __device__ __forceinline__ void dm_epilogue_rows_lean(const GemmParams &p, f32x4
     for (int ii = 0; ii < PASS_TILES; ++ii)
 #pragma unroll
       for (int j = 0; j < 4; ++j)
-        *reinterpret_cast<f32x4 *>(mine + (ii * 16 + li) * DM_EPI_PITCH + (j * 16 + 4 * g) * 4) = acc[ps * PASS_TILES + ii][j];
+        *reinterpret_cast<f32x4 *>(mine + dm_epi_slot<PITCH, SWZ>(ii * 16 + li, j * 4 + g)) = acc[ps * PASS_TILES + ii][j];
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -395,8 +406,8 @@ __device__ __forceinline__ void dm_epilogue_rows_lean(const GemmParams &p, f32x4
       if (q + 1 < Q) prefetch(pre[(q + 1) & 1], q + 1);          // (issued before this item's stores: see the header)
       __builtin_amdgcn_sched_barrier(0);
       const int row = r * 8 + rl;
-      const f32x4 lo = *reinterpret_cast<const f32x4 *>(mine + row * DM_EPI_PITCH + c8 * 32);
-      const f32x4 hi = *reinterpret_cast<const f32x4 *>(mine + row * DM_EPI_PITCH + c8 * 32 + 16);
+      const f32x4 lo = *reinterpret_cast<const f32x4 *>(mine + dm_epi_slot<PITCH, SWZ>(row, c8 * 2));
+      const f32x4 hi = *reinterpret_cast<const f32x4 *>(mine + dm_epi_slot<PITCH, SWZ>(row, c8 * 2 + 1));
       if constexpr (SKIP_STORES) { if (lo[0] == 12345.678f) emit(lo, hi, pre[q & 1], q); }
       else emit(lo, hi, pre[q & 1], q);
       __builtin_amdgcn_sched_barrier(0);
@@ -406,23 +417,36 @@ __device__ __forceinline__ void dm_epilogue_rows_lean(const GemmParams &p, f32x4
   }
 }
 
-// DM_GEMM_EPI_LEAN=0 in the environment selects the generic form everywhere (p.debug bit 0x400: A/B runs).
-template <int WM, int ROWS, bool SKIP_STORES = false>
-__device__ __forceinline__ void dm_epilogue_rows(const GemmParams &p, f32x4 (&acc)[WM][4], char *mine, int m_wave, int n_wave, int lane) {
-  constexpr long long LIM = (1LL << 31) / (16LL * WM * 4);
+// Structure key of an epilogue item (RES | YL << 1 | C32 << 3 | XS << 4) if the lean form's preconditions hold for a wave block of
+// `rows` rows, -1 otherwise (grouped rows, 32-bit offsets, DM_GEMM_EPI_LEAN=0 = p.debug bit 0x400).  Host and device.
+__host__ __device__ inline int dm_epi_lean_key(const GemmParams &p, int rows) {
+  const long long lim = (1LL << 31) / ((long long)rows * 4);
   const bool aux_read = p.aux && (p.epilogue == DM_EPI_DGELU || p.epilogue == DM_EPI_MUL);
   const bool aux_write = p.aux && (p.epilogue == DM_EPI_GELU || p.epilogue == DM_EPI_GELU_GRAD);
-  const bool lean = p.rows_per_group == 0 && !(p.debug & 0x400) && p.ldc < LIM && p.ldr < LIM && p.ldaux < LIM &&
+  const bool lean = p.rows_per_group == 0 && !(p.debug & 0x400) && p.ldc < lim && p.ldr < lim && p.ldaux < lim &&
                     !(aux_read && p.accumulate);          // (one prefetch slot serves the old C or the aux operand)
-  if (!lean) { dm_epilogue_rows_generic<WM, ROWS, SKIP_STORES>(p, acc, mine, m_wave, n_wave, lane); return; }
-  // structure key of an item: residual | old C | aux read (bf16 / fp32) | fp32 C | aux store (bf16 / fp32)
+  if (!lean) return -1;
   const bool c32 = p.c_dtype == DM_F32, x32 = p.aux_dtype == DM_F32;
   const int yl = (c32 && p.accumulate) ? 1 : aux_read ? (x32 ? 3 : 2) : 0;
   const int xs = aux_write ? (x32 ? 2 : 1) : 0;
-  const int key = (p.residual ? 1 : 0) | (yl << 1) | ((c32 ? 1 : 0) << 3) | (xs << 4);
+  return (p.residual ? 1 : 0) | (yl << 1) | ((c32 ? 1 : 0) << 3) | (xs << 4);
+}
+// the keys with a straight-line instance (every memory instruction unconditional, counted waits)
+__host__ __device__ inline bool dm_epi_key_specialised(int key) {
+  return key == 0 || key == (1 | (1 << 3)) || key == (1 << 3) || key == ((1 << 1) | (1 << 3)) || key == (1 << 4) || key == (2 << 1);
+}
+
+// LEAN_ONLY: the caller (a kernel whose K loop must not contain the generic form: the persistent LDS-DMA pipeline, where any load the
+// compiler cannot count drains the DMA queue at the loop head) guarantees on the host that dm_epi_key_specialised holds.
+template <int WM, int ROWS, bool SKIP_STORES = false, int PITCH = DM_EPI_PITCH, bool SWZ = false, bool LEAN_ONLY = false>
+__device__ __forceinline__ void dm_epilogue_rows(const GemmParams &p, f32x4 (&acc)[WM][4], char *mine, int m_wave, int n_wave, int lane) {
+  const int key = dm_epi_lean_key(p, 16 * WM);
+  if constexpr (!LEAN_ONLY) {
+    if (key < 0) { dm_epilogue_rows_generic<WM, ROWS, SKIP_STORES, PITCH, SWZ>(p, acc, mine, m_wave, n_wave, lane); return; }
+  }
 #define DM_EPI_CASE(RES, YL, C32, XS) \
   case ((RES) | ((YL) << 1) | ((C32) << 3) | ((XS) << 4)): \
-    dm_epilogue_rows_lean<WM, ROWS, SKIP_STORES, false, (RES) != 0, (YL), (C32) != 0, (XS)>(p, acc, mine, m_wave, n_wave, lane); break;
+    dm_epilogue_rows_lean<WM, ROWS, SKIP_STORES, false, (RES) != 0, (YL), (C32) != 0, (XS), PITCH, SWZ>(p, acc, mine, m_wave, n_wave, lane); break;
   switch (key) {
     DM_EPI_CASE(0, 0, 0, 0)      // bf16 C (+ bias / GELU without a saved derivative): qkv forward, the dgrads, inference fc1
     DM_EPI_CASE(1, 0, 1, 0)      // fp32 C + fp32 residual: proj / fc2 forward
@@ -430,7 +454,9 @@ __device__ __forceinline__ void dm_epilogue_rows(const GemmParams &p, f32x4 (&ac
     DM_EPI_CASE(0, 1, 1, 0)      // fp32 C accumulated in place
     DM_EPI_CASE(0, 0, 0, 1)      // bf16 C + bf16 aux written: fc1 forward (GELU + saved GELU')
     DM_EPI_CASE(0, 2, 0, 0)      // bf16 C, bf16 aux read: dgrad of fc2 (multiply by the saved GELU')
-    default: dm_epilogue_rows_lean<WM, ROWS, SKIP_STORES, true>(p, acc, mine, m_wave, n_wave, lane); break;
+    default:
+      if constexpr (!LEAN_ONLY) dm_epilogue_rows_lean<WM, ROWS, SKIP_STORES, true, false, 0, false, 0, PITCH, SWZ>(p, acc, mine, m_wave, n_wave, lane);
+      break;
   }
 #undef DM_EPI_CASE
 }

@@ -99,7 +99,7 @@ def test_two_ranks_segmented_graphs(tmp_path):
     out = str(tmp_path / "r0.pt")
     mp.spawn(_worker, args=(2, _free_port(), out, "fp32", True, 3), nprocs=2, join=True)
     got = torch.load(out)
-    assert got["buckets"] == 2 and got["calls"] == 2 * 3          # depth [1,1,1]: tail bucket + the one stage-0 block
+    assert got["buckets"] == 3 and got["calls"] == 3 * 3          # depth [1,1,1]: head + stages 1-2, the one stage-0 block, the patch embeds (round 4: their own bucket)
     from deepmerge_amd.trainer import PairTrainer
     net = _build("fp32")
     tr = PairTrainer(net, lr=1e-4)

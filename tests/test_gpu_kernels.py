@@ -803,6 +803,56 @@ def test_gemm_forward_k_slices_exact_and_epilogues(layout, M, N, K):
         assert torch.equal(cube[:, T:2 * T, :].reshape(M, N), ref + bias) and float(cube[:, :T].abs().max()) == 0 and float(cube[:, 2 * T:].abs().max()) == 0
 
 
+@pytest.mark.parametrize("layout,M,N,K", [("NT", 16384, 3072, 768), ("NN", 16384, 3072, 768), ("NT", 9000, 2304, 768), ("NN", 8200, 768, 2304),
+                                          ("NT", 16384, 768, 128)])
+def test_gemm256_persistent_pipeline_exact_and_epilogues(layout, M, N, K, monkeypatch):
+    """Round 4: the 256x256 LDS-DMA pipeline as a PERSISTENT kernel (several tiles per workgroup, the next tile's first K tiles staged
+    under the current tile's last ones, epilogue between two K tiles through a wave-private swizzled block): exact on integer data
+    for the fused epilogues of the 16384-token stage (nets/ShfitScaleFormer.py:53-56, :119, :134), ragged M, workgroups with
+    different tile counts, run-to-run identical."""
+    ops = _ops()
+    from deepmerge_amd._lib import DM_EPI_GELU_GRAD, DM_EPI_MUL, DM_NN, DM_NT
+    monkeypatch.setenv("DM_GEMM_256", "2")            # every legal product on the pipeline ...
+    monkeypatch.setenv("DM_GEMM_256P", "1")           # ... in its persistent form where tiles > CUs (off by default: no faster)
+    monkeypatch.setenv("DM_GEMM_W4", "0"); monkeypatch.setenv("DM_GEMM_RING", "0")
+    lay = DM_NT if layout == "NT" else DM_NN
+    g = torch.Generator(device=DEV); g.manual_seed(M + N + K)
+    a = torch.randint(-2, 3, (M, K), device=DEV, generator=g).to(torch.bfloat16)
+    if layout == "NT":
+        b = torch.randint(-2, 3, (N, K), device=DEV, generator=g).to(torch.bfloat16)
+        ref, ldb = a.float() @ b.float().T, K
+    else:
+        b = torch.randint(-2, 3, (K, N), device=DEV, generator=g).to(torch.bfloat16)
+        ref, ldb = a.float() @ b.float(), N
+    outs = []
+    for _ in range(2):
+        out = torch.empty((M, N), device=DEV, dtype=torch.bfloat16)
+        ops.gemm(lay, a, b, out, M, N, K, lda=K, ldb=ldb, ldc=N)
+        outs.append(out)
+    assert torch.equal(outs[0], ref.to(torch.bfloat16)) and torch.equal(outs[0], outs[1])
+    bias = torch.randint(-3, 4, (N,), device=DEV, generator=g).float()
+    res = torch.randint(-5, 6, (M, N), device=DEV, generator=g).float()
+    out32 = torch.empty((M, N), device=DEV)
+    ops.gemm(lay, a, b, out32, M, N, K, lda=K, ldb=ldb, ldc=N, bias=bias, residual=res)
+    assert torch.equal(out32, ref + bias + res)
+    outb = torch.empty((M, N), device=DEV, dtype=torch.bfloat16)
+    ops.gemm(lay, a, b, outb, M, N, K, lda=K, ldb=ldb, ldc=N, bias=bias)
+    assert torch.equal(outb, (ref + bias).to(torch.bfloat16))
+    aux = torch.randint(-2, 3, (M, N), device=DEV, generator=g).to(torch.bfloat16)
+    outm = torch.empty((M, N), device=DEV, dtype=torch.bfloat16)
+    ops.gemm(lay, a, b, outm, M, N, K, lda=K, ldb=ldb, ldc=N, epilogue=DM_EPI_MUL, aux=aux, ldaux=N)
+    assert torch.equal(outm, (ref * aux.float()).to(torch.bfloat16))
+    a2 = (a.float() * 0.125).to(torch.bfloat16)
+    d = torch.empty((M, N), device=DEV, dtype=torch.bfloat16)
+    h = torch.empty((M, N), device=DEV, dtype=torch.bfloat16)
+    ops.gemm(lay, a2, b, h, M, N, K, lda=K, ldb=ldb, ldc=N, bias=bias, epilogue=DM_EPI_GELU_GRAD, aux=d, ldaux=N)
+    pre = (ref * 0.125 + bias).double()
+    want_h = torch.nn.functional.gelu(pre).float()
+    want_d = (0.5 * (1 + torch.erf(pre / 2 ** 0.5)) + pre * torch.exp(-0.5 * pre * pre) / (2 * torch.pi) ** 0.5).float()
+    assert float((h.float() - want_h).abs().max()) <= 2.0 ** -7 * float(want_h.abs().max())
+    assert float((d.float() - want_d).abs().max()) <= 2.0 ** -7
+
+
 def test_gemm256_pipeline_wgrad_and_dgrad_layouts():
     """The m-contiguous images of the 256x256 pipeline (hardware-transposed LDS reads): TN with split-K + accumulate
     (wgrad of a 16384-token stage) and NN with many tiles, exact on integer data and run-to-run identical."""

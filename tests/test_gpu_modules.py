@@ -517,7 +517,7 @@ def test_segmented_graphs_equal_plain_step():
         assert float(l0) == float(l1) == float(l2) == float(l3)
     assert torch.equal(eager.fp.flat, seg_eager.fp.flat) and torch.equal(eager.fp.flat, seg_graph.fp.flat)
     assert torch.equal(eager.fp.flat, ov_graph.fp.flat) and torch.equal(eager.m, ov_graph.m) and torch.equal(eager.v, ov_graph.v)
-    assert len(ov_graph._graph["pieces"]) == 1 and len(ov_graph.bucket_slices) == 7
-    assert len(seg_graph._graph["pieces"]) == 1 + 6 and len(seg_graph.bucket_slices) == 7       # tail + the six stage-0 blocks
+    assert len(ov_graph._graph["pieces"]) == 1 and len(ov_graph.bucket_slices) == 8      # 6 stage-0 blocks + head + the patch embeds (round 4)
+    assert len(seg_graph._graph["pieces"]) == 1 + 7 and len(seg_graph.bucket_slices) == 8       # head + the six stage-0 blocks + the patch embeds
     sl = seg_graph.bucket_slices
     assert sl[0].start == 0 and sl[-1].stop == seg_graph.fp.total and all(x.stop == y.start for x, y in zip(sl[:-1], sl[1:]))

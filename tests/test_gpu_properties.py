@@ -216,4 +216,4 @@ def test_config5_model_full_size_properties():
         assert float(le) == float(lg) == float(ls)
         losses.append(float(le))
     assert torch.equal(eager.fp.flat, graph.fp.flat) and torch.equal(eager.fp.flat, seg.fp.flat)
-    assert len(seg.bucket_slices) == 7 and all(np.isfinite(losses)) and losses[2] != losses[0]
+    assert len(seg.bucket_slices) == 8 and all(np.isfinite(losses)) and losses[2] != losses[0]
