@@ -462,15 +462,17 @@ __global__ void colsum_rows_reduce_kernel(const float *__restrict__ rows, float 
 // the four waves of a workgroup split K four ways for one 16x16 output tile (each wave stages its own
 // 16x32 / 32x16 operand slices through a private LDS region), and the partial tiles are summed in a
 // fixed order before the epilogue.  FMA chains in k order within a wave; deterministic.
-template <int LAYOUT>
-__global__ __launch_bounds__(256) void sgemm_small_kernel(const GemmParams p) {
-  __shared__ float sa[4][32][17], sb[4][32][17];
-  __shared__ float red[4][16][17];
+// NW waves split K (4, or 16 for a long contraction: the 3840-wide head products walked 30 stages of two barriers per workgroup --
+// 15 us for 49 MFLOP; 16 waves walk 8).  The partial tiles are summed in wave order: deterministic for a given NW.
+template <int LAYOUT, int NW = 4>
+__global__ __launch_bounds__(64 * NW) void sgemm_small_kernel(const GemmParams p) {
+  __shared__ float sa[NW][32][17], sb[NW][32][17];
+  __shared__ float red[NW][16][17];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int m0 = blockIdx.y * 16, n0 = blockIdx.x * 16;
   const float *A = reinterpret_cast<const float *>(p.A);
   const float *B = reinterpret_cast<const float *>(p.B);
-  const int kq = ((p.K + 3) / 4 + 31) / 32 * 32;          // K slice per wave, multiple of 32
+  const int kq = ((p.K + NW - 1) / NW + 31) / 32 * 32;    // K slice per wave, multiple of 32
   const int kbeg = w * kq, kend = min(p.K, kbeg + kq);
   const int tx = lane & 15, ty = lane >> 4;                // lane computes rows 4ty..4ty+3 of column tx
   float acc[4] = {0.f, 0.f, 0.f, 0.f};
@@ -522,10 +524,15 @@ __global__ __launch_bounds__(256) void sgemm_small_kernel(const GemmParams p) {
 #pragma unroll
   for (int j = 0; j < 4; ++j) red[w][4 * ty + j][tx] = acc[j];
   __syncthreads();
+  if (threadIdx.x >= 256) return;                              // 16 x 16 outputs
   const int om = threadIdx.x >> 4, on = threadIdx.x & 15;
   const int m = m0 + om, n = n0 + on;
   if (m >= p.M || n >= p.N) return;
   float v = (red[0][om][on] + red[1][om][on]) + (red[2][om][on] + red[3][om][on]);
+  if constexpr (NW > 4) {
+#pragma unroll
+    for (int q = 4; q < NW; q += 4) v += (red[q][om][on] + red[q + 1][om][on]) + (red[q + 2][om][on] + red[q + 3][om][on]);
+  }
   if (p.bias) v += p.bias[n];
   const long long ro = (long long)m;
   if (p.epilogue == DM_EPI_GELU) {
@@ -673,9 +680,18 @@ extern "C" int dm_gemm(const DmGemmArgs *a, void *stream) {
     DM_REQUIRE(a->rows_per_group == 0, DM_ERR_UNSUPPORTED, "dm_gemm: grouped rows need the MFMA path");
     dim3 grid((a->N + 15) / 16, (a->M + 15) / 16);
     switch (a->layout) {
-      case DM_NT: hipLaunchKernelGGL((sgemm_small_kernel<DM_NT>), grid, dim3(256), 0, s, p); break;
-      case DM_NN: hipLaunchKernelGGL((sgemm_small_kernel<DM_NN>), grid, dim3(256), 0, s, p); break;
-      default: hipLaunchKernelGGL((sgemm_small_kernel<DM_TN>), grid, dim3(256), 0, s, p); break;
+      case DM_NT:
+        if (a->K >= 1024) hipLaunchKernelGGL((sgemm_small_kernel<DM_NT, 16>), grid, dim3(1024), 0, s, p);
+        else hipLaunchKernelGGL((sgemm_small_kernel<DM_NT>), grid, dim3(256), 0, s, p);
+        break;
+      case DM_NN:
+        if (a->K >= 1024) hipLaunchKernelGGL((sgemm_small_kernel<DM_NN, 16>), grid, dim3(1024), 0, s, p);
+        else hipLaunchKernelGGL((sgemm_small_kernel<DM_NN>), grid, dim3(256), 0, s, p);
+        break;
+      default:
+        if (a->K >= 1024) hipLaunchKernelGGL((sgemm_small_kernel<DM_TN, 16>), grid, dim3(1024), 0, s, p);
+        else hipLaunchKernelGGL((sgemm_small_kernel<DM_TN>), grid, dim3(256), 0, s, p);
+        break;
     }
     DM_LAUNCH_CHECK("dm_gemm(generic)");
     if (a->colsum_a) return dm_colsum(a->A, a->ab_dtype, a->lda, a->colsum_a, a->K, a->M, a->colsum_accumulate, cs_region, stream);

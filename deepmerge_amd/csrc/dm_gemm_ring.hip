@@ -185,7 +185,9 @@ int dm_gemm_ring_plan(GemmParams &p, int layout, int ab_dtype, bool aligned8) {
   // ... until the 128x128 kernel got the same whole-line epilogue (dm_gemm.hip): where its tiles make whole rounds of 3 workgroups per
   // CU it is now ahead inside the training step (tools/prof_shapes.py, per launch, same box: 16384 x 2304 90 -> 79 us,
   // 16384 x 3072 + GELU' 121 -> 116 us, 4096 x 3072 + GELU' 44 -> 36 us); 4096 x 2304 (576 tiles = 0.75 round) stays here (29 vs 31 us)
-  if (mode == 1 && ((long long)((p.M + 127) / 128) * ((p.N + 127) / 128)) % 768 == 0) return 0;
+  // Round 4, both kernels on the lean epilogue (dm_gemm_common.h), same box, per step: 16384 x 3072 + GELU' 0.353 ms on 128 x 128 tiles,
+  // 0.330 here (0.335 on the 256 x 256 pipeline); 16384 x 2304 0.235 / 0.235; 4096 x 3072 + GELU' 0.073 / 0.080 -> the widest product is back
+  if (mode == 1 && ((long long)((p.M + 127) / 128) * ((p.N + 127) / 128)) % 768 == 0 && !(p.N >= 3072 && p.M >= 8192)) return 0;
   int wm = t256 >= 384 ? 8 : 4;
   if (force == 8 || force == 4) wm = force;
   static const bool ok = dmring::set_lds_limit<8>() && dmring::set_lds_limit<4>();

@@ -48,6 +48,10 @@ if which == "w4set":          # the multi-tile K = 768 products (w4 under DM_GEM
     bench("fc1", DM_NT, 16384, 3072, 768, "none")
     bench("dfc2", DM_NN, 16384, 3072, 768, "mul")
     bench("qkv", DM_NT, 16384, 2304, 768, "bias")
+elif which == "proj":         # the one-round N = 768 products at 16384 tokens: tile choices
+    for tile in (None, 128, 64):
+        bench("proj", DM_NT, 16384, 768, 768, "res_f32", tile)
+        bench("projd", DM_NN, 16384, 768, 768, "none", tile)
 elif which == "epi":
     for v in ("none", "bias", "gelu", "gelu_grad"):
         for tile in (None, 128):
