@@ -263,10 +263,24 @@ __device__ __forceinline__ void dm_epilogue_rows_generic(const GemmParams &p, f3
 #ifndef DM_EPI_STORE_NOP
 #define DM_EPI_STORE_NOP "s_nop 7\n\ts_nop 7"
 #endif
+// DM_EPI_STORE_AUX: cache policy of the epilogue's stores (experiment builds: 2 = nt, 16 = sc1, 17 = sc0 sc1; default 0)
+#ifndef DM_EPI_STORE_AUX
+#define DM_EPI_STORE_AUX 0
+#endif
+// The operand an epilogue SAVES for the backward pass (fc1's GELU' / pre-activation: 100 MB per stage-0 block) is not read again before
+// the backward pass: non-temporal stores (nt) keep it from displacing what the next kernels read (-DDM_EPI_AUX_POLICY=0 for A/B builds).
+#ifndef DM_EPI_AUX_POLICY
+#define DM_EPI_AUX_POLICY 2
+#endif
+// cache policy of the epilogue's read-once operands (fp32 residual, the saved GELU'): nt like the saved operand's stores.  Step A/B on one box,
+// 100 steps x 3 alternating rounds: default 5.807 / 5.884 / 5.796 ms, nt aux stores 5.803 / 5.797 / 5.867, + nt loads 5.792 / 5.785 / 5.790 (-D...=0 for A/B builds)
+#ifndef DM_EPI_LOAD_POLICY
+#define DM_EPI_LOAD_POLICY 2
+#endif
 #define DM_EPI_BSTORE(data, rsrc, vo, so, aux)                                  \
   do {                                                                          \
     const u32x4 dm_bs_ = (data);                                                \
-    __builtin_amdgcn_raw_buffer_store_b128(dm_bs_, rsrc, vo, so, aux);          \
+    __builtin_amdgcn_raw_buffer_store_b128(dm_bs_, rsrc, vo, so, (aux) | DM_EPI_STORE_AUX); \
     asm volatile(DM_EPI_STORE_NOP ::"v"(dm_bs_) : "memory");                    \
   } while (0)
 struct DmEpiPre { f32x4 r0, r1; u32x4 y0, y1; };      // residual; the old C (accumulate) OR the aux operand (never both: see dm_epilogue_rows)
@@ -316,16 +330,16 @@ __device__ __forceinline__ void dm_epilogue_rows_lean(const GemmParams &p, f32x4
 
   auto prefetch = [&](DmEpiPre &pre, int q) __attribute__((always_inline)) {
     if (has_res) {
-      pre.r0 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsR, voR, q * stepR, 0));
-      pre.r1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsR, voR + 16, q * stepR, 0));
+      pre.r0 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsR, voR, q * stepR, DM_EPI_LOAD_POLICY));
+      pre.r1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsR, voR + 16, q * stepR, DM_EPI_LOAD_POLICY));
     }
     if (has_acc) {
       pre.y0 = __builtin_amdgcn_raw_buffer_load_b128(rsC, voC, q * stepC, 0);
       pre.y1 = __builtin_amdgcn_raw_buffer_load_b128(rsC, voC + 16, q * stepC, 0);
     }
     if (aux_load) {
-      pre.y0 = __builtin_amdgcn_raw_buffer_load_b128(rsX, voX, q * stepX, 0);
-      if (x32) pre.y1 = __builtin_amdgcn_raw_buffer_load_b128(rsX, voX + 16, q * stepX, 0);
+      pre.y0 = __builtin_amdgcn_raw_buffer_load_b128(rsX, voX, q * stepX, DM_EPI_LOAD_POLICY);
+      if (x32) pre.y1 = __builtin_amdgcn_raw_buffer_load_b128(rsX, voX + 16, q * stepX, DM_EPI_LOAD_POLICY);
     }
   };
   auto pack8 = [](const f32x4 &a, const f32x4 &b) __attribute__((always_inline)) {
@@ -337,10 +351,10 @@ __device__ __forceinline__ void dm_epilogue_rows_lean(const GemmParams &p, f32x4
     if (p.epilogue == DM_EPI_GELU) {
       if (aux_store) {
         if (x32) {
-          DM_EPI_BSTORE(__builtin_bit_cast(u32x4, lo), rsX, voX, q * stepX, 0);
-          DM_EPI_BSTORE(__builtin_bit_cast(u32x4, hi), rsX, voX + 16, q * stepX, 0);
+          DM_EPI_BSTORE(__builtin_bit_cast(u32x4, lo), rsX, voX, q * stepX, DM_EPI_AUX_POLICY);
+          DM_EPI_BSTORE(__builtin_bit_cast(u32x4, hi), rsX, voX + 16, q * stepX, DM_EPI_AUX_POLICY);
         } else {
-          DM_EPI_BSTORE(pack8(lo, hi), rsX, voX, q * stepX, 0);
+          DM_EPI_BSTORE(pack8(lo, hi), rsX, voX, q * stepX, DM_EPI_AUX_POLICY);
         }
       }
 #pragma unroll
@@ -359,10 +373,10 @@ __device__ __forceinline__ void dm_epilogue_rows_lean(const GemmParams &p, f32x4
       }
       if (aux_store) {
         if (x32) {
-          DM_EPI_BSTORE(__builtin_bit_cast(u32x4, dl), rsX, voX, q * stepX, 0);
-          DM_EPI_BSTORE(__builtin_bit_cast(u32x4, dh), rsX, voX + 16, q * stepX, 0);
+          DM_EPI_BSTORE(__builtin_bit_cast(u32x4, dl), rsX, voX, q * stepX, DM_EPI_AUX_POLICY);
+          DM_EPI_BSTORE(__builtin_bit_cast(u32x4, dh), rsX, voX + 16, q * stepX, DM_EPI_AUX_POLICY);
         } else {
-          DM_EPI_BSTORE(pack8(dl, dh), rsX, voX, q * stepX, 0);
+          DM_EPI_BSTORE(pack8(dl, dh), rsX, voX, q * stepX, DM_EPI_AUX_POLICY);
         }
       }
     } else if (aux_load) {

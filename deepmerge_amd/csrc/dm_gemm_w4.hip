@@ -432,16 +432,16 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmParams p) {
     }
     auto prefetch = [&](DmEpiPre &pre, int i, int q3) __attribute__((always_inline)) {
       if (has_res) {
-        pre.r0 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsR, oR[q3], i * stepR, 0));
-        pre.r1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsR, oR[q3] + 16, i * stepR, 0));
+        pre.r0 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsR, oR[q3], i * stepR, DM_EPI_LOAD_POLICY));
+        pre.r1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsR, oR[q3] + 16, i * stepR, DM_EPI_LOAD_POLICY));
       }
       if (has_acc) {
         pre.y0 = __builtin_amdgcn_raw_buffer_load_b128(rsC, oC[q3], i * stepC, 0);
         pre.y1 = __builtin_amdgcn_raw_buffer_load_b128(rsC, oC[q3] + 16, i * stepC, 0);
       }
       if (aux_load) {
-        pre.y0 = __builtin_amdgcn_raw_buffer_load_b128(rsX, oX[q3], i * stepX, 0);
-        if (x32) pre.y1 = __builtin_amdgcn_raw_buffer_load_b128(rsX, oX[q3] + 16, i * stepX, 0);
+        pre.y0 = __builtin_amdgcn_raw_buffer_load_b128(rsX, oX[q3], i * stepX, DM_EPI_LOAD_POLICY);
+        if (x32) pre.y1 = __builtin_amdgcn_raw_buffer_load_b128(rsX, oX[q3] + 16, i * stepX, DM_EPI_LOAD_POLICY);
       }
     };
     auto pack8 = [](const f32x4 &a, const f32x4 &b) __attribute__((always_inline)) {
@@ -453,10 +453,10 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmParams p) {
       if (!plain && p.epilogue == DM_EPI_GELU) {
         if (aux_store) {
           if (x32) {
-            DM_EPI_BSTORE(__builtin_bit_cast(u32x4, lo), rsX, oX[q3], i * stepX, 0);
-            DM_EPI_BSTORE(__builtin_bit_cast(u32x4, hi), rsX, oX[q3] + 16, i * stepX, 0);
+            DM_EPI_BSTORE(__builtin_bit_cast(u32x4, lo), rsX, oX[q3], i * stepX, DM_EPI_AUX_POLICY);
+            DM_EPI_BSTORE(__builtin_bit_cast(u32x4, hi), rsX, oX[q3] + 16, i * stepX, DM_EPI_AUX_POLICY);
           } else {
-            DM_EPI_BSTORE(pack8(lo, hi), rsX, oX[q3], i * stepX, 0);
+            DM_EPI_BSTORE(pack8(lo, hi), rsX, oX[q3], i * stepX, DM_EPI_AUX_POLICY);
           }
         }
 #pragma unroll
@@ -475,10 +475,10 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmParams p) {
         }
         if (aux_store) {
           if (x32) {
-            DM_EPI_BSTORE(__builtin_bit_cast(u32x4, dl), rsX, oX[q3], i * stepX, 0);
-            DM_EPI_BSTORE(__builtin_bit_cast(u32x4, dh), rsX, oX[q3] + 16, i * stepX, 0);
+            DM_EPI_BSTORE(__builtin_bit_cast(u32x4, dl), rsX, oX[q3], i * stepX, DM_EPI_AUX_POLICY);
+            DM_EPI_BSTORE(__builtin_bit_cast(u32x4, dh), rsX, oX[q3] + 16, i * stepX, DM_EPI_AUX_POLICY);
           } else {
-            DM_EPI_BSTORE(pack8(dl, dh), rsX, oX[q3], i * stepX, 0);
+            DM_EPI_BSTORE(pack8(dl, dh), rsX, oX[q3], i * stepX, DM_EPI_AUX_POLICY);
           }
         }
       } else if (aux_load) {
