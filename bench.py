@@ -27,13 +27,14 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 # profiler row (a class of launches) -> the device symbols behind it, as rocprofv3 prints them
-KERNEL_SYMBOLS = {
-    "gemm_bf16_NT": ["dmring::gemm_ring_kernel<8|4, 0> (wide outputs)", "dmw4::gemm_w4_kernel<0, 0, 0> (one round of tiles, K >= 1536)", "dm256::gemm256_kernel<0> (long K)",
-                     "gemm_kernel<__bf16, 0, 4|2> (128x128 / 64x64 tiles)"],
-    "gemm_bf16_NN": ["gemm_kernel<__bf16, 1, 4|2>", "dmw4::gemm_w4_kernel<1, 0, 0> (one round of tiles, K >= 1536)", "dm256::gemm256_kernel<1>"],
-    "gemm_bf16_TN": ["dmw4::gemm_w4_kernel<2, 0, 0> (+ splitk_reduce_kernel)", "dm256::gemm256_kernel<2> (+ splitk_reduce_kernel)", "gemm_kernel<__bf16, 2, 4|2>"],
-    "attn_fwd_bf16": ["dmpipe::attn_fwd_pipe_kernel<NKT, RAGGED, PF>", "attn_fwd_kernel<__bf16, ...> (N < 128)"],
-    "attn_bwd_bf16": ["dmpipe::attn_bwd_dq_pipe_kernel", "dmpipe::attn_bwd_dkv_pipe_kernel", "attn_bwd_dq_kernel / attn_bwd_dkv_kernel (N < 128)"],
+KERNEL_SYMBOLS = {      # (the 4-wave kernel's third template argument is its epilogue instance: dm_gemm_w4.hip)
+    "gemm_bf16_NT": ["gemm_kernel<__bf16, 0, 4|2> (128x128 / 64x64 tiles)", "dmring::gemm_ring_kernel<8|4, 0> (wide outputs: fc1 forward, the 4096-token qkv)",
+                     "dmw4::gemm_w4_kernel<0, 0, 1|10|17> (one round of tiles, K >= 1536: fc2 forward)", "dm256::gemm256_kernel<0> (long K)",
+                     "splitk_epilogue_kernel (K slices of the 1024-token stage)"],
+    "gemm_bf16_NN": ["gemm_kernel<__bf16, 1, 4|2>", "dmw4::gemm_w4_kernel<1, 0, 1|5> (one round of tiles, K >= 1536)", "dm256::gemm256_kernel<1>"],
+    "gemm_bf16_TN": ["dmw4::gemm_w4_kernel<2, 0, 9|11> (+ splitk_reduce_kernel)", "dm256::gemm256_kernel<2> (+ splitk_reduce_kernel)", "gemm_kernel<__bf16, 2, 4|2>"],
+    "attn_fwd_bf16": ["dmq32::attn_fwd_q32_kernel<NKT, RAGGED, BIAS, NW> (128 < N <= 256)", "attn_fwd_kernel<__bf16, ...> (N <= 128)"],
+    "attn_bwd_bf16": ["dmq32::attn_bwd_dq_q32_kernel", "dmq32::attn_bwd_dkv_tab_kernel / attn_bwd_dkv_q32_kernel", "attn_bwd_dq_kernel / attn_bwd_dkv_kernel (N <= 128)"],
 }
 
 

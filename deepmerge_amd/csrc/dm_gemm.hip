@@ -325,6 +325,15 @@ __global__ __launch_bounds__(NTHREADS, (TM == 4 ? WG_PER_CU : 4)) void gemm_kern
 
   // ---- epilogue ----------------------------------------------------------------------------
   const int g = lane >> 4, li = lane & 15;
+#ifdef DM_GEMM_ABLATE
+  if (p.debug & 0x800) {                 // (ablation builds, DM_GEMM_NOEPI=1: no epilogue at all -- what the K loops alone cost; the asm keeps the MFMAs alive)
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TM; ++j) asm volatile("" ::"v"(acc[i][j]));
+    return;
+  }
+#endif
   if (p.split_k > 1) {
     float *W = p.workspace + (long long)z * p.M * p.N;
 #pragma unroll
@@ -353,6 +362,7 @@ __global__ __launch_bounds__(NTHREADS, (TM == 4 ? WG_PER_CU : 4)) void gemm_kern
       return;
     }
   }
+#ifndef DM_TM2_STRIPS_OLD      // (A/B builds: the one-step strips below keep the 64 x 64 kernel at 64-76 registers instead of 94; step A/B: no difference)
   if (TM == 2 && !(p.debug & 0x400)) {
     // 64 x 64 tiles (the 4096- / 1024-token stages, the patch embeds): all loads of the wave's four strips first, then the stores
     // (dm_gemm_common.h: a load behind a store waits for the store's acknowledgement)
@@ -377,6 +387,7 @@ __global__ __launch_bounds__(NTHREADS, (TM == 4 ? WG_PER_CU : 4)) void gemm_kern
         if (ok[i][j]) dm_gemm_strip_store<sizeof(T) == 2>(p, acc[i][j], rbs[i], n0 + wn * WT + j * 16 + 4 * g, pre[i][j]);
     return;
   }
+#endif
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
     const int m = m0 + wm * WT + i * 16 + li;
@@ -462,8 +473,7 @@ __global__ void colsum_rows_reduce_kernel(const float *__restrict__ rows, float 
 // the four waves of a workgroup split K four ways for one 16x16 output tile (each wave stages its own
 // 16x32 / 32x16 operand slices through a private LDS region), and the partial tiles are summed in a
 // fixed order before the epilogue.  FMA chains in k order within a wave; deterministic.
-// NW waves split K (4, or 16 for a long contraction: the 3840-wide head products walked 30 stages of two barriers per workgroup --
-// 15 us for 49 MFLOP; 16 waves walk 8).  The partial tiles are summed in wave order: deterministic for a given NW.
+// NW waves split K; the partial tiles are summed in wave order: deterministic for a given NW.
 template <int LAYOUT, int NW = 4>
 __global__ __launch_bounds__(64 * NW) void sgemm_small_kernel(const GemmParams p) {
   __shared__ float sa[NW][32][17], sb[NW][32][17];
@@ -680,18 +690,11 @@ extern "C" int dm_gemm(const DmGemmArgs *a, void *stream) {
     DM_REQUIRE(a->rows_per_group == 0, DM_ERR_UNSUPPORTED, "dm_gemm: grouped rows need the MFMA path");
     dim3 grid((a->N + 15) / 16, (a->M + 15) / 16);
     switch (a->layout) {
-      case DM_NT:
-        if (a->K >= 1024) hipLaunchKernelGGL((sgemm_small_kernel<DM_NT, 16>), grid, dim3(1024), 0, s, p);
-        else hipLaunchKernelGGL((sgemm_small_kernel<DM_NT>), grid, dim3(256), 0, s, p);
-        break;
-      case DM_NN:
-        if (a->K >= 1024) hipLaunchKernelGGL((sgemm_small_kernel<DM_NN, 16>), grid, dim3(1024), 0, s, p);
-        else hipLaunchKernelGGL((sgemm_small_kernel<DM_NN>), grid, dim3(256), 0, s, p);
-        break;
-      default:
-        if (a->K >= 1024) hipLaunchKernelGGL((sgemm_small_kernel<DM_TN, 16>), grid, dim3(1024), 0, s, p);
-        else hipLaunchKernelGGL((sgemm_small_kernel<DM_TN>), grid, dim3(256), 0, s, p);
-        break;
+      // (a 16-wave instance -- K split 16 ways, 8 stages instead of 30 for the 3840-wide head product -- measured 92 us against ~36 us for
+      // this one: not used)
+      case DM_NT: hipLaunchKernelGGL((sgemm_small_kernel<DM_NT>), grid, dim3(256), 0, s, p); break;
+      case DM_NN: hipLaunchKernelGGL((sgemm_small_kernel<DM_NN>), grid, dim3(256), 0, s, p); break;
+      default: hipLaunchKernelGGL((sgemm_small_kernel<DM_TN>), grid, dim3(256), 0, s, p); break;
     }
     DM_LAUNCH_CHECK("dm_gemm(generic)");
     if (a->colsum_a) return dm_colsum(a->A, a->ab_dtype, a->lda, a->colsum_a, a->K, a->M, a->colsum_accumulate, cs_region, stream);
@@ -756,6 +759,9 @@ extern "C" int dm_gemm(const DmGemmArgs *a, void *stream) {
     if (touch_off) p.debug |= 0x200;
     static const bool lean_off = [] { const char *e = getenv("DM_GEMM_EPI_LEAN"); return e && e[0] == '0'; }();     // A/B aid: the generic whole-line epilogue (dm_gemm_common.h)
     if (lean_off) p.debug |= 0x400;
+#ifdef DM_GEMM_ABLATE
+    { const char *e = getenv("DM_GEMM_NOEPI"); if (e && e[0] == '1') p.debug |= 0x800; }
+#endif
   }
   {
     static const int forced = [] { const char *e = getenv("DM_GEMM_GROUP_M"); return e ? atoi(e) : -1; }();
