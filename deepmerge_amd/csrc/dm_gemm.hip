@@ -252,6 +252,17 @@ __global__ __launch_bounds__(NTHREADS, (TM == 4 ? WG_PER_CU : 4)) void gemm_kern
 #pragma unroll
     for (int j = 0; j < TM; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+  // Weight gradients on 64 x 64 tiles (the 4096- / 1024-token stages, the patch embeds): the bias gradient = column sums of A = dy rides
+  // along as in the 256 x 256 / 4-wave kernels -- the waves wn == 0 of the workgroups of column tile 0 multiply their A fragments with a
+  // ones fragment (+50 % MFMAs in those workgroups only); partial rows [z][M] in p.colsum_slab, folded by the split-K reduction.
+  // Round 4: nine colsum + nine partial-reduce launches per step gone.
+  constexpr bool CS = A_MMAJOR && TM == 2 && sizeof(T) == 2;
+  const bool colsum = CS && p.colsum_slab != nullptr && tn == 0 && wn == 0;
+  f32x4 accb[CS ? TM : 1];
+#pragma unroll
+  for (int i = 0; i < (CS ? TM : 1); ++i) accb[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const u32x4 ones = {0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};     // eight bf16 1.0
+
   u32x4 ra[TM], rb[TM];
   OperandView<TM> va, vb;
   if constexpr (A_MMAJOR) va = view_mmajor<T, TM>(A, p.lda, m0, p.M, p.K, t);
@@ -317,6 +328,12 @@ __global__ __launch_bounds__(NTHREADS, (TM == 4 ? WG_PER_CU : 4)) void gemm_kern
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TM; ++j) mma<T>(acc[i][j], fa[i], fb[j]);
+      if constexpr (CS) {
+        if (colsum) {
+#pragma unroll
+          for (int i = 0; i < TM; ++i) mma<T>(accb[i], fa[i], ones);
+        }
+      }
     }
     if constexpr (LDS_STAGES == 1) __syncthreads();   // every wave is done reading the single buffer
     if (more) lstore(cur ^ 1);
@@ -325,6 +342,16 @@ __global__ __launch_bounds__(NTHREADS, (TM == 4 ? WG_PER_CU : 4)) void gemm_kern
 
   // ---- epilogue ----------------------------------------------------------------------------
   const int g = lane >> 4, li = lane & 15;
+  if constexpr (CS) {
+    if (colsum && g == 0) {        // every column of an accb tile holds the same sum: lanes g == 0 write element 0
+      float *row = p.colsum_slab + (long long)z * p.M;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int m = m0 + wm * WT + i * 16 + li;
+        if (m < p.M) row[m] = accb[i][0];
+      }
+    }
+  }
 #ifdef DM_GEMM_ABLATE
   if (p.debug & 0x800) {                 // (ablation builds, DM_GEMM_NOEPI=1: no epilogue at all -- what the K loops alone cost; the asm keeps the MFMAs alive)
 #pragma unroll
@@ -785,7 +812,8 @@ extern "C" int dm_gemm(const DmGemmArgs *a, void *stream) {
     DmProfScope prof(pname, s, 2.0 * a->M * a->N * a->K,
                      esz * ((double)a->M * a->K + (double)a->N * a->K) + csz * mn * (a->accumulate ? 2.0 : 1.0) +
                          (a->residual ? 4.0 * mn : 0.0) + (a->aux ? ((a->aux_dtype == DM_BF16) ? 2.0 : 4.0) * mn : 0.0));
-    p.colsum_slab = ((big || (w4 && a->layout == DM_TN)) && cs_region) ? cs_region : nullptr;
+    const bool cs_t64 = !big && !w4 && !ring && a->layout == DM_TN && a->ab_dtype == DM_BF16 && tile == 64 && a->colsum_a != nullptr && split <= 128;
+    p.colsum_slab = ((big || (w4 && a->layout == DM_TN) || cs_t64) && cs_region) ? cs_region : nullptr;
     if (w4) {
       dm_gemm_w4_launch(p, a->layout, w4, s);
     } else if (ring) {
@@ -807,8 +835,9 @@ extern "C" int dm_gemm(const DmGemmArgs *a, void *stream) {
   }
   DM_LAUNCH_CHECK("dm_gemm");
   if (fwd_split) return DM_OK;
-  const bool cs_fused = big || (w4 && a->layout == DM_TN);      // these kernels produce the partial column sums of A themselves
-  const int cs_rows_per_slice = big ? 4 : 2;
+  const bool cs_t64 = !big && !w4 && !ring && a->layout == DM_TN && a->ab_dtype == DM_BF16 && tile == 64 && a->colsum_a != nullptr && split <= 128;
+  const bool cs_fused = big || (w4 && a->layout == DM_TN) || cs_t64;      // these kernels produce the partial column sums of A themselves
+  const int cs_rows_per_slice = big ? 4 : cs_t64 ? 1 : 2;
   if (split > 1) {
     const long long n4 = (long long)a->M * a->N / 4;
     const long long want = (n4 + 255) / 256;

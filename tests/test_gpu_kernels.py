@@ -878,10 +878,12 @@ def test_gemm256_pipeline_wgrad_and_dgrad_layouts():
     assert torch.equal(out, (a.float() @ w.float()).to(torch.bfloat16))
 
 
-@pytest.mark.parametrize("M,N,K", [(768, 3072, 16384), (2304, 768, 16384), (776, 3072, 16384), (768, 768, 4096), (104, 768, 640)])
+@pytest.mark.parametrize("M,N,K", [(768, 3072, 16384), (2304, 768, 16384), (776, 3072, 16384), (768, 768, 4096), (104, 768, 640),
+                                   (768, 768, 1024), (3072, 768, 1024), (768, 256, 4096), (768, 64, 4096), (40, 24, 72), (200, 136, 1000)])
 def test_gemm_wgrad_with_fused_column_sums(M, N, K):
-    """colsum_a: the bias gradient rides on the wgrad (ones-fragment MFMAs on the 256x256 pipeline, the column-sum kernels
-    otherwise); exact on integer data, accumulate honoured separately for dW and db."""
+    """colsum_a: the bias gradient rides on the wgrad (ones-fragment MFMAs on the 256x256, 4-wave and 64x64 kernels, the column-sum
+    kernels otherwise); exact on integer data, accumulate honoured separately for dW and db.  The second row of shapes takes the
+    64x64 tiles (1024-token stage, patch embeds, ragged M / N / K tails)."""
     ops = _ops()
     from deepmerge_amd._lib import DM_TN
     g = torch.Generator(device=DEV); g.manual_seed(M + N)
