@@ -1147,7 +1147,9 @@ def _grad_done(param: torch.Tensor, g: torch.Tensor, direct: bool):
 # enqueued on a side stream (own split-K workspace) next to the dgrad chain for blocks of at most that many tokens, and joined
 # before the block's backward returns.  Meant for the small stages, whose kernels cannot fill the chip on their own.
 # Measured under graph replay: 6.96 ms/step with the 4096-token stages on the side stream, 6.75 ms with every block, 6.75 ms
-# without -- the fork / join edges cost what the overlap gains, so the default is off (0).
+# without -- the fork / join edges cost what the overlap gains, so the default is off (0).  Round 4, faster kernels, same verdict:
+# 5.71-5.73 ms off, 5.88 ms with every block on the side stream, 5.87 ms with ONE join per backward pass instead of one per block,
+# 5.85 ms with only the <= 4096-token stages (the large kernels own a CU's whole LDS / register file, so nothing co-resides).
 _WGRAD_SIDE_TOKENS = int(os.environ.get("DM_WGRAD_STREAM", "0"))
 _side_streams = {}
 
