@@ -41,6 +41,7 @@ class DmGemmArgs(C.Structure):
         ("rows_per_group", C.c_int32), ("group_stride", C.c_int64),
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
         ("colsum_a", C.c_void_p), ("colsum_accumulate", C.c_int32),
+        ("k_fold", C.c_int32), ("a_fold", C.c_int64 * 3), ("b_fold", C.c_int64 * 3),
     ]
 
 
@@ -90,6 +91,7 @@ SIGNATURES = {
     "dm_split_bf16": (_I, [_P, _L, _L, _L, _P, _I, _I, _P]),
     "dm_split_colsum_partial_floats": (_L, [_L, _L]),
     "dm_split_bf16_colsum": (_I, [_P, _L, _L, _L, _P, _I, _I, _P, _P, _P]),
+    "dm_split_bf16_planes": (_I, [_P, _L, _L, _L, _P, _P, _P, _P]),
     "dm_patchify": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "dm_contrastive_loss": (_I, [_P, _P, _P, _F, _F, _P, _P, _P, _I, _I, _P]),
     "dm_cross_entropy": (_I, [_P, _P, _P, _F, _P, _P, _I, _I, _P]),
@@ -148,8 +150,8 @@ def lib() -> C.CDLL:
                 raise DeepMergeLibraryError(f"{LIB_PATH} does not export {name}") from e
             fn.restype = res
             fn.argtypes = args
-        if handle.dm_abi_version() != 3:
-            raise DeepMergeLibraryError(f"ABI version mismatch: library {handle.dm_abi_version()} != 3")
+        if handle.dm_abi_version() != 4:
+            raise DeepMergeLibraryError(f"ABI version mismatch: library {handle.dm_abi_version()} != 4")
         _lib = handle
         return _lib
 

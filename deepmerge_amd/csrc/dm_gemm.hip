@@ -120,10 +120,11 @@ __device__ __forceinline__ OperandView<TM> view_kmajor(const T *base, long long 
   return v;
 }
 template <typename T, int TM>
-__device__ __forceinline__ void load_kmajor(u32x4 (&r)[TM], const OperandView<TM> &v, int k0, int kend) {
-  // chunks at or beyond kend (K tail of the last stage) must read zero, not the next row
+__device__ __forceinline__ void load_kmajor(u32x4 (&r)[TM], const OperandView<TM> &v, int k0, int kend, long long kphys) {
+  // chunks at or beyond kend (K tail of the last stage) must read zero, not the next row; kphys = element offset of logical column k0
+  // inside a row (k0 itself for a plain operand, segment offset + in-segment column for a folded one)
   const unsigned kill = ((int)(k0 + v.chunk_k) < kend) ? 0u : 0x80000000u;
-  const unsigned soff = (unsigned)k0 * (unsigned)sizeof(T);
+  const unsigned soff = (unsigned)kphys * (unsigned)sizeof(T);
 #pragma unroll
   for (int i = 0; i < TM; ++i) r[i] = __builtin_amdgcn_raw_buffer_load_b128(v.rsrc, v.voff[i] | kill, soff, 0);
 }
@@ -156,10 +157,11 @@ __device__ __forceinline__ OperandView<TM> view_mmajor(const T *base, long long 
   return v;
 }
 template <typename T, int TM>
-__device__ __forceinline__ void load_mmajor(u32x4 (&r)[TM], const OperandView<TM> &v, long long ld, int k0) {
+__device__ __forceinline__ void load_mmajor(u32x4 (&r)[TM], const OperandView<TM> &v, long long ld, int k0, long long seg_off = 0) {
+  // k0 = first row of the stage inside its K segment (the operand itself when not folded), seg_off = the segment's element offset
   const long long skip = (long long)k0 * ld * (long long)sizeof(T);
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<char *>(reinterpret_cast<const char *>(v.base) + skip), 0, clamp_records(v.tail_bytes - skip), 0x00020000);
+      const_cast<char *>(reinterpret_cast<const char *>(v.base) + skip + seg_off * (long long)sizeof(T)), 0, clamp_records(v.tail_bytes - skip), 0x00020000);
 #pragma unroll
   for (int i = 0; i < TM; ++i) r[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, v.voff[i], 0, 0);
 }
@@ -209,7 +211,9 @@ template <typename T, int TM> __device__ __forceinline__ u32x4 frag_mmajor(const
   return out;
 }
 
-template <typename T, int LAYOUT, int TM>
+// FOLD: the operands are hi / lo plane pairs and the contraction runs over three segments of p.k_fold (GemmParams.k_fold; a multiple
+// of the K stage, so a stage never straddles two segments and there is no K tail).
+template <typename T, int LAYOUT, int TM, bool FOLD = false>
 __global__ __launch_bounds__(NTHREADS, (TM == 4 ? WG_PER_CU : 4)) void gemm_kernel(const GemmParams p) {
   using G = Geo<T, TM>;
   constexpr bool A_MMAJOR = (LAYOUT == DM_TN);
@@ -265,15 +269,26 @@ __global__ __launch_bounds__(NTHREADS, (TM == 4 ? WG_PER_CU : 4)) void gemm_kern
 
   u32x4 ra[TM], rb[TM];
   OperandView<TM> va, vb;
-  if constexpr (A_MMAJOR) va = view_mmajor<T, TM>(A, p.lda, m0, p.M, p.K, t);
-  else va = view_kmajor<T, TM>(A, p.lda, m0, p.M, p.K, t);
-  if constexpr (B_MMAJOR) vb = view_mmajor<T, TM>(B, p.ldb, n0, p.N, p.K, t);
-  else vb = view_kmajor<T, TM>(B, p.ldb, n0, p.N, p.K, t);
+  // (folded: a k-contiguous view spans up to the farthest segment's last column, an m-contiguous one the rows of ONE segment)
+  const long long a_far = FOLD ? max(p.a_fold[0], max(p.a_fold[1], p.a_fold[2])) : 0, b_far = FOLD ? max(p.b_fold[0], max(p.b_fold[1], p.b_fold[2])) : 0;
+  const int k_seg = FOLD ? p.k_fold : p.K;
+  if constexpr (A_MMAJOR) va = view_mmajor<T, TM>(A, p.lda, m0, p.M, k_seg, t);
+  else va = view_kmajor<T, TM>(A, p.lda, m0, p.M, (int)min((long long)0x7fffffff, a_far + k_seg), t);
+  if constexpr (B_MMAJOR) vb = view_mmajor<T, TM>(B, p.ldb, n0, p.N, k_seg, t);
+  else vb = view_kmajor<T, TM>(B, p.ldb, n0, p.N, (int)min((long long)0x7fffffff, b_far + k_seg), t);
   auto gload = [&](int k0) {
-    if constexpr (A_MMAJOR) load_mmajor<T, TM>(ra, va, p.lda, k0);
-    else load_kmajor<T, TM>(ra, va, k0, kend);
-    if constexpr (B_MMAJOR) load_mmajor<T, TM>(rb, vb, p.ldb, k0);
-    else load_kmajor<T, TM>(rb, vb, k0, kend);
+    int kk = k0;
+    long long oa = 0, ob = 0;
+    if constexpr (FOLD) {
+      const int seg = (k0 >= 2 * p.k_fold) ? 2 : (k0 >= p.k_fold) ? 1 : 0;
+      kk = k0 - seg * p.k_fold;
+      oa = seg == 0 ? p.a_fold[0] : seg == 1 ? p.a_fold[1] : p.a_fold[2];
+      ob = seg == 0 ? p.b_fold[0] : seg == 1 ? p.b_fold[1] : p.b_fold[2];
+    }
+    if constexpr (A_MMAJOR) load_mmajor<T, TM>(ra, va, p.lda, kk, oa);
+    else load_kmajor<T, TM>(ra, va, k0, kend, oa + kk);
+    if constexpr (B_MMAJOR) load_mmajor<T, TM>(rb, vb, p.ldb, kk, ob);
+    else load_kmajor<T, TM>(rb, vb, k0, kend, ob + kk);
   };
   auto lstore = [&](int buf) {
     if constexpr (A_MMAJOR) store_mmajor<T, TM>(ldsA(buf), ra, t);
@@ -591,6 +606,16 @@ __global__ __launch_bounds__(64 * NW) void sgemm_small_kernel(const GemmParams p
 
 template <typename T, int TM>
 void launch_mfma(const GemmParams &p, int layout, int grid, hipStream_t s) {
+  if constexpr (sizeof(T) == 2) {
+    if (p.k_fold > 0) {
+      switch (layout) {
+        case DM_NT: hipLaunchKernelGGL((gemm_kernel<T, DM_NT, TM, true>), dim3(grid), dim3(NTHREADS), 0, s, p); break;
+        case DM_NN: hipLaunchKernelGGL((gemm_kernel<T, DM_NN, TM, true>), dim3(grid), dim3(NTHREADS), 0, s, p); break;
+        default: hipLaunchKernelGGL((gemm_kernel<T, DM_TN, TM, true>), dim3(grid), dim3(NTHREADS), 0, s, p); break;
+      }
+      return;
+    }
+  }
   switch (layout) {
     case DM_NT: hipLaunchKernelGGL((gemm_kernel<T, DM_NT, TM>), dim3(grid), dim3(NTHREADS), 0, s, p); break;
     case DM_NN: hipLaunchKernelGGL((gemm_kernel<T, DM_NN, TM>), dim3(grid), dim3(NTHREADS), 0, s, p); break;
@@ -681,6 +706,22 @@ extern "C" int dm_gemm(const DmGemmArgs *a, void *stream) {
   p.M = a->M; p.N = a->N; p.K = a->K;
   p.epilogue = a->epilogue; p.accumulate = a->accumulate; p.c_dtype = a->c_dtype; p.aux_dtype = a->aux_dtype;
 
+  // folded contraction (hi / lo plane pairs of the "bf16x3" products): three K segments of k_fold, each a plain operand at its offset
+  p.k_fold = 0;
+  if (a->k_fold > 0) {
+    DM_REQUIRE(a->ab_dtype == DM_BF16 && a->K == 3 * a->k_fold && a->k_fold % 64 == 0, DM_ERR_UNSUPPORTED,
+               "dm_gemm: k_fold needs bf16 operands, K == 3 * k_fold and k_fold %% 64 == 0 (K=%d k_fold=%d)", a->K, a->k_fold);
+    DM_REQUIRE(!a->colsum_a, DM_ERR_UNSUPPORTED, "dm_gemm: colsum_a does not go with k_fold (take the sums from dm_split_bf16_planes)");
+    for (int sgm = 0; sgm < 3; ++sgm) {
+      DM_REQUIRE(a->a_fold[sgm] >= 0 && a->a_fold[sgm] < (1LL << 30) && a->b_fold[sgm] >= 0 && a->b_fold[sgm] < (1LL << 30) &&
+                     a->a_fold[sgm] % 8 == 0 && a->b_fold[sgm] % 8 == 0,
+                 DM_ERR_UNSUPPORTED, "dm_gemm: k_fold segment offsets must be multiples of 8 in [0, 2^30)");
+      p.a_fold[sgm] = a->a_fold[sgm];
+      p.b_fold[sgm] = a->b_fold[sgm];
+    }
+    p.k_fold = a->k_fold;
+  }
+  const bool folded = p.k_fold > 0;
   // the tail of the workspace belongs to the column sums of A, the rest to the split-K slab
   float *cs_region = nullptr;
   int64_t slab_bytes = a->workspace_bytes;
@@ -711,6 +752,7 @@ extern "C" int dm_gemm(const DmGemmArgs *a, void *stream) {
                          (a->aux == nullptr || a->aux_dtype == DM_F32) &&
                          ((a->M + BM - 1) / BM) * ((a->N + BN - 1) / BN) < 16);
   if (!mfma_ok) {
+    DM_REQUIRE(!folded, DM_ERR_UNSUPPORTED, "dm_gemm: k_fold needs the MFMA path's alignment (M=%d N=%d K=%d)", a->M, a->N, a->K);
     DM_REQUIRE(a->ab_dtype == DM_F32 && a->c_dtype == DM_F32 && (a->aux == nullptr || a->aux_dtype == DM_F32),
                DM_ERR_BAD_ALIGN, "dm_gemm: shape/alignment needs the generic path, which is fp32-only "
                "(M=%d N=%d K=%d lda=%lld ldb=%lld)", a->M, a->N, a->K, (long long)a->lda, (long long)a->ldb);
@@ -748,10 +790,10 @@ extern "C" int dm_gemm(const DmGemmArgs *a, void *stream) {
   // 8-column epilogue of splitk_epilogue_kernel must be legal, and the caller's workspace holds the slab
   const bool fwd_slices_ok = a->layout != DM_TN && a->ab_dtype == DM_BF16 && a->split_k == 0 && ring_aligned && a->N % 8 == 0 &&
                              (a->residual == nullptr || a->ldr % 8 == 0) && a->workspace != nullptr && slab_bytes > 0;
-  const int w4 = w4_ok ? dm_gemm_w4_plan(p, a->layout, a->ab_dtype, true, a->layout == DM_TN ? can_split : fwd_slices_ok, slab_bytes) : 0;
+  const int w4 = (w4_ok && !folded) ? dm_gemm_w4_plan(p, a->layout, a->ab_dtype, true, a->layout == DM_TN ? can_split : fwd_slices_ok, slab_bytes) : 0;
   const bool persistent = w4 != 0;
-  const int ring = persistent ? 0 : dm_gemm_ring_plan(p, a->layout, a->ab_dtype, ring_aligned);
-  const bool big = !persistent && !ring && dm_gemm256_plan(p, a->layout, a->ab_dtype, can_split, slab_bytes, a->split_k);
+  const int ring = (persistent || folded) ? 0 : dm_gemm_ring_plan(p, a->layout, a->ab_dtype, ring_aligned);
+  const bool big = !persistent && !ring && !folded && dm_gemm256_plan(p, a->layout, a->ab_dtype, can_split, slab_bytes, a->split_k);
   int tile = w4 ? 1924 : ring ? (ring == 8 ? 2568 : 1288) : big ? 256 : pick_tile(a->layout, a->M, a->N, a->K);
   int split = w4 ? p.split_k : (ring || persistent) ? 1 : p.split_k;
   // forward / dgrad K slices (plan_fwd_split): bf16, automatic slice count, 8-column epilogue legal, slab inside the workspace

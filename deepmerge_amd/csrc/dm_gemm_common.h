@@ -17,6 +17,10 @@ struct GemmParams {
   float *workspace;
   int debug;     // ring kernel ablations (-DDM_RING_ABLATE builds, DM_RING_DEBUG: 1 no DMA in the loop, 2 no MFMA, 4 no fragment reads, 8 no stores); 0 in production
   float *colsum_slab;   // TN pipeline: partial column sums of A, [split_k * 4][M] (NULL: not wanted)
+  // Folded contraction ("bf16x3" products on hi / lo plane pairs, DmGemmArgs.k_fold): K = 3 * k_fold; K segment s of A starts a_fold[s]
+  // elements behind A (b_fold: B) and is addressed inside the segment as a plain operand of contraction length k_fold.  0: plain.
+  int k_fold;
+  long long a_fold[3], b_fold[3];
 };
 
 struct DmGemmRow { long long c, r, x; };

@@ -369,12 +369,12 @@ __global__ void split_bf16_kernel(const float *__restrict__ src, long long ld, l
 // weight gradient: the operand is read once for both); rows in a fixed order per thread, the block's 8 row-threads in a fixed tree.
 template <bool CS>
 __global__ __launch_bounds__(256) void split_bf16_rows_kernel(const float *__restrict__ src, long long ld, int rows, int cols,
-                                                              bf16_t *__restrict__ dst, int stack, int pattern, float *__restrict__ partial) {
+                                                              bf16_t *__restrict__ dst, int stack, int pattern, float *__restrict__ partial, int pieces) {
   __shared__ float red[CS ? 8 : 1][CS ? 264 : 1];
   const int c = (blockIdx.x * 32 + threadIdx.x) * 8;
   const bool live = c < cols;
   if (!CS && !live) return;
-  const long long piece = stack ? (long long)rows * cols : cols, ldd = stack ? cols : 3LL * cols;
+  const long long piece = stack ? (long long)rows * cols : cols, ldd = stack ? cols : 3LL * cols;      // (pieces == 2: the plane pair, stacked)
   float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   for (int r = blockIdx.y * 8 + threadIdx.y; live && r < rows; r += gridDim.y * 8) {
     const float *sp = src + (long long)r * ld + c;
@@ -394,7 +394,8 @@ __global__ __launch_bounds__(256) void split_bf16_rows_kernel(const float *__res
     }
     bf16_t *d = dst + (long long)r * ldd + c;
 #pragma unroll
-    for (int j = 0; j < 3; ++j) *reinterpret_cast<u32x4 *>(d + j * piece) = ((pattern >> j) & 1) ? lo : hi;
+    for (int j = 0; j < 3; ++j)
+      if (j < pieces) *reinterpret_cast<u32x4 *>(d + j * piece) = ((pattern >> j) & 1) ? lo : hi;
   }
   if constexpr (CS) {
 #pragma unroll
@@ -803,9 +804,28 @@ extern "C" int dm_split_bf16_colsum(const float *src, int64_t ld, int64_t rows, 
   int gx, gy;
   split_rows_grid(rows, cols, gx, gy);
   hipLaunchKernelGGL(split_bf16_rows_kernel<true>, dim3(gx, (unsigned)gy), dim3(32, 8), 0, reinterpret_cast<hipStream_t>(stream), src, (long long)ld,
-                     (int)rows, (int)cols, (bf16_t *)dst, stack ? 1 : 0, pattern, partial);
+                     (int)rows, (int)cols, (bf16_t *)dst, stack ? 1 : 0, pattern, partial, 3);
   DM_LAUNCH_CHECK("dm_split_bf16_colsum");
   *n_partial = gy;
+  return DM_OK;
+}
+
+extern "C" int dm_split_bf16_planes(const float *src, int64_t ld, int64_t rows, int64_t cols, void *dst, float *partial, int32_t *n_partial,
+                                    void *stream) {
+  DM_REQUIRE(src && dst && rows > 0 && cols > 0 && ld >= cols && ((partial == nullptr) == (n_partial == nullptr)), DM_ERR_BAD_SHAPE,
+             "dm_split_bf16_planes: bad arguments (rows=%lld cols=%lld ld=%lld)", (long long)rows, (long long)cols, (long long)ld);
+  DM_REQUIRE(split_rows_ok(src, ld, rows, cols, dst, 1), DM_ERR_UNSUPPORTED,
+             "dm_split_bf16_planes: needs cols %% 8 == 0, ld %% 4 == 0 and 16-byte aligned tensors (cols=%lld ld=%lld)", (long long)cols, (long long)ld);
+  int gx, gy;
+  split_rows_grid(rows, cols, gx, gy);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (partial)
+    hipLaunchKernelGGL(split_bf16_rows_kernel<true>, dim3(gx, (unsigned)gy), dim3(32, 8), 0, s, src, (long long)ld, (int)rows, (int)cols, (bf16_t *)dst, 1, 0b10, partial, 2);
+  else
+    hipLaunchKernelGGL(split_bf16_rows_kernel<false>, dim3(gx, (unsigned)gy), dim3(32, 8), 0, s, src, (long long)ld, (int)rows, (int)cols, (bf16_t *)dst, 1, 0b10,
+                       (float *)nullptr, 2);
+  DM_LAUNCH_CHECK("dm_split_bf16_planes");
+  if (n_partial) *n_partial = gy;
   return DM_OK;
 }
 
@@ -819,7 +839,7 @@ extern "C" int dm_split_bf16(const float *src, int64_t ld, int64_t rows, int64_t
     int gx, gy;
     split_rows_grid(rows, cols, gx, gy);
     hipLaunchKernelGGL(split_bf16_rows_kernel<false>, dim3(gx, (unsigned)gy), dim3(32, 8), 0, s, src, (long long)ld, (int)rows, (int)cols,
-                       (bf16_t *)dst, stack ? 1 : 0, pattern, (float *)nullptr);
+                       (bf16_t *)dst, stack ? 1 : 0, pattern, (float *)nullptr, 3);
   } else {
     hipLaunchKernelGGL(split_bf16_kernel, dim3(grid_for(rows * (cols / 4))), dim3(256), 0, s, src, (long long)ld, (long long)rows,
                        (long long)cols, (bf16_t *)dst, stack ? 1 : 0, pattern);

@@ -179,6 +179,46 @@ def workspace(nbytes: int, device, slot: str = "main") -> torch.Tensor:
 # ------------------------------------------------------------------------------------------------
 # raw calls
 # ------------------------------------------------------------------------------------------------
+class Planes:
+    """hi / lo plane pair of an fp32 matrix (dm_split_bf16_planes): `t` is bf16 [2, rows, cols], the operand format of the folded
+    "bf16x3" products (DmGemmArgs.k_fold).  One split serves every product that reads the matrix, on either side and in any layout."""
+    __slots__ = ("t", "rows", "cols")
+
+    def __init__(self, t: torch.Tensor):
+        self.t, self.rows, self.cols = t, t.shape[1], t.shape[2]
+
+
+_PLANES = os.environ.get("DM_X3_PLANES", "1") != "0"      # A/B aid: 0 = the three-piece images of dm_split_bf16 everywhere
+
+
+def planes_ok(rows: int, cols: int) -> bool:
+    """Can a [rows, cols] fp32 matrix be a folded operand on either side?  (contraction along either extent: a multiple of the K stage;
+    16-byte row pieces; plane offset inside the kernels' 32-bit range)"""
+    return _PLANES and rows % 64 == 0 and cols % 64 == 0 and rows * cols < (1 << 30)
+
+
+def split_planes(x: torch.Tensor, colsum_out: Optional[torch.Tensor] = None, colsum_accumulate: bool = False) -> Planes:
+    """x fp32 [rows, cols] (row stride % 4 == 0) -> Planes; with colsum_out [cols] (+)= the column sums of x on the side (the bias
+    gradient that goes with a weight gradient: x = dy is read once for both)."""
+    _need_cuda(x, colsum_out)
+    if x.dtype != torch.float32 or x.dim() != 2 or x.stride(1) != 1:
+        raise ValueError("split_planes takes a 2-D fp32 matrix with contiguous rows")
+    rows, cols = x.shape
+    out = torch.empty((2, rows, cols), dtype=torch.bfloat16, device=x.device)
+    if colsum_out is None:
+        check(_lib.lib().dm_split_bf16_planes(x.data_ptr(), x.stride(0), rows, cols, out.data_ptr(), None, None, _stream()), "dm_split_bf16_planes")
+        return Planes(out)
+    part = workspace(4 * _lib.lib().dm_split_colsum_partial_floats(rows, cols), x.device, "planes.partial").view(torch.float32)
+    rows_out = C.c_int32(0)
+    check(_lib.lib().dm_split_bf16_planes(x.data_ptr(), x.stride(0), rows, cols, out.data_ptr(), part.data_ptr(), C.byref(rows_out), _stream()),
+          "dm_split_bf16_planes")
+    item = (_lib.DmReduceItem * 1)()
+    item[0].partial, item[0].out0, item[0].out1 = part.data_ptr(), colsum_out.data_ptr(), colsum_out.data_ptr()
+    item[0].nrows, item[0].width, item[0].split, item[0].accumulate = rows_out.value, cols, cols, int(bool(colsum_accumulate))
+    check(_lib.lib().dm_partial_reduce_batch(item, 1, _stream()), "dm_partial_reduce_batch")
+    return Planes(out)
+
+
 def gemm(layout: int, A: torch.Tensor, B: torch.Tensor, C_out: torch.Tensor, M: int, N: int, K: int, *,
          lda: Optional[int] = None, ldb: Optional[int] = None, ldc: Optional[int] = None,
          bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None, ldr: Optional[int] = None,
@@ -187,6 +227,25 @@ def gemm(layout: int, A: torch.Tensor, B: torch.Tensor, C_out: torch.Tensor, M: 
          colsum_out: Optional[torch.Tensor] = None, colsum_accumulate: bool = False, ws_slot: str = "gemm") -> torch.Tensor:
     """dm_gemm.  A/B/C are 2-D (or flat) row-major tensors; leading dims default to their last-dim size.
     DM_TN only: colsum_out [M] fp32 (+)= column sums of A (the bias gradient that goes with dW = dy^T x)."""
+    fold = None
+    if isinstance(A, Planes) or isinstance(B, Planes) or (
+            _FP32_PRODUCTS == "bf16x3" and A.dtype == torch.float32 and M * N * K >= _SPLIT_MIN_WORK and planes_ok(M, K) and planes_ok(N, K)
+            and (lda is None or lda % 4 == 0) and (ldb is None or ldb % 4 == 0) and A.data_ptr() % 16 == 0 and B.data_ptr() % 16 == 0):
+        # folded split-bf16 product: both operands as hi / lo plane pairs (split here unless the caller already holds the pair),
+        # one bf16 product over three K segments (hi.hi + hi.lo + lo.hi) that re-read the planes in place
+        a_rows, a_cols = (M, K) if layout != DM_TN else (K, M)
+        b_rows, b_cols = (N, K) if layout == DM_NT else (K, N)
+        if not isinstance(A, Planes):
+            A = split_planes(torch.as_strided(A, (a_rows, a_cols), (lda if lda is not None else a_cols, 1)), colsum_out, colsum_accumulate)
+            colsum_out = None
+        if not isinstance(B, Planes):
+            B = split_planes(torch.as_strided(B, (b_rows, b_cols), (ldb if ldb is not None else b_cols, 1)))
+        if (A.rows, A.cols) != (a_rows, a_cols) or (B.rows, B.cols) != (b_rows, b_cols):
+            raise ValueError(f"plane pair shapes {(A.rows, A.cols)} / {(B.rows, B.cols)} do not match the product {(a_rows, a_cols)} / {(b_rows, b_cols)}")
+        if colsum_out is not None:
+            raise ValueError("column sums of a pre-split operand belong to its split_planes call")
+        fold = (K, A.rows * A.cols, B.rows * B.cols)
+        A, B, lda, ldb, K = A.t, B.t, a_cols, b_cols, 3 * K
     _need_cuda(A, B, C_out, bias, residual, aux, colsum_out)
     if A.dtype != B.dtype:
         raise ValueError(f"A/B dtype mismatch: {A.dtype} vs {B.dtype}")
@@ -243,6 +302,10 @@ def gemm(layout: int, A: torch.Tensor, B: torch.Tensor, C_out: torch.Tensor, M: 
         if colsum_out.dtype != torch.float32 or colsum_out.numel() < M or not colsum_out.is_contiguous():
             raise ValueError("colsum_out must be a contiguous fp32 tensor with >= M elements")
         a.colsum_a, a.colsum_accumulate = colsum_out.data_ptr(), int(colsum_accumulate)
+    if fold is not None:
+        a.k_fold = fold[0]
+        a.a_fold[0], a.a_fold[1], a.a_fold[2] = 0, 0, fold[1]           # left operand: hi, hi, lo
+        a.b_fold[0], a.b_fold[1], a.b_fold[2] = 0, fold[2], 0           # right operand: hi, lo, hi
     ws_bytes = _lib.lib().dm_gemm_workspace_bytes(layout, M, N, K) if (split_k != 1 or colsum_out is not None) else 0
     if split_k > 1:                       # caller-chosen slice count: its slab may be larger than the automatic one
         ws_bytes = max(ws_bytes, _lib.lib().dm_gemm_workspace_bytes(layout, M, N, K) + split_k * M * N * 4)

@@ -40,7 +40,8 @@ typedef enum {
 } DmStatus;
 
 /* ---- library ------------------------------------------------------------------------- */
-int dm_abi_version(void);   /* 2: dm_patch_pyramid / dm_patch_pyramid_cols take a resize rule; 3: table-reading and split-bf16 attention entry points, dm_split_bf16_colsum (round 3) */
+int dm_abi_version(void);   /* 2: dm_patch_pyramid / dm_patch_pyramid_cols take a resize rule; 3: table-reading and split-bf16 attention entry points, dm_split_bf16_colsum (round 3);
+                             * 4: DmGemmArgs.k_fold / a_fold / b_fold, dm_split_bf16_planes (round 4) */
 const char *dm_last_error(void);
 /* Name of the code object architecture the library was built for ("gfx950"). */
 const char *dm_arch(void);
@@ -99,6 +100,15 @@ typedef struct {
    * MFMAs against a ones fragment instead of another pass over dy; otherwise dm_gemm runs the column-sum kernels itself.
    * Needs the workspace (dm_gemm_workspace_bytes covers it). */
   float *colsum_a; int32_t colsum_accumulate;
+  /* ABI 4, optional: folded contraction for the "bf16x3" products on hi / lo PLANE PAIRS (dm_split_bf16_planes).  k_fold > 0:
+   * K == 3 * k_fold, and the K segment s = 0, 1, 2 of A is the plain operand (same layout, same lda, contraction length k_fold)
+   * that starts a_fold[s] ELEMENTS behind A -- {0, 0, plane} for the left operand (hi, hi, lo), {0, plane, 0} for the right one
+   * (hi, lo, hi), plane = rows * ld of the plane pair.  Every tensor is then split ONCE, whatever side and layout its consumers
+   * read it in, and the hi plane is fetched twice from the same addresses instead of being stored twice.
+   * bf16 operands only; k_fold % 64 == 0; 0 <= offsets < 2^30; not with colsum_a (the sums of a split operand belong to the split
+   * pass: dm_split_bf16_planes).  Shapes the folded kernels do not take return DM_ERR_UNSUPPORTED (fall back to dm_split_bf16 images). */
+  int32_t k_fold;
+  int64_t a_fold[3], b_fold[3];
 } DmGemmArgs;
 
 int dm_gemm(const DmGemmArgs *args, void *stream);
@@ -242,6 +252,10 @@ int dm_split_bf16(const float *src, int64_t ld, int64_t rows, int64_t cols, void
  * *n_partial rows of `cols` floats (dm_split_colsum_partial_floats(rows, cols) floats at most), to be summed in row order --
  * e.g. by dm_partial_reduce_batch.  cols % 8 == 0, ld % 4 == 0, 16-byte aligned tensors (DM_ERR_UNSUPPORTED otherwise). */
 int64_t dm_split_colsum_partial_floats(int64_t rows, int64_t cols);
+/* The hi / lo PLANE PAIR of src: dst bf16 [2, rows, cols] (plane 0 = hi, plane 1 = lo, each with leading dimension cols), the operand
+ * format of DmGemmArgs.k_fold.  partial / n_partial as for dm_split_bf16_colsum, or both NULL (no column sums).
+ * cols % 8 == 0, ld % 4 == 0, 16-byte aligned tensors (DM_ERR_UNSUPPORTED otherwise). */
+int dm_split_bf16_planes(const float *src, int64_t ld, int64_t rows, int64_t cols, void *dst, float *partial, int32_t *n_partial, void *stream);
 int dm_split_bf16_colsum(const float *src, int64_t ld, int64_t rows, int64_t cols, void *dst, int32_t stack, int32_t pattern,
                          float *partial, int32_t *n_partial, void *stream);
 

@@ -1042,6 +1042,55 @@ def test_split_bf16_wgrad_with_an_offset_operand():
         outs.append((dw, db))
 
 
+@pytest.mark.parametrize("layout,M,N,K", [("NT", 2048, 768, 768), ("NT", 1024, 768, 3072), ("NT", 320, 192, 128), ("NN", 2048, 768, 2304),
+                                          ("NN", 4096, 3072, 768), ("TN", 768, 768, 4096), ("TN", 2304, 768, 16384), ("TN", 192, 320, 1024)])
+def test_folded_split_product_equals_the_image_product(layout, M, N, K, monkeypatch):
+    """DmGemmArgs.k_fold (ABI 4): the bf16x3 product on hi / lo PLANE PAIRS, three K segments that re-read the planes in place, is the
+    same sum in the same order as the product over the three-piece images of dm_split_bf16 -- bit-identical on the same kernel
+    (the other GEMM families are switched off for both runs), with the fused epilogues and the split-K / K-slice paths."""
+    from deepmerge_amd import ops
+    from deepmerge_amd._lib import DM_EPI_MUL, DM_EPI_NONE, DM_NN, DM_NT, DM_TN
+    for k in ("DM_GEMM_W4", "DM_GEMM_256", "DM_GEMM_RING"):
+        monkeypatch.setenv(k, "0")
+    torch.manual_seed(M + N + K)
+    lay = {"NT": DM_NT, "NN": DM_NN, "TN": DM_TN}[layout]
+    A = torch.randn((K, M) if layout == "TN" else (M, K), device=DEV)
+    B = torch.randn((N, K) if layout == "NT" else (K, N), device=DEV)
+    ref = (A.double().t() if layout == "TN" else A.double()) @ (B.double().t() if layout == "NT" else B.double())
+    bias, res, aux = torch.randn(N, device=DEV), torch.randn(M, N, device=DEV), torch.randn(M, N, device=DEV)
+    kw = dict(bias=bias, residual=res) if layout == "NT" else dict(epilogue=DM_EPI_MUL, aux=aux, ldaux=N) if layout == "NN" else {}
+    if layout == "NT":
+        ref = ref + bias.double() + res.double()
+    elif layout == "NN":
+        ref = ref * aux.double()
+    outs = []
+    for planes in (False, True):
+        monkeypatch.setattr(ops, "_PLANES", planes)
+        C_ = torch.empty(M, N, device=DEV)
+        with ops.fp32_products("bf16x3"):
+            ops.gemm(lay, A, B, C_, M, N, K, **kw)
+        outs.append(C_)
+    assert torch.equal(outs[0], outs[1])
+    assert ((outs[1].double() - ref).abs().max() / ref.abs().max()).item() < 3e-5
+    # a plane pair made once serves both sides and every layout: A as the left operand here, then as the right operand of a weight gradient
+    monkeypatch.setattr(ops, "_PLANES", True)
+    if layout != "TN":
+        Ap = ops.split_planes(A)
+        C2 = torch.empty(M, N, device=DEV)
+        ops.gemm(lay, Ap, B, C2, M, N, K, **kw)
+        if M * N * K >= ops._SPLIT_MIN_WORK:           # (below that ops.gemm keeps fp32 operands on the fp32 MFMA kernel)
+            assert torch.equal(C2, outs[1])
+        assert ((C2.double() - ref).abs().max() / ref.abs().max()).item() < 3e-5
+        dy = torch.randn(M, 256, device=DEV)
+        db = torch.zeros(256, device=DEV)
+        dyp = ops.split_planes(dy, colsum_out=db)
+        dW = torch.empty(256, K, device=DEV)
+        ops.gemm(DM_TN, dyp, Ap, dW, 256, K, M)
+        wref = dy.double().t() @ A.double()
+        assert ((dW.double() - wref).abs().max() / wref.abs().max()).item() < 3e-5
+        assert (db.double() - dy.double().sum(0)).abs().max().item() < 1e-3 * max(1.0, M / 1024)
+
+
 @pytest.mark.parametrize("layout", ["NT", "NN", "TN"])
 def test_split_bf16_gemm_against_float64(layout):
     """ops.gemm under fp32_products("bf16x3"): every layout, with bias / GELU / residual epilogues and the fused column sums,

@@ -11,6 +11,10 @@ g = torch.Generator(device=dev); g.manual_seed(1)
 def rnd(shape, dt=torch.bfloat16): return torch.randn(shape, device=dev, generator=g).to(dt)
 R, IT = 3, 30
 T = int(os.environ.get("TOKENS", 16384))
+PAD = int(os.environ.get("PAD", 0))        # extra elements per operand / output row: leading dimensions off the power-of-two-ish strides
+def padded(shape, dt=torch.bfloat16, fill=True):
+    full = rnd((shape[0], shape[1] + PAD), dt) if fill else torch.empty((shape[0], shape[1] + PAD), device=dev, dtype=dt)
+    return full[:, :shape[1]]
 
 def timeit(run):
     for i in range(6): run(i)
@@ -26,10 +30,10 @@ def case(name, layout, M, N, K):
     elif layout == DM_NN: sa, sb = (M, K), (K, N)
     else:                 sa, sb = (K, M), (K, N)
     cdt = torch.float32 if layout == DM_TN else torch.bfloat16
-    sets = [(rnd(sa), rnd(sb), torch.empty((M, N), device=dev, dtype=cdt), torch.empty((M, N), device=dev, dtype=torch.bfloat16)) for _ in range(R)]
+    sets = [(padded(sa), padded(sb), padded((M, N), cdt, False), padded((M, N), torch.bfloat16, False)) for _ in range(R)]
     def mine(i):
         a, b, o, _ = sets[i % R]
-        ops.gemm(layout, a, b, o, M, N, K, lda=sa[1], ldb=sb[1], ldc=N)
+        ops.gemm(layout, a, b, o, M, N, K, lda=sa[1] + PAD, ldb=sb[1] + PAD, ldc=N + PAD)
     def lib(i):
         a, b, _, o = sets[i % R]
         if layout == DM_NT:   torch.matmul(a, b.t(), out=o)

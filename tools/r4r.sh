@@ -1,0 +1,8 @@
+set -e
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+OUT=gpurun_out/gaps
+rm -rf $OUT && mkdir -p $OUT
+rocprofv3 --kernel-trace -d $OUT/trace -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extras > $OUT/bench.json 2> $OUT/trace.log
+DB=$(find $OUT/trace -name "*.db" | head -1)
+python tools/rocpd_gaps.py $DB $OUT/gaps.md $OUT/seq.txt > /dev/null
+rm -rf $OUT/trace
