@@ -790,10 +790,10 @@ extern "C" int dm_gemm(const DmGemmArgs *a, void *stream) {
   // 8-column epilogue of splitk_epilogue_kernel must be legal, and the caller's workspace holds the slab
   const bool fwd_slices_ok = a->layout != DM_TN && a->ab_dtype == DM_BF16 && a->split_k == 0 && ring_aligned && a->N % 8 == 0 &&
                              (a->residual == nullptr || a->ldr % 8 == 0) && a->workspace != nullptr && slab_bytes > 0;
-  const int w4 = (w4_ok && !folded) ? dm_gemm_w4_plan(p, a->layout, a->ab_dtype, true, a->layout == DM_TN ? can_split : fwd_slices_ok, slab_bytes) : 0;
+  const int w4 = w4_ok ? dm_gemm_w4_plan(p, a->layout, a->ab_dtype, true, a->layout == DM_TN ? can_split : fwd_slices_ok, slab_bytes) : 0;
   const bool persistent = w4 != 0;
-  const int ring = (persistent || folded) ? 0 : dm_gemm_ring_plan(p, a->layout, a->ab_dtype, ring_aligned);
-  const bool big = !persistent && !ring && !folded && dm_gemm256_plan(p, a->layout, a->ab_dtype, can_split, slab_bytes, a->split_k);
+  const int ring = persistent ? 0 : dm_gemm_ring_plan(p, a->layout, a->ab_dtype, ring_aligned);
+  const bool big = !persistent && !ring && dm_gemm256_plan(p, a->layout, a->ab_dtype, can_split, slab_bytes, a->split_k);
   int tile = w4 ? 1924 : ring ? (ring == 8 ? 2568 : 1288) : big ? 256 : pick_tile(a->layout, a->M, a->N, a->K);
   int split = w4 ? p.split_k : (ring || persistent) ? 1 : p.split_k;
   // forward / dgrad K slices (plan_fwd_split): bf16, automatic slice count, 8-column epilogue legal, slab inside the workspace

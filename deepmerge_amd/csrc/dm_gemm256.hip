@@ -146,7 +146,9 @@ template <bool MM, bool IS_B> struct Operand {
   }
 };
 
-template <int LAYOUT>
+// FOLD: hi / lo plane pairs, three K segments of p.k_fold (GemmParams.k_fold): the panels start at segment offset 0 and a K tile's DMA
+// offset is its segment's offset plus its position inside the segment.
+template <int LAYOUT, bool FOLD = false>
 __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
   constexpr bool AM = (LAYOUT == DM_TN), BMM = (LAYOUT != DM_NT);
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -177,16 +179,30 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
 
   Operand<AM, false> opA;
   Operand<BMM, true> opB;
-  opA.setup(reinterpret_cast<const bf16_t *>(p.A), p.lda, m0, p.M, kbeg, kend, wave, lane, wr);
-  opB.setup(reinterpret_cast<const bf16_t *>(p.B), p.ldb, n0, p.N, kbeg, kend, wave, lane, wc);
+  opA.setup(reinterpret_cast<const bf16_t *>(p.A), p.lda, m0, p.M, FOLD ? 0 : kbeg, FOLD ? p.k_fold : kend, wave, lane, wr);
+  opB.setup(reinterpret_cast<const bf16_t *>(p.B), p.ldb, n0, p.N, FOLD ? 0 : kbeg, FOLD ? p.k_fold : kend, wave, lane, wc);
+  if constexpr (FOLD) {      // the descriptors reach to the end of the farthest segment
+    const long long a_far = max(p.a_fold[0], max(p.a_fold[1], p.a_fold[2])), b_far = max(p.b_fold[0], max(p.b_fold[1], p.b_fold[2]));
+    opA.nbytes = (int)min((long long)opA.nbytes + a_far * 2, 0x7fffffffLL);
+    opB.nbytes = (int)min((long long)opB.nbytes + b_far * 2, 0x7fffffffLL);
+  }
 
   const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t *>(opA.pnl), 0, opA.nbytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t *>(opB.pnl), 0, opB.nbytes, 0x00020000);
   // piece u of the A (which = 0) / B (which = 1) image of K tile kt.  (The int casts matter: with unsigned arguments the
   // builtin call fails to instantiate in the HOST pass of this template -- silently -- and no launch stub is emitted.)
+  const int seg_tiles = FOLD ? p.k_fold / BK256 : 1;
   auto stage = [&](int kt, int which, int u) {
-    if (which == 0) DM_LDS_DMA(rsA, smem + (kt & 1) * BUF_BYTES + opA.piece_offset(u, wave), (int)opA.vo[u], (int)(kt * opA.tile_step));
-    else DM_LDS_DMA(rsB, smem + (kt & 1) * BUF_BYTES + OPER_BYTES + opB.piece_offset(u, wave), (int)opB.vo[u], (int)(kt * opB.tile_step));
+    int sa = (int)(kt * opA.tile_step), sb = (int)(kt * opB.tile_step);
+    if constexpr (FOLD) {
+      const int tg = kbeg / BK256 + kt;
+      const int seg = (tg >= 2 * seg_tiles) ? 2 : (tg >= seg_tiles) ? 1 : 0;
+      const int kk = tg - seg * seg_tiles;
+      sa = (int)((seg == 0 ? p.a_fold[0] : seg == 1 ? p.a_fold[1] : p.a_fold[2]) * 2) + (int)(kk * opA.tile_step);
+      sb = (int)((seg == 0 ? p.b_fold[0] : seg == 1 ? p.b_fold[1] : p.b_fold[2]) * 2) + (int)(kk * opB.tile_step);
+    }
+    if (which == 0) DM_LDS_DMA(rsA, smem + (kt & 1) * BUF_BYTES + opA.piece_offset(u, wave), (int)opA.vo[u], sa);
+    else DM_LDS_DMA(rsB, smem + (kt & 1) * BUF_BYTES + OPER_BYTES + opB.piece_offset(u, wave), (int)opB.vo[u], sb);
   };
 
   f32x4 acc[8][4];
@@ -524,8 +540,8 @@ int p256_cu_count() {
   }();
   return n;
 }
-template <int LAYOUT> bool set_lds_limit() {
-  return hipFuncSetAttribute(reinterpret_cast<const void *>(dm256::gemm256_kernel<LAYOUT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+template <int LAYOUT, bool FOLD = false> bool set_lds_limit() {
+  return hipFuncSetAttribute(reinterpret_cast<const void *>(dm256::gemm256_kernel<LAYOUT, FOLD>), hipFuncAttributeMaxDynamicSharedMemorySize,
                              dm256::LDS256) == hipSuccess;
 }
 }  // namespace
@@ -538,6 +554,7 @@ bool dm_gemm256_plan(GemmParams &p, int layout, int ab_dtype, bool can_split, lo
   const int mode = menv ? atoi(menv) : 1;
   if (mode == 0 || ab_dtype != DM_BF16) return false;
   if (p.K < BK256) return false;
+  if (p.k_fold > 0 && p.k_fold % BK256 != 0) return false;              // folded contraction: segments of whole K tiles
   const bool am = layout == DM_TN, bm = layout != DM_NT;
   if ((!am || !bm) && p.K % BK256 != 0) return false;                    // the K tail of k-contiguous rows is not masked
   if (am && p.M % 8 != 0) return false;                                  // m-contiguous rows are fetched in 16-byte chunks
@@ -584,7 +601,8 @@ bool dm_gemm256_plan(GemmParams &p, int layout, int ab_dtype, bool can_split, lo
   }
   if (mode == 2) take = true;
   if (!take) return false;
-  static const bool attr_ok = set_lds_limit<DM_NT>() && set_lds_limit<DM_NN>() && set_lds_limit<DM_TN>();
+  static const bool attr_ok = set_lds_limit<DM_NT>() && set_lds_limit<DM_NN>() && set_lds_limit<DM_TN>() && set_lds_limit<DM_NT, true>() &&
+                              set_lds_limit<DM_NN, true>() && set_lds_limit<DM_TN, true>();
   if (!attr_ok) return false;
   int kps = (int)((((long long)p.K + split - 1) / split + BK256 - 1) / BK256 * BK256);
   split = (p.K + kps - 1) / kps;
@@ -621,6 +639,14 @@ void dm_gemm256_launch(const GemmParams &p_in, int layout, hipStream_t s) {
     }
   }
   const dim3 grid((unsigned)(p.tiles_m * p.tiles_n * p.split_k));
+  if (p.k_fold > 0) {
+    switch (layout) {
+      case DM_NT: hipLaunchKernelGGL((dm256::gemm256_kernel<DM_NT, true>), grid, dim3(512), LDS256, s, p); break;
+      case DM_NN: hipLaunchKernelGGL((dm256::gemm256_kernel<DM_NN, true>), grid, dim3(512), LDS256, s, p); break;
+      default: hipLaunchKernelGGL((dm256::gemm256_kernel<DM_TN, true>), grid, dim3(512), LDS256, s, p); break;
+    }
+    return;
+  }
   switch (layout) {
     case DM_NT: hipLaunchKernelGGL(dm256::gemm256_kernel<DM_NT>, grid, dim3(512), LDS256, s, p); break;
     case DM_NN: hipLaunchKernelGGL(dm256::gemm256_kernel<DM_NN>, grid, dim3(512), LDS256, s, p); break;

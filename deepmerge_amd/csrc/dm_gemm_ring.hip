@@ -52,7 +52,8 @@ template <int WM> struct Cfg {
 #define DM_RING_DMA(rsrc, dst, voff, soff) \
   __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void *)(dst), 16, voff, soff, 0, 0)
 
-template <int WM, int DBG = 0>
+// FOLD: hi / lo plane pairs, three K segments of p.k_fold (GemmParams.k_fold), as in the other GEMM kernels.
+template <int WM, int DBG = 0, bool FOLD = false>
 __global__ __launch_bounds__(256, 2) void gemm_ring_kernel(const GemmParams p) {
   using C = Cfg<WM>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -80,8 +81,16 @@ __global__ __launch_bounds__(256, 2) void gemm_ring_kernel(const GemmParams p) {
   // ---- DMA addressing: piece q = 8 image rows x 128 B; this wave fills pieces wave + 4u ---------------------------
   const bf16_t *pa = reinterpret_cast<const bf16_t *>(p.A) + (long long)m0 * p.lda;
   const bf16_t *pb = reinterpret_cast<const bf16_t *>(p.B) + (long long)n0 * p.ldb;
-  const long long ba = ((long long)(min(C::BM, p.M - m0) - 1) * p.lda + p.K) * 2;
-  const long long bb = ((long long)(min(BN, p.N - n0) - 1) * p.ldb + p.K) * 2;
+  const long long a_far = FOLD ? max(p.a_fold[0], max(p.a_fold[1], p.a_fold[2])) : 0, b_far = FOLD ? max(p.b_fold[0], max(p.b_fold[1], p.b_fold[2])) : 0;
+  const long long ba = ((long long)(min(C::BM, p.M - m0) - 1) * p.lda + (FOLD ? a_far + p.k_fold : (long long)p.K)) * 2;
+  const long long bb = ((long long)(min(BN, p.N - n0) - 1) * p.ldb + (FOLD ? b_far + p.k_fold : (long long)p.K)) * 2;
+  const int seg_tiles = FOLD ? p.k_fold / BK : 1;
+  auto k_off = [&](int kt, bool is_b) -> int {       // byte offset of K tile kt inside a row of the operand
+    if constexpr (!FOLD) return kt * (BK * 2);
+    const int seg = (kt >= 2 * seg_tiles) ? 2 : (kt >= seg_tiles) ? 1 : 0;
+    const long long o = is_b ? (seg == 0 ? p.b_fold[0] : seg == 1 ? p.b_fold[1] : p.b_fold[2]) : (seg == 0 ? p.a_fold[0] : seg == 1 ? p.a_fold[1] : p.a_fold[2]);
+    return (int)(o * 2) + (kt - seg * seg_tiles) * (BK * 2);
+  };
   const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t *>(pa), 0, (int)min(ba, 0x7fffffffLL), 0x00020000);
   const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t *>(pb), 0, (int)min(bb, 0x7fffffffLL), 0x00020000);
   const int prow = lane >> 3;
@@ -96,13 +105,15 @@ __global__ __launch_bounds__(256, 2) void gemm_ring_kernel(const GemmParams p) {
   // instantiate in the HOST pass of this template -- silently -- and no launch stub is emitted)
   auto stage_a = [&](int kt, int u0, int u1) {
     const int sb = (kt & 1) * C::A_BYTES;
+    const int ko = k_off(kt, false);
 #pragma unroll
     for (int u = 0; u < C::NA; ++u)
-      if (u >= u0 && u < u1) DM_RING_DMA(rsA, smem + sb + (wave + 4 * u) * 1024, (int)voA[u], (int)(kt * (BK * 2)));
+      if (u >= u0 && u < u1) DM_RING_DMA(rsA, smem + sb + (wave + 4 * u) * 1024, (int)voA[u], (int)ko);
   };
   auto stage_b = [&](int kt) {
+    const int ko = k_off(kt, true);
 #pragma unroll
-    for (int u = 0; u < C::NB; ++u) DM_RING_DMA(rsB, smem + C::B_OFF + (wave + 4 * u) * 1024, (int)voB[u], (int)(kt * (BK * 2)));
+    for (int u = 0; u < C::NB; ++u) DM_RING_DMA(rsB, smem + C::B_OFF + (wave + 4 * u) * 1024, (int)voB[u], (int)ko);
   };
 
   // fragment reads: k-step ks of row r lives in slots (4 ks + g) ^ (r & 7)
@@ -161,8 +172,8 @@ __global__ __launch_bounds__(256, 2) void gemm_ring_kernel(const GemmParams p) {
   dm_epilogue_rows<WM, C::EPI_ROWS, (DBG & 8) != 0>(p, acc, mine, m0 + wr * (WM * 16), n0 + wc * 64, lane);
 }
 
-template <int WM> bool set_lds_limit() {
-  return hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_ring_kernel<WM>), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg<WM>::LDS) == hipSuccess;
+template <int WM, bool FOLD = false> bool set_lds_limit() {
+  return hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_ring_kernel<WM, 0, FOLD>), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg<WM>::LDS) == hipSuccess;
 }
 
 }  // namespace dmring
@@ -173,6 +184,7 @@ int dm_gemm_ring_plan(GemmParams &p, int layout, int ab_dtype, bool aligned8) {
   const int mode = env ? atoi(env) : 1;
   if (mode == 0 || layout != DM_NT || ab_dtype != DM_BF16 || !aligned8) return 0;
   if (p.K % dmring::BK != 0 || p.N % 8 != 0) return 0;
+  if (p.k_fold > 0 && p.k_fold % dmring::BK != 0) return 0;      // folded contraction: segments of whole K tiles
   if (256LL * p.lda * 2 >= (1LL << 31) || 128LL * p.ldb * 2 >= (1LL << 31)) return 0;
   const char *fenv = getenv("DM_GEMM_RING_WM");
   const int force = fenv ? atoi(fenv) : 0;
@@ -190,7 +202,7 @@ int dm_gemm_ring_plan(GemmParams &p, int layout, int ab_dtype, bool aligned8) {
   if (mode == 1 && ((long long)((p.M + 127) / 128) * ((p.N + 127) / 128)) % 768 == 0 && !(p.N >= 3072 && p.M >= 8192)) return 0;
   int wm = t256 >= 384 ? 8 : 4;
   if (force == 8 || force == 4) wm = force;
-  static const bool ok = dmring::set_lds_limit<8>() && dmring::set_lds_limit<4>();
+  static const bool ok = dmring::set_lds_limit<8>() && dmring::set_lds_limit<4>() && dmring::set_lds_limit<8, true>() && dmring::set_lds_limit<4, true>();
   if (!ok) return 0;
   const int bm = wm * 32;
   p.tiles_m = (p.M + bm - 1) / bm;
@@ -214,6 +226,11 @@ void dm_gemm_ring_launch(const GemmParams &p, int wm, hipStream_t s) {
     }
   }
 #endif
+  if (p.k_fold > 0) {
+    if (wm == 8) hipLaunchKernelGGL((dmring::gemm_ring_kernel<8, 0, true>), grid, dim3(256), dmring::Cfg<8>::LDS, s, p);
+    else hipLaunchKernelGGL((dmring::gemm_ring_kernel<4, 0, true>), grid, dim3(256), dmring::Cfg<4>::LDS, s, p);
+    return;
+  }
   if (wm == 8) hipLaunchKernelGGL(dmring::gemm_ring_kernel<8>, grid, dim3(256), dmring::Cfg<8>::LDS, s, p);
   else hipLaunchKernelGGL(dmring::gemm_ring_kernel<4>, grid, dim3(256), dmring::Cfg<4>::LDS, s, p);
 }

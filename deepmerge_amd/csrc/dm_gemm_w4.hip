@@ -51,7 +51,9 @@ __device__ __forceinline__ void mma_pinned(f32x4 &acc, const u32x4 &a, const u32
 // EK: 0 = the generic fused epilogue (any operand combination, grouped rows); k > 0 = the lean epilogue with item structure key
 // k - 1 = RES | YL << 1 | C32 << 3 | XS << 4 (dm_gemm_common.h).  ONE epilogue per kernel instance: with two in one kernel the
 // accumulators meet in phi nodes behind them and the register allocator spills all 48 tiles around every tile end (tried).
-template <int LAYOUT, int DBG = 0, int EK = 0>
+// FOLD: hi / lo plane pairs, the contraction runs over three segments of p.k_fold (GemmParams.k_fold): the K-step cursors carry the
+// byte offset of their step inside A and B (segment offset + in-segment step) instead of the step index times a constant.
+template <int LAYOUT, int DBG = 0, int EK = 0, bool FOLD = false>
 __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmParams p) {
   constexpr int EPIU = 0;
   constexpr bool AMM = (LAYOUT == DM_TN);      // A m-contiguous [K][M] (wgrad) or k-contiguous [M][K]
@@ -168,22 +170,25 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmParams p) {
     m0 = tm * TM;
     n0 = (tid - tm * p.tiles_n) * TN;
   };
+  // (folded: the descriptor starts at the tile's first row / column of segment offset 0 and reaches to the end of the farthest
+  // segment -- rows past the operand's last one then still fall outside it in the farthest segment, i.e. never outside the plane pair)
+  const long long a_far = FOLD ? max(p.a_fold[0], max(p.a_fold[1], p.a_fold[2])) : 0, b_far = FOLD ? max(p.b_fold[0], max(p.b_fold[1], p.b_fold[2])) : 0;
   auto make_a = [&](int m0, bool live) __attribute__((always_inline)) {
     if constexpr (!AMM) {
-      const long long bytes = ((long long)(min(TM, p.M - m0) - 1) * p.lda + (kend - kbeg)) * 2;
-      return __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t *>(Ab + (long long)m0 * p.lda + kbeg), 0, live ? (int)min(bytes, 0x7fffffffLL) : 0, 0x00020000);
+      const long long bytes = FOLD ? ((long long)(min(TM, p.M - m0) - 1) * p.lda + a_far + p.k_fold) * 2 : ((long long)(min(TM, p.M - m0) - 1) * p.lda + (kend - kbeg)) * 2;
+      return __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t *>(Ab + (long long)m0 * p.lda + (FOLD ? 0 : kbeg)), 0, live ? (int)min(bytes, 0x7fffffffLL) : 0, 0x00020000);
     } else {
-      const long long bytes = ((long long)(kend - kbeg - 1) * p.lda + (p.M - m0)) * 2;
-      return __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t *>(Ab + (long long)kbeg * p.lda + m0), 0, live ? (int)min(bytes, 0x7fffffffLL) : 0, 0x00020000);
+      const long long bytes = FOLD ? (a_far + (long long)(p.k_fold - 1) * p.lda + (p.M - m0)) * 2 : ((long long)(kend - kbeg - 1) * p.lda + (p.M - m0)) * 2;
+      return __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t *>(Ab + (FOLD ? 0LL : (long long)kbeg * p.lda) + m0), 0, live ? (int)min(bytes, 0x7fffffffLL) : 0, 0x00020000);
     }
   };
   auto make_b = [&](int n0, bool live) __attribute__((always_inline)) {
     if constexpr (!BMM) {
-      const long long bytes = ((long long)(min(TN, p.N - n0) - 1) * p.ldb + (kend - kbeg)) * 2;
-      return __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t *>(Bb + (long long)n0 * p.ldb + kbeg), 0, live ? (int)min(bytes, 0x7fffffffLL) : 0, 0x00020000);
+      const long long bytes = FOLD ? ((long long)(min(TN, p.N - n0) - 1) * p.ldb + b_far + p.k_fold) * 2 : ((long long)(min(TN, p.N - n0) - 1) * p.ldb + (kend - kbeg)) * 2;
+      return __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t *>(Bb + (long long)n0 * p.ldb + (FOLD ? 0 : kbeg)), 0, live ? (int)min(bytes, 0x7fffffffLL) : 0, 0x00020000);
     } else {
-      const long long bytes = ((long long)(kend - kbeg - 1) * p.ldb + (p.N - n0)) * 2;
-      return __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t *>(Bb + (long long)kbeg * p.ldb + n0), 0, live ? (int)min(bytes, 0x7fffffffLL) : 0, 0x00020000);
+      const long long bytes = FOLD ? (b_far + (long long)(p.k_fold - 1) * p.ldb + (p.N - n0)) * 2 : ((long long)(kend - kbeg - 1) * p.ldb + (p.N - n0)) * 2;
+      return __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t *>(Bb + (FOLD ? 0LL : (long long)kbeg * p.ldb) + n0), 0, live ? (int)min(bytes, 0x7fffffffLL) : 0, 0x00020000);
     }
   };
   int m_cur, n_cur;
@@ -199,8 +204,29 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmParams p) {
   // over the WHOLE step instead of two per row tile over half of it.  Two load cursors (one per group); past the end of the
   // sequence: null descriptors, the loads return zeros.
   constexpr int PH = (8 + NB) / 2;
-  struct Cursor { int r, k; };
-  Cursor cx{0, 0}, cy{0, 0};
+  struct Cursor { int r, k, ka, kb, left; };      // ka / kb: byte offset of the step in A / B; left: steps to the end of its K segment (FOLD)
+  const int seg_steps = FOLD ? p.k_fold / BK : 1;
+  auto fold_seek = [&](Cursor &c) __attribute__((always_inline)) {      // position ka / kb / left at the cursor's K step
+    if constexpr (FOLD) {
+      const int tg = kbeg / BK + c.k;
+      const int seg = (tg >= 2 * seg_steps) ? 2 : (tg >= seg_steps) ? 1 : 0;
+      const int kk = tg - seg * seg_steps;
+      const long long oa = seg == 0 ? p.a_fold[0] : seg == 1 ? p.a_fold[1] : p.a_fold[2];
+      const long long ob = seg == 0 ? p.b_fold[0] : seg == 1 ? p.b_fold[1] : p.b_fold[2];
+      c.ka = (int)(oa * 2) + kk * stepA;
+      c.kb = (int)(ob * 2) + kk * stepB;
+      c.left = seg_steps - kk;
+    }
+  };
+  auto fold_next = [&](Cursor &c) __attribute__((always_inline)) {      // after ++c.k inside a tile
+    if constexpr (FOLD) {
+      if (--c.left == 0) fold_seek(c);
+      else { c.ka += stepA; c.kb += stepB; }
+    }
+  };
+  Cursor cx{0, 0, 0, 0, 0}, cy{0, 0, 0, 0, 0};
+  fold_seek(cx);
+  cy = cx;
   __amdgpu_buffer_rsrc_t rsAx = make_a(m_cur, true), rsBx = make_b(n_cur, true), rsAy = rsAx, rsBy = rsBx;
   auto advance_x = [&]() __attribute__((always_inline)) {
     if (++cx.k == ntile) {
@@ -210,6 +236,9 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmParams p) {
       if (live) tile_mn(cx.r, m0, n0);
       rsAx = make_a(m0, live);
       rsBx = make_b(n0, live);
+      fold_seek(cx);
+    } else {
+      fold_next(cx);
     }
   };
   auto advance_y = [&]() __attribute__((always_inline)) {
@@ -220,6 +249,9 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmParams p) {
       if (live) tile_mn(cy.r, m0, n0);
       rsAy = make_a(m0, live);
       rsBy = make_b(n0, live);
+      fold_seek(cy);
+    } else {
+      fold_next(cy);
     }
   };
 
@@ -240,8 +272,9 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmParams p) {
     constexpr int set = decltype(set_tag)::value;
     constexpr bool GX = decltype(grp_tag)::value == 0;
     const int k = GX ? cx.k : cy.k;
-    if (q < 8) ga[set][q] = __builtin_amdgcn_raw_buffer_load_b128(GX ? rsAx : rsAy, voA, k * stepA + q * strideA, 0);
-    else if (b_loader) gb[set][q - 8] = __builtin_amdgcn_raw_buffer_load_b128(GX ? rsBx : rsBy, voB, k * stepB + (q - 8) * strideB, 0);
+    const int ka = FOLD ? (GX ? cx.ka : cy.ka) : k * stepA, kb = FOLD ? (GX ? cx.kb : cy.kb) : k * stepB;
+    if (q < 8) ga[set][q] = __builtin_amdgcn_raw_buffer_load_b128(GX ? rsAx : rsAy, voA, ka + q * strideA, 0);
+    else if (b_loader) gb[set][q - 8] = __builtin_amdgcn_raw_buffer_load_b128(GX ? rsBx : rsBy, voB, kb + (q - 8) * strideB, 0);
   };
   // piece q: register set -> LDS buffer
   auto lwrite = [&](auto set_tag, auto buf_tag, int q) __attribute__((always_inline)) {
@@ -683,8 +716,8 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmParams p) {
 }  // namespace dmw4
 
 namespace {
-template <int LAYOUT, int DBG = 0, int EK = 0> bool w4_set_lds_limit() {
-  return hipFuncSetAttribute(reinterpret_cast<const void *>(dmw4::gemm_w4_kernel<LAYOUT, DBG, EK>), hipFuncAttributeMaxDynamicSharedMemorySize,
+template <int LAYOUT, int DBG = 0, int EK = 0, bool FOLD = false> bool w4_set_lds_limit() {
+  return hipFuncSetAttribute(reinterpret_cast<const void *>(dmw4::gemm_w4_kernel<LAYOUT, DBG, EK, FOLD>), hipFuncAttributeMaxDynamicSharedMemorySize,
                              dmw4::LDS_BYTES) == hipSuccess;
 }
 int w4_cu_count() {
@@ -710,6 +743,12 @@ int dm_gemm_w4_plan(GemmParams &p, int layout, int ab_dtype, bool aligned8, bool
   const char *env = getenv("DM_GEMM_W4");         // 0 = off, 1 = routing rule, 2 = every legal product, 3 = every whole-round shape (read per call: tests flip it)
   const int mode = env ? atoi(env) : 1;
   if (mode == 0 || ab_dtype != DM_BF16 || !aligned8) return 0;
+  if (p.k_fold > 0) {      // folded contraction: the FOLD instances (K segments of whole K steps; a tile is an even number of steps as ever)
+    if (p.k_fold % BK != 0) return 0;
+    static const bool attr_fold = w4_set_lds_limit<DM_TN, 0, 0, true>() && w4_set_lds_limit<DM_TN, 0, 9, true>() && w4_set_lds_limit<DM_TN, 0, 11, true>() &&
+                                  w4_set_lds_limit<DM_NT, 0, 0, true>() && w4_set_lds_limit<DM_NT, 0, 10, true>() && w4_set_lds_limit<DM_NN, 0, 0, true>();
+    if (!attr_fold) return 0;
+  }
   if (layout == DM_TN) {
     // wgrad: one (256 x 192 tile, K slice) per workgroup; slices of an even number of K steps chosen so that tiles x slices fills the CUs
     const char *tenv = getenv("DM_GEMM_W4_TN");     // 0 = off, 1 = routing rule (default), 2 = every legal product
@@ -762,7 +801,7 @@ int dm_gemm_w4_plan(GemmParams &p, int layout, int ab_dtype, bool aligned8, bool
     // reduction -- OFF by default (DM_GEMM_W4_SLICES=1 for A/B runs); the M <= 1024 products gain from slices on 64 x 64 tiles instead.
     static const bool slices_on = [] { const char *e = getenv("DM_GEMM_W4_SLICES"); return e && atoi(e) == 1; }();
     constexpr long long LIM = (1LL << 31) / (128LL * 4);
-    if (slices_on && can_split && mode != 0 && tiles * 2 <= cus && p.K >= 1536 && p.N < LIM && !(p.debug & 0x400)) {
+    if (slices_on && p.k_fold == 0 && can_split && mode != 0 && tiles * 2 <= cus && p.K >= 1536 && p.N < LIM && !(p.debug & 0x400)) {
       const int steps = p.K / BK;
       int split = (int)(cus / tiles);
       if (split > 4) split = 4;
@@ -835,6 +874,20 @@ void dm_gemm_w4_launch(const GemmParams &p, int layout, int grid, hipStream_t s)
     if (stag > 0 && layout != DM_TN && q.tiles_m * q.tiles_n > grid) q.debug |= (stag & 0x7fff) << 16;      // multi-tile forward / dgrad launches only
   }
 #define W4_GO(LAY, EKV) hipLaunchKernelGGL((dmw4::gemm_w4_kernel<LAY, 0, EKV>), dim3(grid), dim3(256), dmw4::LDS_BYTES, s, q)
+#define W4_GOF(LAY, EKV) hipLaunchKernelGGL((dmw4::gemm_w4_kernel<LAY, 0, EKV, true>), dim3(grid), dim3(256), dmw4::LDS_BYTES, s, q)
+  if (p.k_fold > 0) {                                      // hi / lo plane pairs ("bf16x3"): fp32 outputs
+    if (layout == DM_TN) {
+      if (lean_ok && key == 8) W4_GOF(DM_TN, 9);
+      else if (lean_ok && key == 10) W4_GOF(DM_TN, 11);
+      else W4_GOF(DM_TN, 0);
+    } else if (layout == DM_NT) {
+      if (lean_ok && key == 9) W4_GOF(DM_NT, 10);          // fp32 C + fp32 residual: fc2 / proj forward
+      else W4_GOF(DM_NT, 0);
+    } else {
+      W4_GOF(DM_NN, 0);
+    }
+    return;
+  }
   if (layout == DM_TN) {
     if (lean_ok && key == 8) W4_GO(DM_TN, 9);             // fp32 slab / gradient written
     else if (lean_ok && key == 10) W4_GO(DM_TN, 11);      // fp32 gradient accumulated in place
@@ -852,4 +905,5 @@ void dm_gemm_w4_launch(const GemmParams &p, int layout, int grid, hipStream_t s)
     else W4_GO(DM_NN, 0);
   }
 #undef W4_GO
+#undef W4_GOF
 }

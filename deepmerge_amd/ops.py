@@ -1244,7 +1244,17 @@ class BlockFn(torch.autograd.Function):
         wq, wp = lp_weight(qkv_w, dtype, (3 * Cc, Cc)), lp_weight(proj_w, dtype, (Cc, Cc))
         w1, w2 = lp_weight(fc1_w, dtype, (Hd, Cc)), lp_weight(fc2_w, dtype, (Cc, Hd))
         x2d = x.view(M, Cc)
+        # "bf16x3": every GEMM operand of the block as ONE hi / lo plane pair (Planes), made where the tensor is produced and used by
+        # all its consumers -- the forward product, and in the backward pass the weight gradient (as the right operand) or both the
+        # weight gradient and the data gradient (dy, as the left operand).  12 splits per block and step instead of 24, two pieces
+        # written per split instead of three, and the saved activations ARE the plane pairs (same bytes as the fp32 tensors).
+        planes = (dtype == torch.float32 and _FP32_PRODUCTS == "bf16x3" and planes_ok(M, Cc) and planes_ok(M, Hd) and planes_ok(Hd, Cc)
+                  and M * Cc * Cc >= _SPLIT_MIN_WORK)
+        if planes:
+            wq, wp, w1, w2 = (split_planes(w) for w in (wq, wp, w1, w2))
         y1, mean1, rstd1 = layernorm_fwd(x2d, n1w, n1b, eps, dtype)
+        if planes:
+            y1 = split_planes(y1)
         qkv = torch.empty((M, 3 * Cc), dtype=dtype, device=dev)
         gemm(DM_NT, y1, wq, qkv, M, 3 * Cc, Cc, lda=Cc, ldb=Cc, ldc=3 * Cc, bias=qkv_b)
         bias = bias_t = None
@@ -1261,8 +1271,11 @@ class BlockFn(torch.autograd.Function):
                 bias, bias_t = relpos_bias_gather(table.contiguous(), index32, N, transposed=True)
             o, lse = attention_fwd(qkv, bias, B, N, heads, D, scale)
         x1 = torch.empty((M, Cc), dtype=torch.float32, device=dev)
-        gemm(DM_NT, o.view(M, Cc), wp, x1, M, Cc, Cc, lda=Cc, ldb=Cc, ldc=Cc, bias=proj_b, residual=x2d)
+        o_op = split_planes(o.view(M, Cc)) if planes else o.view(M, Cc)
+        gemm(DM_NT, o_op, wp, x1, M, Cc, Cc, lda=Cc, ldb=Cc, ldc=Cc, bias=proj_b, residual=x2d)
         y2, mean2, rstd2 = layernorm_fwd(x1, n2w, n2b, eps, dtype)
+        if planes:
+            y2 = split_planes(y2)
         h = torch.empty((M, Hd), dtype=dtype, device=dev)
         if any(ctx.needs_input_grad):
             pre = torch.empty((M, Hd), dtype=dtype, device=dev)       # GELU'(pre-activation), saved for backward
@@ -1271,9 +1284,14 @@ class BlockFn(torch.autograd.Function):
             pre = None
             gemm(DM_NT, y2, w1, h, M, Hd, Cc, lda=Cc, ldb=Cc, ldc=Hd, bias=fc1_b, epilogue=DM_EPI_GELU)
         x2 = torch.empty((M, Cc), dtype=torch.float32, device=dev)
+        if planes:
+            h = split_planes(h)
         gemm(DM_NT, h, w2, x2, M, Cc, Hd, lda=Hd, ldb=Hd, ldc=Cc, bias=fc2_b, residual=x1)
+        if planes:          # (the bf16 [2, rows, cols] tensors travel through save_for_backward like any other)
+            y1, y2, h, wq, wp, w1, w2, o_op = y1.t, y2.t, h.t, wq.t, wp.t, w1.t, w2.t, o_op.t
+        ctx.planes = planes
         ctx.save_for_backward(x2d, mean1, rstd1, y1, qkv, o, lse, bias, bias_t, index32, x1, mean2, rstd2, y2, pre, h,
-                              wq, wp, w1, w2, n1w, n2w)
+                              wq, wp, w1, w2, n1w, n2w, o_op if planes else None)
         ctx.dims = (B, N, Cc, heads, D, Hd, scale, None if table is None else table.shape[0])
         ctx.table_in_kernel = cube is not None
         ctx.split_imgs = split_imgs         # (two bf16 tensors of qkv's size, alive until this node's backward has run)
@@ -1284,11 +1302,14 @@ class BlockFn(torch.autograd.Function):
     @_replay_products
     def backward(ctx, dx2):
         (x, mean1, rstd1, y1, qkv, o, lse, bias, bias_t, index32, x1, mean2, rstd2, y2, pre, h,
-         wq, wp, w1, w2, n1w, n2w) = ctx.saved_tensors
+         wq, wp, w1, w2, n1w, n2w, o_op) = ctx.saved_tensors
+        planes = ctx.planes
+        if planes:
+            y1, y2, h, wq, wp, w1, w2, o_op = (Planes(t_) for t_ in (y1, y2, h, wq, wp, w1, w2, o_op))
         (P_n1w, P_n1b, P_table, P_qkv_w, P_qkv_b, P_proj_w, P_proj_b, P_n2w, P_n2b, P_fc1_w, P_fc1_b, P_fc2_w, P_fc2_b) = ctx.params
         B, N, Cc, heads, D, Hd, scale, n_bins = ctx.dims
         M = B * N
-        dtype, dev = y1.dtype, x.device
+        dtype, dev = (torch.float32 if planes else y1.dtype), x.device
         lp = dtype != torch.float32
         lp_copy = getattr(dx2, "_dm_lp_copy", None)
         dx2 = dx2.contiguous().view(M, Cc)
@@ -1306,12 +1327,21 @@ class BlockFn(torch.autograd.Function):
             side.wait_stream(torch.cuda.current_stream())          # the operands' producers
             with torch.cuda.stream(side):
                 return gemm(*a, ws_slot="gemm_side", **kw)
-        wgrad(DM_TN, dy, h, dw2, Cc, Hd, M, lda=Cc, ldb=Hd, ldc=Hd, accumulate=_acc(P_fc2_w, k_w2), colsum_out=db2, colsum_accumulate=_acc(P_fc2_b, k_b2))
+
+        def bias_grad(g2d, db, acc_b):
+            """(operand for the two products that read the gradient g2d, kwargs that make the weight-gradient call produce db):
+            on plane pairs the column sums come from the split pass, otherwise they ride on the weight gradient."""
+            if planes:
+                return split_planes(g2d, colsum_out=db, colsum_accumulate=acc_b), {}
+            return g2d, dict(colsum_out=db, colsum_accumulate=acc_b)
+        dy, cs = bias_grad(dy, db2, _acc(P_fc2_b, k_b2))
+        wgrad(DM_TN, dy, h, dw2, Cc, Hd, M, lda=Cc, ldb=Hd, ldc=Hd, accumulate=_acc(P_fc2_w, k_w2), **cs)
         dpre = torch.empty((M, Hd), dtype=dtype, device=dev)
         gemm(DM_NN, dy, w2, dpre, M, Hd, Cc, lda=Cc, ldb=Hd, ldc=Hd, epilogue=DM_EPI_MUL, aux=pre, ldaux=Hd)
         dw1, k_w1 = _grad_out(P_fc1_w, (Hd, Cc), dev)
         db1, k_b1 = _grad_out(P_fc1_b, (Hd,), dev)
-        wgrad(DM_TN, dpre, y2, dw1, Hd, Cc, M, lda=Hd, ldb=Cc, ldc=Cc, accumulate=_acc(P_fc1_w, k_w1), colsum_out=db1, colsum_accumulate=_acc(P_fc1_b, k_b1))
+        dpre, cs = bias_grad(dpre, db1, _acc(P_fc1_b, k_b1))
+        wgrad(DM_TN, dpre, y2, dw1, Hd, Cc, M, lda=Hd, ldb=Cc, ldc=Cc, accumulate=_acc(P_fc1_w, k_w1), **cs)
         dy2 = torch.empty((M, Cc), dtype=dtype, device=dev)
         gemm(DM_NN, dpre, w1, dy2, M, Cc, Hd, lda=Hd, ldb=Cc, ldc=Cc)
         dg2, k_n2 = _grad_out(P_n2w, (Cc,), dev)
@@ -1325,9 +1355,10 @@ class BlockFn(torch.autograd.Function):
         # ---- attention -----------------------------------------------------------------------
         dwp, k_wp = _grad_out(P_proj_w, (Cc, Cc), dev)
         dbp, k_bp = _grad_out(P_proj_b, (Cc,), dev)
-        wgrad(DM_TN, dx1_lp, o.view(M, Cc), dwp, Cc, Cc, M, lda=Cc, ldb=Cc, ldc=Cc, accumulate=_acc(P_proj_w, k_wp), colsum_out=dbp, colsum_accumulate=_acc(P_proj_b, k_bp))
+        dx1_op, cs = bias_grad(dx1_lp, dbp, _acc(P_proj_b, k_bp))
+        wgrad(DM_TN, dx1_op, o_op if planes else o.view(M, Cc), dwp, Cc, Cc, M, lda=Cc, ldb=Cc, ldc=Cc, accumulate=_acc(P_proj_w, k_wp), **cs)
         do = torch.empty((M, Cc), dtype=dtype, device=dev)
-        gemm(DM_NN, dx1_lp, wp, do, M, Cc, Cc, lda=Cc, ldb=Cc, ldc=Cc)
+        gemm(DM_NN, dx1_op, wp, do, M, Cc, Cc, lda=Cc, ldb=Cc, ldc=Cc)
         tab, cube = None, None
         if ctx.split_imgs is not None:                       # "bf16x3": the split-bf16 backward kernels (table read in the kernel, slab included)
             hi, lo, scube = ctx.split_imgs
@@ -1350,9 +1381,10 @@ class BlockFn(torch.autograd.Function):
         dqkv2 = dqkv.view(M, 3 * Cc)
         dwq, k_wq = _grad_out(P_qkv_w, (3 * Cc, Cc), dev)
         dbq, k_bq = _grad_out(P_qkv_b, (3 * Cc,), dev)
-        wgrad(DM_TN, dqkv2, y1, dwq, 3 * Cc, Cc, M, lda=3 * Cc, ldb=Cc, ldc=Cc, accumulate=_acc(P_qkv_w, k_wq), colsum_out=dbq, colsum_accumulate=_acc(P_qkv_b, k_bq))
+        dqkv_op, cs = bias_grad(dqkv2, dbq, _acc(P_qkv_b, k_bq))
+        wgrad(DM_TN, dqkv_op, y1, dwq, 3 * Cc, Cc, M, lda=3 * Cc, ldb=Cc, ldc=Cc, accumulate=_acc(P_qkv_w, k_wq), **cs)
         dy1 = torch.empty((M, Cc), dtype=dtype, device=dev)
-        gemm(DM_NN, dqkv2, wq, dy1, M, Cc, 3 * Cc, lda=3 * Cc, ldb=Cc, ldc=Cc)
+        gemm(DM_NN, dqkv_op, wq, dy1, M, Cc, 3 * Cc, lda=3 * Cc, ldb=Cc, ldc=Cc)
         dg1, k_n1 = _grad_out(P_n1w, (Cc,), dev)
         dbt1, k_n1b = _grad_out(P_n1b, (Cc,), dev)
         if k_n1 != k_n1b:

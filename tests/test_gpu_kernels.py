@@ -1044,14 +1044,22 @@ def test_split_bf16_wgrad_with_an_offset_operand():
 
 @pytest.mark.parametrize("layout,M,N,K", [("NT", 2048, 768, 768), ("NT", 1024, 768, 3072), ("NT", 320, 192, 128), ("NN", 2048, 768, 2304),
                                           ("NN", 4096, 3072, 768), ("TN", 768, 768, 4096), ("TN", 2304, 768, 16384), ("TN", 192, 320, 1024)])
-def test_folded_split_product_equals_the_image_product(layout, M, N, K, monkeypatch):
+@pytest.mark.parametrize("family", ["tiles", "w4", "lds"])
+def test_folded_split_product_equals_the_image_product(layout, M, N, K, family, monkeypatch):
     """DmGemmArgs.k_fold (ABI 4): the bf16x3 product on hi / lo PLANE PAIRS, three K segments that re-read the planes in place, is the
     same sum in the same order as the product over the three-piece images of dm_split_bf16 -- bit-identical on the same kernel
-    (the other GEMM families are switched off for both runs), with the fused epilogues and the split-K / K-slice paths."""
+    (the 128 x 128 / 64 x 64 tiles, the 4-wave persistent kernel, or the LDS-DMA kernels; the other families are off for both runs), with
+    the fused epilogues and the split-K / K-slice paths."""
     from deepmerge_amd import ops
     from deepmerge_amd._lib import DM_EPI_MUL, DM_EPI_NONE, DM_NN, DM_NT, DM_TN
     for k in ("DM_GEMM_W4", "DM_GEMM_256", "DM_GEMM_RING"):
         monkeypatch.setenv(k, "0")
+    if family == "w4":                                 # the 4-wave persistent kernel wherever it is legal (256 x 192 tiles, K % 128 == 0)
+        monkeypatch.setenv("DM_GEMM_W4", "2")
+        monkeypatch.setenv("DM_GEMM_W4_TN", "2")
+    if family == "lds":                                # the LDS-DMA kernels: two-workgroup ring (NT) and the 256 x 256 pipeline
+        monkeypatch.setenv("DM_GEMM_RING", "2")
+        monkeypatch.setenv("DM_GEMM_256", "2")
     torch.manual_seed(M + N + K)
     lay = {"NT": DM_NT, "NN": DM_NN, "TN": DM_TN}[layout]
     A = torch.randn((K, M) if layout == "TN" else (M, K), device=DEV)
