@@ -781,17 +781,20 @@ static bool split_rows_ok(const float *src, int64_t ld, int64_t rows, int64_t co
   return cols % 8 == 0 && rows < (1LL << 31) && cols < (1LL << 31) && dm_aligned16(src) && dm_aligned16(dst) && ld % 4 == 0 &&
          (stack ? (rows * cols) % 8 == 0 : true);
 }
-static void split_rows_grid(int64_t rows, int64_t cols, int &gx, int &gy) {
+static void split_rows_grid(int64_t rows, int64_t cols, int &gx, int &gy, bool colsum = false) {
   gx = (int)((cols / 8 + 31) / 32);
   long long y = (rows + 7) / 8;
-  const long long cap = 8192 / gx > 0 ? 8192 / gx : 1;       // ~32 blocks per CU in flight at most; rows beyond are walked
+  // ~32 blocks per CU in flight at most; rows beyond are walked.  With column sums every row of blocks leaves a partial row behind
+  // (8 MB for a 16384 x 3072 operand at 8192 blocks, ~7 us to fold): a quarter of the blocks still fills the chip (8 per CU)
+  const int blocks = colsum ? 2048 : 8192;
+  const long long cap = blocks / gx > 0 ? blocks / gx : 1;
   gy = (int)(y > cap ? cap : y);
 }
 
 extern "C" int64_t dm_split_colsum_partial_floats(int64_t rows, int64_t cols) {
   if (rows <= 0 || cols <= 0 || cols % 8) return 0;
   int gx, gy;
-  split_rows_grid(rows, cols, gx, gy);
+  split_rows_grid(rows, cols, gx, gy, true);
   return (int64_t)gy * cols;
 }
 
@@ -802,7 +805,7 @@ extern "C" int dm_split_bf16_colsum(const float *src, int64_t ld, int64_t rows, 
   DM_REQUIRE(split_rows_ok(src, ld, rows, cols, dst, stack), DM_ERR_UNSUPPORTED,
              "dm_split_bf16_colsum: needs cols %% 8 == 0, ld %% 4 == 0 and 16-byte aligned tensors (cols=%lld ld=%lld)", (long long)cols, (long long)ld);
   int gx, gy;
-  split_rows_grid(rows, cols, gx, gy);
+  split_rows_grid(rows, cols, gx, gy, true);
   hipLaunchKernelGGL(split_bf16_rows_kernel<true>, dim3(gx, (unsigned)gy), dim3(32, 8), 0, reinterpret_cast<hipStream_t>(stream), src, (long long)ld,
                      (int)rows, (int)cols, (bf16_t *)dst, stack ? 1 : 0, pattern, partial, 3);
   DM_LAUNCH_CHECK("dm_split_bf16_colsum");
@@ -817,7 +820,7 @@ extern "C" int dm_split_bf16_planes(const float *src, int64_t ld, int64_t rows, 
   DM_REQUIRE(split_rows_ok(src, ld, rows, cols, dst, 1), DM_ERR_UNSUPPORTED,
              "dm_split_bf16_planes: needs cols %% 8 == 0, ld %% 4 == 0 and 16-byte aligned tensors (cols=%lld ld=%lld)", (long long)cols, (long long)ld);
   int gx, gy;
-  split_rows_grid(rows, cols, gx, gy);
+  split_rows_grid(rows, cols, gx, gy, partial != nullptr);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (partial)
     hipLaunchKernelGGL(split_bf16_rows_kernel<true>, dim3(gx, (unsigned)gy), dim3(32, 8), 0, s, src, (long long)ld, (int)rows, (int)cols, (bf16_t *)dst, 1, 0b10, partial, 2);

@@ -197,9 +197,11 @@ def planes_ok(rows: int, cols: int) -> bool:
     return _PLANES and rows % 64 == 0 and cols % 64 == 0 and rows * cols < (1 << 30)
 
 
-def split_planes(x: torch.Tensor, colsum_out: Optional[torch.Tensor] = None, colsum_accumulate: bool = False) -> Planes:
+def split_planes(x: torch.Tensor, colsum_out: Optional[torch.Tensor] = None, colsum_accumulate: bool = False, defer: bool = False) -> Planes:
     """x fp32 [rows, cols] (row stride % 4 == 0) -> Planes; with colsum_out [cols] (+)= the column sums of x on the side (the bias
-    gradient that goes with a weight gradient: x = dy is read once for both)."""
+    gradient that goes with a weight gradient: x = dy is read once for both).  defer=True (inside a backward pass, colsum_out a
+    gradient sink nobody reads before the pass ends): the reduction of the partial rows joins the end-of-backward batch
+    (`flush_reductions`) instead of being a launch of its own."""
     _need_cuda(x, colsum_out)
     if x.dtype != torch.float32 or x.dim() != 2 or x.stride(1) != 1:
         raise ValueError("split_planes takes a 2-D fp32 matrix with contiguous rows")
@@ -208,10 +210,16 @@ def split_planes(x: torch.Tensor, colsum_out: Optional[torch.Tensor] = None, col
     if colsum_out is None:
         check(_lib.lib().dm_split_bf16_planes(x.data_ptr(), x.stride(0), rows, cols, out.data_ptr(), None, None, _stream()), "dm_split_bf16_planes")
         return Planes(out)
-    part = workspace(4 * _lib.lib().dm_split_colsum_partial_floats(rows, cols), x.device, "planes.partial").view(torch.float32)
+    n_part = _lib.lib().dm_split_colsum_partial_floats(rows, cols)
+    deferred = defer and _DEFER_REDUCTIONS and _in_backward()
+    part = (torch.empty(n_part, dtype=torch.float32, device=x.device) if deferred      # (alive until the batch launch: not a shared slot)
+            else workspace(4 * n_part, x.device, "planes.partial").view(torch.float32))
     rows_out = C.c_int32(0)
     check(_lib.lib().dm_split_bf16_planes(x.data_ptr(), x.stride(0), rows, cols, out.data_ptr(), part.data_ptr(), C.byref(rows_out), _stream()),
           "dm_split_bf16_planes")
+    if deferred:
+        _queue_reduce(part, colsum_out, colsum_out, rows_out.value, cols, cols, colsum_accumulate)
+        return Planes(out)
     item = (_lib.DmReduceItem * 1)()
     item[0].partial, item[0].out0, item[0].out1 = part.data_ptr(), colsum_out.data_ptr(), colsum_out.data_ptr()
     item[0].nrows, item[0].width, item[0].split, item[0].accumulate = rows_out.value, cols, cols, int(bool(colsum_accumulate))
@@ -1328,19 +1336,19 @@ class BlockFn(torch.autograd.Function):
             with torch.cuda.stream(side):
                 return gemm(*a, ws_slot="gemm_side", **kw)
 
-        def bias_grad(g2d, db, acc_b):
+        def bias_grad(g2d, db, acc_b, direct):
             """(operand for the two products that read the gradient g2d, kwargs that make the weight-gradient call produce db):
             on plane pairs the column sums come from the split pass, otherwise they ride on the weight gradient."""
             if planes:
-                return split_planes(g2d, colsum_out=db, colsum_accumulate=acc_b), {}
+                return split_planes(g2d, colsum_out=db, colsum_accumulate=acc_b, defer=direct), {}
             return g2d, dict(colsum_out=db, colsum_accumulate=acc_b)
-        dy, cs = bias_grad(dy, db2, _acc(P_fc2_b, k_b2))
+        dy, cs = bias_grad(dy, db2, _acc(P_fc2_b, k_b2), k_b2)
         wgrad(DM_TN, dy, h, dw2, Cc, Hd, M, lda=Cc, ldb=Hd, ldc=Hd, accumulate=_acc(P_fc2_w, k_w2), **cs)
         dpre = torch.empty((M, Hd), dtype=dtype, device=dev)
         gemm(DM_NN, dy, w2, dpre, M, Hd, Cc, lda=Cc, ldb=Hd, ldc=Hd, epilogue=DM_EPI_MUL, aux=pre, ldaux=Hd)
         dw1, k_w1 = _grad_out(P_fc1_w, (Hd, Cc), dev)
         db1, k_b1 = _grad_out(P_fc1_b, (Hd,), dev)
-        dpre, cs = bias_grad(dpre, db1, _acc(P_fc1_b, k_b1))
+        dpre, cs = bias_grad(dpre, db1, _acc(P_fc1_b, k_b1), k_b1)
         wgrad(DM_TN, dpre, y2, dw1, Hd, Cc, M, lda=Hd, ldb=Cc, ldc=Cc, accumulate=_acc(P_fc1_w, k_w1), **cs)
         dy2 = torch.empty((M, Cc), dtype=dtype, device=dev)
         gemm(DM_NN, dpre, w1, dy2, M, Cc, Hd, lda=Hd, ldb=Cc, ldc=Cc)
@@ -1355,7 +1363,7 @@ class BlockFn(torch.autograd.Function):
         # ---- attention -----------------------------------------------------------------------
         dwp, k_wp = _grad_out(P_proj_w, (Cc, Cc), dev)
         dbp, k_bp = _grad_out(P_proj_b, (Cc,), dev)
-        dx1_op, cs = bias_grad(dx1_lp, dbp, _acc(P_proj_b, k_bp))
+        dx1_op, cs = bias_grad(dx1_lp, dbp, _acc(P_proj_b, k_bp), k_bp)
         wgrad(DM_TN, dx1_op, o_op if planes else o.view(M, Cc), dwp, Cc, Cc, M, lda=Cc, ldb=Cc, ldc=Cc, accumulate=_acc(P_proj_w, k_wp), **cs)
         do = torch.empty((M, Cc), dtype=dtype, device=dev)
         gemm(DM_NN, dx1_op, wp, do, M, Cc, Cc, lda=Cc, ldb=Cc, ldc=Cc)
@@ -1381,7 +1389,7 @@ class BlockFn(torch.autograd.Function):
         dqkv2 = dqkv.view(M, 3 * Cc)
         dwq, k_wq = _grad_out(P_qkv_w, (3 * Cc, Cc), dev)
         dbq, k_bq = _grad_out(P_qkv_b, (3 * Cc,), dev)
-        dqkv_op, cs = bias_grad(dqkv2, dbq, _acc(P_qkv_b, k_bq))
+        dqkv_op, cs = bias_grad(dqkv2, dbq, _acc(P_qkv_b, k_bq), k_bq)
         wgrad(DM_TN, dqkv_op, y1, dwq, 3 * Cc, Cc, M, lda=3 * Cc, ldb=Cc, ldc=Cc, accumulate=_acc(P_qkv_w, k_wq), **cs)
         dy1 = torch.empty((M, Cc), dtype=dtype, device=dev)
         gemm(DM_NN, dqkv_op, wq, dy1, M, Cc, 3 * Cc, lda=3 * Cc, ldb=Cc, ldc=Cc)
