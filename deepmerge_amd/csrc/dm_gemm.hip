@@ -344,7 +344,7 @@ __global__ __launch_bounds__(NTHREADS, (TM == 4 ? WG_PER_CU : 4)) void gemm_kern
 #pragma unroll
         for (int j = 0; j < TM; ++j) mma<T>(acc[i][j], fa[i], fb[j]);
       if constexpr (CS) {
-        if (colsum) {
+        if (colsum && (!FOLD || dm_fold_counts(p, kbeg + kt * BK))) {
 #pragma unroll
           for (int i = 0; i < TM; ++i) mma<T>(accb[i], fa[i], ones);
         }
@@ -711,7 +711,6 @@ extern "C" int dm_gemm(const DmGemmArgs *a, void *stream) {
   if (a->k_fold > 0) {
     DM_REQUIRE(a->ab_dtype == DM_BF16 && a->K == 3 * a->k_fold && a->k_fold % 64 == 0, DM_ERR_UNSUPPORTED,
                "dm_gemm: k_fold needs bf16 operands, K == 3 * k_fold and k_fold %% 64 == 0 (K=%d k_fold=%d)", a->K, a->k_fold);
-    DM_REQUIRE(!a->colsum_a, DM_ERR_UNSUPPORTED, "dm_gemm: colsum_a does not go with k_fold (take the sums from dm_split_bf16_planes)");
     for (int sgm = 0; sgm < 3; ++sgm) {
       DM_REQUIRE(a->a_fold[sgm] >= 0 && a->a_fold[sgm] < (1LL << 30) && a->b_fold[sgm] >= 0 && a->b_fold[sgm] < (1LL << 30) &&
                      a->a_fold[sgm] % 8 == 0 && a->b_fold[sgm] % 8 == 0,
@@ -897,6 +896,16 @@ extern "C" int dm_gemm(const DmGemmArgs *a, void *stream) {
       hipLaunchKernelGGL(colsum_rows_reduce_kernel, dim3((a->M + 63) / 64), dim3(64), 0, s, cs_region, a->colsum_a, a->M, split * cs_rows_per_slice,
                          a->colsum_accumulate);
       DM_LAUNCH_CHECK("dm_gemm(colsum reduce)");
+    } else if (folded) {      // the distinct pieces of A, one pass each: colsum(hi) + colsum(lo)
+      int accum = a->colsum_accumulate;
+      for (int sgm = 0; sgm < 3; ++sgm) {
+        bool first = true;
+        for (int e = 0; e < sgm; ++e) first = first && a->a_fold[e] != a->a_fold[sgm];
+        if (!first) continue;
+        const int rc = dm_colsum(reinterpret_cast<const unsigned short *>(a->A) + a->a_fold[sgm], a->ab_dtype, a->lda, a->colsum_a, a->k_fold, a->M, accum, cs_region, stream);
+        if (rc != DM_OK) return rc;
+        accum = 1;
+      }
     } else {
       const int rc = dm_colsum(a->A, a->ab_dtype, a->lda, a->colsum_a, a->K, a->M, a->colsum_accumulate, cs_region, stream);
       if (rc != DM_OK) return rc;

@@ -221,7 +221,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
 #define DM_COLSUM(MI)                                                                      \
   do {                                                                                     \
     if constexpr (AM) {                                                                    \
-      if (colsum && (kt & 3) == wc) {                                                      \
+      if (colsum && (kt & 3) == wc && (!FOLD || dm_fold_counts(p, kbeg + kt * BK256))) {   \
         _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                   \
         _Pragma("unroll") for (int i = 0; i < 4; ++i)                                      \
             mma<bf16_t>(accb[(MI) * 4 + i], fa[2 * i + ks], ones);                         \

@@ -23,6 +23,14 @@ struct GemmParams {
   long long a_fold[3], b_fold[3];
 };
 
+// Folded contraction + column sums of A (the bias gradient on a weight gradient over plane pairs): a K position counts when its
+// segment is the FIRST one that reads its piece of A -- (hi, hi, lo): segments 0 and 2, so that the sums are colsum(hi) + colsum(lo).
+__device__ __forceinline__ bool dm_fold_counts(const GemmParams &p, int k) {
+  if (p.k_fold <= 0 || k < p.k_fold) return true;
+  if (k < 2 * p.k_fold) return p.a_fold[1] != p.a_fold[0];
+  return p.a_fold[2] != p.a_fold[0] && p.a_fold[2] != p.a_fold[1];
+}
+
 struct DmGemmRow { long long c, r, x; };
 
 // Element offsets of output row m in C / residual / aux (grouped-row addressing writes patch tokens straight

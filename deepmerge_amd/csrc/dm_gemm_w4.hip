@@ -350,6 +350,7 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmParams p) {
   auto mm = [&](f32x4 &c, const u32x4 &a, const u32x4 &b) __attribute__((always_inline)) {
     if constexpr (!(DBG & 32)) mma_pinned(c, a, b);
   };
+  bool cs_seg = true;      // folded contraction: does the K step in progress count in A's column sums (dm_fold_counts)
   auto mfmas = [&](auto ks_tag, auto nks_tag, auto nbuf_tag, auto grp_tag, auto sset_tag, auto sbuf_tag) __attribute__((always_inline)) {
     constexpr int ks = decltype(ks_tag)::value;
     constexpr int q0 = decltype(grp_tag)::value == 0 ? 0 : PH;
@@ -371,7 +372,7 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmParams p) {
       mm(acc[i][5], fa[i], fb[ks][5]);
       if (i < 6) load_b1(i, nks_tag, nbuf_tag);
       if constexpr (AMM) {
-        if (colsum && wn == ks) {
+        if (colsum && wn == ks && cs_seg) {
           mm(accb[i], fa[i], ones);
         }
       }
@@ -658,6 +659,7 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmParams p) {
   // the freed set then fetches step s + 3.
   auto body = [&](auto par_tag) __attribute__((always_inline)) {
     constexpr int PAR = decltype(par_tag)::value;
+    if constexpr (FOLD && AMM) cs_seg = dm_fold_counts(p, kbeg + (kt + PAR) * BK);
     mfmas(IC<0>{}, IC<1>{}, IC<PAR>{}, IC<1>{}, IC<1 - PAR>{}, IC<1 - PAR>{});     // k-step 0 (+ fragments of k-step 1; group Y of step s + 1)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();

@@ -250,8 +250,7 @@ def gemm(layout: int, A: torch.Tensor, B: torch.Tensor, C_out: torch.Tensor, M: 
             B = split_planes(torch.as_strided(B, (b_rows, b_cols), (ldb if ldb is not None else b_cols, 1)))
         if (A.rows, A.cols) != (a_rows, a_cols) or (B.rows, B.cols) != (b_rows, b_cols):
             raise ValueError(f"plane pair shapes {(A.rows, A.cols)} / {(B.rows, B.cols)} do not match the product {(a_rows, a_cols)} / {(b_rows, b_cols)}")
-        if colsum_out is not None:
-            raise ValueError("column sums of a pre-split operand belong to its split_planes call")
+        # (column sums of a pre-split left operand: dm_gemm sums the hi and the lo plane -- fused into the weight-gradient kernels)
         fold = (K, A.rows * A.cols, B.rows * B.cols)
         A, B, lda, ldb, K = A.t, B.t, a_cols, b_cols, 3 * K
     _need_cuda(A, B, C_out, bias, residual, aux, colsum_out)

@@ -1097,6 +1097,13 @@ def test_folded_split_product_equals_the_image_product(layout, M, N, K, family, 
         wref = dy.double().t() @ A.double()
         assert ((dW.double() - wref).abs().max() / wref.abs().max()).item() < 3e-5
         assert (db.double() - dy.double().sum(0)).abs().max().item() < 1e-3 * max(1.0, M / 1024)
+        # the column sums of a plane pair ride on the weight gradient itself: colsum(hi) + colsum(lo), the duplicate hi segment skipped
+        db2 = torch.full((256,), 3.0, device=DEV)
+        dW2 = torch.empty(256, K, device=DEV)
+        ops.gemm(DM_TN, dyp, Ap, dW2, 256, K, M, colsum_out=db2, colsum_accumulate=True)
+        assert torch.equal(dW2, dW)
+        pair = dyp.t.float().sum(0)                                        # hi + lo, as fp32 values
+        assert (db2.double() - 3.0 - pair.double().sum(0)).abs().max().item() < 2e-3 * max(1.0, M / 1024)
 
 
 @pytest.mark.parametrize("layout", ["NT", "NN", "TN"])
