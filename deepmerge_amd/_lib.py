@@ -18,6 +18,7 @@ HEADER_PATH = os.path.join(ROOT, "include", "deepmerge_hip.h")
 
 DM_F32, DM_BF16 = 0, 1
 DM_NT, DM_NN, DM_TN = 0, 1, 2
+DM_BF16_PAIR = 2      # DmGemmArgs.c_dtype: C as a hi / lo plane pair
 DM_EPI_NONE, DM_EPI_GELU, DM_EPI_DGELU, DM_EPI_GELU_GRAD, DM_EPI_MUL = 0, 1, 2, 3, 4
 
 _STATUS = {-1: "bad shape", -2: "bad dtype", -3: "bad alignment", -4: "workspace", -5: "HIP error", -6: "unsupported"}
@@ -42,6 +43,7 @@ class DmGemmArgs(C.Structure):
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
         ("colsum_a", C.c_void_p), ("colsum_accumulate", C.c_int32),
         ("k_fold", C.c_int32), ("a_fold", C.c_int64 * 3), ("b_fold", C.c_int64 * 3),
+        ("c_plane", C.c_int64),
     ]
 
 

@@ -690,7 +690,11 @@ extern "C" int dm_gemm(const DmGemmArgs *a, void *stream) {
   DM_REQUIRE(a->M > 0 && a->N > 0 && a->K > 0, DM_ERR_BAD_SHAPE, "dm_gemm: M,N,K must be positive (got %d,%d,%d)", a->M, a->N, a->K);
   DM_REQUIRE(a->layout >= DM_NT && a->layout <= DM_TN, DM_ERR_BAD_SHAPE, "dm_gemm: bad layout %d", a->layout);
   DM_REQUIRE(a->ab_dtype == DM_F32 || a->ab_dtype == DM_BF16, DM_ERR_BAD_DTYPE, "dm_gemm: bad ab_dtype %d", a->ab_dtype);
-  DM_REQUIRE(a->c_dtype == DM_F32 || a->c_dtype == DM_BF16, DM_ERR_BAD_DTYPE, "dm_gemm: bad c_dtype %d", a->c_dtype);
+  DM_REQUIRE(a->c_dtype == DM_F32 || a->c_dtype == DM_BF16 || a->c_dtype == DM_BF16_PAIR, DM_ERR_BAD_DTYPE, "dm_gemm: bad c_dtype %d", a->c_dtype);
+  if (a->c_dtype == DM_BF16_PAIR)
+    DM_REQUIRE(a->layout != DM_TN && !a->accumulate && a->split_k <= 1 && a->c_plane > 0 && a->c_plane % 8 == 0 && a->ldc % 8 == 0 && a->N % 8 == 0 &&
+                   a->ab_dtype == DM_BF16 && a->rows_per_group == 0,
+               DM_ERR_UNSUPPORTED, "dm_gemm: a plane-pair result needs an NT / NN bf16 product without accumulate, N, ldc and c_plane multiples of 8");
   DM_REQUIRE(a->A && a->B && a->C, DM_ERR_BAD_SHAPE, "dm_gemm: null operand");
   DM_REQUIRE(!(a->accumulate && a->c_dtype != DM_F32), DM_ERR_BAD_DTYPE, "dm_gemm: accumulate needs an fp32 C");
   DM_REQUIRE(!(a->accumulate && (a->epilogue == DM_EPI_DGELU || a->epilogue == DM_EPI_MUL)), DM_ERR_UNSUPPORTED,
@@ -707,6 +711,7 @@ extern "C" int dm_gemm(const DmGemmArgs *a, void *stream) {
   p.epilogue = a->epilogue; p.accumulate = a->accumulate; p.c_dtype = a->c_dtype; p.aux_dtype = a->aux_dtype;
 
   // folded contraction (hi / lo plane pairs of the "bf16x3" products): three K segments of k_fold, each a plain operand at its offset
+  p.c_plane = a->c_dtype == DM_BF16_PAIR ? a->c_plane : 0;
   p.k_fold = 0;
   if (a->k_fold > 0) {
     DM_REQUIRE(a->ab_dtype == DM_BF16 && a->K == 3 * a->k_fold && a->k_fold % 64 == 0, DM_ERR_UNSUPPORTED,
@@ -751,7 +756,7 @@ extern "C" int dm_gemm(const DmGemmArgs *a, void *stream) {
                          (a->aux == nullptr || a->aux_dtype == DM_F32) &&
                          ((a->M + BM - 1) / BM) * ((a->N + BN - 1) / BN) < 16);
   if (!mfma_ok) {
-    DM_REQUIRE(!folded, DM_ERR_UNSUPPORTED, "dm_gemm: k_fold needs the MFMA path's alignment (M=%d N=%d K=%d)", a->M, a->N, a->K);
+    DM_REQUIRE(!folded && a->c_dtype != DM_BF16_PAIR, DM_ERR_UNSUPPORTED, "dm_gemm: k_fold / a plane-pair result need the MFMA path's alignment (M=%d N=%d K=%d)", a->M, a->N, a->K);
     DM_REQUIRE(a->ab_dtype == DM_F32 && a->c_dtype == DM_F32 && (a->aux == nullptr || a->aux_dtype == DM_F32),
                DM_ERR_BAD_ALIGN, "dm_gemm: shape/alignment needs the generic path, which is fp32-only "
                "(M=%d N=%d K=%d lda=%lld ldb=%lld)", a->M, a->N, a->K, (long long)a->lda, (long long)a->ldb);

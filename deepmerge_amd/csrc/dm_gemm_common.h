@@ -21,7 +21,21 @@ struct GemmParams {
   // elements behind A (b_fold: B) and is addressed inside the segment as a plain operand of contraction length k_fold.  0: plain.
   int k_fold;
   long long a_fold[3], b_fold[3];
+  long long c_plane;    // c_dtype == DM_BF16_PAIR: element offset of the lo plane behind C (the hi plane)
 };
+
+// The result strip as a hi / lo plane pair (c_dtype == DM_BF16_PAIR): hi = bf16(v), lo = bf16(v - hi) -- the split of dm_split_bf16.
+__device__ __forceinline__ void dm_store_pair4(const GemmParams &p, long long off, const f32x4 &v) {
+  bf16x4 h, l;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    h[e] = (bf16_t)v[e];
+    l[e] = (bf16_t)(v[e] - (float)h[e]);
+  }
+  bf16_t *c = reinterpret_cast<bf16_t *>(p.C) + off;
+  *reinterpret_cast<bf16x4 *>(c) = h;
+  *reinterpret_cast<bf16x4 *>(c + p.c_plane) = l;
+}
 
 // Folded contraction + column sums of A (the bias gradient on a weight gradient over plane pairs): a K position counts when its
 // segment is the FIRST one that reads its piece of A -- (hi, hi, lo): segments 0 and 2, so that the sums are colsum(hi) + colsum(lo).
@@ -93,8 +107,10 @@ __device__ __forceinline__ void dm_gemm_emit(const GemmParams &p, f32x4 v, const
     float *c = reinterpret_cast<float *>(p.C) + rb.c + n;
     if (p.accumulate) v += dm_load4(c);
     dm_store4(c, v);
-  } else {
+  } else if (p.c_dtype == DM_BF16) {
     dm_store4(reinterpret_cast<bf16_t *>(p.C) + rb.c + n, v);
+  } else {
+    dm_store_pair4(p, rb.c + n, v);
   }
 }
 
@@ -149,8 +165,10 @@ __device__ __forceinline__ void dm_gemm_strip_store(const GemmParams &p, f32x4 v
   if (p.c_dtype == DM_F32) {
     if (p.accumulate) v += pre.y;      // (accumulate never goes with an aux-reading epilogue: dm_gemm refuses the combination)
     dm_store4(reinterpret_cast<float *>(p.C) + rb.c + n, v);
-  } else {
+  } else if (p.c_dtype == DM_BF16) {
     dm_store4(reinterpret_cast<bf16_t *>(p.C) + rb.c + n, v);
+  } else {
+    dm_store_pair4(p, rb.c + n, v);
   }
 }
 
@@ -212,9 +230,20 @@ __device__ __forceinline__ void dm_gemm_emit8(const GemmParams &p, f32x4 lo, f32
     if (p.accumulate) { lo += dm_load4(c); hi += dm_load4(c + 4); }
     dm_store4(c, lo);
     dm_store4(c + 4, hi);
-  } else {
+  } else if (p.c_dtype == DM_BF16) {
     bf16x8 o = {(bf16_t)lo[0], (bf16_t)lo[1], (bf16_t)lo[2], (bf16_t)lo[3], (bf16_t)hi[0], (bf16_t)hi[1], (bf16_t)hi[2], (bf16_t)hi[3]};
     *reinterpret_cast<bf16x8 *>(reinterpret_cast<bf16_t *>(p.C) + rb.c + n) = o;
+  } else {      // hi / lo plane pair: two 16-byte stores, as an fp32 row piece would take
+    bf16x8 h = {(bf16_t)lo[0], (bf16_t)lo[1], (bf16_t)lo[2], (bf16_t)lo[3], (bf16_t)hi[0], (bf16_t)hi[1], (bf16_t)hi[2], (bf16_t)hi[3]};
+    bf16x8 l;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      l[e] = (bf16_t)(lo[e] - (float)h[e]);
+      l[4 + e] = (bf16_t)(hi[e] - (float)h[4 + e]);
+    }
+    bf16_t *c = reinterpret_cast<bf16_t *>(p.C) + rb.c + n;
+    *reinterpret_cast<bf16x8 *>(c) = h;
+    *reinterpret_cast<bf16x8 *>(c + p.c_plane) = l;
   }
 }
 
@@ -450,7 +479,8 @@ __host__ __device__ inline int dm_epi_lean_key(const GemmParams &p, int rows) {
   const bool aux_read = p.aux && (p.epilogue == DM_EPI_DGELU || p.epilogue == DM_EPI_MUL);
   const bool aux_write = p.aux && (p.epilogue == DM_EPI_GELU || p.epilogue == DM_EPI_GELU_GRAD);
   const bool lean = p.rows_per_group == 0 && !(p.debug & 0x400) && p.ldc < lim && p.ldr < lim && p.ldaux < lim &&
-                    !(aux_read && p.accumulate);          // (one prefetch slot serves the old C or the aux operand)
+                    !(aux_read && p.accumulate) &&        // (one prefetch slot serves the old C or the aux operand)
+                    p.c_dtype != DM_BF16_PAIR;            // (plane-pair results: the generic form's dm_gemm_emit8)
   if (!lean) return -1;
   const bool c32 = p.c_dtype == DM_F32, x32 = p.aux_dtype == DM_F32;
   const int yl = (c32 && p.accumulate) ? 1 : aux_read ? (x32 ? 3 : 2) : 0;

@@ -862,7 +862,7 @@ void dm_gemm_w4_launch(const GemmParams &p, int layout, int grid, hipStream_t s)
   // Which epilogue: the lean form (dm_gemm_common.h) where its preconditions hold -- plain rows, 32-bit offsets inside a wave pair's
   // 128 rows -- and the item structure is one of the instantiated ones; the generic form otherwise (and with DM_GEMM_EPI_LEAN=0).
   constexpr long long LIM = (1LL << 31) / (128LL * 4);
-  const bool lean_ok = !(p.debug & 0x400) && p.rows_per_group == 0 && p.ldc < LIM && p.ldr < LIM && p.ldaux < LIM && p.N < LIM;
+  const bool lean_ok = !(p.debug & 0x400) && p.rows_per_group == 0 && p.ldc < LIM && p.ldr < LIM && p.ldaux < LIM && p.N < LIM && p.c_dtype != DM_BF16_PAIR;
   const bool c32 = p.c_dtype == DM_F32, x32 = p.aux_dtype == DM_F32;
   const bool aux_read = p.aux && (p.epilogue == DM_EPI_DGELU || p.epilogue == DM_EPI_MUL);
   const bool aux_write = p.aux && (p.epilogue == DM_EPI_GELU || p.epilogue == DM_EPI_GELU_GRAD);

@@ -235,6 +235,11 @@ def gemm(layout: int, A: torch.Tensor, B: torch.Tensor, C_out: torch.Tensor, M: 
          colsum_out: Optional[torch.Tensor] = None, colsum_accumulate: bool = False, ws_slot: str = "gemm") -> torch.Tensor:
     """dm_gemm.  A/B/C are 2-D (or flat) row-major tensors; leading dims default to their last-dim size.
     DM_TN only: colsum_out [M] fp32 (+)= column sums of A (the bias gradient that goes with dW = dy^T x)."""
+    c_pair = C_out if isinstance(C_out, Planes) else None      # the result as a hi / lo plane pair (DM_BF16_PAIR): no split pass for its consumers
+    if c_pair is not None:
+        if (c_pair.rows, c_pair.cols) != (M, N) or ldc not in (None, N):
+            raise ValueError("a plane-pair result is a dense [2, M, N] tensor")
+        C_out = c_pair.t
     fold = None
     if isinstance(A, Planes) or isinstance(B, Planes) or (
             _FP32_PRODUCTS == "bf16x3" and A.dtype == torch.float32 and M * N * K >= _SPLIT_MIN_WORK and planes_ok(M, K) and planes_ok(N, K)
@@ -291,6 +296,10 @@ def gemm(layout: int, A: torch.Tensor, B: torch.Tensor, C_out: torch.Tensor, M: 
                     split_k=split_k, rows_per_group=rows_per_group, group_stride=group_stride, ws_slot=ws_slot)
     a = DmGemmArgs()
     a.layout, a.ab_dtype, a.c_dtype = layout, _dt(A), _dt(C_out)
+    if c_pair is not None:
+        if _dt(A) != DM_BF16:
+            raise ValueError("a plane-pair result goes with bf16 / folded operands")
+        a.c_dtype, a.c_plane = _lib.DM_BF16_PAIR, M * N
     a.aux_dtype = _dt(aux) if aux is not None else DM_F32
     a.M, a.N, a.K = M, N, K
     a.epilogue, a.accumulate, a.split_k = epilogue, int(accumulate), split_k
@@ -320,7 +329,7 @@ def gemm(layout: int, A: torch.Tensor, B: torch.Tensor, C_out: torch.Tensor, M: 
         ws = workspace(ws_bytes, A.device, ws_slot)
         a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
     check(_lib.lib().dm_gemm(C.byref(a), _stream()), "dm_gemm")
-    return C_out
+    return c_pair if c_pair is not None else C_out
 
 
 def cast(src: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
@@ -1283,7 +1292,7 @@ class BlockFn(torch.autograd.Function):
         y2, mean2, rstd2 = layernorm_fwd(x1, n2w, n2b, eps, dtype)
         if planes:
             y2 = split_planes(y2)
-        h = torch.empty((M, Hd), dtype=dtype, device=dev)
+        h = Planes(torch.empty((2, M, Hd), dtype=torch.bfloat16, device=dev)) if planes else torch.empty((M, Hd), dtype=dtype, device=dev)
         if any(ctx.needs_input_grad):
             pre = torch.empty((M, Hd), dtype=dtype, device=dev)       # GELU'(pre-activation), saved for backward
             gemm(DM_NT, y2, w1, h, M, Hd, Cc, lda=Cc, ldb=Cc, ldc=Hd, bias=fc1_b, epilogue=DM_EPI_GELU_GRAD, aux=pre, ldaux=Hd)
@@ -1291,8 +1300,6 @@ class BlockFn(torch.autograd.Function):
             pre = None
             gemm(DM_NT, y2, w1, h, M, Hd, Cc, lda=Cc, ldb=Cc, ldc=Hd, bias=fc1_b, epilogue=DM_EPI_GELU)
         x2 = torch.empty((M, Cc), dtype=torch.float32, device=dev)
-        if planes:
-            h = split_planes(h)
         gemm(DM_NT, h, w2, x2, M, Cc, Hd, lda=Hd, ldb=Hd, ldc=Cc, bias=fc2_b, residual=x1)
         if planes:          # (the bf16 [2, rows, cols] tensors travel through save_for_backward like any other)
             y1, y2, h, wq, wp, w1, w2, o_op = y1.t, y2.t, h.t, wq.t, wp.t, w1.t, w2.t, o_op.t
@@ -1338,13 +1345,13 @@ class BlockFn(torch.autograd.Function):
         def bias_grad(g2d, db, acc_b, direct):
             """(operand for the two products that read the gradient g2d, kwargs that make the weight-gradient call produce db):
             on plane pairs the column sums come from the split pass, otherwise they ride on the weight gradient."""
-            if planes:
+            if planes and not isinstance(g2d, Planes):
                 return split_planes(g2d, colsum_out=db, colsum_accumulate=acc_b, defer=direct), {}
-            return g2d, dict(colsum_out=db, colsum_accumulate=acc_b)
+            return g2d, dict(colsum_out=db, colsum_accumulate=acc_b)      # (a plane pair: colsum(hi) + colsum(lo), fused into the weight gradient)
         dy, cs = bias_grad(dy, db2, _acc(P_fc2_b, k_b2), k_b2)
         wgrad(DM_TN, dy, h, dw2, Cc, Hd, M, lda=Cc, ldb=Hd, ldc=Hd, accumulate=_acc(P_fc2_w, k_w2), **cs)
-        dpre = torch.empty((M, Hd), dtype=dtype, device=dev)
-        gemm(DM_NN, dy, w2, dpre, M, Hd, Cc, lda=Cc, ldb=Hd, ldc=Hd, epilogue=DM_EPI_MUL, aux=pre, ldaux=Hd)
+        dpre = Planes(torch.empty((2, M, Hd), dtype=torch.bfloat16, device=dev)) if planes else torch.empty((M, Hd), dtype=dtype, device=dev)
+        gemm(DM_NN, dy, w2, dpre, M, Hd, Cc, lda=Cc, ldb=Hd, ldc=None if planes else Hd, epilogue=DM_EPI_MUL, aux=pre, ldaux=Hd)
         dw1, k_w1 = _grad_out(P_fc1_w, (Hd, Cc), dev)
         db1, k_b1 = _grad_out(P_fc1_b, (Hd,), dev)
         dpre, cs = bias_grad(dpre, db1, _acc(P_fc1_b, k_b1), k_b1)

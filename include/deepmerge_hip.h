@@ -27,7 +27,9 @@
 extern "C" {
 #endif
 
-typedef enum { DM_F32 = 0, DM_BF16 = 1 } DmDtype;
+typedef enum { DM_F32 = 0, DM_BF16 = 1,
+               DM_BF16_PAIR = 2      /* ABI 4, DmGemmArgs.c_dtype only: C is written as a hi / lo plane pair (see c_plane) */
+} DmDtype;
 
 typedef enum {
   DM_OK = 0,
@@ -109,6 +111,10 @@ typedef struct {
    * pass: dm_split_bf16_planes).  Shapes the folded kernels do not take return DM_ERR_UNSUPPORTED (fall back to dm_split_bf16 images). */
   int32_t k_fold;
   int64_t a_fold[3], b_fold[3];
+  /* ABI 4: c_dtype == DM_BF16_PAIR writes the result as the hi / lo plane pair a later folded product reads (the split pass of
+   * that tensor disappears): hi = bf16(v) at C[m * ldc + n], lo = bf16(v - hi) at C[c_plane + m * ldc + n], C a bf16 pointer, ldc and
+   * c_plane in bf16 elements (multiples of 8).  Not with accumulate; NT / NN products on the MFMA path (DM_ERR_UNSUPPORTED otherwise). */
+  int64_t c_plane;
 } DmGemmArgs;
 
 int dm_gemm(const DmGemmArgs *args, void *stream);

@@ -1089,6 +1089,10 @@ def test_folded_split_product_equals_the_image_product(layout, M, N, K, family, 
         if M * N * K >= ops._SPLIT_MIN_WORK:           # (below that ops.gemm keeps fp32 operands on the fp32 MFMA kernel)
             assert torch.equal(C2, outs[1])
         assert ((C2.double() - ref).abs().max() / ref.abs().max()).item() < 3e-5
+        # the result as a plane pair (DM_BF16_PAIR): what splitting the fp32 result would give, without the pass
+        Cp = ops.Planes(torch.empty(2, M, N, dtype=torch.bfloat16, device=DEV))
+        ops.gemm(lay, Ap, B, Cp, M, N, K, **kw)
+        assert torch.equal(Cp.t, ops.split_planes(C2).t)
         dy = torch.randn(M, 256, device=DEV)
         db = torch.zeros(256, device=DEV)
         dyp = ops.split_planes(dy, colsum_out=db)
