@@ -81,6 +81,7 @@ SIGNATURES = {
     "dm_layernorm_fwd": (_I, [_P, _P, _P, _P, _I, _P, _P, _I, _I, _F, _P]),
     "dm_layernorm_bwd": (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _I, _I, _P]),
     "dm_layernorm_bwd_partials": (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, C.POINTER(C.c_int32), _P]),
+    "dm_layernorm_bwd_partials_pair": (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, C.POINTER(C.c_int32), _P]),
     "dm_partial_reduce_batch": (_I, [C.POINTER(DmReduceItem), _I, _P]),
     "dm_layernorm_bwd_partial_floats": (_L, [_I]),
     "dm_token_pool_fwd": (_I, [_P, _P, _I, _I, _I, _I, _P]),

@@ -28,7 +28,9 @@ constexpr int CS_MAX_SLICES = 64;
 // ---------------------------------------------------------------------------------------------
 // LayerNorm forward: one wave per row.
 // ---------------------------------------------------------------------------------------------
-template <typename TY>
+// PAIR (TY = bf16): y is the hi / lo plane pair [2, rows, cols] of the normalised rows (the operand format of the folded "bf16x3"
+// products: no fp32 y, no split pass).
+template <typename TY, bool PAIR = false>
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float *__restrict__ x, const float *__restrict__ gamma,
                                                             const float *__restrict__ beta, TY *__restrict__ y,
                                                             float *__restrict__ mean_out, float *__restrict__ rstd_out,
@@ -72,7 +74,18 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float *__restr
         f32x4 o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mean) * rstd * g[e] + b[e];
-        dm_store4(yr + 4 * c, o);
+        if constexpr (PAIR) {
+          bf16x4 h, l;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            h[e] = (bf16_t)o[e];
+            l[e] = (bf16_t)(o[e] - (float)h[e]);
+          }
+          *reinterpret_cast<bf16x4 *>(yr + 4 * c) = h;
+          *reinterpret_cast<bf16x4 *>(yr + (long long)rows * cols + 4 * c) = l;
+        } else {
+          dm_store4(yr + 4 * c, o);
+        }
       }
     }
   }
@@ -88,7 +101,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const TDY *__restric
                                                             const float *__restrict__ gamma, const float *__restrict__ mean,
                                                             const float *__restrict__ rstd, const float *__restrict__ dres,
                                                             float *__restrict__ dx, bf16_t *__restrict__ dx_lp,
-                                                            float *__restrict__ partial, int rows, int cols) {
+                                                            float *__restrict__ partial, int rows, int cols, long long lp_plane) {
+  // lp_plane > 0: dx_lp is the hi / lo plane pair of dx (lo plane lp_plane elements behind), not a rounded bf16 copy
   __shared__ float red[4][2][CH * 256];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nch = cols >> 2;
@@ -140,7 +154,20 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const TDY *__restric
         for (int e = 0; e < 4; ++e) o[e] = rs * (g[i][e] - c1 - xh[i][e] * c2);
         if (dres) o += dr[i];
         dm_store4(dx + off + 4 * c, o);
-        if (dx_lp) dm_store4(dx_lp + off + 4 * c, o);
+        if (dx_lp) {
+          if (lp_plane > 0) {
+            bf16x4 h, l;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              h[e] = (bf16_t)o[e];
+              l[e] = (bf16_t)(o[e] - (float)h[e]);
+            }
+            *reinterpret_cast<bf16x4 *>(dx_lp + off + 4 * c) = h;
+            *reinterpret_cast<bf16x4 *>(dx_lp + lp_plane + off + 4 * c) = l;
+          } else {
+            dm_store4(dx_lp + off + 4 * c, o);
+          }
+        }
       }
     }
   }
@@ -626,6 +653,7 @@ extern "C" int dm_layernorm_fwd(const float *x, const float *gamma, const float 
   DM_REQUIRE(x && gamma && beta && y && mean && rstd, DM_ERR_BAD_SHAPE, "dm_layernorm_fwd: null pointer");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (cols > MAXCH * 256) {
+    DM_REQUIRE(y_dtype != DM_BF16_PAIR, DM_ERR_UNSUPPORTED, "dm_layernorm_fwd: a plane-pair result needs cols <= %d", MAXCH * 256);
     const int rc = dm_layernorm_wide_fwd(x, gamma, beta, y, y_dtype, mean, rstd, rows, cols, eps, s);
     DM_REQUIRE(rc == DM_OK, rc, "dm_layernorm_fwd: bad y_dtype %d", y_dtype);
     DM_LAUNCH_CHECK("dm_layernorm_fwd(wide)");
@@ -636,6 +664,8 @@ extern "C" int dm_layernorm_fwd(const float *x, const float *gamma, const float 
     hipLaunchKernelGGL(layernorm_fwd_kernel<float>, dim3(grid), dim3(256), 0, s, x, gamma, beta, (float *)y, mean, rstd, rows, cols, eps);
   else if (y_dtype == DM_BF16)
     hipLaunchKernelGGL(layernorm_fwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, x, gamma, beta, (bf16_t *)y, mean, rstd, rows, cols, eps);
+  else if (y_dtype == DM_BF16_PAIR)
+    hipLaunchKernelGGL((layernorm_fwd_kernel<bf16_t, true>), dim3(grid), dim3(256), 0, s, x, gamma, beta, (bf16_t *)y, mean, rstd, rows, cols, eps);
   else DM_REQUIRE(false, DM_ERR_BAD_DTYPE, "dm_layernorm_fwd: bad y_dtype %d", y_dtype);
   DM_LAUNCH_CHECK("dm_layernorm_fwd");
   return DM_OK;
@@ -646,7 +676,9 @@ extern "C" int64_t dm_layernorm_bwd_partial_floats(int32_t cols) { return (int64
 // main kernel of the LayerNorm backward: dx (+ dres), optional bf16 copy, one [dgamma | dbeta] partial row per workgroup; *n_partial rows
 static int ln_bwd_main(const void *dy, int32_t dy_dtype, const float *x, const float *gamma, const float *mean, const float *rstd,
                        const float *dres, float *dx, void *dx_lp, float *partial, int32_t rows, int32_t cols, int32_t *n_partial, hipStream_t s,
-                       const char *who) {
+                       const char *who, bool lp_pair = false) {
+  const long long lp_plane = lp_pair ? (long long)rows * cols : 0;
+  DM_REQUIRE(!lp_pair || (dx_lp && cols <= MAXCH * 256), DM_ERR_UNSUPPORTED, "%s: the plane-pair copy needs dx_lp and cols <= %d", who, MAXCH * 256);
   DM_REQUIRE(rows > 0 && cols > 0 && cols % 4 == 0 && cols <= LN_WIDE_MAX, DM_ERR_BAD_SHAPE, "%s: rows=%d cols=%d", who, rows, cols);
   DM_REQUIRE(dy && x && gamma && mean && rstd && dx && partial && n_partial, DM_ERR_BAD_SHAPE, "%s: null pointer", who);
   if (cols > MAXCH * 256) {
@@ -661,13 +693,13 @@ static int ln_bwd_main(const void *dy, int32_t dy_dtype, const float *x, const f
   DM_REQUIRE(dy_dtype == DM_F32 || dy_dtype == DM_BF16, DM_ERR_BAD_DTYPE, "%s: bad dy_dtype %d", who, dy_dtype);
   const bool narrow = cols <= 768;
   if (dy_dtype == DM_F32 && narrow)
-    hipLaunchKernelGGL((layernorm_bwd_kernel<float, 3>), dim3(grid), dim3(256), 0, s, (const float *)dy, x, gamma, mean, rstd, dres, dx, (bf16_t *)dx_lp, partial, rows, cols);
+    hipLaunchKernelGGL((layernorm_bwd_kernel<float, 3>), dim3(grid), dim3(256), 0, s, (const float *)dy, x, gamma, mean, rstd, dres, dx, (bf16_t *)dx_lp, partial, rows, cols, lp_plane);
   else if (dy_dtype == DM_F32)
-    hipLaunchKernelGGL((layernorm_bwd_kernel<float, MAXCH>), dim3(grid), dim3(256), 0, s, (const float *)dy, x, gamma, mean, rstd, dres, dx, (bf16_t *)dx_lp, partial, rows, cols);
+    hipLaunchKernelGGL((layernorm_bwd_kernel<float, MAXCH>), dim3(grid), dim3(256), 0, s, (const float *)dy, x, gamma, mean, rstd, dres, dx, (bf16_t *)dx_lp, partial, rows, cols, lp_plane);
   else if (narrow)
-    hipLaunchKernelGGL((layernorm_bwd_kernel<bf16_t, 3>), dim3(grid), dim3(256), 0, s, (const bf16_t *)dy, x, gamma, mean, rstd, dres, dx, (bf16_t *)dx_lp, partial, rows, cols);
+    hipLaunchKernelGGL((layernorm_bwd_kernel<bf16_t, 3>), dim3(grid), dim3(256), 0, s, (const bf16_t *)dy, x, gamma, mean, rstd, dres, dx, (bf16_t *)dx_lp, partial, rows, cols, lp_plane);
   else
-    hipLaunchKernelGGL((layernorm_bwd_kernel<bf16_t, MAXCH>), dim3(grid), dim3(256), 0, s, (const bf16_t *)dy, x, gamma, mean, rstd, dres, dx, (bf16_t *)dx_lp, partial, rows, cols);
+    hipLaunchKernelGGL((layernorm_bwd_kernel<bf16_t, MAXCH>), dim3(grid), dim3(256), 0, s, (const bf16_t *)dy, x, gamma, mean, rstd, dres, dx, (bf16_t *)dx_lp, partial, rows, cols, lp_plane);
   DM_LAUNCH_CHECK("dm_layernorm_bwd");
   *n_partial = grid;
   return DM_OK;
@@ -690,6 +722,13 @@ extern "C" int dm_layernorm_bwd_partials(const void *dy, int32_t dy_dtype, const
                                          int32_t cols, int32_t *n_partial, void *stream) {
   return ln_bwd_main(dy, dy_dtype, x, gamma, mean, rstd, dres, dx, dx_lp, partial, rows, cols, n_partial, reinterpret_cast<hipStream_t>(stream),
                      "dm_layernorm_bwd_partials");
+}
+
+extern "C" int dm_layernorm_bwd_partials_pair(const void *dy, int32_t dy_dtype, const float *x, const float *gamma, const float *mean,
+                                              const float *rstd, const float *dres, float *dx, void *dx_pair, float *partial, int32_t rows,
+                                              int32_t cols, int32_t *n_partial, void *stream) {
+  return ln_bwd_main(dy, dy_dtype, x, gamma, mean, rstd, dres, dx, dx_pair, partial, rows, cols, n_partial, reinterpret_cast<hipStream_t>(stream),
+                     "dm_layernorm_bwd_partials_pair", true);
 }
 
 extern "C" int dm_partial_reduce_batch(const DmReduceItem *items, int32_t n, void *stream) {

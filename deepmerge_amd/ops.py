@@ -353,12 +353,18 @@ def colsum(X: torch.Tensor, out: torch.Tensor, accumulate: bool = False, ws_slot
     return out
 
 
-def layernorm_fwd(x: torch.Tensor, gamma, beta, eps: float, out_dtype: torch.dtype):
+def layernorm_fwd(x: torch.Tensor, gamma, beta, eps: float, out_dtype: torch.dtype, pair: bool = False):
+    """(y, mean, rstd); pair=True: y is the Planes (hi / lo plane pair) of the normalised rows -- written by the kernel itself."""
     _need_cuda(x, gamma, beta)
     rows, cols = x.numel() // x.shape[-1], x.shape[-1]
-    y = torch.empty(x.shape, dtype=out_dtype, device=x.device)
     mean = torch.empty(rows, dtype=torch.float32, device=x.device)
     rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+    if pair:
+        yp = torch.empty((2, rows, cols), dtype=torch.bfloat16, device=x.device)
+        check(_lib.lib().dm_layernorm_fwd(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), yp.data_ptr(), _lib.DM_BF16_PAIR, mean.data_ptr(),
+                                          rstd.data_ptr(), rows, cols, eps, _stream()), "dm_layernorm_fwd")
+        return Planes(yp), mean, rstd
+    y = torch.empty(x.shape, dtype=out_dtype, device=x.device)
     check(_lib.lib().dm_layernorm_fwd(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), _dt(y), mean.data_ptr(),
                                       rstd.data_ptr(), rows, cols, eps, _stream()), "dm_layernorm_fwd")
     return y, mean, rstd
@@ -415,8 +421,8 @@ def _queue_reduce(part, out0, out1, nrows, width, split, accumulate) -> None:
         _flush_queued = True
 
 
-def layernorm_bwd(dy, x, gamma, mean, rstd, dres=None, dgamma=None, dbeta=None, accumulate=False, want_lp=False, defer=False):
-    """Returns (dx, dgamma, dbeta) or, with want_lp, (dx, dx_bf16, dgamma, dbeta).
+def layernorm_bwd(dy, x, gamma, mean, rstd, dres=None, dgamma=None, dbeta=None, accumulate=False, want_lp=False, defer=False, want_pair=False):
+    """Returns (dx, dgamma, dbeta) or, with want_lp, (dx, dx_bf16, dgamma, dbeta); with want_pair, (dx, Planes(dx), dgamma, dbeta).
     defer=True (only with caller-provided dgamma / dbeta, inside a backward pass): their reduction is queued for the end of the pass
     (`flush_reductions`); dx is complete on return."""
     _need_cuda(dy, x)
@@ -430,6 +436,23 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dres=None, dgamma=None, dbeta=None, 
         dbeta = torch.empty(cols, dtype=torch.float32, device=x.device)
         accumulate = False
         defer = False
+    if want_pair:
+        pair = torch.empty((2, rows, cols), dtype=torch.bfloat16, device=x.device)
+        deferred = defer and _DEFER_REDUCTIONS and _in_backward()
+        part = (torch.empty(_lib.lib().dm_layernorm_bwd_partial_floats(cols), dtype=torch.float32, device=x.device) if deferred
+                else workspace(_lib.lib().dm_layernorm_bwd_partial_floats(cols) * 4, x.device, "partial").view(torch.float32))
+        n_part = C.c_int32(0)
+        check(_lib.lib().dm_layernorm_bwd_partials_pair(dy.data_ptr(), _dt(dy), x.data_ptr(), gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                                        _ptr(dres), dx.data_ptr(), pair.data_ptr(), part.data_ptr(), rows, cols, C.byref(n_part),
+                                                        _stream()), "dm_layernorm_bwd_partials_pair")
+        if deferred:
+            _queue_reduce(part, dgamma, dbeta, n_part.value, 2 * cols, cols, accumulate)
+        else:
+            item = (_lib.DmReduceItem * 1)()
+            item[0].partial, item[0].out0, item[0].out1 = part.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr()
+            item[0].nrows, item[0].width, item[0].split, item[0].accumulate = n_part.value, 2 * cols, cols, int(bool(accumulate))
+            check(_lib.lib().dm_partial_reduce_batch(item, 1, _stream()), "dm_partial_reduce_batch")
+        return dx, Planes(pair), dgamma, dbeta
     if defer and _DEFER_REDUCTIONS and _in_backward():
         part = torch.empty(_lib.lib().dm_layernorm_bwd_partial_floats(cols), dtype=torch.float32, device=x.device)
         n_part = C.c_int32(0)
@@ -1268,9 +1291,7 @@ class BlockFn(torch.autograd.Function):
                   and M * Cc * Cc >= _SPLIT_MIN_WORK)
         if planes:
             wq, wp, w1, w2 = (split_planes(w) for w in (wq, wp, w1, w2))
-        y1, mean1, rstd1 = layernorm_fwd(x2d, n1w, n1b, eps, dtype)
-        if planes:
-            y1 = split_planes(y1)
+        y1, mean1, rstd1 = layernorm_fwd(x2d, n1w, n1b, eps, dtype, pair=planes)
         qkv = torch.empty((M, 3 * Cc), dtype=dtype, device=dev)
         gemm(DM_NT, y1, wq, qkv, M, 3 * Cc, Cc, lda=Cc, ldb=Cc, ldc=3 * Cc, bias=qkv_b)
         bias = bias_t = None
@@ -1289,9 +1310,7 @@ class BlockFn(torch.autograd.Function):
         x1 = torch.empty((M, Cc), dtype=torch.float32, device=dev)
         o_op = split_planes(o.view(M, Cc)) if planes else o.view(M, Cc)
         gemm(DM_NT, o_op, wp, x1, M, Cc, Cc, lda=Cc, ldb=Cc, ldc=Cc, bias=proj_b, residual=x2d)
-        y2, mean2, rstd2 = layernorm_fwd(x1, n2w, n2b, eps, dtype)
-        if planes:
-            y2 = split_planes(y2)
+        y2, mean2, rstd2 = layernorm_fwd(x1, n2w, n2b, eps, dtype, pair=planes)
         h = Planes(torch.empty((2, M, Hd), dtype=torch.bfloat16, device=dev)) if planes else torch.empty((M, Hd), dtype=dtype, device=dev)
         if any(ctx.needs_input_grad):
             pre = torch.empty((M, Hd), dtype=dtype, device=dev)       # GELU'(pre-activation), saved for backward
@@ -1326,10 +1345,17 @@ class BlockFn(torch.autograd.Function):
         dtype, dev = (torch.float32 if planes else y1.dtype), x.device
         lp = dtype != torch.float32
         lp_copy = getattr(dx2, "_dm_lp_copy", None)
+        dy_pair = getattr(dx2, "_dm_planes", None)   # the plane pair the LayerNorm backward of the NEXT block wrote next to this very tensor
+        if dy_pair is not None and dy_pair[1] != (dx2.data_ptr(), dx2._version):
+            dy_pair = None                           # (the engine summed another contribution into the tensor in place: the pair is stale)
+        elif dy_pair is not None:
+            dy_pair = dy_pair[0]
         dx2 = dx2.contiguous().view(M, Cc)
         if lp_copy is not None:
             dx2._dm_lp_copy = lp_copy                # (.contiguous() is the same storage; the attribute rides along)
         dy = _operand_grad(dx2, dtype)
+        if planes and isinstance(dy_pair, Planes) and (dy_pair.rows, dy_pair.cols) == (M, Cc):
+            dy = dy_pair
         # ---- MLP ---------------------------------------------------------------------------
         dw2, k_w2 = _grad_out(P_fc2_w, (Cc, Hd), dev)
         db2, k_b2 = _grad_out(P_fc2_b, (Cc,), dev)
@@ -1364,8 +1390,9 @@ class BlockFn(torch.autograd.Function):
             dg2, dbt2, k_n2, k_n2b = torch.empty(Cc, device=dev), torch.empty(Cc, device=dev), False, False
         a_n2 = _acc(P_n2w, k_n2)
         _acc(P_n2b, k_n2b)                              # (gamma and beta are written by the same launch)
-        r = layernorm_bwd(dy2, x1, n2w, mean2, rstd2, dres=dx2, dgamma=dg2, dbeta=dbt2, accumulate=a_n2, want_lp=lp, defer=bool(k_n2 and k_n2b))
-        dx1, dx1_lp = (r[0], r[1]) if lp else (r[0], r[0])
+        r = layernorm_bwd(dy2, x1, n2w, mean2, rstd2, dres=dx2, dgamma=dg2, dbeta=dbt2, accumulate=a_n2, want_lp=lp, defer=bool(k_n2 and k_n2b),
+                          want_pair=planes)
+        dx1, dx1_lp = (r[0], r[1]) if (lp or planes) else (r[0], r[0])      # (planes: r[1] is the plane pair of dx1)
         # ---- attention -----------------------------------------------------------------------
         dwp, k_wp = _grad_out(P_proj_w, (Cc, Cc), dev)
         dbp, k_bp = _grad_out(P_proj_b, (Cc,), dev)
@@ -1405,7 +1432,8 @@ class BlockFn(torch.autograd.Function):
             dg1, dbt1, k_n1, k_n1b = torch.empty(Cc, device=dev), torch.empty(Cc, device=dev), False, False
         a_n1 = _acc(P_n1w, k_n1)
         _acc(P_n1b, k_n1b)
-        r = layernorm_bwd(dy1, x, n1w, mean1, rstd1, dres=dx1, dgamma=dg1, dbeta=dbt1, accumulate=a_n1, want_lp=lp, defer=bool(k_n1 and k_n1b))
+        r = layernorm_bwd(dy1, x, n1w, mean1, rstd1, dres=dx1, dgamma=dg1, dbeta=dbt1, accumulate=a_n1, want_lp=lp, defer=bool(k_n1 and k_n1b),
+                          want_pair=planes)
         if side is not None:
             torch.cuda.current_stream().wait_stream(side)          # join: every weight gradient of this block is complete
         dx = r[0].view(B, N, Cc)
@@ -1413,6 +1441,8 @@ class BlockFn(torch.autograd.Function):
             # The bf16 copy the LayerNorm backward wrote rides on the tensor object autograd hands to the next node (the
             # engine preserves the Python object); a consumer that gets some other tensor simply casts.
             dx._dm_lp_copy = r[1]
+        if planes:
+            dx._dm_planes = (r[1], (dx.data_ptr(), dx._version))      # likewise the plane pair ("bf16x3"); a consumer that gets another tensor splits
         return (dx, _grad_done(P_n1w, dg1, k_n1), _grad_done(P_n1b, dbt1, k_n1b),
                 _grad_done(P_table, dtable, k_t) if want_table else None, None,
                 _grad_done(P_qkv_w, dwq, k_wq), _grad_done(P_qkv_b, dbq, k_bq),

@@ -199,7 +199,8 @@ int dm_relpos_bias_reduce(float *dbias_slab, const int32_t *positions, const int
 
 /* ---- row kernels (HBM-bound) ------------------------------------------------------------ */
 /* nn.LayerNorm over the last dim (nets/ShfitScaleFormer.py:182-183, :902, :915, :926, :941;
- * vit_model.py:183-184, :498): x [rows, cols] fp32 -> y (y_dtype), saving mean / rstd [rows]. */
+ * vit_model.py:183-184, :498): x [rows, cols] fp32 -> y (y_dtype), saving mean / rstd [rows].
+ * y_dtype == DM_BF16_PAIR (ABI 4, cols <= 1024): y is the hi / lo plane pair [2, rows, cols] of the result. */
 int dm_layernorm_fwd(const float *x, const float *gamma, const float *beta, void *y, int32_t y_dtype,
                      float *mean, float *rstd, int32_t rows, int32_t cols, float eps, void *stream);
 /* dx = (dres ? dres : 0) + LN'(dy); dx_lp (optional) receives the same values as bf16 (the operand
@@ -217,6 +218,11 @@ int64_t dm_layernorm_bwd_partial_floats(int32_t cols);
 int dm_layernorm_bwd_partials(const void *dy, int32_t dy_dtype, const float *x, const float *gamma,
                               const float *mean, const float *rstd, const float *dres, float *dx, void *dx_lp,
                               float *partial, int32_t rows, int32_t cols, int32_t *n_partial, void *stream);
+/* The same with the hi / lo PLANE PAIR of dx on the side (dx_pair bf16 [2, rows, cols]; ABI 4): the gradient that leaves a LayerNorm
+ * is the left operand of the next weight / data gradient products of the "bf16x3" mode, which then need no split pass.  cols <= 1024. */
+int dm_layernorm_bwd_partials_pair(const void *dy, int32_t dy_dtype, const float *x, const float *gamma,
+                                   const float *mean, const float *rstd, const float *dres, float *dx, void *dx_pair, float *partial,
+                                   int32_t rows, int32_t cols, int32_t *n_partial, void *stream);
 /* One job of dm_partial_reduce_batch: out0[j] (+)= sum_r partial[r][j] for j < split, out1[j - split] (+)= ... for split <= j < width;
  * rows are summed in a fixed order (deterministic).  Jobs of one batch must not share output elements. */
 typedef struct DmReduceItem {

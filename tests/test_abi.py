@@ -40,7 +40,7 @@ def test_library_identity_calls(built_lib):
     assert lib.dm_gemm_workspace_bytes(built_lib.DM_TN, 768, 768, 16384) > 0
     assert lib.dm_attention_bwd_batch_chunks(64, 256, 12, 0) == 8 and lib.dm_attention_bwd_batch_chunks(2, 12, 12, 0) == 2 and lib.dm_attention_bwd_batch_chunks(64, 256, 12, 1) == 10
     assert lib.dm_layernorm_bwd_partial_floats(768) >= 2 * 768
-    assert ctypes.sizeof(built_lib.DmGemmArgs) == 176   # == sizeof(DmGemmArgs) in C (gcc, LP64)
+    assert ctypes.sizeof(built_lib.DmGemmArgs) == 232   # == sizeof(DmGemmArgs) in C (gcc, LP64)
     assert ctypes.sizeof(built_lib.DmProfRow) == 96
 
 
