@@ -723,13 +723,13 @@ extern "C" int dm_attention_split_fwd(const float *qkv, void *qkv_hi, void *qkv_
                                       void *stream) {
   DM_REQUIRE(split_shape(B, N, H, D, table != nullptr, cube_s, cube_h, cube_w), DM_ERR_UNSUPPORTED,
              "dm_attention_split_fwd: shape not taken (B=%d N=%d H=%d D=%d cube=%dx%dx%d); use dm_attention_fwd", B, N, H, D, cube_s, cube_h, cube_w);
-  DM_REQUIRE(qkv && qkv_hi && qkv_lo && out && lse, DM_ERR_BAD_SHAPE, "dm_attention_split_fwd: null pointer");
+  DM_REQUIRE(qkv_hi && qkv_lo && out && lse, DM_ERR_BAD_SHAPE, "dm_attention_split_fwd: null pointer");
   DM_REQUIRE(dm_aligned16(qkv) && dm_aligned16(qkv_hi) && dm_aligned16(qkv_lo) && dm_aligned16(out), DM_ERR_BAD_ALIGN,
              "dm_attention_split_fwd: tensors must be 16-byte aligned");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   {
     DmProfScope prof("attn_fwd_x3", s, 3.0 * 4.0 * B * H * (double)N * N * HD, 4.0 * 4.0 * B * H * (double)N * HD);
-    dm_attn_x3_split(qkv, qkv_hi, qkv_lo, (long long)B * N * 3 * H * HD, s);
+    if (qkv) dm_attn_x3_split(qkv, qkv_hi, qkv_lo, (long long)B * N * 3 * H * HD, s);      // (NULL: the caller filled the two images -- a DM_BF16_PAIR product)
     AttnX3Params p{reinterpret_cast<const bf16_t *>(qkv_hi), reinterpret_cast<const bf16_t *>(qkv_lo), table, cube_s, out, lse, B, N, H, scale};
     DM_REQUIRE(dm_attn_fwd_x3(p, s), DM_ERR_UNSUPPORTED, "dm_attention_split_fwd: kernel could not be configured");
   }
@@ -739,21 +739,38 @@ extern "C" int dm_attention_split_fwd(const float *qkv, void *qkv_hi, void *qkv_
 
 extern "C" int32_t dm_attention_split_bwd_chunks(int32_t B, int32_t N, int32_t H) { return dm_attn_x3_chunks(B, N, H); }
 
+static int split_bwd_impl(const void *qkv_hi, const void *qkv_lo, const float *table, int32_t cube_s, int32_t cube_h, int32_t cube_w,
+                          const float *out, const float *dout, void *dout_hi, void *dout_lo, const float *lse, float *dqkv, void *dqkv_pair,
+                          float *delta, float *dbias_slab, int32_t B, int32_t N, int32_t H, int32_t D, float scale, void *stream);
 extern "C" int dm_attention_split_bwd(const void *qkv_hi, const void *qkv_lo, const float *table, int32_t cube_s, int32_t cube_h, int32_t cube_w,
                                       const float *out, const float *dout, void *dout_hi, void *dout_lo, const float *lse, float *dqkv,
                                       float *delta, float *dbias_slab, int32_t B, int32_t N, int32_t H, int32_t D, float scale, void *stream) {
+  DM_REQUIRE(dqkv, DM_ERR_BAD_SHAPE, "dm_attention_split_bwd: null pointer");
+  return split_bwd_impl(qkv_hi, qkv_lo, table, cube_s, cube_h, cube_w, out, dout, dout_hi, dout_lo, lse, dqkv, nullptr, delta, dbias_slab, B, N, H, D, scale, stream);
+}
+extern "C" int dm_attention_split_bwd_pair(const void *qkv_hi, const void *qkv_lo, const float *table, int32_t cube_s, int32_t cube_h, int32_t cube_w,
+                                           const float *out, const float *dout, void *dout_hi, void *dout_lo, const float *lse, void *dqkv_pair,
+                                           float *delta, float *dbias_slab, int32_t B, int32_t N, int32_t H, int32_t D, float scale, void *stream) {
+  DM_REQUIRE(dqkv_pair, DM_ERR_BAD_SHAPE, "dm_attention_split_bwd_pair: null pointer");
+  return split_bwd_impl(qkv_hi, qkv_lo, table, cube_s, cube_h, cube_w, out, dout, dout_hi, dout_lo, lse, nullptr, dqkv_pair, delta, dbias_slab, B, N, H, D, scale, stream);
+}
+static int split_bwd_impl(const void *qkv_hi, const void *qkv_lo, const float *table, int32_t cube_s, int32_t cube_h, int32_t cube_w,
+                          const float *out, const float *dout, void *dout_hi, void *dout_lo, const float *lse, float *dqkv, void *dqkv_pair,
+                          float *delta, float *dbias_slab, int32_t B, int32_t N, int32_t H, int32_t D, float scale, void *stream) {
   DM_REQUIRE(split_shape(B, N, H, D, table != nullptr, cube_s, cube_h, cube_w), DM_ERR_UNSUPPORTED,
              "dm_attention_split_bwd: shape not taken (B=%d N=%d H=%d D=%d cube=%dx%dx%d); use dm_attention_bwd", B, N, H, D, cube_s, cube_h, cube_w);
-  DM_REQUIRE(qkv_hi && qkv_lo && out && dout && dout_hi && dout_lo && lse && dqkv && delta, DM_ERR_BAD_SHAPE, "dm_attention_split_bwd: null pointer");
+  DM_REQUIRE(qkv_hi && qkv_lo && out && dout && dout_hi && dout_lo && lse && (dqkv || dqkv_pair) && delta, DM_ERR_BAD_SHAPE, "dm_attention_split_bwd: null pointer");
   DM_REQUIRE(table || !dbias_slab, DM_ERR_BAD_SHAPE, "dm_attention_split_bwd: a bias-gradient slab needs the table");
   DM_REQUIRE(dm_aligned16(qkv_hi) && dm_aligned16(qkv_lo) && dm_aligned16(out) && dm_aligned16(dout) && dm_aligned16(dout_hi) &&
-             dm_aligned16(dout_lo) && dm_aligned16(dqkv) && dm_aligned16(dbias_slab), DM_ERR_BAD_ALIGN, "dm_attention_split_bwd: tensors must be 16-byte aligned");
+             dm_aligned16(dout_lo) && dm_aligned16(dqkv) && dm_aligned16(dqkv_pair) && dm_aligned16(dbias_slab), DM_ERR_BAD_ALIGN,
+             "dm_attention_split_bwd: tensors must be 16-byte aligned");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   {
     DmProfScope prof("attn_bwd_x3", s, 3.0 * 10.0 * B * H * (double)N * N * HD, 4.0 * 8.0 * B * H * (double)N * HD);
     dm_attn_x3_split(dout, dout_hi, dout_lo, (long long)B * N * H * HD, s);
     AttnX3BwdParams p{reinterpret_cast<const bf16_t *>(qkv_hi), reinterpret_cast<const bf16_t *>(qkv_lo), reinterpret_cast<const bf16_t *>(dout_hi),
-                      reinterpret_cast<const bf16_t *>(dout_lo), out, dout, lse, delta, dqkv, dbias_slab, table, cube_s, B, N, H, scale};
+                      reinterpret_cast<const bf16_t *>(dout_lo), out, dout, lse, delta, dqkv, reinterpret_cast<bf16_t *>(dqkv_pair),
+                      (long long)B * N * 3 * H * HD, dbias_slab, table, cube_s, B, N, H, scale};
     DM_REQUIRE(dm_attn_bwd_dq_x3(p, s) && dm_attn_bwd_dkv_x3(p, s), DM_ERR_UNSUPPORTED, "dm_attention_split_bwd: kernels could not be configured");
   }
   DM_LAUNCH_CHECK("dm_attention_split_bwd");

@@ -26,7 +26,9 @@ struct AttnX3BwdParams {
   const float *out, *dout;     // [B, N, H*64] fp32 (delta = rowsum(dO . O))
   const float *lse;            // [B, H, N]
   float *delta;                // [B, H, N]: written by the dQ pass, read by the dK / dV pass
-  float *dqkv;                 // [B, N, 3, H, 64] fp32, fully written by the two passes
+  float *dqkv;                 // [B, N, 3, H, 64] fp32, fully written by the two passes (unless dqkv_pair)
+  bf16_t *dqkv_pair;           // or NULL: the result as a hi / lo plane pair instead (lo plane pair_plane elements behind the hi plane)
+  long long pair_plane;
   float *slab;                 // [chunks, H, N, N] or NULL
   const float *table;
   int cube_s;

@@ -17,6 +17,23 @@ namespace dmx3 {
 using namespace dmq32;
 
 // x -> hi = bf16(x), lo = bf16(x - hi); n4 groups of four
+// four consecutive elements of dqkv: fp32, or -- AttnX3BwdParams::dqkv_pair -- as the hi / lo plane pair the qkv weight / data gradient
+// products of the "bf16x3" mode read (no fp32 dqkv, no split pass)
+__device__ __forceinline__ void x3_store_grad(const AttnX3BwdParams &p, long long off, const f32x4 &v) {
+  if (p.dqkv_pair) {
+    bf16x4 h, l;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      h[e] = (bf16_t)v[e];
+      l[e] = (bf16_t)(v[e] - (float)h[e]);
+    }
+    *reinterpret_cast<bf16x4 *>(p.dqkv_pair + off) = h;
+    *reinterpret_cast<bf16x4 *>(p.dqkv_pair + p.pair_plane + off) = l;
+  } else {
+    dm_store4(p.dqkv + off, v);
+  }
+}
+
 __global__ __launch_bounds__(256) void split2_kernel(const float *__restrict__ x, bf16_t *__restrict__ hi, bf16_t *__restrict__ lo, long long n4) {
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
     const f32x4 v = dm_load4(x + 4 * i);
@@ -535,13 +552,13 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_x3_kernel(const AttnX3BwdP
     }
     asm volatile("s_nop 15\n\ts_nop 7" : "+a"(dq0), "+a"(dq1));
     if (row_ok) {
-      float *drow = p.dqkv + ((long long)b * N + q) * tok_stride + (long long)h * HD + 4 * hh;
+      const long long roff = ((long long)b * N + q) * tok_stride + (long long)h * HD + 4 * hh;
       const float f = p.scale;
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt) {
         const f32x16 &o = dt ? dq1 : dq0;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) dm_store4(drow + 32 * dt + 8 * c, (f32x4){o[4 * c] * f, o[4 * c + 1] * f, o[4 * c + 2] * f, o[4 * c + 3] * f});
+        for (int c = 0; c < 4; ++c) x3_store_grad(p, roff + 32 * dt + 8 * c, (f32x4){o[4 * c] * f, o[4 * c + 1] * f, o[4 * c + 2] * f, o[4 * c + 3] * f});
       }
     }
   }
@@ -792,8 +809,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_x3_kernel(const AttnX3Bwd
     }
     asm volatile("s_nop 15\n\ts_nop 7" : "+a"(dk0), "+a"(dk1), "+a"(dv0), "+a"(dv1));
     if (row_ok) {
-      float *krow = p.dqkv + ((long long)b * N + key) * tok_stride + (long long)(H + h) * HD + 4 * hh;
-      float *vrow = krow + (long long)H * HD;
+      const long long koff = ((long long)b * N + key) * tok_stride + (long long)(H + h) * HD + 4 * hh;
+      const long long voff = koff + (long long)H * HD;
       const float f = p.scale;
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt) {
@@ -801,8 +818,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_x3_kernel(const AttnX3Bwd
         const f32x16 &v = dt ? dv1 : dv0;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-          dm_store4(krow + 32 * dt + 8 * c, (f32x4){a[4 * c] * f, a[4 * c + 1] * f, a[4 * c + 2] * f, a[4 * c + 3] * f});
-          dm_store4(vrow + 32 * dt + 8 * c, (f32x4){v[4 * c], v[4 * c + 1], v[4 * c + 2], v[4 * c + 3]});
+          x3_store_grad(p, koff + 32 * dt + 8 * c, (f32x4){a[4 * c] * f, a[4 * c + 1] * f, a[4 * c + 2] * f, a[4 * c + 3] * f});
+          x3_store_grad(p, voff + 32 * dt + 8 * c, (f32x4){v[4 * c], v[4 * c + 1], v[4 * c + 2], v[4 * c + 3]});
         }
       }
     }

@@ -493,8 +493,8 @@ def attention_fwd(qkv: torch.Tensor, bias: Optional[torch.Tensor], B: int, N: in
 
 def _split_attention(table, index32, qkv, B, N, H, D):
     """(use, cube): whether the forward runs on the split-bf16 attention kernels -- fp32 tensors inside a "bf16x3" scope, a shape they
-    take, and a bias that is either absent or the table of a token cube the module vouches for."""
-    if qkv.dtype != torch.float32 or _FP32_PRODUCTS != "bf16x3" or not _SPLIT_ATTENTION:
+    take, and a bias that is either absent or the table of a token cube the module vouches for.  `qkv`: the tensor or its dtype."""
+    if (qkv if isinstance(qkv, torch.dtype) else qkv.dtype) != torch.float32 or _FP32_PRODUCTS != "bf16x3" or not _SPLIT_ATTENTION:
         return False, None
     cube = None if table is None else getattr(index32, "_dm_cube", None)
     if table is not None and cube is None:
@@ -546,28 +546,36 @@ def attention_split_ok(B: int, N: int, H: int, D: int, cube=None) -> bool:
 
 
 def attention_fwd_split(qkv: torch.Tensor, table: Optional[torch.Tensor], cube, B: int, N: int, H: int, D: int, scale: float):
-    """fp32 attention with split-bf16 products.  Returns (out, lse, qkv_hi, qkv_lo); the two bf16 images go to the backward pass."""
-    _need_cuda(qkv, table)
-    if qkv.dtype != torch.float32 or not qkv.is_contiguous():
-        raise ValueError("attention_fwd_split: qkv must be a contiguous fp32 tensor")
+    """fp32 attention with split-bf16 products.  Returns (out, lse, qkv_hi, qkv_lo); the two bf16 images go to the backward pass.
+    qkv: the fp32 tensor, or its Planes (the qkv product wrote the pair itself: its planes ARE the two images)."""
     if table is not None and (table.dtype != torch.float32 or not table.is_contiguous()):
         raise ValueError("attention_fwd_split: table must be contiguous fp32")
-    out = torch.empty((B, N, H * D), dtype=torch.float32, device=qkv.device)
-    lse = torch.empty((B, H, N), dtype=torch.float32, device=qkv.device)
-    hi = torch.empty(qkv.shape, dtype=torch.bfloat16, device=qkv.device)
-    lo = torch.empty(qkv.shape, dtype=torch.bfloat16, device=qkv.device)
+    if isinstance(qkv, Planes):
+        _need_cuda(qkv.t, table)
+        hi, lo, src, dev = qkv.t[0], qkv.t[1], None, qkv.t.device
+    else:
+        _need_cuda(qkv, table)
+        if qkv.dtype != torch.float32 or not qkv.is_contiguous():
+            raise ValueError("attention_fwd_split: qkv must be a contiguous fp32 tensor")
+        hi = torch.empty(qkv.shape, dtype=torch.bfloat16, device=qkv.device)
+        lo = torch.empty(qkv.shape, dtype=torch.bfloat16, device=qkv.device)
+        src, dev = qkv.data_ptr(), qkv.device
+    out = torch.empty((B, N, H * D), dtype=torch.float32, device=dev)
+    lse = torch.empty((B, H, N), dtype=torch.float32, device=dev)
     c = (0, 0, 0) if cube is None else tuple(int(v) for v in cube)
-    check(_lib.lib().dm_attention_split_fwd(qkv.data_ptr(), hi.data_ptr(), lo.data_ptr(), _ptr(table), c[0], c[1], c[2], out.data_ptr(),
+    check(_lib.lib().dm_attention_split_fwd(src, hi.data_ptr(), lo.data_ptr(), _ptr(table), c[0], c[1], c[2], out.data_ptr(),
                                             lse.data_ptr(), B, N, H, D, scale, _stream()), "dm_attention_split_fwd")
     return out, lse, hi, lo
 
 
-def attention_bwd_split(hi, lo, table, cube, out, dout, lse, B, N, H, D, scale, index32=None, n_bins=0):
-    """Backward of attention_fwd_split.  Returns (dqkv fp32, dbias_slab or None, info) like attention_bwd."""
+def attention_bwd_split(hi, lo, table, cube, out, dout, lse, B, N, H, D, scale, index32=None, n_bins=0, pair=False):
+    """Backward of attention_fwd_split.  Returns (dqkv fp32, dbias_slab or None, info) like attention_bwd; pair=True: dqkv as the
+    Planes of the [B*N, 3*H*D] matrix (written by the kernels themselves)."""
     _need_cuda(hi, lo, table, out, dout, lse, index32)
     if out.dtype != torch.float32 or dout.dtype != torch.float32 or not (out.is_contiguous() and dout.is_contiguous()):
         raise ValueError("attention_bwd_split: out / dout must be contiguous fp32")
-    dqkv = torch.empty(hi.shape, dtype=torch.float32, device=hi.device)
+    dqkv = (torch.empty((2, B * N, 3 * H * D), dtype=torch.bfloat16, device=hi.device) if pair
+            else torch.empty(hi.shape, dtype=torch.float32, device=hi.device))
     delta = torch.empty((B, H, N), dtype=torch.float32, device=hi.device)
     dhi = torch.empty(dout.shape, dtype=torch.bfloat16, device=hi.device)
     dlo = torch.empty(dout.shape, dtype=torch.bfloat16, device=hi.device)
@@ -577,10 +585,11 @@ def attention_bwd_split(hi, lo, table, cube, out, dout, lse, B, N, H, D, scale, 
         slab = torch.empty((chunks, H, N, N), dtype=torch.float32, device=hi.device)
         info = (chunks, N, relpos_index_csr(index32, n_bins))
     c = (0, 0, 0) if cube is None else tuple(int(v) for v in cube)
-    check(_lib.lib().dm_attention_split_bwd(hi.data_ptr(), lo.data_ptr(), _ptr(table), c[0], c[1], c[2], out.data_ptr(), dout.data_ptr(),
-                                            dhi.data_ptr(), dlo.data_ptr(), lse.data_ptr(), dqkv.data_ptr(), delta.data_ptr(), _ptr(slab),
-                                            B, N, H, D, scale, _stream()), "dm_attention_split_bwd")
-    return dqkv, slab, info
+    fn = _lib.lib().dm_attention_split_bwd_pair if pair else _lib.lib().dm_attention_split_bwd
+    check(fn(hi.data_ptr(), lo.data_ptr(), _ptr(table), c[0], c[1], c[2], out.data_ptr(), dout.data_ptr(),
+             dhi.data_ptr(), dlo.data_ptr(), lse.data_ptr(), dqkv.data_ptr(), delta.data_ptr(), _ptr(slab),
+             B, N, H, D, scale, _stream()), "dm_attention_split_bwd")
+    return (Planes(dqkv) if pair else dqkv), slab, info
 
 
 def relpos_index_csr(index32: torch.Tensor, n_bins: int):
@@ -1292,11 +1301,13 @@ class BlockFn(torch.autograd.Function):
         if planes:
             wq, wp, w1, w2 = (split_planes(w) for w in (wq, wp, w1, w2))
         y1, mean1, rstd1 = layernorm_fwd(x2d, n1w, n1b, eps, dtype, pair=planes)
-        qkv = torch.empty((M, 3 * Cc), dtype=dtype, device=dev)
+        split, scube = _split_attention(table, index32, dtype, B, N, heads, D)
+        # (plane pairs + the split-bf16 attention: the qkv product writes the two images the attention kernels read)
+        qkv = (Planes(torch.empty((2, M, 3 * Cc), dtype=torch.bfloat16, device=dev)) if (planes and split)
+               else torch.empty((M, 3 * Cc), dtype=dtype, device=dev))
         gemm(DM_NT, y1, wq, qkv, M, 3 * Cc, Cc, lda=Cc, ldb=Cc, ldc=3 * Cc, bias=qkv_b)
         bias = bias_t = None
         cube = _inkernel_cube(table, index32, B, N, heads, D, dtype)
-        split, scube = _split_attention(table, index32, qkv, B, N, heads, D)
         split_imgs = None
         if split:
             o, lse, hi, lo = attention_fwd_split(qkv, None if table is None else table.contiguous(), scube, B, N, heads, D, scale)
@@ -1322,6 +1333,8 @@ class BlockFn(torch.autograd.Function):
         gemm(DM_NT, h, w2, x2, M, Cc, Hd, lda=Hd, ldb=Hd, ldc=Cc, bias=fc2_b, residual=x1)
         if planes:          # (the bf16 [2, rows, cols] tensors travel through save_for_backward like any other)
             y1, y2, h, wq, wp, w1, w2, o_op = y1.t, y2.t, h.t, wq.t, wp.t, w1.t, w2.t, o_op.t
+            if isinstance(qkv, Planes):
+                qkv = qkv.t     # (its two planes are the images in ctx.split_imgs)
         ctx.planes = planes
         ctx.save_for_backward(x2d, mean1, rstd1, y1, qkv, o, lse, bias, bias_t, index32, x1, mean2, rstd2, y2, pre, h,
                               wq, wp, w1, w2, n1w, n2w, o_op if planes else None)
@@ -1406,7 +1419,8 @@ class BlockFn(torch.autograd.Function):
             ctx.split_imgs = None
             want_table = P_table is not None
             dqkv, slab, rows = attention_bwd_split(hi, lo, None if P_table is None else P_table.detach().contiguous(), scube, o.view(B, N, Cc),
-                                                   do.view(B, N, Cc), lse, B, N, heads, D, scale, index32 if want_table else None, n_bins or 0)
+                                                   do.view(B, N, Cc), lse, B, N, heads, D, scale, index32 if want_table else None, n_bins or 0,
+                                                   pair=planes)
         else:
             if ctx.table_in_kernel:                          # the forward kernel read the table itself; so do both backward passes
                 tab, cube = P_table.detach().contiguous(), index32._dm_cube
@@ -1419,7 +1433,7 @@ class BlockFn(torch.autograd.Function):
         if want_table:
             dtable, k_t = _grad_out(P_table, (n_bins, heads), dev)
             relpos_bias_scatter(slab, dtable, B, heads, rows, n_bins, accumulate=_acc(P_table, k_t))
-        dqkv2 = dqkv.view(M, 3 * Cc)
+        dqkv2 = dqkv if isinstance(dqkv, Planes) else dqkv.view(M, 3 * Cc)
         dwq, k_wq = _grad_out(P_qkv_w, (3 * Cc, Cc), dev)
         dbq, k_bq = _grad_out(P_qkv_b, (3 * Cc,), dev)
         dqkv_op, cs = bias_grad(dqkv2, dbq, _acc(P_qkv_b, k_bq), k_bq)

@@ -165,7 +165,8 @@ int dm_attention_bwd_relpos(const void *qkv, const float *table, int32_t cube_s,
  * lo.hi + hi.lo into fp32: ~2^-17 relative per product, where the plain fp32 entry points above use fp32 FMA / fp32 MFMA
  * arithmetic at a fraction of the rate).  Replaces the same reference statements as dm_attention_fwd.  qkv_hi / qkv_lo:
  * caller-allocated bf16 tensors of qkv's shape, WRITTEN here (hi = bf16(x), lo = bf16(x - hi)) and kept by the caller for
- * the backward pass.  table: NULL (no bias) or the relative-position table of a (cube_s, 8, 8) token cube as for
+ * the backward pass -- or, with qkv == NULL (ABI 4), READ here: the caller filled them (the qkv product with a DM_BF16_PAIR result).
+ * table: NULL (no bias) or the relative-position table of a (cube_s, 8, 8) token cube as for
  * dm_attention_fwd_relpos.  dm_attention_split_ok returns 1 for the shapes taken (D = 64, 128 < N <= 256, cube (3|4, 8, 8)
  * when a table is given). */
 int32_t dm_attention_split_ok(int32_t B, int32_t N, int32_t H, int32_t D, int32_t has_table, int32_t cube_s, int32_t cube_h,
@@ -181,6 +182,12 @@ int dm_attention_split_bwd(const void *qkv_hi, const void *qkv_lo, const float *
                            int32_t cube_w, const float *out, const float *dout, void *dout_hi, void *dout_lo,
                            const float *lse, float *dqkv, float *delta, float *dbias_slab, int32_t B, int32_t N,
                            int32_t H, int32_t D, float scale, void *stream);
+/* The same with dqkv written as a hi / lo PLANE PAIR (dqkv_pair bf16 [2][B,N,3,H,64]; ABI 4) instead of fp32: the operand format of the
+ * folded qkv weight / data gradient products (DmGemmArgs.k_fold), which then need no split pass. */
+int dm_attention_split_bwd_pair(const void *qkv_hi, const void *qkv_lo, const float *table, int32_t cube_s, int32_t cube_h,
+                                int32_t cube_w, const float *out, const float *dout, void *dout_hi, void *dout_lo,
+                                const float *lse, void *dqkv_pair, float *delta, float *dbias_slab, int32_t B, int32_t N,
+                                int32_t H, int32_t D, float scale, void *stream);
 /* Number of batch chunks dm_attention_bwd uses for this problem size and dtype (first dimension of dbias_slab). */
 int32_t dm_attention_bwd_batch_chunks(int32_t B, int32_t N, int32_t H, int32_t dtype);
 

@@ -471,6 +471,16 @@ def test_attention_split_forward_backward(N, scales, B, H):
     err_g = (dqkv.cpu().double() - g).abs().max().item() / g.abs().max().item()
     print(f"split-bf16 attention backward N={N}: max |dqkv - fp64| / max |dqkv| = {err_g:.2e}")
     assert err_g < 2e-5
+    # ABI 4, plane pairs on both sides: a pre-split qkv (what the qkv product writes with DM_BF16_PAIR) gives the same forward, and
+    # the backward writes dqkv as the pair that splitting the fp32 result would give -- neither pass exists any more in the model
+    if (B * N) % 8 == 0:
+        qp = ops.split_planes(qkv.to(DEV).view(B * N, 3 * H * D))
+        out2, lse2, hi2, lo2 = ops.attention_fwd_split(qp, None if table is None else table.to(DEV), cube, B, N, H, D, 0.125)
+        assert torch.equal(out2, out) and torch.equal(lse2, lse) and torch.equal(hi2.reshape(hi.shape), hi) and torch.equal(lo2.reshape(lo.shape), lo)
+        dq_pair, slab2, _ = ops.attention_bwd_split(hi, lo, None if table is None else table.to(DEV), cube, out, dout.to(DEV), lse, B, N, H, D, 0.125,
+                                                    idx32, 0 if table is None else n_bins, pair=True)
+        assert torch.equal(dq_pair.t, ops.split_planes(dqkv.view(B * N, 3 * H * D)).t)
+        assert slab is None or torch.equal(slab2, slab)
     if table is not None:
         dt = torch.empty((n_bins, H), device=DEV)
         ops.relpos_bias_scatter(slab, dt, B, H, info, n_bins)
