@@ -360,6 +360,11 @@ __device__ __forceinline__ void dm_epilogue_rows_lean(const GemmParams &p, f32x4
   const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(
       reinterpret_cast<char *>(p.aux) + (p.aux ? ((long long)m_wave * p.ldaux + n_wave) * xsz : 0), 0,
       (live && p.aux) ? dm_epi_records((rows_below * p.ldaux + cols_right) * xsz) : 0, 0x00020000);
+  // run-time form only: the result as a hi / lo plane pair (DM_BF16_PAIR) -- a second descriptor, lo plane p.c_plane elements behind
+  const bool pair = RT && p.c_dtype == DM_BF16_PAIR;
+  const __amdgpu_buffer_rsrc_t rsC2 = __builtin_amdgcn_make_buffer_rsrc(
+      reinterpret_cast<char *>(p.C) + ((pair ? p.c_plane : 0) + (long long)m_wave * p.ldc + n_wave) * csz, 0,
+      (live && pair) ? dm_epi_records((rows_below * p.ldc + cols_right) * csz) : 0, 0x00020000);
   const unsigned voC = (unsigned)((rl * (int)p.ldc + c8 * 8) * csz) | kill;
   const unsigned voR = (unsigned)((rl * (int)p.ldr + c8 * 8) * 4) | kill;
   const unsigned voX = (unsigned)((rl * (int)p.ldaux + c8 * 8) * xsz) | kill;
@@ -439,6 +444,14 @@ __device__ __forceinline__ void dm_epilogue_rows_lean(const GemmParams &p, f32x4
       if (has_acc) { lo += __builtin_bit_cast(f32x4, pre.y0); hi += __builtin_bit_cast(f32x4, pre.y1); }
       DM_EPI_BSTORE(__builtin_bit_cast(u32x4, lo), rsC, voC, q * stepC, 0);
       DM_EPI_BSTORE(__builtin_bit_cast(u32x4, hi), rsC, voC + 16, q * stepC, 0);
+    } else if (pair) {
+      const u32x4 h8 = pack8(lo, hi);
+      const bf16x8 hb = __builtin_bit_cast(bf16x8, h8);
+      f32x4 rl0, rl1;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { rl0[e] = lo[e] - (float)hb[e]; rl1[e] = hi[e] - (float)hb[4 + e]; }
+      DM_EPI_BSTORE(h8, rsC, voC, q * stepC, 0);
+      DM_EPI_BSTORE(pack8(rl0, rl1), rsC2, voC, q * stepC, 0);
     } else {
       DM_EPI_BSTORE(pack8(lo, hi), rsC, voC, q * stepC, 0);
     }
@@ -479,9 +492,9 @@ __host__ __device__ inline int dm_epi_lean_key(const GemmParams &p, int rows) {
   const bool aux_read = p.aux && (p.epilogue == DM_EPI_DGELU || p.epilogue == DM_EPI_MUL);
   const bool aux_write = p.aux && (p.epilogue == DM_EPI_GELU || p.epilogue == DM_EPI_GELU_GRAD);
   const bool lean = p.rows_per_group == 0 && !(p.debug & 0x400) && p.ldc < lim && p.ldr < lim && p.ldaux < lim &&
-                    !(aux_read && p.accumulate) &&        // (one prefetch slot serves the old C or the aux operand)
-                    p.c_dtype != DM_BF16_PAIR;            // (plane-pair results: the generic form's dm_gemm_emit8)
+                    !(aux_read && p.accumulate);          // (one prefetch slot serves the old C or the aux operand)
   if (!lean) return -1;
+  if (p.c_dtype == DM_BF16_PAIR) return 1 << 8;           // plane-pair results: the run-time lean form (no straight-line instance)
   const bool c32 = p.c_dtype == DM_F32, x32 = p.aux_dtype == DM_F32;
   const int yl = (c32 && p.accumulate) ? 1 : aux_read ? (x32 ? 3 : 2) : 0;
   const int xs = aux_write ? (x32 ? 2 : 1) : 0;
