@@ -71,6 +71,7 @@ SIGNATURES = {
     "dm_attention_fwd_relpos": (_I, [_P, _P, _I, _I, _I, _P, _P, _I, _I, _I, _I, _F, _I, _P]),
     "dm_attention_split_ok": (_I, [_I, _I, _I, _I, _I, _I, _I, _I]),
     "dm_attention_split_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _P, _P, _I, _I, _I, _I, _F, _P]),
+    "dm_attention_split_fwd_pair": (_I, [_P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _I, _I, _I, _I, _F, _P]),
     "dm_attention_split_bwd_chunks": (_I, [_I, _I, _I]),
     "dm_attention_split_bwd": (_I, [_P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P]),
     "dm_attention_split_bwd_pair": (_I, [_P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P]),

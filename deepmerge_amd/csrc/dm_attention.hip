@@ -718,9 +718,21 @@ extern "C" int32_t dm_attention_split_ok(int32_t B, int32_t N, int32_t H, int32_
   return split_shape(B, N, H, D, has_table, cube_s, cube_h, cube_w) ? 1 : 0;
 }
 
+static int split_fwd_impl(const float *qkv, void *qkv_hi, void *qkv_lo, const float *table, int32_t cube_s, int32_t cube_h, int32_t cube_w, float *out,
+                          void *out_pair, float *lse, int32_t B, int32_t N, int32_t H, int32_t D, float scale, void *stream);
 extern "C" int dm_attention_split_fwd(const float *qkv, void *qkv_hi, void *qkv_lo, const float *table, int32_t cube_s, int32_t cube_h,
                                       int32_t cube_w, float *out, float *lse, int32_t B, int32_t N, int32_t H, int32_t D, float scale,
                                       void *stream) {
+  return split_fwd_impl(qkv, qkv_hi, qkv_lo, table, cube_s, cube_h, cube_w, out, nullptr, lse, B, N, H, D, scale, stream);
+}
+extern "C" int dm_attention_split_fwd_pair(const float *qkv, void *qkv_hi, void *qkv_lo, const float *table, int32_t cube_s, int32_t cube_h,
+                                           int32_t cube_w, float *out, void *out_pair, float *lse, int32_t B, int32_t N, int32_t H, int32_t D,
+                                           float scale, void *stream) {
+  DM_REQUIRE(out_pair && dm_aligned16(out_pair), DM_ERR_BAD_SHAPE, "dm_attention_split_fwd_pair: out_pair must be a 16-byte aligned pointer");
+  return split_fwd_impl(qkv, qkv_hi, qkv_lo, table, cube_s, cube_h, cube_w, out, out_pair, lse, B, N, H, D, scale, stream);
+}
+static int split_fwd_impl(const float *qkv, void *qkv_hi, void *qkv_lo, const float *table, int32_t cube_s, int32_t cube_h, int32_t cube_w, float *out,
+                          void *out_pair, float *lse, int32_t B, int32_t N, int32_t H, int32_t D, float scale, void *stream) {
   DM_REQUIRE(split_shape(B, N, H, D, table != nullptr, cube_s, cube_h, cube_w), DM_ERR_UNSUPPORTED,
              "dm_attention_split_fwd: shape not taken (B=%d N=%d H=%d D=%d cube=%dx%dx%d); use dm_attention_fwd", B, N, H, D, cube_s, cube_h, cube_w);
   DM_REQUIRE(qkv_hi && qkv_lo && out && lse, DM_ERR_BAD_SHAPE, "dm_attention_split_fwd: null pointer");
@@ -730,7 +742,8 @@ extern "C" int dm_attention_split_fwd(const float *qkv, void *qkv_hi, void *qkv_
   {
     DmProfScope prof("attn_fwd_x3", s, 3.0 * 4.0 * B * H * (double)N * N * HD, 4.0 * 4.0 * B * H * (double)N * HD);
     if (qkv) dm_attn_x3_split(qkv, qkv_hi, qkv_lo, (long long)B * N * 3 * H * HD, s);      // (NULL: the caller filled the two images -- a DM_BF16_PAIR product)
-    AttnX3Params p{reinterpret_cast<const bf16_t *>(qkv_hi), reinterpret_cast<const bf16_t *>(qkv_lo), table, cube_s, out, lse, B, N, H, scale};
+    AttnX3Params p{reinterpret_cast<const bf16_t *>(qkv_hi), reinterpret_cast<const bf16_t *>(qkv_lo), table, cube_s, out, lse, B, N, H, scale,
+                   reinterpret_cast<bf16_t *>(out_pair)};
     DM_REQUIRE(dm_attn_fwd_x3(p, s), DM_ERR_UNSUPPORTED, "dm_attention_split_fwd: kernel could not be configured");
   }
   DM_LAUNCH_CHECK("dm_attention_split_fwd");

@@ -12,6 +12,7 @@ struct AttnX3Params {
   float *lse;              // [B, H, N]
   int B, N, H;
   float scale;
+  bf16_t *out_pair;        // or NULL: the hi / lo plane pair of `out` on the side (lo plane B*N*H*64 elements behind the hi plane)
 };
 
 // shapes the kernels take: head dim 64, 128 < N <= 256, bias absent or a (3 | 4, 8, 8) cube's table; DM_ATTN_X3=0 switches them off

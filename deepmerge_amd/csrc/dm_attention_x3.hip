@@ -346,7 +346,21 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_x3_kernel(const AttnX3Params 
       for (int dt = 0; dt < 2; ++dt) {
         const f32x16 &o = dt ? o1 : o0;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) dm_store4(orow + 32 * dt + 8 * c, (f32x4){o[4 * c] * inv, o[4 * c + 1] * inv, o[4 * c + 2] * inv, o[4 * c + 3] * inv});
+        for (int c = 0; c < 4; ++c) {
+          const f32x4 v = {o[4 * c] * inv, o[4 * c + 1] * inv, o[4 * c + 2] * inv, o[4 * c + 3] * inv};
+          dm_store4(orow + 32 * dt + 8 * c, v);
+          if (p.out_pair) {      // the projection's left operand ("bf16x3" plane pairs): no split pass over `out`
+            bf16x4 h4, l4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              h4[e] = (bf16_t)v[e];
+              l4[e] = (bf16_t)(v[e] - (float)h4[e]);
+            }
+            bf16_t *pr = p.out_pair + (orow - p.out) + 32 * dt + 8 * c;
+            *reinterpret_cast<bf16x4 *>(pr) = h4;
+            *reinterpret_cast<bf16x4 *>(pr + (long long)p.B * N * H * HD) = l4;
+          }
+        }
       }
       if (hh == 0) p.lse[((long long)b * H + h) * N + q] = (m * scale2 + __builtin_amdgcn_logf(l)) * LN2;
     }

@@ -545,7 +545,7 @@ def attention_split_ok(B: int, N: int, H: int, D: int, cube=None) -> bool:
     return bool(_lib.lib().dm_attention_split_ok(B, N, H, D, int(cube is not None), c[0], c[1], c[2]))
 
 
-def attention_fwd_split(qkv: torch.Tensor, table: Optional[torch.Tensor], cube, B: int, N: int, H: int, D: int, scale: float):
+def attention_fwd_split(qkv: torch.Tensor, table: Optional[torch.Tensor], cube, B: int, N: int, H: int, D: int, scale: float, out_pair: bool = False):
     """fp32 attention with split-bf16 products.  Returns (out, lse, qkv_hi, qkv_lo); the two bf16 images go to the backward pass.
     qkv: the fp32 tensor, or its Planes (the qkv product wrote the pair itself: its planes ARE the two images)."""
     if table is not None and (table.dtype != torch.float32 or not table.is_contiguous()):
@@ -563,6 +563,11 @@ def attention_fwd_split(qkv: torch.Tensor, table: Optional[torch.Tensor], cube, 
     out = torch.empty((B, N, H * D), dtype=torch.float32, device=dev)
     lse = torch.empty((B, H, N), dtype=torch.float32, device=dev)
     c = (0, 0, 0) if cube is None else tuple(int(v) for v in cube)
+    if out_pair:        # (out, lse, hi, lo, Planes(out as [B*N, H*D])): the kernel writes the pair next to the fp32 result
+        op = torch.empty((2, B * N, H * D), dtype=torch.bfloat16, device=dev)
+        check(_lib.lib().dm_attention_split_fwd_pair(src, hi.data_ptr(), lo.data_ptr(), _ptr(table), c[0], c[1], c[2], out.data_ptr(), op.data_ptr(),
+                                                     lse.data_ptr(), B, N, H, D, scale, _stream()), "dm_attention_split_fwd_pair")
+        return out, lse, hi, lo, Planes(op)
     check(_lib.lib().dm_attention_split_fwd(src, hi.data_ptr(), lo.data_ptr(), _ptr(table), c[0], c[1], c[2], out.data_ptr(),
                                             lse.data_ptr(), B, N, H, D, scale, _stream()), "dm_attention_split_fwd")
     return out, lse, hi, lo
@@ -1310,7 +1315,11 @@ class BlockFn(torch.autograd.Function):
         cube = _inkernel_cube(table, index32, B, N, heads, D, dtype)
         split_imgs = None
         if split:
-            o, lse, hi, lo = attention_fwd_split(qkv, None if table is None else table.contiguous(), scube, B, N, heads, D, scale)
+            o_op = None
+            if planes:
+                o, lse, hi, lo, o_op = attention_fwd_split(qkv, None if table is None else table.contiguous(), scube, B, N, heads, D, scale, out_pair=True)
+            else:
+                o, lse, hi, lo = attention_fwd_split(qkv, None if table is None else table.contiguous(), scube, B, N, heads, D, scale)
             split_imgs = (hi, lo, scube)
         elif cube is not None:
             o, lse = attention_fwd_relpos(qkv, table.contiguous(), cube, B, N, heads, D, scale)
@@ -1319,7 +1328,8 @@ class BlockFn(torch.autograd.Function):
                 bias, bias_t = relpos_bias_gather(table.contiguous(), index32, N, transposed=True)
             o, lse = attention_fwd(qkv, bias, B, N, heads, D, scale)
         x1 = torch.empty((M, Cc), dtype=torch.float32, device=dev)
-        o_op = split_planes(o.view(M, Cc)) if planes else o.view(M, Cc)
+        if not (planes and split):
+            o_op = split_planes(o.view(M, Cc)) if planes else o.view(M, Cc)
         gemm(DM_NT, o_op, wp, x1, M, Cc, Cc, lda=Cc, ldb=Cc, ldc=Cc, bias=proj_b, residual=x2d)
         y2, mean2, rstd2 = layernorm_fwd(x1, n2w, n2b, eps, dtype, pair=planes)
         h = Planes(torch.empty((2, M, Hd), dtype=torch.bfloat16, device=dev)) if planes else torch.empty((M, Hd), dtype=dtype, device=dev)

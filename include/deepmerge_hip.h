@@ -174,6 +174,11 @@ int32_t dm_attention_split_ok(int32_t B, int32_t N, int32_t H, int32_t D, int32_
 int dm_attention_split_fwd(const float *qkv, void *qkv_hi, void *qkv_lo, const float *table, int32_t cube_s, int32_t cube_h,
                            int32_t cube_w, float *out, float *lse, int32_t B, int32_t N, int32_t H, int32_t D, float scale,
                            void *stream);
+/* The same with the hi / lo PLANE PAIR of `out` written on the side (out_pair bf16 [2][B*N, H*64]; ABI 4): the output projection of the
+ * "bf16x3" mode reads it as its folded left operand (DmGemmArgs.k_fold). */
+int dm_attention_split_fwd_pair(const float *qkv, void *qkv_hi, void *qkv_lo, const float *table, int32_t cube_s, int32_t cube_h,
+                                int32_t cube_w, float *out, void *out_pair, float *lse, int32_t B, int32_t N, int32_t H, int32_t D,
+                                float scale, void *stream);
 /* Backward of dm_attention_split_fwd: dqkv [B,N,3,H,64] fp32 fully written; qkv_hi / qkv_lo as the forward left them;
  * dout_hi / dout_lo: caller-allocated bf16 scratch of dout's shape (written here); delta [B,H,N] scratch; dbias_slab
  * (needs the table): dm_attention_split_bwd_chunks(B,N,H) x H x N x N floats, layout and reduction as for dm_attention_bwd. */

@@ -477,6 +477,8 @@ def test_attention_split_forward_backward(N, scales, B, H):
         qp = ops.split_planes(qkv.to(DEV).view(B * N, 3 * H * D))
         out2, lse2, hi2, lo2 = ops.attention_fwd_split(qp, None if table is None else table.to(DEV), cube, B, N, H, D, 0.125)
         assert torch.equal(out2, out) and torch.equal(lse2, lse) and torch.equal(hi2.reshape(hi.shape), hi) and torch.equal(lo2.reshape(lo.shape), lo)
+        out3, _, _, _, op = ops.attention_fwd_split(qp, None if table is None else table.to(DEV), cube, B, N, H, D, 0.125, out_pair=True)
+        assert torch.equal(out3, out) and torch.equal(op.t, ops.split_planes(out.view(B * N, H * D)).t)
         dq_pair, slab2, _ = ops.attention_bwd_split(hi, lo, None if table is None else table.to(DEV), cube, out, dout.to(DEV), lse, B, N, H, D, 0.125,
                                                     idx32, 0 if table is None else n_bins, pair=True)
         assert torch.equal(dq_pair.t, ops.split_planes(dqkv.view(B * N, 3 * H * D)).t)
