@@ -516,6 +516,27 @@ __global__ void colsum_rows_reduce_kernel(const float *__restrict__ rows, float 
 // 16x32 / 32x16 operand slices through a private LDS region), and the partial tiles are summed in a
 // fixed order before the epilogue.  FMA chains in k order within a wave; deterministic.
 // NW waves split K; the partial tiles are summed in wave order: deterministic for a given NW.
+// one output of the generic fp32 path through the fused epilogue
+__device__ __forceinline__ void sgemm_small_emit(const GemmParams &p, int m, int n, float v) {
+  if (p.bias) v += p.bias[n];
+  const long long ro = (long long)m;
+  if (p.epilogue == DM_EPI_GELU) {
+    if (p.aux) reinterpret_cast<float *>(p.aux)[ro * p.ldaux + n] = v;
+    v = dm_gelu(v);
+  } else if (p.epilogue == DM_EPI_DGELU) {
+    v *= dm_dgelu(reinterpret_cast<const float *>(p.aux)[ro * p.ldaux + n]);
+  } else if (p.epilogue == DM_EPI_GELU_GRAD) {
+    reinterpret_cast<float *>(p.aux)[ro * p.ldaux + n] = dm_dgelu(v);
+    v = dm_gelu(v);
+  } else if (p.epilogue == DM_EPI_MUL) {
+    v *= reinterpret_cast<const float *>(p.aux)[ro * p.ldaux + n];
+  }
+  if (p.residual) v += p.residual[ro * p.ldr + n];
+  float *c = reinterpret_cast<float *>(p.C) + ro * p.ldc + n;
+  if (p.accumulate) v += *c;
+  *c = v;
+}
+
 template <int LAYOUT, int NW = 4>
 __global__ __launch_bounds__(64 * NW) void sgemm_small_kernel(const GemmParams p) {
   __shared__ float sa[NW][32][17], sb[NW][32][17];
@@ -524,8 +545,12 @@ __global__ __launch_bounds__(64 * NW) void sgemm_small_kernel(const GemmParams p
   const int m0 = blockIdx.y * 16, n0 = blockIdx.x * 16;
   const float *A = reinterpret_cast<const float *>(p.A);
   const float *B = reinterpret_cast<const float *>(p.B);
-  const int kq = ((p.K + NW - 1) / NW + 31) / 32 * 32;    // K slice per wave, multiple of 32
-  const int kbeg = w * kq, kend = min(p.K, kbeg + kq);
+  // gridDim.z > 1 (skinny products with a long contraction -- the 100-wide head over 3840 features: 28 tiles): the contraction is cut
+  // into gridDim.z slices of p.k_per_split, partial tiles go to p.workspace [z][M][N], sgemm_small_reduce_kernel sums them in slice
+  // order and applies the epilogue
+  const int kz0 = gridDim.z > 1 ? blockIdx.z * p.k_per_split : 0, kz1 = gridDim.z > 1 ? min(p.K, kz0 + p.k_per_split) : p.K;
+  const int kq = ((kz1 - kz0 + NW - 1) / NW + 31) / 32 * 32;    // K slice per wave, multiple of 32
+  const int kbeg = kz0 + w * kq, kend = min(kz1, kbeg + kq);
   const int tx = lane & 15, ty = lane >> 4;                // lane computes rows 4ty..4ty+3 of column tx
   float acc[4] = {0.f, 0.f, 0.f, 0.f};
   float ra[8], rb[8];
@@ -585,23 +610,20 @@ __global__ __launch_bounds__(64 * NW) void sgemm_small_kernel(const GemmParams p
 #pragma unroll
     for (int q = 4; q < NW; q += 4) v += (red[q][om][on] + red[q + 1][om][on]) + (red[q + 2][om][on] + red[q + 3][om][on]);
   }
-  if (p.bias) v += p.bias[n];
-  const long long ro = (long long)m;
-  if (p.epilogue == DM_EPI_GELU) {
-    if (p.aux) reinterpret_cast<float *>(p.aux)[ro * p.ldaux + n] = v;
-    v = dm_gelu(v);
-  } else if (p.epilogue == DM_EPI_DGELU) {
-    v *= dm_dgelu(reinterpret_cast<const float *>(p.aux)[ro * p.ldaux + n]);
-  } else if (p.epilogue == DM_EPI_GELU_GRAD) {
-    reinterpret_cast<float *>(p.aux)[ro * p.ldaux + n] = dm_dgelu(v);
-    v = dm_gelu(v);
-  } else if (p.epilogue == DM_EPI_MUL) {
-    v *= reinterpret_cast<const float *>(p.aux)[ro * p.ldaux + n];
+  if (gridDim.z > 1) {
+    p.workspace[((long long)blockIdx.z * p.M + m) * p.N + n] = v;
+    return;
   }
-  if (p.residual) v += p.residual[ro * p.ldr + n];
-  float *c = reinterpret_cast<float *>(p.C) + ro * p.ldc + n;
-  if (p.accumulate) v += *c;
-  *c = v;
+  sgemm_small_emit(p, m, n, v);
+}
+
+// sum of the K slices of a skinny product (slice order: deterministic) + the fused epilogue; one output per thread
+__global__ __launch_bounds__(256) void sgemm_small_reduce_kernel(const GemmParams p, int slices) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x, mn = (long long)p.M * p.N;
+  if (i >= mn) return;
+  float v = p.workspace[i];
+  for (int z = 1; z < slices; ++z) v += p.workspace[z * mn + i];
+  sgemm_small_emit(p, (int)(i / p.N), (int)(i % p.N), v);
 }
 
 template <typename T, int TM>
@@ -677,7 +699,10 @@ extern "C" int64_t dm_gemm_workspace_bytes(int32_t layout, int32_t M, int32_t N,
   if (layout != DM_TN) {
     // forward / dgrad K slices (plan_fwd_split, dm_gemm_w4_plan): at most 4 partial tiles
     const long long t128 = (long long)((M + 127) / 128) * ((N + 127) / 128);
-    return (N % 8 == 0 && K >= 1536 && t128 < 256) ? (int64_t)4 * M * N * 4 : 0;
+    const long long t16 = (long long)((M + 15) / 16) * ((N + 15) / 16);
+    const int64_t skinny = (K >= 1024 && t16 <= 128) ? (int64_t)32 * M * N * 4 : 0;      // K slices of the generic fp32 path
+    const int64_t sliced = (N % 8 == 0 && K >= 1536 && t128 < 256) ? (int64_t)4 * M * N * 4 : 0;
+    return skinny > sliced ? skinny : sliced;
   }
   const int tile = pick_tile(layout, M, N, K);
   const int tiles = ((M + tile - 1) / tile) * ((N + tile - 1) / tile);
@@ -762,6 +787,23 @@ extern "C" int dm_gemm(const DmGemmArgs *a, void *stream) {
                "(M=%d N=%d K=%d lda=%lld ldb=%lld)", a->M, a->N, a->K, (long long)a->lda, (long long)a->ldb);
     DM_REQUIRE(a->rows_per_group == 0, DM_ERR_UNSUPPORTED, "dm_gemm: grouped rows need the MFMA path");
     dim3 grid((a->N + 15) / 16, (a->M + 15) / 16);
+    // skinny products with a long contraction (the head: 64 x 100 over 3840 features = 28 tiles, 36 us on 28 workgroups): K slices
+    // over gridDim.z, summed in slice order by a second small launch.  DM_GEMM_SKINNY=0 for A/B runs.
+    static const bool skinny_on = [] { const char *e = getenv("DM_GEMM_SKINNY"); return !(e && atoi(e) == 0); }();
+    const long long tiles16 = (long long)grid.x * grid.y;
+    int slices = 1;
+    if (skinny_on && a->workspace && !a->colsum_a && a->K >= 1024 && tiles16 <= 128) {
+      slices = (int)(512 / tiles16);
+      if (slices > a->K / 128) slices = a->K / 128;
+      if (slices > 32) slices = 32;
+      while (slices > 1 && (int64_t)slices * a->M * a->N * 4 > slab_bytes) slices >>= 1;
+    }
+    if (slices > 1) {
+      p.workspace = reinterpret_cast<float *>(a->workspace);
+      p.k_per_split = ((a->K + slices - 1) / slices + 31) / 32 * 32;
+      slices = (a->K + p.k_per_split - 1) / p.k_per_split;
+      grid.z = slices;
+    }
     switch (a->layout) {
       // (a 16-wave instance -- K split 16 ways, 8 stages instead of 30 for the 3840-wide head product -- measured 92 us against ~36 us for
       // this one: not used)
@@ -769,6 +811,8 @@ extern "C" int dm_gemm(const DmGemmArgs *a, void *stream) {
       case DM_NN: hipLaunchKernelGGL((sgemm_small_kernel<DM_NN>), grid, dim3(256), 0, s, p); break;
       default: hipLaunchKernelGGL((sgemm_small_kernel<DM_TN>), grid, dim3(256), 0, s, p); break;
     }
+    if (slices > 1)
+      hipLaunchKernelGGL(sgemm_small_reduce_kernel, dim3((unsigned)(((long long)a->M * a->N + 255) / 256)), dim3(256), 0, s, p, slices);
     DM_LAUNCH_CHECK("dm_gemm(generic)");
     if (a->colsum_a) return dm_colsum(a->A, a->ab_dtype, a->lda, a->colsum_a, a->K, a->M, a->colsum_accumulate, cs_region, stream);
     return DM_OK;

@@ -913,6 +913,37 @@ def test_gemm_wgrad_with_fused_column_sums(M, N, K):
         ops.gemm(DM_TN, dy, x, dw, M, N, K, lda=M, ldb=N, ldc=N, colsum_out=torch.empty(M - 1, device=DEV))
 
 
+@pytest.mark.parametrize("layout,M,N,K", [("NT", 64, 100, 3840), ("NN", 64, 100, 3840), ("TN", 100, 52, 2050), ("NT", 7, 19, 1024), ("NT", 128, 256, 1500)])
+def test_gemm_skinny_fp32_k_slices(layout, M, N, K, monkeypatch):
+    """The generic fp32 path cuts the contraction of skinny products (the 100-wide head over 3840 pooled features,
+    nets/ShfitScaleFormer.py:958-975: 28 output tiles) into K slices over gridDim.z and sums them in slice order in a second launch:
+    exact on integer data, every epilogue, ragged K, and the same bits as the unsliced kernel on such data."""
+    ops = _ops()
+    from deepmerge_amd._lib import DM_EPI_GELU, DM_EPI_NONE, DM_NN, DM_NT, DM_TN
+    lay = {"NT": DM_NT, "NN": DM_NN, "TN": DM_TN}[layout]
+    g = torch.Generator(device=DEV); g.manual_seed(M * N + K)
+    A = torch.randint(-2, 3, (K, M) if layout == "TN" else (M, K), device=DEV, generator=g).float()
+    B = torch.randint(-2, 3, (N, K) if layout == "NT" else (K, N), device=DEV, generator=g).float()
+    bias = torch.randint(-3, 4, (N,), device=DEV, generator=g).float()
+    res = torch.randint(-3, 4, (M, N), device=DEV, generator=g).float()
+    ref = (A.t() if layout == "TN" else A) @ (B.t() if layout == "NT" else B) + bias + res
+    outs = []
+    for on in ("1", "0"):
+        monkeypatch.setenv("DM_GEMM_SKINNY", on)      # (read once per process: the first value wins; both runs are checked against the exact result)
+        C_ = torch.empty(M, N, device=DEV)
+        ops.gemm(lay, A, B, C_, M, N, K, bias=bias, residual=res)
+        assert torch.equal(C_, ref)
+        Cg = torch.empty(M, N, device=DEV)
+        aux = torch.empty(M, N, device=DEV)
+        ops.gemm(lay, A * 0.25, B * 0.25, Cg, M, N, K, bias=bias, epilogue=DM_EPI_GELU, aux=aux, ldaux=N)
+        pre = ref - res - bias
+        assert torch.equal(aux, pre / 16 + bias)
+        assert (Cg - torch.nn.functional.gelu(aux)).abs().max().item() < 1e-5
+        acc = torch.ones(M, N, device=DEV)
+        ops.gemm(lay, A, B, acc, M, N, K, accumulate=True)
+        assert torch.equal(acc, ref - bias - res + 1)
+
+
 def test_gemm_user_split_k_is_bounds_checked():
     """A caller-chosen split_k above the automatic one used to write past the split-K slab (GPU fault, round 2).  The library now
     refuses a workspace that is too small, and ops.gemm sizes the workspace for the requested slice count."""

@@ -1,8 +1,7 @@
 set -e
-run() { echo "== $*"; env "$@" timeout -k 10 300 python bench.py --steps 100 --warmup 10 --no-extras --no-cpu-baseline --numerics bf16x3 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['value'], d['ms_per_step'])"; }
-run DM_GEMM_256_FOLD_NN=0 DM_GEMM_RING_FOLD=1
-run DM_GEMM_256_FOLD_NN=1 DM_GEMM_RING_FOLD=0
-run DM_GEMM_256_FOLD_NN=0 DM_GEMM_RING_FOLD=1
-run DM_GEMM_256_FOLD_NN=1 DM_GEMM_RING_FOLD=0
-run DM_GEMM_256_FOLD_NN=1 DM_GEMM_RING_FOLD=1
-run DM_GEMM_256_FOLD_NN=0 DM_GEMM_RING_FOLD=0
+timeout -k 10 600 python -m pytest tests/test_gpu_kernels.py -x -q -k "skinny or gemm" 2>&1 | tail -3
+run() { echo "== $*"; env "$@" timeout -k 10 300 python bench.py --steps 200 --warmup 20 --no-extras --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['value'], d['ms_per_step'])"; }
+run DM_GEMM_SKINNY=0
+run DM_GEMM_SKINNY=1
+run DM_GEMM_SKINNY=0
+run DM_GEMM_SKINNY=1
