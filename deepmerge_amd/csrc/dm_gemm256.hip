@@ -590,7 +590,12 @@ bool dm_gemm256_plan(GemmParams &p, int layout, int ab_dtype, bool can_split, lo
   bool take;
   static const int tn_min_tiles = [] { const char *e = getenv("DM_GEMM_256_TN_MINK"); return e ? atoi(e) : 8; }();   // K tiles per slice (8: the 4096-token stage's wgrads gain 12-30 % in the step; 16 left them on the 64x64 kernel)
   if (layout == DM_TN) take = wgs >= 200 && (long long)p.K / split >= (long long)tn_min_tiles * BK256;
-  else if (layout == DM_NN) take = tiles >= 1024;
+  else if (layout == DM_NN) {
+    // folded products (K = 3 x the layer's width: a tile's fill and epilogue weigh a third of what they do in bf16 mode): the dgrad of
+    // fc2 (768 tiles, plane-pair result x saved GELU') 285 us here against 305 on 128 x 128 tiles (tools/mb_fold.py); DM_GEMM_FOLD_ROUTES=0: off
+    static const bool fold_routes = [] { const char *e = getenv("DM_GEMM_FOLD_ROUTES"); return !(e && atoi(e) == 0); }();
+    take = tiles >= 1024 || (fold_routes && p.k_fold > 0 && p.K >= 2048 && tiles >= 512);
+  }
   else {
     // long-K forward products (fc2: K = 3072, 192 tiles) amortise the fill / epilogue: -0.03 ms/step measured
     static const int longk = [] { const char *e = getenv("DM_GEMM_256_NT_LONGK"); return e ? atoi(e) : 1; }();

@@ -199,7 +199,11 @@ int dm_gemm_ring_plan(GemmParams &p, int layout, int ab_dtype, bool aligned8) {
   // 16384 x 3072 + GELU' 121 -> 116 us, 4096 x 3072 + GELU' 44 -> 36 us); 4096 x 2304 (576 tiles = 0.75 round) stays here (29 vs 31 us)
   // Round 4, both kernels on the lean epilogue (dm_gemm_common.h), same box, per step: 16384 x 3072 + GELU' 0.353 ms on 128 x 128 tiles,
   // 0.330 here (0.335 on the 256 x 256 pipeline); 16384 x 2304 0.235 / 0.235; 4096 x 3072 + GELU' 0.073 / 0.080 -> the widest product is back
-  if (mode == 1 && ((long long)((p.M + 127) / 128) * ((p.N + 127) / 128)) % 768 == 0 && !(p.N >= 3072 && p.M >= 8192)) return 0;
+  // folded products (tools/mb_fold.py, the qkv forward with a plane-pair result, 16384 x 2304 x 3*768): 192 us here, 199 on the 4-wave kernel,
+  // 208 on the 256 x 256 pipeline, 236 on 128 x 128 tiles -- the whole-rounds exception below is a bf16-mode (K = 768) finding
+  static const bool fold_routes = [] { const char *e = getenv("DM_GEMM_FOLD_ROUTES"); return !(e && atoi(e) == 0); }();
+  const bool fold_wide = fold_routes && p.k_fold > 0 && p.N >= 2048 && p.M >= 8192;
+  if (mode == 1 && !fold_wide && ((long long)((p.M + 127) / 128) * ((p.N + 127) / 128)) % 768 == 0 && !(p.N >= 3072 && p.M >= 8192)) return 0;
   int wm = t256 >= 384 ? 8 : 4;
   if (force == 8 || force == 4) wm = force;
   static const bool ok = dmring::set_lds_limit<8>() && dmring::set_lds_limit<4>() && dmring::set_lds_limit<8, true>() && dmring::set_lds_limit<4, true>();

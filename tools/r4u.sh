@@ -1,7 +1,6 @@
 set -e
-timeout -k 10 600 python -m pytest tests/test_gpu_kernels.py -x -q -k "skinny or gemm" 2>&1 | tail -3
-run() { echo "== $*"; env "$@" timeout -k 10 300 python bench.py --steps 200 --warmup 20 --no-extras --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['value'], d['ms_per_step'])"; }
-run DM_GEMM_SKINNY=0
-run DM_GEMM_SKINNY=1
-run DM_GEMM_SKINNY=0
-run DM_GEMM_SKINNY=1
+run() { echo "== $*"; env "$@" timeout -k 10 300 python bench.py --steps 100 --warmup 10 --no-extras --no-cpu-baseline --numerics bf16x3 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['value'], d['ms_per_step'])"; }
+for i in 1 2 3; do
+run DM_GEMM_FOLD_ROUTES=0
+run DM_GEMM_FOLD_ROUTES=1
+done
