@@ -622,7 +622,15 @@ __global__ __launch_bounds__(256) void sgemm_small_reduce_kernel(const GemmParam
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x, mn = (long long)p.M * p.N;
   if (i >= mn) return;
   float v = p.workspace[i];
-  for (int z = 1; z < slices; ++z) v += p.workspace[z * mn + i];
+  int z = 1;
+  for (; z + 8 <= slices; z += 8) {        // eight slices in flight (a one-by-one loop pays a memory round trip per slice); same order of sums
+    float t[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) t[u] = p.workspace[(z + u) * mn + i];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v += t[u];
+  }
+  for (; z < slices; ++z) v += p.workspace[z * mn + i];
   sgemm_small_emit(p, (int)(i / p.N), (int)(i % p.N), v);
 }
 
