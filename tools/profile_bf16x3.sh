@@ -1,3 +1,4 @@
+# One traced step of the bf16x3 numerics mode: launch sequence, kernel statistics.
 set -e
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/x3prof

@@ -1,3 +1,4 @@
+# Kernel-trace of the headline bench; idle time between kernels and one step's launch sequence (tools/rocpd_gaps.py).
 set -e
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/gaps

@@ -1,3 +1,4 @@
+# Full end-of-round refresh: tools/profile_round.sh + one traced bf16x3 step + the per-shape tables of configs 2 / 3 / 5.
 set -e
 bash tools/profile_round.sh r04
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
