@@ -28,17 +28,20 @@ constexpr float NEG_BIG = -1.0e30f;
 // `s_nop 1`; with two waves per SIMD a wave's issue slots are not the limit.
 #define DMQ_PAD "s_nop 1\n\t"
 template <bool QA, bool PAD> __device__ __forceinline__ void qk_first(f32x16 &d, const u32x4 &k, const u32x4 &q, const f32x16 &c) {
-  if constexpr (QA) asm volatile(DMQ_MFMA " %0, %1, %2, %3" : "=&v"(d) : "v"(k), "a"(q), "v"(c));
+  if constexpr (QA && PAD) asm volatile(DMQ_PAD DMQ_MFMA " %0, %1, %2, %3" : "=&v"(d) : "v"(k), "a"(q), "v"(c));
+  else if constexpr (QA) asm volatile(DMQ_MFMA " %0, %1, %2, %3" : "=&v"(d) : "v"(k), "a"(q), "v"(c));
   else if constexpr (PAD) asm volatile(DMQ_PAD DMQ_MFMA " %0, %1, %2, %3" : "=&v"(d) : "v"(k), "v"(q), "v"(c));
   else asm volatile(DMQ_MFMA " %0, %1, %2, %3" : "=&v"(d) : "v"(k), "v"(q), "v"(c));
 }
 template <bool QA, bool PAD> __device__ __forceinline__ void qk_first0(f32x16 &d, const u32x4 &k, const u32x4 &q) {
-  if constexpr (QA) asm volatile(DMQ_MFMA " %0, %1, %2, 0" : "=&v"(d) : "v"(k), "a"(q));
+  if constexpr (QA && PAD) asm volatile(DMQ_PAD DMQ_MFMA " %0, %1, %2, 0" : "=&v"(d) : "v"(k), "a"(q));
+  else if constexpr (QA) asm volatile(DMQ_MFMA " %0, %1, %2, 0" : "=&v"(d) : "v"(k), "a"(q));
   else if constexpr (PAD) asm volatile(DMQ_PAD DMQ_MFMA " %0, %1, %2, 0" : "=&v"(d) : "v"(k), "v"(q));
   else asm volatile(DMQ_MFMA " %0, %1, %2, 0" : "=&v"(d) : "v"(k), "v"(q));
 }
 template <bool QA, bool PAD> __device__ __forceinline__ void qk_acc(f32x16 &d, const u32x4 &k, const u32x4 &q) {
-  if constexpr (QA) asm volatile(DMQ_MFMA " %0, %1, %2, %0" : "+v"(d) : "v"(k), "a"(q));
+  if constexpr (QA && PAD) asm volatile(DMQ_PAD DMQ_MFMA " %0, %1, %2, %0" : "+v"(d) : "v"(k), "a"(q));
+  else if constexpr (QA) asm volatile(DMQ_MFMA " %0, %1, %2, %0" : "+v"(d) : "v"(k), "a"(q));
   else if constexpr (PAD) asm volatile(DMQ_PAD DMQ_MFMA " %0, %1, %2, %0" : "+v"(d) : "v"(k), "v"(q));
   else asm volatile(DMQ_MFMA " %0, %1, %2, %0" : "+v"(d) : "v"(k), "v"(q));
 }

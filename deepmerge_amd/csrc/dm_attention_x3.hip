@@ -56,8 +56,12 @@ __device__ __forceinline__ unsigned split_lo(float a, float b, unsigned h2) {   
 }
 
 // NKT: 32-key tiles; RAGGED: N < 32 NKT (no table then); TAB: p.table != NULL (N = 64 cube_s)
-template <int NKT, bool RAGGED, bool TAB>
-__global__ __launch_bounds__(256, 1) void attn_fwd_x3_kernel(const AttnX3Params p, int bchunk, int nblk, int chunks) {
+// NW = 4: one wave per SIMD, a workgroup owns a 128-row block of one head for a chunk of samples (`coords`).  NW = 8 (round 4): two waves
+// per SIMD on the SAME K / V images (the register budget of 242 fits twice; one wave's exp / split VALU work runs under the other's MFMAs,
+// and a unit's K / V are staged once instead of once per row block); the (head, sample) units u = head * B + sample are dealt out as
+// gridDim.x contiguous runs of equal length +- 1, which may cross a head boundary (the table is reloaded there).
+template <int NKT, bool RAGGED, bool TAB, int NW = 4>
+__global__ __launch_bounds__(64 * NW, 1) void attn_fwd_x3_kernel(const AttnX3Params p, int bchunk, int nblk, int chunks) {
   static_assert(!(TAB && (RAGGED || NKT % 2)), "table form: N = 64 x scales");
   constexpr int NP = NKT * 32;
   const int N = RAGGED ? p.N : NP;
@@ -66,12 +70,22 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_x3_kernel(const AttnX3Params 
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int r = lane & 31, hh = lane >> 5;
-  int h, rb, chunk;
-  if (!coords(nblk, p.H, chunks, h, rb, chunk)) return;
   const int H = p.H;
-  const int b0 = chunk * bchunk, b1 = min(p.B, b0 + bchunk);
-  if (b0 >= b1) return;
-  const int q_wave = rb * 128 + wave * 32;
+  int rb = 0, u0, u1;
+  if constexpr (NW == 8) {
+    const int units = p.B * H, G = gridDim.x, base = units / G, rem = units - base * G, w = blockIdx.x;
+    u0 = w * base + min(w, rem);
+    u1 = u0 + base + (w < rem ? 1 : 0);
+  } else {
+    int h0, chunk;
+    if (!coords(nblk, H, chunks, h0, rb, chunk)) return;
+    u0 = h0 * p.B + chunk * bchunk;
+    u1 = h0 * p.B + min(p.B, chunk * bchunk + bchunk);
+  }
+  if (u0 >= u1) return;
+  int h = -1;                                                       // head of the unit in progress (its table is in LDS)
+  constexpr bool PAD = NW == 8;      // (256-register budget: operands may come fresh from v_accvgpr moves -- every asm MFMA opens with a wait state)
+  const int q_wave = rb * (32 * NW) + wave * 32;
   const int q = q_wave + r;
   const bool wave_live = q_wave < N;
   const bool row_ok = q < N;
@@ -84,15 +98,19 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_x3_kernel(const AttnX3Params 
   float *tab = reinterpret_cast<float *>(smem + 4 * IMG);
   const float *tabl = tab;
   if constexpr (TAB) {
-    const float inv_scale = 1.f / p.scale;
-    for (int i = t; i < (NKT - 1) * 225; i += 256) {
-      const int prow = i / 15, px = i - prow * 15;
-      tab[prow * 16 + (14 - px)] = p.table[(long long)i * H + h] * inv_scale;
-    }
     const int qz = q >> 6, qy = (q >> 3) & 7, qx = q & 7;
     tabl = tab + ((qz + NKT / 2 - 1) * 15 + qy + 7 - TAB_MAXC) * 16 + 7 - qx + 4 * hh;
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              // (in LDS before the first unit's barrier)
   }
+  auto load_table = [&](int hd) {                                   // (called between two barriers: nobody reads the old table any more)
+    if constexpr (TAB) {
+      const float inv_scale = 1.f / p.scale;
+      for (int i = t; i < (NKT - 1) * 225; i += 64 * NW) {
+        const int prow = i / 15, px = i - prow * 15;
+        tab[prow * 16 + (14 - px)] = p.table[(long long)i * H + hd] * inv_scale;
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+  };
   auto init_c = [&](int kt, f32x16 &d) {                            // what the tile's score chain accumulates onto
     if constexpr (TAB) {
 #pragma unroll
@@ -107,9 +125,12 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_x3_kernel(const AttnX3Params 
   };
 
   // ---- DMA: the forward kernel's K / V piece layout, for the hi and the lo tensor ---------------------------------------------------------
+  // (a 32-key tile is four 8-row pieces per image; 4 waves: wave w stages piece w of all four images; 8 waves: waves 0..3 the K images,
+  // waves 4..7 the V images)
   const int dkey = lane >> 3;
-  const unsigned rowoff0 = (unsigned)((8 * wave + dkey) * tok_stride * 2);
-  const unsigned voffK = rowoff0 + (unsigned)(1 * H * HD * 2) + (unsigned)(((lane & 7) ^ (((wave & 1) << 2) | (dkey >> 1))) * 16);
+  const int pw = wave & 3;                                          // the 8-row piece of a tile this wave stages
+  const unsigned rowoff0 = (unsigned)((8 * pw + dkey) * tok_stride * 2);
+  const unsigned voffK = rowoff0 + (unsigned)(1 * H * HD * 2) + (unsigned)(((lane & 7) ^ (((pw & 1) << 2) | (dkey >> 1))) * 16);
   const unsigned voffV = rowoff0 + (unsigned)(2 * H * HD * 2) + (unsigned)(((lane & 7) ^ (((dkey >> 1) & 1) << 2)) * 16);
   const unsigned lds0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(uintptr_t)(DM_LDS char *)smem);
   unsigned step_bytes = (unsigned)__builtin_amdgcn_readfirstlane((int)(32 * tok_stride * 2));
@@ -126,13 +147,17 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_x3_kernel(const AttnX3Params 
   };
   auto stage_all = [&](int b) {
     const i32x4 rh = sample_rsrc(p.hi, b), rl = sample_rsrc(p.lo, b);
-    const unsigned base = lds0 + (unsigned)wave * 1024u;
+    const unsigned base = lds0 + (unsigned)pw * 1024u;
 #pragma unroll
     for (int j = 0; j < NKT; ++j) {
-      lds_dma(rh, base + 0 * IMG + (unsigned)j * 4096u, voffK, (unsigned)j * step_bytes);
-      lds_dma(rl, base + 1 * IMG + (unsigned)j * 4096u, voffK, (unsigned)j * step_bytes);
-      lds_dma(rh, base + 2 * IMG + (unsigned)j * 4096u, voffV, (unsigned)j * step_bytes);
-      lds_dma(rl, base + 3 * IMG + (unsigned)j * 4096u, voffV, (unsigned)j * step_bytes);
+      if (NW == 4 || wave < 4) {
+        lds_dma(rh, base + 0 * IMG + (unsigned)j * 4096u, voffK, (unsigned)j * step_bytes);
+        lds_dma(rl, base + 1 * IMG + (unsigned)j * 4096u, voffK, (unsigned)j * step_bytes);
+      }
+      if (NW == 4 || wave >= 4) {
+        lds_dma(rh, base + 2 * IMG + (unsigned)j * 4096u, voffV, (unsigned)j * step_bytes);
+        lds_dma(rl, base + 3 * IMG + (unsigned)j * 4096u, voffV, (unsigned)j * step_bytes);
+      }
     }
   };
   auto load_q = [&](int b, u32x4 (&fh)[4], u32x4 (&fl)[4]) {
@@ -154,8 +179,10 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_x3_kernel(const AttnX3Params 
 
   constexpr float RESCALE_LOG2 = 16.f;
   u32x4 qh[4], ql[4];
-  for (int b = b0; b < b1; ++b) {
-    __builtin_amdgcn_s_barrier();                                   // everyone is done with the previous unit's images (and the table is written)
+  for (int u = u0; u < u1; ++u) {
+    const int hu = u / p.B, b = u - hu * p.B;
+    __builtin_amdgcn_s_barrier();                                   // everyone is done with the previous unit's images and table
+    if (hu != h) { h = hu; load_table(h); }                         // (uniform: the first unit, or the run crossed into the next head)
     stage_all(b);
     load_q(b, qh, ql);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -196,7 +223,7 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_x3_kernel(const AttnX3Params 
     // piece pi (0..11) of a tile's score chain: k-step pi / 3, term pi % 3 = (K hi, Q hi), (K lo, Q hi), (K hi, Q lo)
     auto qk_piece = [&](int pi, f32x16 &d) {
       const int ks = pi / 3, term = pi % 3;
-      qk_acc<true, false>(d, term == 1 ? kfl[ks] : kfh[ks], term == 2 ? ql[ks] : qh[ks]);
+      qk_acc<true, PAD>(d, term == 1 ? kfl[ks] : kfh[ks], term == 2 ? ql[ks] : qh[ks]);
     };
     // piece pi (0..11) of a tile's P.V: (k-step, d tile) = (pi / 6, (pi / 3) % 2), term pi % 3 = (V hi, P hi), (V lo, P hi), (V hi, P lo)
     auto pv_piece = [&](int kt, int pi, const u32x4 (&ph)[2], const u32x4 (&pl)[2]) {
@@ -204,11 +231,11 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_x3_kernel(const AttnX3Params 
       f32x16 &o = dt ? o1 : o0;
       const u32x4 a = term == 1 ? vfrag(vfl, sx, dt) : vfrag(vfh, sx, dt);
       const u32x4 &bq = term == 2 ? pl[sx] : ph[sx];
-      if (kt == 0 && sx == 0 && term == 0) pv_first<false>(o, a, bq); else pv_acc<false>(o, a, bq);
+      if (kt == 0 && sx == 0 && term == 0) pv_first<PAD>(o, a, bq); else pv_acc<PAD>(o, a, bq);
     };
     auto l_piece = [&](int kt, int pi, const u32x4 (&ph)[2], const u32x4 (&pl)[2]) {      // pi 0..3: hi k-steps, lo k-steps
       const u32x4 &bq = pi < 2 ? ph[pi] : pl[pi - 2];
-      if (kt == 0 && pi == 0) l_first<false>(la, ones, bq); else l_acc<false>(la, ones, bq);
+      if (kt == 0 && pi == 0) l_first<PAD>(la, ones, bq); else l_acc<PAD>(la, ones, bq);
     };
     float fa[8][2], ex[8][2];
     unsigned wh[8];
@@ -372,8 +399,9 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_x3_kernel(const AttnX3Params 
 // Images [K hi | K lo | V hi | V lo] with the dual-use swizzle (K is read by rows and transposed); Q / dO fragments of the lane's row
 // come from the split tensors in global memory, dS^T is split in registers.  36 MFMAs per 32-key tile; a tile runs start to end
 // (score chains, wait, VALU, dQ chain): the simple form already is several times the fp32-MFMA kernels' rate.
-template <int NKT, bool RAGGED, bool TAB>
-__global__ __launch_bounds__(256, 1) void attn_bwd_dq_x3_kernel(const AttnX3BwdParams p, int bchunk, int nblk, int chunks) {
+// NW: 4 = one wave per SIMD on 128-row blocks; 8 = two waves per SIMD over whole (head, sample) units dealt out as runs (see attn_fwd_x3_kernel)
+template <int NKT, bool RAGGED, bool TAB, int NW = 4>
+__global__ __launch_bounds__(64 * NW, 1) void attn_bwd_dq_x3_kernel(const AttnX3BwdParams p, int bchunk, int nblk, int chunks) {
   static_assert(!(TAB && (RAGGED || NKT % 2)), "table form: N = 64 x scales");
   constexpr int NP = NKT * 32;
   const int N = RAGGED ? p.N : NP;
@@ -382,12 +410,22 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_x3_kernel(const AttnX3BwdP
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int r = lane & 31, hh = lane >> 5;
-  int h, rb, chunk;
-  if (!coords(nblk, p.H, chunks, h, rb, chunk)) return;
   const int H = p.H;
-  const int b0 = chunk * bchunk, b1 = min(p.B, b0 + bchunk);
-  if (b0 >= b1) return;
-  const int q_wave = rb * 128 + wave * 32;
+  int rb = 0, u0, u1;
+  if constexpr (NW == 8) {
+    const int units = p.B * H, G = gridDim.x, base = units / G, rem = units - base * G, w = blockIdx.x;
+    u0 = w * base + min(w, rem);
+    u1 = u0 + base + (w < rem ? 1 : 0);
+  } else {
+    int h0, chunk;
+    if (!coords(nblk, H, chunks, h0, rb, chunk)) return;
+    u0 = h0 * p.B + chunk * bchunk;
+    u1 = h0 * p.B + min(p.B, chunk * bchunk + bchunk);
+  }
+  if (u0 >= u1) return;
+  int h = -1;                                                       // head of the unit in progress (its table is in LDS)
+  constexpr bool PAD = NW == 8;      // (256-register budget: operands may come fresh from v_accvgpr moves -- every asm MFMA opens with a wait state)
+  const int q_wave = rb * (32 * NW) + wave * 32;
   const int q = q_wave + r;
   const bool wave_live = q_wave < N;
   const bool row_ok = q < N;
@@ -399,15 +437,19 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_x3_kernel(const AttnX3BwdP
   float *tab = reinterpret_cast<float *>(smem + 4 * IMG);
   const float *tabl = tab;
   if constexpr (TAB) {
-    const float inv_scale = 1.f / p.scale;
-    for (int i = t; i < (NKT - 1) * 225; i += 256) {
-      const int prow = i / 15, px = i - prow * 15;
-      tab[prow * 16 + (14 - px)] = p.table[(long long)i * H + h] * inv_scale;
-    }
     const int qz = q >> 6, qy = (q >> 3) & 7, qx = q & 7;
     tabl = tab + ((qz + NKT / 2 - 1) * 15 + qy + 7 - TAB_MAXC) * 16 + 7 - qx + 4 * hh;
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   }
+  auto load_table = [&](int hd) {                                   // (between two barriers: nobody reads the old table any more)
+    if constexpr (TAB) {
+      const float inv_scale = 1.f / p.scale;
+      for (int i = t; i < (NKT - 1) * 225; i += 64 * NW) {
+        const int prow = i / 15, px = i - prow * 15;
+        tab[prow * 16 + (14 - px)] = p.table[(long long)i * H + hd] * inv_scale;
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+  };
   auto init_c = [&](int kt, f32x16 &d) {
     if constexpr (TAB) {
 #pragma unroll
@@ -422,8 +464,9 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_x3_kernel(const AttnX3BwdP
   };
 
   const int dkey = lane >> 3;
-  const unsigned rowoff0 = (unsigned)((8 * wave + dkey) * tok_stride * 2);
-  const unsigned src_swz = (unsigned)(((lane & 7) ^ ((((dkey >> 1) & 1) << 2) | ((((wave & 1) << 1) | (dkey >> 2)) & 3))) * 16);
+  const int pw = wave & 3;                                          // the 8-row piece of a tile this wave stages (8 waves: 0..3 K, 4..7 V)
+  const unsigned rowoff0 = (unsigned)((8 * pw + dkey) * tok_stride * 2);
+  const unsigned src_swz = (unsigned)(((lane & 7) ^ ((((dkey >> 1) & 1) << 2) | ((((pw & 1) << 1) | (dkey >> 2)) & 3))) * 16);
   const unsigned voffK = rowoff0 + (unsigned)(1 * H * HD * 2) + src_swz;
   const unsigned voffV = rowoff0 + (unsigned)(2 * H * HD * 2) + src_swz;
   const unsigned lds0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(uintptr_t)(DM_LDS char *)smem);
@@ -441,13 +484,17 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_x3_kernel(const AttnX3BwdP
   };
   auto stage_all = [&](int b) {
     const i32x4 rh = sample_rsrc(p.hi, b), rl = sample_rsrc(p.lo, b);
-    const unsigned base = lds0 + (unsigned)wave * 1024u;
+    const unsigned base = lds0 + (unsigned)pw * 1024u;
 #pragma unroll
     for (int j = 0; j < NKT; ++j) {
-      lds_dma(rh, base + 0 * IMG + (unsigned)j * 4096u, voffK, (unsigned)j * step_bytes);
-      lds_dma(rl, base + 1 * IMG + (unsigned)j * 4096u, voffK, (unsigned)j * step_bytes);
-      lds_dma(rh, base + 2 * IMG + (unsigned)j * 4096u, voffV, (unsigned)j * step_bytes);
-      lds_dma(rl, base + 3 * IMG + (unsigned)j * 4096u, voffV, (unsigned)j * step_bytes);
+      if (NW == 4 || wave < 4) {
+        lds_dma(rh, base + 0 * IMG + (unsigned)j * 4096u, voffK, (unsigned)j * step_bytes);
+        lds_dma(rl, base + 1 * IMG + (unsigned)j * 4096u, voffK, (unsigned)j * step_bytes);
+      }
+      if (NW == 4 || wave >= 4) {
+        lds_dma(rh, base + 2 * IMG + (unsigned)j * 4096u, voffV, (unsigned)j * step_bytes);
+        lds_dma(rl, base + 3 * IMG + (unsigned)j * 4096u, voffV, (unsigned)j * step_bytes);
+      }
     }
   };
   const int xr = (((r >> 1) & 1) << 2) | ((r >> 2) & 3);
@@ -464,8 +511,10 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_x3_kernel(const AttnX3BwdP
       toff[dt][j2] = (8 * j2 + 4 * hh + qd) * 128 + (((4 * dt + 2 * ve + (pp >> 1)) ^ x) << 4) + 8 * (pp & 1);
     }
 
-  for (int b = b0; b < b1; ++b) {
+  for (int u = u0; u < u1; ++u) {
+    const int hu = u / p.B, b = u - hu * p.B;
     __builtin_amdgcn_s_barrier();
+    if (hu != h) { h = hu; load_table(h); }                         // (uniform: the first unit, or the run crossed into the next head)
     stage_all(b);
     // this lane's row: Q and dO fragments (hi / lo), delta = rowsum(dO . O) in fp32, -lse in log2 units
     u32x4 qh[4], ql[4], dh[4], dl[4];
@@ -529,15 +578,15 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_x3_kernel(const AttnX3BwdP
         }
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
-        qk_acc<true, false>(sc, kfh[ks], qh[ks]);
-        qk_acc<true, false>(sc, kfl[ks], qh[ks]);
-        qk_acc<true, false>(sc, kfh[ks], ql[ks]);
+        qk_acc<true, PAD>(sc, kfh[ks], qh[ks]);
+        qk_acc<true, PAD>(sc, kfl[ks], qh[ks]);
+        qk_acc<true, PAD>(sc, kfh[ks], ql[ks]);
       }
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
-        if (ks == 0) qk_first0<true, false>(dp, vfh[0], dh[0]); else qk_acc<true, false>(dp, vfh[ks], dh[ks]);
-        qk_acc<true, false>(dp, vfl[ks], dh[ks]);
-        qk_acc<true, false>(dp, vfh[ks], dl[ks]);
+        if (ks == 0) qk_first0<true, PAD>(dp, vfh[0], dh[0]); else qk_acc<true, PAD>(dp, vfh[ks], dh[ks]);
+        qk_acc<true, PAD>(dp, vfl[ks], dh[ks]);
+        qk_acc<true, PAD>(dp, vfh[ks], dl[ks]);
       }
       asm volatile("s_nop 15\n\ts_nop 7" : "+v"(sc), "+v"(dp)
                    : "v"(kfh[0]), "v"(kfh[1]), "v"(kfh[2]), "v"(kfh[3]), "v"(kfl[0]), "v"(kfl[1]), "v"(kfl[2]), "v"(kfl[3]),
@@ -556,9 +605,9 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_x3_kernel(const AttnX3BwdP
       for (int g = 0; g < 4; ++g) {
         const int sx = g >> 1, dt = g & 1;
         f32x16 &o = dt ? dq1 : dq0;
-        if (j == 0 && sx == 0) pv_first<false>(o, tfrag(tfh, 0, dt), dsh[0]); else pv_acc<false>(o, tfrag(tfh, sx, dt), dsh[sx]);
-        pv_acc<false>(o, tfrag(tfl, sx, dt), dsh[sx]);
-        pv_acc<false>(o, tfrag(tfh, sx, dt), dsl[sx]);
+        if (j == 0 && sx == 0) pv_first<PAD>(o, tfrag(tfh, 0, dt), dsh[0]); else pv_acc<PAD>(o, tfrag(tfh, sx, dt), dsh[sx]);
+        pv_acc<PAD>(o, tfrag(tfl, sx, dt), dsh[sx]);
+        pv_acc<PAD>(o, tfrag(tfh, sx, dt), dsl[sx]);
       }
       asm volatile("" :: "v"(tfh[0]), "v"(tfh[1]), "v"(tfh[2]), "v"(tfh[3]), "v"(tfh[4]), "v"(tfh[5]), "v"(tfh[6]), "v"(tfh[7]),
                    "v"(tfl[0]), "v"(tfl[1]), "v"(tfl[2]), "v"(tfl[3]), "v"(tfl[4]), "v"(tfl[5]), "v"(tfl[6]), "v"(tfl[7]),
@@ -860,16 +909,26 @@ inline void grid(int B, int N, int H, int &nblk, int &chunks, int &bchunk) {
   chunks = (B + bchunk - 1) / bchunk;
 }
 
-template <int NKT, bool RAGGED, bool TAB> bool launch_fwd(const AttnX3Params &p, hipStream_t s) {
+// DM_ATTN_X3_W8=0: the one-wave-per-SIMD forms of the forward / dQ kernels (A/B runs)
+inline bool x3_w8() {
+  static const bool on = [] { const char *e = getenv("DM_ATTN_X3_W8"); return !(e && atoi(e) == 0); }();
+  return on;
+}
+
+template <int NKT, bool RAGGED, bool TAB, int NW> bool launch_fwd_nw(const AttnX3Params &p, hipStream_t s) {
   constexpr int LDS = 4 * NKT * 32 * 128 + (TAB ? (NKT - 1) * 15 * 64 : 0);
   static_assert(LDS <= 160 * 1024, "LDS budget");
-  static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void *>(attn_fwd_x3_kernel<NKT, RAGGED, TAB>),
+  static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void *>(attn_fwd_x3_kernel<NKT, RAGGED, TAB, NW>),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS) == hipSuccess;
   if (!ok) return false;
   int nblk, chunks, bchunk;
   grid(p.B, p.N, p.H, nblk, chunks, bchunk);
-  hipLaunchKernelGGL((attn_fwd_x3_kernel<NKT, RAGGED, TAB>), dim3(grid_size(nblk, p.H, chunks)), dim3(256), LDS, s, p, bchunk, nblk, chunks);
+  const int wgs = NW == 8 ? (p.B * p.H < 256 ? p.B * p.H : 256) : grid_size(nblk, p.H, chunks);      // 8 waves: one run of units per CU
+  hipLaunchKernelGGL((attn_fwd_x3_kernel<NKT, RAGGED, TAB, NW>), dim3(wgs), dim3(64 * NW), LDS, s, p, bchunk, nblk, chunks);
   return true;
+}
+template <int NKT, bool RAGGED, bool TAB> bool launch_fwd(const AttnX3Params &p, hipStream_t s) {
+  return x3_w8() ? launch_fwd_nw<NKT, RAGGED, TAB, 8>(p, s) : launch_fwd_nw<NKT, RAGGED, TAB, 4>(p, s);
 }
 
 template <int NKT> bool launch_fwd_n(const AttnX3Params &p, hipStream_t s) {
@@ -881,15 +940,19 @@ template <int NKT> bool launch_fwd_n(const AttnX3Params &p, hipStream_t s) {
   return ragged ? launch_fwd<NKT, true, false>(p, s) : launch_fwd<NKT, false, false>(p, s);
 }
 
-template <int NKT, bool RAGGED, bool TAB> bool launch_dq(const AttnX3BwdParams &p, hipStream_t s) {
+template <int NKT, bool RAGGED, bool TAB, int NW> bool launch_dq_nw(const AttnX3BwdParams &p, hipStream_t s) {
   constexpr int LDS = 4 * NKT * 32 * 128 + (TAB ? (NKT - 1) * 15 * 64 : 0);
-  static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void *>(attn_bwd_dq_x3_kernel<NKT, RAGGED, TAB>),
+  static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void *>(attn_bwd_dq_x3_kernel<NKT, RAGGED, TAB, NW>),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS) == hipSuccess;
   if (!ok) return false;
   int nblk, chunks, bchunk;
   grid(p.B, p.N, p.H, nblk, chunks, bchunk);
-  hipLaunchKernelGGL((attn_bwd_dq_x3_kernel<NKT, RAGGED, TAB>), dim3(grid_size(nblk, p.H, chunks)), dim3(256), LDS, s, p, bchunk, nblk, chunks);
+  const int wgs = NW == 8 ? (p.B * p.H < 256 ? p.B * p.H : 256) : grid_size(nblk, p.H, chunks);
+  hipLaunchKernelGGL((attn_bwd_dq_x3_kernel<NKT, RAGGED, TAB, NW>), dim3(wgs), dim3(64 * NW), LDS, s, p, bchunk, nblk, chunks);
   return true;
+}
+template <int NKT, bool RAGGED, bool TAB> bool launch_dq(const AttnX3BwdParams &p, hipStream_t s) {
+  return x3_w8() ? launch_dq_nw<NKT, RAGGED, TAB, 8>(p, s) : launch_dq_nw<NKT, RAGGED, TAB, 4>(p, s);
 }
 
 template <int NKT> bool launch_dq_n(const AttnX3BwdParams &p, hipStream_t s) {
