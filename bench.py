@@ -415,15 +415,28 @@ def main():
     lib.dm_prof_enable(0)
     log(f"timed region: {args.steps} steps in {dt:.3f} s")
     prof_steps, prof_note = args.steps, "hipEvents around every launch of the timed region"
+
+    def collect():
+        rows = (_lib.DmProfRow * 256)()
+        n = lib.dm_prof_collect(rows, 256)
+        return {rows[i].name.decode(): (rows[i].launches, rows[i].total_ms, rows[i].total_flops, rows[i].total_bytes) for i in range(n)}
+    prof = None
     if use_graph:
-        # graph replays carry no per-kernel events: time the same kernels on the same stream in 3 eager steps right after
+        # graph replays carry no per-kernel events: time the same kernels on the same stream in eager steps right after.  Two passes
+        # of 3 steps, per kernel class the faster pass: one stalled launch (a 25 ms outlier was seen once on the shared pool) would
+        # otherwise name the wrong dominant class
         loss = loss.clone()
-        prof_steps, prof_note = 3, "hipEvents around every launch of 3 eager steps run right after the timed region (graph replays carry no events)"
-        lib.dm_prof_enable(1)
-        for _ in range(prof_steps):
-            trainer._eager_step(*batch)
-        torch.cuda.synchronize()
-        lib.dm_prof_enable(0)
+        prof_steps, prof_note = 3, ("hipEvents around every launch of 3 eager steps run right after the timed region (graph replays carry no "
+                                    "events); two such passes, per kernel class the faster one")
+        passes = []
+        for _ in range(2):
+            lib.dm_prof_enable(1)
+            for _ in range(prof_steps):
+                trainer._eager_step(*batch)
+            torch.cuda.synchronize()
+            lib.dm_prof_enable(0)
+            passes.append(collect())
+        prof = {k: min((p_[k] for p_ in passes if k in p_), key=lambda v: v[1]) for k in passes[0]}
     dp = None
     if world > 1 or force_dp:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -460,9 +473,8 @@ def main():
               "segmented_backward": bool(trainer.segmented), "graph_capture_error": trainer.graph_error,
               "bucket_dtype": "bf16" if trainer.compress_grads else "f32",
               "rehearsal_single_rank": bool(force_dp and world == 1)}
-    rows = (_lib.DmProfRow * 256)()
-    n = lib.dm_prof_collect(rows, 256)
-    prof = {rows[i].name.decode(): (rows[i].launches, rows[i].total_ms, rows[i].total_flops, rows[i].total_bytes) for i in range(n)}
+    if prof is None:
+        prof = collect()
 
     if rank == 0:
         flop_pair = pair_step_flops(scales, in_c, depth)
