@@ -1392,11 +1392,13 @@ class BlockFn(torch.autograd.Function):
                 return gemm(*a, ws_slot="gemm_side", **kw)
 
         def bias_grad(g2d, db, acc_b, direct):
-            """(operand for the two products that read the gradient g2d, kwargs that make the weight-gradient call produce db):
-            on plane pairs the column sums come from the split pass, otherwise they ride on the weight gradient."""
+            """(operand for the two products that read the gradient g2d, kwargs that make the weight-gradient call produce db).
+            The column sums always ride on the weight gradient -- of a plane pair: colsum(hi) + colsum(lo), whether the pair came
+            from its producer or from the split pass here, so the bias gradient does not depend on which of the two happened
+            (a segmented backward hands over plain tensors at its cuts)."""
             if planes and not isinstance(g2d, Planes):
-                return split_planes(g2d, colsum_out=db, colsum_accumulate=acc_b, defer=direct), {}
-            return g2d, dict(colsum_out=db, colsum_accumulate=acc_b)      # (a plane pair: colsum(hi) + colsum(lo), fused into the weight gradient)
+                g2d = split_planes(g2d)
+            return g2d, dict(colsum_out=db, colsum_accumulate=acc_b)
         dy, cs = bias_grad(dy, db2, _acc(P_fc2_b, k_b2), k_b2)
         wgrad(DM_TN, dy, h, dw2, Cc, Hd, M, lda=Cc, ldb=Hd, ldc=Hd, accumulate=_acc(P_fc2_w, k_w2), **cs)
         dpre = Planes(torch.empty((2, M, Hd), dtype=torch.bfloat16, device=dev)) if planes else torch.empty((M, Hd), dtype=dtype, device=dev)

@@ -497,15 +497,17 @@ def test_first_write_sink_contract_is_enforced():
             assert torch.isfinite(tr.step(*b))
 
 
-def test_segmented_graphs_equal_plain_step():
+@pytest.mark.parametrize("mode", ["bf16", "bf16x3"])
+def test_segmented_graphs_equal_plain_step(mode):
     """The data-parallel schedule on one process: backward in segments, one hipGraph per segment + one for Adam, buckets derived
-    from the cuts -- weights after 4 steps are bit-identical to the single-graph and to the eager step."""
+    from the cuts -- weights after 4 steps are bit-identical to the single-graph and to the eager step.  bf16x3: the plane pairs a
+    block hands to the next one do not cross a cut (the next segment splits the gradient itself): same bits either way."""
     from deepmerge_amd.trainer import PairTrainer
     tag = "v3_3s3c_642"
     cfg = MODEL_CASES[tag]
     left, ld, right, rd, flag = model_inputs(tag, cfg.scales, cfg.in_c, 4)
     b = ([t.to(DEV) for t in left], ld.to(DEV), [t.to(DEV) for t in right], rd.to(DEV), flag.to(DEV))
-    nets = [build_model(tag, "bf16")[1].train() for _ in range(4)]
+    nets = [build_model(tag, mode)[1].train() for _ in range(4)]
     eager = PairTrainer(nets[0], lr=1e-4)
     seg_eager = PairTrainer(nets[1], lr=1e-4, segmented=True)
     seg_graph = PairTrainer(nets[2], lr=1e-4, segmented=True)
