@@ -51,8 +51,12 @@ __device__ __forceinline__ void mma_pinned(f32x4 &acc, const u32x4 &a, const u32
 // EK: 0 = the generic fused epilogue (any operand combination, grouped rows); k > 0 = the lean epilogue with item structure key
 // k - 1 = RES | YL << 1 | C32 << 3 | XS << 4 (dm_gemm_common.h).  ONE epilogue per kernel instance: with two in one kernel the
 // accumulators meet in phi nodes behind them and the register allocator spills all 48 tiles around every tile end (tried).
-// FOLD: hi / lo plane pairs, the contraction runs over three segments of p.k_fold (GemmParams.k_fold): the K-step cursors carry the
-// byte offset of their step inside A and B (segment offset + in-segment step) instead of the step index times a constant.
+// FOLD ("bf16x3" products on hi / lo plane pairs, GemmParams.k_fold; the standard pattern A = (hi, hi, lo), B = (hi, lo, hi)): a K step
+// covers 32 contraction positions and stages BOTH pieces of both operands -- the 128-byte row of an LDS image is [32 hi | 32 lo]
+// (k-contiguous operands) resp. its k-rows 0..31 hi, 32..63 lo (m-contiguous ones), i.e. the images keep their format and only the
+// global addresses of the staged pieces change -- and runs THREE MFMA sets on them: hi.hi, hi.lo, lo.hi.  Per 64 contraction
+// positions that is 2 steps of staging for 6 MFMA sets where the generic folded form (three K segments, one MFMA set pair per step)
+// needs 3 steps: the staging / fragment traffic that bounds this kernel's step drops by a third.
 template <int LAYOUT, int DBG = 0, int EK = 0, bool FOLD = false>
 __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmParams p) {
   constexpr int EPIU = 0;
@@ -84,9 +88,12 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmParams p) {
   // tiles to the slab, dm_gemm's splitk_epilogue_kernel applies the fused epilogue)
   const bool sliced = AMM || p.split_k > 1;
   const int zslice = sliced ? L / tiles : 0;
+  constexpr int BKR = FOLD ? 32 : BK;                  // contraction positions per K step
+  const int k_total = FOLD ? p.k_fold : p.K;
   const int kbeg = sliced ? zslice * p.k_per_split : 0;
-  const int kend = sliced ? min(p.K, kbeg + p.k_per_split) : p.K;
-  const int ntile = (kend - kbeg) / BK;
+  const int kend = sliced ? min(k_total, kbeg + p.k_per_split) : k_total;
+  const int ntile = (kend - kbeg) / BKR;
+  const long long a_lo = FOLD ? p.a_fold[2] : 0, b_lo = FOLD ? p.b_fold[1] : 0;      // element offset of the lo plane behind the hi plane
   const int n_my = sliced ? 1 : (tiles - L + G - 1) / G;
   const int total = n_my * ntile;
 
@@ -96,26 +103,27 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmParams p) {
   const int lrow = t >> 3, lchunk = t & 7;
   const int wA = lrow * 128 + ((lchunk ^ (lrow & 7)) << 4);           // + u * 4096
   int voA, strideA, stepA, wA0, wA1;
+  // (FOLD: chunks 0..3 of a row come from the hi plane, 4..7 from the lo plane, 32 contraction positions each)
   if constexpr (!AMM) {
-    voA = (int)(((long long)lrow * p.lda + lchunk * 8) * 2);
+    voA = FOLD ? (int)(((long long)lrow * p.lda + (lchunk & 3) * 8 + (lchunk >= 4 ? a_lo : 0)) * 2) : (int)(((long long)lrow * p.lda + lchunk * 8) * 2);
     strideA = (int)(32 * p.lda * 2);
-    stepA = BK * 2;
+    stepA = BKR * 2;
     wA0 = wA1 = wA;
   } else {
     // m-contiguous A [K][M]: chunk c32 = t % 32 (8 rows of the tile) of k-row t / 32 + 8 u; image = 4 bands of [64 k-rows][64 m], as B below
     const int krow = t >> 5, c32 = t & 31, band = c32 >> 3, c8 = c32 & 7;
     voA = (int)(((long long)krow * p.lda + c32 * 8) * 2);
     strideA = (int)(8 * p.lda * 2);
-    stepA = (int)(BK * p.lda * 2);
+    stepA = (int)(BKR * p.lda * 2);
     const int f0 = (krow >> 1) & 1;
     wA0 = band * 8192 + krow * 128 + (((c8 >> 1) ^ f0) << 5) + ((c8 & 1) << 4);          // even u: + u * 1024
     wA1 = band * 8192 + krow * 128 + (((c8 >> 1) ^ (f0 | 2)) << 5) + ((c8 & 1) << 4);    // odd u
   }
   int voB, strideB, stepB, wB0, wB1;
   if constexpr (!BMM) {
-    voB = (int)(((long long)lrow * p.ldb + lchunk * 8) * 2);
+    voB = FOLD ? (int)(((long long)lrow * p.ldb + (lchunk & 3) * 8 + (lchunk >= 4 ? b_lo : 0)) * 2) : (int)(((long long)lrow * p.ldb + lchunk * 8) * 2);
     strideB = (int)(32 * p.ldb * 2);
-    stepB = BK * 2;
+    stepB = BKR * 2;
     wB0 = wB1 = wA;                                                   // + u * 4096
   } else {
     // m-contiguous operand [K][N]: threads 0..191 load chunk c24 = t % 24 (8 columns) of k-row t / 24 + 8 u.  LDS image = 3 bands of
@@ -123,7 +131,7 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmParams p) {
     const int krow = t / 24, c24 = t - krow * 24, band = c24 >> 3, c8 = c24 & 7;
     voB = (int)(((long long)krow * p.ldb + c24 * 8) * 2);
     strideB = (int)(8 * p.ldb * 2);
-    stepB = (int)(BK * p.ldb * 2);
+    stepB = (int)(BKR * p.ldb * 2);
     const int f0 = (krow >> 1) & 1;
     wB0 = band * 8192 + krow * 128 + (((c8 >> 1) ^ f0) << 5) + ((c8 & 1) << 4);          // even u: + u * 1024
     wB1 = band * 8192 + krow * 128 + (((c8 >> 1) ^ (f0 | 2)) << 5) + ((c8 & 1) << 4);    // odd u
@@ -170,25 +178,24 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmParams p) {
     m0 = tm * TM;
     n0 = (tid - tm * p.tiles_n) * TN;
   };
-  // (folded: the descriptor starts at the tile's first row / column of segment offset 0 and reaches to the end of the farthest
-  // segment -- rows past the operand's last one then still fall outside it in the farthest segment, i.e. never outside the plane pair)
-  const long long a_far = FOLD ? max(p.a_fold[0], max(p.a_fold[1], p.a_fold[2])) : 0, b_far = FOLD ? max(p.b_fold[0], max(p.b_fold[1], p.b_fold[2])) : 0;
+  // (FOLD: the descriptor also reaches over the lo plane's part of the panel -- rows past the operand's last one then still fall outside
+  // it in the lo plane, i.e. never outside the plane pair; in the hi plane they read other rows of the pair: outputs nobody stores)
   auto make_a = [&](int m0, bool live) __attribute__((always_inline)) {
     if constexpr (!AMM) {
-      const long long bytes = FOLD ? ((long long)(min(TM, p.M - m0) - 1) * p.lda + a_far + p.k_fold) * 2 : ((long long)(min(TM, p.M - m0) - 1) * p.lda + (kend - kbeg)) * 2;
-      return __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t *>(Ab + (long long)m0 * p.lda + (FOLD ? 0 : kbeg)), 0, live ? (int)min(bytes, 0x7fffffffLL) : 0, 0x00020000);
+      const long long bytes = ((long long)(min(TM, p.M - m0) - 1) * p.lda + (kend - kbeg) + a_lo) * 2;
+      return __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t *>(Ab + (long long)m0 * p.lda + kbeg), 0, live ? (int)min(bytes, 0x7fffffffLL) : 0, 0x00020000);
     } else {
-      const long long bytes = FOLD ? (a_far + (long long)(p.k_fold - 1) * p.lda + (p.M - m0)) * 2 : ((long long)(kend - kbeg - 1) * p.lda + (p.M - m0)) * 2;
-      return __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t *>(Ab + (FOLD ? 0LL : (long long)kbeg * p.lda) + m0), 0, live ? (int)min(bytes, 0x7fffffffLL) : 0, 0x00020000);
+      const long long bytes = ((long long)(kend - kbeg - 1) * p.lda + (p.M - m0) + a_lo) * 2;
+      return __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t *>(Ab + (long long)kbeg * p.lda + m0), 0, live ? (int)min(bytes, 0x7fffffffLL) : 0, 0x00020000);
     }
   };
   auto make_b = [&](int n0, bool live) __attribute__((always_inline)) {
     if constexpr (!BMM) {
-      const long long bytes = FOLD ? ((long long)(min(TN, p.N - n0) - 1) * p.ldb + b_far + p.k_fold) * 2 : ((long long)(min(TN, p.N - n0) - 1) * p.ldb + (kend - kbeg)) * 2;
-      return __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t *>(Bb + (long long)n0 * p.ldb + (FOLD ? 0 : kbeg)), 0, live ? (int)min(bytes, 0x7fffffffLL) : 0, 0x00020000);
+      const long long bytes = ((long long)(min(TN, p.N - n0) - 1) * p.ldb + (kend - kbeg) + b_lo) * 2;
+      return __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t *>(Bb + (long long)n0 * p.ldb + kbeg), 0, live ? (int)min(bytes, 0x7fffffffLL) : 0, 0x00020000);
     } else {
-      const long long bytes = FOLD ? (b_far + (long long)(p.k_fold - 1) * p.ldb + (p.N - n0)) * 2 : ((long long)(kend - kbeg - 1) * p.ldb + (p.N - n0)) * 2;
-      return __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t *>(Bb + (FOLD ? 0LL : (long long)kbeg * p.ldb) + n0), 0, live ? (int)min(bytes, 0x7fffffffLL) : 0, 0x00020000);
+      const long long bytes = ((long long)(kend - kbeg - 1) * p.ldb + (p.N - n0) + b_lo) * 2;
+      return __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t *>(Bb + (long long)kbeg * p.ldb + n0), 0, live ? (int)min(bytes, 0x7fffffffLL) : 0, 0x00020000);
     }
   };
   int m_cur, n_cur;
@@ -204,29 +211,8 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmParams p) {
   // over the WHOLE step instead of two per row tile over half of it.  Two load cursors (one per group); past the end of the
   // sequence: null descriptors, the loads return zeros.
   constexpr int PH = (8 + NB) / 2;
-  struct Cursor { int r, k, ka, kb, left; };      // ka / kb: byte offset of the step in A / B; left: steps to the end of its K segment (FOLD)
-  const int seg_steps = FOLD ? p.k_fold / BK : 1;
-  auto fold_seek = [&](Cursor &c) __attribute__((always_inline)) {      // position ka / kb / left at the cursor's K step
-    if constexpr (FOLD) {
-      const int tg = kbeg / BK + c.k;
-      const int seg = (tg >= 2 * seg_steps) ? 2 : (tg >= seg_steps) ? 1 : 0;
-      const int kk = tg - seg * seg_steps;
-      const long long oa = seg == 0 ? p.a_fold[0] : seg == 1 ? p.a_fold[1] : p.a_fold[2];
-      const long long ob = seg == 0 ? p.b_fold[0] : seg == 1 ? p.b_fold[1] : p.b_fold[2];
-      c.ka = (int)(oa * 2) + kk * stepA;
-      c.kb = (int)(ob * 2) + kk * stepB;
-      c.left = seg_steps - kk;
-    }
-  };
-  auto fold_next = [&](Cursor &c) __attribute__((always_inline)) {      // after ++c.k inside a tile
-    if constexpr (FOLD) {
-      if (--c.left == 0) fold_seek(c);
-      else { c.ka += stepA; c.kb += stepB; }
-    }
-  };
-  Cursor cx{0, 0, 0, 0, 0}, cy{0, 0, 0, 0, 0};
-  fold_seek(cx);
-  cy = cx;
+  struct Cursor { int r, k; };
+  Cursor cx{0, 0}, cy{0, 0};
   __amdgpu_buffer_rsrc_t rsAx = make_a(m_cur, true), rsBx = make_b(n_cur, true), rsAy = rsAx, rsBy = rsBx;
   auto advance_x = [&]() __attribute__((always_inline)) {
     if (++cx.k == ntile) {
@@ -236,9 +222,6 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmParams p) {
       if (live) tile_mn(cx.r, m0, n0);
       rsAx = make_a(m0, live);
       rsBx = make_b(n0, live);
-      fold_seek(cx);
-    } else {
-      fold_next(cx);
     }
   };
   auto advance_y = [&]() __attribute__((always_inline)) {
@@ -249,9 +232,6 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmParams p) {
       if (live) tile_mn(cy.r, m0, n0);
       rsAy = make_a(m0, live);
       rsBy = make_b(n0, live);
-      fold_seek(cy);
-    } else {
-      fold_next(cy);
     }
   };
 
@@ -272,9 +252,13 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmParams p) {
     constexpr int set = decltype(set_tag)::value;
     constexpr bool GX = decltype(grp_tag)::value == 0;
     const int k = GX ? cx.k : cy.k;
-    const int ka = FOLD ? (GX ? cx.ka : cy.ka) : k * stepA, kb = FOLD ? (GX ? cx.kb : cy.kb) : k * stepB;
-    if (q < 8) ga[set][q] = __builtin_amdgcn_raw_buffer_load_b128(GX ? rsAx : rsAy, voA, ka + q * strideA, 0);
-    else if (b_loader) gb[set][q - 8] = __builtin_amdgcn_raw_buffer_load_b128(GX ? rsBx : rsBy, voB, kb + (q - 8) * strideB, 0);
+    // (FOLD, m-contiguous operands: pieces 0..3 are the hi plane's k-rows, 4..7 the lo plane's rows of the same 32 positions; the
+    // k-contiguous ones carry the plane in their per-thread offset)
+    const int u = q - 8;
+    const int pa = (FOLD && AMM) ? (q & 3) * strideA + (q >= 4 ? (int)(a_lo * 2) : 0) : q * strideA;
+    const int pb = (FOLD && BMM) ? (u & 3) * strideB + (u >= 4 ? (int)(b_lo * 2) : 0) : u * strideB;
+    if (q < 8) ga[set][q] = __builtin_amdgcn_raw_buffer_load_b128(GX ? rsAx : rsAy, voA, k * stepA + pa, 0);
+    else if (b_loader) gb[set][q - 8] = __builtin_amdgcn_raw_buffer_load_b128(GX ? rsBx : rsBy, voB, k * stepB + pb, 0);
   };
   // piece q: register set -> LDS buffer
   auto lwrite = [&](auto set_tag, auto buf_tag, int q) __attribute__((always_inline)) {
@@ -329,18 +313,20 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmParams p) {
       return (u32x4){lo[0], lo[1], hi[0], hi[1]};
     }
   };
-  auto load_b1 = [&](int j, auto ks_tag, auto buf_tag) __attribute__((always_inline)) {
-    constexpr int ks = decltype(ks_tag)::value;
+  // B fragment of column tile j, k-step ks of LDS buffer buf, into fragment set dst
+  auto load_bx = [&](int j, auto ks_tag, auto buf_tag, auto dst_tag) __attribute__((always_inline)) {
+    constexpr int ks = decltype(ks_tag)::value, dst = decltype(dst_tag)::value;
     if constexpr (DBG & 16) return;
     const char *b = smem + decltype(buf_tag)::value * BUF_BYTES + A_BYTES;
     if constexpr (!BMM) {
-      fb[ks][j] = *reinterpret_cast<const u32x4 *>(b + j * 2048 + offB[ks]);
+      fb[dst][j] = *reinterpret_cast<const u32x4 *>(b + j * 2048 + offB[ks]);
     } else {
       const u32x2 lo = dm_ds_read_tr16(b + offB[j] + ks * 4096);
       const u32x2 hi = dm_ds_read_tr16(b + offB[j] + ks * 4096 + 512);
-      fb[ks][j] = (u32x4){lo[0], lo[1], hi[0], hi[1]};
+      fb[dst][j] = (u32x4){lo[0], lo[1], hi[0], hi[1]};
     }
   };
+  auto load_b1 = [&](int j, auto ks_tag, auto buf_tag) __attribute__((always_inline)) { load_bx(j, ks_tag, buf_tag, ks_tag); };
   // 48 MFMAs of k-step KS, row tile by row tile.  A wave issues in order, so everything else is placed BETWEEN the MFMAs (one
   // piece after each, scheduling fences in between): the matrix pipe takes 16 cycles per MFMA, the pieces fit in its shadow.
   //   after MFMA 0: read the row tile's A fragment of the NEXT k-step (NKS of buffer NBUF; it replaces fa[i] after the row)
@@ -350,7 +336,6 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmParams p) {
   auto mm = [&](f32x4 &c, const u32x4 &a, const u32x4 &b) __attribute__((always_inline)) {
     if constexpr (!(DBG & 32)) mma_pinned(c, a, b);
   };
-  bool cs_seg = true;      // folded contraction: does the K step in progress count in A's column sums (dm_fold_counts)
   auto mfmas = [&](auto ks_tag, auto nks_tag, auto nbuf_tag, auto grp_tag, auto sset_tag, auto sbuf_tag) __attribute__((always_inline)) {
     constexpr int ks = decltype(ks_tag)::value;
     constexpr int q0 = decltype(grp_tag)::value == 0 ? 0 : PH;
@@ -372,7 +357,7 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmParams p) {
       mm(acc[i][5], fa[i], fb[ks][5]);
       if (i < 6) load_b1(i, nks_tag, nbuf_tag);
       if constexpr (AMM) {
-        if (colsum && wn == ks && cs_seg) {
+        if (colsum && wn == ks) {
           mm(accb[i], fa[i], ones);
         }
       }
@@ -380,6 +365,46 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmParams p) {
       __builtin_amdgcn_sched_barrier(0);
     }
     if constexpr (decltype(grp_tag)::value == 0) advance_x(); else advance_y();
+  };
+
+  // FOLD: one MFMA set of the three of a K step: 48 MFMAs of the A fragments in fa (hi or lo piece) with fragment set FB of B.
+  //   ANX:  after MFMA 0 of a row tile, read the A fragment that replaces fa[i] after the row (k-step AKS of buffer ABUF), or nothing;
+  //   GRP:  staging group (0 = X, 1 = Y, -1 = none) moved register set SSET -> LDS buffer SBUF after MFMA 2 and refilled after MFMA 3;
+  //   BNX:  after MFMA 5, B fragment i of k-step BKS of buffer BBUF into fragment set BDST, or nothing;
+  //   CSW:  the waves wn == CSW add this set's A piece to the column sums (weight gradients), -1 = nobody.
+  auto mfmas3 = [&](auto fb_tag, auto anx_tag, auto aks_tag, auto abuf_tag, auto grp_tag, auto sset_tag, auto sbuf_tag, auto bnx_tag, auto bks_tag,
+                    auto bbuf_tag, auto bdst_tag, auto csw_tag) __attribute__((always_inline)) {
+    constexpr int FB = decltype(fb_tag)::value, GRP = decltype(grp_tag)::value, CSW = decltype(csw_tag)::value;
+    constexpr bool ANX = decltype(anx_tag)::value != 0, BNX = decltype(bnx_tag)::value != 0;
+    constexpr int q0 = GRP == 1 ? PH : 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      mm(acc[i][0], fa[i], fb[FB][0]);
+      u32x4 na = fa[i];
+      if constexpr (ANX) na = read_a(i, aks_tag, abuf_tag);
+      __builtin_amdgcn_sched_barrier(0);
+      mm(acc[i][1], fa[i], fb[FB][1]);
+      __builtin_amdgcn_sched_barrier(0);
+      mm(acc[i][2], fa[i], fb[FB][2]);
+      if constexpr (GRP >= 0) { if (i < PH) lwrite(sset_tag, sbuf_tag, q0 + i); }
+      __builtin_amdgcn_sched_barrier(0);
+      mm(acc[i][3], fa[i], fb[FB][3]);
+      if constexpr (GRP >= 0) { if (i < PH) gload(sset_tag, IC<(GRP > 0 ? 1 : 0)>{}, q0 + i); }
+      __builtin_amdgcn_sched_barrier(0);
+      mm(acc[i][4], fa[i], fb[FB][4]);
+      __builtin_amdgcn_sched_barrier(0);
+      mm(acc[i][5], fa[i], fb[FB][5]);
+      if constexpr (BNX) { if (i < 6) load_bx(i, bks_tag, bbuf_tag, bdst_tag); }
+      if constexpr (AMM && CSW >= 0) {
+        if (colsum && wn == CSW) {
+          mm(accb[i], fa[i], ones);
+        }
+      }
+      if constexpr (ANX) fa[i] = na;
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if constexpr (GRP == 0) advance_x();
+    if constexpr (GRP == 1) advance_y();
   };
 
   int kt = 0, r = 0;
@@ -659,11 +684,23 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmParams p) {
   // the freed set then fetches step s + 3.
   auto body = [&](auto par_tag) __attribute__((always_inline)) {
     constexpr int PAR = decltype(par_tag)::value;
-    if constexpr (FOLD && AMM) cs_seg = dm_fold_counts(p, kbeg + (kt + PAR) * BK);
     mfmas(IC<0>{}, IC<1>{}, IC<PAR>{}, IC<1>{}, IC<1 - PAR>{}, IC<1 - PAR>{});     // k-step 0 (+ fragments of k-step 1; group Y of step s + 1)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     mfmas(IC<1>{}, IC<0>{}, IC<1 - PAR>{}, IC<0>{}, IC<PAR>{}, IC<PAR>{});         // k-step 1 (+ fragments of step s + 1; group X of step s + 2)
+  };
+
+  // FOLD: one K step (32 contraction positions, both pieces of both operands).  PAR = step & 1 = its LDS buffer AND the fragment set that
+  // holds its B hi piece (the lo piece sits in set 1 - PAR: the roles alternate, so the next step's hi fragments can load while this
+  // step's are still in use).  hi.hi [B lo fragments; group Y of step s + 1 -> buffer 1 - PAR] | hi.lo [A lo fragments] | barrier |
+  // lo.hi [fragments of step s + 1; group X of step s + 2 -> buffer PAR].
+  auto body3 = [&](auto par_tag) __attribute__((always_inline)) {
+    constexpr int PAR = decltype(par_tag)::value;
+    mfmas3(IC<PAR>{}, IC<0>{}, IC<0>{}, IC<0>{}, IC<1>{}, IC<1 - PAR>{}, IC<1 - PAR>{}, IC<1>{}, IC<1>{}, IC<PAR>{}, IC<1 - PAR>{}, IC<0>{});
+    mfmas3(IC<1 - PAR>{}, IC<1>{}, IC<1>{}, IC<PAR>{}, IC<-1>{}, IC<0>{}, IC<0>{}, IC<0>{}, IC<0>{}, IC<0>{}, IC<0>{}, IC<-1>{});
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    mfmas3(IC<PAR>{}, IC<1>{}, IC<0>{}, IC<1 - PAR>{}, IC<0>{}, IC<PAR>{}, IC<PAR>{}, IC<1>{}, IC<0>{}, IC<1 - PAR>{}, IC<1 - PAR>{}, IC<1>{});
   };
 
   // ---- prologue: the state the schedule above expects at step 0 (buffer 0 complete, X(1) in buffer 1, Y(1) / X(2) / Y(2) / X(3) in flight) ----
@@ -698,8 +735,8 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmParams p) {
   // K % 128 == 0 (plan): a tile is an even number of K steps, so tiles end after an odd step only
   for (int step = 0; step < total; step += 2) {
     if constexpr (!AMM) { if (kt + 2 == ntile && p.split_k <= 1) touch_epilogue_operands(); }
-    body(IC<0>{});
-    body(IC<1>{});
+    if constexpr (FOLD) { body3(IC<0>{}); body3(IC<1>{}); }
+    else { body(IC<0>{}); body(IC<1>{}); }
     kt += 2;
     if (kt == ntile) {
       if constexpr (DBG & 1) { kt = 0; ++r; if (r < n_my) tile_mn(r, m_cur, n_cur); } else
@@ -745,8 +782,14 @@ int dm_gemm_w4_plan(GemmParams &p, int layout, int ab_dtype, bool aligned8, bool
   const char *env = getenv("DM_GEMM_W4");         // 0 = off, 1 = routing rule, 2 = every legal product, 3 = every whole-round shape (read per call: tests flip it)
   const int mode = env ? atoi(env) : 1;
   if (mode == 0 || ab_dtype != DM_BF16 || !aligned8) return 0;
-  if (p.k_fold > 0) {      // folded contraction: the FOLD instances (K segments of whole K steps; a tile is an even number of steps as ever)
-    if (p.k_fold % BK != 0) return 0;
+  // FOLD instances: K steps of 32 contraction positions on both pieces of both operands (see the kernel): the standard plane-pair
+  // pattern only -- left operand (hi, hi, lo), right operand (hi, lo, hi) -- and an even number of steps per tile
+  const bool fold = p.k_fold > 0;
+  const int k_eff = fold ? p.k_fold : p.K, bk_eff = fold ? 32 : BK;
+  if (fold) {
+    if (p.k_fold % (2 * bk_eff) != 0) return 0;
+    if (p.a_fold[0] != 0 || p.a_fold[1] != 0 || p.a_fold[2] <= 0 || p.b_fold[0] != 0 || p.b_fold[2] != 0 || p.b_fold[1] <= 0) return 0;
+    if (p.a_fold[2] * 2 >= (1LL << 30) || p.b_fold[1] * 2 >= (1LL << 30)) return 0;      // (byte offsets live in 32-bit lane offsets)
     static const bool attr_fold = w4_set_lds_limit<DM_TN, 0, 0, true>() && w4_set_lds_limit<DM_TN, 0, 9, true>() && w4_set_lds_limit<DM_TN, 0, 11, true>() &&
                                   w4_set_lds_limit<DM_NT, 0, 0, true>() && w4_set_lds_limit<DM_NT, 0, 10, true>() && w4_set_lds_limit<DM_NN, 0, 0, true>();
     if (!attr_fold) return 0;
@@ -755,13 +798,13 @@ int dm_gemm_w4_plan(GemmParams &p, int layout, int ab_dtype, bool aligned8, bool
     // wgrad: one (256 x 192 tile, K slice) per workgroup; slices of an even number of K steps chosen so that tiles x slices fills the CUs
     const char *tenv = getenv("DM_GEMM_W4_TN");     // 0 = off, 1 = routing rule (default), 2 = every legal product
     const int tmode = tenv ? atoi(tenv) : 1;
-    if (tmode == 0 || p.M % TM != 0 || p.N % TN != 0 || p.K % (2 * BK) != 0 || p.M % 8 != 0 || p.N % 8 != 0) return 0;
+    if (tmode == 0 || p.M % TM != 0 || p.N % TN != 0 || k_eff % (2 * bk_eff) != 0 || p.M % 8 != 0 || p.N % 8 != 0) return 0;
     if (!can_split || p.c_dtype != DM_F32) return 0;
-    if ((long long)p.K * p.lda * 2 >= (1LL << 31) || (long long)p.K * p.ldb * 2 >= (1LL << 31)) return 0;
+    if (((long long)k_eff * p.lda + (fold ? p.a_fold[2] : 0)) * 2 >= (1LL << 31) || ((long long)k_eff * p.ldb + (fold ? p.b_fold[1] : 0)) * 2 >= (1LL << 31)) return 0;
     const int cus = w4_cu_count();
     const long long tiles = (long long)(p.M / TM) * (p.N / TN);
     if (cus <= 0 || tiles > cus) return 0;
-    const int steps = p.K / BK;
+    const int steps = k_eff / bk_eff;
     int split = (int)(cus / tiles);
     if (split > 16) split = 16;
     int per = (steps + split - 1) / split;
@@ -775,19 +818,19 @@ int dm_gemm_w4_plan(GemmParams &p, int layout, int ab_dtype, bool aligned8, bool
     if (split > 1 && (long long)split * p.M * p.N * 4 > workspace_bytes) return 0;
     // in-step per launch (tools/prof_shapes.py): K = 16384: 100 -> 84, 92 -> 83, 80 -> 67, 41 -> 38 us; K = 4096 with 48 tiles x 4 slices:
     // 26 -> 24 us; fewer workgroups than 0.7 of the CUs, or the 1024-token stage, lose
-    if (tmode == 1 && ((double)(tiles * split) / cus < 0.7 || tiles < 12 || (tiles < 24 && p.K < 8192))) return 0;
+    if (tmode == 1 && ((double)(tiles * split) / cus < 0.7 || tiles < 12 || (tiles < 24 && k_eff < 8192))) return 0;
     static const bool attr_tn = w4_set_lds_limit<DM_TN>() && w4_set_lds_limit<DM_TN, 0, 9>() && w4_set_lds_limit<DM_TN, 0, 11>();
     if (!attr_tn) return 0;
     p.tiles_m = p.M / TM;
     p.tiles_n = p.N / TN;
     p.split_k = split;
-    p.k_per_split = per * BK;
+    p.k_per_split = per * bk_eff;       // (FOLD: in contraction positions of ONE piece)
     return (int)(tiles * split);
   }
   if (layout != DM_NT && layout != DM_NN) return 0;
-  if (p.K < 2 * BK || p.K % (2 * BK) != 0 || p.N % TN != 0) return 0;
-  const long long spanA = 256LL * p.lda * 2 + 2LL * p.K;
-  const long long spanB = (layout == DM_NN) ? (long long)p.K * p.ldb * 2 : 192LL * p.ldb * 2 + 2LL * p.K;
+  if (k_eff < 2 * bk_eff || k_eff % (2 * bk_eff) != 0 || p.N % TN != 0) return 0;
+  const long long spanA = 256LL * p.lda * 2 + 2LL * k_eff + (fold ? 2 * p.a_fold[2] : 0);
+  const long long spanB = ((layout == DM_NN) ? (long long)k_eff * p.ldb * 2 : 192LL * p.ldb * 2 + 2LL * k_eff) + (fold ? 2 * p.b_fold[1] : 0);
   if (spanA >= (1LL << 31) || spanB >= (1LL << 31)) return 0;
   const int tiles_m = (p.M + TM - 1) / TM, tiles_n = p.N / TN;
   const long long tiles = (long long)tiles_m * tiles_n;

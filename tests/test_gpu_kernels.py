@@ -1121,7 +1121,11 @@ def test_folded_split_product_equals_the_image_product(layout, M, N, K, family, 
         with ops.fp32_products("bf16x3"):
             ops.gemm(lay, A, B, C_, M, N, K, **kw)
         outs.append(C_)
-    assert torch.equal(outs[0], outs[1])
+    if family == "w4":      # the 4-wave kernel's folded form sums hi.hi + hi.lo + lo.hi per 32 contraction positions (one staging of both
+        # pieces for three MFMA sets), not segment after segment: same terms, another fp32 summation order
+        assert ((outs[0].double() - outs[1].double()).abs().max() / ref.abs().max()).item() < 1e-5
+    else:
+        assert torch.equal(outs[0], outs[1])
     assert ((outs[1].double() - ref).abs().max() / ref.abs().max()).item() < 3e-5
     # a plane pair made once serves both sides and every layout: A as the left operand here, then as the right operand of a weight gradient
     monkeypatch.setattr(ops, "_PLANES", True)
