@@ -428,10 +428,12 @@ def test_attention_relpos_table_in_kernel(scales, B, H):
     assert torch.equal(d_tab, d_tab2) and torch.equal(dt_tab, dt_tab2)          # run-to-run deterministic (no atomics anywhere)
 
 
-@pytest.mark.parametrize("N,scales,B,H", [(256, 4, 8, 12), (192, 3, 9, 12), (197, 0, 10, 12), (160, 0, 7, 5), (224, 0, 3, 4), (256, 0, 5, 3)])
+@pytest.mark.parametrize("N,scales,B,H", [(256, 4, 8, 12), (192, 3, 9, 12), (197, 0, 10, 12), (160, 0, 7, 5), (224, 0, 3, 4), (256, 0, 5, 3),
+                                         (256, 4, 24, 12), (192, 3, 30, 12)])
 def test_attention_split_forward_backward(N, scales, B, H):
     """dm_attention_split_fwd (the bf16x3 mode's attention): fp32 tensors, every product a split-bf16 triple on the matrix pipe, the
-    bias from the table in LDS (scales > 0) or none (ragged N allowed).  Against fp64: the error must be at the fp32 kernels' level
+    bias from the table in LDS (scales > 0) or none (ragged N allowed; the last two cases have more (head, sample) units than CUs: the
+    8-wave forward / dQ kernels then walk runs of units that cross head boundaries and reload the table).  Against fp64: the error must be at the fp32 kernels' level
     (1e-5-ish), nowhere near bf16's 1e-2.  Reference: nets/ShfitScaleFormer.py:119-133 / vit_model.py:119-133 in fp32."""
     from oracle import s2former as O
     ops = _ops()
