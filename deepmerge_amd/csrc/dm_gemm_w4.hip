@@ -24,6 +24,16 @@
 #include "dm_gemm_common.h"
 #include "dm_mfma.h"
 
+// -DDM_W4_STAMP (diagnostic build, tools/w4_stamps.py): wave 0 of the first 64 workgroups stamps s_memtime at six points of its K steps
+// 8 .. 23 of the folded form's three-set step into a __device__ array
+#ifdef DM_W4_STAMP
+__device__ unsigned long long dmw4_stamps[64 * 16 * 8];
+#define DMW4_T(i) do { if (wave == 0 && lane == 0 && blockIdx.x < 64 && sstep >= 8 && sstep < 24) dmw4_stamps[(blockIdx.x * 16 + (sstep - 8)) * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+extern "C" int dm_debug_w4_stamps(unsigned long long *out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(dmw4_stamps), sizeof(dmw4_stamps)); }
+#else
+#define DMW4_T(i) do { } while (0)
+#endif
+
 namespace dmw4 {
 
 constexpr int TM = 256, TN = 192, BK = 64;
@@ -174,6 +184,10 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmParams p) {
   const bf16_t *Ab = reinterpret_cast<const bf16_t *>(p.A), *Bb = reinterpret_cast<const bf16_t *>(p.B);
   auto tile_mn = [&](int r, int &m0, int &n0) __attribute__((always_inline)) {
     const int tid = (DBG & 64) ? (L & 7) : sliced ? L - zslice * tiles : L + r * G;        // (ablation 64: every workgroup reads the same few L2-resident tiles)
+    // (A BLOCKED order -- column blocks of 8 tiles walked row by row, an XCD keeping its own chunk over the rounds, so that its 32
+    // workgroups share 4 panels of A and 8 of B instead of 2 and 16 -- was measured in round 4: 16384 x 3072 x 768 on 4 rounds 103 -> 97 us,
+    // x 2304 on 3 rounds 80 -> 77 us, the sliced weight gradients unchanged; the multi-round products still lose to the kernels with 2-3
+    // workgroups per CU inside the step (qkv forward 85 vs 77 us per launch), so the row-major order stayed.)
     const int tm = tid / p.tiles_n;
     m0 = tm * TM;
     n0 = (tid - tm * p.tiles_n) * TN;
@@ -694,13 +708,28 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmParams p) {
   // holds its B hi piece (the lo piece sits in set 1 - PAR: the roles alternate, so the next step's hi fragments can load while this
   // step's are still in use).  hi.hi [B lo fragments; group Y of step s + 1 -> buffer 1 - PAR] | hi.lo [A lo fragments] | barrier |
   // lo.hi [fragments of step s + 1; group X of step s + 2 -> buffer PAR].
+  // s_memtime stamps of the three sets (tools/w4_stamps.py, -DDM_W4_STAMP; weight gradient 768 x 3072 x 3*16384, cycles per set for 768
+  // cycles of MFMAs): 1780 / 972 / 1492, + 330 for the wait and the barrier; with BOTH staging groups in front of the barrier (buffer
+  // 1 - PAR is free from the previous barrier on) 1440 / 1452 / 1244: a staging group costs ~500-700 cycles wherever it sits, the 14
+  // transposed fragment reads of the next step ~450 -- moving the pieces does not shorten the step.  It is not the LDS array either
+  // (tools/pmc_gemm_lds.sh: SQ_LDS_IDX_ACTIVE 22 % of the kernel's cycles per CU, bank conflicts 1 % of those); what the counters do
+  // show is the operand delivery: L2 hit rates of 73 / 75 / 80 % (profiles/r04_gemm_attn_mfma_util.md) are exactly 1 - (panels an XCD's 32
+  // workgroups share) / (panels they load) for 2 x 16, 2 x 16 and 8 x 4 tiles per XCD, i.e. every fourth or fifth line comes from the
+  // fabric at less than half the L2's rate per CU (MI355X_MICROARCH.md 'Indexed rows': 33 vs 70 GB/s per CU).
   auto body3 = [&](auto par_tag) __attribute__((always_inline)) {
     constexpr int PAR = decltype(par_tag)::value;
+    [[maybe_unused]] const int sstep = kt + PAR;
+    DMW4_T(0);
     mfmas3(IC<PAR>{}, IC<0>{}, IC<0>{}, IC<0>{}, IC<1>{}, IC<1 - PAR>{}, IC<1 - PAR>{}, IC<1>{}, IC<1>{}, IC<PAR>{}, IC<1 - PAR>{}, IC<0>{});
+    DMW4_T(1);
     mfmas3(IC<1 - PAR>{}, IC<1>{}, IC<1>{}, IC<PAR>{}, IC<-1>{}, IC<0>{}, IC<0>{}, IC<0>{}, IC<0>{}, IC<0>{}, IC<0>{}, IC<-1>{});
+    DMW4_T(2);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    DMW4_T(3);
     __builtin_amdgcn_s_barrier();
+    DMW4_T(4);
     mfmas3(IC<PAR>{}, IC<1>{}, IC<0>{}, IC<1 - PAR>{}, IC<0>{}, IC<PAR>{}, IC<PAR>{}, IC<1>{}, IC<0>{}, IC<1 - PAR>{}, IC<1 - PAR>{}, IC<1>{});
+    DMW4_T(5);
   };
 
   // ---- prologue: the state the schedule above expects at step 0 (buffer 0 complete, X(1) in buffer 1, Y(1) / X(2) / Y(2) / X(3) in flight) ----
