@@ -16,7 +16,7 @@ class Loss(nn.Module):
         self.margin, self.lamda, self.belta = margin, lamda, belta   # lamda / belta unused upstream too
 
     def forward(self, positive, negative, flag, size_average=True):
-        return ops.ContrastiveLossFn.apply(positive, negative, flag, float(self.margin))
+        return ops.contrastive_loss(positive, negative, flag, float(self.margin))
 
 
 class MultiLoss(nn.Module):
@@ -28,7 +28,7 @@ class MultiLoss(nn.Module):
         return ops.CrossEntropyFn.apply(inputs, targets)
 
     def forward(self, positive, negative, flag, left_logits, left_one_hot, right_logits, right_one_hot, size_average=True):
-        c = ops.ContrastiveLossFn.apply(positive, negative, flag, float(self.margin))
+        c = ops.contrastive_loss(positive, negative, flag, float(self.margin))
         return 0.7 * c + 0.15 * self.Loss_Class(left_logits, left_one_hot) + 0.15 * self.Loss_Class(right_logits, right_one_hot)
 
 

@@ -370,7 +370,7 @@ class ShfitScaleFormer_v3(nn.Module):
                 f = self.forward_once_design_feature(both, torch.cat((x1_designed_features, x2_designed_features), 0))
             else:
                 f = self.forward_once(both)
-            return f[:B], f[B:]
+            return ops.split_halves(f)
         if self.is_designed_feature_embedding:
             return self.forward_once_design_feature(x1_patches, x1_designed_features)
         return self.forward_once(x1_patches)
@@ -384,7 +384,7 @@ class ShfitScaleFormer_v3(nn.Module):
             f = self.forward_once_design_feature(both_patches, both_designed)
         else:
             f = self.forward_once(both_patches)
-        return f[:B], f[B:]
+        return ops.split_halves(f)
 
     def _init_weights(self, m):
         if isinstance(m, nn.Linear):
@@ -686,7 +686,7 @@ class _SingleStage(nn.Module):
             f = self.forward_once_design_feature(both, torch.cat((d1, d2), 0))
         else:
             f = self.forward_once(both)
-        return f[:B], f[B:]
+        return ops.split_halves(f)
 
 
 class ShfitScaleFormer(_SingleStage):
@@ -801,4 +801,4 @@ class ShfitScaleFormer_v6(_SingleStage):
             raise TypeError("ShfitScaleFormer_v6 needs designed features (upstream raises here too, :1549)")
         B = x1_designed_features.shape[0]
         f = self.forward_once_design_feature(None, torch.cat((x1_designed_features, x2_designed_features), 0))
-        return f[:B], f[B:]
+        return ops.split_halves(f)

@@ -889,10 +889,13 @@ class PatchEmbedCatFn(torch.autograd.Function):
         cols, ws = saved[:S], saved[S:]
         weights, biases = ctx.params
         grads_w, grads_b = [], []
+        # every scale's gradient rows in the operands' dtype, [S, B * T, C]: ONE strided cast-copy for all scales when they share a dtype
+        same = all(c.dtype == cols[0].dtype for c in cols)
+        dys = torch.empty((S, B, T, Cc), dtype=cols[0].dtype, device=dcube.device).copy_(dcube.contiguous().view(B, S, T, Cc).transpose(0, 1)) if same else None
         for i in range(S):
             c = cols[i]
             K = c.shape[1]
-            dy = dcube[:, i * T:(i + 1) * T, :].to(c.dtype).reshape(B * T, Cc)      # one strided cast-copy
+            dy = dys[i].view(B * T, Cc) if same else dcube[:, i * T:(i + 1) * T, :].to(c.dtype).reshape(B * T, Cc)
             need_w, need_b = ctx.needs_input_grad[2 + S + i], ctx.needs_input_grad[2 + 2 * S + i]
             _, dw, db = _linear_backward(c, ws[i], dy, False, need_w, need_b and biases[i] is not None, weights[i].shape, weights[i], biases[i])
             grads_w.append(dw)
@@ -1157,7 +1160,76 @@ class ContrastiveLossFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         da, db = ctx.saved_tensors
+        if is_unit_grad(g):
+            return da, db, None, None
         return da * g, db * g, None, None
+
+
+_unit_grads = {}
+
+
+def unit_grad(device) -> torch.Tensor:
+    """The scalar 1.0 on `device`, one tensor per device for the life of the process: `loss.backward(ops.unit_grad(loss.device))` tells the
+    loss functions below that the incoming gradient is exactly 1, so they return their stored gradients as they are (no ones_like, no
+    scalar multiply launches in the step; same bits: x * 1.0 == x)."""
+    key = torch.device(device)
+    t = _unit_grads.get(key)
+    if t is None:
+        t = _unit_grads[key] = torch.ones((), dtype=torch.float32, device=key)
+    return t
+
+
+def is_unit_grad(g: torch.Tensor) -> bool:
+    t = _unit_grads.get(g.device)
+    return t is not None and g.data_ptr() == t.data_ptr() and g.dim() == 0
+
+
+def split_halves(f: torch.Tensor):
+    """(f[:B], f[B:]) of a contiguous [2B, D] matrix, tagged so that contrastive_loss can hand the whole matrix to one kernel call and
+    return ONE gradient (the Siamese encoders run both sides as one batch)."""
+    B = f.shape[0] // 2
+    a, b = f[:B], f[B:]
+    a._dm_pair, b._dm_pair = f, f
+    return a, b
+
+
+def stacked_halves(a: torch.Tensor, b: torch.Tensor):
+    """The matrix split_halves cut a and b from, or None."""
+    f = getattr(a, "_dm_pair", None)
+    if f is None or f is not getattr(b, "_dm_pair", None) or f.dim() != 2 or not f.is_contiguous() or a.shape != b.shape:
+        return None
+    B, D = a.shape
+    if tuple(f.shape) != (2 * B, D) or a.data_ptr() != f.data_ptr() or b.data_ptr() != f.data_ptr() + B * D * f.element_size():
+        return None
+    return f
+
+
+class ContrastivePairLossFn(torch.autograd.Function):
+    """ContrastiveLossFn on the two halves of ONE [2B, D] matrix (the Siamese encoder runs both sides as one batch and returns
+    f[:B], f[B:]): the gradient is written as one [2B, D] matrix, so autograd has no two slices to pad with zeros and add."""
+
+    @staticmethod
+    def forward(ctx, both, flag, margin):
+        B, D = both.shape[0] // 2, both.shape[1]
+        flag = flag.to(torch.float32).contiguous()
+        loss = torch.empty(1, dtype=torch.float32, device=both.device)
+        d = torch.empty_like(both)
+        check(_lib.lib().dm_contrastive_loss(both.data_ptr(), both[B:].data_ptr(), flag.data_ptr(), margin, 1.0, loss.data_ptr(),
+                                             d.data_ptr(), d[B:].data_ptr(), B, D, _stream()), "dm_contrastive_loss")
+        ctx.save_for_backward(d)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        d, = ctx.saved_tensors
+        return (d if is_unit_grad(g) else d * g), None, None
+
+
+def contrastive_loss(a: torch.Tensor, b: torch.Tensor, flag: torch.Tensor, margin: float) -> torch.Tensor:
+    both = stacked_halves(a, b) if (a.dtype == torch.float32 and b.dtype == torch.float32) else None
+    if both is not None:
+        return ContrastivePairLossFn.apply(both, flag, margin)
+    return ContrastiveLossFn.apply(a, b, flag, margin)
 
 
 class CrossEntropyFn(torch.autograd.Function):

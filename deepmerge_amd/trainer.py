@@ -186,6 +186,12 @@ class _Cuts:
         return leaf
 
 
+def _unit(loss: torch.Tensor):
+    """The gradient to start a scalar fp32 loss's backward pass with: ops.unit_grad -- the loss functions recognise it and skip the
+    scalar multiply (and autograd creates no ones_like); anything else starts the default way."""
+    return ops.unit_grad(loss.device) if (loss.dim() == 0 and loss.dtype == torch.float32) else None
+
+
 class PairTrainer:
     """One training step of the Siamese encoder on this rank's shard of the pair batch.
 
@@ -209,6 +215,7 @@ class PairTrainer:
         the model supports cuts); `n_buckets` is the bucket count for models without cut support."""
         self.net = net
         self.criterion = criterion if criterion is not None else Loss(margin, lamda, belta)
+        ops.unit_grad(next(net.parameters()).device)      # (exists before any capture: creating it is a fill launch)
         self.adam_fn = adam_fn if adam_fn is not None else ops.adam_step
         self.lr, self.betas, self.eps = lr, betas, eps
         self.pg = process_group
@@ -326,7 +333,7 @@ class PairTrainer:
 
     def _backward_segments(self, loss, cuts: _Cuts):
         """Generator over the backward pieces: yields the index of the piece that has just been enqueued."""
-        loss.backward()
+        loss.backward(_unit(loss))
         yield 0
         for k, (x, leaf) in enumerate(reversed(cuts.pairs)):
             x.backward(leaf.grad)
@@ -374,7 +381,7 @@ class PairTrainer:
             st["right"] = [t.clone() for t in right]
             st["ld"] = None if left_designed is None else left_designed.clone()
             st["rd"] = None if right_designed is None else right_designed.clone()
-        st["flag"] = flag.clone()
+        st["flag"] = flag.to(torch.float32).clone() if not flag.is_floating_point() else flag.clone()     # (the loss kernel reads fp32 flags: cast once here, not per step)
         st["hyper"] = torch.zeros(2, dtype=torch.float32, device=self.fp.flat.device)
         st["shapes"] = [tuple(t.shape) for t in st["left"] + st["right"]]
 
@@ -393,7 +400,7 @@ class PairTrainer:
             with torch.cuda.graph(g, capture_error_mode="thread_local"):
                 self.fp.zero_grad()
                 loss = self._forward_loss(st)
-                loss.backward()
+                loss.backward(_unit(loss))
                 self.fp.finish_grads()
                 if not self.dp:
                     self._adam_slice(slice(0, self.fp.total), st["hyper"], 1.0)
@@ -412,7 +419,7 @@ class PairTrainer:
             with torch.cuda.graph(g0, capture_error_mode="thread_local"):
                 self.fp.zero_grad()
                 loss = self._forward_loss(st)
-                loss.backward()
+                loss.backward(_unit(loss))
                 st["loss"] = loss.detach()
             pieces.append(g0)
             for x, leaf in reversed(cuts.pairs):
@@ -558,7 +565,7 @@ class PairTrainer:
             for piece in self._backward_segments(loss, cuts):
                 self._launch_ready(piece)
         else:
-            loss.backward()
+            loss.backward(_unit(loss))
             if self.dp:
                 for bi in range(len(self.bucket_slices)):
                     self._launch_bucket(bi)

@@ -356,7 +356,7 @@ class ScaleEmbedTransformer(nn.Module):
         y = self.forward_features(xs, torch.cat((x2, x4), 0))
         if isinstance(y, tuple):                         # label-token / distilled variants return tuples per side
             return tuple(v[:B] for v in y), tuple(v[B:] for v in y)
-        return y[:B], y[B:]
+        return ops.split_halves(y) if (y.dim() == 2 and y.is_contiguous()) else (y[:B], y[B:])
 
     def forward(self, *args):
         n = len(args)
