@@ -716,6 +716,31 @@ def test_contrastive_loss_and_adam():
     assert torch.equal(lp.cpu(), pd.cpu().bfloat16())
 
 
+@pytest.mark.parametrize("unit", [True, False])
+def test_stacked_pair_loss_equals_the_two_tensor_loss(unit):
+    """The loss on the two halves of one [2B, D] matrix (ops.split_halves, what the Siamese encoders return): one gradient matrix,
+    bit-identical to the two-tensor form; started with ops.unit_grad the stored gradients come back as they are."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(5)
+    f = torch.randn(2 * 33, 100, generator=g)
+    flag = (torch.arange(33) % 2).to(DEV)
+    fd = f.to(DEV).requires_grad_(True)
+    h = fd * 1.0                                           # (a non-leaf, as the encoder's output is)
+    a, b = ops.split_halves(h)
+    assert ops.stacked_halves(a, b) is h and ops.stacked_halves(b, a) is None and ops.stacked_halves(h[:33], h[33:]) is None
+    loss = ops.contrastive_loss(a, b, flag, 1.0)
+    assert type(loss.grad_fn).__name__ == "ContrastivePairLossFnBackward"
+    if unit:
+        loss.backward(ops.unit_grad(DEV))
+    else:
+        (loss * 0.7).backward()
+    ad, bd = f[:33].to(DEV).requires_grad_(True), f[33:].to(DEV).requires_grad_(True)
+    ref = ops.ContrastiveLossFn.apply(ad, bd, flag, 1.0)
+    (ref * (1.0 if unit else 0.7)).backward()
+    assert torch.equal(loss.detach(), ref.detach())
+    assert torch.equal(fd.grad[:33], ad.grad) and torch.equal(fd.grad[33:], bd.grad)
+
+
 @pytest.mark.parametrize("B,K", [(4, 11), (37, 100), (256, 1000)])
 def test_cross_entropy_matches_torch(B, K):
     """dm_cross_entropy (MultiLoss / ClassLoss, Losses.py:52-53, :83-84) against torch's CPU float64 CrossEntropyLoss."""
