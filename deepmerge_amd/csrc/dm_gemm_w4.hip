@@ -30,8 +30,15 @@
 __device__ unsigned long long dmw4_stamps[64 * 16 * 8];
 #define DMW4_T(i) do { if (wave == 0 && lane == 0 && blockIdx.x < 64 && sstep >= 8 && sstep < 24) dmw4_stamps[(blockIdx.x * 16 + (sstep - 8)) * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
 extern "C" int dm_debug_w4_stamps(unsigned long long *out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(dmw4_stamps), sizeof(dmw4_stamps)); }
+// ... and every workgroup's wave 0 stamps the phases of its FIRST tile: 0 kernel entry, 1 addresses set up (first global load next), 2 prologue
+// done (two K steps staged, first fragments read), 3 K loop done, 4 epilogue issued
+__device__ unsigned long long dmw4_kstamps[512 * 8];
+#define DMW4_K(i) do { if (wave == 0 && lane == 0 && blockIdx.x < 512) { dmw4_kstamps[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime(); \
+    if ((i) == 0 || (i) == 4) dmw4_kstamps[blockIdx.x * 8 + ((i) == 0 ? 5 : 6)] = __builtin_amdgcn_s_memrealtime(); } } while (0)     /* (slots 5 / 6: the chip-wide 100 MHz clock at entry / end) */
+extern "C" int dm_debug_w4_kstamps(unsigned long long *out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(dmw4_kstamps), sizeof(dmw4_kstamps)); }
 #else
 #define DMW4_T(i) do { } while (0)
+#define DMW4_K(i) do { } while (0)
 #endif
 
 namespace dmw4 {
@@ -79,6 +86,7 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmParams p) {
   const int wm = wave & 1, wn = wave >> 1;
   const int g = lane >> 4, li = lane & 15;
 
+  DMW4_K(0);
   const int G = gridDim.x;
   const int L = dm_xcd_remap(blockIdx.x, G);
   const int tiles = p.tiles_m * p.tiles_n;
@@ -733,6 +741,7 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmParams p) {
   };
 
   // ---- prologue: the state the schedule above expects at step 0 (buffer 0 complete, X(1) in buffer 1, Y(1) / X(2) / Y(2) / X(3) in flight) ----
+  DMW4_K(1);
 #pragma unroll
   for (int q = 0; q < PH; ++q) gload(IC<0>{}, IC<0>{}, q);                 // X(0) -> set 0
   advance_x();
@@ -761,6 +770,7 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmParams p) {
 #pragma unroll
   for (int i = 0; i < 8; ++i) fa[i] = read_a(i, IC<0>{}, IC<0>{});
 
+  DMW4_K(2);
   // K % 128 == 0 (plan): a tile is an even number of K steps, so tiles end after an odd step only
   for (int step = 0; step < total; step += 2) {
     if constexpr (!AMM) { if (kt + 2 == ntile && p.split_k <= 1) touch_epilogue_operands(); }
@@ -768,9 +778,11 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmParams p) {
     else { body(IC<0>{}); body(IC<1>{}); }
     kt += 2;
     if (kt == ntile) {
+      if (r == 0) DMW4_K(3);
       if constexpr (DBG & 1) { kt = 0; ++r; if (r < n_my) tile_mn(r, m_cur, n_cur); } else
       if constexpr (EK == 0) epilogue_generic();
       else epilogue_lean(IC<0>{}, IC<(EK - 1) & 1>{}, IC<((EK - 1) >> 1) & 3>{}, IC<((EK - 1) >> 3) & 1>{}, IC<((EK - 1) >> 4) & 3>{});
+      if (r == 1) DMW4_K(4);
       // The next step's k-step-0 fragments were prefetched during the last MFMAs; holding their 56 registers across the epilogue
       // (on top of the 88 staging registers in flight) overflows the register file, so they are read again here instead.
 #pragma unroll
