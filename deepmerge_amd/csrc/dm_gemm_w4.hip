@@ -79,7 +79,7 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmParams p) {
   constexpr int EPIU = 0;
   constexpr bool AMM = (LAYOUT == DM_TN);      // A m-contiguous [K][M] (wgrad) or k-contiguous [M][K]
   constexpr bool BMM = (LAYOUT != DM_NT);      // B m-contiguous [K][N] (dgrad, wgrad) or k-contiguous [N][K] (forward)
-  constexpr int NB = BMM ? 8 : 6;              // global loads of B per thread and K step
+  constexpr int NB = 6;                        // global loads of B per thread and K step
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -137,24 +137,30 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmParams p) {
     wA0 = band * 8192 + krow * 128 + (((c8 >> 1) ^ f0) << 5) + ((c8 & 1) << 4);          // even u: + u * 1024
     wA1 = band * 8192 + krow * 128 + (((c8 >> 1) ^ (f0 | 2)) << 5) + ((c8 & 1) << 4);    // odd u
   }
-  int voB, strideB, stepB, wB0, wB1;
+  int voB = 0, strideB = 0, stepB, wB0 = 0;
+  int voB3[3] = {0, 0, 0}, wB3[3] = {0, 0, 0}, halfB = 0;
   if constexpr (!BMM) {
     voB = FOLD ? (int)(((long long)lrow * p.ldb + (lchunk & 3) * 8 + (lchunk >= 4 ? b_lo : 0)) * 2) : (int)(((long long)lrow * p.ldb + lchunk * 8) * 2);
     strideB = (int)(32 * p.ldb * 2);
     stepB = BKR * 2;
-    wB0 = wB1 = wA;                                                   // + u * 4096
+    wB0 = wA;                                                         // + u * 4096
   } else {
-    // m-contiguous operand [K][N]: threads 0..191 load chunk c24 = t % 24 (8 columns) of k-row t / 24 + 8 u.  LDS image = 3 bands of
-    // [64 k-rows][64 columns = 128 B]; the 32-byte slot index of k-row r is XORed with f(r) = ((r >> 1) & 1) | (((r >> 3) & 1) << 1).
-    const int krow = t / 24, c24 = t - krow * 24, band = c24 >> 3, c8 = c24 & 7;
-    voB = (int)(((long long)krow * p.ldb + c24 * 8) * 2);
-    strideB = (int)(8 * p.ldb * 2);
+    // m-contiguous operand [K][N]: a half tile (32 k-rows x 192 columns) is 768 16-byte chunks = 3 pieces of all 256 threads -- piece i
+    // of a thread is chunk c = t + 256 i: k-row c / 24, columns 8 (c % 24) .. + 7 -- and pieces 3..5 are the same chunks 32 k-rows
+    // further down (plain) resp. of the lo plane (FOLD), i.e. a scalar offset on the global side and + 4096 in the image.  (Until round 4
+    // threads 0..191 loaded 8 pieces of 8 k-rows each and wave 3 none: two load / write pairs more on the waves every barrier waits for.)
+    // LDS image = 3 bands of [64 k-rows][64 columns = 128 B]; the 32-byte slot index of k-row r is XORed with
+    // f(r) = ((r >> 1) & 1) | (((r >> 3) & 1) << 1).
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int c = t + 256 * i, krow = c / 24, c24 = c - krow * 24, band = c24 >> 3, c8 = c24 & 7;
+      const int f = ((krow >> 1) & 1) | (((krow >> 3) & 1) << 1);
+      voB3[i] = (int)(((long long)krow * p.ldb + c24 * 8) * 2);
+      wB3[i] = band * 8192 + krow * 128 + (((c8 >> 1) ^ f) << 5) + ((c8 & 1) << 4);
+    }
+    halfB = FOLD ? (int)(b_lo * 2) : (int)(32 * p.ldb * 2);
     stepB = (int)(BKR * p.ldb * 2);
-    const int f0 = (krow >> 1) & 1;
-    wB0 = band * 8192 + krow * 128 + (((c8 >> 1) ^ f0) << 5) + ((c8 & 1) << 4);          // even u: + u * 1024
-    wB1 = band * 8192 + krow * 128 + (((c8 >> 1) ^ (f0 | 2)) << 5) + ((c8 & 1) << 4);    // odd u
   }
-  const bool b_loader = !BMM || t < 192;
 
   // ---- fragment offsets -----------------------------------------------------------------------------------------------------------
   // A fragments.  k-contiguous: two offsets (k-steps), + i * 2048 per row tile.  m-contiguous: row tile i of this wave is column block
@@ -278,9 +284,9 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmParams p) {
     // k-contiguous ones carry the plane in their per-thread offset)
     const int u = q - 8;
     const int pa = (FOLD && AMM) ? (q & 3) * strideA + (q >= 4 ? (int)(a_lo * 2) : 0) : q * strideA;
-    const int pb = (FOLD && BMM) ? (u & 3) * strideB + (u >= 4 ? (int)(b_lo * 2) : 0) : u * strideB;
     if (q < 8) ga[set][q] = __builtin_amdgcn_raw_buffer_load_b128(GX ? rsAx : rsAy, voA, k * stepA + pa, 0);
-    else if (b_loader) gb[set][q - 8] = __builtin_amdgcn_raw_buffer_load_b128(GX ? rsBx : rsBy, voB, k * stepB + pb, 0);
+    else if constexpr (BMM) gb[set][u] = __builtin_amdgcn_raw_buffer_load_b128(GX ? rsBx : rsBy, voB3[u % 3], k * stepB + (u / 3) * halfB, 0);
+    else gb[set][u] = __builtin_amdgcn_raw_buffer_load_b128(GX ? rsBx : rsBy, voB, k * stepB + u * strideB, 0);
   };
   // piece q: register set -> LDS buffer
   auto lwrite = [&](auto set_tag, auto buf_tag, int q) __attribute__((always_inline)) {
@@ -290,10 +296,10 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmParams p) {
     if (q < 8) {
       if constexpr (!AMM) *reinterpret_cast<u32x4 *>(a + wA + q * 4096) = ga[set][q];
       else *reinterpret_cast<u32x4 *>(a + ((q & 1) ? wA1 : wA0) + q * 1024) = ga[set][q];
-    } else if (b_loader) {
+    } else {
       const int u = q - 8;
       if constexpr (!BMM) *reinterpret_cast<u32x4 *>(a + A_BYTES + wB0 + u * 4096) = gb[set][u];
-      else *reinterpret_cast<u32x4 *>(a + A_BYTES + ((u & 1) ? wB1 : wB0) + u * 1024) = gb[set][u];
+      else *reinterpret_cast<u32x4 *>(a + A_BYTES + wB3[u % 3] + (u / 3) * 4096) = gb[set][u];
     }
   };
 
