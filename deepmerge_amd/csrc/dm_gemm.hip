@@ -935,7 +935,7 @@ extern "C" int dm_gemm(const DmGemmArgs *a, void *stream) {
   if (fwd_split) return DM_OK;
   const bool cs_t64 = !big && !w4 && !ring && a->layout == DM_TN && a->ab_dtype == DM_BF16 && tile == 64 && a->colsum_a != nullptr && split <= 128;
   const bool cs_fused = big || (w4 && a->layout == DM_TN) || cs_t64;      // these kernels produce the partial column sums of A themselves
-  const int cs_rows_per_slice = big ? 4 : cs_t64 ? 1 : 2;
+  const int cs_rows_per_slice = big ? 4 : 1;      // (256x256 pipeline: one row per wave column; 64x64 tiles and the 4-wave kernel: one per slice)
   if (split > 1) {
     const long long n4 = (long long)a->M * a->N / 4;
     const long long want = (n4 + 255) / 256;

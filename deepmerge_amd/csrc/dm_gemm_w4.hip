@@ -74,7 +74,7 @@ __device__ __forceinline__ void mma_pinned(f32x4 &acc, const u32x4 &a, const u32
 // global addresses of the staged pieces change -- and runs THREE MFMA sets on them: hi.hi, hi.lo, lo.hi.  Per 64 contraction
 // positions that is 2 steps of staging for 6 MFMA sets where the generic folded form (three K segments, one MFMA set pair per step)
 // needs 3 steps: the staging / fragment traffic that bounds this kernel's step drops by a third.
-template <int LAYOUT, int DBG = 0, int EK = 0, bool FOLD = false>
+template <int LAYOUT, int DBG = 0, int EK = 0, bool FOLD = false, bool CS = true>
 __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmParams p) {
   constexpr int EPIU = 0;
   constexpr bool AMM = (LAYOUT == DM_TN);      // A m-contiguous [K][M] (wgrad) or k-contiguous [M][K]
@@ -308,13 +308,18 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmParams p) {
   for (int i = 0; i < 8; ++i)
 #pragma unroll
     for (int j = 0; j < 6; ++j) zero_pinned(acc[i][j], vzero);
-  // wgrad: column sums of A (the bias gradient that goes with dW = dy^T x) ride along in the workgroups of column tile 0: their waves
-  // multiply the A fragments with a ones fragment (every column of the 16 x 16 result = the row sums); the two waves that hold the
-  // same A rows take one k-step each (+8 % MFMAs there).  Partial rows [z * 2 + wn][M] in p.colsum_slab.
-  const bool colsum = AMM && p.colsum_slab != nullptr && n_cur == 0;
-  f32x4 accb[AMM ? 8 : 1];
-  u32x4 ones = {0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};     // eight bf16 1.0
-  if constexpr (AMM) {
+  // wgrad: column sums of A (the bias gradient that goes with dW = dy^T x) ride along: every wave multiplies its A fragments with a
+  // "ones" fragment (every column of the 16 x 16 result = the row sums) -- eight bf16 1.0 in the workgroups of column tile 0, zeros
+  // everywhere else -- in BOTH k-steps, unconditionally; the waves wn == 0 of column tile 0 write the partial row [z][M] of
+  // p.colsum_slab.  (Until round 4 only column tile 0 did this, one k-step per wave, behind a uniform branch per row tile: sixteen
+  // branches per K step in EVERY workgroup cost more than the MFMAs they skipped -- weight gradients 96 -> 91 us.  CS = false: instances
+  // without any of it, for launches that want no column sums.)
+  constexpr bool CSM = AMM && CS;
+  const bool colsum = CSM && p.colsum_slab != nullptr && n_cur == 0;
+  f32x4 accb[CSM ? 8 : 1];
+  const unsigned one2 = colsum ? 0x3F803F80u : 0u;
+  u32x4 ones = {one2, one2, one2, one2};     // eight bf16 1.0 (column tile 0) or zeros
+  if constexpr (CSM) {
     asm volatile("" : "+v"(ones));
 #pragma unroll
     for (int i = 0; i < 8; ++i) zero_pinned(accb[i], vzero);
@@ -384,11 +389,7 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmParams p) {
       __builtin_amdgcn_sched_barrier(0);
       mm(acc[i][5], fa[i], fb[ks][5]);
       if (i < 6) load_b1(i, nks_tag, nbuf_tag);
-      if constexpr (AMM) {
-        if (colsum && wn == ks) {
-          mm(accb[i], fa[i], ones);
-        }
-      }
+      if constexpr (CSM) mm(accb[i], fa[i], ones);
       fa[i] = na;
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -423,11 +424,7 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmParams p) {
       __builtin_amdgcn_sched_barrier(0);
       mm(acc[i][5], fa[i], fb[FB][5]);
       if constexpr (BNX) { if (i < 6) load_bx(i, bks_tag, bbuf_tag, bdst_tag); }
-      if constexpr (AMM && CSW >= 0) {
-        if (colsum && wn == CSW) {
-          mm(accb[i], fa[i], ones);
-        }
-      }
+      if constexpr (CSM && CSW >= 0) mm(accb[i], fa[i], ones);
       if constexpr (ANX) fa[i] = na;
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -618,11 +615,11 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmParams p) {
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
     }
-    if constexpr (AMM) {
+    if constexpr (CSM) {
 #pragma unroll
       for (int i = 0; i < 8; ++i) asm volatile("" : "+a"(accb[i]));
-      if (colsum && g == 0) {
-        float *row = p.colsum_slab + (long long)(zslice * 2 + wn) * p.M;
+      if (colsum && wn == 0 && g == 0) {
+        float *row = p.colsum_slab + (long long)zslice * p.M;
 #pragma unroll
         for (int i = 0; i < 8; ++i) row[m_cur + wm * 128 + i * 16 + li] = accb[i][0];
       }
@@ -691,14 +688,14 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmParams p) {
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
     }
-    if constexpr (AMM) {
-      // The compiler does not know the asm statements are MFMAs: it copies accb[i] out of the AGPRs right behind the conditional MFMA
+    if constexpr (CSM) {
+      // The compiler does not know the asm statements are MFMAs: it copies accb[i] out of the AGPRs right behind the last MFMA
       // (no wait states -> the copy misses the last update) and would store that copy here.  Re-reading through an asm operand forces
       // a fresh copy, long after the last MFMA has retired.
 #pragma unroll
       for (int i = 0; i < 8; ++i) asm volatile("" : "+a"(accb[i]));
-      if (colsum && g == 0) {        // every column of an accb tile holds the same sum: lanes g == 0 write element 0
-        float *row = p.colsum_slab + (long long)(zslice * 2 + wn) * p.M;
+      if (colsum && wn == 0 && g == 0) {        // every column of an accb tile holds the same sum: lanes g == 0 write element 0
+        float *row = p.colsum_slab + (long long)zslice * p.M;
 #pragma unroll
         for (int i = 0; i < 8; ++i) row[m_cur + wm * 128 + i * 16 + li] = accb[i][0];
       }
@@ -802,8 +799,8 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmParams p) {
 }  // namespace dmw4
 
 namespace {
-template <int LAYOUT, int DBG = 0, int EK = 0, bool FOLD = false> bool w4_set_lds_limit() {
-  return hipFuncSetAttribute(reinterpret_cast<const void *>(dmw4::gemm_w4_kernel<LAYOUT, DBG, EK, FOLD>), hipFuncAttributeMaxDynamicSharedMemorySize,
+template <int LAYOUT, int DBG = 0, int EK = 0, bool FOLD = false, bool CS = true> bool w4_set_lds_limit() {
+  return hipFuncSetAttribute(reinterpret_cast<const void *>(dmw4::gemm_w4_kernel<LAYOUT, DBG, EK, FOLD, CS>), hipFuncAttributeMaxDynamicSharedMemorySize,
                              dmw4::LDS_BYTES) == hipSuccess;
 }
 int w4_cu_count() {
@@ -838,6 +835,7 @@ int dm_gemm_w4_plan(GemmParams &p, int layout, int ab_dtype, bool aligned8, bool
     if (p.a_fold[0] != 0 || p.a_fold[1] != 0 || p.a_fold[2] <= 0 || p.b_fold[0] != 0 || p.b_fold[2] != 0 || p.b_fold[1] <= 0) return 0;
     if (p.a_fold[2] * 2 >= (1LL << 30) || p.b_fold[1] * 2 >= (1LL << 30)) return 0;      // (byte offsets live in 32-bit lane offsets)
     static const bool attr_fold = w4_set_lds_limit<DM_TN, 0, 0, true>() && w4_set_lds_limit<DM_TN, 0, 9, true>() && w4_set_lds_limit<DM_TN, 0, 11, true>() &&
+                                  w4_set_lds_limit<DM_TN, 0, 0, true, false>() && w4_set_lds_limit<DM_TN, 0, 9, true, false>() && w4_set_lds_limit<DM_TN, 0, 11, true, false>() &&
                                   w4_set_lds_limit<DM_NT, 0, 0, true>() && w4_set_lds_limit<DM_NT, 0, 10, true>() && w4_set_lds_limit<DM_NN, 0, 0, true>();
     if (!attr_fold) return 0;
   }
@@ -866,7 +864,8 @@ int dm_gemm_w4_plan(GemmParams &p, int layout, int ab_dtype, bool aligned8, bool
     // in-step per launch (tools/prof_shapes.py): K = 16384: 100 -> 84, 92 -> 83, 80 -> 67, 41 -> 38 us; K = 4096 with 48 tiles x 4 slices:
     // 26 -> 24 us; fewer workgroups than 0.7 of the CUs, or the 1024-token stage, lose
     if (tmode == 1 && ((double)(tiles * split) / cus < 0.7 || tiles < 12 || (tiles < 24 && k_eff < 8192))) return 0;
-    static const bool attr_tn = w4_set_lds_limit<DM_TN>() && w4_set_lds_limit<DM_TN, 0, 9>() && w4_set_lds_limit<DM_TN, 0, 11>();
+    static const bool attr_tn = w4_set_lds_limit<DM_TN>() && w4_set_lds_limit<DM_TN, 0, 9>() && w4_set_lds_limit<DM_TN, 0, 11>() &&
+                                w4_set_lds_limit<DM_TN, 0, 0, false, false>() && w4_set_lds_limit<DM_TN, 0, 9, false, false>() && w4_set_lds_limit<DM_TN, 0, 11, false, false>();
     if (!attr_tn) return 0;
     p.tiles_m = p.M / TM;
     p.tiles_n = p.N / TN;
@@ -967,11 +966,14 @@ void dm_gemm_w4_launch(const GemmParams &p, int layout, int grid, hipStream_t s)
   }
 #define W4_GO(LAY, EKV) hipLaunchKernelGGL((dmw4::gemm_w4_kernel<LAY, 0, EKV>), dim3(grid), dim3(256), dmw4::LDS_BYTES, s, q)
 #define W4_GOF(LAY, EKV) hipLaunchKernelGGL((dmw4::gemm_w4_kernel<LAY, 0, EKV, true>), dim3(grid), dim3(256), dmw4::LDS_BYTES, s, q)
+// weight gradients: the instance with the column-sum MFMAs only when the launch wants column sums
+#define W4_GOT(EKV, FOLDV) do { if (q.colsum_slab) hipLaunchKernelGGL((dmw4::gemm_w4_kernel<DM_TN, 0, EKV, FOLDV, true>), dim3(grid), dim3(256), dmw4::LDS_BYTES, s, q); \
+    else hipLaunchKernelGGL((dmw4::gemm_w4_kernel<DM_TN, 0, EKV, FOLDV, false>), dim3(grid), dim3(256), dmw4::LDS_BYTES, s, q); } while (0)
   if (p.k_fold > 0) {                                      // hi / lo plane pairs ("bf16x3"): fp32 outputs
     if (layout == DM_TN) {
-      if (lean_ok && key == 8) W4_GOF(DM_TN, 9);
-      else if (lean_ok && key == 10) W4_GOF(DM_TN, 11);
-      else W4_GOF(DM_TN, 0);
+      if (lean_ok && key == 8) W4_GOT(9, true);
+      else if (lean_ok && key == 10) W4_GOT(11, true);
+      else W4_GOT(0, true);
     } else if (layout == DM_NT) {
       if (lean_ok && key == 9) W4_GOF(DM_NT, 10);          // fp32 C + fp32 residual: fc2 / proj forward
       else W4_GOF(DM_NT, 0);
@@ -981,9 +983,9 @@ void dm_gemm_w4_launch(const GemmParams &p, int layout, int grid, hipStream_t s)
     return;
   }
   if (layout == DM_TN) {
-    if (lean_ok && key == 8) W4_GO(DM_TN, 9);             // fp32 slab / gradient written
-    else if (lean_ok && key == 10) W4_GO(DM_TN, 11);      // fp32 gradient accumulated in place
-    else W4_GO(DM_TN, 0);
+    if (lean_ok && key == 8) W4_GOT(9, false);            // fp32 slab / gradient written
+    else if (lean_ok && key == 10) W4_GOT(11, false);     // fp32 gradient accumulated in place
+    else W4_GOT(0, false);
   } else if (p.split_k > 1) {                             // sliced forward / dgrad: fp32 partial tile into the slab
     if (layout == DM_NT) W4_GO(DM_NT, 9); else W4_GO(DM_NN, 9);
   } else if (layout == DM_NT) {
@@ -998,4 +1000,5 @@ void dm_gemm_w4_launch(const GemmParams &p, int layout, int grid, hipStream_t s)
   }
 #undef W4_GO
 #undef W4_GOF
+#undef W4_GOT
 }
