@@ -472,33 +472,35 @@ __global__ void splitk_reduce_kernel(const float *__restrict__ slab, float *__re
     float *o = out + (long long)m * ldc + n;
     // slices summed in index order, but LOADED eight (then four) at a time: with one load per trip of a run-time loop a thread pays S
     // dependent memory round trips for its single output group -- the kernel was latency-bound at ~6 x 1.3 us, not bandwidth-bound
+    // (slabs are read exactly once, here: non-temporal)
+    auto ntl = [](const float *q) { return __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(q)); };
     const float *sl = slab + e;
     const long long mn = (long long)M * N;
-    f32x4 v = accumulate ? dm_load4(o) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    f32x4 v = accumulate ? ntl(o) : (f32x4){0.f, 0.f, 0.f, 0.f};
     int s = 0;
     for (; s + 8 <= S; s += 8) {
       f32x4 t[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) t[u] = dm_load4(sl + (long long)(s + u) * mn);
+      for (int u = 0; u < 8; ++u) t[u] = ntl(sl + (long long)(s + u) * mn);
 #pragma unroll
       for (int u = 0; u < 8; ++u) v += t[u];
     }
     if (s + 4 <= S) {
       f32x4 t[4];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) t[u] = dm_load4(sl + (long long)(s + u) * mn);
+      for (int u = 0; u < 4; ++u) t[u] = ntl(sl + (long long)(s + u) * mn);
 #pragma unroll
       for (int u = 0; u < 4; ++u) v += t[u];
       s += 4;
     }
     if (s + 2 <= S) {
-      const f32x4 t0 = dm_load4(sl + (long long)s * mn), t1 = dm_load4(sl + (long long)(s + 1) * mn);
+      const f32x4 t0 = ntl(sl + (long long)s * mn), t1 = ntl(sl + (long long)(s + 1) * mn);
       v += t0;
       v += t1;
       s += 2;
     }
-    if (s < S) v += dm_load4(sl + (long long)s * mn);
-    dm_store4(o, v);
+    if (s < S) v += ntl(sl + (long long)s * mn);
+    __builtin_nontemporal_store(v, reinterpret_cast<f32x4 *>(o));      // (the gradient is next read by Adam, a whole backward pass later)
   }
 }
 

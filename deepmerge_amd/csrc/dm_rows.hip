@@ -557,7 +557,11 @@ __global__ void adam_kernel(float *__restrict__ param, const float *__restrict__
   }
   const long long n4 = n >> 2;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
-    f32x4 p = dm_load4(param + 4 * i), g = dm_load4(grad + 4 * i) * grad_scale, mm = dm_load4(m + 4 * i), vv = dm_load4(v + 4 * i);
+    // every operand is touched once per step (1.3 GB for the headline model: nothing of it survives in the caches until the next step):
+    // non-temporal loads / stores, except the bf16 weight copy that the next step's GEMMs read (86 MB: stays in the Infinity Cache)
+    f32x4 p = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(param + 4 * i));
+    f32x4 g = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(grad + 4 * i)) * grad_scale;
+    f32x4 mm = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(m + 4 * i)), vv = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(v + 4 * i));
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       mm[e] = mm[e] * beta1 + g[e] * omb1;
@@ -565,7 +569,9 @@ __global__ void adam_kernel(float *__restrict__ param, const float *__restrict__
       const float denom = sqrtf(vv[e]) / bc2_sqrt + eps;
       p[e] = p[e] - step_size * (mm[e] / denom);
     }
-    dm_store4(param + 4 * i, p); dm_store4(m + 4 * i, mm); dm_store4(v + 4 * i, vv);
+    __builtin_nontemporal_store(p, reinterpret_cast<f32x4 *>(param + 4 * i));
+    __builtin_nontemporal_store(mm, reinterpret_cast<f32x4 *>(m + 4 * i));
+    __builtin_nontemporal_store(vv, reinterpret_cast<f32x4 *>(v + 4 * i));
     if (lp) dm_store4(lp + 4 * i, p);
   }
   if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
