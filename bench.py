@@ -51,25 +51,15 @@ def csrc_hash():
     return h.hexdigest()
 
 
-PEAK_BF16_TFLOPS = 2500.0    # dense bf16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
+PEAK_BF16_TFLOPS = 2500.0    # dense bf16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters" (same constants: deepmerge_amd/workload.py)
 PEAK_HBM_TBPS = 8.0
 PEAK_F32_TFLOPS = 157.3
 
 
 def synth_batch(B, scales, in_c, device, seed):
-    """Synthetic pair batch of the reference's tensor contract (MyUtils1.py:41-77): per side a list of
-    [B, in_c, s, s] float32 patches in [0,1] on a uint8 grid, designed features [B,1,19], flag [B]."""
-    import torch
-    g = torch.Generator(device="cpu").manual_seed(seed)
-    left = [torch.randint(0, 256, (B, in_c, s, s), generator=g, dtype=torch.uint8).float().div_(255.0) for s in scales]
-    right = [torch.randint(0, 256, (B, in_c, s, s), generator=g, dtype=torch.uint8).float().div_(255.0) for s in scales]
-    flag = (torch.arange(B) % 2 == 0).to(torch.int64)
-    for i in range(len(scales)):        # positives: jittered copy of the left crop (so some d < margin)
-        right[i][flag == 1] = (left[i][flag == 1] * 0.9 + 0.1 * right[i][flag == 1])
-    ld = torch.exp(torch.empty(B, 1, 19).uniform_(-4.6, 6.9, generator=g))
-    rd = torch.where(flag.view(B, 1, 1) == 1, ld * 1.05, torch.exp(torch.empty(B, 1, 19).uniform_(-4.6, 6.9, generator=g)))
-    mv = lambda t: t.to(device)
-    return [mv(t) for t in left], mv(ld), [mv(t) for t in right], mv(rd), mv(flag)
+    """deepmerge_amd.workload.synth_batch (imported on first use: the self-launching parent of a multi-GPU run never imports torch)."""
+    from deepmerge_amd.workload import synth_batch as f
+    return f(B, scales, in_c, device, seed)
 
 
 def log(msg):
@@ -143,6 +133,7 @@ def extras(args, scales, in_c, depth, dev):
         f32 = at_tolerance(args, scales, in_c, depth, dev, steps=NS, numerics="fp32")
         out["fp32_parity_pairs_per_s"] = round(f32["value"], 1)
         out["fp32_parity_ms_per_step"] = round(f32["ms_per_step"], 2)
+        out["fp32_parity_roofline_frac"] = f32["roofline_frac_f32_peak"]      # model FLOPs / s over the 157.3 TFLOP/s fp32 matrix peak
         batch = None
         log(f"extras: bf16x3 mode (fp32 path, large products as split-bf16 triples on the bf16 matrix pipe), {NS} steps")
         # (graph replay like the headline: ~450 launches of 12 ms GPU time per step leave an eager loop host-bound on a slow host --
@@ -150,37 +141,46 @@ def extras(args, scales, in_c, depth, dev):
         x3 = at_tolerance(args, scales, in_c, depth, dev, steps=NS)
         out["bf16x3_pairs_per_s"] = round(x3["value"], 1)
         out["bf16x3_ms_per_step"] = round(x3["ms_per_step"], 2)
+        out["bf16x3_roofline_frac"] = x3["roofline_frac"]                     # MODEL FLOPs (one product counted once) over the bf16 peak
         del batch
         torch.cuda.empty_cache()
-        sys.path.insert(0, os.path.join(ROOT, "tools"))
-        import bench_configs as BC
+        from deepmerge_amd import workload as BC
         log("extras: config 3 (ViT-B/16 pairs)")
         c3 = BC.config3(steps=NS)
         out["config3_vit_pairs_per_s"], out["config3"] = c3["pairs_per_s"], c3
+        out["config3_vit_roofline_frac"] = c3["roofline_frac"]       # model FLOPs / s over the dense bf16 MFMA peak
         torch.cuda.empty_cache()
         log("extras: config 5 per GPU (v3 [6,4,2], 120 pairs)")
         c5 = BC.config5(steps=NS, graph=True)
         out["config5_per_gpu_pairs_per_s"], out["config5"] = c5["pairs_per_s"], c5
+        out["config5_per_gpu_roofline_frac"] = c5["roofline_frac"]       # model FLOPs / s over the dense bf16 MFMA peak
         torch.cuda.empty_cache()
         log("extras: config 5 per GPU, the reference's default 3-scale / 3-channel geometry")
         c53 = BC.config5(steps=NS, graph=True, three_scale=True)
         out["config5_3scale_per_gpu_pairs_per_s"], out["config5_3scale"] = c53["pairs_per_s"], c53
+        out["config5_3scale_per_gpu_roofline_frac"] = c53["roofline_frac"]       # model FLOPs / s over the dense bf16 MFMA peak
         torch.cuda.empty_cache()
         # the mode that meets north_star's 1e-3 tolerance (bf16x3), on the model the >= 10 k pairs/s target is defined on and on config 3
         log("extras: config 5 per GPU in bf16x3 (4 scales x 4 ch), then 3 scales x 3 ch, then config 3 in bf16x3")
         c5x = BC.config5(steps=NS, graph=True, numerics="bf16x3")
         out["config5_bf16x3_per_gpu_pairs_per_s"], out["config5_bf16x3"] = c5x["pairs_per_s"], c5x
+        out["config5_bf16x3_per_gpu_roofline_frac"] = c5x["roofline_frac"]       # model FLOPs / s over the dense bf16 MFMA peak
         torch.cuda.empty_cache()
         c53x = BC.config5(steps=NS, graph=True, three_scale=True, numerics="bf16x3")
         out["config5_3scale_bf16x3_per_gpu_pairs_per_s"], out["config5_3scale_bf16x3"] = c53x["pairs_per_s"], c53x
+        out["config5_3scale_bf16x3_per_gpu_roofline_frac"] = c53x["roofline_frac"]       # model FLOPs / s over the dense bf16 MFMA peak
         torch.cuda.empty_cache()
         c3x = BC.config3(steps=NS, numerics="bf16x3")
         out["config3_bf16x3_pairs_per_s"], out["config3_bf16x3"] = c3x["pairs_per_s"], c3x
+        out["config3_bf16x3_roofline_frac"] = c3x["roofline_frac"]       # model FLOPs / s over the dense bf16 MFMA peak
         torch.cuda.empty_cache()
         log("extras: config 4 (ExtractFeatures tile)")
         c4 = BC.config4(passes=1)
         out["config4_points_per_s"] = c4["encode(gather + v3[6,4,2] eval, batch 2000)"]["points_per_s"]
         out["config4_edges_per_s"] = c4["edge_similarity"]["edges_per_s"]
+        out["config4_encode_roofline_frac"] = c4["encode(gather + v3[6,4,2] eval, batch 2000)"]["roofline_frac"]      # of the bf16 MFMA peak
+        out["config4_sweep_roofline_frac"] = c4["edge_similarity"]["roofline_frac"]                                   # algorithmic GB/s of 8 TB/s
+        out["config4_pool_roofline_frac"] = c4["segment_mean"]["roofline_frac"]
         out["config4"] = c4
     except Exception as e:      # secondary numbers must never take the headline line down
         out["error"] = f"{type(e).__name__}: {e}"
@@ -191,7 +191,8 @@ def at_tolerance(args, scales, in_c, depth, dev, steps=20, numerics="bf16x3"):
     """The headline config in the numerics mode that MEETS north_star's tolerance (logits / grads within 1e-3 rel of the fp32
     reference): `bf16x3` (fp32 tensors, every large product a split-bf16 triple on the bf16 matrix pipe; whole-model parity
     7e-6 / 4e-5, tests/test_gpu_modules.py::test_whole_model_parity_bf16x3).  Same model, batch, step (fwd + loss + bwd + Adam) and
-    hipGraph replay as the headline `value`, >= 20 timed steps; outside the headline's timed region."""
+    hipGraph replay as the headline `value`; `steps` timed steps (20 for `value_at_tolerance`, 10 inside `extras`), outside the
+    headline's timed region."""
     import torch
     from deepmerge_amd.nets.ShfitScaleFormer import ShfitScaleFormer_v3
     from deepmerge_amd.trainer import PairTrainer
@@ -213,7 +214,11 @@ def at_tolerance(args, scales, in_c, depth, dev, steps=20, numerics="bf16x3"):
     ok = bool(graph and tr.graph_error is None)
     del net, tr, batch
     torch.cuda.empty_cache()
+    from deepmerge_amd.workload import pair_step_flops
+    tf = args.pairs / d * pair_step_flops(scales, in_c, depth) / 1e12
     return {"value": round(args.pairs / d, 2), "ms_per_step": round(1e3 * d, 3), "dtype": numerics, "steps": steps, "hip_graph": ok,
+            "model_TFLOPs": round(tf, 1), "roofline_frac": round(tf / PEAK_BF16_TFLOPS, 4), "roofline_frac_f32_peak": round(tf / PEAK_F32_TFLOPS, 4),
+            "roofline_note": "model FLOPs (each product once) / s over the dense bf16 MFMA peak; bf16x3 executes 3 MFMA products per model product",
             "tolerance": "1e-3 rel vs fp32 reference (observed 7e-6 outputs / 4e-5 gradients); the bf16 headline drifts 4.3e-3 / 2.2e-2"}
 
 
@@ -299,15 +304,17 @@ def launch_ranks(world, argv, script=None, poll_s=0.2):
                 os.killpg(p.pid, sig)           # the child is its own session / group leader (_child_setup)
             except (ProcessLookupError, PermissionError):
                 pass
+        # every rank's GROUP, whether its leader is still alive or not: a rank that has already exited (the failing one that triggered
+        # this teardown, say) may have left helpers behind in its session, and those can keep holding the GPU
         for p in procs:
-            if p.poll() is None:
-                end(p, signal.SIGTERM)
+            end(p, signal.SIGTERM)
         for p in procs:
             try:
                 p.wait(timeout=20)
             except subprocess.TimeoutExpired:
-                end(p, signal.SIGKILL)
-                p.wait()
+                pass
+            end(p, signal.SIGKILL)              # whatever of the group ignored SIGTERM (no-op once the group is empty)
+            p.wait()
         for sg, h in previous.items():
             signal.signal(sg, h)
     return rc

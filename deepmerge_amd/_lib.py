@@ -110,6 +110,7 @@ SIGNATURES = {
     "dm_edge_similarity": (_I, [_P, _P, _P, _P, _I, _I, _F, _P]),
     "dm_patch_pyramid": (_I, [_P, _I, _I, _I, _P, _P, _I, _I, _I, _I, _P, _P]),
     "dm_patch_pyramid_cols": (_I, [_P, _I, _I, _I, _P, _P, _I, _I, _I, _I, _I, _P, _I, _P]),
+    "dm_pair_batch_gather": (_I, [_P, _I, _I, _I, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _I, _P, _P, _P, _P]),
     "dm_label_stats": (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
     "dm_label_features": (_I, [_P, _P, _P, _P, _P, _I, _I, _P, _P]),
     "dm_rag_edges": (_I, [_P, _I, _I, _I, _P, _P, _I, _P, _P, _I, _P, _P, _P]),
@@ -155,8 +156,8 @@ def lib() -> C.CDLL:
                 raise DeepMergeLibraryError(f"{LIB_PATH} does not export {name}") from e
             fn.restype = res
             fn.argtypes = args
-        if handle.dm_abi_version() != 4:
-            raise DeepMergeLibraryError(f"ABI version mismatch: library {handle.dm_abi_version()} != 4")
+        if handle.dm_abi_version() != 5:
+            raise DeepMergeLibraryError(f"ABI version mismatch: library {handle.dm_abi_version()} != 5")
         _lib = handle
         return _lib
 

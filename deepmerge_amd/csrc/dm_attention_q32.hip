@@ -43,15 +43,21 @@
 #ifndef DMQ_ABL
 #define DMQ_ABL 0
 #endif
+#ifndef DMQ_PRIO_FLIP
+#define DMQ_PRIO_FLIP 1
+#endif
 
 // -DDMQ_STAMP: wave 0 of every workgroup stamps s_memtime at six points of each of its first 8 samples into a __device__ array
 // (diagnostic build only: tools/q32_stamps.py reads it through dm_debug_q32_stamps)
 #ifdef DMQ_STAMP
 __device__ unsigned long long dmq_stamps[512 * 8 * 8];
 #define DMQ_T(i) do { if (wave == 0 && lane == 0 && (b - b0) < 8 && blockIdx.x < 512) dmq_stamps[(blockIdx.x * 8 + (b - b0)) * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+// chip-wide 100 MHz clock at kernel entry (k = 0), in front of the unit loop (1) and at kernel exit (2): slot 7 of units 0 / 1 / 2
+#define DMQ_RT(k) do { if (wave == 0 && lane == 0 && blockIdx.x < 512) dmq_stamps[(blockIdx.x * 8 + (k)) * 8 + 7] = __builtin_amdgcn_s_memrealtime(); } while (0)
 extern "C" int dm_debug_q32_stamps(unsigned long long *out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(dmq_stamps), sizeof(dmq_stamps)); }
 #else
 #define DMQ_T(i) do { } while (0)
+#define DMQ_RT(k) do { } while (0)
 #endif
 
 namespace dmq32 {
@@ -73,6 +79,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void attn_fwd_q32_kernel(const Att
   extern __shared__ __attribute__((aligned(16))) char smem[];      // [2 buffers][K image | V image] | 4 x write-back block
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  DMQ_RT(0);
   const int r = lane & 31, hh = lane >> 5;
   // Work units are (head, sample) pairs, u = head * B + sample.  4 waves: a workgroup owns one row block of one head for a chunk of
   // samples (`coords`).  8 waves (RUNS: the workgroup covers all rows of a unit, nothing is shared between workgroups): the units are
@@ -137,16 +144,29 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void attn_fwd_q32_kernel(const Att
   constexpr int TAB_MAXC = 15 * ((NKT - 1) >> 1) + 7;               // largest (15 kz + ky) of a key
   float *tab = reinterpret_cast<float *>(smem + 4 * IMG + (DIRECT ? 0 : NW * WB_WAVE));
   const float *tabl = tab;
-  auto fill_table = [&](int hd) {                                   // every thread; a barrier must follow before the table is read
+  // Two phases: the global loads of the FIRST table are issued behind the first unit's K / V / Q transfers and land under them (as one
+  // loop in front of the staging the fill was three dependent memory round trips: 3.9 us from kernel entry to the unit loop, r05 stamps)
+  constexpr int TAB_N = (NKT - 1) * 225, TAB_IT = (TAB_N + 64 * NW - 1) / (64 * NW);
+  float tv[TAB ? TAB_IT : 1];
+  auto load_table = [&](int hd) {
+#pragma unroll
+    for (int k = 0; k < TAB_IT; ++k) {
+      const int i = t + k * 64 * NW;
+      tv[k] = i < TAB_N ? p.table[(long long)i * H + hd] : 0.f;
+    }
+  };
+  auto store_table = [&]() {                                        // every thread; a barrier must follow before the table is read
     const float inv_scale = 1.f / p.scale;
-    for (int i = t; i < (NKT - 1) * 225; i += 64 * NW) {
+#pragma unroll
+    for (int k = 0; k < TAB_IT; ++k) {
+      const int i = t + k * 64 * NW;
       const int pz = i / 225, rem = i - pz * 225, py = rem / 15, px = rem - py * 15;
-      tab[(pz * 15 + py) * 16 + (14 - px)] = p.table[(long long)i * H + hd] * inv_scale;
+      if (i < TAB_N) tab[(pz * 15 + py) * 16 + (14 - px)] = tv[k] * inv_scale;
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   };
+  auto fill_table = [&](int hd) { load_table(hd); store_table(); };
   if constexpr (TAB) {
-    fill_table(h);                                                  // (visible to the other waves behind the first unit's barrier)
     const int qz = q >> 6, qy = (q >> 3) & 7, qx = q & 7;
     tabl = tab + ((qz + NKT / 2 - 1) * 15 + qy + 7 - TAB_MAXC) * 16 + 7 - qx + 4 * hh;
   }
@@ -247,12 +267,16 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void attn_fwd_q32_kernel(const Att
   u32x4 qf[4], qld[4];                                              // qld: the next sample's rows, requested late in this sample
   stage_all(u0, 0);
   load_q(u0, qld);
+  if constexpr (TAB) load_table(h);
+  DMQ_RT(1);
   for (int b = u0; b < u1; ++b) {                                   // b: the unit (head * B + sample)
     const int b0 = u0, b1 = u1;
     const int buf = (b - b0) & 1;
     DMQ_T(0);
+    if (DMQ_PRIO_FLIP && NW == 8 && wave >= 4) __builtin_amdgcn_s_setprio(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // this sample's K / V / Q have landed (issued during the previous sample)
     DMQ_T(1);
+    if (TAB && b == u0) store_table();                              // (visible to the other waves behind the barrier)
     __builtin_amdgcn_s_barrier();                                   // ... for every wave; and everyone is done with the other buffer
     DMQ_T(2);
     if constexpr (RUNS) {
@@ -402,6 +426,10 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void attn_fwd_q32_kernel(const Att
 #pragma unroll
       for (int j = 0; j < NKT; ++j) {
         if (j == 4) DMQ_T(4);
+        // Two waves per SIMD: the older one (waves 0-3) wins the issue arbitration and reached the unit's barrier ~2700 cycles before its
+        // partner (stamps, profiles/r05_attn_fwd_stamps.txt).  The younger half takes priority for the second half of the tiles, so the
+        // two finish together (-DDMQ_PRIO_FLIP=0 for A/B builds).
+        if (DMQ_PRIO_FLIP && NW == 8 && j == NKT / 2 && wave >= 4) __builtin_amdgcn_s_setprio(1);
         // iteration j, ten MFMA gaps: QK^T(j + 1) x 4, row sums(j - 1) x 2, P.V(j - 1) x 4, with tile j's VALU pipeline between them
         f32x16 &sc = (j & 1) ? s1 : s0;                              // tile j's scores; tile j + 1 accumulates into sn
         f32x16 &sn = (j & 1) ? s0 : s1;
@@ -508,6 +536,10 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void attn_fwd_q32_kernel(const Att
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   if constexpr (!DIRECT) flush(u1 - 1);
+#ifdef DMQ_STAMP
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  DMQ_RT(2);
+#endif
 }
 
 inline void grid(int B, int N, int H, int rows, int &nblk, int &chunks, int &bchunk) {

@@ -158,16 +158,28 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void attn_bwd_dq_q32_kernel(const 
   constexpr int TAB_MAXC = 15 * ((NKT - 1) >> 1) + 7;
   float *tab = reinterpret_cast<float *>(smem + 4 * IMG + (DIRECT ? 0 : NW * WB_WAVE));
   const float *tabl = tab;
-  auto fill_table = [&](int hd) {                                   // every thread; a barrier must follow before the table is read
+  // (two phases, as in the forward kernel: the first table's loads fly under the first unit's transfers)
+  constexpr int TAB_N = (NKT - 1) * 225, TAB_IT = (TAB_N + 64 * NW - 1) / (64 * NW);
+  float tv[TAB ? TAB_IT : 1];
+  auto load_table = [&](int hd) {
+#pragma unroll
+    for (int k = 0; k < TAB_IT; ++k) {
+      const int i = t + k * 64 * NW;
+      tv[k] = i < TAB_N ? p.table[(long long)i * H + hd] : 0.f;
+    }
+  };
+  auto store_table = [&]() {                                        // every thread; a barrier must follow before the table is read
     const float inv_scale = 1.f / p.scale;
-    for (int i = t; i < (NKT - 1) * 225; i += 64 * NW) {
+#pragma unroll
+    for (int k = 0; k < TAB_IT; ++k) {
+      const int i = t + k * 64 * NW;
       const int pz = i / 225, rem = i - pz * 225, py = rem / 15, px = rem - py * 15;
-      tab[(pz * 15 + py) * 16 + (14 - px)] = p.table[(long long)i * H + hd] * inv_scale;
+      if (i < TAB_N) tab[(pz * 15 + py) * 16 + (14 - px)] = tv[k] * inv_scale;
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   };
+  auto fill_table = [&](int hd) { load_table(hd); store_table(); };
   if constexpr (TAB) {
-    fill_table(h);
     const int qz = q >> 6, qy = (q >> 3) & 7, qx = q & 7;
     tabl = tab + ((qz + NKT / 2 - 1) * 15 + qy + 7 - TAB_MAXC) * 16 + 7 - qx + 4 * hh;
   }
@@ -213,10 +225,12 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void attn_bwd_dq_q32_kernel(const 
   float lse_ld = 0.f;
   stage_all(u0, 0);
   load_rows(u0, qld, dold, old, lse_ld);
+  if constexpr (TAB) load_table(h);
   for (int b = u0; b < u1; ++b) {                                   // b: the unit (head * B + sample)
     const int b0 = u0, b1 = u1;
     const int buf = (b - b0) & 1;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (TAB && b == u0) store_table();
     __builtin_amdgcn_s_barrier();
     if constexpr (RUNS) {
       const int hn = b / p.B;
@@ -748,13 +762,10 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_tab_kernel(const AttnPipe
   char *stat0 = smem + 4 * IMG;
   char *wb = smem + 4 * IMG + 2 * STAT + wave * WB_WAVE;
   float *tab = reinterpret_cast<float *>(smem + 4 * IMG + 2 * STAT + NW * WB_WAVE);
-  {                                                                 // the head's table, natural order: row (dz + S - 1) * 15 + dy + 7, entry dx + 7
-    const float inv_scale = 1.f / p.scale;
-    for (int i = t; i < (NKT - 1) * 225; i += 256) {
-      const int prow = i / 15, px = i - prow * 15;
-      tab[prow * 16 + px] = p.table[(long long)i * H + h] * inv_scale;
-    }
-  }
+  // the head's table, natural order: row (dz + S - 1) * 15 + dy + 7, entry dx + 7 -- loaded behind the first sample's transfers, written
+  // to LDS in front of the first barrier (in front of the staging the fill cost its memory round trips in full)
+  constexpr int TAB_N = (NKT - 1) * 225, TAB_IT = (TAB_N + 255) / 256;
+  float tv[TAB_IT];
   const int kz = key >> 6, ky = (key >> 3) & 7, kx = key & 7;
   const float *tabl = tab + (wave_live ? ((NKT / 2 - 1 - kz) * 15 + 7 - ky) * 16 + 4 * hh - kx + 7 : 0);
   // selection matrices of the table-gradient accumulation: E_s[row][k] = 1 where row = 16 s + 8 (i >> 2) + 4 hh + (i & 3), k = 8 hh + i
@@ -784,9 +795,23 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_tab_kernel(const AttnPipe
     for (int j = 0; j < NKT; ++j) stage_piece(rq, rd, 0, j);
   }
   load_rows(b0, kld, vld, lse_ld, dl_ld);
+#pragma unroll
+  for (int k = 0; k < TAB_IT; ++k) {
+    const int i = t + k * 256;
+    tv[k] = i < TAB_N ? p.table[(long long)i * H + h] : 0.f;
+  }
   for (int b = b0; b < b1; ++b) {
     const int buf = (b - b0) & 1;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (b == b0) {
+      const float inv_scale = 1.f / p.scale;
+#pragma unroll
+      for (int k = 0; k < TAB_IT; ++k) {
+        const int i = t + k * 256;
+        const int prow = i / 15, px = i - prow * 15;
+        if (i < TAB_N) tab[prow * 16 + px] = tv[k] * inv_scale;
+      }
+    }
     if (sq < NP) {
       float *st = reinterpret_cast<float *>(stat0 + buf * STAT);
       st[sq] = -lse_ld * LOG2E;

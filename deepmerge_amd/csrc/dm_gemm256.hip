@@ -632,7 +632,8 @@ void dm_gemm256_launch(const GemmParams &p_in, int layout, hipStream_t s) {
     const long long tiles = (long long)p.tiles_m * p.tiles_n;
     const bool rows_ok = (p.N % 8 == 0) && (p.ldc % 8 == 0) && (p.aux == nullptr || p.ldaux % 8 == 0) && (p.rows_per_group == 0 || p.group_stride % 8 == 0) &&
                          (p.residual == nullptr || p.ldr % 8 == 0);
-    if (pmode != 0 && layout != DM_TN && p.split_k <= 1 && cus > 0 && (tiles > cus || pmode == 2) && p.N % 256 == 0 && p.K % BK256 == 0 && rows_ok &&
+    // (the persistent kernel has no folded-contraction / plane-pair forms: such a launch stays on gemm256_kernel<.., true>)
+    if (pmode != 0 && layout != DM_TN && p.k_fold == 0 && p.c_dtype != DM_BF16_PAIR && p.split_k <= 1 && cus > 0 && (tiles > cus || pmode == 2) && p.N % 256 == 0 && p.K % BK256 == 0 && rows_ok &&
         dm_epi_key_specialised(dm_epi_lean_key(p, 128))) {
       static const bool attr_ok = set_lds_limit_p<DM_NT>() && set_lds_limit_p<DM_NN>();
       if (attr_ok) {

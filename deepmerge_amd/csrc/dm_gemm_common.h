@@ -318,10 +318,34 @@ __device__ __forceinline__ void dm_epilogue_rows_generic(const GemmParams &p, f3
 #ifndef DM_EPI_LOAD_POLICY
 #define DM_EPI_LOAD_POLICY 2
 #endif
+// Experiment builds (tools/epi_store_hazard.sh, profiles/r05_epi_store_hazard.txt): -DDM_EPI_SOFF_V=1 adds the scalar row step to the
+// VECTOR offset and leaves soffset 0 -- the form for which LLVM's hazard recogniser pads a > 64-bit MUBUF store followed by a VALU
+// write of its data registers (it deliberately does not when soffset is a register) -- and -DDM_EPI_STORE_PAD=n picks the pad
+// behind the store (0 none, 1 / 2 / 4 / 8 cycles ... via s_nop).
+#ifndef DM_EPI_SOFF_V
+#define DM_EPI_SOFF_V 0
+#endif
+#ifdef DM_EPI_STORE_PAD
+#undef DM_EPI_STORE_NOP
+#if DM_EPI_STORE_PAD == 0
+#define DM_EPI_STORE_NOP ""
+#elif DM_EPI_STORE_PAD == 1
+#define DM_EPI_STORE_NOP "s_nop 0"
+#elif DM_EPI_STORE_PAD == 2
+#define DM_EPI_STORE_NOP "s_nop 1"
+#elif DM_EPI_STORE_PAD == 4
+#define DM_EPI_STORE_NOP "s_nop 3"
+#elif DM_EPI_STORE_PAD == 8
+#define DM_EPI_STORE_NOP "s_nop 7"
+#else
+#define DM_EPI_STORE_NOP "s_nop 7\n\ts_nop 7"
+#endif
+#endif
 #define DM_EPI_BSTORE(data, rsrc, vo, so, aux)                                  \
   do {                                                                          \
     const u32x4 dm_bs_ = (data);                                                \
-    __builtin_amdgcn_raw_buffer_store_b128(dm_bs_, rsrc, vo, so, (aux) | DM_EPI_STORE_AUX); \
+    if (DM_EPI_SOFF_V) __builtin_amdgcn_raw_buffer_store_b128(dm_bs_, rsrc, (vo) + (unsigned)(so), 0, (aux) | DM_EPI_STORE_AUX); \
+    else __builtin_amdgcn_raw_buffer_store_b128(dm_bs_, rsrc, vo, so, (aux) | DM_EPI_STORE_AUX); \
     asm volatile(DM_EPI_STORE_NOP ::"v"(dm_bs_) : "memory");                    \
   } while (0)
 struct DmEpiPre { f32x4 r0, r1; u32x4 y0, y1; };      // residual; the old C (accumulate) OR the aux operand (never both: see dm_epilogue_rows)

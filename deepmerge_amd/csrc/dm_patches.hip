@@ -100,18 +100,57 @@ __device__ __forceinline__ int cv_area_pixel(const unsigned char *win, int L, in
   return min(255, max(0, v));
 }
 
+// The sample table of a training batch (dm_pair_batch_gather; all pointers null for the single-tile entry points): the tile a sample
+// is cut from, its inner / object window sides -- the four window sides of MyUtils1.py:130-156 are derived here, `scale_index` picks
+// one -- and, in the blocks of band 0, the designed-feature row [15 region attributes | 4 scale factors] (MyUtils1.py:60-77).  A sample
+// whose tile id or window is out of range gets zeros and raises `err[0]` (read back by the host every few steps, not per step).
+struct BatchTable {
+  const int *tile_id, *inner, *obj;
+  const float *region;
+  float *designed;
+  int *err;
+  int n_tiles, scale_index, max_window;
+};
+
 template <int TLOG2, typename OUT, bool COLS>
 __global__ __launch_bounds__(256) void patch_pyramid_kernel(const unsigned char *__restrict__ tile, int bands, int H, int W,
                                                             const int *__restrict__ xy, const int *__restrict__ wins,
-                                                            int Trt, int G, OUT *__restrict__ out, int rule) {
+                                                            int Trt, int G, OUT *__restrict__ out, int rule, const BatchTable bt) {
   extern __shared__ unsigned char win[];
   const int T = TLOG2 >= 0 ? (1 << TLOG2) : Trt;
   auto divT = [&](int v) { return TLOG2 >= 0 ? (v >> TLOG2) : v / T; };
   const int p = blockIdx.x, c = blockIdx.y, t = threadIdx.x;
-  const int L = wins[p];
+  int L, tid = 0;
+  if (bt.inner) {
+    const int in = bt.inner[p], ob = bt.obj[p], iv = ob - in;
+    L = bt.scale_index == 0 ? in : ob + (bt.scale_index - 1) * iv;
+    tid = bt.tile_id ? bt.tile_id[p] : 0;
+    if (c == 0 && bt.designed && t < 19) {
+      const int k = t - 15;
+      const float wk = (float)(k == 0 ? in : ob + (k - 1) * iv);
+      const float sk = k == 0 ? 32.f : k == 1 ? 64.f : k == 2 ? 128.f : 1.f;          // config.py:32 (patches.CONFIG_SCALES)
+      bt.designed[(long long)p * 19 + t] = t < 15 ? bt.region[(long long)p * 15 + t] : __fdiv_rn(wk, sk);
+    }
+    if (L <= 0 || L > bt.max_window || tid < 0 || tid >= bt.n_tiles) {                 // (uniform per block)
+      if (t == 0 && bt.err) atomicOr(bt.err, 1);
+      const int ps0 = COLS ? T / G : 1;
+      const long long Kc0 = (long long)bands * ps0 * ps0;
+      for (int o = t; o < T * T; o += 256) {
+        if constexpr (COLS) {
+          const int oy = divT(o), ox = o - oy * T, py = oy / ps0, dy = oy - py * ps0, px = ox / ps0, dx = ox - px * ps0;
+          out[(((long long)p * G + py) * G + px) * Kc0 + ((long long)c * ps0 + dy) * ps0 + dx] = (OUT)0.f;
+        } else {
+          out[((long long)p * bands + c) * T * T + o] = (OUT)0.f;
+        }
+      }
+      return;
+    }
+  } else {
+    L = wins[p];
+  }
   const int mx = xy[2 * p], my = xy[2 * p + 1];
   const int x0 = (2 * mx - L) / 2, y0 = (2 * my - L) / 2;     // int(mid - L/2): truncation toward zero
-  const unsigned char *band = tile + (long long)c * H * W;
+  const unsigned char *band = tile + ((long long)tid * bands + c) * H * W;
   // window -> LDS, row by row: a wave walks along a row (coalesced bytes), no per-element division
   for (int j = t >> 6; j < L; j += 4) {
     const int gy = y0 + j;
@@ -171,16 +210,50 @@ __global__ __launch_bounds__(256) void patch_pyramid_kernel(const unsigned char 
 namespace {
 template <typename OUT, bool COLS>
 void launch_pyramid(dim3 grid, size_t lds, hipStream_t s, const uint8_t *tile, int bands, int H, int W, const int32_t *xy, const int32_t *windows,
-                    int target, int G, OUT *out, int rule) {
+                    int target, int G, OUT *out, int rule, const BatchTable bt = BatchTable{}) {
   switch (target) {
-    case 32: hipLaunchKernelGGL((patch_pyramid_kernel<5, OUT, COLS>), grid, dim3(256), lds, s, tile, bands, H, W, xy, windows, target, G, out, rule); break;
-    case 64: hipLaunchKernelGGL((patch_pyramid_kernel<6, OUT, COLS>), grid, dim3(256), lds, s, tile, bands, H, W, xy, windows, target, G, out, rule); break;
-    case 128: hipLaunchKernelGGL((patch_pyramid_kernel<7, OUT, COLS>), grid, dim3(256), lds, s, tile, bands, H, W, xy, windows, target, G, out, rule); break;
-    case 256: hipLaunchKernelGGL((patch_pyramid_kernel<8, OUT, COLS>), grid, dim3(256), lds, s, tile, bands, H, W, xy, windows, target, G, out, rule); break;
-    default: hipLaunchKernelGGL((patch_pyramid_kernel<-1, OUT, COLS>), grid, dim3(256), lds, s, tile, bands, H, W, xy, windows, target, G, out, rule); break;
+    case 32: hipLaunchKernelGGL((patch_pyramid_kernel<5, OUT, COLS>), grid, dim3(256), lds, s, tile, bands, H, W, xy, windows, target, G, out, rule, bt); break;
+    case 64: hipLaunchKernelGGL((patch_pyramid_kernel<6, OUT, COLS>), grid, dim3(256), lds, s, tile, bands, H, W, xy, windows, target, G, out, rule, bt); break;
+    case 128: hipLaunchKernelGGL((patch_pyramid_kernel<7, OUT, COLS>), grid, dim3(256), lds, s, tile, bands, H, W, xy, windows, target, G, out, rule, bt); break;
+    case 256: hipLaunchKernelGGL((patch_pyramid_kernel<8, OUT, COLS>), grid, dim3(256), lds, s, tile, bands, H, W, xy, windows, target, G, out, rule, bt); break;
+    default: hipLaunchKernelGGL((patch_pyramid_kernel<-1, OUT, COLS>), grid, dim3(256), lds, s, tile, bands, H, W, xy, windows, target, G, out, rule, bt); break;
   }
 }
 }  // namespace
+
+// One scale of a TRAINING batch straight from resident tiles and a device sample table: no host-side window arithmetic, no per-tile
+// launches, nothing to synchronise on (Train_SMT.py:212-262 draws a batch from the loaders of MyUtils1.py:41-77 on the host).
+extern "C" int dm_pair_batch_gather(const uint8_t *tiles, int32_t n_tiles, int32_t bands, int32_t H, int32_t W, const int32_t *tile_id,
+                                    const int32_t *xy, const int32_t *inner, const int32_t *obj, int32_t scale_index, int32_t max_window,
+                                    int32_t P, int32_t target, int32_t grid, int32_t resize_rule, void *out, int32_t dtype,
+                                    const float *region_features, float *designed, int32_t *error_flag, void *stream) {
+  DM_REQUIRE(resize_rule == DM_RESIZE_OPENCV || resize_rule == DM_RESIZE_EXACT_AREA, DM_ERR_UNSUPPORTED, "dm_pair_batch_gather: unknown resize rule %d", resize_rule);
+  DM_REQUIRE(tiles && xy && inner && obj && out && n_tiles > 0 && bands > 0 && H > 0 && W > 0 && P > 0 && target > 0, DM_ERR_BAD_SHAPE,
+             "dm_pair_batch_gather: bad arguments");
+  DM_REQUIRE(scale_index >= 0 && scale_index < 4, DM_ERR_BAD_SHAPE, "dm_pair_batch_gather: scale index %d outside 0..3", scale_index);
+  DM_REQUIRE(grid >= 0 && (grid == 0 || target % grid == 0), DM_ERR_BAD_SHAPE, "dm_pair_batch_gather: target %d is not a multiple of the token grid %d", target, grid);
+  DM_REQUIRE(max_window > 0 && max_window <= MAX_WINDOW, DM_ERR_UNSUPPORTED, "dm_pair_batch_gather: window bound %d outside 1..%d", max_window, MAX_WINDOW);
+  DM_REQUIRE(bands <= 65535, DM_ERR_BAD_SHAPE, "dm_pair_batch_gather: too many bands");
+  DM_REQUIRE((designed == nullptr) == (region_features == nullptr), DM_ERR_BAD_SHAPE, "dm_pair_batch_gather: designed rows need the region features (and vice versa)");
+  BatchTable bt;
+  bt.tile_id = tile_id; bt.inner = inner; bt.obj = obj; bt.region = region_features; bt.designed = designed; bt.err = error_flag;
+  bt.n_tiles = n_tiles; bt.scale_index = scale_index; bt.max_window = max_window;
+  const dim3 g(P, bands);
+  const size_t lds = (size_t)max_window * max_window;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (grid == 0) {
+    DM_REQUIRE(dtype == DM_F32, DM_ERR_BAD_DTYPE, "dm_pair_batch_gather: planar patches are fp32");
+    launch_pyramid<float, false>(g, lds, s, tiles, bands, H, W, xy, nullptr, target, 1, reinterpret_cast<float *>(out), resize_rule, bt);
+  } else if (dtype == DM_BF16) {
+    launch_pyramid<bf16_t, true>(g, lds, s, tiles, bands, H, W, xy, nullptr, target, grid, reinterpret_cast<bf16_t *>(out), resize_rule, bt);
+  } else if (dtype == DM_F32) {
+    launch_pyramid<float, true>(g, lds, s, tiles, bands, H, W, xy, nullptr, target, grid, reinterpret_cast<float *>(out), resize_rule, bt);
+  } else {
+    DM_REQUIRE(false, DM_ERR_BAD_DTYPE, "dm_pair_batch_gather: bad dtype %d", dtype);
+  }
+  DM_LAUNCH_CHECK("dm_pair_batch_gather");
+  return DM_OK;
+}
 
 extern "C" int dm_patch_pyramid(const uint8_t *tile, int32_t bands, int32_t H, int32_t W, const int32_t *xy, const int32_t *windows,
                                 int32_t max_window, int32_t P, int32_t target, int32_t resize_rule, float *out, void *stream) {

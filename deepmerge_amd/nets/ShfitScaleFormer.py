@@ -365,7 +365,7 @@ class ShfitScaleFormer_v3(nn.Module):
         S = self.input_scales_num
         if self.training:
             B = x1_patches[0].shape[0]
-            both = [torch.cat((x1_patches[i], x2_patches[i]), 0) for i in range(S)]
+            both = [ops.cat_batch(x1_patches[i], x2_patches[i]) for i in range(S)]
             if self.is_designed_feature_embedding:
                 f = self.forward_once_design_feature(both, torch.cat((x1_designed_features, x2_designed_features), 0))
             else:
@@ -565,7 +565,7 @@ class ShfitScaleFormer_v4(ShfitScaleFormer_v3):
         if not self.training:
             return self._encode(x1_patches, x1_designed_features, 1)[0]
         B = x1_patches[0].shape[0]
-        both = [torch.cat((x1_patches[i], x2_patches[i]), 0) for i in range(self.input_scales_num)]
+        both = [ops.cat_batch(x1_patches[i], x2_patches[i]) for i in range(self.input_scales_num)]
         d = torch.cat((x1_designed_features, x2_designed_features), 0) if self.is_designed_feature_embedding else None
         y, aux0, aux1 = self._encode(both, d, 2)
         return (y[:B], aux0[0], aux1[0]), (y[B:], aux0[1], aux1[1])

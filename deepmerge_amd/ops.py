@@ -29,6 +29,7 @@ _NUMERICS = "bf16"
 NUMERICS_MODES = ("bf16", "fp32", "bf16x3")
 _FP32_PRODUCTS = "mfma_f32"     # how gemm() multiplies fp32 operands: "mfma_f32" (exact fmaf chains) or "bf16x3" (split-bf16)
 _SPLIT_MIN_WORK = 1 << 24       # products below this many multiply-adds stay on the fp32 MFMA kernel
+_PAIR_LN_MAX_COLS = 1024        # widest row dm_layernorm_fwd(DM_BF16_PAIR) / dm_layernorm_bwd_partials_pair take (csrc/dm_rows.hip, MAXCH)
 
 
 def set_numerics(mode: str) -> None:
@@ -714,6 +715,56 @@ class PatchCols:
     def to(self, *_a, **_k):
         return self
 
+    @staticmethod
+    def cat(a: "PatchCols", b: "PatchCols") -> "PatchCols":
+        """[a; b] along the batch (what torch.cat((x1, x2), 0) is for image tensors).  Two halves of one buffer -- the trainer's
+        static step inputs, the rows a feed wrote for both sides -- are joined without a copy."""
+        if (a.side, a.patch, a.bands, a.cols.dtype) != (b.side, b.patch, b.bands, b.cols.dtype):
+            raise ValueError("PatchCols.cat: the two sides were built for different scales / dtypes")
+        ca, cb = a.cols, b.cols
+        if (ca.is_contiguous() and cb.is_contiguous() and ca.untyped_storage().data_ptr() == cb.untyped_storage().data_ptr()
+                and cb.data_ptr() == ca.data_ptr() + ca.numel() * ca.element_size()):
+            both = ca.as_strided((ca.shape[0] + cb.shape[0], ca.shape[1]), (ca.shape[1], 1), ca.storage_offset())
+        else:
+            both = torch.cat((ca, cb), 0)
+        return PatchCols(both, a.batch + b.batch, a.side, a.patch, a.bands)
+
+
+def cat_batch(a, b):
+    """[a; b] along the batch for image tensors or PatchCols (the two sides of a pair batch)."""
+    if isinstance(a, PatchCols) or isinstance(b, PatchCols):
+        return PatchCols.cat(a, b)
+    return torch.cat((a, b), 0)
+
+
+def pair_batch_gather(tiles: torch.Tensor, tile_id: Optional[torch.Tensor], xy: torch.Tensor, inner: torch.Tensor, obj: torch.Tensor,
+                      scale_index: int, target: int, max_window: int, out: torch.Tensor, grid: int = 0, resize: str = "opencv",
+                      region_features: Optional[torch.Tensor] = None, designed: Optional[torch.Tensor] = None,
+                      error_flag: Optional[torch.Tensor] = None) -> None:
+    """One scale of a training batch, gathered into `out` from resident tiles and a device sample table (dm_pair_batch_gather):
+    no host-side window arithmetic, no synchronisation.  tiles uint8 [T, bands, H, W]; tile_id / inner / obj int32 [P]; xy int32
+    [P, 2]; out: float32 [P, bands, target, target] (grid = 0) or the patch-embed rows [P * grid^2, bands * (target / grid)^2]
+    (bf16 / fp32) -- e.g. the trainer's static step inputs.  region_features [P, 15] + designed [P, 1, 19]: also writes the
+    designed-feature rows.  error_flag int32 [1]: set when a sample's tile id / window is out of range (read it with the loss)."""
+    _need_cuda(tiles, tile_id, xy, inner, obj, out, region_features, designed, error_flag)
+    if tiles.dtype != torch.uint8 or tiles.dim() != 4 or not tiles.is_contiguous():
+        raise ValueError("tiles must be a contiguous uint8 [T, bands, H, W] tensor")
+    for name, t in (("tile_id", tile_id), ("xy", xy), ("inner", inner), ("obj", obj), ("error_flag", error_flag)):
+        if t is not None and (t.dtype != torch.int32 or not t.is_contiguous()):
+            raise ValueError(f"{name} must be a contiguous int32 tensor (a per-step cast would be a launch of its own)")
+    T, bands, H, W = tiles.shape
+    P = xy.shape[0]
+    if not out.is_contiguous() or out.numel() != P * bands * target * target:
+        raise ValueError(f"out must be contiguous with {P * bands * target * target} elements, got {tuple(out.shape)}")
+    if (region_features is None) != (designed is None):
+        raise ValueError("designed rows need the region features (and vice versa)")
+    if designed is not None and (designed.dtype != torch.float32 or designed.numel() != P * 19 or not designed.is_contiguous()
+                                 or region_features.dtype != torch.float32 or region_features.numel() != P * 15 or not region_features.is_contiguous()):
+        raise ValueError("region_features must be contiguous float32 [P, 15] and designed contiguous float32 [P, 1, 19]")
+    check(_lib.lib().dm_pair_batch_gather(tiles.data_ptr(), T, bands, H, W, _ptr(tile_id), xy.data_ptr(), inner.data_ptr(), obj.data_ptr(),
+                                          scale_index, max_window, P, target, grid, _resize_rule(resize), out.data_ptr(), _dt(out),
+                                          _ptr(region_features), _ptr(designed), _ptr(error_flag), _stream()), "dm_pair_batch_gather")
+
 
 def patch_pyramid_cols(tile: torch.Tensor, xy: torch.Tensor, windows: torch.Tensor, target: int, grid: int = 8,
                        dtype: torch.dtype = torch.bfloat16, max_window: Optional[int] = None, resize: str = "opencv") -> PatchCols:
@@ -1373,8 +1424,10 @@ class BlockFn(torch.autograd.Function):
         # all its consumers -- the forward product, and in the backward pass the weight gradient (as the right operand) or both the
         # weight gradient and the data gradient (dy, as the left operand).  12 splits per block and step instead of 24, two pieces
         # written per split instead of three, and the saved activations ARE the plane pairs (same bytes as the fp32 tensors).
+        # (Cc <= 1024: the LayerNorm kernels write / take the pair only for rows that fit their register form -- ViT-H's 1280-wide
+        # rows keep fp32 activations and per-use splits)
         planes = (dtype == torch.float32 and _FP32_PRODUCTS == "bf16x3" and planes_ok(M, Cc) and planes_ok(M, Hd) and planes_ok(Hd, Cc)
-                  and M * Cc * Cc >= _SPLIT_MIN_WORK)
+                  and Cc <= _PAIR_LN_MAX_COLS and M * Cc * Cc >= _SPLIT_MIN_WORK)
         if planes:
             wq, wp, w1, w2 = (split_planes(w) for w in (wq, wp, w1, w2))
         y1, mean1, rstd1 = layernorm_fwd(x2d, n1w, n1b, eps, dtype, pair=planes)

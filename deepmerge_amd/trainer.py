@@ -360,13 +360,22 @@ class PairTrainer:
             return None
         return st["left"], st["ld"], st["right"], st["rd"], st["flag"]
 
+    def graph_inputs_both(self):
+        """(both, designed_both, flag) of the captured step for models that take the two sides stacked along the batch ([left; right],
+        2B samples; the v3 family): the buffers a feed fills in ONE gather launch per scale (deepmerge_amd/feed.py).  None before
+        capture or for other models."""
+        st = self._graph
+        if not st or st.get("g") is None or st.get("both") is None:
+            return None
+        return st["both"], st["dboth"], st["flag"]
+
     def _static_inputs(self, st, left, left_designed, right, right_designed, flag):
         # models that take the two sides pre-stacked ([left; right] along the batch) get static buffers of that form, so
         # the step's inputs are copied once and the captured graph holds no torch.cat
         batched = type(self.net).__dict__.get("forward_pair_batched") is not None or \
             (hasattr(self.net, "forward_pair_batched") and type(self.net).forward is _v3_forward())
         if batched:
-            both = [torch.cat((l, r), 0) for l, r in zip(left, right)]
+            both = [ops.cat_batch(l, r) for l, r in zip(left, right)]      # (image tensors or ops.PatchCols: patch-embed rows from a feed)
             Bp = left[0].shape[0]
             st["left"], st["right"] = [t[:Bp] for t in both], [t[Bp:] for t in both]
             st["both"] = both
@@ -377,6 +386,8 @@ class PairTrainer:
                 st["dboth"] = st["ld"] = st["rd"] = None
         else:
             st["both"] = None
+            if any(isinstance(t, ops.PatchCols) for t in list(left) + list(right)):
+                raise ValueError("ops.PatchCols inputs need a model with forward_pair_batched (the v3 family)")
             st["left"] = [t.clone() for t in left]
             st["right"] = [t.clone() for t in right]
             st["ld"] = None if left_designed is None else left_designed.clone()
@@ -506,6 +517,10 @@ class PairTrainer:
         if [tuple(t.shape) for t in list(left) + list(right)] != st["shapes"]:
             raise ValueError("graph replay needs the input shapes it was captured with; call enable_graph() again for a new batch size")
         def put(dst, src):                                    # a loader that fills graph_inputs() directly pays no copy
+            if isinstance(dst, ops.PatchCols) or isinstance(src, ops.PatchCols):
+                if not (isinstance(dst, ops.PatchCols) and isinstance(src, ops.PatchCols)):
+                    raise ValueError("the step was captured with patch-embed rows (ops.PatchCols) for this input: pass the same kind")
+                dst, src = dst.cols, src.cols
             if src is not dst and (src.data_ptr() != dst.data_ptr() or src.dtype != dst.dtype):
                 dst.copy_(src, non_blocking=True)
         for dst, src in zip(st["left"] + st["right"], list(left) + list(right)):

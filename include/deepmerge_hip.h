@@ -43,7 +43,7 @@ typedef enum {
 
 /* ---- library ------------------------------------------------------------------------- */
 int dm_abi_version(void);   /* 2: dm_patch_pyramid / dm_patch_pyramid_cols take a resize rule; 3: table-reading and split-bf16 attention entry points, dm_split_bf16_colsum (round 3);
-                             * 4: DmGemmArgs.k_fold / a_fold / b_fold, dm_split_bf16_planes (round 4) */
+                             * 4: DmGemmArgs.k_fold / a_fold / b_fold, dm_split_bf16_planes (round 4); 5: dm_pair_batch_gather (round 5) */
 const char *dm_last_error(void);
 /* Name of the code object architecture the library was built for ("gfx950"). */
 const char *dm_arch(void);
@@ -107,8 +107,10 @@ typedef struct {
    * that starts a_fold[s] ELEMENTS behind A -- {0, 0, plane} for the left operand (hi, hi, lo), {0, plane, 0} for the right one
    * (hi, lo, hi), plane = rows * ld of the plane pair.  Every tensor is then split ONCE, whatever side and layout its consumers
    * read it in, and the hi plane is fetched twice from the same addresses instead of being stored twice.
-   * bf16 operands only; k_fold % 64 == 0; 0 <= offsets < 2^30; not with colsum_a (the sums of a split operand belong to the split
-   * pass: dm_split_bf16_planes).  Shapes the folded kernels do not take return DM_ERR_UNSUPPORTED (fall back to dm_split_bf16 images). */
+   * bf16 operands only; k_fold % 64 == 0; 0 <= offsets < 2^30.  With colsum_a (DM_TN) the sums are colsum(hi plane) +
+   * colsum(lo plane) of A, fp32 -- the bias gradient to the accuracy of the folded product itself, NOT the exact fp32 column sum of
+   * the unsplit tensor (the segment that re-reads the hi plane is skipped).  Shapes the folded kernels do not take return
+   * DM_ERR_UNSUPPORTED; nothing falls back inside the library (a caller may split into dm_split_bf16 images and call again). */
   int32_t k_fold;
   int64_t a_fold[3], b_fold[3];
   /* ABI 4: c_dtype == DM_BF16_PAIR writes the result as the hi / lo plane pair a later folded product reads (the split pass of
@@ -349,6 +351,24 @@ int dm_patch_pyramid(const uint8_t *tile, int32_t bands, int32_t H, int32_t W, c
 int dm_patch_pyramid_cols(const uint8_t *tile, int32_t bands, int32_t H, int32_t W, const int32_t *xy, const int32_t *windows,
                           int32_t max_window, int32_t P, int32_t target, int32_t grid, int32_t resize_rule, void *cols, int32_t dtype,
                           void *stream);
+
+/* ---- training feed: one scale of a pair batch from resident tiles and a DEVICE sample table (ABI 5) -----------------------
+ * Replaces, for the training loop, the host-side batch assembly of Train_SMT.py:212-262 (DataLoader items of MyUtils1.py:41-77:
+ * get_scales :130-156, the crop / pad / resize chain :116-223, the designed-feature row :60-77) without any host round trip:
+ * no window arithmetic on the host, no per-tile launches, nothing read back.  Sample p is cut from tile tile_id[p] (tiles uint8
+ * [n_tiles, bands, H, W], tile_id may be NULL: one tile) around pixel xy[p] with the window side the reference derives from
+ * inner[p] / obj[p]: (inner, obj, obj + (obj - inner), obj + 2 (obj - inner))[scale_index].  Same crop / pad / resize arithmetic
+ * and results as dm_patch_pyramid / dm_patch_pyramid_cols, bit for bit.
+ *   grid == 0: out float32 [P, bands, target, target];  grid > 0: out = patch-embed rows [P * grid * grid, bands * ps * ps],
+ *   dtype DM_BF16 / DM_F32 (the layout of dm_patch_pyramid_cols).
+ *   region_features [P, 15] + designed [P, 19] (both or neither): designed[p] = region_features[p] || window sides / (32, 64, 128, 1)
+ *   (patches.CONFIG_SCALES, config.py:32) -- the `designed features` tensor of MyUtils1.py:74-77.
+ *   max_window bounds the LDS staging (<= 384).  A sample whose tile id or window side is out of range produces zeros and sets
+ *   error_flag[0] |= 1 (int32 on the device, may be NULL): the caller reads it when it reads the loss, not per step. */
+int dm_pair_batch_gather(const uint8_t *tiles, int32_t n_tiles, int32_t bands, int32_t H, int32_t W, const int32_t *tile_id,
+                         const int32_t *xy, const int32_t *inner, const int32_t *obj, int32_t scale_index, int32_t max_window,
+                         int32_t P, int32_t target, int32_t grid, int32_t resize_rule, void *out, int32_t dtype,
+                         const float *region_features, float *designed, int32_t *error_flag, void *stream);
 
 /* ---- region-adjacency graph + superpixel statistics from a label raster ---------------------------
  * Replaces, on the device, the inputs the reference reads from files written by external GIS software: the RAG edge

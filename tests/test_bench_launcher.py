@@ -126,3 +126,44 @@ def test_sigterm_to_the_launcher_ends_every_rank(tmp_path):
     while time.time() < deadline and any(alive(x) for x in pids):
         time.sleep(0.1)
     assert not any(alive(x) for x in pids)
+
+
+def test_a_rank_that_exits_early_does_not_leave_its_helper_behind(tmp_path):
+    """the failing rank has ALREADY exited when the launcher tears the job down -- its helper processes (same session)
+    must be ended too, or they keep holding the GPU."""
+    import time
+    child = tmp_path / "child.py"
+    child.write_text(textwrap.dedent(f"""
+        import os, subprocess, sys, time
+        helper = subprocess.Popen([sys.executable, "-c", "import time; time.sleep(300)"])
+        open(os.path.join({str(tmp_path)!r}, "pids.%s" % os.environ["RANK"]), "w").write("%d %d" % (os.getpid(), helper.pid))
+        if os.environ["RANK"] == "1":
+            sys.exit(9)              # leaves its helper running
+        time.sleep(300)
+    """))
+    driver = tmp_path / "driver.py"
+    driver.write_text(textwrap.dedent(f"""
+        import sys
+        sys.path.insert(0, {ROOT!r})
+        import bench
+        raise SystemExit(bench.launch_ranks(2, [], script={str(child)!r}, poll_s=0.05))
+    """))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, str(driver)], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 9
+    pids = [int(x) for rk in (0, 1) for x in (tmp_path / f"pids.{rk}").read_text().split()]
+    assert len(pids) == 4
+
+    def alive(pid):
+        try:
+            os.kill(pid, 0)
+        except ProcessLookupError:
+            return False
+        try:
+            return open(f"/proc/{pid}/stat").read().split(")")[-1].split()[0] != "Z"
+        except FileNotFoundError:
+            return False
+    deadline = time.time() + 10
+    while time.time() < deadline and any(alive(x) for x in pids):
+        time.sleep(0.1)
+    assert not any(alive(x) for x in pids)

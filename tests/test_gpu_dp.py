@@ -230,3 +230,60 @@ def test_extract_features_shards_over_ranks(tmp_path):
     want = _extract(sharded=False).cpu()
     assert got.shape == want.shape == (37, 100)
     assert float((got - want).norm() / want.norm()) < 2e-2
+
+
+_RCCL_CHILD = r"""
+import json, os, sys
+import torch
+import torch.distributed as dist
+ROOT = sys.argv[1]; graph = sys.argv[2] == "1"; out = sys.argv[3]
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+import test_gpu_dp as T
+torch.cuda.set_device(0)
+force = os.environ.get("DM_DP_FORCE") == "1"
+if force:
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+from deepmerge_amd.trainer import PairTrainer
+net = T._build("bf16")
+tr = PairTrainer(net, lr=1e-4)
+assert tr.dp == force and tr.segmented == force
+if graph:
+    tr.enable_graph(warmup=1)
+left, ld, right, rd, flag = T._batch(8)
+mv = lambda t: t.to("cuda:0")
+losses = []
+for _ in range(3):
+    losses.append(float(tr.step([mv(t) for t in left], mv(ld), [mv(t) for t in right], mv(rd), mv(flag))))
+torch.cuda.synchronize()
+torch.save({"flat": tr.fp.flat.cpu(), "m": tr.m.cpu(), "v": tr.v.cpu(), "loss": losses, "calls": tr.stats["allreduce_calls"],
+            "buckets": len(tr.bucket_slices), "graph_error": tr.graph_error,
+            "nccl": ".".join(str(v) for v in torch.cuda.nccl.version()) if force else None}, out)
+if force:
+    dist.destroy_process_group()
+"""
+
+
+@pytest.mark.parametrize("graph", [False, True])
+def test_rccl_backend_single_rank_equals_plain_step(tmp_path, graph):
+    """The data-parallel schedule over RCCL itself (backend "nccl", world 1, DM_DP_FORCE=1: communicator, segmented backward, one
+    asynchronous all-reduce per bucket between the backward pieces, per-bucket Adam; with `graph` the per-segment hipGraphs captured
+    while the backend's watchdog thread is alive) leaves, after three steps, bit for bit the weights and Adam moments of the plain
+    one-GPU step -- a one-rank sum is the identity -- and capture must not have fallen back to eager launches.  Each arm runs in a child
+    process (a process group per test process; RCCL refuses two ranks on one device, so world > 1 stays with the gloo tests above).
+    No multi-GPU RCCL run and no scaling curve exist for this build: this is the RCCL coverage a one-GPU box can give."""
+    import subprocess
+    script = tmp_path / "child.py"
+    script.write_text(_RCCL_CHILD)
+    got = {}
+    for arm, force in (("rccl", "1"), ("plain", "0")):
+        out = str(tmp_path / f"{arm}.pt")
+        env = dict(os.environ, DM_DP_FORCE=force, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        r = subprocess.run([sys.executable, str(script), ROOT, "1" if graph else "0", out], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-3000:]
+        got[arm] = torch.load(out)
+    a, b = got["rccl"], got["plain"]
+    assert a["nccl"] is not None and a["buckets"] == 3 and a["calls"] == 3 * 3
+    assert a["graph_error"] is None and b["graph_error"] is None
+    assert a["loss"] == b["loss"]
+    for k in ("flat", "m", "v"):
+        assert torch.equal(a[k], b[k]), k

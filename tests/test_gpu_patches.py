@@ -172,3 +172,119 @@ def test_extract_from_tile_equals_image_path():
     edges = torch.tensor([[0, 1], [1, 2], [-1, 3], [8, 9]], dtype=torch.int32, device=DEV)
     pooled, simi, merge = rag_similarity_sweep(F, ptr, idx, edges, 1.0)
     assert pooled.shape == (10, 100) and bool(torch.isnan(simi[2])) and not bool(merge[2])
+
+
+def _feed_table(rng, T, size, B):
+    from deepmerge_amd.feed import PairTable
+    P = 2 * B
+    inner = rng.integers(16, 65, P).astype(np.int32)
+    obj = (inner + rng.integers(8, 49, P)).astype(np.int32)
+    tid = rng.integers(0, T, P).astype(np.int32)
+    xy = rng.integers(-4, size + 4, (P, 2)).astype(np.int32)            # some windows hang over the raster edge (zero padding)
+    feats = rng.normal(size=(P, 15)).astype(np.float32)
+    flag = (np.arange(B) % 2).astype(np.int64)
+    mv = lambda a: torch.from_numpy(a).to(DEV)
+    return PairTable(mv(tid), mv(xy), mv(inner), mv(obj), mv(feats), mv(flag)), (tid, xy, inner, obj, feats, flag)
+
+
+@pytest.mark.parametrize("rows,numerics", [(True, "bf16"), (True, "fp32"), (False, "bf16")])
+def test_pair_feed_equals_point_batch_per_tile(rows, numerics):
+    """The sync-free training feed (deepmerge_amd/feed.py, dm_pair_batch_gather: tile id as a table column, window arithmetic and the
+    designed rows on the device) produces, bit for bit, what `point_batch` / `point_batch_cols` produce tile by tile from host-side
+    windows (the feed of rounds 1-4)."""
+    from deepmerge_amd import ops
+    from deepmerge_amd.feed import PairFeed
+    from deepmerge_amd.patches import point_batch, point_batch_cols
+    rng = np.random.default_rng(11)
+    T, bands, size, B = 3, 4, 320, 9
+    scales = [32, 64, 128, 256]
+    tiles = torch.from_numpy(rng.integers(0, 256, size=(T, bands, size, size), dtype=np.uint8)).to(DEV)
+    table, (tid, xy, inner, obj, feats, flag) = _feed_table(rng, T, size, B)
+    feed = PairFeed(tiles, scales, B, [64, 112, 160, 208], rows=rows, numerics=numerics)
+    left, ld, right, rd, fl = feed.fill(table)
+    feed.check()
+    assert torch.equal(fl.cpu(), torch.from_numpy(flag).float())
+    dtype = ops.act_dtype(numerics)
+    for t in range(T):
+        sel = np.nonzero(tid == t)[0]
+        if sel.size == 0:
+            continue
+        args = (tiles[t], torch.from_numpy(xy[sel]).to(DEV), torch.from_numpy(inner[sel]), torch.from_numpy(obj[sel]), torch.from_numpy(feats[sel]).to(DEV))
+        want, wd = (point_batch_cols(*args, scales=scales, dtype=dtype) if rows else point_batch(*args, scales=scales))
+        for i, s in enumerate(scales):
+            for k, p in enumerate(sel):
+                got = (left[i][p:p + 1] if p < B else right[i][p - B:p - B + 1])
+                ref = want[i][k:k + 1]
+                if rows:
+                    got, ref = got.cols, ref.cols
+                assert got.dtype == ref.dtype and torch.equal(got.view(torch.uint8), ref.reshape(got.shape).view(torch.uint8)), (t, s, p)
+        for k, p in enumerate(sel):
+            got = ld[p] if p < B else rd[p - B]
+            assert torch.equal(got.view(torch.int32), wd[k].view(torch.int32))
+
+
+def test_pair_feed_flags_out_of_range_samples_without_a_sync():
+    from deepmerge_amd.feed import PairFeed
+    rng = np.random.default_rng(12)
+    T, bands, size, B = 2, 3, 200, 4
+    tiles = torch.from_numpy(rng.integers(0, 256, size=(T, bands, size, size), dtype=np.uint8)).to(DEV)
+    table, _ = _feed_table(rng, T, size, B)
+    feed = PairFeed(tiles, [32, 64, 128], B, 160, rows=False)
+    feed.fill(table); feed.check()
+    table.tile_id[3] = T                      # no such tile
+    left, *_ = feed.fill(table)
+    assert float(left[0][3].abs().max()) == 0.0 and float(left[0][2].abs().max()) > 0.0
+    with pytest.raises(ValueError):
+        feed.check()
+    feed.fill(_feed_table(rng, T, size, B)[0]); feed.check()          # the flag was cleared
+    small = PairFeed(tiles, [32, 64, 128], B, 40, rows=False)         # bound below the table's windows
+    small.fill(table)
+    with pytest.raises(ValueError):
+        small.check()
+
+
+def test_trainer_steps_on_feed_rows_equal_steps_on_patch_tensors():
+    """PairTrainer fed by PairFeed rows (graph replay, the feed writing straight into the captured step's inputs) == the same steps on
+    fp32 patch tensors from the per-tile feed: same loss every step, same weights after three steps, bit for bit."""
+    from deepmerge_amd.feed import PairFeed
+    from deepmerge_amd.nets.ShfitScaleFormer import ShfitScaleFormer_v3
+    from deepmerge_amd.patches import point_batch
+    from deepmerge_amd.trainer import PairTrainer
+    rng = np.random.default_rng(13)
+    T, bands, size, B = 3, 3, 256, 4
+    scales = [32, 64, 128]
+    tiles = torch.from_numpy(rng.integers(0, 256, size=(T, bands, size, size), dtype=np.uint8)).to(DEV)
+    tables = [_feed_table(rng, T, size, B) for _ in range(4)]
+    losses, weights = {}, {}
+    for kind in ("feed", "tensors"):
+        torch.manual_seed(3)
+        net = ShfitScaleFormer_v3(cube_size=[8, 8], input_image_scales=list(scales), depth=[1, 1, 1], in_c=bands, numerics="bf16").to(DEV)
+        tr = PairTrainer(net, margin=1.0, lr=1e-3)
+        tr.enable_graph(warmup=1)
+        feed = PairFeed(tiles, scales, B, [64, 112, 160], numerics="bf16", trainer=tr) if kind == "feed" else None
+        out = []
+        for table, (tid, xy, inner, obj, feats, flag) in tables:
+            if feed is not None:
+                batch = feed.fill(table)
+            else:
+                P = 2 * B
+                patches = [torch.empty((P, bands, s, s), device=DEV) for s in scales]
+                designed = torch.empty((P, 1, 19), device=DEV)
+                for t in range(T):
+                    sel = np.nonzero(tid == t)[0]
+                    if sel.size == 0:
+                        continue
+                    p, d = point_batch(tiles[t], torch.from_numpy(xy[sel]).to(DEV), torch.from_numpy(inner[sel]), torch.from_numpy(obj[sel]),
+                                       torch.from_numpy(feats[sel]).to(DEV), scales=scales)
+                    idx = torch.from_numpy(sel).to(DEV)
+                    for i in range(len(scales)):
+                        patches[i][idx] = p[i]
+                    designed[idx] = d
+                batch = ([t[:B] for t in patches], designed[:B], [t[B:] for t in patches], designed[B:], torch.from_numpy(flag).to(DEV))
+            out.append(float(tr.step(*batch)))
+        if feed is not None:
+            feed.check()
+            assert feed._bound and tr.graph_error is None
+        losses[kind], weights[kind] = out, tr.fp.flat.clone()
+    assert losses["feed"] == losses["tensors"]
+    assert torch.equal(weights["feed"], weights["tensors"])

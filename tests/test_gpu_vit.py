@@ -127,6 +127,25 @@ def test_vit_huge_factory_and_bf16_mode():
     assert e[0] < 3e-2 and np.median(errs) < 0.25
 
 
+def test_wide_block_bf16x3_with_rows_multiple_of_64():
+    """ViT-H's 1280-wide block in bf16x3 mode with B x N a multiple of 64: the plane-pair LayerNorm kernels take rows of
+    <= 1024 columns only, so the block must keep fp32 activations there -- and still agree with the fp32 mode far inside 1e-3."""
+    vm = VM()
+    torch.manual_seed(5)
+    x = torch.randn(64, 16, 1280, device=DEV) * 0.5          # M = 1024 rows
+    g = torch.randn_like(x)
+    outs = {}
+    for mode in ("fp32", "bf16x3"):
+        torch.manual_seed(7)
+        blk = vm.Block(dim=1280, num_heads=16, mlp_ratio=4.0, qkv_bias=True, numerics=mode).to(DEV).train()
+        xi = x.clone().requires_grad_(True)
+        y = blk(xi)
+        y.backward(g)
+        outs[mode] = (y.detach(), xi.grad.detach(), blk.mlp.fc1.weight.grad.detach().clone(), blk.norm1.weight.grad.detach().clone())
+    for a, b in zip(outs["fp32"], outs["bf16x3"]):
+        assert float((a - b).norm() / a.norm()) < 1e-4
+
+
 def test_scale_embed_trainer_first_write_sinks():
     """ScaleEmbedTransformer under PairTrainer: its blocks' gradients take the first-write path (FlatParams.tracked); three steps leave
     the same weights and Adam state, bit for bit, as zero-then-accumulate."""

@@ -8,7 +8,8 @@ OUT=gpurun_out/q32_abl.log
 for abl in ${ABLS:-0 1 2 4 8 16 32 64 128 12 28 158}; do
   touch deepmerge_amd/csrc/dm_attention_q32.hip
   make -C deepmerge_amd/csrc EXTRA=-DDMQ_ABL=$abl > gpurun_out/q32_abl_build.log 2>&1 || { echo "build failed for $abl" | tee -a $OUT; tail -5 gpurun_out/q32_abl_build.log; continue; }
-  for cfg in ${CFGS:-"64 256 0" "256 197 1"}; do set -- $cfg
+  IFS=';' read -ra CFG_LIST <<< "${CFGS:-64 256 0;256 197 1}"        # CFGS="B N NOBIAS;B N NOBIAS"
+  for cfg in "${CFG_LIST[@]}"; do set -- $cfg
     echo "abl=$abl B=$1 N=$2 NOBIAS=$3: $(B=$1 N=$2 NOBIAS=$3 FWD_ONLY=1 timeout -k 10 120 python tools/mb_attn.py 2>&1 | grep fwd)" | tee -a $OUT
   done
 done
