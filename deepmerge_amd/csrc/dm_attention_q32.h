@@ -18,6 +18,11 @@ constexpr int HD = 64;
 constexpr int WB_PITCH = 144;                   // write-back staging: 128-byte row + 16 bytes (keeps rows 16-byte aligned)
 constexpr int WB_WAVE = 32 * WB_PITCH;
 constexpr float NEG_BIG = -1.0e30f;
+// Row pitch (floats) of the head's relative-position table in LDS: 15 entries per (dz, dy) row.  A lane's address is
+// pitch * (its token's y) -+ (its token's x) + const, and a 32-lane group of a ds_read2_b32 covers 4 y x 8 x: with a pitch of 16 the rows
+// y and y + 2 fall on the same 8 banks (2-way conflict on every bias read: the 50 k conflict cycles of profiles/r04_attn_mfma_util.md);
+// 24 puts the four rows on banks 0-7 / 24-31 / 16-23 / 8-15.
+constexpr int TAB_PITCH = 24;
 
 // ---- MFMAs with explicit register classes (see the header: hipcc pads nothing inside or around these) ----------------------------
 #define DMQ_MFMA "v_mfma_f32_32x32x16_bf16"

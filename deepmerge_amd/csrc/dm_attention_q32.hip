@@ -44,7 +44,14 @@
 #define DMQ_ABL 0
 #endif
 #ifndef DMQ_PRIO_FLIP
-#define DMQ_PRIO_FLIP 1
+#define DMQ_PRIO_FLIP 0
+#endif
+// Half-unit stagger of the 8-wave instances (see the kernel); -DDMQ_STAGGER=0 for A/B builds
+#ifndef DMQ_STORES_IN_FLIGHT
+#define DMQ_STORES_IN_FLIGHT 0
+#endif
+#ifndef DMQ_STAGGER
+#define DMQ_STAGGER 0
 #endif
 
 // -DDMQ_STAMP: wave 0 of every workgroup stamps s_memtime at six points of each of its first 8 samples into a __device__ array
@@ -86,6 +93,20 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void attn_fwd_q32_kernel(const Att
   // dealt out as gridDim.x contiguous runs of equal length +- 1, which may cross a head boundary -- 64 samples x 12 heads on 256 CUs
   // are 3 units each, where whole-sample chunks per head would be 192 workgroups of 4.
   constexpr bool RUNS = NW == 8;
+  // STAG (8 waves, round 5): waves 4-7 run HALF A UNIT behind waves 0-3.  The stamps of the lockstep form (profiles/r05_attn_fwd_ablations_and_
+  // stamps.md) show 43 % of a unit outside its tile loop -- barrier wait, pipeline fill, epilogue -- with both waves of a SIMD in those phases
+  // together.  Every wave now passes TWO barriers per unit (top, and in front of tile HT = NKT / 2); waves 4-7 pass one extra barrier before their
+  // first unit and waves 0-3 one after their last, so that barrier k of the older half (top of unit u) is barrier k of the younger half (middle
+  // of unit u - 1): one half's fill / epilogue runs under the other half's tiles.  What that obliges:
+  //   * K / V of unit u + 1 go into the buffer the younger half still reads (unit u - 1, tiles >= HT) while the older half is in tiles
+  //     < HT of unit u: there only pieces the younger half is done with are staged -- K tiles < HT + 2 (tile j + 2's fragments are read in
+  //     tile j), V tiles < HT - 1 (tile j - 1's in tile j) -- the rest during the older half's tiles >= HT, when the younger half is in unit u;
+  //   * the DMA waves (0-3) wait for their transfers in front of THEIR top barrier; the younger half reads the unit one barrier later;
+  //   * the head's table has two slots (head parity): a run that crosses into the next head finds the older half filling the new
+  //     head's slot in front of its top barrier while the younger half still reads the old one.
+  constexpr bool STAG = RUNS && (DMQ_STAGGER != 0);
+  constexpr int HT = NKT / 2;
+  const bool older = wave < 4;
   const int H = p.H;
   int rb = 0, u0, u1;
   if constexpr (RUNS) {
@@ -146,36 +167,44 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void attn_fwd_q32_kernel(const Att
   const float *tabl = tab;
   // Two phases: the global loads of the FIRST table are issued behind the first unit's K / V / Q transfers and land under them (as one
   // loop in front of the staging the fill was three dependent memory round trips: 3.9 us from kernel entry to the unit loop, r05 stamps)
-  constexpr int TAB_N = (NKT - 1) * 225, TAB_IT = (TAB_N + 64 * NW - 1) / (64 * NW);
+  constexpr int TAB_N = (NKT - 1) * 225, TAB_FLOATS = TAB_ROWS * TAB_PITCH;
+  constexpr int TAB_T = STAG ? 256 : 64 * NW;                       // threads that fill a table (STAG: the older half)
+  constexpr int TAB_IT = (TAB_N + TAB_T - 1) / TAB_T;
   float tv[TAB ? TAB_IT : 1];
   auto load_table = [&](int hd) {
+    if (STAG && !older) return;
 #pragma unroll
     for (int k = 0; k < TAB_IT; ++k) {
-      const int i = t + k * 64 * NW;
+      const int i = t + k * TAB_T;
       tv[k] = i < TAB_N ? p.table[(long long)i * H + hd] : 0.f;
     }
   };
-  auto store_table = [&]() {                                        // every thread; a barrier must follow before the table is read
+  auto store_table = [&](int hd) {                                  // a barrier must follow before the table is read (slot = head parity under STAG)
+    if (STAG && !older) return;
     const float inv_scale = 1.f / p.scale;
+    float *dst = tab + (STAG ? (hd & 1) * TAB_FLOATS : 0);
 #pragma unroll
     for (int k = 0; k < TAB_IT; ++k) {
-      const int i = t + k * 64 * NW;
+      const int i = t + k * TAB_T;
       const int pz = i / 225, rem = i - pz * 225, py = rem / 15, px = rem - py * 15;
-      if (i < TAB_N) tab[(pz * 15 + py) * 16 + (14 - px)] = tv[k] * inv_scale;
+      if (i < TAB_N) dst[(pz * 15 + py) * TAB_PITCH + (14 - px)] = tv[k] * inv_scale;
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   };
-  auto fill_table = [&](int hd) { load_table(hd); store_table(); };
+  auto fill_table = [&](int hd) { load_table(hd); store_table(hd); };
+  int tabl_off = 0;
+  auto point_table = [&](int hd) { tabl = tab + (STAG ? (hd & 1) * TAB_FLOATS : 0) + tabl_off; };
   if constexpr (TAB) {
     const int qz = q >> 6, qy = (q >> 3) & 7, qx = q & 7;
-    tabl = tab + ((qz + NKT / 2 - 1) * 15 + qy + 7 - TAB_MAXC) * 16 + 7 - qx + 4 * hh;
+    tabl_off = ((qz + NKT / 2 - 1) * 15 + qy + 7 - TAB_MAXC) * TAB_PITCH + 7 - qx + 4 * hh;
+    point_table(h);
   }
   // bias / scale of tile kt into its score registers: key (kz, ky, kx) = (kt >> 1, 4 (kt & 1) + c, 4 hh + e) for register 4 c + e
   auto read_bias = [&](int kt, f32x16 &d) {
 #pragma unroll
     for (int c = 0; c < 4; ++c)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) d[4 * c + e] = tabl[16 * (TAB_MAXC - (15 * (kt >> 1) + 4 * (kt & 1) + c)) + e];
+      for (int e = 0; e < 4; ++e) d[4 * c + e] = tabl[TAB_PITCH * (TAB_MAXC - (15 * (kt >> 1) + 4 * (kt & 1) + c)) + e];
   };
 
   // ---- DMA: one wave-instruction = 8 keys x 128 B (1 KiB of an image); every wave stages NKT instructions of K and of V ------------
@@ -209,6 +238,37 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void attn_fwd_q32_kernel(const Att
     const unsigned kimg = lds0 + (unsigned)(buf * (2 * IMG)) + (unsigned)wave * 1024u, vimg = kimg + (unsigned)IMG;
     lds_dma(rs, kimg + (unsigned)j * 4096u, voffK, (unsigned)j * step_bytes);
     lds_dma(rs, vimg + (unsigned)j * 4096u, voffV, (unsigned)j * step_bytes);
+  };
+  auto stage_k = [&](const i32x4 &rs, int buf, int j) {
+    if ((DMQ_ABL & 2) || !dma_wave) return;
+    lds_dma(rs, lds0 + (unsigned)(buf * (2 * IMG)) + (unsigned)wave * 1024u + (unsigned)j * 4096u, voffK, (unsigned)j * step_bytes);
+  };
+  auto stage_v = [&](const i32x4 &rs, int buf, int j) {
+    if ((DMQ_ABL & 2) || !dma_wave) return;
+    lds_dma(rs, lds0 + (unsigned)(buf * (2 * IMG)) + (unsigned)IMG + (unsigned)wave * 1024u + (unsigned)j * 4096u, voffV, (unsigned)j * step_bytes);
+  };
+  // STAG: the pieces of the NEXT unit that tile j's gap stages.  First half (j < HT): K 0 .. HT + 1 and V 0 .. HT - 2 (what the lagging half
+  // no longer reads), alternating K, V, dealt evenly over the HT tiles; second half: the rest over the NKT - HT tiles.
+  auto stage_stag = [&](const i32x4 &rs, int buf, int j) {
+    constexpr int NK1 = (HT + 2 < NKT) ? HT + 2 : NKT, NV1 = HT - 1 > 0 ? HT - 1 : 0, N1 = NK1 + NV1, N2 = 2 * NKT - N1;
+    if (j < HT) {
+#pragma unroll
+      for (int i = 0; i < N1; ++i) {
+        if (i * HT / N1 != j) continue;
+        // order: K0 V0 K1 V1 ... while V pieces last, then the remaining K pieces
+        if (i < 2 * NV1) { if (i & 1) stage_v(rs, buf, i >> 1); else stage_k(rs, buf, i >> 1); }
+        else stage_k(rs, buf, i - NV1);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < N2; ++i) {
+        if (HT + i * (NKT - HT) / N2 != j) continue;
+        // order: V(NV1) K(NK1) V(NV1 + 1) K(NK1 + 1) ... while K pieces last, then the remaining V pieces
+        constexpr int NK2 = NKT - NK1;
+        if (i < 2 * NK2) { if (i & 1) stage_k(rs, buf, NK1 + (i >> 1)); else stage_v(rs, buf, NV1 + (i >> 1)); }
+        else stage_v(rs, buf, NV1 + i - NK2);
+      }
+    }
   };
   auto stage_all = [&](int u, int buf) {
     if (!dma_wave) return;
@@ -269,17 +329,32 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void attn_fwd_q32_kernel(const Att
   load_q(u0, qld);
   if constexpr (TAB) load_table(h);
   DMQ_RT(1);
+  if (STAG && !older) __builtin_amdgcn_s_barrier();                 // the lagging half's extra barrier (the older half's top of its first unit)
   for (int b = u0; b < u1; ++b) {                                   // b: the unit (head * B + sample)
     const int b0 = u0, b1 = u1;
     const int buf = (b - b0) & 1;
     DMQ_T(0);
     if (DMQ_PRIO_FLIP && NW == 8 && wave >= 4) __builtin_amdgcn_s_setprio(0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // this sample's K / V / Q have landed (issued during the previous sample)
+    // this sample's K / V / Q have landed (issued during the previous sample).  The table form's waves store their result rows from
+    // registers at the end of a unit -- four 16-byte stores and the lse store, the YOUNGEST vector-memory operations at this point: they are
+    // left in flight (a store's acknowledgement takes ~1 us: 1 270 cycles per unit at this wait in the stamped skeleton build).
+    if (DIRECT && DMQ_STORES_IN_FLIGHT && b != u0) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     DMQ_T(1);
-    if (TAB && b == u0) store_table();                              // (visible to the other waves behind the barrier)
+    if constexpr (STAG) {
+      const int hn = b / p.B;
+      if constexpr (TAB) {
+        if (b == u0) store_table(h);                                // (visible to the other waves behind the barrier)
+        else if (hn != h) fill_table(hn);                           // the run crossed into the next head: the OTHER slot, which nobody reads any more
+        point_table(hn);
+      }
+      h = hn;
+    } else {
+      if (TAB && b == u0) store_table(h);
+    }
     __builtin_amdgcn_s_barrier();                                   // ... for every wave; and everyone is done with the other buffer
     DMQ_T(2);
-    if constexpr (RUNS) {
+    if constexpr (RUNS && !STAG) {
       const int hn = b / p.B;
       if (TAB && hn != h) {                                         // the run crossed into the next head: everyone is past the old table's last read
         fill_table(hn);
@@ -427,9 +502,10 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void attn_fwd_q32_kernel(const Att
       for (int j = 0; j < NKT; ++j) {
         if (j == 4) DMQ_T(4);
         // Two waves per SIMD: the older one (waves 0-3) wins the issue arbitration and reached the unit's barrier ~2700 cycles before its
-        // partner (stamps, profiles/r05_attn_fwd_stamps.txt).  The younger half takes priority for the second half of the tiles, so the
-        // two finish together (-DDMQ_PRIO_FLIP=0 for A/B builds).
+        // partner (stamps, profiles/r05_attn_fwd_ablations_and_stamps.md).  With -DDMQ_PRIO_FLIP=1 the younger half takes priority for the second half of the tiles so the
+        // two finish together: measured inside the noise (30.2 / 30.5 us with, 31.4 / 30.6 without), OFF by default.
         if (DMQ_PRIO_FLIP && NW == 8 && j == NKT / 2 && wave >= 4) __builtin_amdgcn_s_setprio(1);
+        if (STAG && j == HT) __builtin_amdgcn_s_barrier();          // the unit's second barrier (the other half's top)
         // iteration j, ten MFMA gaps: QK^T(j + 1) x 4, row sums(j - 1) x 2, P.V(j - 1) x 4, with tile j's VALU pipeline between them
         f32x16 &sc = (j & 1) ? s1 : s0;                              // tile j's scores; tile j + 1 accumulates into sn
         f32x16 &sn = (j & 1) ? s0 : s1;
@@ -468,8 +544,12 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void attn_fwd_q32_kernel(const Att
           }
           if (TAB && g == 8 && j + 2 < NKT) read_bias(j + 2, sc);     // tile j's scores were last read in gap 7; tile j + 2 accumulates onto these
           if (g == 5 && more) {                                      // next sample's K / V: one (K, V) pair of pieces per tile, all before the last
-            if (j < NKT - 1) stage_piece(rs_next, buf ^ 1, j);
-            if (j == 0) stage_piece(rs_next, buf ^ 1, NKT - 1);
+            if constexpr (STAG) {
+              stage_stag(rs_next, buf ^ 1, j);
+            } else {
+              if (j < NKT - 1) stage_piece(rs_next, buf ^ 1, j);
+              if (j == 0) stage_piece(rs_next, buf ^ 1, NKT - 1);
+            }
           }
           if (g < 4) {
             if (j + 1 < NKT) asm volatile("" :: "v"(kf[g]));
@@ -530,10 +610,12 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void attn_fwd_q32_kernel(const Att
         *reinterpret_cast<u32x2 *>(wb + r * WB_PITCH + (32 + 8 * c + 4 * hh) * 2) = w1;
       }
       DMQ_T(6);
-    } else if (more) {
-      stage_all(b + 1, buf ^ 1);                                     // a wave without rows still stages its share
+    } else {
+      if (STAG) __builtin_amdgcn_s_barrier();                        // (a wave without rows: the unit's second barrier; such waves are never DMA waves)
+      if (more) stage_all(b + 1, buf ^ 1);                           // a wave without rows still stages its share
     }
   }
+  if (STAG && older) __builtin_amdgcn_s_barrier();                  // the older half's extra barrier (the lagging half's middle of its last unit)
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   if constexpr (!DIRECT) flush(u1 - 1);
 #ifdef DMQ_STAMP
@@ -552,7 +634,7 @@ inline void grid(int B, int N, int H, int rows, int &nblk, int &chunks, int &bch
 }
 
 template <int NKT, bool RAGGED, int BM, int NW> bool launch(const AttnPipeParams &p, hipStream_t s) {
-  constexpr int LDS = 4 * NKT * 32 * 128 + (BM == 2 && NW == 8 ? 0 : NW * WB_WAVE) + (BM == 2 ? (NKT - 1) * 15 * 64 : 0);
+  constexpr int LDS = 4 * NKT * 32 * 128 + (BM == 2 && NW == 8 ? 0 : NW * WB_WAVE) + (BM == 2 ? (NKT - 1) * 15 * TAB_PITCH * 4 * (NW == 8 ? 2 : 1) : 0);
   static_assert(LDS <= 160 * 1024, "LDS budget");
   static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void *>(attn_fwd_q32_kernel<NKT, RAGGED, BM, NW>),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS) == hipSuccess;

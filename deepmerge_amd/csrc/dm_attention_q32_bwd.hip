@@ -174,20 +174,20 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void attn_bwd_dq_q32_kernel(const 
     for (int k = 0; k < TAB_IT; ++k) {
       const int i = t + k * 64 * NW;
       const int pz = i / 225, rem = i - pz * 225, py = rem / 15, px = rem - py * 15;
-      if (i < TAB_N) tab[(pz * 15 + py) * 16 + (14 - px)] = tv[k] * inv_scale;
+      if (i < TAB_N) tab[(pz * 15 + py) * TAB_PITCH + (14 - px)] = tv[k] * inv_scale;
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   };
   auto fill_table = [&](int hd) { load_table(hd); store_table(); };
   if constexpr (TAB) {
     const int qz = q >> 6, qy = (q >> 3) & 7, qx = q & 7;
-    tabl = tab + ((qz + NKT / 2 - 1) * 15 + qy + 7 - TAB_MAXC) * 16 + 7 - qx + 4 * hh;
+    tabl = tab + ((qz + NKT / 2 - 1) * 15 + qy + 7 - TAB_MAXC) * TAB_PITCH + 7 - qx + 4 * hh;
   }
   auto read_bias = [&](int kt, f32x16 &d) {
 #pragma unroll
     for (int c = 0; c < 4; ++c)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) d[4 * c + e] = tabl[16 * (TAB_MAXC - (15 * (kt >> 1) + 4 * (kt & 1) + c)) + e];
+      for (int e = 0; e < 4; ++e) d[4 * c + e] = tabl[TAB_PITCH * (TAB_MAXC - (15 * (kt >> 1) + 4 * (kt & 1) + c)) + e];
   };
 
   // ---- fragment offsets ---------------------------------------------------------------------------------------------------------
@@ -767,7 +767,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_tab_kernel(const AttnPipe
   constexpr int TAB_N = (NKT - 1) * 225, TAB_IT = (TAB_N + 255) / 256;
   float tv[TAB_IT];
   const int kz = key >> 6, ky = (key >> 3) & 7, kx = key & 7;
-  const float *tabl = tab + (wave_live ? ((NKT / 2 - 1 - kz) * 15 + 7 - ky) * 16 + 4 * hh - kx + 7 : 0);
+  const float *tabl = tab + (wave_live ? ((NKT / 2 - 1 - kz) * 15 + 7 - ky) * TAB_PITCH + 4 * hh - kx + 7 : 0);
   // selection matrices of the table-gradient accumulation: E_s[row][k] = 1 where row = 16 s + 8 (i >> 2) + 4 hh + (i & 3), k = 8 hh + i
   u32x4 esel[2];
 #pragma unroll
@@ -809,7 +809,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_tab_kernel(const AttnPipe
       for (int k = 0; k < TAB_IT; ++k) {
         const int i = t + k * 256;
         const int prow = i / 15, px = i - prow * 15;
-        if (i < TAB_N) tab[prow * 16 + px] = tv[k] * inv_scale;
+        if (i < TAB_N) tab[prow * TAB_PITCH + px] = tv[k] * inv_scale;
       }
     }
     if (sq < NP) {
@@ -861,7 +861,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_tab_kernel(const AttnPipe
 #pragma unroll
         for (int c = 0; c < 4; ++c)
 #pragma unroll
-          for (int e = 0; e < 4; ++e) d[4 * c + e] = tabl[16 * (15 * (jt >> 1) + 4 * (jt & 1) + c) + e];
+          for (int e = 0; e < 4; ++e) d[4 * c + e] = tabl[TAB_PITCH * (15 * (jt >> 1) + 4 * (jt & 1) + c) + e];
       };
       auto read_stat = [&](int jt, int which, f32x16 &d) {
 #pragma unroll
@@ -1035,7 +1035,7 @@ inline void grid_bwd(int B, int N, int H, int rows, int &nblk, int &chunks, int 
 }
 
 template <int NKT, bool RAGGED, int BM, int NW> bool launch_dq(const AttnPipeBwdParams &p, hipStream_t s) {
-  constexpr int LDS = 4 * NKT * 32 * 128 + (BM == 2 ? 0 : NW * WB_WAVE) + (BM == 2 ? (NKT - 1) * 15 * 64 : 0);
+  constexpr int LDS = 4 * NKT * 32 * 128 + (BM == 2 ? 0 : NW * WB_WAVE) + (BM == 2 ? (NKT - 1) * 15 * TAB_PITCH * 4 : 0);
   static_assert(LDS <= 160 * 1024, "LDS budget");
   static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void *>(attn_bwd_dq_q32_kernel<NKT, RAGGED, BM, NW>),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS) == hipSuccess;
@@ -1073,7 +1073,7 @@ template <int NKT, bool RAGGED, int NW> bool launch_dkv(const AttnPipeBwdParams 
 }
 
 template <int NKT> bool launch_dkv_tab(const AttnPipeBwdParams &p, hipStream_t s) {
-  constexpr int LDS = 4 * NKT * 32 * 128 + 2 * (2 * NKT * 32 * 4) + 4 * WB_WAVE + (NKT - 1) * 15 * 64;
+  constexpr int LDS = 4 * NKT * 32 * 128 + 2 * (2 * NKT * 32 * 4) + 4 * WB_WAVE + (NKT - 1) * 15 * TAB_PITCH * 4;
   static_assert(LDS <= 160 * 1024, "LDS budget");
   static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void *>(attn_bwd_dkv_tab_kernel<NKT>),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS) == hipSuccess;

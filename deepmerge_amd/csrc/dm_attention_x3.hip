@@ -99,14 +99,14 @@ __global__ __launch_bounds__(64 * NW, 1) void attn_fwd_x3_kernel(const AttnX3Par
   const float *tabl = tab;
   if constexpr (TAB) {
     const int qz = q >> 6, qy = (q >> 3) & 7, qx = q & 7;
-    tabl = tab + ((qz + NKT / 2 - 1) * 15 + qy + 7 - TAB_MAXC) * 16 + 7 - qx + 4 * hh;
+    tabl = tab + ((qz + NKT / 2 - 1) * 15 + qy + 7 - TAB_MAXC) * TAB_PITCH + 7 - qx + 4 * hh;
   }
   auto load_table = [&](int hd) {                                   // (called between two barriers: nobody reads the old table any more)
     if constexpr (TAB) {
       const float inv_scale = 1.f / p.scale;
       for (int i = t; i < (NKT - 1) * 225; i += 64 * NW) {
         const int prow = i / 15, px = i - prow * 15;
-        tab[prow * 16 + (14 - px)] = p.table[(long long)i * H + hd] * inv_scale;
+        tab[prow * TAB_PITCH + (14 - px)] = p.table[(long long)i * H + hd] * inv_scale;
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
@@ -116,7 +116,7 @@ __global__ __launch_bounds__(64 * NW, 1) void attn_fwd_x3_kernel(const AttnX3Par
 #pragma unroll
       for (int c = 0; c < 4; ++c)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) d[4 * c + e] = tabl[16 * (TAB_MAXC - (15 * (kt >> 1) + 4 * (kt & 1) + c)) + e];
+        for (int e = 0; e < 4; ++e) d[4 * c + e] = tabl[TAB_PITCH * (TAB_MAXC - (15 * (kt >> 1) + 4 * (kt & 1) + c)) + e];
     } else {
 #pragma unroll
       for (int i = 0; i < 16; ++i) d[i] = (RAGGED && kt == NKT - 1 && 32 * kt + 8 * (i >> 2) + 4 * hh + (i & 3) >= N) ? NEG_BIG : 0.f;
@@ -438,14 +438,14 @@ __global__ __launch_bounds__(64 * NW, 1) void attn_bwd_dq_x3_kernel(const AttnX3
   const float *tabl = tab;
   if constexpr (TAB) {
     const int qz = q >> 6, qy = (q >> 3) & 7, qx = q & 7;
-    tabl = tab + ((qz + NKT / 2 - 1) * 15 + qy + 7 - TAB_MAXC) * 16 + 7 - qx + 4 * hh;
+    tabl = tab + ((qz + NKT / 2 - 1) * 15 + qy + 7 - TAB_MAXC) * TAB_PITCH + 7 - qx + 4 * hh;
   }
   auto load_table = [&](int hd) {                                   // (between two barriers: nobody reads the old table any more)
     if constexpr (TAB) {
       const float inv_scale = 1.f / p.scale;
       for (int i = t; i < (NKT - 1) * 225; i += 64 * NW) {
         const int prow = i / 15, px = i - prow * 15;
-        tab[prow * 16 + (14 - px)] = p.table[(long long)i * H + hd] * inv_scale;
+        tab[prow * TAB_PITCH + (14 - px)] = p.table[(long long)i * H + hd] * inv_scale;
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
@@ -455,7 +455,7 @@ __global__ __launch_bounds__(64 * NW, 1) void attn_bwd_dq_x3_kernel(const AttnX3
 #pragma unroll
       for (int c = 0; c < 4; ++c)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) d[4 * c + e] = tabl[16 * (TAB_MAXC - (15 * (kt >> 1) + 4 * (kt & 1) + c)) + e];
+        for (int e = 0; e < 4; ++e) d[4 * c + e] = tabl[TAB_PITCH * (TAB_MAXC - (15 * (kt >> 1) + 4 * (kt & 1) + c)) + e];
     } else {
 #pragma unroll
       for (int i = 0; i < 16; ++i) d[i] = (RAGGED && kt == NKT - 1 && 32 * kt + 8 * (i >> 2) + 4 * hh + (i & 3) >= N) ? NEG_BIG : 0.f;
@@ -707,10 +707,10 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_x3_kernel(const AttnX3Bwd
     const float inv_scale = 1.f / p.scale;
     for (int i = t; i < (NKT - 1) * 225; i += 256) {
       const int prow = i / 15, px = i - prow * 15;
-      tab[prow * 16 + px] = p.table[(long long)i * H + h] * inv_scale;
+      tab[prow * TAB_PITCH + px] = p.table[(long long)i * H + h] * inv_scale;
     }
     const int kz = key >> 6, ky = (key >> 3) & 7, kx = key & 7;
-    tabl = tab + (wave_live ? ((NKT / 2 - 1 - kz) * 15 + 7 - ky) * 16 + 4 * hh - kx + 7 : 0);
+    tabl = tab + (wave_live ? ((NKT / 2 - 1 - kz) * 15 + 7 - ky) * TAB_PITCH + 4 * hh - kx + 7 : 0);
   }
   u32x4 esel[2];
 #pragma unroll
@@ -806,7 +806,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_x3_kernel(const AttnX3Bwd
         for (int e = 0; e < 4; ++e) {
           nl[4 * c + e] = a[e];
           dp[4 * c + e] = d[e];
-          if constexpr (TAB) sc[4 * c + e] = tabl[16 * (15 * (j >> 1) + 4 * (j & 1) + c) + e];
+          if constexpr (TAB) sc[4 * c + e] = tabl[TAB_PITCH * (15 * (j >> 1) + 4 * (j & 1) + c) + e];
           else sc[4 * c + e] = 0.f;
         }
       }
@@ -916,7 +916,7 @@ inline bool x3_w8() {
 }
 
 template <int NKT, bool RAGGED, bool TAB, int NW> bool launch_fwd_nw(const AttnX3Params &p, hipStream_t s) {
-  constexpr int LDS = 4 * NKT * 32 * 128 + (TAB ? (NKT - 1) * 15 * 64 : 0);
+  constexpr int LDS = 4 * NKT * 32 * 128 + (TAB ? (NKT - 1) * 15 * TAB_PITCH * 4 : 0);
   static_assert(LDS <= 160 * 1024, "LDS budget");
   static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void *>(attn_fwd_x3_kernel<NKT, RAGGED, TAB, NW>),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS) == hipSuccess;
@@ -941,7 +941,7 @@ template <int NKT> bool launch_fwd_n(const AttnX3Params &p, hipStream_t s) {
 }
 
 template <int NKT, bool RAGGED, bool TAB, int NW> bool launch_dq_nw(const AttnX3BwdParams &p, hipStream_t s) {
-  constexpr int LDS = 4 * NKT * 32 * 128 + (TAB ? (NKT - 1) * 15 * 64 : 0);
+  constexpr int LDS = 4 * NKT * 32 * 128 + (TAB ? (NKT - 1) * 15 * TAB_PITCH * 4 : 0);
   static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void *>(attn_bwd_dq_x3_kernel<NKT, RAGGED, TAB, NW>),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS) == hipSuccess;
   if (!ok) return false;
@@ -965,7 +965,7 @@ template <int NKT> bool launch_dq_n(const AttnX3BwdParams &p, hipStream_t s) {
 }
 
 template <int NKT, bool RAGGED, bool TAB> bool launch_dkv(const AttnX3BwdParams &p, hipStream_t s) {
-  constexpr int LDS = 4 * NKT * 32 * 128 + 2 * NKT * 32 * 4 + (TAB ? (NKT - 1) * 15 * 64 : 0);
+  constexpr int LDS = 4 * NKT * 32 * 128 + 2 * NKT * 32 * 4 + (TAB ? (NKT - 1) * 15 * TAB_PITCH * 4 : 0);
   static_assert(LDS <= 160 * 1024, "LDS budget");
   static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void *>(attn_bwd_dkv_x3_kernel<NKT, RAGGED, TAB>),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS) == hipSuccess;

@@ -691,7 +691,9 @@ inline int pick_tile(int layout, int M, int N, int K) {
   }
   const long long t128 = (long long)((M + 127) / 128) * ((N + 127) / 128);
   if (t128 >= 256) return 128;
-  return (layout == DM_TN && K > 4096) ? 128 : 64;
+  // (round 5, tools/routing_check.py: the 768 x 768 weight gradient -- 36 tiles of 128x128 -- at K = 5120 .. 12288 runs 23-36 us on 64x64
+  // tiles + split-K against 34-43 us on 128x128; the wider gradients go to the 4-wave kernel before this rule is asked)
+  return (layout == DM_TN && K > 4096 && t128 >= 64) ? 128 : 64;
 }
 
 int choose_split(int tiles, int K, int bk) {

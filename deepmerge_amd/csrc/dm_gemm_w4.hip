@@ -863,7 +863,9 @@ int dm_gemm_w4_plan(GemmParams &p, int layout, int ab_dtype, bool aligned8, bool
     if (split > 1 && (long long)split * p.M * p.N * 4 > workspace_bytes) return 0;
     // in-step per launch (tools/prof_shapes.py): K = 16384: 100 -> 84, 92 -> 83, 80 -> 67, 41 -> 38 us; K = 4096 with 48 tiles x 4 slices:
     // 26 -> 24 us; fewer workgroups than 0.7 of the CUs, or the 1024-token stage, lose
-    if (tmode == 1 && ((double)(tiles * split) / cus < 0.7 || tiles < 12 || (tiles < 24 && k_eff < 8192))) return 0;
+    // (round 5, tools/routing_check.py: 2304 x 768 x 4096 -- 36 tiles x 4 slices = 0.56 of the CUs -- 36.0 us here against 41.1 on the 256 x 256
+    // pipeline: the fill bound is 0.55 for >= 24 tiles)
+    if (tmode == 1 && ((double)(tiles * split) / cus < (tiles >= 24 ? 0.55 : 0.7) || tiles < 12 || (tiles < 24 && k_eff < 8192))) return 0;
     static const bool attr_tn = w4_set_lds_limit<DM_TN>() && w4_set_lds_limit<DM_TN, 0, 9>() && w4_set_lds_limit<DM_TN, 0, 11>() &&
                                 w4_set_lds_limit<DM_TN, 0, 0, false, false>() && w4_set_lds_limit<DM_TN, 0, 9, false, false>() && w4_set_lds_limit<DM_TN, 0, 11, false, false>();
     if (!attr_tn) return 0;
@@ -917,7 +919,18 @@ int dm_gemm_w4_plan(GemmParams &p, int layout, int ab_dtype, bool aligned8, bool
     // ~10 us per round (tools/mb_w4_loop.py).  With ONE tile per workgroup that is paid once and the deep operand pipeline wins
     // (dgrads into N = 768: -13 .. -15 %, fc2 forward: -3 %); with 3-4 tiles per workgroup the older kernels, whose 2-3 workgroups
     // per CU overlap each other's epilogues, stay ahead (+14 .. +19 %).  mode 3 = every whole-round shape (for measurements).
-    if (tiles > cus || (double)tiles / (double)cus < 0.85) return 0;
+    // Round 5 (tools/routing_check.py at token counts the routing had not been tuned on, profiles/r05_routing_check.txt): the data
+    // gradients into N <= 768 with a long contraction (qkv / fc1 dgrad: K = 2304 / 3072) win on this kernel at ANY number of rounds once
+    // there are >= 96 tiles -- 12288 tokens 47.5 / 63.5 us against 62.8 / 83.3 on 128x128 tiles, 32768: 107 / 138 against 143 / 189,
+    // 61440 (config 5's stage 0): 206 / 271 against 269 / 360, 50432 (ViT-B, 3.08 rounds): 195 / 257 against 219 / 297 -- their four
+    // column tiles keep a round's stores at a third of the N = 2304 / 3072 products'; below 96 tiles (the 4096-token stage) 64x64 tiles win.
+    // The fp32-residual forward products (fc2) keep the one-round rule, from 0.72 of the CUs on (12288 tokens: 80 against 92 us).
+    const bool deep_dgrad = layout == DM_NN && !fold && p.K >= 1536 && tiles_n <= 4;
+    if (deep_dgrad) {
+      if (tiles < 96) return 0;
+    } else if (tiles > cus || (double)tiles / (double)cus < (layout == DM_NT ? 0.72 : 0.85)) {
+      return 0;
+    }
     // Inside the training step (tools/prof_shapes.py, per launch, same box): dgrad 16384 x 768 x 3072 90 -> 77 us, x 2304 71 -> 64 us,
     // fc2 forward (fp32 rows + residual, touched towards L2 two K steps ahead) 103 -> 99 us; the K = 768 products are all fill and
     // epilogue (49 -> 57 us) and stay on the older kernels.

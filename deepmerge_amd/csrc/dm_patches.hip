@@ -135,7 +135,8 @@ __global__ __launch_bounds__(256) void patch_pyramid_kernel(const unsigned char 
       if (t == 0 && bt.err) atomicOr(bt.err, 1);
       const int ps0 = COLS ? T / G : 1;
       const long long Kc0 = (long long)bands * ps0 * ps0;
-      for (int o = t; o < T * T; o += 256) {
+      const int zA = (int)blockIdx.z * T / (int)gridDim.z, zB = ((int)blockIdx.z + 1) * T / (int)gridDim.z;
+      for (int o = zA * T + t; o < zB * T; o += 256) {
         if constexpr (COLS) {
           const int oy = divT(o), ox = o - oy * T, py = oy / ps0, dy = oy - py * ps0, px = ox / ps0, dx = ox - px * ps0;
           out[(((long long)p * G + py) * G + px) * Kc0 + ((long long)c * ps0 + dy) * ps0 + dx] = (OUT)0.f;
@@ -151,8 +152,14 @@ __global__ __launch_bounds__(256) void patch_pyramid_kernel(const unsigned char 
   const int mx = xy[2 * p], my = xy[2 * p + 1];
   const int x0 = (2 * mx - L) / 2, y0 = (2 * my - L) / 2;     // int(mid - L/2): truncation toward zero
   const unsigned char *band = tile + ((long long)tid * bands + c) * H * W;
+  // gridDim.z > 1 (dm_pair_batch_gather): block z produces the output rows [oyA, oyB) of its (sample, band) and stages only the window
+  // rows those pixels read (every resize rule reads source rows floor(oy L / T) - 1 .. ceil((oy + 1) L / T) + 1 at most) -- a 256 x 256
+  // target is 256 pixels per thread, and a training batch has only 2B x bands (sample, band) pairs to fill 256 CUs with
+  const int oyA = (int)blockIdx.z * T / (int)gridDim.z, oyB = ((int)blockIdx.z + 1) * T / (int)gridDim.z;
+  const int jA = gridDim.z > 1 ? max(0, (int)((long long)oyA * L / T) - 1) : 0;
+  const int jB = gridDim.z > 1 ? min(L, (int)(((long long)oyB * L + T - 1) / T) + 2) : L;
   // window -> LDS, row by row: a wave walks along a row (coalesced bytes), no per-element division
-  for (int j = t >> 6; j < L; j += 4) {
+  for (int j = jA + (t >> 6); j < jB; j += 4) {
     const int gy = y0 + j;
     const bool rowin = gy >= 0 && gy < H;
     const unsigned char *src = band + (long long)gy * W;
@@ -167,7 +174,7 @@ __global__ __launch_bounds__(256) void patch_pyramid_kernel(const unsigned char 
   OUT *dst = COLS ? out : out + ((long long)p * bands + c) * T * T;
   const int ps = COLS ? T / G : 1;
   const long long Kc = (long long)bands * ps * ps;
-  for (int o = t; o < T * T; o += 256) {
+  for (int o = oyA * T + t; o < oyB * T; o += 256) {
     const int oy = divT(o), ox = o - oy * T;
     if (rule == DM_RESIZE_OPENCV) {
       const float v = (float)cv_area_pixel(win, L, T, oy, ox) / 255.0f;
@@ -238,7 +245,10 @@ extern "C" int dm_pair_batch_gather(const uint8_t *tiles, int32_t n_tiles, int32
   BatchTable bt;
   bt.tile_id = tile_id; bt.inner = inner; bt.obj = obj; bt.region = region_features; bt.designed = designed; bt.err = error_flag;
   bt.n_tiles = n_tiles; bt.scale_index = scale_index; bt.max_window = max_window;
-  const dim3 g(P, bands);
+  // <= 32 output pixels per thread while the grid stays small (a batch of 64 samples x 4 bands at target 256: 8 blocks per pair)
+  int zn = target * target / (256 * 32);
+  while (zn > 1 && (long long)P * bands * zn > 8192) zn >>= 1;
+  const dim3 g(P, bands, zn < 1 ? 1 : zn);
   const size_t lds = (size_t)max_window * max_window;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (grid == 0) {

@@ -1,14 +1,19 @@
 #!/bin/bash
-# Builds variant libraries for the buffer-store hazard experiment: only dm_gemm.o (the 128x128 / 64x64 kernels) differs.
-# Variants: <soff in V><pad cycles>: s16 (shipped: SGPR soffset + 16 cycles), s0, s2, v0 (VGPR offset, compiler's own hazard handling), v2
+# Builds the variant library for the buffer-store hazard experiment: every GEMM kernel family (dm_gemm, dm_gemm256,
+# dm_gemm_ring, dm_gemm_w4) with NO pad behind the epilogues' 16-byte buffer stores (-DDM_EPI_STORE_PAD=0); the row step stays in the
+# SGPR soffset as shipped.  tools/epi_store_hazard.sh runs the exact-integer GELU + aux product on each family against it.
 set -euo pipefail
 cd "$(dirname "$0")/.."
 CS=deepmerge_amd/csrc
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Iinclude -I$CS -Wno-unused-result -Wno-unused-value -Wno-pass-failed"
-OBJS=$(ls $CS/build/*.o | grep -v dm_gemm.o)
-for v in "s0:-DDM_EPI_STORE_PAD=0" "s2:-DDM_EPI_STORE_PAD=2" "v0:-DDM_EPI_SOFF_V=1 -DDM_EPI_STORE_PAD=0" "v2:-DDM_EPI_SOFF_V=1 -DDM_EPI_STORE_PAD=2"; do
-  name=${v%%:*}; ex=${v#*:}
-  hipcc $FLAGS $ex -c $CS/dm_gemm.hip -o tools/hip/variants/dm_gemm_$name.o
-  hipcc --offload-arch=gfx950 -shared -fPIC -Wl,-z,defs -o tools/hip/variants/libdm_$name.so $OBJS tools/hip/variants/dm_gemm_$name.o
-  echo built $name
+mkdir -p tools/hip/variants
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Iinclude -I$CS -Wno-unused-result -Wno-unused-value -Wno-pass-failed -DDM_EPI_STORE_PAD=0"
+OBJS=$(ls $CS/build/*.o | grep -v -E "dm_gemm.o|dm_gemm256.o|dm_gemm_ring.o|dm_gemm_w4.o")
+VAR=""
+for f in dm_gemm dm_gemm256 dm_gemm_ring dm_gemm_w4; do
+  hipcc $FLAGS -c $CS/$f.hip -o tools/hip/variants/${f}_s0.o &
+  VAR="$VAR tools/hip/variants/${f}_s0.o"
 done
+wait
+hipcc --offload-arch=gfx950 -shared -fPIC -Wl,-z,defs -o tools/hip/variants/libdm_s0all.so $OBJS $VAR
+rm -f tools/hip/variants/libdm_s0.so tools/hip/variants/libdm_s2.so tools/hip/variants/libdm_v0.so tools/hip/variants/libdm_v2.so tools/hip/variants/dm_gemm_s2.o tools/hip/variants/dm_gemm_v0.o tools/hip/variants/dm_gemm_v2.o
+echo built s0all

@@ -108,10 +108,15 @@ def main():  # noqa: C901
     curve = []
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    WARM = 3                                                 # eager step(s) + the capturing step: not steady state (one extra sync after them)
+    t_warm, done = None, 0
     for epoch in range(args.epochs):
         lr = multistep_lr(args.lr, epoch, ms)
         tot = torch.zeros((), device=DEV)
         for k in range(args.steps_per_epoch):
+            if done == WARM:
+                torch.cuda.synchronize(); t_warm = time.perf_counter()
+            done += 1
             if feed is None:
                 batch = make_pairs_looped(tiles, args.pairs, scales, g)
             else:
@@ -127,7 +132,9 @@ def main():  # noqa: C901
     dt = time.perf_counter() - t0
     n = args.epochs * args.steps_per_epoch
     print(json.dumps({"tool": "train_synth", "feed": args.feed, "numerics": args.numerics, "depth": depth, "pairs_per_step": args.pairs, "steps": n,
-                      "loss_curve": curve, "hip_graph": tr.graph_error is None, "pairs_per_s_incl_data_generation": round(n * args.pairs / dt, 1)}))
+                      "loss_curve": curve, "hip_graph": tr.graph_error is None, "pairs_per_s_incl_data_generation": round(n * args.pairs / dt, 1),
+                      "pairs_per_s_steady_incl_data_generation": None if t_warm is None else round((n - WARM) * args.pairs / (t0 + dt - t_warm), 1),
+                      "steady_note": f"after the first {WARM} steps (eager warm-up + hipGraph capture)"}))
 
 
 if __name__ == "__main__":
