@@ -31,6 +31,8 @@
 #include <cstdlib>
 
 #include "dm_common.h"
+#include <cstring>
+
 #include "dm_gemm_common.h"
 #include "dm_mfma.h"
 #include "dm_prof.h"
@@ -681,6 +683,44 @@ void launch_mfma(const GemmParams &p, int layout, int grid, hipStream_t s) {
   }
 }
 
+// DM_GEMM_ROUTE (see dm_gemm): per-product family override for in-step A/B runs; restores the environment when it goes out of scope.
+struct DmRouteOverride {
+  static constexpr int NKEY = 5;
+  const char *keys[NKEY] = {"DM_GEMM_W4", "DM_GEMM_W4_TN", "DM_GEMM_RING", "DM_GEMM_256", "DM_GEMM_FORCE_TILE"};
+  char saved[NKEY][16];
+  bool had[NKEY];
+  bool active = false;
+  DmRouteOverride(int layout, int M, int N, int K) {
+    const char *e = getenv("DM_GEMM_ROUTE");
+    if (!e || !*e) return;
+    char want[64];
+    snprintf(want, sizeof(want), "%s:%dx%dx%d=", layout == DM_NT ? "NT" : layout == DM_NN ? "NN" : "TN", M, N, K);
+    const char *hit = strstr(e, want);
+    if (!hit) return;
+    const char *fam = hit + strlen(want);
+    const char *vals[NKEY] = {"0", "0", "0", "0", nullptr};
+    if (!strncmp(fam, "w4", 2)) { vals[0] = "2"; vals[1] = "2"; }
+    else if (!strncmp(fam, "ring", 4)) vals[2] = "2";
+    else if (!strncmp(fam, "256", 3)) vals[3] = "2";
+    else if (!strncmp(fam, "128", 3)) vals[4] = "128";
+    else if (!strncmp(fam, "64", 2)) vals[4] = "64";
+    else return;
+    active = true;
+    for (int i = 0; i < NKEY; ++i) {
+      const char *old = getenv(keys[i]);
+      had[i] = old != nullptr;
+      snprintf(saved[i], sizeof(saved[i]), "%s", old ? old : "");
+      if (vals[i]) setenv(keys[i], vals[i], 1); else unsetenv(keys[i]);
+    }
+  }
+  ~DmRouteOverride() {
+    if (!active) return;
+    for (int i = 0; i < NKEY; ++i) {
+      if (had[i]) setenv(keys[i], saved[i], 1); else unsetenv(keys[i]);
+    }
+  }
+};
+
 // 64x64 tiles when the product has too few 128x128 tiles to give every CU its share
 // Measured on MI355X (tools/microbench.py, A/B in one process): 64x64 wins only when there are fewer 128x128 tiles than
 // CUs; for wgrad (long contraction, small output) 128x128 + split-K stays ahead unless the contraction is short.
@@ -876,6 +916,10 @@ extern "C" int dm_gemm(const DmGemmArgs *a, void *stream) {
   // 8-column epilogue of splitk_epilogue_kernel must be legal, and the caller's workspace holds the slab
   const bool fwd_slices_ok = a->layout != DM_TN && a->ab_dtype == DM_BF16 && a->split_k == 0 && ring_aligned && a->N % 8 == 0 &&
                              (a->residual == nullptr || a->ldr % 8 == 0) && a->workspace != nullptr && slab_bytes > 0;
+  // A/B aid (tools/routing_check.py finds candidates in a cold microbenchmark; the decision is taken INSIDE the step): DM_GEMM_ROUTE names a
+  // kernel family for single products, e.g. "NT:16384x2304x768=ring,NN:16384x3072x768=256" (families: w4, ring, 256, 128, 64).  The plans
+  // below read their switches per call, so the override sets them for this call only.  Not thread-safe; never set in production.
+  DmRouteOverride route_guard(a->layout, a->M, a->N, a->K);
   const int w4 = w4_ok ? dm_gemm_w4_plan(p, a->layout, a->ab_dtype, true, a->layout == DM_TN ? can_split : fwd_slices_ok, slab_bytes) : 0;
   const bool persistent = w4 != 0;
   const int ring = persistent ? 0 : dm_gemm_ring_plan(p, a->layout, a->ab_dtype, ring_aligned);

@@ -1,9 +1,9 @@
-"""Copy what tools/profile_round_full.sh left under gpurun_out/r04_prof into profiles/ under the names the documents cite, rebuild the derived
+"""Copy what tools/profile_round_full.sh left under gpurun_out/<tag>_prof into profiles/ under the names the documents cite, rebuild the derived
 tables (matrix-pipe utilisation, the bf16x3 step's per-kernel table) and check the source stamp.   python tools/collect_round_profiles.py [r04]"""
 import collections, json, os, shutil, subprocess, sys
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 sys.path.insert(0, ROOT)
-tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r05"
 src, dst = os.path.join(ROOT, "gpurun_out", f"{tag}_prof"), os.path.join(ROOT, "profiles")
 pairs = {"kernel_stats.md": f"{tag}_kernel_stats.md", "pmc_traffic.json": "pmc_traffic.json", "gemm_counters.txt": f"{tag}_gemm_attn_counters.txt",
          "bench_under_rocprof.json": f"{tag}_bench_under_rocprof.json", "bench_bf16x3_under_rocprof.json": f"{tag}_bench_bf16x3_under_rocprof.json",

@@ -1,8 +1,9 @@
 # Full end-of-round refresh: tools/profile_round.sh + one traced bf16x3 step + the per-shape tables of configs 2 / 3 / 5.
 set -e
-bash tools/profile_round.sh r04
+TAG=${1:-r05}
+bash tools/profile_round.sh $TAG
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-OUT=gpurun_out/r04_prof
+OUT=gpurun_out/${TAG}_prof
 rocprofv3 --kernel-trace -d $OUT/x3trace -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extras --numerics bf16x3 > $OUT/bench_bf16x3_under_rocprof.json 2> $OUT/x3trace.log
 DB=$(find $OUT/x3trace -name "*.db" | head -1)
 python tools/rocpd_gaps.py $DB $OUT/x3_gaps.md $OUT/x3_seq.txt > /dev/null
