@@ -691,7 +691,7 @@ struct DmRouteOverride {
   bool had[NKEY];
   bool active = false;
   DmRouteOverride(int layout, int M, int N, int K) {
-    const char *e = getenv("DM_GEMM_ROUTE");
+    static const char *const e = getenv("DM_GEMM_ROUTE");      // read once: unset (the product's case) costs nothing per call
     if (!e || !*e) return;
     char want[64];
     snprintf(want, sizeof(want), "%s:%dx%dx%d=", layout == DM_NT ? "NT" : layout == DM_NN ? "NN" : "TN", M, N, K);

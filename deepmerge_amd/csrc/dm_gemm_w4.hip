@@ -925,7 +925,9 @@ int dm_gemm_w4_plan(GemmParams &p, int layout, int ab_dtype, bool aligned8, bool
     // 61440 (config 5's stage 0): 206 / 271 against 269 / 360, 50432 (ViT-B, 3.08 rounds): 195 / 257 against 219 / 297 -- their four
     // column tiles keep a round's stores at a third of the N = 2304 / 3072 products'; below 96 tiles (the 4096-token stage) 64x64 tiles win.
     // The fp32-residual forward products (fc2) keep the one-round rule, from 0.72 of the CUs on (12288 tokens: 80 against 92 us).
-    const bool deep_dgrad = layout == DM_NN && !fold && p.K >= 1536 && tiles_n <= 4;
+    // (folded products too -- tools/mb_fold.py with TOKENS=61440 / 50432: qkv / fc1 / proj dgrad 551 / 734 / 226 us here against 712 / 927 / 273 on the
+    // 256 x 256 pipeline, 519 / 672 / 216 against 691 / 915 / 248)
+    const bool deep_dgrad = layout == DM_NN && p.K >= 1536 && tiles_n <= 4;
     if (deep_dgrad) {
       if (tiles < 96) return 0;
     } else if (tiles > cus || (double)tiles / (double)cus < (layout == DM_NT ? 0.72 : 0.85)) {

@@ -1113,7 +1113,8 @@ def test_split_bf16_wgrad_with_an_offset_operand():
 
 
 @pytest.mark.parametrize("layout,M,N,K", [("NT", 2048, 768, 768), ("NT", 1024, 768, 3072), ("NT", 320, 192, 128), ("NN", 2048, 768, 2304),
-                                          ("NN", 4096, 3072, 768), ("TN", 768, 768, 4096), ("TN", 2304, 768, 16384), ("TN", 192, 320, 1024)])
+                                          ("NN", 4096, 3072, 768), ("TN", 768, 768, 4096), ("TN", 2304, 768, 16384), ("TN", 192, 320, 1024),
+                                          ("NN", 24576, 768, 2304)])      # (1.5 rounds of 256 x 192 tiles: round 5 routes such dgrads to the 4-wave kernel)
 @pytest.mark.parametrize("family", ["tiles", "w4", "lds"])
 def test_folded_split_product_equals_the_image_product(layout, M, N, K, family, monkeypatch):
     """DmGemmArgs.k_fold (ABI 4): the bf16x3 product on hi / lo PLANE PAIRS, three K segments that re-read the planes in place, is the

@@ -6,7 +6,7 @@ import torch
 from deepmerge_amd import ops
 from deepmerge_amd._lib import DM_NT, DM_NN, DM_TN, DM_EPI_MUL, DM_EPI_GELU_GRAD, DM_EPI_NONE
 dev = "cuda:0"
-T, C, H = 16384, 768, 3072
+T, C, H = int(os.environ.get("TOKENS", 16384)), 768, 3072
 R = 3
 def planes(r, c): return ops.Planes(torch.randn(2, r, c, device=dev).bfloat16())
 def timeit(fn, it=20):
