@@ -194,6 +194,9 @@ int dm_gemm_ring_plan(GemmParams &p, int layout, int ab_dtype, bool aligned8) {
   //   M =  4096: qkv 23 / 31, fc1 36 / 38, proj 19 / 16, fc2 45 / 42          M = 1024: never ahead
   // -> wide outputs (several rounds of tiles, so the two workgroups of a CU drift apart and overlap) take it
   if (mode == 1 && !(p.N >= 2048 && p.M >= 2048)) return 0;
+  // (round 5, tools/routing_check.py: from ~100 k tokens on the 256 x 256 pipeline is ahead on the wide forward products -- the 2000-point evaluation
+  // batch, 384 000 tokens: qkv 1364 against 1456 us, fc1 2393 against 2458 -- below that the two tie within 2 %)
+  if (mode == 1 && p.k_fold == 0 && p.M >= 262144) return 0;
   // ... until the 128x128 kernel got the same whole-line epilogue (dm_gemm.hip): where its tiles make whole rounds of 3 workgroups per
   // CU it is now ahead inside the training step (tools/prof_shapes.py, per launch, same box: 16384 x 2304 90 -> 79 us,
   // 16384 x 3072 + GELU' 121 -> 116 us, 4096 x 3072 + GELU' 44 -> 36 us); 4096 x 2304 (576 tiles = 0.75 round) stays here (29 vs 31 us)

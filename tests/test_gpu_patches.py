@@ -288,3 +288,12 @@ def test_trainer_steps_on_feed_rows_equal_steps_on_patch_tensors():
         losses[kind], weights[kind] = out, tr.fp.flat.clone()
     assert losses["feed"] == losses["tensors"]
     assert torch.equal(weights["feed"], weights["tensors"])
+
+
+def test_pair_feed_fuzz_against_the_single_tile_gathers():
+    """tools/fuzz_feed.py, a short run: random tile stacks, window sides 1 .. bound, points outside the raster, power-of-two and other
+    targets, both resize rules, patches and rows -- the banded multi-tile gather equals the single-tile entry points bit for bit."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import fuzz_feed
+    assert fuzz_feed.run(rounds=25, seed=11, verbose=False) == 0

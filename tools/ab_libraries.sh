@@ -1,5 +1,5 @@
 #!/bin/bash
-# Same-box A/B of two kernel LIBRARIES under the same Python: tools/hip/variants/libdm_r04.so (the round-4 sources rebuilt with the ABI-5 stub,
+# Same-box A/B of two kernel LIBRARIES under the same Python: tools/hip/variants/libdm_r04.so (tools/build_prev_round_library.sh ce9590d r04,
 # see DESIGN.md section 5) against the shipped library; REPS alternating rounds of `bench.py --steps 100` (+ config 5 / config 3 with CONFIGS=1).
 set -uo pipefail
 cd "${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
