@@ -78,6 +78,11 @@ __device__ __forceinline__ float dm_dgelu(float x) {
 // (|error| <= 1.5e-7) on v_rcp_f32 / v_exp_f32 instead of the ~40-instruction erff; GELU and its
 // derivative share the single exp(-x^2/2).
 __device__ __forceinline__ void dm_gelu_parts_fast(float x, float &cdf, float &pdf) {
+#ifdef DM_GELU_ABLATE      // (tools/gelu_cost.sh: what the epilogue's GELU arithmetic costs -- a three-instruction stand-in, wrong results)
+  cdf = fmaf(0.1f, x, 0.5f);
+  pdf = 0.3f;
+  return;
+#endif
   const float z = fabsf(x) * 0.70710678118654752440f;
   const float e = __expf(-z * z);                                    // exp(-x^2/2)
   const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));

@@ -975,6 +975,7 @@ class MlpFn(torch.autograd.Function):
              residual=None if residual is None else residual.contiguous())
         ctx.save_for_backward(x, w1c, w2c, pre, h)
         ctx.shapes = (w1.shape, w2.shape)
+        ctx.params = (w1, b1, w2, b2)
         return y
 
     @staticmethod
@@ -987,10 +988,11 @@ class MlpFn(torch.autograd.Function):
         dres = dy if need[5] else None
         dyo = _as_operand(dy, x.dtype)
         # fc2: dW2 = dy^T h, db2 = colsum(dy); dpre = (dy W2) * gelu'(pre)  (DGELU epilogue)
-        _, dw2, db2 = _linear_backward(h, w2c, dyo, False, need[3], need[4], ctx.shapes[1])
+        w1, b1, w2, b2 = ctx.params         # (gradients go to the trainer's sinks when there are any, like LinearFn's)
+        _, dw2, db2 = _linear_backward(h, w2c, dyo, False, need[3], need[4], ctx.shapes[1], w2, b2)
         dpre = torch.empty((M, Hd), dtype=x.dtype, device=x.device)
         gemm(DM_NN, dyo, w2c, dpre, M, Hd, N, lda=N, ldb=Hd, ldc=Hd, epilogue=DM_EPI_MUL, aux=pre, ldaux=Hd)
-        dx, dw1, db1 = _linear_backward(x, w1c, dpre, need[0], need[1], need[2], ctx.shapes[0])
+        dx, dw1, db1 = _linear_backward(x, w1c, dpre, need[0], need[1], need[2], ctx.shapes[0], w1, b1)
         return dx, dw1, db1, dw2, db2, dres, None
 
 
