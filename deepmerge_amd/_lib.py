@@ -66,6 +66,7 @@ SIGNATURES = {
     "dm_arch": (C.c_char_p, []),
     "dm_gemm": (_I, [C.POINTER(DmGemmArgs), _P]),
     "dm_gemm_workspace_bytes": (_L, [_I, _I, _I, _I]),
+    "dm_gemm_grouped": (_I, [C.POINTER(DmGemmArgs), _I, _P]),
     "dm_attention_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _P]),
     "dm_attention_relpos_inkernel": (_I, [_I, _I, _I, _I, _I, _I, _I, _I]),
     "dm_attention_fwd_relpos": (_I, [_P, _P, _I, _I, _I, _P, _P, _I, _I, _I, _I, _F, _I, _P]),
@@ -156,8 +157,8 @@ def lib() -> C.CDLL:
                 raise DeepMergeLibraryError(f"{LIB_PATH} does not export {name}") from e
             fn.restype = res
             fn.argtypes = args
-        if handle.dm_abi_version() != 5:
-            raise DeepMergeLibraryError(f"ABI version mismatch: library {handle.dm_abi_version()} != 5")
+        if handle.dm_abi_version() != 6:
+            raise DeepMergeLibraryError(f"ABI version mismatch: library {handle.dm_abi_version()} != 6")
         _lib = handle
         return _lib
 

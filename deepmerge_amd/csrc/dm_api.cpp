@@ -13,6 +13,6 @@ void dm_set_error(const char *fmt, ...) {
   va_end(ap);
 }
 
-extern "C" int dm_abi_version(void) { return 5; }
+extern "C" int dm_abi_version(void) { return 6; }
 extern "C" const char *dm_last_error(void) { return g_err; }
 extern "C" const char *dm_arch(void) { return "gfx950"; }

@@ -44,6 +44,7 @@ int dm_gemm_ring_plan(GemmParams &p, int layout, int ab_dtype, bool aligned8);  
 void dm_gemm_ring_launch(const GemmParams &p, int wm, hipStream_t s);
 int dm_gemm_w4_plan(GemmParams &p, int layout, int ab_dtype, bool aligned8, bool can_split, long long workspace_bytes);   // dm_gemm_w4.hip (grid size, 0 = not taken)
 void dm_gemm_w4_launch(const GemmParams &p, int layout, int grid, hipStream_t s);
+bool dm_gemm_w4_grouped(GemmParams *ps, int n, hipStream_t s, bool launch);      // dm_gemm_w4.hip: n weight gradients in one launch (false = not taken)
 
 namespace {
 
@@ -1041,6 +1042,84 @@ extern "C" int dm_gemm(const DmGemmArgs *a, void *stream) {
       const int rc = dm_colsum(a->A, a->ab_dtype, a->lda, a->colsum_a, a->K, a->M, a->colsum_accumulate, cs_region, stream);
       if (rc != DM_OK) return rc;
     }
+  }
+  return DM_OK;
+}
+
+// n independent products, results as n dm_gemm calls in order would give them (weight gradients: up to the order of the fp32 additions
+// over K -- a grouped launch takes each in ONE K slice, the separate calls may slice).  The products must not overlap in their outputs and
+// none may read another's output.  Fast path: 2 .. 8 plain bf16 weight gradients (DM_TN, fp32 C, no epilogue operands, whole 256 x 192
+// tiles, automatic slice count) whose tiles together fit one round of the CUs -- ONE launch of the 4-wave kernel (dm_gemm_w4_grouped), the
+// column sums of A written in the same launch.  Anything else: the calls one after the other.
+extern "C" int dm_gemm_grouped(const DmGemmArgs *args, int32_t n, void *stream) {
+  DM_REQUIRE(args != nullptr && n >= 1, DM_ERR_BAD_SHAPE, "dm_gemm_grouped: null args / n < 1");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  bool fast = n >= 2 && n <= 8;
+  GemmParams ps[8];
+  float *cs_rows[8] = {nullptr};       // per product: the row the launch writes when the sums must be ADDED to colsum_a afterwards
+  for (int i = 0; fast && i < n; ++i) {
+    const DmGemmArgs &a = args[i];
+    fast = a.layout == DM_TN && a.ab_dtype == DM_BF16 && a.c_dtype == DM_F32 && a.epilogue == DM_EPI_NONE && a.split_k == 0 && a.k_fold >= 0 &&
+           a.A && a.B && a.C && !a.bias && !a.residual && !a.aux && a.rows_per_group == 0 && a.M > 0 && a.N > 0 && a.K > 0 &&
+           a.M % 8 == 0 && a.N % 8 == 0 && a.lda % 8 == 0 && a.ldb % 8 == 0 && a.ldc % 4 == 0 && a.lda >= a.M && a.ldb >= a.N && a.ldc >= a.N &&
+           dm_aligned16(a.A) && dm_aligned16(a.B) && dm_aligned16(a.C);
+    if (!fast) break;
+    GemmParams p{};
+    p.A = a.A; p.B = a.B; p.C = a.C;
+    p.lda = a.lda; p.ldb = a.ldb; p.ldc = a.ldc; p.ldr = a.ldc; p.ldaux = a.ldc;
+    p.M = a.M; p.N = a.N; p.K = a.K;
+    p.epilogue = DM_EPI_NONE; p.accumulate = a.accumulate ? 1 : 0; p.c_dtype = DM_F32; p.aux_dtype = DM_F32;
+    p.group_m = 8;
+    if (a.k_fold > 0) {      // hi / lo plane pairs: dm_gemm's own preconditions, then the segments as given
+      fast = a.K == 3 * a.k_fold && a.k_fold % 64 == 0;
+      for (int sgm = 0; fast && sgm < 3; ++sgm) {
+        fast = a.a_fold[sgm] >= 0 && a.a_fold[sgm] < (1LL << 30) && a.b_fold[sgm] >= 0 && a.b_fold[sgm] < (1LL << 30) && a.a_fold[sgm] % 8 == 0 && a.b_fold[sgm] % 8 == 0;
+        p.a_fold[sgm] = a.a_fold[sgm];
+        p.b_fold[sgm] = a.b_fold[sgm];
+      }
+      if (!fast) break;
+      p.k_fold = a.k_fold;
+    }
+    if (a.colsum_a) {
+      if (!a.colsum_accumulate) {
+        p.colsum_slab = a.colsum_a;                      // first write of the step: the launch stores the sums where they belong
+      } else {
+        const int64_t need = colsum_region_floats(a.M) * 4;
+        fast = a.workspace != nullptr && a.workspace_bytes >= need;
+        if (!fast) break;
+        cs_rows[i] = reinterpret_cast<float *>(reinterpret_cast<char *>(a.workspace) + ((a.workspace_bytes - need) & ~15LL));
+        p.colsum_slab = cs_rows[i];
+      }
+    }
+    ps[i] = p;
+  }
+  if (fast) fast = dm_gemm_w4_grouped(ps, n, s, false);
+  if (fast) {
+    double flops = 0, bytes = 0;
+    for (int i = 0; i < n; ++i) {
+      flops += 2.0 * args[i].M * args[i].N * args[i].K;
+      bytes += 2.0 * ((double)args[i].M * args[i].K + (double)args[i].N * args[i].K) + 4.0 * (double)args[i].M * args[i].N * (args[i].accumulate ? 2.0 : 1.0);
+    }
+    static const bool by_shape = [] { const char *e = getenv("DM_PROF_SHAPES"); return e && e[0] == '1'; }();
+    char shaped[64];
+    const char *pname = "gemm_bf16_TN";
+    if (by_shape) {
+      snprintf(shaped, sizeof(shaped), "gemm_bf16_TN_grouped%d_K%d", n, args[0].K);
+      pname = shaped;
+    }
+    {
+      DmProfScope prof(pname, s, flops, bytes);
+      dm_gemm_w4_grouped(ps, n, s, true);
+    }
+    for (int i = 0; i < n; ++i)
+      if (cs_rows[i])
+        hipLaunchKernelGGL(colsum_rows_reduce_kernel, dim3((args[i].M + 63) / 64), dim3(64), 0, s, cs_rows[i], args[i].colsum_a, args[i].M, 1, 1);
+    DM_LAUNCH_CHECK("dm_gemm_grouped");
+    return DM_OK;
+  }
+  for (int i = 0; i < n; ++i) {
+    const int rc = dm_gemm(&args[i], stream);
+    if (rc != DM_OK) return rc;
   }
   return DM_OK;
 }

@@ -74,8 +74,10 @@ __device__ __forceinline__ void mma_pinned(f32x4 &acc, const u32x4 &a, const u32
 // global addresses of the staged pieces change -- and runs THREE MFMA sets on them: hi.hi, hi.lo, lo.hi.  Per 64 contraction
 // positions that is 2 steps of staging for 6 MFMA sets where the generic folded form (three K segments, one MFMA set pair per step)
 // needs 3 steps: the staging / fragment traffic that bounds this kernel's step drops by a third.
-template <int LAYOUT, int DBG = 0, int EK = 0, bool FOLD = false, bool CS = true>
-__global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmParams p) {
+// The kernel body: workgroup L of G (XCD-remapped ids) of the launch described by p.  gemm_w4_kernel runs it for one product;
+// gemm_w4_grouped_kernel for one of several independent weight gradients sharing a launch (dm_gemm_grouped).
+template <int LAYOUT, int DBG, int EK, bool FOLD, bool CS>
+__device__ __forceinline__ void gemm_w4_body(const GemmParams &p, const int G, const int L) {
   constexpr int EPIU = 0;
   constexpr bool AMM = (LAYOUT == DM_TN);      // A m-contiguous [K][M] (wgrad) or k-contiguous [M][K]
   constexpr bool BMM = (LAYOUT != DM_NT);      // B m-contiguous [K][N] (dgrad, wgrad) or k-contiguous [N][K] (forward)
@@ -87,8 +89,6 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmParams p) {
   const int g = lane >> 4, li = lane & 15;
 
   DMW4_K(0);
-  const int G = gridDim.x;
-  const int L = dm_xcd_remap(blockIdx.x, G);
   const int tiles = p.tiles_m * p.tiles_n;
   {
     // Experiment (DM_W4_STAGGER = n, off by default): the workgroups of every other XCD start n x 1024 cycles late, so that half of the
@@ -796,6 +796,32 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmParams p) {
   }
 }
 
+template <int LAYOUT, int DBG = 0, int EK = 0, bool FOLD = false, bool CS = true>
+__global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmParams p) {
+  gemm_w4_body<LAYOUT, DBG, EK, FOLD, CS>(p, (int)gridDim.x, dm_xcd_remap(blockIdx.x, gridDim.x));
+}
+
+// Several independent weight gradients (DM_TN, one K slice each) in ONE launch: workgroups first[i] .. first[i + 1] - 1 (after the XCD
+// remap of the whole grid) are the tiles of product i.  The small stages' weight gradients have 12 .. 48 tiles each: alone they
+// either leave most CUs idle or pay K slices + a slab + a reduction launch; the four of a block together are 144 tiles.
+constexpr int GROUP_MAX = 8;
+struct GemmGroup {
+  GemmParams p[GROUP_MAX];
+  int first[GROUP_MAX + 1];
+  int n;
+};
+template <int EK, bool FOLD, bool CS>
+__global__ __launch_bounds__(256) void gemm_w4_grouped_kernel(const GemmGroup grp) {
+  const int L = dm_xcd_remap(blockIdx.x, gridDim.x);
+  int i = 0;
+#pragma unroll
+  for (int k = 1; k < GROUP_MAX; ++k)
+    if (k < grp.n && L >= grp.first[k]) i = k;
+  i = __builtin_amdgcn_readfirstlane(i);
+  const int tiles = grp.first[i + 1] - grp.first[i];
+  gemm_w4_body<DM_TN, 0, EK, FOLD, CS>(grp.p[i], tiles, L - grp.first[i]);
+}
+
 }  // namespace dmw4
 
 namespace {
@@ -1016,4 +1042,66 @@ void dm_gemm_w4_launch(const GemmParams &p, int layout, int grid, hipStream_t s)
 #undef W4_GO
 #undef W4_GOF
 #undef W4_GOT
+}
+
+// One launch for n independent weight gradients (dm_gemm_grouped): every product a plain bf16 DM_TN with fp32 C, whole 256 x 192
+// tiles, ONE K slice (the gradient is stored / accumulated in place, no slab), the same `accumulate` flag, column sums (if wanted)
+// written to ps[i].colsum_slab as ONE row [M].  Returns false (nothing launched) when the group does not fit this form or is not worth it:
+// (launch = false: decide only.)  All tiles together must fit one round of the CUs and fill at least 0.4 of them, and the contraction must be short enough that slicing the
+// products separately would not win (measured, tools/mb_grouped_estimate.py: the four weight gradients of a block 78 -> 34 us at 1024
+// tokens, 142 -> 85 us at 4096, 186 -> 142 us at 8192, 250 -> 206 us at 12288, 301 -> 293 us at 16384).
+bool dm_gemm_w4_grouped(GemmParams *ps, int n, hipStream_t s, bool launch) {
+  using namespace dmw4;
+  static const int mode = [] { const char *e = getenv("DM_GEMM_GROUPED"); return e ? atoi(e) : 1; }();      // 0 = off, 1 = rule, 2 = every legal group
+  if (mode == 0 || n < 2 || n > GROUP_MAX) return false;
+  const int cus = w4_cu_count();
+  if (cus <= 0) return false;
+  GemmGroup grp{};
+  long long tiles = 0;
+  int k_max = 0;
+  bool any_cs = false;
+  constexpr long long LIM = (1LL << 31) / (128LL * 4);
+  const bool fold = ps[0].k_fold > 0;        // hi / lo plane pairs ("bf16x3"): all members or none; the standard pattern, as in dm_gemm_w4_plan
+  for (int i = 0; i < n; ++i) {
+    GemmParams &p = ps[i];
+    if ((p.k_fold > 0) != fold) return false;
+    const int k_eff = fold ? p.k_fold : p.K, bk_eff = fold ? 32 : BK;
+    if (fold) {
+      if (p.a_fold[0] != 0 || p.a_fold[1] != 0 || p.a_fold[2] <= 0 || p.b_fold[0] != 0 || p.b_fold[2] != 0 || p.b_fold[1] <= 0) return false;
+      if (p.a_fold[2] * 2 >= (1LL << 30) || p.b_fold[1] * 2 >= (1LL << 30)) return false;
+    }
+    if (p.M % TM != 0 || p.N % TN != 0 || k_eff % (2 * bk_eff) != 0 || k_eff < 2 * bk_eff || p.ldc % 4 != 0) return false;
+    if (p.c_dtype != DM_F32 || p.epilogue != DM_EPI_NONE || p.bias || p.residual || p.aux || p.rows_per_group != 0) return false;
+    if (p.accumulate != ps[0].accumulate || p.ldc >= LIM || p.N >= LIM) return false;
+    if (((long long)k_eff * p.lda + (fold ? p.a_fold[2] : 0)) * 2 >= (1LL << 31) || ((long long)k_eff * p.ldb + (fold ? p.b_fold[1] : 0)) * 2 >= (1LL << 31)) return false;
+    p.tiles_m = p.M / TM;
+    p.tiles_n = p.N / TN;
+    p.split_k = 1;
+    p.k_per_split = k_eff;       // (FOLD: in contraction positions of ONE piece)
+    grp.first[i] = (int)tiles;
+    tiles += (long long)p.tiles_m * p.tiles_n;
+    k_max = k_eff > k_max ? k_eff : k_max;
+    any_cs = any_cs || p.colsum_slab != nullptr;
+    grp.p[i] = p;
+  }
+  for (int i = n; i <= GROUP_MAX; ++i) grp.first[i] = (int)tiles;
+  grp.n = n;
+  if (tiles > cus) return false;
+  // (the contraction bound: in the step, grouping the 16384-token blocks' gradients is neutral for the headline and costs config 5 0.1-0.7 %
+  // (15360 tokens) -- there every product fills the chip with its own slices; 12288 is the last length the microbenchmark shows a clear gain for)
+  if (mode == 1 && ((double)tiles / cus < 0.4 || k_max > 12288)) return false;
+  auto lds_ok = [](const void *f) { return hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) == hipSuccess; };
+#define DM_GRP_ATTR(EKV, FOLDV) (lds_ok(reinterpret_cast<const void *>(gemm_w4_grouped_kernel<EKV, FOLDV, true>)) && lds_ok(reinterpret_cast<const void *>(gemm_w4_grouped_kernel<EKV, FOLDV, false>)))
+  static const bool attr = DM_GRP_ATTR(9, false) && DM_GRP_ATTR(11, false) && DM_GRP_ATTR(9, true) && DM_GRP_ATTR(11, true);
+#undef DM_GRP_ATTR
+  if (!attr) return false;
+  if (!launch) return true;          // (plan only: the caller opens its profiler scope around the real launch)
+  const dim3 grid((unsigned)tiles), block(256);
+  // lean epilogue keys as in dm_gemm_w4_launch: 8 = fp32 C written (EK 9), 10 = fp32 C accumulated in place (EK 11)
+#define DM_GRP_GO(EKV, FOLDV) do { if (any_cs) hipLaunchKernelGGL((gemm_w4_grouped_kernel<EKV, FOLDV, true>), grid, block, LDS_BYTES, s, grp); \
+    else hipLaunchKernelGGL((gemm_w4_grouped_kernel<EKV, FOLDV, false>), grid, block, LDS_BYTES, s, grp); } while (0)
+  if (ps[0].accumulate) { if (fold) DM_GRP_GO(11, true); else DM_GRP_GO(11, false); }
+  else { if (fold) DM_GRP_GO(9, true); else DM_GRP_GO(9, false); }
+#undef DM_GRP_GO
+  return true;
 }

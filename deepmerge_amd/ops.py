@@ -295,6 +295,15 @@ def gemm(layout: int, A: torch.Tensor, B: torch.Tensor, C_out: torch.Tensor, M: 
         return gemm(layout, A3, B3, C_out, M, N, 3 * K, lda=(a_cols if a_stack else 3 * a_cols), ldb=(b_cols if b_stack else 3 * b_cols),
                     ldc=ldc, bias=bias, residual=residual, ldr=ldr, epilogue=epilogue, aux=aux, ldaux=ldaux, accumulate=accumulate,
                     split_k=split_k, rows_per_group=rows_per_group, group_stride=group_stride, ws_slot=ws_slot)
+    a = _gemm_args(layout, A, B, C_out, M, N, K, lda, ldb, ldc, bias, residual, ldr, epilogue, aux, ldaux, accumulate, split_k,
+                   rows_per_group, group_stride, colsum_out, colsum_accumulate, ws_slot, c_pair, fold)
+    check(_lib.lib().dm_gemm(C.byref(a), _stream()), "dm_gemm")
+    return c_pair if c_pair is not None else C_out
+
+
+def _gemm_args(layout, A, B, C_out, M, N, K, lda, ldb, ldc, bias, residual, ldr, epilogue, aux, ldaux, accumulate, split_k,
+               rows_per_group, group_stride, colsum_out, colsum_accumulate, ws_slot, c_pair=None, fold=None) -> DmGemmArgs:
+    """The DmGemmArgs of one product (operands already in their final form), its workspace taken from slot `ws_slot`."""
     a = DmGemmArgs()
     a.layout, a.ab_dtype, a.c_dtype = layout, _dt(A), _dt(C_out)
     if c_pair is not None:
@@ -329,8 +338,46 @@ def gemm(layout: int, A: torch.Tensor, B: torch.Tensor, C_out: torch.Tensor, M: 
     if ws_bytes > 0:
         ws = workspace(ws_bytes, A.device, ws_slot)
         a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
-    check(_lib.lib().dm_gemm(C.byref(a), _stream()), "dm_gemm")
-    return c_pair if c_pair is not None else C_out
+    return a
+
+
+def gemm_grouped(calls) -> None:
+    """dm_gemm_grouped: `calls` is a list of (args, kwargs) as for gemm() -- INDEPENDENT products (the weight gradients of a block),
+    issued as one library call that may run them in one launch.  Products the grouped entry does not describe (plane pairs, the
+    split-bf16 forms of fp32 operands) make the whole list run as separate gemm() calls."""
+    if not calls:
+        return
+    # the forms the entry describes: plain bf16 operands, or BOTH operands as hi / lo plane pairs (the folded "bf16x3" product)
+    plain = len(calls) > 1
+    for args, kw in calls:
+        A, B = args[1], args[2]
+        pair = isinstance(A, Planes) and isinstance(B, Planes)
+        plain = plain and not isinstance(args[3], Planes) and (pair or (not isinstance(A, Planes) and not isinstance(B, Planes) and A.dtype == torch.bfloat16))
+    if not plain:
+        for args, kw in calls:
+            gemm(*args, **kw)
+        return
+    arr = (DmGemmArgs * len(calls))()
+    for i, (args, kw) in enumerate(calls):
+        layout, A, B, C_out, M, N, K = args
+        lda, ldb, fold = kw.get("lda"), kw.get("ldb"), None
+        if isinstance(A, Planes):            # as in gemm(): three K segments that re-read the planes in place
+            a_rows, a_cols = (M, K) if layout != DM_TN else (K, M)
+            b_rows, b_cols = (N, K) if layout == DM_NT else (K, N)
+            if (A.rows, A.cols) != (a_rows, a_cols) or (B.rows, B.cols) != (b_rows, b_cols):
+                raise ValueError(f"plane pair shapes {(A.rows, A.cols)} / {(B.rows, B.cols)} do not match the product {(a_rows, a_cols)} / {(b_rows, b_cols)}")
+            fold = (K, A.rows * A.cols, B.rows * B.cols)
+            A, B, lda, ldb, K = A.t, B.t, a_cols, b_cols, 3 * K
+        _need_cuda(A, B, C_out, kw.get("colsum_out"))
+        if A.dtype != B.dtype:
+            raise ValueError(f"A/B dtype mismatch: {A.dtype} vs {B.dtype}")
+        lda = lda if lda is not None else (A.stride(-2) if A.dim() >= 2 else K)
+        ldb = ldb if ldb is not None else (B.stride(-2) if B.dim() >= 2 else K)
+        arr[i] = _gemm_args(layout, A, B, C_out, M, N, K, lda, ldb, kw.get("ldc"), kw.get("bias"), kw.get("residual"), kw.get("ldr"),
+                            kw.get("epilogue", DM_EPI_NONE), kw.get("aux"), kw.get("ldaux"), kw.get("accumulate", False), kw.get("split_k", 0),
+                            kw.get("rows_per_group", 0), kw.get("group_stride", 0), kw.get("colsum_out"), kw.get("colsum_accumulate", False),
+                            f"{kw.get('ws_slot', 'gemm')}.g{i}", None, fold)
+    check(_lib.lib().dm_gemm_grouped(arr, len(calls), _stream()), "dm_gemm_grouped")
 
 
 def cast(src: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
@@ -1392,6 +1439,12 @@ def _grad_done(param: torch.Tensor, g: torch.Tensor, direct: bool):
 # 5.71-5.73 ms off, 5.88 ms with every block on the side stream, 5.87 ms with ONE join per backward pass instead of one per block,
 # 5.85 ms with only the <= 4096-token stages (the large kernels own a CU's whole LDS / register file, so nothing co-resides).
 _WGRAD_SIDE_TOKENS = int(os.environ.get("DM_WGRAD_STREAM", "0"))
+# The same independence, used the other way round (round 5): for blocks of at most DM_WGRAD_GROUP tokens the four weight gradients are
+# collected and issued at the END of the block's backward as ONE dm_gemm_grouped call -- 144 tiles in one launch of the 4-wave kernel, no K
+# slices, no slab, no reduction launches (tools/mb_grouped_estimate.py: 78 -> 34 us per block at 1024 tokens, 142 -> 85 us at 4096,
+# 250 -> 206 us at 12288; in the step the 16384-token blocks gain nothing -- every product fills the chip with its own slices).  Headline
+# step 5.28 -> 5.12 ms, "bf16x3" 11.03 -> 10.89 ms (same box, tools/ab_grouped.sh).  bf16 operands or plane pairs ("bf16x3"); 0 = off.
+_WGRAD_GROUP_TOKENS = int(os.environ.get("DM_WGRAD_GROUP", "12288"))
 _side_streams = {}
 
 
@@ -1511,7 +1564,12 @@ class BlockFn(torch.autograd.Function):
         db2, k_b2 = _grad_out(P_fc2_b, (Cc,), dev)
         side = _side_stream(dev) if 0 < M <= _WGRAD_SIDE_TOKENS else None
 
+        pending = [] if (side is None and (lp or planes) and 0 < M <= _WGRAD_GROUP_TOKENS) else None
+
         def wgrad(*a, **kw):
+            if pending is not None:           # issued together at the end of this backward (gemm_grouped)
+                pending.append((a, kw))
+                return None
             if side is None:
                 return gemm(*a, **kw)
             side.wait_stream(torch.cuda.current_stream())          # the operands' producers
@@ -1589,6 +1647,8 @@ class BlockFn(torch.autograd.Function):
                           want_pair=planes)
         if side is not None:
             torch.cuda.current_stream().wait_stream(side)          # join: every weight gradient of this block is complete
+        if pending:
+            gemm_grouped(pending)
         dx = r[0].view(B, N, Cc)
         if lp:
             # The bf16 copy the LayerNorm backward wrote rides on the tensor object autograd hands to the next node (the

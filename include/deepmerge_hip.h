@@ -43,7 +43,7 @@ typedef enum {
 
 /* ---- library ------------------------------------------------------------------------- */
 int dm_abi_version(void);   /* 2: dm_patch_pyramid / dm_patch_pyramid_cols take a resize rule; 3: table-reading and split-bf16 attention entry points, dm_split_bf16_colsum (round 3);
-                             * 4: DmGemmArgs.k_fold / a_fold / b_fold, dm_split_bf16_planes (round 4); 5: dm_pair_batch_gather (round 5) */
+                             * 4: DmGemmArgs.k_fold / a_fold / b_fold, dm_split_bf16_planes (round 4); 5: dm_pair_batch_gather (round 5); 6: dm_gemm_grouped (round 5) */
 const char *dm_last_error(void);
 /* Name of the code object architecture the library was built for ("gfx950"). */
 const char *dm_arch(void);
@@ -122,6 +122,15 @@ typedef struct {
 int dm_gemm(const DmGemmArgs *args, void *stream);
 /* Bytes of workspace dm_gemm may use for these dimensions (upper bound over split_k choices). */
 int64_t dm_gemm_workspace_bytes(int32_t layout, int32_t M, int32_t N, int32_t K);
+/* ABI 6: n INDEPENDENT products (no output overlaps another product's operands or output), results as n dm_gemm calls in order --
+ * weight gradients up to the order of the fp32 additions over K (a grouped launch takes each product in one K slice, separate calls
+ * may slice).  The four weight gradients of a transformer block (dW = dy^T x for qkv / proj / fc1 / fc2: nets/ShfitScaleFormer.py:35,
+ * :119, :134 under autograd) do not feed anything else in the block's backward pass; at the 4096- and 1024-token stages each of them has
+ * 12 .. 48 output tiles, too few for the chip, and alone pays K slices + a slab + a reduction launch.  Fast path: 2 .. 8 plain bf16 DM_TN
+ * products (fp32 C, no epilogue operands, split_k == 0, M % 256 == N % 192 == K % 128 == 0) whose 256 x 192 tiles together fit one round
+ * of the CUs and whose contraction is <= 12288 (plain bf16 operands, or hi / lo plane pairs through k_fold): ONE launch, colsum_a produced by the same launch.  Every other group: the calls one
+ * after the other (same errors as dm_gemm).  Each args[i] carries its own workspace, as for dm_gemm. */
+int dm_gemm_grouped(const DmGemmArgs *args, int32_t n, void *stream);
 
 /* ---- fused attention with 3-D relative-position bias -------------------------------------
  * Replaces nets/ShfitScaleFormer.py:119-133 (reshape/permute, q*scale, q@k^T, bias add, softmax,

@@ -34,7 +34,7 @@ def test_library_exports_every_declared_symbol(built_lib):
 
 def test_library_identity_calls(built_lib):
     lib = built_lib.lib()
-    assert lib.dm_abi_version() == 5
+    assert lib.dm_abi_version() == 6
     assert lib.dm_arch() == b"gfx950"
     assert lib.dm_gemm_workspace_bytes(built_lib.DM_NT, 1024, 768, 768) == 0
     assert lib.dm_gemm_workspace_bytes(built_lib.DM_TN, 768, 768, 16384) > 0

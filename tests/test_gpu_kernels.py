@@ -940,6 +940,91 @@ def test_gemm_wgrad_with_fused_column_sums(M, N, K):
         ops.gemm(DM_TN, dy, x, dw, M, N, K, lda=M, ldb=N, ldc=N, colsum_out=torch.empty(M - 1, device=DEV))
 
 
+@pytest.mark.parametrize("T,acc", [(1024, False), (4096, False), (4096, True), (1152, True)])
+def test_gemm_grouped_block_weight_gradients(T, acc):
+    """dm_gemm_grouped: the four weight gradients of a block (dW = dy^T x for qkv / proj / fc1 / fc2, nets/ShfitScaleFormer.py:35, :119,
+    :134 under autograd) in ONE launch of the 4-wave kernel -- 144 tiles, one K slice each, the bias gradients from the same launch.
+    Exact on integer data (so the order of the fp32 additions does not matter): equal to the separate dm_gemm calls bit for bit, with
+    `accumulate` / `colsum_accumulate` honoured."""
+    ops = _ops()
+    from deepmerge_amd._lib import DM_TN
+    g = torch.Generator(device=DEV); g.manual_seed(T + int(acc))
+    C, H = 768, 3072
+    calls, want = [], []
+    for i, (m, n) in enumerate([(C, H), (H, C), (C, C), (3 * C, C)]):          # the order BlockFn.backward issues them in
+        dy = torch.randint(-1, 2, (T, m), device=DEV, generator=g).to(torch.bfloat16)
+        x = torch.randint(-1, 2, (T, n), device=DEV, generator=g).to(torch.bfloat16)
+        dw0 = torch.randint(-3, 4, (m, n), device=DEV, generator=g).float()
+        db0 = torch.randint(-3, 4, (m,), device=DEV, generator=g).float()
+        dw, db = dw0.clone(), db0.clone()
+        calls.append(((DM_TN, dy, x, dw, m, n, T), dict(lda=m, ldb=n, ldc=n, accumulate=acc, colsum_out=db, colsum_accumulate=acc)))
+        want.append((dy.float().T @ x.float() + (dw0 if acc else 0), dy.float().sum(0) + (db0 if acc else 0), dw, db))
+    ops.gemm_grouped(calls)
+    for k, (w_dw, w_db, dw, db) in enumerate(want):
+        assert torch.equal(dw, w_dw), f"product {k}: weight gradient"
+        assert torch.equal(db, w_db), f"product {k}: bias gradient"
+
+
+@pytest.mark.parametrize("T,acc", [(1024, False), (4096, True)])
+def test_gemm_grouped_plane_pair_weight_gradients(T, acc):
+    """The grouped launch on hi / lo plane pairs (the "bf16x3" products of the tolerance mode): dW = hi^T hi + hi^T lo + lo^T hi and
+    db = colsum(hi) + colsum(lo), exact on data whose pieces, products and partial sums are exactly representable."""
+    ops = _ops()
+    from deepmerge_amd._lib import DM_TN
+    g = torch.Generator(device=DEV); g.manual_seed(3 * T + int(acc))
+    C, H = 768, 3072
+
+    def mat(shape):      # +-(i + j / 1024), i in {1, 2}: hi = +-i, lo = +-j / 1024; every product kept and every partial sum fits 24 bits
+        sign = torch.randint(0, 2, shape, device=DEV, generator=g).float() * 2 - 1
+        return sign * (torch.randint(1, 3, shape, device=DEV, generator=g).float() + torch.randint(0, 4, shape, device=DEV, generator=g).float() / 1024)
+    calls, want = [], []
+    for (m, n) in [(C, H), (H, C), (C, C), (3 * C, C)]:
+        dy, x = ops.split_planes(mat((T, m))), ops.split_planes(mat((T, n)))
+        dw0 = torch.randint(-3, 4, (m, n), device=DEV, generator=g).float()
+        db0 = torch.randint(-3, 4, (m,), device=DEV, generator=g).float()
+        dw, db = dw0.clone(), db0.clone()
+        calls.append(((DM_TN, dy, x, dw, m, n, T), dict(lda=m, ldb=n, ldc=n, accumulate=acc, colsum_out=db, colsum_accumulate=acc)))
+        ah, al, bh, bl = dy.t[0].double(), dy.t[1].double(), x.t[0].double(), x.t[1].double()
+        w = (ah.T @ bh + ah.T @ bl + al.T @ bh).float()
+        want.append((w + (dw0 if acc else 0), (ah.sum(0) + al.sum(0)).float() + (db0 if acc else 0), dw, db))
+    ops.gemm_grouped(calls)
+    for k, (w_dw, w_db, dw, db) in enumerate(want):
+        assert torch.equal(dw, w_dw), f"product {k}: weight gradient"
+        assert torch.equal(db, w_db), f"product {k}: bias gradient"
+
+
+def test_gemm_grouped_falls_back_to_separate_calls():
+    """Groups the one-launch form does not describe -- a ragged member, a single product, a forward product, mixed `accumulate`, fp32
+    operands -- run as the separate calls would; errors of a member surface as dm_gemm's."""
+    ops = _ops()
+    from deepmerge_amd._lib import DM_NT, DM_TN
+    g = torch.Generator(device=DEV); g.manual_seed(11)
+
+    def tn(m, n, K, acc=False, dt=torch.bfloat16):
+        dy = torch.randint(-1, 2, (K, m), device=DEV, generator=g).to(dt)
+        x = torch.randint(-1, 2, (K, n), device=DEV, generator=g).to(dt)
+        dw0 = torch.randint(-3, 4, (m, n), device=DEV, generator=g).float()
+        dw = dw0.clone()
+        return ((DM_TN, dy, x, dw, m, n, K), dict(lda=m, ldb=n, ldc=n, accumulate=acc)), dy.float().T @ x.float() + (dw0 if acc else 0), dw
+    groups = [[tn(768, 768, 1024), tn(104, 768, 640)],                       # ragged member
+              [tn(768, 768, 1024)],                                          # one product
+              [tn(768, 768, 1024, acc=True), tn(768, 3072, 1024)],           # mixed accumulate
+              [tn(768, 768, 1024, dt=torch.float32), tn(256, 192, 256, dt=torch.float32)],      # fp32 operands
+              [tn(768, 3072, 16384), tn(3072, 768, 16384)]]                  # long contraction: separate slices win, the rule keeps them apart
+    for grp in groups:
+        ops.gemm_grouped([c for c, _, _ in grp])
+        for _, want, dw in grp:
+            assert torch.equal(dw, want)
+    a = torch.randint(-2, 3, (512, 768), device=DEV, generator=g).to(torch.bfloat16)
+    w = torch.randint(-2, 3, (768, 768), device=DEV, generator=g).to(torch.bfloat16)
+    out = torch.empty((512, 768), device=DEV, dtype=torch.bfloat16)
+    (c, want, dw) = tn(768, 768, 1024)
+    ops.gemm_grouped([((DM_NT, a, w, out, 512, 768, 768), dict(lda=768, ldb=768, ldc=768)), c])
+    assert torch.equal(out, (a.float() @ w.float().T).to(torch.bfloat16)) and torch.equal(dw, want)
+    with pytest.raises(ValueError):
+        ops.gemm_grouped([c, ((DM_TN, a, w, out, 768, 768, 512), dict(lda=768, ldb=768, ldc=768, accumulate=True))])      # accumulate needs fp32 C
+
+
 @pytest.mark.parametrize("layout,M,N,K", [("NT", 64, 100, 3840), ("NN", 64, 100, 3840), ("TN", 100, 52, 2050), ("NT", 7, 19, 1024), ("NT", 128, 256, 1500)])
 def test_gemm_skinny_fp32_k_slices(layout, M, N, K, monkeypatch):
     """The generic fp32 path cuts the contraction of skinny products (the 100-wide head over 3840 pooled features,

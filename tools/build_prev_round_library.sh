@@ -15,6 +15,14 @@ extern "C" int dm_pair_batch_gather(const void *, int, int, int, int, const void
                                     const void *, void *, void *, void *) { return -6; }
 EOS
 fi
+if ! grep -q dm_gemm_grouped "$TMP/include/deepmerge_hip.h"; then      # (ABI 6: the separate calls, which is what the entry point means)
+cat >> "$TMP/deepmerge_amd/csrc/dm_api.cpp" <<'EOS'
+extern "C" int dm_gemm_grouped(const DmGemmArgs *args, int32_t n, void *stream) {
+  for (int i = 0; i < n; ++i) { const int rc = dm_gemm(&args[i], stream); if (rc != 0) return rc; }
+  return 0;
+}
+EOS
+fi
 make -C "$TMP/deepmerge_amd/csrc" -j6 > "$TMP/build.log" 2>&1 || { tail -20 "$TMP/build.log"; exit 1; }
 mkdir -p "$ROOT/tools/hip/variants"
 cp "$TMP/deepmerge_amd/libdeepmerge_hip.so" "$ROOT/tools/hip/variants/libdm_$TAG.so"
