@@ -66,7 +66,8 @@ SIGNATURES = {
     "dm_arch": (C.c_char_p, []),
     "dm_gemm": (_I, [C.POINTER(DmGemmArgs), _P]),
     "dm_gemm_workspace_bytes": (_L, [_I, _I, _I, _I]),
-    "dm_gemm_grouped": (_I, [C.POINTER(DmGemmArgs), _I, _P]),
+    "dm_gemm_grouped": (_I, [C.POINTER(DmGemmArgs), _I, _P, _L, _P]),
+    "dm_gemm_grouped_workspace_bytes": (_L, [C.POINTER(DmGemmArgs), _I]),
     "dm_attention_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _P]),
     "dm_attention_relpos_inkernel": (_I, [_I, _I, _I, _I, _I, _I, _I, _I]),
     "dm_attention_fwd_relpos": (_I, [_P, _P, _I, _I, _I, _P, _P, _I, _I, _I, _I, _F, _I, _P]),

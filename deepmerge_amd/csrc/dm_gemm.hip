@@ -44,7 +44,8 @@ int dm_gemm_ring_plan(GemmParams &p, int layout, int ab_dtype, bool aligned8);  
 void dm_gemm_ring_launch(const GemmParams &p, int wm, hipStream_t s);
 int dm_gemm_w4_plan(GemmParams &p, int layout, int ab_dtype, bool aligned8, bool can_split, long long workspace_bytes);   // dm_gemm_w4.hip (grid size, 0 = not taken)
 void dm_gemm_w4_launch(const GemmParams &p, int layout, int grid, hipStream_t s);
-bool dm_gemm_w4_grouped(GemmParams *ps, int n, hipStream_t s, bool launch);      // dm_gemm_w4.hip: n weight gradients in one launch (false = not taken)
+int dm_gemm_w4_grouped(GemmParams *ps, int n, hipStream_t s, bool launch, const DmGroupedExtra &x);      // dm_gemm_w4.hip: n weight gradients in one launch (0 = not taken, 1 = one K slice per tile, 2 = stream-K)
+long long dm_gemm_w4_grouped_ws_bytes();
 
 namespace {
 
@@ -1047,16 +1048,28 @@ extern "C" int dm_gemm(const DmGemmArgs *a, void *stream) {
 }
 
 // n independent products, results as n dm_gemm calls in order would give them (weight gradients: up to the order of the fp32 additions
-// over K -- a grouped launch takes each in ONE K slice, the separate calls may slice).  The products must not overlap in their outputs and
-// none may read another's output.  Fast path: 2 .. 8 plain bf16 weight gradients (DM_TN, fp32 C, no epilogue operands, whole 256 x 192
-// tiles, automatic slice count) whose tiles together fit one round of the CUs -- ONE launch of the 4-wave kernel (dm_gemm_w4_grouped), the
-// column sums of A written in the same launch.  Anything else: the calls one after the other.
-extern "C" int dm_gemm_grouped(const DmGemmArgs *args, int32_t n, void *stream) {
+// over K).  The products must not overlap in their outputs and none may read another's output.  Fast path: 1 .. 8 bf16 weight gradients
+// (DM_TN, plain operands or plane pairs, fp32 C, no epilogue operands, whole 256 x 192 tiles, automatic slice count) in ONE launch of the
+// 4-wave kernel (dm_gemm_w4_grouped: one K slice per tile for short contractions, stream-K + one fix-up launch for long ones; the column sums
+// of A from the same launches).  Anything else: the calls one after the other.
+extern "C" int64_t dm_gemm_grouped_workspace_bytes(const DmGemmArgs *args, int32_t n) {
+  if (args == nullptr || n < 1 || n > 8) return 0;
+  const char *menv = getenv("DM_GEMM_GROUPED");      // only the stream-K form (never chosen by the default rule) takes a group workspace
+  if (!menv || atoi(menv) != 3) return 0;
+  for (int i = 0; i < n; ++i)
+    if (args[i].layout != DM_TN || args[i].ab_dtype != DM_BF16 || args[i].M % 256 != 0 || args[i].N % 192 != 0) return 0;
+  return dm_gemm_w4_grouped_ws_bytes();
+}
+
+extern "C" int dm_gemm_grouped(const DmGemmArgs *args, int32_t n, void *workspace, int64_t workspace_bytes, void *stream) {
   DM_REQUIRE(args != nullptr && n >= 1, DM_ERR_BAD_SHAPE, "dm_gemm_grouped: null args / n < 1");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  bool fast = n >= 2 && n <= 8;
+  bool fast = n <= 8;
   GemmParams ps[8];
-  float *cs_rows[8] = {nullptr};       // per product: the row the launch writes when the sums must be ADDED to colsum_a afterwards
+  float *cs_rows[8] = {nullptr};       // form 1, per product: the row the launch writes when the sums must be ADDED to colsum_a afterwards
+  DmGroupedExtra x{};
+  x.ws = (workspace && dm_aligned16(workspace)) ? workspace : nullptr;
+  x.ws_bytes = x.ws ? workspace_bytes : 0;
   for (int i = 0; fast && i < n; ++i) {
     const DmGemmArgs &a = args[i];
     fast = a.layout == DM_TN && a.ab_dtype == DM_BF16 && a.c_dtype == DM_F32 && a.epilogue == DM_EPI_NONE && a.split_k == 0 && a.k_fold >= 0 &&
@@ -1080,9 +1093,11 @@ extern "C" int dm_gemm_grouped(const DmGemmArgs *args, int32_t n, void *stream) 
       if (!fast) break;
       p.k_fold = a.k_fold;
     }
+    x.cs_out[i] = a.colsum_a;
+    x.cs_acc[i] = a.colsum_accumulate ? 1 : 0;
     if (a.colsum_a) {
       if (!a.colsum_accumulate) {
-        p.colsum_slab = a.colsum_a;                      // first write of the step: the launch stores the sums where they belong
+        p.colsum_slab = a.colsum_a;                      // form 1, first write of the step: the launch stores the sums where they belong
       } else {
         const int64_t need = colsum_region_floats(a.M) * 4;
         fast = a.workspace != nullptr && a.workspace_bytes >= need;
@@ -1093,8 +1108,8 @@ extern "C" int dm_gemm_grouped(const DmGemmArgs *args, int32_t n, void *stream) 
     }
     ps[i] = p;
   }
-  if (fast) fast = dm_gemm_w4_grouped(ps, n, s, false);
-  if (fast) {
+  const int form = fast ? dm_gemm_w4_grouped(ps, n, s, false, x) : 0;
+  if (form != 0) {
     double flops = 0, bytes = 0;
     for (int i = 0; i < n; ++i) {
       flops += 2.0 * args[i].M * args[i].N * args[i].K;
@@ -1104,16 +1119,17 @@ extern "C" int dm_gemm_grouped(const DmGemmArgs *args, int32_t n, void *stream) 
     char shaped[64];
     const char *pname = "gemm_bf16_TN";
     if (by_shape) {
-      snprintf(shaped, sizeof(shaped), "gemm_bf16_TN_grouped%d_K%d", n, args[0].K);
+      snprintf(shaped, sizeof(shaped), "gemm_bf16_TN_grouped%d_K%d_%s", n, args[0].K, form == 2 ? "streamk" : "1slice");
       pname = shaped;
     }
     {
-      DmProfScope prof(pname, s, flops, bytes);
-      dm_gemm_w4_grouped(ps, n, s, true);
+      DmProfScope prof(pname, s, flops, bytes);      // (stream-K: the fix-up launch is inside the scope, like the reductions of sliced products are not)
+      dm_gemm_w4_grouped(ps, n, s, true, x);
     }
-    for (int i = 0; i < n; ++i)
-      if (cs_rows[i])
-        hipLaunchKernelGGL(colsum_rows_reduce_kernel, dim3((args[i].M + 63) / 64), dim3(64), 0, s, cs_rows[i], args[i].colsum_a, args[i].M, 1, 1);
+    if (form == 1)
+      for (int i = 0; i < n; ++i)
+        if (cs_rows[i])
+          hipLaunchKernelGGL(colsum_rows_reduce_kernel, dim3((args[i].M + 63) / 64), dim3(64), 0, s, cs_rows[i], args[i].colsum_a, args[i].M, 1, 1);
     DM_LAUNCH_CHECK("dm_gemm_grouped");
     return DM_OK;
   }

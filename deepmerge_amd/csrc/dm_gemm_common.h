@@ -24,6 +24,9 @@ struct GemmParams {
   long long c_plane;    // c_dtype == DM_BF16_PAIR: element offset of the lo plane behind C (the hi plane)
 };
 
+// dm_gemm_grouped -> dm_gemm_w4_grouped: where the column sums of A go (stream-K form) and the group's workspace
+struct DmGroupedExtra { float *cs_out[8]; int cs_acc[8]; void *ws; long long ws_bytes; };
+
 // The result strip as a hi / lo plane pair (c_dtype == DM_BF16_PAIR): hi = bf16(v), lo = bf16(v - hi) -- the split of dm_split_bf16.
 __device__ __forceinline__ void dm_store_pair4(const GemmParams &p, long long off, const f32x4 &v) {
   bf16x4 h, l;

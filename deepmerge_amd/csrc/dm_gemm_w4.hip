@@ -76,8 +76,14 @@ __device__ __forceinline__ void mma_pinned(f32x4 &acc, const u32x4 &a, const u32
 // needs 3 steps: the staging / fragment traffic that bounds this kernel's step drops by a third.
 // The kernel body: workgroup L of G (XCD-remapped ids) of the launch described by p.  gemm_w4_kernel runs it for one product;
 // gemm_w4_grouped_kernel for one of several independent weight gradients sharing a launch (dm_gemm_grouped).
-template <int LAYOUT, int DBG, int EK, bool FOLD, bool CS>
-__device__ __forceinline__ void gemm_w4_body(const GemmParams &p, const int G, const int L) {
+// SK ("stream-K" weight gradients, gemm_w4_streamk_kernel): the workgroup owns `sk.count` consecutive K steps of the product's step space
+// (tile-major: tile t is steps [t * sk.steps, (t + 1) * sk.steps)) starting at sk.g0, i.e. the tail of one tile, then whole tiles, then the
+// head of another; every piece (segment) leaves a partial tile in slot sk.slot0 + r of the tile-local slab p.workspace [slot][256][192]
+// (column sums: p.colsum_slab [slot][256]) and streamk_fixup_kernel sums a tile's pieces in workgroup order.
+struct W4Sk { int g0, count, steps, slot0; };
+template <int LAYOUT, int DBG, int EK, bool FOLD, bool CS, bool SK = false>
+__device__ __forceinline__ void gemm_w4_body(const GemmParams &p, const int G, const int L, const W4Sk sk = W4Sk{0, 0, 1, 0}) {
+  static_assert(!SK || (LAYOUT == DM_TN && EK != 0 && DBG == 0), "stream-K segments: weight gradients with the lean epilogue");
   constexpr int EPIU = 0;
   constexpr bool AMM = (LAYOUT == DM_TN);      // A m-contiguous [K][M] (wgrad) or k-contiguous [M][K]
   constexpr bool BMM = (LAYOUT != DM_NT);      // B m-contiguous [K][N] (dgrad, wgrad) or k-contiguous [N][K] (forward)
@@ -112,8 +118,22 @@ __device__ __forceinline__ void gemm_w4_body(const GemmParams &p, const int G, c
   const int kend = sliced ? min(k_total, kbeg + p.k_per_split) : k_total;
   const int ntile = (kend - kbeg) / BKR;
   const long long a_lo = FOLD ? p.a_fold[2] : 0, b_lo = FOLD ? p.b_fold[1] : 0;      // element offset of the lo plane behind the hi plane
-  const int n_my = sliced ? 1 : (tiles - L + G - 1) / G;
-  const int total = n_my * ntile;
+  const int sk_t0 = SK ? sk.g0 / sk.steps : 0;          // first tile this workgroup touches
+  const int n_my = SK ? (sk.g0 + sk.count - 1) / sk.steps - sk_t0 + 1 : sliced ? 1 : (tiles - L + G - 1) / G;
+  const int total = SK ? sk.count : n_my * ntile;
+  // K steps / first contraction position / contraction length of work item r (SK: segment r; else every item is [kbeg, kend))
+  auto nt = [&](int r) __attribute__((always_inline)) {
+    if constexpr (!SK) return ntile;
+    else return min((sk_t0 + r + 1) * sk.steps, sk.g0 + sk.count) - max((sk_t0 + r) * sk.steps, sk.g0);
+  };
+  auto kb = [&](int r) __attribute__((always_inline)) {
+    if constexpr (!SK) return kbeg;
+    else return (r == 0 ? sk.g0 - sk_t0 * sk.steps : 0) * BKR;
+  };
+  auto kl = [&](int r) __attribute__((always_inline)) {
+    if constexpr (!SK) return kend - kbeg;
+    else return nt(r) * BKR;
+  };
 
   // ---- global -> register mapping -----------------------------------------------------------------------------------------------
   // k-contiguous operand: load u of a thread is the 16-byte chunk (t & 7) of tile row (t >> 3) + 32 u; LDS image = rows of 128 B,
@@ -197,7 +217,7 @@ __device__ __forceinline__ void gemm_w4_body(const GemmParams &p, const int G, c
   // ---- tile cursors (uniform) -------------------------------------------------------------------------------------------------------
   const bf16_t *Ab = reinterpret_cast<const bf16_t *>(p.A), *Bb = reinterpret_cast<const bf16_t *>(p.B);
   auto tile_mn = [&](int r, int &m0, int &n0) __attribute__((always_inline)) {
-    const int tid = (DBG & 64) ? (L & 7) : sliced ? L - zslice * tiles : L + r * G;        // (ablation 64: every workgroup reads the same few L2-resident tiles)
+    const int tid = SK ? sk_t0 + r : (DBG & 64) ? (L & 7) : sliced ? L - zslice * tiles : L + r * G;        // (ablation 64: every workgroup reads the same few L2-resident tiles)
     // (A BLOCKED order -- column blocks of 8 tiles walked row by row, an XCD keeping its own chunk over the rounds, so that its 32
     // workgroups share 4 panels of A and 8 of B instead of 2 and 16 -- was measured in round 4: 16384 x 3072 x 768 on 4 rounds 103 -> 97 us,
     // x 2304 on 3 rounds 80 -> 77 us, the sliced weight gradients unchanged; the multi-round products still lose to the kernels with 2-3
@@ -208,22 +228,24 @@ __device__ __forceinline__ void gemm_w4_body(const GemmParams &p, const int G, c
   };
   // (FOLD: the descriptor also reaches over the lo plane's part of the panel -- rows past the operand's last one then still fall outside
   // it in the lo plane, i.e. never outside the plane pair; in the hi plane they read other rows of the pair: outputs nobody stores)
-  auto make_a = [&](int m0, bool live) __attribute__((always_inline)) {
+  auto make_a = [&](int m0, bool live, int r = 0) __attribute__((always_inline)) {
+    const int kb0 = kb(live ? r : 0), kl0 = kl(live ? r : 0);
     if constexpr (!AMM) {
-      const long long bytes = ((long long)(min(TM, p.M - m0) - 1) * p.lda + (kend - kbeg) + a_lo) * 2;
-      return __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t *>(Ab + (long long)m0 * p.lda + kbeg), 0, live ? (int)min(bytes, 0x7fffffffLL) : 0, 0x00020000);
+      const long long bytes = ((long long)(min(TM, p.M - m0) - 1) * p.lda + kl0 + a_lo) * 2;
+      return __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t *>(Ab + (long long)m0 * p.lda + kb0), 0, live ? (int)min(bytes, 0x7fffffffLL) : 0, 0x00020000);
     } else {
-      const long long bytes = ((long long)(kend - kbeg - 1) * p.lda + (p.M - m0) + a_lo) * 2;
-      return __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t *>(Ab + (long long)kbeg * p.lda + m0), 0, live ? (int)min(bytes, 0x7fffffffLL) : 0, 0x00020000);
+      const long long bytes = ((long long)(kl0 - 1) * p.lda + (p.M - m0) + a_lo) * 2;
+      return __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t *>(Ab + (long long)kb0 * p.lda + m0), 0, live ? (int)min(bytes, 0x7fffffffLL) : 0, 0x00020000);
     }
   };
-  auto make_b = [&](int n0, bool live) __attribute__((always_inline)) {
+  auto make_b = [&](int n0, bool live, int r = 0) __attribute__((always_inline)) {
+    const int kb0 = kb(live ? r : 0), kl0 = kl(live ? r : 0);
     if constexpr (!BMM) {
-      const long long bytes = ((long long)(min(TN, p.N - n0) - 1) * p.ldb + (kend - kbeg) + b_lo) * 2;
-      return __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t *>(Bb + (long long)n0 * p.ldb + kbeg), 0, live ? (int)min(bytes, 0x7fffffffLL) : 0, 0x00020000);
+      const long long bytes = ((long long)(min(TN, p.N - n0) - 1) * p.ldb + kl0 + b_lo) * 2;
+      return __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t *>(Bb + (long long)n0 * p.ldb + kb0), 0, live ? (int)min(bytes, 0x7fffffffLL) : 0, 0x00020000);
     } else {
-      const long long bytes = ((long long)(kend - kbeg - 1) * p.ldb + (p.N - n0) + b_lo) * 2;
-      return __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t *>(Bb + (long long)kbeg * p.ldb + n0), 0, live ? (int)min(bytes, 0x7fffffffLL) : 0, 0x00020000);
+      const long long bytes = ((long long)(kl0 - 1) * p.ldb + (p.N - n0) + b_lo) * 2;
+      return __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t *>(Bb + (long long)kb0 * p.ldb + n0), 0, live ? (int)min(bytes, 0x7fffffffLL) : 0, 0x00020000);
     }
   };
   int m_cur, n_cur;
@@ -243,23 +265,23 @@ __device__ __forceinline__ void gemm_w4_body(const GemmParams &p, const int G, c
   Cursor cx{0, 0}, cy{0, 0};
   __amdgpu_buffer_rsrc_t rsAx = make_a(m_cur, true), rsBx = make_b(n_cur, true), rsAy = rsAx, rsBy = rsBx;
   auto advance_x = [&]() __attribute__((always_inline)) {
-    if (++cx.k == ntile) {
+    if (++cx.k == nt(cx.r)) {
       cx.k = 0; ++cx.r;
       int m0 = 0, n0 = 0;
       const bool live = cx.r < n_my;
       if (live) tile_mn(cx.r, m0, n0);
-      rsAx = make_a(m0, live);
-      rsBx = make_b(n0, live);
+      rsAx = make_a(m0, live, cx.r);
+      rsBx = make_b(n0, live, cx.r);
     }
   };
   auto advance_y = [&]() __attribute__((always_inline)) {
-    if (++cy.k == ntile) {
+    if (++cy.k == nt(cy.r)) {
       cy.k = 0; ++cy.r;
       int m0 = 0, n0 = 0;
       const bool live = cy.r < n_my;
       if (live) tile_mn(cy.r, m0, n0);
-      rsAy = make_a(m0, live);
-      rsBy = make_b(n0, live);
+      rsAy = make_a(m0, live, cy.r);
+      rsBy = make_b(n0, live, cy.r);
     }
   };
 
@@ -315,7 +337,7 @@ __device__ __forceinline__ void gemm_w4_body(const GemmParams &p, const int G, c
   // branches per K step in EVERY workgroup cost more than the MFMAs they skipped -- weight gradients 96 -> 91 us.  CS = false: instances
   // without any of it, for launches that want no column sums.)
   constexpr bool CSM = AMM && CS;
-  const bool colsum = CSM && p.colsum_slab != nullptr && n_cur == 0;
+  bool colsum = CSM && p.colsum_slab != nullptr && n_cur == 0;      // (SK: re-evaluated when the workgroup moves on to its next tile)
   f32x4 accb[CSM ? 8 : 1];
   const unsigned one2 = colsum ? 0x3F803F80u : 0u;
   u32x4 ones = {one2, one2, one2, one2};     // eight bf16 1.0 (column tile 0) or zeros
@@ -473,7 +495,7 @@ __device__ __forceinline__ void gemm_w4_body(const GemmParams &p, const int G, c
     int lane = lane_outer;
     asm volatile("" : "+v"(lane) : "v"(tv[0]), "v"(tv[1]), "v"(tv[2]), "v"(tv[3]), "v"(tv[4]), "v"(tv[5]));
     const int g = lane >> 4, li = lane & 15;
-    const bool split = p.split_k > 1;
+    const bool split = SK || p.split_k > 1;
     const bool c32 = (AMM || split) ? true : (RT ? (p.c_dtype == DM_F32) : C32);
     const bool x32 = RT ? (p.aux_dtype == DM_F32) : (YL == 3 || XS == 2);
     const bool plain = AMM || split;                       // no fused epilogue: partial tile / weight gradient
@@ -484,9 +506,10 @@ __device__ __forceinline__ void gemm_w4_body(const GemmParams &p, const int G, c
     const int csz = c32 ? 4 : 2, xsz = x32 ? 4 : 2;
     const int m_base = m_cur + wm * 128, n_base = n_cur;            // wave-uniform (wave id through readfirstlane)
     const bool live = m_base < p.M;
-    const long long rows_below = (long long)(p.M - 1 - m_base), cols_right = (long long)(p.N - n_base);
-    const long long ldc_eff = split ? (long long)p.N : p.ldc;
-    char *cptr = split ? reinterpret_cast<char *>(p.workspace + ((long long)zslice * p.M + m_base) * p.N + n_base)
+    const long long rows_below = SK ? (long long)(TM - 1 - wm * 128) : (long long)(p.M - 1 - m_base), cols_right = SK ? (long long)TN : (long long)(p.N - n_base);
+    const long long ldc_eff = SK ? (long long)TN : split ? (long long)p.N : p.ldc;
+    char *cptr = SK ? reinterpret_cast<char *>(p.workspace + ((long long)(sk.slot0 + r) * TM + wm * 128) * TN)      // tile-local slab slot of this segment
+               : split ? reinterpret_cast<char *>(p.workspace + ((long long)zslice * p.M + m_base) * p.N + n_base)
                        : reinterpret_cast<char *>(p.C) + ((long long)m_base * p.ldc + n_base) * csz;
     const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc(cptr, 0, live ? dm_epi_records((rows_below * ldc_eff + cols_right) * csz) : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc(
@@ -619,7 +642,7 @@ __device__ __forceinline__ void gemm_w4_body(const GemmParams &p, const int G, c
 #pragma unroll
       for (int i = 0; i < 8; ++i) asm volatile("" : "+a"(accb[i]));
       if (colsum && wn == 0 && g == 0) {
-        float *row = p.colsum_slab + (long long)zslice * p.M;
+        float *row = SK ? p.colsum_slab + (long long)(sk.slot0 + r) * TM - m_cur : p.colsum_slab + (long long)zslice * p.M;
 #pragma unroll
         for (int i = 0; i < 8; ++i) row[m_cur + wm * 128 + i * 16 + li] = accb[i][0];
       }
@@ -627,6 +650,14 @@ __device__ __forceinline__ void gemm_w4_body(const GemmParams &p, const int G, c
     kt = 0;
     ++r;
     if (r < n_my) tile_mn(r, m_cur, n_cur);
+    if constexpr (SK && CSM) {      // the next segment belongs to another tile: fresh column sums, and only column tile 0 takes them
+      colsum = p.colsum_slab != nullptr && n_cur == 0 && r < n_my;
+      const unsigned o2 = colsum ? 0x3F803F80u : 0u;
+      ones = (u32x4){o2, o2, o2, o2};
+      asm volatile("" : "+v"(ones));
+#pragma unroll
+      for (int i = 0; i < 8; ++i) zero_pinned(accb[i], vzero);
+    }
   };
 
   auto epilogue_generic = [&]() __attribute__((always_inline)) {
@@ -780,7 +811,7 @@ __device__ __forceinline__ void gemm_w4_body(const GemmParams &p, const int G, c
     if constexpr (FOLD) { body3(IC<0>{}); body3(IC<1>{}); }
     else { body(IC<0>{}); body(IC<1>{}); }
     kt += 2;
-    if (kt == ntile) {
+    if (kt == nt(r)) {
       if (r == 0) DMW4_K(3);
       if constexpr (DBG & 1) { kt = 0; ++r; if (r < n_my) tile_mn(r, m_cur, n_cur); } else
       if constexpr (EK == 0) epilogue_generic();
@@ -810,6 +841,87 @@ struct GemmGroup {
   int first[GROUP_MAX + 1];
   int n;
 };
+// Stream-K form of the grouped launch (long contractions: the 16384-token blocks, ViT's 50 k tokens): product i owns workgroups first[i] ..
+// first[i + 1] - 1, each of which takes q[i] consecutive K steps of the product's tile-major step space (W4Sk), so that every CU does the same
+// number of K steps whatever the tile count -- where K slices per product leave 181 MB of slabs per block (up to 16 partial copies of a gradient)
+// and a reduction launch per product, a tile here has 2-3 partial pieces (~65 MB per block) and ONE fix-up launch sums them in workgroup order.
+// MEASURED AND NOT USED (round 5; DM_GEMM_GROUPED=3 selects it, the tests cover it): exact, but the four weight gradients of a 16384-token
+// block take 287 us in this kernel + 32 us of fix-up against 283 us for the four sliced launches with their reductions (8192 tokens: 195 vs
+// 186 us).  The step count per CU is what was planned (146 vs 4 x ~37-52); the step itself is 1.96 us instead of 1.27: workgroups that run
+// at the same time sit at DIFFERENT K offsets of their tiles, so no two of them ever want the same operand panel at the same time, and the
+// launch fetches (256 + 192) x 64 x 2 B per workgroup and step = 2.1 GB at 7.3 TB/s -- where the tiles of one K slice, walking K in lockstep,
+// share every A panel four ways and every B panel nine ways through L2 (10.7 KB per workgroup and step instead of 57).  An L2 of 4 MB holds
+// two steps of an XCD's panels, so an offset in time is as bad as no reuse.  What would keep both properties -- equal step counts AND
+// lockstep -- is a rectangular decomposition (all tiles x K[0, q) on T workgroups, the remainders on the others); priced at <= 25 us per
+// block over today's launches (their K loops sum to 199 us against an ideal 183; the rest is 4 x prologue / epilogue and 29 us of
+// reductions) and not built.
+struct GemmGroupSk {
+  GemmGroup g;
+  int q[GROUP_MAX];          // K steps per workgroup (even)
+  int steps[GROUP_MAX];      // K steps per tile (even)
+  int tile0[GROUP_MAX + 1];  // first tile of product i in the group's tile numbering (fix-up grid)
+  int chunks;                // fix-up workgroups per tile
+  int slots;                 // partial pieces a workgroup can leave: 2 (q <= steps: tail of a tile, head of the next) or 3 (q <= 2 * steps)
+  float *cs_out[GROUP_MAX];  // column sums of A wanted for product i (NULL: not), summed by the fix-up from the pieces' partial rows
+  int cs_acc[GROUP_MAX];     // ... added to what is there
+};
+template <int EK, bool FOLD, bool CS>
+__global__ __launch_bounds__(256) void gemm_w4_streamk_kernel(const GemmGroupSk grp) {
+  const int L = dm_xcd_remap(blockIdx.x, gridDim.x);
+  int i = 0;
+#pragma unroll
+  for (int k = 1; k < GROUP_MAX; ++k)
+    if (k < grp.g.n && L >= grp.g.first[k]) i = k;
+  i = __builtin_amdgcn_readfirstlane(i);
+  const GemmParams &p = grp.g.p[i];
+  const int w = L - grp.g.first[i];
+  const int total = p.tiles_m * p.tiles_n * grp.steps[i];
+  W4Sk sk;
+  sk.g0 = w * grp.q[i];
+  sk.count = min(grp.q[i], total - sk.g0);
+  sk.steps = grp.steps[i];
+  sk.slot0 = L * grp.slots;
+  if (sk.count <= 0) return;          // (the plan gives every workgroup work; uniform exit otherwise)
+  gemm_w4_body<DM_TN, 0, EK, FOLD, CS, true>(p, 1, 0, sk);
+}
+
+// Sums the partial pieces of every tile of a stream-K launch in workgroup order and stores (accumulate: adds to) the gradient; the
+// workgroups of a column-0 tile do the same for the partial column sums.  grid = tiles x chunks; a workgroup handles 256 / chunks rows.
+__global__ __launch_bounds__(256) void streamk_fixup_kernel(const GemmGroupSk grp) {
+  const int tile_g = blockIdx.x / grp.chunks, chunk = blockIdx.x - tile_g * grp.chunks;
+  int i = 0;
+#pragma unroll
+  for (int k = 1; k < GROUP_MAX; ++k)
+    if (k < grp.g.n && tile_g >= grp.tile0[k]) i = k;
+  const GemmParams &p = grp.g.p[i];
+  const int t = tile_g - grp.tile0[i], q = grp.q[i], steps = grp.steps[i];
+  const int tm = t / p.tiles_n, tn = t - tm * p.tiles_n;
+  const int w_lo = (t * steps) / q, w_hi = ((t + 1) * steps - 1) / q;
+  const int rows = TM / grp.chunks, row0 = chunk * rows;
+  auto ntl = [](const float *x) { return __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(x)); };
+  float *C = reinterpret_cast<float *>(p.C);
+  for (int e = threadIdx.x; e < rows * (TN / 4); e += blockDim.x) {
+    const int rr = row0 + e / (TN / 4), c4 = (e % (TN / 4)) * 4;
+    float *o = C + (long long)(tm * TM + rr) * p.ldc + tn * TN + c4;
+    f32x4 v = p.accumulate ? *reinterpret_cast<const f32x4 *>(o) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int w = w_lo; w <= w_hi; ++w) {
+      const int slot = (grp.g.first[i] + w) * grp.slots + (t - (w * q) / steps);
+      v += ntl(p.workspace + ((long long)slot * TM + rr) * TN + c4);
+    }
+    __builtin_nontemporal_store(v, reinterpret_cast<f32x4 *>(o));
+  }
+  if (tn == 0 && grp.cs_out[i] != nullptr && threadIdx.x < rows) {
+    const int rr = row0 + threadIdx.x;
+    float *out = grp.cs_out[i] + tm * TM + rr;
+    float v = grp.cs_acc[i] ? *out : 0.f;
+    for (int w = w_lo; w <= w_hi; ++w) {
+      const int slot = (grp.g.first[i] + w) * grp.slots + (t - (w * q) / steps);
+      v += p.colsum_slab[(long long)slot * TM + rr];
+    }
+    *out = v;
+  }
+}
+
 template <int EK, bool FOLD, bool CS>
 __global__ __launch_bounds__(256) void gemm_w4_grouped_kernel(const GemmGroup grp) {
   const int L = dm_xcd_remap(blockIdx.x, gridDim.x);
@@ -1044,64 +1156,134 @@ void dm_gemm_w4_launch(const GemmParams &p, int layout, int grid, hipStream_t s)
 #undef W4_GOT
 }
 
-// One launch for n independent weight gradients (dm_gemm_grouped): every product a plain bf16 DM_TN with fp32 C, whole 256 x 192
-// tiles, ONE K slice (the gradient is stored / accumulated in place, no slab), the same `accumulate` flag, column sums (if wanted)
-// written to ps[i].colsum_slab as ONE row [M].  Returns false (nothing launched) when the group does not fit this form or is not worth it:
-// (launch = false: decide only.)  All tiles together must fit one round of the CUs and fill at least 0.4 of them, and the contraction must be short enough that slicing the
-// products separately would not win (measured, tools/mb_grouped_estimate.py: the four weight gradients of a block 78 -> 34 us at 1024
-// tokens, 142 -> 85 us at 4096, 186 -> 142 us at 8192, 250 -> 206 us at 12288, 301 -> 293 us at 16384).
-bool dm_gemm_w4_grouped(GemmParams *ps, int n, hipStream_t s, bool launch) {
-  using namespace dmw4;
-  static const int mode = [] { const char *e = getenv("DM_GEMM_GROUPED"); return e ? atoi(e) : 1; }();      // 0 = off, 1 = rule, 2 = every legal group
-  if (mode == 0 || n < 2 || n > GROUP_MAX) return false;
+// One launch for n independent weight gradients (dm_gemm_grouped): every product a bf16 DM_TN (plain operands or hi / lo plane pairs) with
+// fp32 C and whole 256 x 192 tiles.  Two forms:
+//   1  ONE K slice per tile (short contractions, all tiles within one round of the CUs): the gradient is stored / accumulated in place, no
+//      slab; column sums (if wanted) written to ps[i].colsum_slab as ONE row [M]; the same `accumulate` flag for every product.
+//      Measured (tools/mb_grouped_estimate.py): the four weight gradients of a block 78 -> 34 us at 1024 tokens, 142 -> 85 us at 4096.
+//   2  stream-K (long contractions): see gemm_w4_streamk_kernel; needs x.ws (dm_gemm_w4_grouped_ws_bytes), column sums to x.cs_out.
+// Returns the form taken, 0 = none (nothing launched).  launch = false: decide only.
+long long dm_gemm_w4_grouped_ws_bytes() {
   const int cus = w4_cu_count();
-  if (cus <= 0) return false;
-  GemmGroup grp{};
-  long long tiles = 0;
+  return (long long)(cus > 0 ? cus : 256) * 3 * (dmw4::TM * dmw4::TN + dmw4::TM) * 4;
+}
+int dm_gemm_w4_grouped(GemmParams *ps, int n, hipStream_t s, bool launch, const DmGroupedExtra &x) {
+  using namespace dmw4;
+  // DM_GEMM_GROUPED: 0 = off, 1 = rule (default), 2 = the one-slice form for every legal group, 3 = stream-K for every legal group
+  // (read per call: the tests flip it)
+  const char *menv = getenv("DM_GEMM_GROUPED");
+  const int mode = menv ? atoi(menv) : 1;
+  if (mode == 0 || n < 1 || n > GROUP_MAX) return 0;
+  const int cus = w4_cu_count();
+  if (cus <= 0) return 0;
+  GemmGroupSk sk{};
+  GemmGroup &grp = sk.g;
+  long long tiles = 0, work = 0;
   int k_max = 0;
-  bool any_cs = false;
+  bool any_cs = false, same_acc = true;
   constexpr long long LIM = (1LL << 31) / (128LL * 4);
   const bool fold = ps[0].k_fold > 0;        // hi / lo plane pairs ("bf16x3"): all members or none; the standard pattern, as in dm_gemm_w4_plan
   for (int i = 0; i < n; ++i) {
     GemmParams &p = ps[i];
-    if ((p.k_fold > 0) != fold) return false;
+    if ((p.k_fold > 0) != fold) return 0;
     const int k_eff = fold ? p.k_fold : p.K, bk_eff = fold ? 32 : BK;
     if (fold) {
-      if (p.a_fold[0] != 0 || p.a_fold[1] != 0 || p.a_fold[2] <= 0 || p.b_fold[0] != 0 || p.b_fold[2] != 0 || p.b_fold[1] <= 0) return false;
-      if (p.a_fold[2] * 2 >= (1LL << 30) || p.b_fold[1] * 2 >= (1LL << 30)) return false;
+      if (p.a_fold[0] != 0 || p.a_fold[1] != 0 || p.a_fold[2] <= 0 || p.b_fold[0] != 0 || p.b_fold[2] != 0 || p.b_fold[1] <= 0) return 0;
+      if (p.a_fold[2] * 2 >= (1LL << 30) || p.b_fold[1] * 2 >= (1LL << 30)) return 0;
     }
-    if (p.M % TM != 0 || p.N % TN != 0 || k_eff % (2 * bk_eff) != 0 || k_eff < 2 * bk_eff || p.ldc % 4 != 0) return false;
-    if (p.c_dtype != DM_F32 || p.epilogue != DM_EPI_NONE || p.bias || p.residual || p.aux || p.rows_per_group != 0) return false;
-    if (p.accumulate != ps[0].accumulate || p.ldc >= LIM || p.N >= LIM) return false;
-    if (((long long)k_eff * p.lda + (fold ? p.a_fold[2] : 0)) * 2 >= (1LL << 31) || ((long long)k_eff * p.ldb + (fold ? p.b_fold[1] : 0)) * 2 >= (1LL << 31)) return false;
+    if (p.M % TM != 0 || p.N % TN != 0 || k_eff % (2 * bk_eff) != 0 || k_eff < 2 * bk_eff || p.ldc % 4 != 0) return 0;
+    if (p.c_dtype != DM_F32 || p.epilogue != DM_EPI_NONE || p.bias || p.residual || p.aux || p.rows_per_group != 0) return 0;
+    if (p.ldc >= LIM || p.N >= LIM) return 0;
+    same_acc = same_acc && p.accumulate == ps[0].accumulate;
+    if (((long long)k_eff * p.lda + (fold ? p.a_fold[2] : 0)) * 2 >= (1LL << 31) || ((long long)k_eff * p.ldb + (fold ? p.b_fold[1] : 0)) * 2 >= (1LL << 31)) return 0;
     p.tiles_m = p.M / TM;
     p.tiles_n = p.N / TN;
     p.split_k = 1;
     p.k_per_split = k_eff;       // (FOLD: in contraction positions of ONE piece)
     grp.first[i] = (int)tiles;
+    sk.tile0[i] = (int)tiles;
+    sk.steps[i] = k_eff / bk_eff;
     tiles += (long long)p.tiles_m * p.tiles_n;
+    work += (long long)p.tiles_m * p.tiles_n * sk.steps[i];
     k_max = k_eff > k_max ? k_eff : k_max;
-    any_cs = any_cs || p.colsum_slab != nullptr;
-    grp.p[i] = p;
+    any_cs = any_cs || p.colsum_slab != nullptr || x.cs_out[i] != nullptr;
   }
-  for (int i = n; i <= GROUP_MAX; ++i) grp.first[i] = (int)tiles;
+  if (tiles >= (1 << 20) || work >= (1LL << 30)) return 0;
+  for (int i = n; i <= GROUP_MAX; ++i) { grp.first[i] = (int)tiles; sk.tile0[i] = (int)tiles; }
   grp.n = n;
-  if (tiles > cus) return false;
-  // (the contraction bound: in the step, grouping the 16384-token blocks' gradients is neutral for the headline and costs config 5 0.1-0.7 %
-  // (15360 tokens) -- there every product fills the chip with its own slices; 12288 is the last length the microbenchmark shows a clear gain for)
-  if (mode == 1 && ((double)tiles / cus < 0.4 || k_max > 12288)) return false;
   auto lds_ok = [](const void *f) { return hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) == hipSuccess; };
+  // ---- form 1: one K slice per tile.  (The contraction bound: in the step, grouping the 16384-token blocks' gradients is neutral for the
+  // headline and costs config 5 0.1-0.7 % (15360 tokens) -- there every product fills the chip with its own slices; 12288 is the last
+  // length the microbenchmark shows a clear gain for: 250 -> 206 us per block.)
+  const bool one_ok = n >= 2 && same_acc && tiles <= cus;
+  const bool sk_wanted = mode == 3;      // stream-K: measured SLOWER than the separate sliced launches at every length -- see gemm_w4_streamk_kernel
+  if (one_ok && mode != 3 && (mode == 2 || ((double)tiles / cus >= 0.4 && k_max <= 12288))) {
 #define DM_GRP_ATTR(EKV, FOLDV) (lds_ok(reinterpret_cast<const void *>(gemm_w4_grouped_kernel<EKV, FOLDV, true>)) && lds_ok(reinterpret_cast<const void *>(gemm_w4_grouped_kernel<EKV, FOLDV, false>)))
-  static const bool attr = DM_GRP_ATTR(9, false) && DM_GRP_ATTR(11, false) && DM_GRP_ATTR(9, true) && DM_GRP_ATTR(11, true);
+    static const bool attr = DM_GRP_ATTR(9, false) && DM_GRP_ATTR(11, false) && DM_GRP_ATTR(9, true) && DM_GRP_ATTR(11, true);
 #undef DM_GRP_ATTR
-  if (!attr) return false;
-  if (!launch) return true;          // (plan only: the caller opens its profiler scope around the real launch)
-  const dim3 grid((unsigned)tiles), block(256);
-  // lean epilogue keys as in dm_gemm_w4_launch: 8 = fp32 C written (EK 9), 10 = fp32 C accumulated in place (EK 11)
+    if (!attr) return 0;
+    if (!launch) return 1;          // (plan only: the caller opens its profiler scope around the real launch)
+    for (int i = 0; i < n; ++i) grp.p[i] = ps[i];
+    const dim3 grid((unsigned)tiles), block(256);
+    // lean epilogue keys as in dm_gemm_w4_launch: 8 = fp32 C written (EK 9), 10 = fp32 C accumulated in place (EK 11)
 #define DM_GRP_GO(EKV, FOLDV) do { if (any_cs) hipLaunchKernelGGL((gemm_w4_grouped_kernel<EKV, FOLDV, true>), grid, block, LDS_BYTES, s, grp); \
     else hipLaunchKernelGGL((gemm_w4_grouped_kernel<EKV, FOLDV, false>), grid, block, LDS_BYTES, s, grp); } while (0)
-  if (ps[0].accumulate) { if (fold) DM_GRP_GO(11, true); else DM_GRP_GO(11, false); }
-  else { if (fold) DM_GRP_GO(9, true); else DM_GRP_GO(9, false); }
+    if (ps[0].accumulate) { if (fold) DM_GRP_GO(11, true); else DM_GRP_GO(11, false); }
+    else { if (fold) DM_GRP_GO(9, true); else DM_GRP_GO(9, false); }
 #undef DM_GRP_GO
-  return true;
+    return 1;
+  }
+  // ---- form 2: stream-K.  Workgroups are dealt to the products in proportion to their K steps; a product's workgroups take q (even) steps each.
+  if (!sk_wanted || x.ws == nullptr) return 0;
+  int G[GROUP_MAX], given = 0;
+  for (int i = 0; i < n; ++i) {
+    const long long w_i = (long long)ps[i].tiles_m * ps[i].tiles_n * sk.steps[i];
+    G[i] = (int)(w_i * cus / work);
+    if (G[i] < 1) G[i] = 1;
+    given += G[i];
+  }
+  for (int guard = 0; given < cus && guard < 4 * cus; ++guard) {      // the remainder: to the product whose workgroups carry the most steps
+    int best = 0;
+    double worst = -1;
+    for (int i = 0; i < n; ++i) {
+      const double per = (double)ps[i].tiles_m * ps[i].tiles_n * sk.steps[i] / G[i];
+      if (per > worst) { worst = per; best = i; }
+    }
+    ++G[best]; ++given;
+  }
+  if (given > cus) return 0;
+  int grid = 0, slots = 2;
+  for (int i = 0; i < n; ++i) {
+    const long long w_i = (long long)ps[i].tiles_m * ps[i].tiles_n * sk.steps[i];
+    int q = (int)((w_i + G[i] - 1) / G[i]);
+    q += q & 1;
+    if (q < 16 || q > 2 * sk.steps[i]) return 0;       // pieces too short to pay for their epilogues / more than three pieces per workgroup
+    if (q > sk.steps[i]) slots = 3;
+    sk.q[i] = q;
+    grp.first[i] = grid;
+    grid += (int)((w_i + q - 1) / q);
+  }
+  for (int i = n; i <= GROUP_MAX; ++i) grp.first[i] = grid;
+  sk.slots = slots;
+  sk.chunks = 4;
+  const long long slab_floats = (long long)grid * slots * TM * TN, cs_floats = (long long)grid * slots * TM;
+  if ((slab_floats + cs_floats) * 4 > x.ws_bytes) return 0;
+#define DM_SK_ATTR(FOLDV) (lds_ok(reinterpret_cast<const void *>(gemm_w4_streamk_kernel<9, FOLDV, true>)) && lds_ok(reinterpret_cast<const void *>(gemm_w4_streamk_kernel<9, FOLDV, false>)))
+  static const bool attr_sk = DM_SK_ATTR(false) && DM_SK_ATTR(true);
+#undef DM_SK_ATTR
+  if (!attr_sk) return 0;
+  if (!launch) return 2;
+  float *slab = reinterpret_cast<float *>(x.ws), *cs_slab = slab + slab_floats;
+  for (int i = 0; i < n; ++i) {
+    grp.p[i] = ps[i];
+    grp.p[i].workspace = slab;
+    grp.p[i].colsum_slab = x.cs_out[i] ? cs_slab : nullptr;
+    sk.cs_out[i] = x.cs_out[i];
+    sk.cs_acc[i] = x.cs_acc[i];
+  }
+  const dim3 block(256);
+  if (any_cs) { if (fold) hipLaunchKernelGGL((gemm_w4_streamk_kernel<9, true, true>), dim3(grid), block, LDS_BYTES, s, sk); else hipLaunchKernelGGL((gemm_w4_streamk_kernel<9, false, true>), dim3(grid), block, LDS_BYTES, s, sk); }
+  else { if (fold) hipLaunchKernelGGL((gemm_w4_streamk_kernel<9, true, false>), dim3(grid), block, LDS_BYTES, s, sk); else hipLaunchKernelGGL((gemm_w4_streamk_kernel<9, false, false>), dim3(grid), block, LDS_BYTES, s, sk); }
+  hipLaunchKernelGGL(streamk_fixup_kernel, dim3((unsigned)(tiles * sk.chunks)), block, 0, s, sk);
+  return 2;
 }

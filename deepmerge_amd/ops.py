@@ -377,7 +377,9 @@ def gemm_grouped(calls) -> None:
                             kw.get("epilogue", DM_EPI_NONE), kw.get("aux"), kw.get("ldaux"), kw.get("accumulate", False), kw.get("split_k", 0),
                             kw.get("rows_per_group", 0), kw.get("group_stride", 0), kw.get("colsum_out"), kw.get("colsum_accumulate", False),
                             f"{kw.get('ws_slot', 'gemm')}.g{i}", None, fold)
-    check(_lib.lib().dm_gemm_grouped(arr, len(calls), _stream()), "dm_gemm_grouped")
+    ws_bytes = _lib.lib().dm_gemm_grouped_workspace_bytes(arr, len(calls))
+    ws = workspace(ws_bytes, calls[0][0][1].t.device if isinstance(calls[0][0][1], Planes) else calls[0][0][1].device, "gemm_grouped") if ws_bytes > 0 else None
+    check(_lib.lib().dm_gemm_grouped(arr, len(calls), None if ws is None else ws.data_ptr(), 0 if ws is None else ws.numel(), _stream()), "dm_gemm_grouped")
 
 
 def cast(src: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:

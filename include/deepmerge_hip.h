@@ -123,14 +123,21 @@ int dm_gemm(const DmGemmArgs *args, void *stream);
 /* Bytes of workspace dm_gemm may use for these dimensions (upper bound over split_k choices). */
 int64_t dm_gemm_workspace_bytes(int32_t layout, int32_t M, int32_t N, int32_t K);
 /* ABI 6: n INDEPENDENT products (no output overlaps another product's operands or output), results as n dm_gemm calls in order --
- * weight gradients up to the order of the fp32 additions over K (a grouped launch takes each product in one K slice, separate calls
- * may slice).  The four weight gradients of a transformer block (dW = dy^T x for qkv / proj / fc1 / fc2: nets/ShfitScaleFormer.py:35,
- * :119, :134 under autograd) do not feed anything else in the block's backward pass; at the 4096- and 1024-token stages each of them has
- * 12 .. 48 output tiles, too few for the chip, and alone pays K slices + a slab + a reduction launch.  Fast path: 2 .. 8 plain bf16 DM_TN
- * products (fp32 C, no epilogue operands, split_k == 0, M % 256 == N % 192 == K % 128 == 0) whose 256 x 192 tiles together fit one round
- * of the CUs and whose contraction is <= 12288 (plain bf16 operands, or hi / lo plane pairs through k_fold): ONE launch, colsum_a produced by the same launch.  Every other group: the calls one
- * after the other (same errors as dm_gemm).  Each args[i] carries its own workspace, as for dm_gemm. */
-int dm_gemm_grouped(const DmGemmArgs *args, int32_t n, void *stream);
+ * weight gradients up to the order of the fp32 additions over K.  The four weight gradients of a transformer block (dW = dy^T x for
+ * qkv / proj / fc1 / fc2: nets/ShfitScaleFormer.py:35, :119, :134 and vit_model.py:112-135, :160-176 under autograd) feed nothing else
+ * in the block's backward pass.  Alone each has 12 .. 48 output tiles of 256 x 192: it either leaves most CUs idle or pays up to 16 K
+ * slices, a slab round trip of as many partial gradients and a reduction launch.  Fast path: 1 .. 8 bf16 DM_TN products (plain operands
+ * or hi / lo plane pairs through k_fold; fp32 C, no epilogue operands, split_k == 0, M % 256 == N % 192 == 0, K % 128 == 0) in ONE launch:
+ *   contraction <= 12288, 2+ products, all tiles within one round of the CUs: one K slice per tile, the gradient stored / accumulated
+ *   in place (the form the training step uses: -3.0 % on the headline step);
+ *   DM_GEMM_GROUPED=3, with `workspace` (dm_gemm_grouped_workspace_bytes): "stream-K" -- every workgroup takes the same number of
+ *   consecutive K steps of its product's tile-major step space, a tile is left as 2-3 partial pieces and ONE fix-up launch sums them in
+ *   workgroup order (deterministic).  Exact, tested, and slower than the separate launches (no operand panel is shared between
+ *   workgroups that sit at different K offsets: csrc/dm_gemm_w4.hip); never chosen by the default rule.
+ * colsum_a is produced by the same launches.  Every other group: the calls one after the other (same errors as dm_gemm).  Each args[i]
+ * carries its own workspace, as for dm_gemm; `workspace` (16-byte aligned, may be NULL) belongs to the group. */
+int64_t dm_gemm_grouped_workspace_bytes(const DmGemmArgs *args, int32_t n);
+int dm_gemm_grouped(const DmGemmArgs *args, int32_t n, void *workspace, int64_t workspace_bytes, void *stream);
 
 /* ---- fused attention with 3-D relative-position bias -------------------------------------
  * Replaces nets/ShfitScaleFormer.py:119-133 (reshape/permute, q*scale, q@k^T, bias add, softmax,

@@ -940,12 +940,15 @@ def test_gemm_wgrad_with_fused_column_sums(M, N, K):
         ops.gemm(DM_TN, dy, x, dw, M, N, K, lda=M, ldb=N, ldc=N, colsum_out=torch.empty(M - 1, device=DEV))
 
 
-@pytest.mark.parametrize("T,acc", [(1024, False), (4096, False), (4096, True), (1152, True)])
-def test_gemm_grouped_block_weight_gradients(T, acc):
+@pytest.mark.parametrize("T,acc", [(1024, False), (4096, False), (4096, True), (1152, True), (8192, False), (16384, True), (9216, False), (50432, False)])
+def test_gemm_grouped_block_weight_gradients(T, acc, monkeypatch, sk=False):
+    if sk:
+        monkeypatch.setenv("DM_GEMM_GROUPED", "3")
     """dm_gemm_grouped: the four weight gradients of a block (dW = dy^T x for qkv / proj / fc1 / fc2, nets/ShfitScaleFormer.py:35, :119,
-    :134 under autograd) in ONE launch of the 4-wave kernel -- 144 tiles, one K slice each, the bias gradients from the same launch.
-    Exact on integer data (so the order of the fp32 additions does not matter): equal to the separate dm_gemm calls bit for bit, with
-    `accumulate` / `colsum_accumulate` honoured."""
+    :134 under autograd) in ONE launch of the 4-wave kernel -- 144 tiles, one K slice each, up to 12288 tokens; the separate calls
+    beyond (16384 = the headline's stage 0, 50432 = ViT-B/16 at 128 pairs) -- the bias gradients from the same launch.  Exact on integer
+    data (so the order of the fp32 additions does not matter): equal to the separate dm_gemm calls bit for bit, with `accumulate` /
+    `colsum_accumulate` honoured.  (test_gemm_grouped_stream_k_*: the same groups through the stream-K form.)"""
     ops = _ops()
     from deepmerge_amd._lib import DM_TN
     g = torch.Generator(device=DEV); g.manual_seed(T + int(acc))
@@ -965,10 +968,12 @@ def test_gemm_grouped_block_weight_gradients(T, acc):
         assert torch.equal(db, w_db), f"product {k}: bias gradient"
 
 
-@pytest.mark.parametrize("T,acc", [(1024, False), (4096, True)])
-def test_gemm_grouped_plane_pair_weight_gradients(T, acc):
+@pytest.mark.parametrize("T,acc,sk", [(1024, False, False), (4096, True, False), (8192, False, True)])
+def test_gemm_grouped_plane_pair_weight_gradients(T, acc, sk, monkeypatch):
     """The grouped launch on hi / lo plane pairs (the "bf16x3" products of the tolerance mode): dW = hi^T hi + hi^T lo + lo^T hi and
-    db = colsum(hi) + colsum(lo), exact on data whose pieces, products and partial sums are exactly representable."""
+    db = colsum(hi) + colsum(lo), exact on data whose pieces, products and partial sums are exactly representable.  sk: the stream-K form."""
+    if sk:
+        monkeypatch.setenv("DM_GEMM_GROUPED", "3")
     ops = _ops()
     from deepmerge_amd._lib import DM_TN
     g = torch.Generator(device=DEV); g.manual_seed(3 * T + int(acc))
@@ -993,6 +998,35 @@ def test_gemm_grouped_plane_pair_weight_gradients(T, acc):
         assert torch.equal(db, w_db), f"product {k}: bias gradient"
 
 
+@pytest.mark.parametrize("T,acc", [(4096, False), (8192, False), (16384, True), (50432, False)])
+def test_gemm_grouped_stream_k_block_weight_gradients(T, acc, monkeypatch):
+    """The block's four weight gradients through the stream-K form (DM_GEMM_GROUPED=3: equal runs of K steps per workgroup across tile
+    boundaries, partial pieces summed in workgroup order by one fix-up launch): exact."""
+    test_gemm_grouped_block_weight_gradients(T, acc, monkeypatch, sk=True)
+
+
+@pytest.mark.parametrize("shapes,T", [([(768, 768)], 16384), ([(768, 768), (2304, 768)], 9216), ([(256, 192), (3072, 768), (768, 3072)], 12288),
+                                      ([(3072, 3072), (768, 768)], 8192)])
+def test_gemm_grouped_stream_k_uneven_groups(shapes, T, monkeypatch):
+    """The stream-K form on groups whose products differ in tile count (1 .. 192 tiles: the workgroups are dealt in proportion to the K
+    steps), a single product, and a product with more tiles than its share of workgroups (pieces longer than a tile: three slots)."""
+    ops = _ops()
+    from deepmerge_amd._lib import DM_TN
+    monkeypatch.setenv("DM_GEMM_GROUPED", "3")
+    g = torch.Generator(device=DEV); g.manual_seed(T + len(shapes))
+    calls, want = [], []
+    for (m, n) in shapes:
+        dy = torch.randint(-1, 2, (T, m), device=DEV, generator=g).to(torch.bfloat16)
+        x = torch.randint(-1, 2, (T, n), device=DEV, generator=g).to(torch.bfloat16)
+        dw, db = torch.empty((m, n), device=DEV), torch.empty((m,), device=DEV)
+        calls.append(((DM_TN, dy, x, dw, m, n, T), dict(lda=m, ldb=n, ldc=n, colsum_out=db)))
+        want.append((dy.float().T @ x.float(), dy.float().sum(0), dw, db))
+    ops.gemm_grouped(calls)
+    for k, (w_dw, w_db, dw, db) in enumerate(want):
+        assert torch.equal(dw, w_dw), f"product {k}: weight gradient"
+        assert torch.equal(db, w_db), f"product {k}: bias gradient"
+
+
 def test_gemm_grouped_falls_back_to_separate_calls():
     """Groups the one-launch form does not describe -- a ragged member, a single product, a forward product, mixed `accumulate`, fp32
     operands -- run as the separate calls would; errors of a member surface as dm_gemm's."""
@@ -1010,7 +1044,7 @@ def test_gemm_grouped_falls_back_to_separate_calls():
               [tn(768, 768, 1024)],                                          # one product
               [tn(768, 768, 1024, acc=True), tn(768, 3072, 1024)],           # mixed accumulate
               [tn(768, 768, 1024, dt=torch.float32), tn(256, 192, 256, dt=torch.float32)],      # fp32 operands
-              [tn(768, 3072, 16384), tn(3072, 768, 16384)]]                  # long contraction: separate slices win, the rule keeps them apart
+              [tn(768, 3072, 16384, acc=True), tn(3072, 768, 16384)]]       # long contraction: the rule keeps the sliced launches
     for grp in groups:
         ops.gemm_grouped([c for c, _, _ in grp])
         for _, want, dw in grp:

@@ -17,7 +17,8 @@ EOS
 fi
 if ! grep -q dm_gemm_grouped "$TMP/include/deepmerge_hip.h"; then      # (ABI 6: the separate calls, which is what the entry point means)
 cat >> "$TMP/deepmerge_amd/csrc/dm_api.cpp" <<'EOS'
-extern "C" int dm_gemm_grouped(const DmGemmArgs *args, int32_t n, void *stream) {
+extern "C" int64_t dm_gemm_grouped_workspace_bytes(const DmGemmArgs *, int32_t) { return 0; }
+extern "C" int dm_gemm_grouped(const DmGemmArgs *args, int32_t n, void *, int64_t, void *stream) {
   for (int i = 0; i < n; ++i) { const int rc = dm_gemm(&args[i], stream); if (rc != 0) return rc; }
   return 0;
 }

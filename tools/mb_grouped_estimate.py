@@ -46,10 +46,12 @@ for T in [int(a) for a in sys.argv[1:]] or [1024, 4096, 16384]:
     for k in ("DM_GEMM_W4_TN",):
         os.environ.pop(k, None)
     t_sep = timeit(separate)
+    calls = [((DM_TN, a, b, c, m, n, T), dict(lda=m, ldb=n, ldc=n, colsum_out=cs)) for a, b, c, cs, m, n in ops_]
+    t_grp = timeit(lambda: ops.gemm_grouped(calls))
     A, B, Cc, cs = rnd((T, 2304)), rnd((T, 3072)), torch.empty((2304, 3072), device=DEV), torch.empty((2304,), device=DEV)
     os.environ["DM_GEMM_W4_TN"] = "2"
     t_one = timeit(lambda: ops.gemm(DM_TN, A, B, Cc, 2304, 3072, T, lda=2304, ldb=3072, ldc=3072, colsum_out=cs))
     os.environ.pop("DM_GEMM_W4_TN")
     t_one_routed = timeit(lambda: ops.gemm(DM_TN, A, B, Cc, 2304, 3072, T, lda=2304, ldb=3072, ldc=3072, colsum_out=cs))
-    print(f"T = {T:6d}: four weight gradients as routed {t_sep:7.1f} us | one launch, 144 tiles, no K slices (4-wave kernel) {t_one:7.1f} us"
+    print(f"T = {T:6d}: four weight gradients as routed {t_sep:7.1f} us | dm_gemm_grouped {t_grp:7.1f} us | one launch, 144 tiles, no K slices (4-wave kernel) {t_one:7.1f} us"
           f" | the same product as routed {t_one_routed:7.1f} us", flush=True)
