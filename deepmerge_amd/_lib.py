@@ -108,6 +108,7 @@ SIGNATURES = {
     "dm_adam_step": (_I, [_P, _P, _P, _P, _P, _L, _I, _D, _D, _D, _D, _D, _P]),
     "dm_adam_hyper": (_I, [_I, _D, _D, _D, _P]),
     "dm_adam_step_dev": (_I, [_P, _P, _P, _P, _P, _L, _P, _D, _D, _D, _D, _P]),
+    "dm_adam_step_dev_pair": (_I, [_P, _P, _P, _P, _P, _P, _L, _P, _D, _D, _D, _D, _P]),
     "dm_segment_mean": (_I, [_P, _P, _P, _P, _I, _I, _P]),
     "dm_edge_similarity": (_I, [_P, _P, _P, _P, _I, _I, _F, _P]),
     "dm_patch_pyramid": (_I, [_P, _I, _I, _I, _P, _P, _I, _I, _I, _I, _P, _P]),

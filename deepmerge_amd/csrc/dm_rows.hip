@@ -328,8 +328,10 @@ __global__ void group_mean_bwd_kernel(const float *__restrict__ dy, float *__res
 // column sums (bias gradients): slices of rows -> partial[slice][N]
 // ---------------------------------------------------------------------------------------------
 template <typename T>
+// direct >= 0 (one slice only): the sums go straight to `partial` = the destination, added to what is there when direct == 1 -- the
+// reduction launch of a one-slice column sum (the 64-row bias gradients of the head and the FeatureEmbed layers) does nothing else
 __global__ __launch_bounds__(256) void colsum_kernel(const T *__restrict__ X, long long ldx, float *__restrict__ partial,
-                                                     int M, int N, int rows_per_slice) {
+                                                     int M, int N, int rows_per_slice, int direct) {
   __shared__ f32x4 red[16][16];
   const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
   const int n = blockIdx.x * 64 + tx * 4;
@@ -343,6 +345,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T *__restrict__ X, lo
     f32x4 a = red[0][tx];
 #pragma unroll
     for (int k = 1; k < 16; ++k) a += red[k][tx];
+    if (direct == 1) a = dm_load4(partial + n) + a;
     dm_store4(partial + (long long)blockIdx.y * N + n, a);
   }
 }
@@ -550,7 +553,7 @@ __global__ __launch_bounds__(256) void cross_entropy_kernel(const float *__restr
 __global__ void adam_kernel(float *__restrict__ param, const float *__restrict__ grad, float *__restrict__ m,
                             float *__restrict__ v, bf16_t *__restrict__ lp, long long n, float beta1, float beta2,
                             float omb1, float omb2, float eps, float step_size, float bc2_sqrt, float grad_scale,
-                            const float *__restrict__ hyper) {
+                            const float *__restrict__ hyper, bf16_t *__restrict__ lo = nullptr) {
   if (hyper) {   // captured in a hipGraph: the step-dependent scalars live in device memory, rewritten before each replay
     step_size = hyper[0];
     bc2_sqrt = hyper[1];
@@ -573,6 +576,12 @@ __global__ void adam_kernel(float *__restrict__ param, const float *__restrict__
     __builtin_nontemporal_store(mm, reinterpret_cast<f32x4 *>(m + 4 * i));
     __builtin_nontemporal_store(vv, reinterpret_cast<f32x4 *>(v + 4 * i));
     if (lp) dm_store4(lp + 4 * i, p);
+    if (lo) {      // the lo plane of the weight's hi / lo pair ("bf16x3" operands): bf16(p - bf16(p)), the split of dm_split_bf16_planes
+      bf16x4 l;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) l[e] = (bf16_t)(p[e] - (float)(bf16_t)p[e]);
+      *reinterpret_cast<bf16x4 *>(lo + 4 * i) = l;
+    }
   }
   if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
     const long long i = (n4 << 2) + threadIdx.x;
@@ -582,6 +591,7 @@ __global__ void adam_kernel(float *__restrict__ param, const float *__restrict__
     const float p = param[i] - step_size * (mm / (sqrtf(vv) / bc2_sqrt + eps));
     param[i] = p; m[i] = mm; v[i] = vv;
     if (lp) lp[i] = (bf16_t)p;
+    if (lo) lo[i] = (bf16_t)(p - (float)(bf16_t)p);
   }
 }
 
@@ -799,14 +809,19 @@ extern "C" int dm_colsum(const void *X, int32_t dtype, int64_t ldx, float *out, 
   const int rps = (M + slices - 1) / slices;
   slices = (M + rps - 1) / rps;
   dim3 grid((N + 63) / 64, slices), ggrid((N + 255) / 256, slices);
+  // one slice, vector form: out[n] = (accumulate ? out[n] : 0) + sum -- what the reduction launch would compute from the single partial row
+  const bool direct = slices == 1 && vec && dm_aligned16(out);
+  float *dst = direct ? out : partial;
+  const int dflag = direct ? (accumulate ? 1 : 0) : -1;
   if (dtype == DM_F32) {
-    if (vec) hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, s, (const float *)X, (long long)ldx, partial, M, N, rps);
+    if (vec) hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, s, (const float *)X, (long long)ldx, dst, M, N, rps, dflag);
     else hipLaunchKernelGGL(colsum_generic_kernel<float>, ggrid, dim3(256), 0, s, (const float *)X, (long long)ldx, partial, M, N, rps);
   } else if (dtype == DM_BF16) {
-    if (vec) hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t *)X, (long long)ldx, partial, M, N, rps);
+    if (vec) hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t *)X, (long long)ldx, dst, M, N, rps, dflag);
     else hipLaunchKernelGGL(colsum_generic_kernel<bf16_t>, ggrid, dim3(256), 0, s, (const bf16_t *)X, (long long)ldx, partial, M, N, rps);
   } else DM_REQUIRE(false, DM_ERR_BAD_DTYPE, "dm_colsum: bad dtype %d", dtype);
   DM_LAUNCH_CHECK("dm_colsum");
+  if (direct) return DM_OK;
   hipLaunchKernelGGL(partial_reduce_kernel, dim3((N + 15) / 16), dim3(256), 0, s, partial, out, out, slices, N, N, accumulate);
   DM_LAUNCH_CHECK("dm_colsum(reduce)");
   return DM_OK;
@@ -964,6 +979,18 @@ extern "C" int dm_adam_step_dev(float *param, const float *grad, float *m, float
                      (bf16_t *)param_lp, (long long)n, (float)beta1, (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2),
                      (float)eps, 0.f, 1.f, (float)grad_scale, hyper_dev);
   DM_LAUNCH_CHECK("dm_adam_step_dev");
+  return DM_OK;
+}
+
+extern "C" int dm_adam_step_dev_pair(float *param, const float *grad, float *m, float *v, void *param_hi, void *param_lo, int64_t n,
+                                     const float *hyper_dev, double beta1, double beta2, double eps, double grad_scale, void *stream) {
+  DM_REQUIRE(param && grad && m && v && hyper_dev && param_hi && param_lo && n > 0, DM_ERR_BAD_SHAPE, "dm_adam_step_dev_pair: bad arguments");
+  DM_REQUIRE(dm_aligned16(param) && dm_aligned16(grad) && dm_aligned16(m) && dm_aligned16(v) && dm_aligned16(param_hi) && dm_aligned16(param_lo),
+             DM_ERR_BAD_ALIGN, "dm_adam_step_dev_pair: buffers must be 16-byte aligned");
+  hipLaunchKernelGGL(adam_kernel, dim3(adam_grid(n)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), param, grad, m, v,
+                     (bf16_t *)param_hi, (long long)n, (float)beta1, (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2),
+                     (float)eps, 0.f, 1.f, (float)grad_scale, hyper_dev, (bf16_t *)param_lo);
+  DM_LAUNCH_CHECK("dm_adam_step_dev_pair");
   return DM_OK;
 }
 

@@ -257,7 +257,7 @@ def gemm(layout: int, A: torch.Tensor, B: torch.Tensor, C_out: torch.Tensor, M: 
         if (A.rows, A.cols) != (a_rows, a_cols) or (B.rows, B.cols) != (b_rows, b_cols):
             raise ValueError(f"plane pair shapes {(A.rows, A.cols)} / {(B.rows, B.cols)} do not match the product {(a_rows, a_cols)} / {(b_rows, b_cols)}")
         # (column sums of a pre-split left operand: dm_gemm sums the hi and the lo plane -- fused into the weight-gradient kernels)
-        fold = (K, A.rows * A.cols, B.rows * B.cols)
+        fold = (K, A.t.stride(0), B.t.stride(0))      # (plane stride: rows * cols for a split, the flat buffer's length for a weight's mirror pair)
         A, B, lda, ldb, K = A.t, B.t, a_cols, b_cols, 3 * K
     _need_cuda(A, B, C_out, bias, residual, aux, colsum_out)
     if A.dtype != B.dtype:
@@ -366,7 +366,7 @@ def gemm_grouped(calls) -> None:
             b_rows, b_cols = (N, K) if layout == DM_NT else (K, N)
             if (A.rows, A.cols) != (a_rows, a_cols) or (B.rows, B.cols) != (b_rows, b_cols):
                 raise ValueError(f"plane pair shapes {(A.rows, A.cols)} / {(B.rows, B.cols)} do not match the product {(a_rows, a_cols)} / {(b_rows, b_cols)}")
-            fold = (K, A.rows * A.cols, B.rows * B.cols)
+            fold = (K, A.t.stride(0), B.t.stride(0))
             A, B, lda, ldb, K = A.t, B.t, a_cols, b_cols, 3 * K
         _need_cuda(A, B, C_out, kw.get("colsum_out"))
         if A.dtype != B.dtype:
@@ -848,9 +848,14 @@ def adam_hyper(step: int, lr: float, beta1: float = 0.9, beta2: float = 0.999) -
     return h
 
 
-def adam_step_dev(param, grad, m, v, hyper_dev, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0, param_lp=None):
-    """Adam with the step-dependent scalars read from device memory (capturable in a hipGraph)."""
+def adam_step_dev(param, grad, m, v, hyper_dev, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0, param_lp=None, param_lo=None):
+    """Adam with the step-dependent scalars read from device memory (capturable in a hipGraph).  param_lo (with param_lp): the updated
+    weights also as the hi / lo plane pair of the "bf16x3" products (dm_adam_step_dev_pair)."""
     _need_cuda(param, grad, m, v, hyper_dev)
+    if param_lo is not None:
+        check(_lib.lib().dm_adam_step_dev_pair(param.data_ptr(), grad.data_ptr(), m.data_ptr(), v.data_ptr(), param_lp.data_ptr(), param_lo.data_ptr(),
+                                               param.numel(), hyper_dev.data_ptr(), beta1, beta2, eps, grad_scale, _stream()), "dm_adam_step_dev_pair")
+        return
     check(_lib.lib().dm_adam_step_dev(param.data_ptr(), grad.data_ptr(), m.data_ptr(), v.data_ptr(), _ptr(param_lp), param.numel(),
                                       hyper_dev.data_ptr(), beta1, beta2, eps, grad_scale, _stream()), "dm_adam_step_dev")
 
@@ -1383,6 +1388,19 @@ def lp_weight(weight: torch.Tensor, dtype: torch.dtype, shape2d) -> torch.Tensor
     return cast(weight.reshape(shape2d), dtype)
 
 
+def pair_weight(weight: torch.Tensor, w2d: torch.Tensor) -> Planes:
+    """The hi / lo plane pair of a master weight for the folded "bf16x3" products: the mirror pair the trainer's Adam kernel keeps
+    (`weight._dm_pair_src` = (flat [2, total] bf16 buffer, offset): a [2, rows, cols] VIEW whose plane stride is the buffer's length),
+    else a split of the weight."""
+    src = getattr(weight, "_dm_pair_src", None)
+    if src is not None and _PLANES:
+        flat, off = src
+        rows, cols = w2d.shape
+        if rows * cols == weight.numel() and off % 8 == 0 and flat.shape[1] % 8 == 0:
+            return Planes(torch.as_strided(flat, (2, rows, cols), (flat.shape[1], cols, 1), off))
+    return split_planes(w2d)
+
+
 def _operand_grad(dy: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
     """The incoming fp32 gradient as an MFMA operand; reuses the bf16 copy the previous LayerNorm
     backward already wrote, if there is one."""
@@ -1485,8 +1503,8 @@ class BlockFn(torch.autograd.Function):
         # rows keep fp32 activations and per-use splits)
         planes = (dtype == torch.float32 and _FP32_PRODUCTS == "bf16x3" and planes_ok(M, Cc) and planes_ok(M, Hd) and planes_ok(Hd, Cc)
                   and Cc <= _PAIR_LN_MAX_COLS and M * Cc * Cc >= _SPLIT_MIN_WORK)
-        if planes:
-            wq, wp, w1, w2 = (split_planes(w) for w in (wq, wp, w1, w2))
+        if planes:      # (the optimizer's mirror pairs when a trainer keeps them: no per-step split of the weights)
+            wq, wp, w1, w2 = (pair_weight(P, w) for P, w in ((qkv_w, wq), (proj_w, wp), (fc1_w, w1), (fc2_w, w2)))
         y1, mean1, rstd1 = layernorm_fwd(x2d, n1w, n1b, eps, dtype, pair=planes)
         split, scube = _split_attention(table, index32, dtype, B, N, heads, D)
         # (plane pairs + the split-bf16 attention: the qkv product writes the two images the attention kernels read)

@@ -51,7 +51,8 @@ _SINK_VIOLATION = ("first-write gradient sink violated: a parameter of a fused b
 class FlatParams:
     """Re-homes a module's parameters and gradients into flat fp32 buffers (views keep autograd working)."""
 
-    def __init__(self, module: torch.nn.Module, align: int = 64, lp_mirror: bool = True, first_write: Optional[bool] = None):
+    def __init__(self, module: torch.nn.Module, align: int = 64, lp_mirror: bool = True, first_write: Optional[bool] = None,
+                 pair_mirror: bool = False):
         """first_write (default: on unless DM_GRAD_FIRST_WRITE=0): for models whose fused blocks are the only writers of their
         parameters' gradients (`_dm_first_write_blocks` on the model class, `_dm_fused_block` on the block class) those gradients
         are not zeroed at the start of a step; the first write of the step stores instead (ops._acc).  Saves the 195 MB memset and
@@ -69,6 +70,10 @@ class FlatParams:
         self.offsets, self.total = offs, total
         # bf16 mirror of the weights (MFMA operands), rewritten by the fused Adam kernel each step
         self.flat_lp = torch.zeros(total, dtype=torch.bfloat16, device=dev) if lp_mirror and dev.type == "cuda" else None
+        # "bf16x3": the weights as hi / lo plane pairs [2, total] (plane 0 = bf16(w), plane 1 = bf16(w - plane 0)), rewritten by the Adam
+        # kernel; ops.pair_weight hands the blocks [2, rows, cols] views of it (plane stride = total)
+        self.flat_pair = (torch.zeros((2, total), dtype=torch.bfloat16, device=dev)
+                          if pair_mirror and dev.type == "cuda" and total % 8 == 0 and total < (1 << 29) else None)
         for p, o in zip(params, offs):
             n = p.numel()
             self.flat[o:o + n].copy_(p.data.reshape(-1))
@@ -76,6 +81,8 @@ class FlatParams:
             p.grad = self.grad[o:o + n].view_as(p)
             if self.flat_lp is not None:
                 p._dm_lp = self.flat_lp[o:o + n].view_as(p)
+            if self.flat_pair is not None:
+                p._dm_pair_src = (self.flat_pair, o)
             if dev.type == "cuda":
                 # fused backward kernels accumulate straight into the flat gradient buffer (ops._grad_out)
                 p._dm_grad_sink = self.grad[o:o + n].view_as(p)
@@ -115,6 +122,11 @@ class FlatParams:
         """Re-derive the bf16 mirror from the fp32 masters (after load_state_dict or any external update)."""
         if self.flat_lp is not None:
             self.flat_lp.copy_(ops.cast(self.flat, torch.bfloat16))
+        if self.flat_pair is not None:
+            cols = 64
+            while cols < 8192 and self.total % (2 * cols) == 0:
+                cols *= 2
+            self.flat_pair.copy_(ops.split_planes(self.flat.view(self.total // cols, cols)).t.view(2, self.total))
 
     def zero_grad(self):
         if self.tracked:
@@ -223,7 +235,8 @@ class PairTrainer:
         # DM_DP_FORCE=1 (rehearsal): run the data-parallel schedule -- segmented backward, bucket all-reduces through the
         # initialised backend, per-segment graphs -- even with ONE rank, so that a one-GPU box exercises the RCCL calls
         self.force_dp = os.environ.get("DM_DP_FORCE") == "1" and dist.is_available() and dist.is_initialized()
-        self.fp = FlatParams(net, lp_mirror=(getattr(net, "numerics", "bf16") == "bf16"), first_write=first_write)
+        self.fp = FlatParams(net, lp_mirror=(getattr(net, "numerics", "bf16") == "bf16"), first_write=first_write,
+                             pair_mirror=(getattr(net, "numerics", "bf16") == "bf16x3" and os.environ.get("DM_X3_PAIR_MIRROR", "1") != "0"))
         self.m = torch.zeros_like(self.fp.flat)
         self.v = torch.zeros_like(self.fp.flat)
         self.step_count = 0
@@ -547,8 +560,11 @@ class PairTrainer:
 
     def _adam_slice(self, sl: slice, hyper_dev, grad_scale: float):
         lp = self.fp.flat_lp[sl] if self.fp.flat_lp is not None else None
+        lo = None
+        if self.fp.flat_pair is not None:
+            lp, lo = self.fp.flat_pair[0][sl], self.fp.flat_pair[1][sl]
         ops.adam_step_dev(self.fp.flat[sl], self.fp.grad[sl], self.m[sl], self.v[sl], hyper_dev, beta1=self.betas[0], beta2=self.betas[1],
-                          eps=self.eps, grad_scale=grad_scale, param_lp=lp)
+                          eps=self.eps, grad_scale=grad_scale, param_lp=lp, param_lo=lo)
 
     # -- the step ----------------------------------------------------------------------------------
     def step(self, left: Sequence[torch.Tensor], left_designed, right: Sequence[torch.Tensor], right_designed, flag,
@@ -587,6 +603,11 @@ class PairTrainer:
         self.step_count += 1
 
         def update(sl):
+            if self.fp.flat_pair is not None and self.adam_fn is ops.adam_step:      # "bf16x3": the update also rewrites the weights' plane pairs
+                hyper = ops.adam_hyper(self.step_count, self.lr if lr is None else lr, self.betas[0], self.betas[1]).to(self.fp.flat.device, non_blocking=True)
+                ops.adam_step_dev(self.fp.flat[sl], self.fp.grad[sl], self.m[sl], self.v[sl], hyper, beta1=self.betas[0], beta2=self.betas[1], eps=self.eps,
+                                  grad_scale=1.0 / self.world, param_lp=self.fp.flat_pair[0][sl], param_lo=self.fp.flat_pair[1][sl])
+                return
             extra = {"param_lp": self.fp.flat_lp[sl]} if self.fp.flat_lp is not None else {}
             self.adam_fn(self.fp.flat[sl], self.fp.grad[sl], self.m[sl], self.v[sl], self.step_count, lr=self.lr if lr is None else lr,
                          beta1=self.betas[0], beta2=self.betas[1], eps=self.eps, grad_scale=1.0 / self.world, **extra)
@@ -595,4 +616,6 @@ class PairTrainer:
         else:
             self.fp.finish_grads()
             update(slice(0, self.fp.total))
+        if self.fp.flat_pair is not None and self.adam_fn is not ops.adam_step:      # a caller-supplied update: re-derive the pairs from the masters
+            self.fp.refresh_lp()
         return loss.detach()

@@ -333,6 +333,11 @@ int dm_adam_step(float *param, const float *grad, float *m, float *v, void *para
 int dm_adam_hyper(int32_t step, double lr, double beta1, double beta2, float *hyper_host);
 int dm_adam_step_dev(float *param, const float *grad, float *m, float *v, void *param_lp, int64_t n, const float *hyper_dev,
                      double beta1, double beta2, double eps, double grad_scale, void *stream);
+/* ABI 6: the same, and the updated weights also as the hi / lo bf16 plane pair of the "bf16x3" products (param_hi[i] = bf16(p),
+ * param_lo[i] = bf16(p - param_hi[i]): dm_split_bf16_planes' split): the next step's folded GEMMs read the pair the optimizer left instead of
+ * splitting every weight matrix again (24 launches per step of the headline model). */
+int dm_adam_step_dev_pair(float *param, const float *grad, float *m, float *v, void *param_hi, void *param_lo, int64_t n,
+                          const float *hyper_dev, double beta1, double beta2, double eps, double grad_scale, void *stream);
 
 /* ---- ExtractFeatures sweep ---------------------------------------------------------------- */
 /* Per-superpixel mean pooling (ExtractFeatures.py:190-212): F [P,D] fp32, CSR ptr[S+1] / idx[*]

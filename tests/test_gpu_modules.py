@@ -392,6 +392,39 @@ def test_graph_replayed_step_equals_eager_step_bf16x3():
 
 
 @pytest.mark.parametrize("graph", [False, True])
+def test_bf16x3_weight_pairs_from_the_optimizer(graph, monkeypatch):
+    """"bf16x3": the Adam kernel leaves every weight as its hi / lo plane pair (dm_adam_step_dev_pair) and the blocks' folded products read
+    [2, rows, cols] views of that mirror instead of splitting the weights every step.  The pair is exactly dm_split_bf16_planes' split, so
+    the steps are bit-identical to the per-step splits (DM_X3_PAIR_MIRROR=0), eager and replayed, and the mirror always equals the split
+    of the masters."""
+    from deepmerge_amd import ops
+    from deepmerge_amd.trainer import PairTrainer
+    tag = "v3_3s3c_111"
+    cfg = MODEL_CASES[tag]
+    left, ld, right, rd, flag = model_inputs(tag, cfg.scales, cfg.in_c, 4)
+    b = ([t.to(DEV) for t in left], ld.to(DEV), [t.to(DEV) for t in right], rd.to(DEV), flag.to(DEV))
+    nets = [build_model(tag, "bf16x3")[1].train() for _ in range(2)]
+    mirrored = PairTrainer(nets[0], lr=1e-4)
+    monkeypatch.setenv("DM_X3_PAIR_MIRROR", "0")
+    plain = PairTrainer(nets[1], lr=1e-4)
+    monkeypatch.delenv("DM_X3_PAIR_MIRROR")
+    assert mirrored.fp.flat_pair is not None and plain.fp.flat_pair is None
+    if graph:
+        mirrored.enable_graph(warmup=1); plain.enable_graph(warmup=1)
+    for i in range(4):
+        assert float(mirrored.step(*b)) == float(plain.step(*b)), f"step {i}"
+    assert torch.equal(mirrored.fp.flat, plain.fp.flat) and torch.equal(mirrored.m, plain.m) and torch.equal(mirrored.v, plain.v)
+    total = mirrored.fp.total
+    want = ops.split_planes(mirrored.fp.flat.view(total // 64, 64)).t.view(2, total)
+    assert torch.equal(mirrored.fp.flat_pair, want)
+    w = nets[0].blocks0[0].attn.qkv.weight if hasattr(nets[0], "blocks0") else None
+    if w is not None:
+        pair = ops.pair_weight(w, w.reshape(w.shape[0], -1))
+        assert pair.t.stride(0) == total and torch.equal(pair.t[0], want[0][w._dm_pair_src[1]:w._dm_pair_src[1] + w.numel()].view_as(pair.t[0]))
+    assert ops.get_fp32_products() == "mfma_f32"
+
+
+@pytest.mark.parametrize("graph", [False, True])
 def test_first_write_gradient_sinks(graph):
     """FlatParams(first_write=True): the fused blocks' gradients are not zeroed per step, their first write stores.  Three steps must
     leave exactly the weights / Adam state of the zero-then-accumulate protocol; a tracked parameter that gets no gradient in a step is

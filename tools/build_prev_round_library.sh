@@ -24,6 +24,11 @@ extern "C" int dm_gemm_grouped(const DmGemmArgs *args, int32_t n, void *, int64_
 }
 EOS
 fi
+if ! grep -q dm_adam_step_dev_pair "$TMP/include/deepmerge_hip.h"; then      # (bf16x3 runs against such a library: DM_X3_PAIR_MIRROR=0)
+cat >> "$TMP/deepmerge_amd/csrc/dm_api.cpp" <<'EOS'
+extern "C" int dm_adam_step_dev_pair(float *, const float *, float *, float *, void *, void *, int64_t, const float *, double, double, double, double, void *) { return -6; }
+EOS
+fi
 make -C "$TMP/deepmerge_amd/csrc" -j6 > "$TMP/build.log" 2>&1 || { tail -20 "$TMP/build.log"; exit 1; }
 mkdir -p "$ROOT/tools/hip/variants"
 cp "$TMP/deepmerge_amd/libdeepmerge_hip.so" "$ROOT/tools/hip/variants/libdm_$TAG.so"
