@@ -1095,6 +1095,19 @@ extern "C" int dm_gemm_grouped(const DmGemmArgs *args, int32_t n, void *workspac
     }
     x.cs_out[i] = a.colsum_a;
     x.cs_acc[i] = a.colsum_accumulate ? 1 : 0;
+    {      // the product's own workspace, cut as dm_gemm cuts it: split-K slab, then the column-sum rows (the sliced form of the group)
+      int64_t sb = a.workspace ? a.workspace_bytes : 0;
+      x.cs_region[i] = nullptr;
+      if (a.colsum_a && a.workspace) {
+        const int64_t need = colsum_region_floats(a.M) * 4;
+        if (a.workspace_bytes >= need) {
+          sb = (a.workspace_bytes - need) & ~15LL;
+          x.cs_region[i] = reinterpret_cast<float *>(reinterpret_cast<char *>(a.workspace) + sb);
+        } else sb = 0;
+      }
+      x.slab[i] = sb > 0 ? reinterpret_cast<float *>(a.workspace) : nullptr;
+      x.slab_bytes[i] = sb;
+    }
     if (a.colsum_a) {
       if (!a.colsum_accumulate) {
         p.colsum_slab = a.colsum_a;                      // form 1, first write of the step: the launch stores the sums where they belong
@@ -1119,7 +1132,7 @@ extern "C" int dm_gemm_grouped(const DmGemmArgs *args, int32_t n, void *workspac
     char shaped[64];
     const char *pname = "gemm_bf16_TN";
     if (by_shape) {
-      snprintf(shaped, sizeof(shaped), "gemm_bf16_TN_grouped%d_K%d_%s", n, args[0].K, form == 2 ? "streamk" : "1slice");
+      snprintf(shaped, sizeof(shaped), "gemm_bf16_TN_grouped%d_K%d_%s", n, args[0].K, form == 2 ? "streamk" : form == 3 ? "sliced" : "1slice");
       pname = shaped;
     }
     {
@@ -1130,6 +1143,18 @@ extern "C" int dm_gemm_grouped(const DmGemmArgs *args, int32_t n, void *workspac
       for (int i = 0; i < n; ++i)
         if (cs_rows[i])
           hipLaunchKernelGGL(colsum_rows_reduce_kernel, dim3((args[i].M + 63) / 64), dim3(64), 0, s, cs_rows[i], args[i].colsum_a, args[i].M, 1, 1);
+    if (form == 3)      // every product's slices summed in slice order, its column-sum rows folded in the same launch (as dm_gemm does)
+      for (int i = 0; i < n; ++i) {
+        const DmGemmArgs &a = args[i];
+        const int split = ps[i].split_k;
+        const long long want = ((long long)a.M * a.N / 4 + 255) / 256;
+        const int rgrid = (int)(want < 2048 ? want : 2048);
+        const bool fold_cs = a.colsum_a != nullptr;
+        const int cs_blocks = fold_cs ? (a.M + 255) / 256 : 0;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(rgrid + cs_blocks), dim3(256), 0, s, ps[i].workspace, reinterpret_cast<float *>(a.C), (long long)a.ldc,
+                           a.M, a.N, split, a.accumulate, rgrid, fold_cs ? x.cs_region[i] : nullptr, fold_cs ? a.colsum_a : nullptr, a.M, split,
+                           a.colsum_accumulate);
+      }
     DM_LAUNCH_CHECK("dm_gemm_grouped");
     return DM_OK;
   }

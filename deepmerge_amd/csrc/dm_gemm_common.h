@@ -25,7 +25,10 @@ struct GemmParams {
 };
 
 // dm_gemm_grouped -> dm_gemm_w4_grouped: where the column sums of A go (stream-K form) and the group's workspace
-struct DmGroupedExtra { float *cs_out[8]; int cs_acc[8]; void *ws; long long ws_bytes; };
+struct DmGroupedExtra {
+  float *cs_out[8]; int cs_acc[8]; void *ws; long long ws_bytes;
+  float *slab[8]; long long slab_bytes[8]; float *cs_region[8];      // the sliced form: every product's own split-K slab / column-sum rows (its dm_gemm workspace)
+};
 
 // The result strip as a hi / lo plane pair (c_dtype == DM_BF16_PAIR): hi = bf16(v), lo = bf16(v - hi) -- the split of dm_split_bf16.
 __device__ __forceinline__ void dm_store_pair4(const GemmParams &p, long long off, const f32x4 &v) {

@@ -1233,6 +1233,47 @@ int dm_gemm_w4_grouped(GemmParams *ps, int n, hipStream_t s, bool launch, const 
 #undef DM_GRP_GO
     return 1;
   }
+  // ---- form 3: the same K slices for every product of the group, (tile, slice) per workgroup, partial tiles to each product's own slab [S][M][N]
+  // (the caller runs the products' splitk_reduce launches).  For products that are too small to be sliced well ALONE: the 768 x 768 proj
+  // gradient of a 16384-token block has 12 tiles -- 16 slices of 16 K steps, 38 MB of slabs for a 2.4 MB result, 36 us -- but next to the
+  // qkv gradient's 36 tiles the pair takes 5 slices of 52 steps on 240 workgroups, like the fc1 / fc2 gradients do alone.
+  // DM_GEMM_GROUPED=4 forces it for every legal group.
+  {
+    int steps = sk.steps[0];
+    bool same_k = true;
+    for (int i = 1; i < n; ++i) same_k = same_k && sk.steps[i] == steps;
+    int S = (int)(cus / (tiles > 0 ? tiles : 1));
+    if (S > 16) S = 16;
+    int per = S > 0 ? (steps + S - 1) / S : steps;
+    per += per & 1;
+    if (per < 16) per = 16;
+    S = (steps + per - 1) / per;
+    bool fits = same_k && n >= 2 && S >= 2 && mode != 3 && mode != 2;
+    for (int i = 0; fits && i < n; ++i)
+      fits = x.slab[i] != nullptr && (long long)S * ps[i].M * ps[i].N * 4 <= x.slab_bytes[i] && (!x.cs_out[i] || x.cs_region[i] != nullptr);
+    if (fits && (mode == 4 || (k_max > 12288 && (double)(tiles * S) / cus >= 0.85))) {
+#define DM_GRP_ATTR(EKV, FOLDV) (lds_ok(reinterpret_cast<const void *>(gemm_w4_grouped_kernel<EKV, FOLDV, true>)) && lds_ok(reinterpret_cast<const void *>(gemm_w4_grouped_kernel<EKV, FOLDV, false>)))
+      static const bool attr3 = DM_GRP_ATTR(9, false) && DM_GRP_ATTR(9, true);
+#undef DM_GRP_ATTR
+      if (!attr3) return 0;
+      int first = 0;
+      for (int i = 0; i < n; ++i) {
+        ps[i].split_k = S;
+        ps[i].k_per_split = per * (fold ? 32 : BK);
+        ps[i].workspace = x.slab[i];
+        ps[i].colsum_slab = x.cs_out[i] ? x.cs_region[i] : nullptr;
+        grp.first[i] = first;
+        first += ps[i].tiles_m * ps[i].tiles_n * S;
+      }
+      for (int i = n; i <= GROUP_MAX; ++i) grp.first[i] = first;
+      if (!launch) return 3;
+      for (int i = 0; i < n; ++i) grp.p[i] = ps[i];
+      const dim3 grid((unsigned)first), block(256);
+      if (any_cs) { if (fold) hipLaunchKernelGGL((gemm_w4_grouped_kernel<9, true, true>), grid, block, LDS_BYTES, s, grp); else hipLaunchKernelGGL((gemm_w4_grouped_kernel<9, false, true>), grid, block, LDS_BYTES, s, grp); }
+      else { if (fold) hipLaunchKernelGGL((gemm_w4_grouped_kernel<9, true, false>), grid, block, LDS_BYTES, s, grp); else hipLaunchKernelGGL((gemm_w4_grouped_kernel<9, false, false>), grid, block, LDS_BYTES, s, grp); }
+      return 3;
+    }
+  }
   // ---- form 2: stream-K.  Workgroups are dealt to the products in proportion to their K steps; a product's workgroups take q (even) steps each.
   if (!sk_wanted || x.ws == nullptr) return 0;
   int G[GROUP_MAX], given = 0;

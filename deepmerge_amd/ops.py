@@ -302,7 +302,7 @@ def gemm(layout: int, A: torch.Tensor, B: torch.Tensor, C_out: torch.Tensor, M: 
 
 
 def _gemm_args(layout, A, B, C_out, M, N, K, lda, ldb, ldc, bias, residual, ldr, epilogue, aux, ldaux, accumulate, split_k,
-               rows_per_group, group_stride, colsum_out, colsum_accumulate, ws_slot, c_pair=None, fold=None) -> DmGemmArgs:
+               rows_per_group, group_stride, colsum_out, colsum_accumulate, ws_slot, c_pair=None, fold=None, min_slabs: int = 0) -> DmGemmArgs:
     """The DmGemmArgs of one product (operands already in their final form), its workspace taken from slot `ws_slot`."""
     a = DmGemmArgs()
     a.layout, a.ab_dtype, a.c_dtype = layout, _dt(A), _dt(C_out)
@@ -335,6 +335,8 @@ def _gemm_args(layout, A, B, C_out, M, N, K, lda, ldb, ldc, bias, residual, ldr,
     ws_bytes = _lib.lib().dm_gemm_workspace_bytes(layout, M, N, K) if (split_k != 1 or colsum_out is not None) else 0
     if split_k > 1:                       # caller-chosen slice count: its slab may be larger than the automatic one
         ws_bytes = max(ws_bytes, _lib.lib().dm_gemm_workspace_bytes(layout, M, N, K) + split_k * M * N * 4)
+    if min_slabs > 0:                     # a grouped launch may slice the product more finely than dm_gemm alone would
+        ws_bytes = max(ws_bytes, _lib.lib().dm_gemm_workspace_bytes(layout, M, N, K) + min_slabs * M * N * 4)
     if ws_bytes > 0:
         ws = workspace(ws_bytes, A.device, ws_slot)
         a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
@@ -376,7 +378,7 @@ def gemm_grouped(calls) -> None:
         arr[i] = _gemm_args(layout, A, B, C_out, M, N, K, lda, ldb, kw.get("ldc"), kw.get("bias"), kw.get("residual"), kw.get("ldr"),
                             kw.get("epilogue", DM_EPI_NONE), kw.get("aux"), kw.get("ldaux"), kw.get("accumulate", False), kw.get("split_k", 0),
                             kw.get("rows_per_group", 0), kw.get("group_stride", 0), kw.get("colsum_out"), kw.get("colsum_accumulate", False),
-                            f"{kw.get('ws_slot', 'gemm')}.g{i}", None, fold)
+                            f"{kw.get('ws_slot', 'gemm')}.g{i}", None, fold, min_slabs=16 if layout == DM_TN else 0)
     ws_bytes = _lib.lib().dm_gemm_grouped_workspace_bytes(arr, len(calls))
     ws = workspace(ws_bytes, calls[0][0][1].t.device if isinstance(calls[0][0][1], Planes) else calls[0][0][1].device, "gemm_grouped") if ws_bytes > 0 else None
     check(_lib.lib().dm_gemm_grouped(arr, len(calls), None if ws is None else ws.data_ptr(), 0 if ws is None else ws.numel(), _stream()), "dm_gemm_grouped")
@@ -1465,6 +1467,7 @@ _WGRAD_SIDE_TOKENS = int(os.environ.get("DM_WGRAD_STREAM", "0"))
 # 250 -> 206 us at 12288; in the step the 16384-token blocks gain nothing -- every product fills the chip with its own slices).  Headline
 # step 5.28 -> 5.12 ms, "bf16x3" 11.03 -> 10.89 ms (same box, tools/ab_grouped.sh).  bf16 operands or plane pairs ("bf16x3"); 0 = off.
 _WGRAD_GROUP_TOKENS = int(os.environ.get("DM_WGRAD_GROUP", "12288"))
+_WGRAD_PAIR = os.environ.get("DM_WGRAD_PAIR", "1") != "0"      # larger blocks: the proj and qkv gradients in one sliced launch
 _side_streams = {}
 
 
@@ -1585,10 +1588,16 @@ class BlockFn(torch.autograd.Function):
         side = _side_stream(dev) if 0 < M <= _WGRAD_SIDE_TOKENS else None
 
         pending = [] if (side is None and (lp or planes) and 0 < M <= _WGRAD_GROUP_TOKENS) else None
+        # larger blocks: every product fills the chip with its own K slices, except the small proj gradient (12 tiles: 16 short slices) --
+        # it waits for the qkv gradient and the two share one sliced launch (dm_gemm_grouped's third form)
+        late = [] if (pending is None and side is None and (lp or planes) and _WGRAD_PAIR) else None
 
-        def wgrad(*a, **kw):
+        def wgrad(*a, pair=False, **kw):
             if pending is not None:           # issued together at the end of this backward (gemm_grouped)
                 pending.append((a, kw))
+                return None
+            if late is not None and pair:
+                late.append((a, kw))
                 return None
             if side is None:
                 return gemm(*a, **kw)
@@ -1627,7 +1636,7 @@ class BlockFn(torch.autograd.Function):
         dwp, k_wp = _grad_out(P_proj_w, (Cc, Cc), dev)
         dbp, k_bp = _grad_out(P_proj_b, (Cc,), dev)
         dx1_op, cs = bias_grad(dx1_lp, dbp, _acc(P_proj_b, k_bp), k_bp)
-        wgrad(DM_TN, dx1_op, o_op if planes else o.view(M, Cc), dwp, Cc, Cc, M, lda=Cc, ldb=Cc, ldc=Cc, accumulate=_acc(P_proj_w, k_wp), **cs)
+        wgrad(DM_TN, dx1_op, o_op if planes else o.view(M, Cc), dwp, Cc, Cc, M, lda=Cc, ldb=Cc, ldc=Cc, accumulate=_acc(P_proj_w, k_wp), pair=True, **cs)
         do = torch.empty((M, Cc), dtype=dtype, device=dev)
         gemm(DM_NN, dx1_op, wp, do, M, Cc, Cc, lda=Cc, ldb=Cc, ldc=Cc)
         tab, cube = None, None
@@ -1654,7 +1663,7 @@ class BlockFn(torch.autograd.Function):
         dwq, k_wq = _grad_out(P_qkv_w, (3 * Cc, Cc), dev)
         dbq, k_bq = _grad_out(P_qkv_b, (3 * Cc,), dev)
         dqkv_op, cs = bias_grad(dqkv2, dbq, _acc(P_qkv_b, k_bq), k_bq)
-        wgrad(DM_TN, dqkv_op, y1, dwq, 3 * Cc, Cc, M, lda=3 * Cc, ldb=Cc, ldc=Cc, accumulate=_acc(P_qkv_w, k_wq), **cs)
+        wgrad(DM_TN, dqkv_op, y1, dwq, 3 * Cc, Cc, M, lda=3 * Cc, ldb=Cc, ldc=Cc, accumulate=_acc(P_qkv_w, k_wq), pair=True, **cs)
         dy1 = torch.empty((M, Cc), dtype=dtype, device=dev)
         gemm(DM_NN, dqkv_op, wq, dy1, M, Cc, 3 * Cc, lda=3 * Cc, ldb=Cc, ldc=Cc)
         dg1, k_n1 = _grad_out(P_n1w, (Cc,), dev)
@@ -1669,6 +1678,8 @@ class BlockFn(torch.autograd.Function):
             torch.cuda.current_stream().wait_stream(side)          # join: every weight gradient of this block is complete
         if pending:
             gemm_grouped(pending)
+        if late:
+            gemm_grouped(late)
         dx = r[0].view(B, N, Cc)
         if lp:
             # The bf16 copy the LayerNorm backward wrote rides on the tensor object autograd hands to the next node (the

@@ -130,6 +130,9 @@ int64_t dm_gemm_workspace_bytes(int32_t layout, int32_t M, int32_t N, int32_t K)
  * or hi / lo plane pairs through k_fold; fp32 C, no epilogue operands, split_k == 0, M % 256 == N % 192 == 0, K % 128 == 0) in ONE launch:
  *   contraction <= 12288, 2+ products, all tiles within one round of the CUs: one K slice per tile, the gradient stored / accumulated
  *   in place (the form the training step uses: -3.0 % on the headline step);
+ *   contraction > 12288, the same for all products, tiles x slices >= 0.85 of the CUs: the SAME K slices for every product, (product,
+ *   tile, slice) per workgroup, partial tiles to each product's own workspace slab and its own reduction behind (the 12-tile proj gradient
+ *   next to the qkv gradient: 5 slices on 240 workgroups instead of 16 + 7 on two launches; -1.1 % on the headline step);
  *   DM_GEMM_GROUPED=3, with `workspace` (dm_gemm_grouped_workspace_bytes): "stream-K" -- every workgroup takes the same number of
  *   consecutive K steps of its product's tile-major step space, a tile is left as 2-3 partial pieces and ONE fix-up launch sums them in
  *   workgroup order (deterministic).  Exact, tested, and slower than the separate launches (no operand panel is shared between

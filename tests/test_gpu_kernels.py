@@ -1027,6 +1027,32 @@ def test_gemm_grouped_stream_k_uneven_groups(shapes, T, monkeypatch):
         assert torch.equal(db, w_db), f"product {k}: bias gradient"
 
 
+@pytest.mark.parametrize("shapes,T,acc,force", [([(768, 768), (2304, 768)], 16384, False, False), ([(768, 768), (2304, 768)], 50432, True, False),
+                                                  ([(768, 3072), (3072, 768), (768, 768), (2304, 768)], 4096, False, True)])
+def test_gemm_grouped_sliced_form(shapes, T, acc, force, monkeypatch):
+    """dm_gemm_grouped's third form: the products of the group share ONE launch with the same K slices -- the proj gradient (12 tiles) next
+    to the qkv gradient (36) of a 16384-token block: 5 slices on 240 workgroups instead of 16 + 7 on two launches -- partial tiles to each
+    product's own slab, summed in slice order by its own reduction.  Exact on integer data; column sums and `accumulate` honoured."""
+    ops = _ops()
+    from deepmerge_amd._lib import DM_TN
+    if force:
+        monkeypatch.setenv("DM_GEMM_GROUPED", "4")
+    g = torch.Generator(device=DEV); g.manual_seed(T + len(shapes) + int(acc))
+    calls, want = [], []
+    for (m, n) in shapes:
+        dy = torch.randint(-1, 2, (T, m), device=DEV, generator=g).to(torch.bfloat16)
+        x = torch.randint(-1, 2, (T, n), device=DEV, generator=g).to(torch.bfloat16)
+        dw0 = torch.randint(-3, 4, (m, n), device=DEV, generator=g).float()
+        db0 = torch.randint(-3, 4, (m,), device=DEV, generator=g).float()
+        dw, db = dw0.clone(), db0.clone()
+        calls.append(((DM_TN, dy, x, dw, m, n, T), dict(lda=m, ldb=n, ldc=n, accumulate=acc, colsum_out=db, colsum_accumulate=acc)))
+        want.append((dy.float().T @ x.float() + (dw0 if acc else 0), dy.float().sum(0) + (db0 if acc else 0), dw, db))
+    ops.gemm_grouped(calls)
+    for k, (w_dw, w_db, dw, db) in enumerate(want):
+        assert torch.equal(dw, w_dw), f"product {k}: weight gradient"
+        assert torch.equal(db, w_db), f"product {k}: bias gradient"
+
+
 def test_gemm_grouped_falls_back_to_separate_calls():
     """Groups the one-launch form does not describe -- a ragged member, a single product, a forward product, mixed `accumulate`, fp32
     operands -- run as the separate calls would; errors of a member surface as dm_gemm's."""
